@@ -1,0 +1,102 @@
+"""ctypes wrapper over oracle/_ref/libref_harness.so — the reference's own prebuilt libjxl 0.12.0
+(jxlcoder/src/main/cpp/lib/x86_64/libjxl.so) driven with the reference's call sequence
+(jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:46-171, JxlEncoding.cpp:54-192).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke().
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref")
+_lib = None
+
+
+class RefInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "xsize", "ysize", "bits_per_sample", "exponent_bits", "num_color_channels", "num_extra_channels",
+        "alpha_bits", "alpha_premultiplied", "orientation", "have_animation", "uses_original_profile", "out_bits")] + \
+        [("intensity_target", C.c_float), ("prefer_encoding", C.c_uint32), ("have_encoded_profile", C.c_uint32),
+         ("color_space", C.c_uint32), ("white_point", C.c_uint32), ("primaries", C.c_uint32),
+         ("transfer_function", C.c_uint32), ("rendering_intent", C.c_uint32), ("gamma", C.c_double),
+         ("icc_size", C.c_uint32), ("version", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RefEncParams(C.Structure):
+    _fields_ = [("xsize", C.c_uint32), ("ysize", C.c_uint32), ("num_channels", C.c_uint32), ("bits", C.c_uint32),
+                ("lossless", C.c_int32), ("distance", C.c_float), ("effort", C.c_int32), ("decoding_speed", C.c_int32),
+                ("gaborish", C.c_int32), ("epf", C.c_int32), ("primaries", C.c_int32), ("transfer", C.c_int32),
+                ("intensity_target", C.c_float), ("modular", C.c_int32), ("threads", C.c_int32),
+                ("extra", (C.c_int32 * 2) * 8)]
+
+
+def available():
+    return os.path.exists(os.path.join(_DIR, "libref_harness.so")) and os.path.exists(os.path.join(_DIR, "libjxl.so"))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(os.path.join(_DIR, "libref_harness.so"), mode=C.RTLD_LOCAL)
+        _lib.ref_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_size_t), C.POINTER(RefInfo), C.c_void_p, C.c_size_t]
+        _lib.ref_encode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(RefEncParams), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_size_t)]
+        _lib.ref_free.argtypes = [C.c_void_p]
+        _lib.ref_version.restype = C.c_int
+    return _lib
+
+
+def version():
+    return lib().ref_version()
+
+
+def decode(data: bytes, threads=0, allow16=True, mode=0):
+    """-> (pixels ndarray [h,w,4] u8/u16/f32, info dict, icc bytes). Raises ValueError on decode failure."""
+    out = C.c_void_p()
+    n = C.c_size_t()
+    ri = RefInfo()
+    icc = C.create_string_buffer(1 << 20)
+    rc = lib().ref_decode(data, len(data), threads, int(allow16), mode, C.byref(out), C.byref(n), C.byref(ri), icc, len(icc))
+    if rc != 0:
+        raise ValueError(f"ref_decode failed rc={rc}")
+    dt = {8: np.uint8, 16: np.uint16, 32: np.float32}[ri.out_bits]
+    arr = np.frombuffer(C.string_at(out.value, n.value), dtype=dt).reshape(ri.ysize, ri.xsize, 4).copy()
+    lib().ref_free(out)
+    return arr, ri.as_dict(), icc.raw[:ri.icc_size]
+
+
+def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=()):
+    """pixels: [h,w,c] u8 or u16, c in 1,3,4. Same sequence as the reference's EncodeJxlOneshot."""
+    pixels = np.ascontiguousarray(pixels)
+    h, w, c = pixels.shape
+    p = RefEncParams()
+    p.xsize, p.ysize, p.num_channels = w, h, c
+    p.bits = 16 if pixels.dtype == np.uint16 else 8
+    p.lossless, p.distance, p.effort, p.decoding_speed = int(lossless), distance, effort, decoding_speed
+    p.gaborish, p.epf, p.primaries, p.transfer = gaborish, epf, primaries, transfer
+    p.intensity_target, p.modular, p.threads = intensity_target, modular, threads
+    for i in range(8):
+        p.extra[i][0] = -1
+    for i, (k, v) in enumerate(extra):
+        p.extra[i][0], p.extra[i][1] = k, v
+    out = C.c_void_p()
+    n = C.c_size_t()
+    rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"ref_encode failed rc={rc}")
+    data = C.string_at(out.value, n.value)
+    lib().ref_free(out)
+    return data
+
+
+def fnv1a64(b: bytes) -> int:
+    h = 0xcbf29ce484222325
+    # vectorised FNV is awkward; fall back to a C-speed-ish loop via int.from_bytes chunks
+    for x in b:
+        h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h

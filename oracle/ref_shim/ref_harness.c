@@ -1,0 +1,243 @@
+/* oracle/_ref harness — TEST INFRASTRUCTURE ONLY (never linked by the product).
+ *
+ * Drives the reference's own prebuilt libjxl (jxlcoder/src/main/cpp/lib/x86_64/libjxl.so,
+ * libjxl 0.12.0, loaded under the bionic shim next to this file) with exactly the call
+ * sequence of the reference's driver:
+ *   decode: jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:46-171  (DecodeJpegXlOneShot)
+ *   encode: jxlcoder/src/main/cpp/interop/JxlEncoding.cpp:54-192  (EncodeJxlOneshot)
+ * Compiled as C against the public headers where they lie (-I <reference>/jxlcoder/src/main/cpp).
+ * The libraries are dlopen()ed RTLD_LOCAL (libjxl_threads exports libc++abi symbols).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "jxl/decode.h"
+#include "jxl/encode.h"
+#include "jxl/resizable_parallel_runner.h"
+#include "jxl/thread_parallel_runner.h"
+
+typedef struct {
+  uint32_t xsize, ysize, bits_per_sample, exponent_bits;
+  uint32_t num_color_channels, num_extra_channels, alpha_bits, alpha_premultiplied;
+  uint32_t orientation, have_animation, uses_original_profile, out_bits; /* 8,16 or 32(float) */
+  float intensity_target;
+  uint32_t prefer_encoding;       /* JxlDecoding.cpp:126-133 quirk reproduced */
+  uint32_t have_encoded_profile;
+  uint32_t color_space, white_point, primaries, transfer_function, rendering_intent;
+  double gamma;
+  uint32_t icc_size;
+  uint32_t version;
+} RefInfo;
+
+static void *h_jxl, *h_thr;
+#define SYM(h, name) __typeof__(&name) p_##name = (__typeof__(&name))dlsym(h, #name); \
+  if (!p_##name) { fprintf(stderr, "ref_harness: missing %s\n", #name); return -100; }
+
+static int load_libs(void) {
+  if (h_jxl && h_thr) return 0;
+  /* All libraries sit next to this harness (oracle/_ref/). Load by absolute path in dependency
+   * order: glibc matches later DT_NEEDED entries ("libc.so", "libbrotlidec.so", ...) against the
+   * sonames of objects that are already loaded, so no LD_LIBRARY_PATH is needed. */
+  Dl_info di;
+  char dir[4096];
+  if (!dladdr((void *)&load_libs, &di) || !di.dli_fname) return -1;
+  snprintf(dir, sizeof(dir), "%s", di.dli_fname);
+  char *slash = strrchr(dir, '/');
+  if (slash) *slash = 0; else strcpy(dir, ".");
+  static const char *order[] = {"libc.so", "libm.so", "libdl.so", "liblog.so", "libbrotlicommon.so",
+                                "libbrotlidec.so", "libbrotlienc.so", "libjxl_cms.so", "libjxl.so",
+                                "libjxl_threads.so"};
+  for (unsigned i = 0; i < sizeof(order) / sizeof(order[0]); i++) {
+    char path[4300];
+    snprintf(path, sizeof(path), "%s/%s", dir, order[i]);
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "ref_harness: %s\n", dlerror()); return -1; }
+    if (!strcmp(order[i], "libjxl.so")) h_jxl = h;
+    if (!strcmp(order[i], "libjxl_threads.so")) h_thr = h;
+  }
+  return 0;
+}
+
+int ref_version(void) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlDecoderVersion);
+  return (int)p_JxlDecoderVersion();
+}
+
+void ref_free(void *p) { free(p); }
+
+/* mode: 0 = what DecodeJpegXlOneShot does (u8, or u16 when bits>8 && allow16);
+ *       1 = float32 RGBA in the data profile (debug aid);
+ * threads: 0 = JxlResizableParallelRunnerSuggestThreads (the reference's choice), else fixed. */
+int ref_decode(const uint8_t *jxl, size_t size, int threads, int allow16, int mode,
+               uint8_t **out, size_t *out_size, RefInfo *ri, uint8_t *icc_out, size_t icc_cap) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlDecoderCreate); SYM(h_jxl, JxlDecoderDestroy); SYM(h_jxl, JxlDecoderSubscribeEvents);
+  SYM(h_jxl, JxlDecoderSetParallelRunner); SYM(h_jxl, JxlDecoderSetInput); SYM(h_jxl, JxlDecoderCloseInput);
+  SYM(h_jxl, JxlDecoderProcessInput); SYM(h_jxl, JxlDecoderGetBasicInfo); SYM(h_jxl, JxlDecoderGetICCProfileSize);
+  SYM(h_jxl, JxlDecoderGetColorAsEncodedProfile); SYM(h_jxl, JxlDecoderGetColorAsICCProfile);
+  SYM(h_jxl, JxlDecoderImageOutBufferSize); SYM(h_jxl, JxlDecoderSetImageOutBuffer); SYM(h_jxl, JxlDecoderVersion);
+  SYM(h_thr, JxlResizableParallelRunner); SYM(h_thr, JxlResizableParallelRunnerCreate);
+  SYM(h_thr, JxlResizableParallelRunnerDestroy); SYM(h_thr, JxlResizableParallelRunnerSetThreads);
+  SYM(h_thr, JxlResizableParallelRunnerSuggestThreads);
+
+  int rc = -2;
+  *out = NULL; *out_size = 0;
+  memset(ri, 0, sizeof(*ri));
+  ri->version = p_JxlDecoderVersion();
+  void *runner = p_JxlResizableParallelRunnerCreate(NULL);
+  JxlDecoder *dec = p_JxlDecoderCreate(NULL);
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSubscribeEvents(dec, JXL_DEC_BASIC_INFO | JXL_DEC_COLOR_ENCODING | JXL_DEC_FULL_IMAGE)) goto done;
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSetParallelRunner(dec, p_JxlResizableParallelRunner, runner)) goto done;
+  JxlBasicInfo info;
+  JxlPixelFormat format = {4, JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+  size_t bps = 1;
+  p_JxlDecoderSetInput(dec, jxl, size);
+  p_JxlDecoderCloseInput(dec);
+  ri->intensity_target = 255;
+  for (;;) {
+    JxlDecoderStatus st = p_JxlDecoderProcessInput(dec);
+    if (st == JXL_DEC_ERROR) { rc = -3; goto done; }
+    else if (st == JXL_DEC_NEED_MORE_INPUT) { rc = -4; goto done; }
+    else if (st == JXL_DEC_BASIC_INFO) {
+      if (JXL_DEC_SUCCESS != p_JxlDecoderGetBasicInfo(dec, &info)) { rc = -5; goto done; }
+      ri->xsize = info.xsize; ri->ysize = info.ysize; ri->bits_per_sample = info.bits_per_sample;
+      ri->exponent_bits = info.exponent_bits_per_sample;
+      ri->num_color_channels = info.num_color_channels; ri->num_extra_channels = info.num_extra_channels;
+      ri->alpha_bits = info.alpha_bits; ri->alpha_premultiplied = info.alpha_premultiplied;
+      ri->orientation = info.orientation; ri->have_animation = info.have_animation;
+      ri->uses_original_profile = info.uses_original_profile;
+      ri->intensity_target = info.intensity_target <= 0.f ? 255.f : info.intensity_target;
+      if (mode == 1) { format.data_type = JXL_TYPE_FLOAT; bps = 4; ri->out_bits = 32; }
+      else if (info.bits_per_sample > 8 && allow16) { format.data_type = JXL_TYPE_UINT16; bps = 2; ri->out_bits = 16; }
+      else { ri->out_bits = 8; }
+      uint32_t nthr = threads > 0 ? (uint32_t)threads
+                                  : p_JxlResizableParallelRunnerSuggestThreads(info.xsize, info.ysize);
+      p_JxlResizableParallelRunnerSetThreads(runner, nthr);
+    } else if (st == JXL_DEC_COLOR_ENCODING) {
+      size_t icc_size = 0;
+      if (JXL_DEC_SUCCESS != p_JxlDecoderGetICCProfileSize(dec, JXL_COLOR_PROFILE_TARGET_DATA, &icc_size)) { rc = -6; goto done; }
+      ri->icc_size = (uint32_t)icc_size;
+      JxlColorEncoding clr;
+      if (JXL_DEC_SUCCESS == p_JxlDecoderGetColorAsEncodedProfile(dec, JXL_COLOR_PROFILE_TARGET_DATA, &clr)) {
+        ri->have_encoded_profile = 1;
+        ri->color_space = clr.color_space; ri->white_point = clr.white_point; ri->primaries = clr.primaries;
+        ri->transfer_function = clr.transfer_function; ri->rendering_intent = clr.rendering_intent; ri->gamma = clr.gamma;
+        if ((clr.color_space == JXL_COLOR_SPACE_RGB && clr.transfer_function == JXL_TRANSFER_FUNCTION_HLG) ||
+            clr.transfer_function == JXL_TRANSFER_FUNCTION_PQ || clr.transfer_function == JXL_TRANSFER_FUNCTION_DCI ||
+            clr.transfer_function == JXL_TRANSFER_FUNCTION_709 || clr.transfer_function == JXL_TRANSFER_FUNCTION_SRGB ||
+            clr.transfer_function == JXL_TRANSFER_FUNCTION_GAMMA)
+          ri->prefer_encoding = 1;
+      }
+      if (icc_out && icc_size && icc_size <= icc_cap)
+        if (JXL_DEC_SUCCESS != p_JxlDecoderGetColorAsICCProfile(dec, JXL_COLOR_PROFILE_TARGET_DATA, icc_out, icc_size)) { rc = -7; goto done; }
+    } else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) {
+      size_t need = 0;
+      if (JXL_DEC_SUCCESS != p_JxlDecoderImageOutBufferSize(dec, &format, &need)) { rc = -8; goto done; }
+      size_t stride = (size_t)ri->xsize * 4 * bps;
+      if (need != stride * ri->ysize) { rc = -9; goto done; }
+      if (!*out) { *out = (uint8_t *)malloc(need); *out_size = need; }
+      if (JXL_DEC_SUCCESS != p_JxlDecoderSetImageOutBuffer(dec, &format, *out, need)) { rc = -10; goto done; }
+    } else if (st == JXL_DEC_FULL_IMAGE) {
+      /* last frame wins (JxlDecoding.cpp:164-166) */
+    } else if (st == JXL_DEC_SUCCESS) { rc = 0; goto done; }
+    else { rc = -11; goto done; }
+  }
+done:
+  p_JxlDecoderDestroy(dec);
+  p_JxlResizableParallelRunnerDestroy(runner);
+  if (rc != 0 && *out) { free(*out); *out = NULL; *out_size = 0; }
+  return rc;
+}
+
+typedef struct {
+  uint32_t xsize, ysize, num_channels /*1,3,4*/, bits /*8,16*/;
+  int32_t lossless;
+  float distance;
+  int32_t effort, decoding_speed;
+  int32_t gaborish, epf;           /* -1 = encoder default */
+  int32_t primaries, transfer;     /* 0 = sRGB defaults; else JxlPrimaries / JxlTransferFunction ints */
+  float intensity_target;          /* 0 = default */
+  int32_t modular;                 /* -1 default, 0 VarDCT, 1 modular */
+  int32_t threads;                 /* 0 = default */
+  int32_t extra[8][2];             /* further (JxlEncoderFrameSettingId, value) pairs; id<0 = unused */
+} RefEncParams;
+
+int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, uint8_t **out, size_t *out_size) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlEncoderCreate); SYM(h_jxl, JxlEncoderDestroy); SYM(h_jxl, JxlEncoderSetParallelRunner);
+  SYM(h_jxl, JxlEncoderInitBasicInfo); SYM(h_jxl, JxlEncoderSetBasicInfo); SYM(h_jxl, JxlEncoderInitExtraChannelInfo);
+  SYM(h_jxl, JxlEncoderSetExtraChannelInfo); SYM(h_jxl, JxlEncoderSetColorEncoding);
+  SYM(h_jxl, JxlEncoderFrameSettingsCreate); SYM(h_jxl, JxlEncoderSetFrameDistance);
+  SYM(h_jxl, JxlEncoderFrameSettingsSetOption); SYM(h_jxl, JxlEncoderSetFrameLossless);
+  SYM(h_jxl, JxlEncoderAddImageFrame); SYM(h_jxl, JxlEncoderCloseInput); SYM(h_jxl, JxlEncoderProcessOutput);
+  SYM(h_jxl, JxlColorEncodingSetToSRGB);
+  SYM(h_thr, JxlThreadParallelRunner); SYM(h_thr, JxlThreadParallelRunnerCreate);
+  SYM(h_thr, JxlThreadParallelRunnerDestroy); SYM(h_thr, JxlThreadParallelRunnerDefaultNumWorkerThreads);
+
+  int rc = -2;
+  *out = NULL; *out_size = 0;
+  JxlEncoder *enc = p_JxlEncoderCreate(NULL);
+  size_t nthr = p->threads > 0 ? (size_t)p->threads : p_JxlThreadParallelRunnerDefaultNumWorkerThreads();
+  void *runner = p_JxlThreadParallelRunnerCreate(NULL, nthr);
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetParallelRunner(enc, p_JxlThreadParallelRunner, runner)) goto done;
+  JxlPixelFormat pf = {p->num_channels, p->bits == 16 ? JXL_TYPE_UINT16 : JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+  JxlBasicInfo bi;
+  p_JxlEncoderInitBasicInfo(&bi);
+  bi.xsize = p->xsize; bi.ysize = p->ysize; bi.bits_per_sample = p->bits;
+  bi.uses_original_profile = p->lossless ? JXL_TRUE : JXL_FALSE;
+  bi.num_color_channels = p->num_channels == 1 ? 1 : 3;
+  bi.alpha_premultiplied = JXL_FALSE;
+  if (p->intensity_target > 0) bi.intensity_target = p->intensity_target;
+  if (p->num_channels == 4) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
+  if (p->num_channels == 4) {
+    JxlExtraChannelInfo ci;
+    p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
+    ci.bits_per_sample = p->bits; ci.alpha_premultiplied = JXL_FALSE;
+    if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
+  }
+  JxlColorEncoding ce;
+  p_JxlColorEncodingSetToSRGB(&ce, p->num_channels == 1);
+  if (p->primaries) ce.primaries = (JxlPrimaries)p->primaries;
+  if (p->transfer) ce.transfer_function = (JxlTransferFunction)p->transfer;
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetColorEncoding(enc, &ce)) { rc = -5; goto done; }
+  JxlEncoderFrameSettings *fs = p_JxlEncoderFrameSettingsCreate(enc, NULL);
+  if (!p->lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameDistance(fs, p->distance)) { rc = -6; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_EFFORT, p->effort)) { rc = -7; goto done; }
+  if (p->lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameLossless(fs, JXL_TRUE)) { rc = -8; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_DECODING_SPEED, p->decoding_speed)) { rc = -9; goto done; }
+  if (p->gaborish >= 0) p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_GABORISH, p->gaborish);
+  if (p->epf >= 0) p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_EPF, p->epf);
+  if (p->modular >= 0) p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_MODULAR, p->modular);
+  for (int i = 0; i < 8; i++)
+    if (p->extra[i][0] >= 0)
+      if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, (JxlEncoderFrameSettingId)p->extra[i][0], p->extra[i][1])) { rc = -20 - i; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderAddImageFrame(fs, &pf, pixels, pixels_size)) { rc = -10; goto done; }
+  p_JxlEncoderCloseInput(enc);
+  size_t cap = 1 << 16;
+  uint8_t *buf = (uint8_t *)malloc(cap);
+  uint8_t *next = buf;
+  size_t avail = cap;
+  JxlEncoderStatus st = JXL_ENC_NEED_MORE_OUTPUT;
+  while (st == JXL_ENC_NEED_MORE_OUTPUT) {
+    st = p_JxlEncoderProcessOutput(enc, &next, &avail);
+    if (st == JXL_ENC_NEED_MORE_OUTPUT) {
+      size_t off = (size_t)(next - buf);
+      cap *= 2;
+      buf = (uint8_t *)realloc(buf, cap);
+      next = buf + off; avail = cap - off;
+    }
+  }
+  if (st != JXL_ENC_SUCCESS) { free(buf); rc = -11; goto done; }
+  *out = buf; *out_size = (size_t)(next - buf);
+  rc = 0;
+done:
+  p_JxlEncoderDestroy(enc);
+  p_JxlThreadParallelRunnerDestroy(runner);
+  return rc;
+}
