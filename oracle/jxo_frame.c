@@ -1,0 +1,1285 @@
+/* oracle/jxo_frame.c — container, image/frame headers, TOC, LfGlobal/LfGroup/HfGlobal/PassGroup, VarDCT
+ * reconstruction (dequant, CfL, inverse var-size DCT), Gaborish/EPF, XYB->RGB, RGBA writer.
+ * CPU restatement of what the reference executes inside libjxl (call site
+ * jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75). Checker only — see jxo.h. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jxo_int.h"
+#include "jxo_tables.h"
+#include "jxo_dither.h"
+
+int jxo_debug = 0;
+#define PI 3.14159265358979323846
+
+/* ================================================================= headers */
+typedef struct { int type, bits, exp_bits, float_sample, dim_shift, alpha_assoc; } extra_ch;
+typedef struct {
+  jxo_info pub;
+  int num_extra; extra_ch ec[16];
+  int modular_16;
+  int have_preview, have_animation, have_timecodes;
+  int orientation;
+  float opsin_inv[9], opsin_bias[3], quant_bias[4];
+  int custom_upsampling;
+  float wp_xy[2], prim_xy[6];
+} img_meta;
+
+typedef struct {
+  int frame_type, encoding; uint64_t flags;
+  int do_ycbcr, upsampling, group_size_shift, x_qm, b_qm;
+  int num_passes, pass_shift[12], num_ds, ds[4], ds_last[4];
+  int have_crop, x0, y0, width, height;
+  int blend_mode, blend_source, duration, is_last, save_as_ref, save_before_ct;
+  int gab; float gab_w[3][2];
+  int epf_iters; float epf_sharp[8], epf_chscale[3], epf_quant_mul, epf_pass0, epf_pass2, epf_border_sad, epf_sigma_modular;
+  /* derived */
+  int group_dim, xgroups, ygroups, num_groups, xlfg, ylfg, num_lf_groups;
+} frame_hdr;
+
+static int read_size_header(jxo_br *br, uint32_t *xs, uint32_t *ys) {
+  int small = jxo_bool(br);
+  uint32_t y = small ? (jxo_bits(br, 5) + 1) * 8 : 1 + jxo_u32(br, 9, 0, 13, 0, 18, 0, 30, 0);
+  uint32_t ratio = jxo_bits(br, 3), x;
+  if (ratio == 0) x = small ? (jxo_bits(br, 5) + 1) * 8 : 1 + jxo_u32(br, 9, 0, 13, 0, 18, 0, 30, 0);
+  else {
+    static const int num[8] = {0, 1, 12, 4, 3, 16, 5, 2}, den[8] = {1, 1, 10, 3, 2, 9, 4, 1};
+    x = (uint32_t)(((uint64_t)y * (uint64_t)num[ratio]) / (uint64_t)den[ratio]);
+  }
+  *xs = x; *ys = y;
+  return 0;
+}
+
+static void read_bit_depth(jxo_br *br, int *bits, int *exp_bits, int *is_float) {
+  *is_float = jxo_bool(br);
+  if (!*is_float) { *bits = (int)jxo_u32(br, -1, 8, -1, 10, -1, 12, 6, 1); *exp_bits = 0; }
+  else { *bits = (int)jxo_u32(br, -1, 32, -1, 16, -1, 24, 6, 1); *exp_bits = 1 + (int)jxo_bits(br, 4); }
+}
+
+static float read_customxy(jxo_br *br) {
+  uint32_t u = jxo_u32(br, 19, 0, 19, 524288, 20, 1048576, 21, 2097152);
+  return (float)jxo_unpack_signed(u) * 1e-6f;
+}
+
+static int read_extensions(jxo_br *br) {
+  uint64_t ext = jxo_u64(br);
+  uint64_t total = 0;
+  for (int i = 0; i < 64; i++) if (ext & (1ull << i)) total += jxo_u64(br);
+  if (total > (1ull << 32)) return -1;
+  br->pos += (size_t)total;
+  return 0;
+}
+
+static int read_image_header(jxo_br *br, img_meta *m) {
+  memset(m, 0, sizeof(*m));
+  if (jxo_bits(br, 16) != 0x0AFF) JXO_FAIL("not a JPEG XL codestream");
+  uint32_t xs, ys;
+  read_size_header(br, &xs, &ys);
+  jxo_info *p = &m->pub;
+  p->bits_per_sample = 8; p->num_color_channels = 3; p->xyb_encoded = 1; p->intensity_target = 255.f;
+  p->color_space = 0; p->white_point = 1; p->primaries = 1; p->transfer_function = 13; p->rendering_intent = 1;
+  m->orientation = 1; m->modular_16 = 1;
+  memcpy(m->opsin_inv, kOpsinInv, sizeof(kOpsinInv));
+  for (int i = 0; i < 3; i++) m->opsin_bias[i] = kOpsinBias;
+  memcpy(m->quant_bias, kQuantBias, sizeof(kQuantBias));
+  int all_default = jxo_bool(br);
+  int extra_fields = 0;
+  if (!all_default) {
+    extra_fields = jxo_bool(br);
+    if (extra_fields) {
+      m->orientation = 1 + (int)jxo_bits(br, 3);
+      if (jxo_bool(br)) { uint32_t a, b; read_size_header(br, &a, &b); }           /* intrinsic size */
+      m->have_preview = jxo_bool(br);
+      if (m->have_preview) {
+        int div8 = jxo_bool(br);
+        if (div8) (void)jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33); else (void)jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345);
+        uint32_t ratio = jxo_bits(br, 3);
+        if (ratio == 0) { if (div8) (void)jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33); else (void)jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345); }
+      }
+      m->have_animation = jxo_bool(br);
+      if (m->have_animation) {
+        (void)jxo_u32(br, -1, 100, -1, 1000, 10, 1, 30, 1);
+        (void)jxo_u32(br, -1, 1, -1, 1001, 8, 1, 10, 1);
+        (void)jxo_u32(br, -1, 0, 3, 0, 16, 0, 32, 0);
+        m->have_timecodes = jxo_bool(br);
+      }
+    }
+    int bits, eb, fl;
+    read_bit_depth(br, &bits, &eb, &fl);
+    p->bits_per_sample = (uint32_t)bits; p->exp_bits = (uint32_t)eb;
+    m->modular_16 = jxo_bool(br);
+    m->num_extra = (int)jxo_u32(br, -1, 0, -1, 1, 4, 2, 12, 1);
+    if (m->num_extra > 16) JXO_FAIL("unsupported: more than 16 extra channels");
+    for (int i = 0; i < m->num_extra; i++) {
+      extra_ch *e = &m->ec[i];
+      e->type = 0; e->bits = 8; e->exp_bits = 0; e->dim_shift = 0; e->alpha_assoc = 0; e->float_sample = 0;
+      if (!jxo_bool(br)) {
+        e->type = (int)jxo_enum(br);
+        read_bit_depth(br, &e->bits, &e->exp_bits, &e->float_sample);
+        e->dim_shift = (int)jxo_u32(br, -1, 0, -1, 3, -1, 4, 3, 1);
+        uint32_t nl = jxo_u32(br, -1, 0, 4, 0, 5, 16, 10, 48);
+        for (uint32_t k = 0; k < nl; k++) (void)jxo_bits(br, 8);
+        if (e->type == 0) e->alpha_assoc = jxo_bool(br);
+        if (e->type == 2) for (int k = 0; k < 4; k++) (void)jxo_f16(br);
+        if (e->type == 5) (void)jxo_u32(br, -1, 1, 2, 0, 4, 3, 8, 19);
+      }
+    }
+    p->xyb_encoded = (uint32_t)jxo_bool(br);
+    /* ColourEncoding */
+    if (!jxo_bool(br)) {
+      p->want_icc = (uint32_t)jxo_bool(br);
+      p->color_space = jxo_enum(br);
+      if (!p->want_icc) {
+        if (p->color_space != 2) {
+          p->white_point = jxo_enum(br);
+          if (p->white_point == 2) { m->wp_xy[0] = read_customxy(br); m->wp_xy[1] = read_customxy(br); }
+        }
+        if (p->color_space != 2 && p->color_space != 1) {
+          p->primaries = jxo_enum(br);
+          if (p->primaries == 2) for (int k = 0; k < 6; k++) m->prim_xy[k] = read_customxy(br);
+        }
+        if (p->color_space != 2) {
+          p->have_gamma = (uint32_t)jxo_bool(br);
+          if (p->have_gamma) p->gamma = (float)jxo_bits(br, 24) * 1e-7f; else p->transfer_function = jxo_enum(br);
+        }
+        p->rendering_intent = jxo_enum(br);
+      }
+      if (p->color_space == 1) p->num_color_channels = 1;
+    }
+    if (extra_fields && !jxo_bool(br)) {                 /* ToneMapping */
+      p->intensity_target = jxo_f16(br);
+      (void)jxo_f16(br); (void)jxo_bool(br); (void)jxo_f16(br);
+    }
+    if (read_extensions(br)) JXO_FAIL("bad extensions");
+  }
+  int default_m = jxo_bool(br);
+  if (!default_m && p->xyb_encoded) {
+    if (!jxo_bool(br)) {
+      for (int i = 0; i < 9; i++) m->opsin_inv[i] = jxo_f16(br);
+      for (int i = 0; i < 3; i++) m->opsin_bias[i] = jxo_f16(br);
+      for (int i = 0; i < 4; i++) m->quant_bias[i] = jxo_f16(br);
+    }
+  }
+  if (!default_m) {
+    uint32_t cw = jxo_bits(br, 3);
+    if (cw) { m->custom_upsampling = 1; int n = (cw & 1 ? 15 : 0) + (cw & 2 ? 55 : 0) + (cw & 4 ? 210 : 0); for (int i = 0; i < n; i++) (void)jxo_f16(br); }
+  }
+  for (int i = 0; i < m->num_extra; i++)
+    if (m->ec[i].type == 0 && p->alpha_bits == 0) { p->alpha_bits = (uint32_t)m->ec[i].bits; p->alpha_premultiplied = (uint32_t)m->ec[i].alpha_assoc; }
+  p->num_extra_channels = (uint32_t)m->num_extra;
+  p->have_animation = (uint32_t)m->have_animation;
+  p->orientation = 1;
+  if (m->orientation > 4) { p->xsize = ys; p->ysize = xs; } else { p->xsize = xs; p->ysize = ys; }
+  if (br->err) JXO_FAIL("truncated image header");
+  /* raw (unoriented) size kept in wp_xy-adjacent fields: reuse */
+  m->pub.gamma = m->pub.gamma;
+  return (int)0;
+}
+
+static int read_frame_header(jxo_br *br, const img_meta *m, uint32_t img_w, uint32_t img_h, frame_hdr *f) {
+  memset(f, 0, sizeof(*f));
+  f->upsampling = 1; f->group_size_shift = 1; f->x_qm = 3; f->b_qm = 2; f->num_passes = 1; f->is_last = 1;
+  f->gab = 1; f->epf_iters = 2;
+  for (int c = 0; c < 3; c++) { f->gab_w[c][0] = 0.115169525f; f->gab_w[c][1] = 0.061248592f; }
+  for (int i = 0; i < 8; i++) f->epf_sharp[i] = (float)i / 7.0f;
+  f->epf_chscale[0] = 40.0f; f->epf_chscale[1] = 5.0f; f->epf_chscale[2] = 3.5f;
+  f->epf_quant_mul = 0.46f; f->epf_pass0 = 0.9f; f->epf_pass2 = 6.5f; f->epf_border_sad = 2.0f / 3.0f; f->epf_sigma_modular = 1.0f;
+  f->width = (int)img_w; f->height = (int)img_h;
+  int all_default = jxo_bool(br);
+  if (!all_default) {
+    f->frame_type = (int)jxo_bits(br, 2);
+    f->encoding = (int)jxo_bits(br, 1);
+    f->flags = jxo_u64(br);
+    if (!m->pub.xyb_encoded) f->do_ycbcr = jxo_bool(br);
+    int use_lf_frame = (f->flags & 32) != 0;
+    if (f->do_ycbcr && !use_lf_frame) { for (int i = 0; i < 3; i++) if (jxo_bits(br, 2)) JXO_FAIL("unsupported: chroma subsampling"); }
+    if (!use_lf_frame) {
+      f->upsampling = (int)jxo_u32(br, -1, 1, -1, 2, -1, 4, -1, 8);
+      for (int i = 0; i < m->num_extra; i++) if (jxo_u32(br, -1, 1, -1, 2, -1, 4, -1, 8) != 1) JXO_FAIL("unsupported: extra channel upsampling");
+    }
+    if (f->encoding == 1) f->group_size_shift = (int)jxo_bits(br, 2);
+    if (f->encoding == 0 && m->pub.xyb_encoded) { f->x_qm = (int)jxo_bits(br, 3); f->b_qm = (int)jxo_bits(br, 3); }
+    if (f->frame_type != 2) {
+      f->num_passes = (int)jxo_u32(br, -1, 1, -1, 2, -1, 3, 3, 4);
+      if (f->num_passes != 1) {
+        f->num_ds = (int)jxo_u32(br, -1, 0, -1, 1, -1, 2, 1, 3);
+        for (int i = 0; i < f->num_passes - 1; i++) f->pass_shift[i] = (int)jxo_bits(br, 2);
+        for (int i = 0; i < f->num_ds; i++) f->ds[i] = (int)jxo_u32(br, -1, 1, -1, 2, -1, 4, -1, 8);
+        for (int i = 0; i < f->num_ds; i++) f->ds_last[i] = (int)jxo_u32(br, -1, 0, -1, 1, -1, 2, 3, 0);
+      }
+    }
+    if (f->frame_type == 1) (void)jxo_u32(br, -1, 1, -1, 2, -1, 3, -1, 4);
+    if (f->frame_type != 1) {
+      f->have_crop = jxo_bool(br);
+      if (f->have_crop) {
+        if (f->frame_type != 2) {
+          f->x0 = jxo_unpack_signed(jxo_u32(br, 8, 0, 11, 256, 14, 2304, 30, 18688));
+          f->y0 = jxo_unpack_signed(jxo_u32(br, 8, 0, 11, 256, 14, 2304, 30, 18688));
+        }
+        f->width = (int)jxo_u32(br, 8, 0, 11, 256, 14, 2304, 30, 18688);
+        f->height = (int)jxo_u32(br, 8, 0, 11, 256, 14, 2304, 30, 18688);
+      }
+    }
+    int normal = f->frame_type == 0 || f->frame_type == 3;
+    if (normal) {
+      int full = !f->have_crop || (f->x0 == 0 && f->y0 == 0 && f->width == (int)img_w && f->height == (int)img_h);
+      for (int i = 0; i <= m->num_extra; i++) {
+        int mode = (int)jxo_u32(br, -1, 0, -1, 1, -1, 2, 2, 3);
+        if (m->num_extra > 0 && (mode == 2 || mode == 3)) (void)jxo_u32(br, -1, 0, -1, 1, -1, 2, 3, 3);
+        if (m->num_extra > 0 && (mode == 2 || mode == 3 || mode == 4)) (void)jxo_bool(br);
+        int src = 0;
+        if (mode != 0 || !full) src = (int)jxo_bits(br, 2);
+        if (i == 0) { f->blend_mode = mode; f->blend_source = src; }
+      }
+      if (m->have_animation) {
+        f->duration = (int)jxo_u32(br, -1, 0, -1, 1, 8, 0, 32, 0);
+        if (m->have_timecodes) (void)jxo_bits(br, 32);
+      }
+      f->is_last = jxo_bool(br);
+    } else f->is_last = 0;
+    if (f->frame_type != 1 && !f->is_last) f->save_as_ref = (int)jxo_bits(br, 2);
+    {
+      int full = !f->have_crop || (f->x0 == 0 && f->y0 == 0 && f->width == (int)img_w && f->height == (int)img_h);
+      int resets = full && f->blend_mode == 0 && normal;
+      int can_ref = !f->is_last && (f->duration == 0 || f->save_as_ref != 0) && f->frame_type != 1;
+      if (f->frame_type == 2 || (resets && can_ref)) f->save_before_ct = jxo_bool(br);
+    }
+    uint32_t nl = jxo_u32(br, -1, 0, 4, 0, 5, 16, 10, 48);
+    for (uint32_t k = 0; k < nl; k++) (void)jxo_bits(br, 8);
+    /* RestorationFilter */
+    if (!jxo_bool(br)) {
+      f->gab = jxo_bool(br);
+      if (f->gab && jxo_bool(br)) for (int c = 0; c < 3; c++) { f->gab_w[c][0] = jxo_f16(br); f->gab_w[c][1] = jxo_f16(br); }
+      f->epf_iters = (int)jxo_bits(br, 2);
+      if (f->epf_iters) {
+        if (f->encoding == 0 && jxo_bool(br)) for (int i = 0; i < 8; i++) f->epf_sharp[i] = jxo_f16(br);
+        if (jxo_bool(br)) { for (int c = 0; c < 3; c++) f->epf_chscale[c] = jxo_f16(br); (void)jxo_bits(br, 32); }
+        if (jxo_bool(br)) {
+          if (f->encoding == 0) f->epf_quant_mul = jxo_f16(br);
+          f->epf_pass0 = jxo_f16(br); f->epf_pass2 = jxo_f16(br); f->epf_border_sad = jxo_f16(br);
+        }
+        if (f->encoding == 1) f->epf_sigma_modular = jxo_f16(br);
+      }
+      if (read_extensions(br)) JXO_FAIL("bad loop-filter extensions");
+    }
+    if (read_extensions(br)) JXO_FAIL("bad frame extensions");
+  }
+  if (br->err) JXO_FAIL("truncated frame header");
+  f->group_dim = 128 << f->group_size_shift;
+  f->xgroups = (f->width + f->group_dim - 1) / f->group_dim;
+  f->ygroups = (f->height + f->group_dim - 1) / f->group_dim;
+  f->num_groups = f->xgroups * f->ygroups;
+  f->xlfg = (f->width + f->group_dim * 8 - 1) / (f->group_dim * 8);
+  f->ylfg = (f->height + f->group_dim * 8 - 1) / (f->group_dim * 8);
+  f->num_lf_groups = f->xlfg * f->ylfg;
+  return 0;
+}
+
+/* ================================================================= DCT helpers */
+static double *cos_tab[9];   /* log2 n = 0..8: tab[k*n+i] = c_k cos((2i+1)k pi / 2n) */
+static const double *get_cos(int n) {
+  int l = 0; while ((1 << l) < n) l++;
+  if (!cos_tab[l]) {
+    double *t = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+    for (int k = 0; k < n; k++) for (int i = 0; i < n; i++) t[k * n + i] = (k ? sqrt(2.0) : 1.0) * cos((2 * i + 1) * k * PI / (2.0 * n));
+    cos_tab[l] = t;
+  }
+  return cos_tab[l];
+}
+/* inverse: S in storage layout (min(R,C) rows x max(R,C) cols; tall/square blocks are stored transposed) */
+static void idct2d(const float *S, int R, int C, float *out, int ostride) {
+  const double *cr = get_cos(R), *cc = get_cos(C);
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)R * (size_t)C);
+  for (int v = 0; v < R; v++)
+    for (int x = 0; x < C; x++) {
+      double s = 0;
+      for (int u = 0; u < C; u++) { double m = R < C ? S[v * C + u] : S[u * R + v]; s += m * cc[u * C + x]; }
+      tmp[v * C + x] = s;
+    }
+  for (int y = 0; y < R; y++)
+    for (int x = 0; x < C; x++) {
+      double s = 0;
+      for (int v = 0; v < R; v++) s += tmp[v * C + x] * cr[v * R + y];
+      out[y * ostride + x] = (float)s;
+    }
+  free(tmp);
+}
+/* forward scaled DCT (DC = mean) of an R x C block into storage layout */
+static void dct2d(const float *in, int istride, int R, int C, float *S) {
+  const double *cr = get_cos(R), *cc = get_cos(C);
+  double *tmp = (double *)malloc(sizeof(double) * (size_t)R * (size_t)C);
+  for (int y = 0; y < R; y++)
+    for (int u = 0; u < C; u++) {
+      double s = 0;
+      for (int x = 0; x < C; x++) s += in[y * istride + x] * cc[u * C + x];
+      tmp[y * C + u] = s / C;
+    }
+  for (int v = 0; v < R; v++)
+    for (int u = 0; u < C; u++) {
+      double s = 0;
+      for (int y = 0; y < R; y++) s += tmp[y * C + u] * cr[v * R + y];
+      s /= R;
+      if (R < C) S[v * C + u] = (float)s; else S[u * R + v] = (float)s;
+    }
+  free(tmp);
+}
+
+/* ================================================================= quant tables */
+static float *qt_weights[17][3];   /* inverse of weights is the dequant multiplier */
+static double band_mult(double v) { return v > 0 ? 1 + v : 1 / (1 - v); }
+static double interp_bands(double pos, double max, const double *bands, int len) {
+  if (len == 1) return bands[0];
+  double sp = pos * (len - 1) / max;
+  int idx = (int)sp;
+  double a = bands[idx], b = bands[idx + 1];
+  return a * pow(b / a, sp - idx);
+}
+static void quant_weights_dct(const jxo_dctparams *p, int rows, int cols, float *out[3]) {
+  for (int c = 0; c < 3; c++) {
+    double bands[17];
+    bands[0] = p->b[c][0];
+    for (int i = 1; i < p->nbands; i++) bands[i] = bands[i - 1] * band_mult(p->b[c][i]);
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        double dx = (double)x / (cols - 1), dy = (double)y / (rows - 1);
+        double dist = sqrt(dx * dx + dy * dy);
+        out[c][y * cols + x] = (float)interp_bands(dist, sqrt(2.0) + 1e-6, bands, p->nbands);
+      }
+  }
+}
+static void init_quant_tables(void) {
+  if (qt_weights[0][0]) return;
+  static const jxo_dctparams *dctp[17] = {&kDct8, 0, 0, 0, &kDct16, &kDct32, &kDct8x16, &kDct8x32, &kDct16x32, 0, 0,
+                                         &kDct64, &kDct32x64, &kDct128, &kDct64x128, &kDct256, &kDct128x256};
+  for (int t = 0; t < 17; t++) {
+    int rows = kQTRows[t] * 8, cols = kQTCols[t] * 8;
+    float *w[3];
+    for (int c = 0; c < 3; c++) w[c] = qt_weights[t][c] = (float *)calloc((size_t)rows * (size_t)cols, 4);
+    if (dctp[t]) { quant_weights_dct(dctp[t], rows, cols, w); continue; }
+    if (t == 1) {
+      for (int c = 0; c < 3; c++) { for (int i = 0; i < 64; i++) w[c][i] = kIdWeights[c][0]; w[c][1] = w[c][8] = kIdWeights[c][1]; w[c][9] = kIdWeights[c][2]; }
+    } else if (t == 2) {
+      for (int c = 0; c < 3; c++) {
+        const float *d = kDct2Weights[c];
+        w[c][0] = 1.0f; w[c][1] = w[c][8] = d[0]; w[c][9] = d[1];
+        for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { w[c][y * 8 + x + 2] = d[2]; w[c][(y + 2) * 8 + x] = d[2]; w[c][(y + 2) * 8 + x + 2] = d[3]; }
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { w[c][y * 8 + x + 4] = d[4]; w[c][(y + 4) * 8 + x] = d[4]; w[c][(y + 4) * 8 + x + 4] = d[5]; }
+      }
+    } else if (t == 3) {
+      float b4[3][16]; float *p4[3] = {b4[0], b4[1], b4[2]};
+      quant_weights_dct(&kDct4, 4, 4, p4);
+      for (int c = 0; c < 3; c++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b4[c][(y / 2) * 4 + x / 2];
+      /* dct4multipliers are all 1.0 in the default library */
+    } else if (t == 9) {
+      float b48[3][32]; float *p48[3] = {b48[0], b48[1], b48[2]};
+      quant_weights_dct(&kDct4x8, 4, 8, p48);
+      for (int c = 0; c < 3; c++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b48[c][(y / 2) * 8 + x];
+    } else if (t == 10) {
+      float b48[3][32]; float *p48[3] = {b48[0], b48[1], b48[2]};
+      float b4[3][16]; float *p4[3] = {b4[0], b4[1], b4[2]};
+      quant_weights_dct(&kDct4x8, 4, 8, p48);
+      quant_weights_dct(&kDct4, 4, 4, p4);
+      const double lo = 0.8517778890324296, hi = 12.97166202570235 - lo + 1e-6;
+      for (int c = 0; c < 3; c++) {
+        double bands[4];
+        bands[0] = kAfvWeights[c][5];
+        for (int i = 1; i < 4; i++) bands[i] = bands[i - 1] * band_mult(kAfvWeights[c][i + 5]);
+        w[c][0] = 1.0f;
+        #define SETW(x, y, v) w[c][(y) * 8 + (x)] = (float)(v)
+        SETW(0, 1, kAfvWeights[c][0]); SETW(1, 0, kAfvWeights[c][1]);
+        SETW(0, 2, kAfvWeights[c][2]); SETW(2, 0, kAfvWeights[c][3]); SETW(2, 2, kAfvWeights[c][4]);
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+          if (x < 2 && y < 2) continue;
+          SETW(2 * x, 2 * y, interp_bands(kAfvFreqs[y * 4 + x] - lo, hi, bands, 4));
+        }
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y + 1) * 8 + x] = b48[c][y * 8 + x]; }
+        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y) * 8 + 2 * x + 1] = b4[c][y * 4 + x]; }
+        #undef SETW
+      }
+    }
+  }
+}
+
+/* ================================================================= coefficient orders */
+static void natural_order(int strategy, uint32_t *out) {
+  int cx = kCoveredX[strategy], cy = kCoveredY[strategy];
+  if (cy > cx) { int t = cx; cx = cy; cy = t; }
+  int xs = cx / cy, xsm = xs - 1, xss = 0;
+  while ((1 << xss) < xs) xss++;
+  int cur = cx * cy;
+  int n = cx * 8;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      int x = j, y = i - j;
+      if (i % 2) { int t = x; x = y; y = t; }
+      if ((y & xsm) != 0) continue;
+      y >>= xss;
+      int val = (x < cx && y < cy) ? y * cx + x : cur++;
+      out[val] = (uint32_t)(y * cx * 8 + x);
+    }
+  for (int ip = n - 1; ip > 0; ip--) {
+    int i = ip - 1;
+    for (int j = 0; j <= i; j++) {
+      int x = n - 1 - (i - j), y = n - 1 - j;
+      if (i % 2) { int t = x; x = y; y = t; }
+      if ((y & xsm) != 0) continue;
+      y >>= xss;
+      out[cur++] = (uint32_t)(y * cx * 8 + x);
+    }
+  }
+}
+
+/* ================================================================= frame decode state */
+typedef struct {
+  const img_meta *m; frame_hdr f;
+  int xb, yb;                       /* 8x8 cells */
+  /* LfGlobal */
+  float lf_dequant[3];
+  uint32_t global_scale, quant_lf;
+  int nb_lf_thr[3]; int32_t lf_thr[3][16]; int nb_qf_thr; uint32_t qf_thr[16];
+  uint8_t *bctx_map; int bctx_size; int num_bctx;
+  uint32_t color_factor; float base_x, base_b; int ytox_dc, ytob_dc;
+  jxo_tree gtree;
+  jxo_modimg gmod; int gmod_first_undecoded;
+  /* per-cell */
+  uint8_t *strategy;   /* raw strategy of the varblock covering the cell */
+  uint8_t *first;      /* 1 if the cell is the top-left of its varblock */
+  int32_t *qf; uint8_t *sharp; uint8_t *lf_idx;
+  int8_t *xfromy, *bfromy; int tiles_x, tiles_y;
+  float *lf[3];
+  uint32_t *coef_off; int32_t *coef[3];
+  /* HfGlobal */
+  int num_presets;
+  uint32_t *orders[12][13][3];      /* [pass][order][c] */
+  jxo_ec hf_code[12];
+  /* pixels */
+  float *plane[3]; int pw, ph;
+} fstate;
+
+static int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
+
+static int read_lf_global(fstate *s, jxo_br *br) {
+  const frame_hdr *f = &s->f;
+  if (f->flags & (1 | 2 | 16)) JXO_FAIL("unsupported: patches/splines/noise");
+  s->lf_dequant[0] = 1.0f / 4096; s->lf_dequant[1] = 1.0f / 512; s->lf_dequant[2] = 1.0f / 256;
+  if (!jxo_bool(br)) for (int c = 0; c < 3; c++) s->lf_dequant[c] = jxo_f16(br) * (1.0f / 128);
+  if (f->encoding == 0) {
+    s->global_scale = jxo_u32(br, 11, 1, 11, 2049, 12, 4097, 16, 8193);
+    s->quant_lf = jxo_u32(br, -1, 16, 5, 1, 8, 1, 16, 1);
+    /* block context map */
+    if (jxo_bool(br)) {
+      s->bctx_size = 39; s->bctx_map = (uint8_t *)malloc(39); memcpy(s->bctx_map, kDefaultBlockCtxMap, 39); s->num_bctx = 15;
+    } else {
+      int nlf = 1;
+      for (int c = 0; c < 3; c++) {
+        s->nb_lf_thr[c] = (int)jxo_bits(br, 4);
+        for (int i = 0; i < s->nb_lf_thr[c]; i++) s->lf_thr[c][i] = jxo_unpack_signed(jxo_u32(br, 4, 0, 8, 16, 16, 272, 32, 65808));
+        nlf *= s->nb_lf_thr[c] + 1;
+      }
+      s->nb_qf_thr = (int)jxo_bits(br, 4);
+      for (int i = 0; i < s->nb_qf_thr; i++) s->qf_thr[i] = 1 + jxo_u32(br, 2, 0, 3, 4, 5, 12, 8, 44);
+      s->bctx_size = 39 * (s->nb_qf_thr + 1) * nlf;
+      if (s->bctx_size > 39 * 64) JXO_FAIL("block ctx map too large");
+      s->bctx_map = (uint8_t *)calloc((size_t)s->bctx_size, 1);
+      /* context map read (same routine as entropy-code clustering) */
+      extern int jxo__read_ctx_map(jxo_br *, uint8_t *, int, int *);
+      if (jxo__read_ctx_map(br, s->bctx_map, s->bctx_size, &s->num_bctx)) JXO_FAIL("bad block ctx map");
+    }
+    /* CfL */
+    s->color_factor = 84; s->base_x = 0.0f; s->base_b = 1.0f; s->ytox_dc = 0; s->ytob_dc = 0;
+    if (!jxo_bool(br)) {
+      s->color_factor = jxo_u32(br, -1, 84, -1, 256, 8, 2, 16, 258);
+      s->base_x = jxo_f16(br); s->base_b = jxo_f16(br);
+      s->ytox_dc = (int)jxo_bits(br, 8) - 128; s->ytob_dc = (int)jxo_bits(br, 8) - 128;
+    }
+  }
+  /* GlobalModular */
+  if (jxo_bool(br)) { if (jxo_tree_read(&s->gtree, br)) return -1; }
+  jxo_modimg_init(&s->gmod);
+  s->gmod.bitdepth = (int)s->m->pub.bits_per_sample;
+  int ncol = f->encoding == 1 ? (int)(s->m->pub.num_color_channels == 1 && !f->do_ycbcr && !s->m->pub.xyb_encoded ? 1 : 3) : 0;
+  if (f->encoding == 1 && s->m->pub.xyb_encoded) ncol = 3;
+  for (int i = 0; i < ncol; i++) jxo_modimg_add(&s->gmod, f->width, f->height, 0, 0);
+  for (int i = 0; i < s->m->num_extra; i++) {
+    int sh = s->m->ec[i].dim_shift;
+    if (sh) JXO_FAIL("unsupported: extra channel dim_shift");
+    jxo_modimg_add(&s->gmod, f->width, f->height, 0, 0);
+  }
+  if (jxo_modular_decode(br, &s->gmod, 0, f->group_dim, &s->gtree, 0, &s->gmod_first_undecoded)) return -1;
+  if (br->err) JXO_FAIL("truncated LfGlobal");
+  return 0;
+}
+
+static int read_lf_group(fstate *s, jxo_br *br, int g) {
+  const frame_hdr *f = &s->f;
+  int gx = g % f->xlfg, gy = g / f->xlfg;
+  int cells = f->group_dim;                 /* LF group covers group_dim x group_dim cells */
+  int bx0 = gx * cells, by0 = gy * cells;
+  int bw = s->xb - bx0 < cells ? s->xb - bx0 : cells, bh = s->yb - by0 < cells ? s->yb - by0 : cells;
+  if (f->encoding == 0) {
+    if (f->flags & 32) JXO_FAIL("unsupported: LF frame");
+    int extra = (int)jxo_bits(br, 2);
+    jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = 16;
+    for (int c = 0; c < 3; c++) jxo_modimg_add(&im, bw, bh, 0, 0);
+    if (jxo_modular_decode(br, &im, 1 + g, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
+    float inv_quant_dc = 65536.0f / ((float)s->global_scale * (float)s->quant_lf);
+    float mul = 1.0f / (float)(1 << extra);
+    float fac[3];
+    for (int c = 0; c < 3; c++) fac[c] = s->lf_dequant[c] * inv_quant_dc * mul;
+    float cfl_x = s->base_x + (float)s->ytox_dc / (float)s->color_factor;
+    float cfl_b = s->base_b + (float)s->ytob_dc / (float)s->color_factor;
+    for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++) {
+        int32_t qy = im.ch[0].d[y * bw + x], qx = im.ch[1].d[y * bw + x], qb = im.ch[2].d[y * bw + x];
+        size_t o = (size_t)(by0 + y) * (size_t)s->xb + (size_t)(bx0 + x);
+        float Y = (float)qy * fac[1];
+        s->lf[1][o] = Y;
+        s->lf[0][o] = (float)qx * fac[0] + cfl_x * Y;
+        s->lf[2][o] = (float)qb * fac[2] + cfl_b * Y;
+        int ix = 0, iy = 0, ib = 0;
+        for (int t = 0; t < s->nb_lf_thr[0]; t++) if (qx > s->lf_thr[0][t]) ix++;
+        for (int t = 0; t < s->nb_lf_thr[1]; t++) if (qy > s->lf_thr[1][t]) iy++;
+        for (int t = 0; t < s->nb_lf_thr[2]; t++) if (qb > s->lf_thr[2][t]) ib++;
+        int bucket = ix; bucket = bucket * (s->nb_lf_thr[2] + 1) + ib; bucket = bucket * (s->nb_lf_thr[1] + 1) + iy;
+        s->lf_idx[o] = (uint8_t)bucket;
+      }
+    jxo_modimg_free(&im);
+  }
+  /* ModularLfGroup: channels of the global image with hshift>=3 && vshift>=3: none without squeeze */
+  if (f->encoding == 0) {
+    int nblocks = bw * bh;
+    int count = 1 + (int)jxo_bits(br, ceil_log2u((uint32_t)nblocks));
+    if (count > nblocks) JXO_FAIL("HF metadata: too many blocks");
+    jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = 16;
+    int tw = (bw + 7) / 8, th = (bh + 7) / 8;
+    jxo_modimg_add(&im, tw, th, 0, 0); jxo_modimg_add(&im, tw, th, 0, 0);
+    jxo_modimg_add(&im, count, 2, 0, 0); jxo_modimg_add(&im, bw, bh, 0, 0);
+    if (jxo_modular_decode(br, &im, 1 + 2 * f->num_lf_groups + g, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
+    for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) {
+      size_t o = (size_t)(by0 / 8 + y) * (size_t)s->tiles_x + (size_t)(bx0 / 8 + x);
+      int vx = im.ch[0].d[y * tw + x], vb = im.ch[1].d[y * tw + x];
+      if (vx < -128 || vx > 127 || vb < -128 || vb > 127) { jxo_modimg_free(&im); JXO_FAIL("cfl map out of range"); }
+      s->xfromy[o] = (int8_t)vx; s->bfromy[o] = (int8_t)vb;
+    }
+    int num = 0;
+    for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++) {
+        size_t o = (size_t)(by0 + y) * (size_t)s->xb + (size_t)(bx0 + x);
+        int sh = im.ch[3].d[y * bw + x];
+        if (sh < 0 || sh > 7) { jxo_modimg_free(&im); JXO_FAIL("bad sharpness"); }
+        s->sharp[o] = (uint8_t)sh;
+        if (s->strategy[o] != 0xFF) continue;
+        if (num >= count) { jxo_modimg_free(&im); JXO_FAIL("HF metadata: ran out of blocks"); }
+        int st = im.ch[2].d[num], q = 1 + im.ch[2].d[count + num];
+        num++;
+        if (st < 0 || st > 26 || q < 1 || q > 256) { jxo_modimg_free(&im); JXO_FAIL("bad block strategy/quant"); }
+        int cx = kCoveredX[st], cy = kCoveredY[st];
+        if (x + cx > bw || y + cy > bh) { jxo_modimg_free(&im); JXO_FAIL("varblock exceeds LF group"); }
+        /* must not straddle a 256x256 group either */
+        if ((x % 32) + cx > 32 && cx <= 32) {}
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) {
+          size_t oo = o + (size_t)iy * (size_t)s->xb + (size_t)ix;
+          if (s->strategy[oo] != 0xFF) { jxo_modimg_free(&im); JXO_FAIL("overlapping varblocks"); }
+          s->strategy[oo] = (uint8_t)st; s->first[oo] = 0; s->qf[oo] = q;
+        }
+        s->first[o] = 1;
+      }
+    jxo_modimg_free(&im);
+  }
+  if (br->err) JXO_FAIL("truncated LfGroup");
+  return 0;
+}
+
+static int read_hf_global(fstate *s, jxo_br *br) {
+  const frame_hdr *f = &s->f;
+  if (!jxo_bool(br)) JXO_FAIL("unsupported: custom dequant matrices");
+  s->num_presets = 1 + (int)jxo_bits(br, ceil_log2u((uint32_t)f->num_groups));
+  for (int p = 0; p < f->num_passes; p++) {
+    uint32_t used = jxo_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
+    jxo_ec oc; int have_oc = 0;
+    if (used) { if (jxo_ec_read_header(&oc, br, 8)) JXO_FAIL("bad coefficient-order code"); jxo_ec_begin(&oc, br, 0); have_oc = 1; }
+    for (int o = 0; o < 13; o++) {
+      int st = kOrderStrategy[o];
+      uint32_t size = (uint32_t)kCoveredX[st] * kCoveredY[st] * 64;
+      uint32_t *nat = (uint32_t *)malloc(4 * (size_t)size);
+      natural_order(st, nat);
+      for (int c = 0; c < 3; c++) {
+        uint32_t *ord = (uint32_t *)malloc(4 * (size_t)size);
+        if (used & (1u << o)) {
+          uint32_t *perm = (uint32_t *)malloc(4 * (size_t)size);
+          if (jxo_read_permutation(&oc, br, perm, size, size / 64)) { free(perm); free(ord); free(nat); JXO_FAIL("bad coefficient order"); }
+          for (uint32_t i = 0; i < size; i++) ord[i] = nat[perm[i]];
+          free(perm);
+        } else memcpy(ord, nat, 4 * (size_t)size);
+        s->orders[p][o][c] = ord;
+      }
+      free(nat);
+    }
+    if (have_oc) { int ok = jxo_ec_final_ok(&oc); jxo_ec_free(&oc); if (!ok) JXO_FAIL("coefficient orders: ANS final state"); }
+    if (jxo_ec_read_header(&s->hf_code[p], br, 495 * s->num_presets * s->num_bctx)) JXO_FAIL("bad HF histograms");
+  }
+  if (br->err) JXO_FAIL("truncated HfGlobal");
+  return 0;
+}
+
+static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
+  const frame_hdr *f = &s->f;
+  int gx = g % f->xgroups, gy = g / f->xgroups;
+  int gc = f->group_dim / 8;
+  int bx0 = gx * gc, by0 = gy * gc;
+  int bw = s->xb - bx0 < gc ? s->xb - bx0 : gc, bh = s->yb - by0 < gc ? s->yb - by0 : gc;
+  if (f->encoding == 0) {
+    int sel = (int)jxo_bits(br, ceil_log2u((uint32_t)s->num_presets));
+    if (sel >= s->num_presets) JXO_FAIL("bad HF preset");
+    int ctx_offset = sel * 495 * s->num_bctx;
+    jxo_ec *ec = &s->hf_code[pass];
+    jxo_ec_begin(ec, br, 0);
+    int shift = pass < f->num_passes - 1 ? f->pass_shift[pass] : 0;
+    int *nz = (int *)calloc((size_t)3 * (size_t)bw * (size_t)bh, sizeof(int));
+    for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++) {
+        size_t o = (size_t)(by0 + y) * (size_t)s->xb + (size_t)(bx0 + x);
+        if (!s->first[o]) continue;
+        int st = s->strategy[o];
+        int cx = kCoveredX[st], cy = kCoveredY[st];
+        int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
+        int size = covered * 64;
+        int ord = kStrategyOrder[st];
+        static const int corder[3] = {1, 0, 2};
+        for (int ci = 0; ci < 3; ci++) {
+          int c = corder[ci];
+          int *nzc = nz + (size_t)c * (size_t)bw * (size_t)bh;
+          int predicted;
+          if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * bw];
+          else if (y == 0) predicted = nzc[x - 1];
+          else predicted = (nzc[(y - 1) * bw + x] + nzc[y * bw + x - 1] + 1) / 2;
+          /* block context */
+          int qf_idx = 0;
+          for (int t = 0; t < s->nb_qf_thr; t++) if ((uint32_t)s->qf[o] > s->qf_thr[t]) qf_idx++;
+          int idx = c < 2 ? c ^ 1 : 2;
+          int nlf = (s->nb_lf_thr[0] + 1) * (s->nb_lf_thr[1] + 1) * (s->nb_lf_thr[2] + 1);
+          idx = idx * 13 + ord;
+          idx = idx * (s->nb_qf_thr + 1) + qf_idx;
+          idx = idx * nlf + s->lf_idx[o];
+          int bctx = s->bctx_map[idx];
+          int nzp = predicted >= 64 ? 64 : predicted;
+          int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * s->num_bctx + bctx + ctx_offset;
+          int nzeros = (int)jxo_ec_read(ec, br, nzctx);
+          if (nzeros > size - covered) { free(nz); JXO_FAIL("too many nonzeros (group %d)", g); }
+          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * bw + x + ix] = (nzeros + covered - 1) >> log2c;
+          int histo = ctx_offset + s->num_bctx * 37 + 458 * bctx;
+          const uint32_t *order = s->orders[pass][ord][c];
+          int32_t *blk = s->coef[c] + s->coef_off[o];
+          int prev = nzeros > size / 16 ? 0 : 1;
+          for (int k = covered; k < size && nzeros != 0; k++) {
+            int nl = (nzeros + covered - 1) >> log2c;
+            int kk = k >> log2c;
+            int ctx = histo + (kCoeffNumNonzeroContext[nl] + kCoeffFreqContext[kk]) * 2 + prev;
+            uint32_t u = jxo_ec_read(ec, br, ctx);
+            blk[order[k]] += jxo_unpack_signed(u) * (1 << shift);
+            prev = u != 0;
+            nzeros -= prev;
+          }
+          if (nzeros != 0) { free(nz); JXO_FAIL("nonzero count mismatch (group %d)", g); }
+          if (br->err) { free(nz); JXO_FAIL("truncated PassGroup %d", g); }
+        }
+      }
+    free(nz);
+    if (!jxo_ec_final_ok(ec)) JXO_FAIL("PassGroup %d: ANS final state mismatch", g);
+  }
+  /* modular group data */
+  if (s->gmod_first_undecoded < s->gmod.nch) {
+    int x0 = gx * f->group_dim, y0 = gy * f->group_dim;
+    jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = s->gmod.bitdepth;
+    int map[64], nmap = 0;
+    for (int c = s->gmod_first_undecoded; c < s->gmod.nch; c++) {
+      jxo_chan *fc = &s->gmod.ch[c];
+      int sh = fc->hshift < fc->vshift ? fc->hshift : fc->vshift;
+      if (sh > 2 || sh < 0) continue;      /* single-pass bracket: minShift 0, maxShift 2 */
+      int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift;
+      int rw = f->group_dim >> fc->hshift, rh = f->group_dim >> fc->vshift;
+      if (rx >= fc->w || ry >= fc->h) continue;
+      if (rx + rw > fc->w) rw = fc->w - rx;
+      if (ry + rh > fc->h) rh = fc->h - ry;
+      if (rw <= 0 || rh <= 0) continue;
+      jxo_modimg_add(&im, rw, rh, fc->hshift, fc->vshift);
+      map[nmap++] = c;
+    }
+    if (pass == 0 && nmap) {
+      int sid = 1 + 3 * f->num_lf_groups + 17 + f->num_groups * pass + g;
+      if (jxo_modular_decode(br, &im, sid, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
+      for (int i = 0; i < nmap; i++) {
+        jxo_chan *fc = &s->gmod.ch[map[i]];
+        int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift;
+        for (int y = 0; y < im.ch[i].h; y++)
+          memcpy(fc->d + (size_t)(ry + y) * (size_t)fc->w + (size_t)rx, im.ch[i].d + (size_t)y * (size_t)im.ch[i].w, 4 * (size_t)im.ch[i].w);
+      }
+    }
+    jxo_modimg_free(&im);
+  }
+  if (br->err) JXO_FAIL("truncated PassGroup %d", g);
+  return 0;
+}
+
+/* ================================================================= VarDCT reconstruction */
+static void adaptive_lf_smoothing(fstate *s) {
+  int w = s->xb, h = s->yb;
+  if (w < 3 || h < 3) return;
+  float inv_quant_dc = 65536.0f / ((float)s->global_scale * (float)s->quant_lf);
+  float fac[3];
+  for (int c = 0; c < 3; c++) fac[c] = s->lf_dequant[c] * inv_quant_dc;
+  float *out[3];
+  for (int c = 0; c < 3; c++) { out[c] = (float *)malloc(4 * (size_t)w * (size_t)h); memcpy(out[c], s->lf[c], 4 * (size_t)w * (size_t)h); }
+  const float w0 = 0.05226273532324128f, w1 = 0.20345139757231578f, w2 = 0.0334829185968739f;
+  for (int y = 1; y < h - 1; y++)
+    for (int x = 1; x < w - 1; x++) {
+      float sm[3], gap = 0.5f;
+      for (int c = 0; c < 3; c++) {
+        const float *p = s->lf[c] + (size_t)y * (size_t)w + (size_t)x;
+        float side = p[-1] + p[1] + p[-w] + p[w];
+        float corner = p[-w - 1] + p[-w + 1] + p[w - 1] + p[w + 1];
+        sm[c] = w0 * p[0] + w1 * side + w2 * corner;
+        float g = fabsf((sm[c] - p[0]) / fac[c]);
+        if (g > gap) gap = g;
+      }
+      float factor = 3.0f - 4.0f * gap;
+      if (factor < 0) factor = 0;
+      for (int c = 0; c < 3; c++) {
+        float p0 = s->lf[c][(size_t)y * (size_t)w + (size_t)x];
+        out[c][(size_t)y * (size_t)w + (size_t)x] = (sm[c] - p0) * factor + p0;
+      }
+    }
+  for (int c = 0; c < 3; c++) { free(s->lf[c]); s->lf[c] = out[c]; }
+}
+
+static inline float llf_scale(int N, int k) {
+  double t = k * PI / (16.0 * N);
+  return (float)(1.0 / (cos(t) * cos(2 * t) * cos(4 * t)));
+}
+
+static void afv_idct4x4(const float *coef, float *pix) {
+  for (int i = 0; i < 16; i++) { double s = 0; for (int j = 0; j < 16; j++) s += coef[j] * kAFVBasis[j][i]; pix[i] = (float)s; }
+}
+
+static void transform_block(int st, float *S, float *out, int ostride) {
+  int cx = kCoveredX[st], cy = kCoveredY[st];
+  switch (st) {
+    case 1: {   /* IDENTITY */
+      float dcs[4];
+      float b00 = S[0], b01 = S[1], b10 = S[8], b11 = S[9];
+      dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+      for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
+        float block_dc = dcs[y * 2 + x], rs = 0;
+        for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (!ix && !iy) continue; rs += S[(y + iy * 2) * 8 + x + ix * 2]; }
+        float v11 = block_dc - rs * (1.0f / 16);
+        out[(4 * y + 1) * ostride + 4 * x + 1] = v11;
+        for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) {
+          if (ix == 1 && iy == 1) continue;
+          out[(y * 4 + iy) * ostride + x * 4 + ix] = S[(y + iy * 2) * 8 + x + ix * 2] + v11;
+        }
+        out[y * 4 * ostride + x * 4] = S[(y + 2) * 8 + x + 2] + v11;
+      }
+      return;
+    }
+    case 2: {   /* DCT2X2 */
+      float a[64], b[64];
+      memcpy(a, S, sizeof(a));
+      for (int sz = 2; sz <= 8; sz *= 2) {
+        int n2 = sz / 2;
+        memcpy(b, a, sizeof(b));
+        for (int y = 0; y < n2; y++) for (int x = 0; x < n2; x++) {
+          float c00 = a[y * 8 + x], c01 = a[y * 8 + n2 + x], c10 = a[(y + n2) * 8 + x], c11 = a[(y + n2) * 8 + n2 + x];
+          b[y * 2 * 8 + x * 2] = c00 + c01 + c10 + c11;
+          b[y * 2 * 8 + x * 2 + 1] = c00 + c01 - c10 - c11;
+          b[(y * 2 + 1) * 8 + x * 2] = c00 - c01 + c10 - c11;
+          b[(y * 2 + 1) * 8 + x * 2 + 1] = c00 - c01 - c10 + c11;
+        }
+        memcpy(a, b, sizeof(a));
+      }
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) out[y * ostride + x] = a[y * 8 + x];
+      return;
+    }
+    case 3: {   /* DCT4X4 */
+      float dcs[4];
+      float b00 = S[0], b01 = S[1], b10 = S[8], b11 = S[9];
+      dcs[0] = b00 + b01 + b10 + b11; dcs[1] = b00 + b01 - b10 - b11; dcs[2] = b00 - b01 + b10 - b11; dcs[3] = b00 - b01 - b10 + b11;
+      for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) {
+        float blk[16];
+        blk[0] = dcs[y * 2 + x];
+        for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (!ix && !iy) continue; blk[iy * 4 + ix] = S[(y + iy * 2) * 8 + x + ix * 2]; }
+        idct2d(blk, 4, 4, out + y * 4 * ostride + x * 4, ostride);
+      }
+      return;
+    }
+    case 12: case 13: {   /* DCT4X8 (two 4-row x 8-col stacked), DCT8X4 (two 8-row x 4-col side by side) */
+      float dcs[2] = {S[0] + S[8], S[0] - S[8]};
+      for (int k = 0; k < 2; k++) {
+        float blk[32];
+        blk[0] = dcs[k];
+        for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) { if (!ix && !iy) continue; blk[iy * 8 + ix] = S[(k + iy * 2) * 8 + ix]; }
+        if (st == 12) idct2d(blk, 4, 8, out + k * 4 * ostride, ostride);
+        else idct2d(blk, 8, 4, out + k * 4, ostride);
+      }
+      return;
+    }
+    case 14: case 15: case 16: case 17: {   /* AFV */
+      int kind = st - 14, afv_x = kind & 1, afv_y = kind / 2;
+      float dcs[3];
+      float b00 = S[0], b01 = S[1], b10 = S[8];
+      dcs[0] = (b00 + b10 + b01) * 4.0f; dcs[1] = (b00 + b10 - b01); dcs[2] = b00 - b10;
+      float coeff[16], blk[32];
+      coeff[0] = dcs[0];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (!ix && !iy) continue; coeff[iy * 4 + ix] = S[iy * 2 * 8 + ix * 2]; }
+      afv_idct4x4(coeff, blk);
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++)
+        out[(iy + afv_y * 4) * ostride + afv_x * 4 + ix] = blk[(afv_y == 1 ? 3 - iy : iy) * 4 + (afv_x == 1 ? 3 - ix : ix)];
+      blk[0] = dcs[1];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 4; ix++) { if (!ix && !iy) continue; blk[iy * 4 + ix] = S[iy * 2 * 8 + ix * 2 + 1]; }
+      idct2d(blk, 4, 4, out + afv_y * 4 * ostride + (afv_x == 1 ? 0 : 4), ostride);
+      blk[0] = dcs[2];
+      for (int iy = 0; iy < 4; iy++) for (int ix = 0; ix < 8; ix++) { if (!ix && !iy) continue; blk[iy * 8 + ix] = S[(1 + iy * 2) * 8 + ix]; }
+      idct2d(blk, 4, 8, out + (afv_y == 1 ? 0 : 4) * ostride, ostride);
+      return;
+    }
+    default:
+      idct2d(S, cy * 8, cx * 8, out, ostride);
+  }
+}
+
+static void reconstruct_vardct(fstate *s) {
+  const frame_hdr *f = &s->f;
+  init_quant_tables();
+  float inv_gs = 65536.0f / (float)s->global_scale;
+  float xdm = powf(1.0f / 1.25f, (float)f->x_qm - 2.0f), bdm = powf(1.0f / 1.25f, (float)f->b_qm - 2.0f);
+  float dm[3] = {xdm, 1.0f, bdm};
+  float *S[3];
+  for (int c = 0; c < 3; c++) S[c] = (float *)malloc(4 * 256 * 256);
+  for (int by = 0; by < s->yb; by++)
+    for (int bx = 0; bx < s->xb; bx++) {
+      size_t o = (size_t)by * (size_t)s->xb + (size_t)bx;
+      if (!s->first[o]) continue;
+      int st = s->strategy[o], cx = kCoveredX[st], cy = kCoveredY[st], n = cx * cy * 64;
+      int qt = kQuantTableOf[st];
+      float mul = inv_gs / (float)s->qf[o];
+      for (int c = 0; c < 3; c++) {
+        const int32_t *q = s->coef[c] + s->coef_off[o];
+        const float *w = qt_weights[qt][c];
+        for (int k = 0; k < n; k++) {
+          int v = q[k];
+          float a;
+          if (v == 0) a = 0;
+          else if (v == 1) a = s->m->quant_bias[c];
+          else if (v == -1) a = -s->m->quant_bias[c];
+          else a = (float)v - s->m->quant_bias[3] / (float)v;
+          S[c][k] = a * (mul * dm[c] / w[k]);
+        }
+      }
+      size_t to = (size_t)(by / 8) * (size_t)s->tiles_x + (size_t)(bx / 8);
+      float kx = s->base_x + (float)s->xfromy[to] / (float)s->color_factor;
+      float kb = s->base_b + (float)s->bfromy[to] / (float)s->color_factor;
+      for (int k = 0; k < n; k++) { S[0][k] += kx * S[1][k]; S[2][k] += kb * S[1][k]; }
+      /* LLF from LF */
+      int srows = cy < cx ? cy : cx, scols = cy < cx ? cx : cy;   /* storage dims in cells */
+      for (int c = 0; c < 3; c++) {
+        float lfb[32 * 32], ss[32 * 32];
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) lfb[iy * cx + ix] = s->lf[c][o + (size_t)iy * (size_t)s->xb + (size_t)ix];
+        dct2d(lfb, cx, cy, cx, ss);
+        for (int a = 0; a < srows; a++) for (int b = 0; b < scols; b++) {
+          float sa, sb;
+          if (cy >= cx) { sa = llf_scale(cx, a); sb = llf_scale(cy, b); } else { sa = llf_scale(cy, a); sb = llf_scale(cx, b); }
+          S[c][a * scols * 8 + b] = ss[a * scols + b] * sa * sb;
+        }
+        transform_block(st, S[c], s->plane[c] + (size_t)by * 8 * (size_t)s->pw + (size_t)bx * 8, s->pw);
+      }
+    }
+  for (int c = 0; c < 3; c++) free(S[c]);
+}
+
+static inline int mirror(int x, int n) {
+  while (x < 0 || x >= n) { if (x < 0) x = -x - 1; else x = 2 * n - 1 - x; }
+  return x;
+}
+
+static void gaborish(fstate *s, int w, int h) {
+  for (int c = 0; c < 3; c++) {
+    float w1 = s->f.gab_w[c][0], w2 = s->f.gab_w[c][1];
+    float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
+    float wc = norm, ws = w1 * norm, wd = w2 * norm;
+    float *src = s->plane[c], *dst = (float *)malloc(4 * (size_t)s->pw * (size_t)s->ph);
+    memcpy(dst, src, 4 * (size_t)s->pw * (size_t)s->ph);
+    for (int y = 0; y < h; y++) {
+      int ym = mirror(y - 1, h), yp = mirror(y + 1, h);
+      for (int x = 0; x < w; x++) {
+        int xm = mirror(x - 1, w), xp = mirror(x + 1, w);
+        #define P(yy, xx) src[(size_t)(yy) * (size_t)s->pw + (size_t)(xx)]
+        float side = P(ym, x) + P(yp, x) + P(y, xm) + P(y, xp);
+        float diag = P(ym, xm) + P(ym, xp) + P(yp, xm) + P(yp, xp);
+        dst[(size_t)y * (size_t)s->pw + (size_t)x] = P(y, x) * wc + side * ws + diag * wd;
+        #undef P
+      }
+    }
+    free(src);
+    s->plane[c] = dst;
+  }
+}
+
+static void epf_pass(fstate *s, int w, int h, int pass, const float *inv_sigma) {
+  const frame_hdr *f = &s->f;
+  float sm = 1.65f * (pass == 0 ? f->epf_pass0 : pass == 2 ? f->epf_pass2 : 1.0f);
+  float bsm = sm * f->epf_border_sad;
+  float *dst[3];
+  for (int c = 0; c < 3; c++) { dst[c] = (float *)malloc(4 * (size_t)s->pw * (size_t)s->ph); memcpy(dst[c], s->plane[c], 4 * (size_t)s->pw * (size_t)s->ph); }
+  static const int plus[5][2] = {{0, 0}, {0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  static const int taps0[12][2] = {{0, -2}, {-1, -1}, {0, -1}, {1, -1}, {-2, 0}, {-1, 0}, {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {0, 2}};
+  static const int taps1[4][2] = {{0, -1}, {-1, 0}, {1, 0}, {0, 1}};
+  const int (*taps)[2] = pass == 0 ? taps0 : taps1;
+  int ntaps = pass == 0 ? 12 : 4;
+  #define PX(c, yy, xx) s->plane[c][(size_t)mirror((yy), h) * (size_t)s->pw + (size_t)mirror((xx), w)]
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float is = inv_sigma[(size_t)(y / 8) * (size_t)s->xb + (size_t)(x / 8)];
+      if (is < -3.90524291751269967465540850526868f) continue;
+      int border = (y % 8 == 0 || y % 8 == 7 || x % 8 == 0 || x % 8 == 7);
+      float isig = is * (border ? bsm : sm);
+      float wsum = 1.0f, acc[3];
+      for (int c = 0; c < 3; c++) acc[c] = PX(c, y, x);
+      for (int t = 0; t < ntaps; t++) {
+        int tx = taps[t][0], ty = taps[t][1];
+        float sad = 0;
+        if (pass == 2) {
+          for (int c = 0; c < 3; c++) sad += fabsf(PX(c, y, x) - PX(c, y + ty, x + tx)) * f->epf_chscale[c];
+        } else {
+          for (int c = 0; c < 3; c++) {
+            float sc = 0;
+            for (int k = 0; k < 5; k++) sc += fabsf(PX(c, y + plus[k][1], x + plus[k][0]) - PX(c, y + ty + plus[k][1], x + tx + plus[k][0]));
+            sad += sc * f->epf_chscale[c];
+          }
+        }
+        float wgt = 1.0f + sad * isig;
+        if (wgt < 0) wgt = 0;
+        wsum += wgt;
+        for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, y + ty, x + tx);
+      }
+      for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)s->pw + (size_t)x] = acc[c] / wsum;
+    }
+  #undef PX
+  for (int c = 0; c < 3; c++) { free(s->plane[c]); s->plane[c] = dst[c]; }
+}
+
+static void epf(fstate *s, int w, int h) {
+  const frame_hdr *f = &s->f;
+  float *inv_sigma = (float *)malloc(4 * (size_t)s->xb * (size_t)s->yb);
+  float quant_scale = (float)s->global_scale / 65536.0f;
+  for (size_t i = 0; i < (size_t)s->xb * (size_t)s->yb; i++) {
+    float sigma_quant = f->epf_quant_mul / (quant_scale * (float)s->qf[i] * -1.1715728752538099024f);
+    float sigma = sigma_quant * f->epf_sharp[s->sharp[i]];
+    if (f->encoding == 1) sigma = f->epf_sigma_modular * -1.0f / 1.1715728752538099024f;  /* not exercised */
+    if (sigma > -1e-4f) sigma = -1e-4f;
+    inv_sigma[i] = 1.0f / sigma;
+  }
+  if (f->epf_iters >= 3) epf_pass(s, w, h, 0, inv_sigma);
+  if (f->epf_iters >= 1) epf_pass(s, w, h, 1, inv_sigma);
+  if (f->epf_iters >= 2) epf_pass(s, w, h, 2, inv_sigma);
+  free(inv_sigma);
+}
+
+/* ================================================================= colour */
+static float srgb_oetf(float v) {
+  float a = fabsf(v);
+  float r = a <= 0.0031308f ? 12.92f * a : 1.055f * powf(a, 1.0f / 2.4f) - 0.055f;
+  return v < 0 ? -r : r;
+}
+static float pq_oetf(float v, float intensity_target) {
+  /* linear (1.0 = intensity_target nits) -> PQ signal */
+  double a = fabs((double)v) * (intensity_target / 10000.0);
+  const double m1 = 2610.0 / 16384, m2 = 2523.0 / 4096 * 128, c1 = 3424.0 / 4096, c2 = 2413.0 / 4096 * 32, c3 = 2392.0 / 4096 * 32;
+  double p = pow(a, m1);
+  double r = pow((c1 + c2 * p) / (1 + c3 * p), m2);
+  return (float)(v < 0 ? -r : r);
+}
+static float bt709_oetf(float v) {
+  float a = fabsf(v);
+  float r = a < 0.018f ? 4.5f * a : 1.099f * powf(a, 0.45f) - 0.099f;
+  return v < 0 ? -r : r;
+}
+static void primaries_to_xyz(const double xy[8], double M[9]) {   /* r,g,b,w xy -> RGB->XYZ matrix */
+  double X[3], Y[3], Z[3];
+  for (int i = 0; i < 3; i++) { X[i] = xy[2 * i] / xy[2 * i + 1]; Y[i] = 1; Z[i] = (1 - xy[2 * i] - xy[2 * i + 1]) / xy[2 * i + 1]; }
+  double wX = xy[6] / xy[7], wY = 1, wZ = (1 - xy[6] - xy[7]) / xy[7];
+  /* solve [X;Y;Z] * S = w */
+  double A[9] = {X[0], X[1], X[2], Y[0], Y[1], Y[2], Z[0], Z[1], Z[2]};
+  double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+  double inv[9] = {(A[4] * A[8] - A[5] * A[7]) / det, (A[2] * A[7] - A[1] * A[8]) / det, (A[1] * A[5] - A[2] * A[4]) / det,
+                   (A[5] * A[6] - A[3] * A[8]) / det, (A[0] * A[8] - A[2] * A[6]) / det, (A[2] * A[3] - A[0] * A[5]) / det,
+                   (A[3] * A[7] - A[4] * A[6]) / det, (A[1] * A[6] - A[0] * A[7]) / det, (A[0] * A[4] - A[1] * A[3]) / det};
+  double S[3];
+  for (int i = 0; i < 3; i++) S[i] = inv[i * 3] * wX + inv[i * 3 + 1] * wY + inv[i * 3 + 2] * wZ;
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r * 3 + c] = A[r * 3 + c] * S[c];
+}
+static void inv3(const double A[9], double inv[9]) {
+  double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+  double t[9] = {(A[4] * A[8] - A[5] * A[7]) / det, (A[2] * A[7] - A[1] * A[8]) / det, (A[1] * A[5] - A[2] * A[4]) / det,
+                 (A[5] * A[6] - A[3] * A[8]) / det, (A[0] * A[8] - A[2] * A[6]) / det, (A[2] * A[3] - A[0] * A[5]) / det,
+                 (A[3] * A[7] - A[4] * A[6]) / det, (A[1] * A[6] - A[0] * A[7]) / det, (A[0] * A[4] - A[1] * A[3]) / det};
+  memcpy(inv, t, sizeof(t));
+}
+
+/* ================================================================= container */
+static int extract_codestream(const uint8_t *d, size_t n, uint8_t **cs, size_t *csn, int *owned) {
+  static const uint8_t sig[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
+  *owned = 0;
+  if (n >= 2 && d[0] == 0xFF && d[1] == 0x0A) { *cs = (uint8_t *)d; *csn = n; return 0; }
+  if (n < 12 || memcmp(d, sig, 12)) JXO_FAIL("not a JPEG XL file");
+  uint8_t *buf = (uint8_t *)malloc(n);
+  size_t out = 0, pos = 0;
+  while (pos + 8 <= n) {
+    uint64_t sz = ((uint64_t)d[pos] << 24) | (d[pos + 1] << 16) | (d[pos + 2] << 8) | d[pos + 3];
+    const uint8_t *ty = d + pos + 4;
+    size_t hdr = 8;
+    if (sz == 1) {
+      if (pos + 16 > n) break;
+      sz = 0; for (int i = 0; i < 8; i++) sz = (sz << 8) | d[pos + 8 + i];
+      hdr = 16;
+    } else if (sz == 0) sz = n - pos;
+    if (sz < hdr || pos + sz > n) { free(buf); JXO_FAIL("bad box size"); }
+    if (!memcmp(ty, "jxlc", 4)) { memcpy(buf + out, d + pos + hdr, sz - hdr); out += sz - hdr; }
+    else if (!memcmp(ty, "jxlp", 4)) { if (sz - hdr < 4) { free(buf); JXO_FAIL("bad jxlp"); } memcpy(buf + out, d + pos + hdr + 4, sz - hdr - 4); out += sz - hdr - 4; }
+    pos += sz;
+  }
+  if (!out) { free(buf); JXO_FAIL("no codestream box"); }
+  *cs = buf; *csn = out; *owned = 1;
+  return 0;
+}
+
+int jxo_basic_info(const uint8_t *data, size_t size, jxo_info *info) {
+  uint8_t *cs; size_t csn; int owned;
+  if (extract_codestream(data, size, &cs, &csn, &owned)) return -1;
+  jxo_br br; jxo_br_init(&br, cs, csn);
+  img_meta m;
+  int rc = read_image_header(&br, &m);
+  if (!rc) *info = m.pub;
+  if (owned) free(cs);
+  return rc;
+}
+
+/* ================================================================= top level */
+static void free_state(fstate *s) {
+  free(s->bctx_map); jxo_tree_free(&s->gtree); jxo_modimg_free(&s->gmod);
+  free(s->strategy); free(s->first); free(s->qf); free(s->sharp); free(s->lf_idx); free(s->xfromy); free(s->bfromy); free(s->coef_off);
+  for (int c = 0; c < 3; c++) { free(s->lf[c]); free(s->coef[c]); free(s->plane[c]); }
+  for (int p = 0; p < 12; p++) {
+    for (int o = 0; o < 13; o++) for (int c = 0; c < 3; c++) free(s->orders[p][o][c]);
+    if (s->hf_code[p].cl) jxo_ec_free(&s->hf_code[p]);
+  }
+}
+
+int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, size_t *out_size, jxo_info *info) {
+  *out = NULL; *out_size = 0;
+  uint8_t *cs; size_t csn; int owned;
+  if (extract_codestream(data, size, &cs, &csn, &owned)) return -1;
+  int rc = -1;
+  jxo_br br; jxo_br_init(&br, cs, csn);
+  img_meta m;
+  fstate *s = (fstate *)calloc(1, sizeof(fstate));
+  if (read_image_header(&br, &m)) goto done;
+  if (info) *info = m.pub;
+  if (m.pub.want_icc) { jxo_set_error("unsupported: embedded ICC profile"); goto done; }
+  if (m.have_preview) { jxo_set_error("unsupported: preview frame"); goto done; }
+  if (m.custom_upsampling) { jxo_set_error("unsupported: custom upsampling weights"); goto done; }
+  uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
+  jxo_align(&br);
+  s->m = &m;
+  if (read_frame_header(&br, &m, raw_w, raw_h, &s->f)) goto done;
+  frame_hdr *f = &s->f;
+  if (f->frame_type != 0 || !f->is_last) { jxo_set_error("unsupported: multi-frame / non-regular frame"); goto done; }
+  if (f->upsampling != 1) { jxo_set_error("unsupported: upsampling"); goto done; }
+  if (f->have_crop && (f->x0 || f->y0 || f->width != (int)raw_w || f->height != (int)raw_h)) { jxo_set_error("unsupported: cropped frame"); goto done; }
+  if (f->do_ycbcr) { jxo_set_error("unsupported: YCbCr"); goto done; }
+  if (f->num_passes > 11) { jxo_set_error("too many passes"); goto done; }
+  /* TOC */
+  int nsec = (f->num_groups == 1 && f->num_passes == 1) ? 1 : 1 + f->num_lf_groups + 1 + f->num_groups * f->num_passes;
+  uint32_t *perm = NULL;
+  if (jxo_bool(&br)) {
+    jxo_ec tc;
+    if (jxo_ec_read_header(&tc, &br, 8)) { jxo_set_error("bad TOC permutation code"); goto done; }
+    jxo_ec_begin(&tc, &br, 0);
+    perm = (uint32_t *)malloc(4 * (size_t)nsec);
+    int e = jxo_read_permutation(&tc, &br, perm, (uint32_t)nsec, 0);
+    int ok = jxo_ec_final_ok(&tc);
+    jxo_ec_free(&tc);
+    if (e || !ok) { free(perm); jxo_set_error("bad TOC permutation"); goto done; }
+  }
+  jxo_align(&br);
+  uint32_t *sec_size = (uint32_t *)malloc(4 * (size_t)nsec);
+  size_t *sec_off = (size_t *)malloc(sizeof(size_t) * (size_t)nsec);
+  for (int i = 0; i < nsec; i++) sec_size[i] = jxo_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
+  jxo_align(&br);
+  {
+    size_t base = br.pos / 8, acc = 0;
+    if (perm) {
+      size_t *phys = (size_t *)malloc(sizeof(size_t) * (size_t)nsec);
+      for (int i = 0; i < nsec; i++) { phys[i] = base + acc; acc += sec_size[i]; }
+      uint32_t *sz2 = (uint32_t *)malloc(4 * (size_t)nsec);
+      /* physical section i holds logical section perm[i] */
+      for (int i = 0; i < nsec; i++) { sec_off[perm[i]] = phys[i]; sz2[perm[i]] = sec_size[i]; }
+      memcpy(sec_size, sz2, 4 * (size_t)nsec);
+      free(sz2); free(phys); free(perm);
+    } else for (int i = 0; i < nsec; i++) { sec_off[i] = base + acc; acc += sec_size[i]; }
+    if (base + acc > csn || br.err) { free(sec_size); free(sec_off); jxo_set_error("truncated file (TOC exceeds input)"); goto done; }
+  }
+  /* state */
+  s->xb = (f->width + 7) / 8; s->yb = (f->height + 7) / 8;
+  s->pw = s->xb * 8; s->ph = s->yb * 8;
+  s->tiles_x = (s->xb + 7) / 8; s->tiles_y = (s->yb + 7) / 8;
+  size_t ncell = (size_t)s->xb * (size_t)s->yb;
+  if (f->encoding == 0) {
+    s->strategy = (uint8_t *)malloc(ncell); memset(s->strategy, 0xFF, ncell);
+    s->first = (uint8_t *)calloc(ncell, 1); s->qf = (int32_t *)calloc(ncell, 4); s->sharp = (uint8_t *)calloc(ncell, 1);
+    s->lf_idx = (uint8_t *)calloc(ncell, 1);
+    s->xfromy = (int8_t *)calloc((size_t)s->tiles_x * (size_t)s->tiles_y, 1); s->bfromy = (int8_t *)calloc((size_t)s->tiles_x * (size_t)s->tiles_y, 1);
+    s->coef_off = (uint32_t *)calloc(ncell, 4);
+    for (int c = 0; c < 3; c++) {
+      s->lf[c] = (float *)calloc(ncell, 4); s->coef[c] = (int32_t *)calloc(ncell * 64, 4);
+      s->plane[c] = (float *)calloc((size_t)s->pw * (size_t)s->ph, 4);
+    }
+  }
+  {
+    int single = nsec == 1;
+    jxo_br sb;
+    #define SECTION(i) do { if (!single) jxo_br_init(&sb, cs + sec_off[i], sec_size[i]); } while (0)
+    if (single) jxo_br_init(&sb, cs + sec_off[0], sec_size[0]);
+    int err = 0;
+    SECTION(0);
+    err = read_lf_global(s, &sb);
+    for (int g = 0; g < f->num_lf_groups && !err; g++) { SECTION(1 + g); err = read_lf_group(s, &sb, g); }
+    if (!err && f->encoding == 0) {
+      /* coefficient offsets: sequential in raster order of varblock top-lefts */
+      uint32_t off = 0;
+      for (size_t i = 0; i < ncell; i++) if (s->first[i]) { s->coef_off[i] = off; off += (uint32_t)kCoveredX[s->strategy[i]] * kCoveredY[s->strategy[i]] * 64; }
+      SECTION(1 + f->num_lf_groups);
+      err = read_hf_global(s, &sb);
+    }
+    for (int p = 0; p < f->num_passes && !err; p++)
+      for (int g = 0; g < f->num_groups && !err; g++) { SECTION(2 + f->num_lf_groups + p * f->num_groups + g); err = read_pass_group(s, &sb, p, g); }
+    #undef SECTION
+    free(sec_size); free(sec_off);
+    if (err) goto done;
+  }
+  int w = f->width, h = f->height;
+  float *rgb[3] = {NULL, NULL, NULL};
+  size_t npx = (size_t)w * (size_t)h;
+  if (f->encoding == 0) {
+    if (!(f->flags & 128)) adaptive_lf_smoothing(s);
+    reconstruct_vardct(s);
+    if (jxo_debug) { FILE *fp = fopen("/tmp/jxo_xyb.bin", "wb"); for (int c = 0; c < 3; c++) fwrite(s->plane[c], 4, (size_t)s->pw * (size_t)s->ph, fp); fclose(fp); }
+    if (f->gab) gaborish(s, w, h);
+    if (f->epf_iters) epf(s, w, h);
+    for (int c = 0; c < 3; c++) rgb[c] = (float *)malloc(4 * npx);
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int c = 0; c < 3; c++) rgb[c][(size_t)y * (size_t)w + (size_t)x] = s->plane[c][(size_t)y * (size_t)s->pw + (size_t)x];
+  } else {
+    if (jxo_modular_undo_transforms(&s->gmod)) goto done;
+    int ncol = s->gmod.nch - m.num_extra;
+    if (ncol != 1 && ncol != 3) { jxo_set_error("unexpected modular channel count"); goto done; }
+    for (int c = 0; c < 3; c++) {
+      rgb[c] = (float *)malloc(4 * npx);
+      jxo_chan *ch = &s->gmod.ch[ncol == 1 ? 0 : c];
+      if (ch->w != w || ch->h != h) { jxo_set_error("modular channel dims"); goto done; }
+      if (m.pub.xyb_encoded) {
+        /* modular XYB: ints scaled by LF dequant factors; channel order Y, X, B */
+        jxo_chan *cy = &s->gmod.ch[0], *cxx = &s->gmod.ch[1], *cb = &s->gmod.ch[2];
+        for (size_t i = 0; i < npx; i++) {
+          float v;
+          if (c == 1) v = (float)cy->d[i] * s->lf_dequant[1];
+          else if (c == 0) v = (float)cxx->d[i] * s->lf_dequant[0];
+          else v = (float)(cb->d[i] + cy->d[i]) * s->lf_dequant[2];
+          rgb[c][i] = v;
+        }
+      } else {
+        float sc = 1.0f / (float)((1u << m.pub.bits_per_sample) - 1);
+        for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)ch->d[i] * sc;
+      }
+    }
+    if (m.pub.xyb_encoded && f->epf_iters) { jxo_set_error("unsupported: EPF on modular XYB"); goto done; }
+  }
+  if (m.pub.xyb_encoded) {
+    /* XYB -> linear sRGB (opsin inverse), then to the data profile */
+    float itscale = 255.0f / m.pub.intensity_target;
+    float cb[3];
+    for (int c = 0; c < 3; c++) cb[c] = cbrtf(m.opsin_bias[c]);
+    double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (m.pub.primaries != 1 || m.pub.white_point != 1) {
+      static const double srgb[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
+      double dst[8];
+      if (m.pub.white_point != 1) { jxo_set_error("unsupported: non-D65 white point"); goto done; }
+      if (m.pub.primaries == 9) { double t[8] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
+      else if (m.pub.primaries == 11) { double t[8] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
+      else { jxo_set_error("unsupported: custom primaries"); goto done; }
+      double A[9], B[9], Bi[9];
+      primaries_to_xyz(srgb, A); primaries_to_xyz(dst, B); inv3(B, Bi);
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { T[r * 3 + c] = 0; for (int k = 0; k < 3; k++) T[r * 3 + c] += Bi[r * 3 + k] * A[k * 3 + c]; }
+    }
+    for (size_t i = 0; i < npx; i++) {
+      float X = rgb[0][i], Y = rgb[1][i], B = rgb[2][i];
+      float gl = Y + X - cb[0], gm = Y - X - cb[1], gs = B - cb[2];
+      float mix[3] = {gl * gl * gl + m.opsin_bias[0], gm * gm * gm + m.opsin_bias[1], gs * gs * gs + m.opsin_bias[2]};
+      float lin[3];
+      for (int c = 0; c < 3; c++) lin[c] = (m.opsin_inv[c * 3] * mix[0] + m.opsin_inv[c * 3 + 1] * mix[1] + m.opsin_inv[c * 3 + 2] * mix[2]) * itscale;
+      for (int c = 0; c < 3; c++) {
+        float v = (float)(T[c * 3] * lin[0] + T[c * 3 + 1] * lin[1] + T[c * 3 + 2] * lin[2]);
+        if (m.pub.have_gamma) { float a = fabsf(v); a = powf(a, m.pub.gamma); v = v < 0 ? -a : a; }
+        else switch (m.pub.transfer_function) {
+          case 13: v = srgb_oetf(v); break;
+          case 8: break;
+          case 16: v = pq_oetf(v, m.pub.intensity_target); break;
+          case 1: v = bt709_oetf(v); break;
+          default: jxo_set_error("unsupported: transfer function %u", m.pub.transfer_function); goto done;
+        }
+        rgb[c][i] = v;
+      }
+    }
+  }
+  /* alpha */
+  const jxo_chan *alpha = NULL; int alpha_bits = 0;
+  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { alpha = &s->gmod.ch[s->gmod.nch - m.num_extra + i]; alpha_bits = m.ec[i].bits; break; }
+  /* write RGBA with orientation */
+  {
+    uint32_t ow = m.pub.xsize, oh = m.pub.ysize;
+    size_t bps = out_bits == 16 ? 2 : 1;
+    uint8_t *o = (uint8_t *)malloc((size_t)ow * oh * 4 * bps);
+    float maxv = out_bits == 16 ? 65535.0f : 255.0f;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        int ox = x, oy = y;
+        switch (m.orientation) {
+          case 2: ox = w - 1 - x; break;
+          case 3: ox = w - 1 - x; oy = h - 1 - y; break;
+          case 4: oy = h - 1 - y; break;
+          case 5: ox = y; oy = x; break;
+          case 6: ox = h - 1 - y; oy = x; break;
+          case 7: ox = h - 1 - y; oy = w - 1 - x; break;
+          case 8: ox = y; oy = w - 1 - x; break;
+        }
+        size_t si = (size_t)y * (size_t)w + (size_t)x, di = ((size_t)oy * ow + (size_t)ox) * 4;
+        float v[4];
+        for (int c = 0; c < 3; c++) v[c] = rgb[c][si];
+        v[3] = alpha ? (float)alpha->d[si] / (float)((1u << alpha_bits) - 1) : 1.0f;
+        for (int c = 0; c < 4; c++) {
+          float t = v[c];
+          t = t < 0 ? 0 : t > 1 ? 1 : t;   /* NaN -> 0 via first compare false... keep simple */
+          t = t * maxv;
+          if (out_bits == 8 && m.pub.xyb_encoded) t += kDither32[(oy & 31) * 32 + (ox & 31)];   /* libjxl 8-bit writer dither */
+          long q = lrintf(t);
+          if (out_bits == 16) ((uint16_t *)o)[di + (size_t)c] = (uint16_t)q; else o[di + (size_t)c] = (uint8_t)q;
+        }
+      }
+    *out = o; *out_size = (size_t)ow * oh * 4 * bps;
+  }
+  for (int c = 0; c < 3; c++) free(rgb[c]);
+  rc = 0;
+done:
+  free_state(s);
+  free(s);
+  if (owned) free(cs);
+  return rc;
+}
