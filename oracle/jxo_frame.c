@@ -1121,13 +1121,15 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
       size_t *phys = (size_t *)malloc(sizeof(size_t) * (size_t)nsec);
       for (int i = 0; i < nsec; i++) { phys[i] = base + acc; acc += sec_size[i]; }
       uint32_t *sz2 = (uint32_t *)malloc(4 * (size_t)nsec);
-      /* physical section i holds logical section perm[i] */
-      for (int i = 0; i < nsec; i++) { sec_off[perm[i]] = phys[i]; sz2[perm[i]] = sec_size[i]; }
+      /* logical section i lives at physical index perm[i] */
+      for (int i = 0; i < nsec; i++) { sec_off[i] = phys[perm[i]]; sz2[i] = sec_size[perm[i]]; }
       memcpy(sec_size, sz2, 4 * (size_t)nsec);
       free(sz2); free(phys); free(perm);
     } else for (int i = 0; i < nsec; i++) { sec_off[i] = base + acc; acc += sec_size[i]; }
     if (base + acc > csn || br.err) { free(sec_size); free(sec_off); jxo_set_error("truncated file (TOC exceeds input)"); goto done; }
   }
+  if (jxo_debug) { fprintf(stderr, "frame: enc=%d flags=%llx passes=%d groups=%d lfg=%d nsec=%d gab=%d epf=%d xqm=%d bqm=%d\n", f->encoding, (unsigned long long)f->flags, f->num_passes, f->num_groups, f->num_lf_groups, nsec, f->gab, f->epf_iters, f->x_qm, f->b_qm);
+    for (int i = 0; i < nsec && i < 12; i++) fprintf(stderr, "  sec %d off %zu size %u\n", i, sec_off[i], sec_size[i]); }
   /* state */
   s->xb = (f->width + 7) / 8; s->yb = (f->height + 7) / 8;
   s->pw = s->xb * 8; s->ph = s->yb * 8;

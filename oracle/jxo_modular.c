@@ -283,7 +283,7 @@ static int meta_apply(jxo_modimg *img, const jxo_transform *t) {
   }
   if (t->id == JXO_TR_PALETTE) {
     int b = t->begin_c, e = t->begin_c + t->num_c - 1;
-    if (e >= img->nch) JXO_FAIL("palette: channel range");
+    if (e >= img->nch) JXO_FAIL("palette: channel range begin_c=%d num_c=%d nch=%d nbcol=%d nbdelta=%d pred=%d", t->begin_c, t->num_c, img->nch, t->nb_colours, t->nb_deltas, t->d_pred);
     if (b >= img->nb_meta) img->nb_meta += 1; else img->nb_meta += 2 - t->num_c;
     int hs = img->ch[b].hshift, vs = img->ch[b].vshift;
     (void)hs; (void)vs;
