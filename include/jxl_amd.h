@@ -1,0 +1,88 @@
+/* include/jxl_amd.h — C-ABI of the MI355X-native JPEG XL decode path (libjxlamd.so).
+ *
+ * Drop-in boundary: these entry points are what the reference's decode driver would bind instead of libjxl:
+ *   jxlamd_decode        <->  DecodeJpegXlOneShot  (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:36-176,
+ *                                                   declaration interop/JxlDecoding.h:54-63)
+ *   jxlamd_basic_info    <->  DecodeBasicInfo      (interop/JxlDecoding.cpp:178-225, JxlDecoding.h:65)
+ * i.e. the libjxl calls JxlDecoderCreate/SetInput/ProcessInput/GetBasicInfo/GetColorAsEncodedProfile/
+ * ImageOutBufferSize/SetImageOutBuffer (jxlcoder/src/main/cpp/jxl/decode.h:441-1018) collapsed into one call.
+ * Plain pointers and sizes only; no C++/torch types.  See INTEGRATION.md for the reference-side stub.
+ */
+#ifndef JXL_AMD_H_
+#define JXL_AMD_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jxlamd_decoder jxlamd_decoder;
+
+/* Mirrors the JxlBasicInfo / JxlColorEncoding fields the reference driver reads
+ * (interop/JxlDecoding.cpp:81-144; jxl/codestream_header.h:95-261; jxl/color_encoding.h:153). */
+typedef struct {
+  uint32_t xsize, ysize;            /* oriented output size */
+  uint32_t bits_per_sample;         /* of the ORIGINAL image */
+  uint32_t exponent_bits_per_sample;
+  uint32_t num_color_channels, num_extra_channels, alpha_bits, alpha_premultiplied;
+  uint32_t orientation;             /* as libjxl reports after re-orienting: 1 (JXL_ORIENT_IDENTITY) */
+  uint32_t have_animation, uses_original_profile;
+  float intensity_target;           /* 255 when the stream says <= 0 (JxlDecoding.cpp:91) */
+  /* colour encoding of the data profile (JxlColorEncoding enums) */
+  uint32_t have_encoded_profile;
+  uint32_t color_space, white_point, primaries, transfer_function, rendering_intent;
+  double gamma;
+  /* what DecodeJpegXlOneShot derives */
+  uint32_t out_bits;                /* 8 or 16: bitDepth out-param */
+  uint32_t prefer_encoding;         /* JxlDecoding.cpp:126-133 (operator-precedence quirk reproduced) */
+  uint32_t has_alpha_in_origin;     /* num_extra_channels > 0 && alpha_bits > 0 (JxlDecoding.cpp:111) */
+} jxlamd_info;
+
+enum {
+  JXLAMD_OK = 0,
+  JXLAMD_ERR_INVALID = -1,       /* corrupt / truncated stream: the reference returns false -> InvalidJXLException */
+  JXLAMD_ERR_UNSUPPORTED = -2,   /* valid JPEG XL feature this build does not decode on the GPU (message says which) */
+  JXLAMD_ERR_SIZE = -3,          /* w*h*4*bytes >= INT32_MAX: the reference throws InvalidImageSizeException (JxlDecoding.cpp:103-109) */
+  JXLAMD_ERR_DEVICE = -4,        /* HIP failure / no GPU: never falls back to a CPU path */
+  JXLAMD_ERR_BUFFER = -5         /* output buffer too small */
+};
+
+/* flags for jxlamd_decode */
+#define JXLAMD_ALLOW_16BIT 1u     /* "allowedFloats": bits_per_sample > 8 -> RGBA u16 (JxlDecoding.cpp:92-101) */
+#define JXLAMD_OUT_DEVICE 2u      /* `out` is a device pointer (HBM-resident output, no D2H) */
+#define JXLAMD_NO_SIZE_GUARD 4u   /* skip the INT32_MAX guard (BASELINE config 4: 32768^2 below the Bitmap layer) */
+#define JXLAMD_IN_DEVICE 8u       /* `jxl_dev` passed to jxlamd_decode_resident holds the same bytes in HBM */
+
+jxlamd_decoder *jxlamd_decoder_create(int device);        /* NULL if the HIP device cannot be opened */
+void jxlamd_decoder_destroy(jxlamd_decoder *dec);
+const char *jxlamd_last_error(const jxlamd_decoder *dec);  /* dec may be NULL: last error of this thread's stateless calls */
+
+/* DecodeBasicInfo: header-only parse, host only. */
+int jxlamd_basic_info(const uint8_t *jxl, size_t size, jxlamd_info *info);
+
+/* Bytes needed for the RGBA output of this file under `flags`. */
+int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *bytes);
+
+/* DecodeJpegXlOneShot: RGBA interleaved, top-down, no row padding; u8, or u16 when JXLAMD_ALLOW_16BIT and the
+ * image has more than 8 bits.  `out` is host memory unless JXLAMD_OUT_DEVICE. */
+int jxlamd_decode(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t out_capacity,
+                  jxlamd_info *info);
+
+/* Same, with the compressed bytes ALSO resident in device memory at `jxl_dev` (skips the H2D of the codestream;
+ * the host copy is still needed for header/TOC parsing). */
+int jxlamd_decode_resident(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags,
+                           void *out, size_t out_capacity, jxlamd_info *info);
+
+/* Batch extension (BASELINE configs 3/5): n independent files, outputs[i] sized by jxlamd_output_size.
+ * Equivalent to n jxlamd_decode calls; returns the first failing status. */
+int jxlamd_decode_batch(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes, uint32_t flags,
+                        void *const *outs, const size_t *out_capacities, jxlamd_info *infos);
+
+/* Timing of the last decode in milliseconds (HIP events on the decoder's stream):
+ * [0]=LF groups, [1]=pass groups, [2]=reconstruction, [3]=filters+write, [4]=total device time. */
+int jxlamd_last_timing(const jxlamd_decoder *dec, float ms[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's decode API.
+
+Reference surface (Kotlin -> JNI -> C++):
+  JxlCoder.decode / decodeSampled      jxlcoder/src/main/java/com/awxkee/jxlcoder/JxlCoder.kt:50-105
+  decodeSampledImageImpl               jxlcoder/src/main/cpp/JniDecoding.cpp:45-331
+  DecodeJpegXlOneShot / DecodeBasicInfo jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:36-225
+Same names, argument meaning and error behaviour; Android Bitmaps become numpy arrays (host) or torch tensors
+(device-resident).  All pixel work happens in libjxlamd.so on the GPU; there is NO CPU fallback: importing works
+without a GPU (header parsing is host-only) but every decode raises if the HIP device or the library is missing.
+"""
+import ctypes as C
+import enum
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjxlamd.so")
+_lib = None
+
+
+class InvalidJXLException(Exception):
+    """kt/InvalidJXLException — DecodeJpegXlOneShot returned false (JniDecoding.cpp:78)."""
+
+
+class InvalidImageSizeException(Exception):
+    """interop/JxlDecoding.h:38-52 — output >= INT32_MAX bytes."""
+
+
+class UnsupportedJXLFeature(Exception):
+    """Valid JPEG XL that this build does not decode on the GPU yet (never silently routed to a CPU path)."""
+
+
+class PreferredColorConfig(enum.IntEnum):      # kt/PreferredColorConfig.kt, cpp/Support.h:37-44
+    DEFAULT = 1
+    RGBA_8888 = 2
+    RGBA_F16 = 3
+    RGB_565 = 4
+    RGBA_1010102 = 5
+    HARDWARE = 6
+
+
+class ScaleMode(enum.IntEnum):                 # kt/ScaleMode.kt, cpp/SizeScaler.h:36-40
+    FIT = 1
+    FILL = 2
+    RESIZE = 3
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("xsize", "ysize", "bits_per_sample", "exponent_bits_per_sample",
+                                          "num_color_channels", "num_extra_channels", "alpha_bits", "alpha_premultiplied",
+                                          "orientation", "have_animation", "uses_original_profile")] + \
+               [("intensity_target", C.c_float)] + \
+               [(n, C.c_uint32) for n in ("have_encoded_profile", "color_space", "white_point", "primaries",
+                                          "transfer_function", "rendering_intent")] + \
+               [("gamma", C.c_double)] + \
+               [(n, C.c_uint32) for n in ("out_bits", "prefer_encoding", "has_alpha_in_origin")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
+_ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
+
+SOURCES = ["kernels.hip", "decoder.hip", "host_parse.cpp", "host_bits.cpp"]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    src = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + \
+           [os.path.join(os.path.dirname(_HERE), "include", "jxl_amd.h")]
+    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return _LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", _LIB_PATH] + src
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run jxl_coder_amd.build() (python -c 'import __graft_entry__ as g; g.build()'). "
+                               "There is no CPU fallback for the decode path.")
+        L = C.CDLL(_LIB_PATH)
+        L.jxlamd_decoder_create.restype = C.c_void_p
+        L.jxlamd_decoder_create.argtypes = [C.c_int]
+        L.jxlamd_decoder_destroy.argtypes = [C.c_void_p]
+        L.jxlamd_last_error.restype = C.c_char_p
+        L.jxlamd_last_error.argtypes = [C.c_void_p]
+        L.jxlamd_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_output_size.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
+        L.jxlamd_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 5)]
+        _lib = L
+    return _lib
+
+
+def _raise(rc, dec):
+    msg = lib().jxlamd_last_error(dec).decode(errors="replace")
+    raise _ERR.get(rc, RuntimeError)(msg)
+
+
+class JxlDecoder:
+    """One decoder context = one HIP device + stream + reusable HBM work buffers (the reference creates a libjxl
+    decoder + thread-pool runner per call, interop/JxlDecoding.cpp:46-48; here the context is reused)."""
+
+    def __init__(self, device=0):
+        self._h = lib().jxlamd_decoder_create(device)
+        if not self._h:
+            raise RuntimeError(lib().jxlamd_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().jxlamd_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_one_shot(self, data: bytes, allowed_floats=True, size_guard=True):
+        """DecodeJpegXlOneShot (interop/JxlDecoding.cpp:36-176): -> (pixels [h,w,4] u8|u16, info dict)."""
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | (0 if size_guard else JXLAMD_NO_SIZE_GUARD)
+        n = C.c_size_t()
+        rc = lib().jxlamd_output_size(data, len(data), flags, C.byref(n))
+        if rc:
+            _raise(rc, None)
+        out = np.empty(n.value, np.uint8)
+        info = Info()
+        rc = lib().jxlamd_decode(self._h, data, len(data), flags, out.ctypes.data, out.nbytes, C.byref(info))
+        if rc:
+            _raise(rc, self._h)
+        dt = np.uint16 if info.out_bits == 16 else np.uint8
+        return out.view(dt).reshape(info.ysize, info.xsize, 4), info.as_dict()
+
+    def decode_to_device(self, data: bytes, out_ptr: int, out_capacity: int, data_dev_ptr: int = 0, allowed_floats=True,
+                         size_guard=True):
+        """HBM-resident decode: output (and optionally the compressed bytes) stay in device memory."""
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE | (0 if size_guard else JXLAMD_NO_SIZE_GUARD)
+        info = Info()
+        if data_dev_ptr:
+            rc = lib().jxlamd_decode_resident(self._h, data, len(data), data_dev_ptr, flags, out_ptr, out_capacity, C.byref(info))
+        else:
+            rc = lib().jxlamd_decode(self._h, data, len(data), flags, out_ptr, out_capacity, C.byref(info))
+        if rc:
+            _raise(rc, self._h)
+        return info.as_dict()
+
+    def last_timing(self):
+        t = (C.c_float * 5)()
+        lib().jxlamd_last_timing(self._h, C.byref(t))
+        return dict(zip(("lf_groups_ms", "pass_groups_ms", "recon_ms", "filters_write_ms", "device_total_ms"), list(t)))
+
+
+def _check_preconditions(cfg, scale_mode):
+    """checkDecodePreconditions (cpp/Support.cpp:35-92): reject ints outside the enums."""
+    if int(cfg) < 1 or int(cfg) > 6:
+        raise ValueError("Invalid Color Config")
+    if int(scale_mode) < 1 or int(scale_mode) > 3:
+        raise ValueError("Invalid Scale Mode was passed")
+
+
+class JxlCoder:
+    """object JxlCoder (kt/JxlCoder.kt:39-268), decode half."""
+    _default = None
+
+    @classmethod
+    def _decoder(cls):
+        if cls._default is None:
+            cls._default = JxlDecoder(int(os.environ.get("LOCAL_RANK", "0")))
+        return cls._default
+
+    @staticmethod
+    def isJXL(data: bytes) -> bool:              # kt/JxlCoder.kt:244-267
+        return data[:2] == b"\xff\x0a" or data[:12] == bytes([0, 0, 0, 0xC, 0x4A, 0x58, 0x4C, 0x20, 0xD, 0xA, 0x87, 0xA])
+
+    @staticmethod
+    def getSize(data: bytes):                    # kt/JxlCoder.kt:191 -> DecodeBasicInfo
+        info = Info()
+        rc = lib().jxlamd_basic_info(data, len(data), C.byref(info))
+        if rc:
+            raise InvalidJXLException(lib().jxlamd_last_error(None).decode())
+        return info.xsize, info.ysize
+
+    @classmethod
+    def decode(cls, data: bytes, preferredColorConfig=PreferredColorConfig.DEFAULT, scaleMode=ScaleMode.FIT):
+        """kt/JxlCoder.kt:50-63: decodeSampledImpl(bytes, -1, -1, cfg, mode, CATMULL_ROM)."""
+        return cls.decodeSampled(data, -1, -1, preferredColorConfig, scaleMode)
+
+    @classmethod
+    def decodeSampled(cls, data: bytes, width: int, height: int, preferredColorConfig=PreferredColorConfig.DEFAULT,
+                      scaleMode=ScaleMode.FIT, jxlResizeFilter=6):
+        _check_preconditions(preferredColorConfig, scaleMode)
+        use_sampler = (width > 0 or height > 0) and (width != 0 and height != 0)      # JniDecoding.cpp:116-117
+        if use_sampler:
+            raise UnsupportedJXLFeature("decodeSampled resampling (weaver / pic-scale) is a 'next' row, SURVEY.md §8f")
+        px, info = cls._decoder().decode_one_shot(data, allowed_floats=True)
+        if info["has_alpha_in_origin"] and not info["alpha_premultiplied"]:
+            pass   # ReformatColorConfig premultiply (cpp/ReformatBitmap.cpp:65-77): alpha images are not on the device path yet
+        return px

@@ -1,0 +1,76 @@
+// jxl_coder_amd/csrc/dev_bodies.h — per-workgroup bodies of the decode kernels, written against
+// (tid, nthreads, sync) so that kernels.hip instantiates them with __syncthreads() and the CPU test harness
+// (tests/emul, test-only) runs each workgroup as one serial "thread" (nthreads = 1, sync = no-op).
+#pragma once
+#include "dev_recon.h"
+
+namespace jxlamd {
+
+struct DevAux {
+  uint64_t *lf_end_bits;     // [num_lf_groups]: bits consumed by each LfGroup section (single-section frames need it)
+};
+
+// ---- LfGroup: one workgroup (one wave) per 2048x2048 LF group
+template <class Sync>
+JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  const DevTreeNode *gtree = (const DevTreeNode *)(B.tables + F.tree_off);
+  const int ncache = F.tree_count < kTreeLds ? F.tree_count : kTreeLds;
+  for (int i = tid; i < ncache; i += nthreads) S.tree[i] = gtree[i];
+  sync();
+  if (tid == 0) {
+    uint32_t err = lf_group_serial(B, S, g, A.lf_end_bits);
+    if (err) *B.err |= err;   // benign race: any set bit fails the frame
+  }
+  sync();
+  lf_group_epilogue(B, g, tid, nthreads);
+}
+
+// ---- PassGroup: one workgroup (one wave) per 256x256 group; passes are sequential inside
+template <class Sync>
+JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  if (tid == 0) {
+    for (int p = 0; p < F.num_passes; p++) {
+      uint32_t err = pass_group_serial(B, S, p, g);
+      if (err) { *B.err |= err; break; }
+    }
+  }
+  sync();
+  (void)nthreads;
+}
+
+// ---- varblock reconstruction; LDS: S[3*n] + T[n]
+template <class Sync>
+JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, bool want_big,
+                              int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  if (!B.first[o]) return;                       // uniform across the workgroup
+  const int st = B.strategy[o];
+  const int cx = kCoveredX[st], cy = kCoveredY[st];
+  const int n = cx * cy * 64;
+  const bool big = n > 256;
+  if (big != want_big) return;
+  if (n > 4096) { if (tid == 0) *B.err |= kErrUnsupportedBlock; return; }   // DCT128+/256: not emitted by libjxl's encoder
+  recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
+  sync();
+  recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads);
+  sync();
+  float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};
+  const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
+  if (strategy_is_special(st)) {
+    for (int c = tid; c < 3; c += nthreads) recon_special(stat, ST, st, S + c * n, dst[c] + po, F.pw);
+    return;
+  }
+  const int R = cy * 8, C = cx * 8;
+  for (int c = 0; c < 3; c++) {
+    recon_idct_pass1(stat, ST, S + c * n, T, R, C, tid, nthreads);
+    sync();
+    recon_idct_pass2(stat, ST, T, dst[c] + po, F.pw, R, C, tid, nthreads);
+    sync();
+  }
+}
+
+}  // namespace jxlamd

@@ -1,0 +1,136 @@
+// jxl_coder_amd/csrc/dev_entropy.h — device-side bit reader and ANS / prefix symbol reader.
+// One entropy-coded stream is inherently serial (rANS state + bit position), so every stream is decoded by
+// ONE lane; parallelism comes from running one wavefront per stream (135 PassGroup streams in a 4K frame,
+// 34 560 in a 256-frame batch).  Replaces libjxl's ANSSymbolReader that the reference reaches through
+// JxlDecoderProcessInput (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75).
+//
+// The functions are written against plain pointers; JXL_DEV expands to __device__ under hipcc.  The test
+// suite compiles the very same header with g++ (tests/emul) to check the bitstream logic without a GPU —
+// that build is test-only and never part of the shipped library.
+#pragma once
+#include <stdint.h>
+#include "dev_types.h"
+
+#ifdef __HIPCC__
+#define JXL_DEV __device__ __forceinline__
+#else
+#define JXL_DEV static inline
+#endif
+
+namespace jxlamd {
+
+// ------------------------------------------------------------------ bit reader (LSB first)
+struct DevBits {
+  const uint32_t *next;     // next aligned word to fetch
+  uint64_t buf;             // valid bits in the low `n` positions
+  uint32_t ahead;           // word fetched one refill early (hides the load latency of the serial lane)
+  int32_t n;
+  uint64_t consumed;        // bits consumed since the section start
+};
+
+JXL_DEV void bits_init(DevBits &b, const uint8_t *base, uint64_t byte_off) {
+  const uint8_t *p = base + byte_off;
+  uint64_t mis = (uint64_t)(uintptr_t)p & 3;
+  b.next = (const uint32_t *)(p - mis);
+  b.buf = (uint64_t)b.next[0] | ((uint64_t)b.next[1] << 32);
+  b.ahead = b.next[2];
+  b.next += 3;
+  b.buf >>= 8 * mis;
+  b.n = 64 - 8 * (int32_t)mis;
+  b.consumed = 0;
+}
+JXL_DEV void bits_refill(DevBits &b) {     // guarantees >= 32 valid bits
+  if (b.n <= 32) {
+    b.buf |= (uint64_t)b.ahead << b.n;
+    b.n += 32;
+    b.ahead = *b.next++;
+  }
+}
+JXL_DEV uint32_t bits_peek(DevBits &b, int n) {   // n <= 32
+  bits_refill(b);
+  return (uint32_t)(b.buf & ((1ull << n) - 1));
+}
+JXL_DEV void bits_skip(DevBits &b, int n) { b.buf >>= n; b.n -= n; b.consumed += (uint64_t)n; }
+JXL_DEV uint32_t bits_read(DevBits &b, int n) {   // n <= 32
+  if (n == 0) return 0;
+  uint32_t v = bits_peek(b, n);
+  bits_skip(b, n);
+  return v;
+}
+JXL_DEV uint32_t bits_u32(DevBits &b, int b0, uint32_t o0, int b1, uint32_t o1, int b2, uint32_t o2, int b3, uint32_t o3) {
+  uint32_t sel = bits_read(b, 2);
+  int nb = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
+  uint32_t o = sel == 0 ? o0 : sel == 1 ? o1 : sel == 2 ? o2 : o3;
+  return nb < 0 ? o : bits_read(b, nb) + o;
+}
+JXL_DEV int32_t unpack_signed(uint32_t u) { return (int32_t)((u >> 1) ^ (0u - (u & 1))); }
+
+// ------------------------------------------------------------------ symbol reader
+struct DevECView {            // resolved pointers for one entropy code
+  const uint8_t *ctx_map;
+  const uint32_t *cfg;
+  const DevAlias *alias;
+  const DevPrefix *prefix;
+  const uint16_t *pool;
+  int32_t use_prefix, log_alpha;
+};
+
+JXL_DEV DevECView ec_view(const uint8_t *tables, const DevEC &e) {
+  DevECView v;
+  v.ctx_map = tables + e.ctx_map_off;
+  v.cfg = (const uint32_t *)(tables + e.cfg_off);
+  v.alias = (const DevAlias *)(tables + e.alias_off);
+  v.prefix = (const DevPrefix *)(tables + e.prefix_off);
+  v.pool = (const uint16_t *)(tables + e.pool_off);
+  v.use_prefix = e.use_prefix;
+  v.log_alpha = e.log_alpha;
+  return v;
+}
+
+JXL_DEV uint32_t ans_init(const DevECView &v, DevBits &b) { return v.use_prefix ? 0x130000u : bits_read(b, 32); }
+
+JXL_DEV uint32_t ec_token(const DevECView &v, DevBits &b, uint32_t &state, uint32_t cluster) {
+  if (v.use_prefix) {
+    const DevPrefix &p = v.prefix[cluster];
+    if (p.single >= 0) return (uint32_t)p.single;
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; len++) {
+      code |= (int)bits_read(b, 1);
+      int count = p.cnt[len];
+      if (code - first < count) return v.pool[p.sorted_off + (uint32_t)(index + code - first)];
+      index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return 0;
+  }
+  const int lb = 12 - v.log_alpha;
+  uint32_t res = state & 0xfff;
+  uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
+  DevAlias e = v.alias[(cluster << v.log_alpha) + i];
+  bool right = pos >= e.cutoff;
+  uint32_t sym = right ? e.right : i;
+  uint32_t off = right ? (uint32_t)e.off1 + pos : pos;
+  uint32_t freq = right ? e.freq1 : e.freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | bits_read(b, 16);
+  return sym;
+}
+
+JXL_DEV uint32_t ec_hybrid(DevBits &b, uint32_t cfg, uint32_t token) {
+  uint32_t split_exp = cfg & 0xff, msb = (cfg >> 8) & 0xff, lsb = (cfg >> 16) & 0xff;
+  uint32_t split = 1u << split_exp;
+  if (token < split) return token;
+  uint32_t nbits = split_exp - (msb + lsb) + ((token - split) >> (msb + lsb));
+  if (nbits > 31) nbits = 31;   // corrupt stream; the final-state check flags it
+  uint32_t low = token & ((1u << lsb) - 1);
+  token >>= lsb;
+  uint32_t bits = bits_read(b, (int)nbits);
+  return (((((1u << msb) | (token & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+}
+
+JXL_DEV uint32_t ec_read(const DevECView &v, DevBits &b, uint32_t &state, uint32_t ctx) {
+  uint32_t cluster = v.ctx_map[ctx];
+  uint32_t token = ec_token(v, b, state, cluster);
+  return ec_hybrid(b, v.cfg[cluster], token);
+}
+
+}  // namespace jxlamd

@@ -1,0 +1,235 @@
+// jxl_coder_amd/csrc/dev_modular.h — device-side Modular sub-bitstream decoder (ISO/IEC 18181-1 Annex H):
+// MA-tree context modelling, the 14 predictors and the weighted (self-correcting) predictor.
+// Used for the LF image and HF metadata of VarDCT frames (28 % of the bits of a 4K q90 frame), i.e. what
+// libjxl's ModularFrameDecoder does under JxlDecoderProcessInput (reference call site
+// jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75).  Integer-exact by construction.
+//
+// Execution model: one wavefront per stream, lane 0 walks the stream; the previous two rows, the WP error
+// state, the property vector and the head of the MA tree live in LDS so that the serial lane never waits on
+// HBM for its neighbourhood.
+#pragma once
+#include "dev_entropy.h"
+
+namespace jxlamd {
+
+constexpr int kModMaxW = 256;         // widest channel a device stream may carry (LF group = 256 LF samples; 256-px lossless groups)
+constexpr int kWpMaxW = 256;
+constexpr int kTreeLds = 448;         // MA-tree nodes cached in LDS
+
+struct DevModScratch {                // per-wave working memory (LDS on the GPU)
+  int32_t rows[3][kModMaxW + 8];      // cur / prev / prevprev rows
+  uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
+  int32_t wp_err[2 * (kWpMaxW + 2)];
+  int32_t props[32];
+  DevTreeNode tree[kTreeLds];
+};
+
+struct DevChanOut { int32_t *d; int32_t w, h; };
+
+struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
+
+JXL_DEV int32_t floor_log2_u32(uint32_t x) { return 31 - __builtin_clz(x); }
+JXL_DEV int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
+
+struct WPState {
+  int64_t prediction[4];
+  int64_t pred;
+};
+
+JXL_DEV uint32_t wp_error_weight(uint32_t x, uint32_t maxweight) {
+  int shift = floor_log2_u32(x + 1) - 5;
+  if (shift < 0) shift = 0;
+  uint32_t d = (1u << 24) / ((x >> shift) + 1);
+  return 4 + ((maxweight * d) >> shift);
+}
+
+JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x, int y, int xs, int64_t N, int64_t W,
+                           int64_t NE, int64_t NW, int64_t NN, int32_t &max_err) {
+  int cur_row = (y & 1) ? 0 : (xs + 2);
+  int prev_row = (y & 1) ? (xs + 2) : 0;
+  int pos_N = prev_row + x;
+  int pos_NE = x < xs - 1 ? pos_N + 1 : pos_N;
+  int pos_NW = x > 0 ? pos_N - 1 : pos_N;
+  uint32_t w[4];
+  for (int i = 0; i < 4; i++) {
+    uint32_t e = S.wp_pred_err[i][pos_N] + S.wp_pred_err[i][pos_NE] + S.wp_pred_err[i][pos_NW];
+    w[i] = wp_error_weight(e, (uint32_t)h.w[i]);
+  }
+  N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
+  int64_t teW = x == 0 ? 0 : S.wp_err[cur_row + x - 1];
+  int64_t teN = S.wp_err[pos_N], teNW = S.wp_err[pos_NW], teNE = S.wp_err[pos_NE];
+  int64_t sumWN = teN + teW;
+  int64_t p = teW;
+  if (iabs64(teN) > iabs64(p)) p = teN;
+  if (iabs64(teNW) > iabs64(p)) p = teNW;
+  if (iabs64(teNE) > iabs64(p)) p = teNE;
+  max_err = (int32_t)p;
+  st.prediction[0] = W + NE - N;
+  st.prediction[1] = N - (((sumWN + teNE) * h.p1) >> 5);
+  st.prediction[2] = W - (((sumWN + teNW) * h.p2) >> 5);
+  st.prediction[3] = N - ((teNW * h.p3a + teN * h.p3b + teNE * h.p3c + (NN - N) * h.p3d + (NW - W) * h.p3e) >> 5);
+  uint32_t wsum = w[0] + w[1] + w[2] + w[3];
+  int lw = floor_log2_u32(wsum);
+  wsum = 0;
+  for (int i = 0; i < 4; i++) { w[i] >>= lw - 4; wsum += w[i]; }
+  int64_t sum = (int64_t)(wsum >> 1) - 1;
+  for (int i = 0; i < 4; i++) sum += st.prediction[i] * (int64_t)w[i];
+  st.pred = (sum * (int64_t)((1u << 24) / wsum)) >> 24;
+  if (((teN ^ teW) | (teN ^ teNW)) > 0) return (st.pred + 3) >> 3;
+  int64_t mx = W > NE ? W : NE; if (N > mx) mx = N;
+  int64_t mn = W < NE ? W : NE; if (N < mn) mn = N;
+  if (st.pred > mx) st.pred = mx;
+  if (st.pred < mn) st.pred = mn;
+  return (st.pred + 3) >> 3;
+}
+
+JXL_DEV void wp_update(DevModScratch &S, const WPState &st, int64_t val, int x, int y, int xs) {
+  int cur_row = (y & 1) ? 0 : (xs + 2);
+  int prev_row = (y & 1) ? (xs + 2) : 0;
+  val *= 8;
+  S.wp_err[cur_row + x] = (int32_t)(st.pred - val);
+  for (int i = 0; i < 4; i++) {
+    uint32_t err = (uint32_t)((iabs64(st.prediction[i] - val) + 3) >> 3);
+    S.wp_pred_err[i][cur_row + x] = err;
+    S.wp_pred_err[i][prev_row + x + 1] += err;
+  }
+}
+
+JXL_DEV int64_t clamped_gradient(int64_t n, int64_t w, int64_t l) {
+  int64_t m = n < w ? n : w, M = n < w ? w : n;
+  int64_t g = n + w - l;
+  return g < m ? m : g > M ? M : g;
+}
+
+JXL_DEV int64_t predict_plain(int predictor, int64_t W, int64_t N, int64_t NW, int64_t NE, int64_t NN, int64_t WW,
+                              int64_t NEE, int64_t wp) {
+  switch (predictor) {
+    case 0: return 0;
+    case 1: return W;
+    case 2: return N;
+    case 3: return (W + N) / 2;
+    case 4: { int64_t p = W + N - NW; return iabs64(p - W) < iabs64(p - N) ? W : N; }
+    case 5: return clamped_gradient(N, W, NW);
+    case 6: return wp;
+    case 7: return NE;
+    case 8: return NW;
+    case 9: return WW;
+    case 10: return (W + NW) / 2;
+    case 11: return (N + NW) / 2;
+    case 12: return (N + NE) / 2;
+    case 13: return (6 * N - 2 * NN + 7 * W + WW + NEE + 3 * NE + 8) / 16;
+  }
+  return 0;
+}
+
+// Does the part of the MA tree reachable for this (channel, stream) use the weighted predictor (property 15 or
+// predictor 6), and which is the largest property it tests?  Properties 0 and 1 are static per channel, so the
+// unreachable branches are pruned exactly as libjxl's tree filtering does.
+struct TreeFacts { int uses_wp; int max_prop; };
+JXL_DEV TreeFacts tree_facts(const DevTreeNode *tree, int count, int chan, int stream) {
+  TreeFacts f; f.uses_wp = 0; f.max_prop = 0;
+  int stack[64]; int sp = 0;
+  stack[sp++] = 0;
+  int guard = 0;
+  while (sp > 0 && guard++ < 4 * count + 8) {
+    const DevTreeNode nd = tree[stack[--sp]];
+    if (nd.prop < 0) { if (nd.lchild == 6) f.uses_wp = 1; continue; }
+    if (nd.prop == 0 || nd.prop == 1) {
+      int v = nd.prop == 0 ? chan : stream;
+      stack[sp++] = v > nd.splitval ? nd.lchild : nd.rchild;
+      continue;
+    }
+    if (nd.prop == 15) f.uses_wp = 1;
+    if (nd.prop > f.max_prop) f.max_prop = nd.prop;
+    if (sp + 2 > 64) { f.uses_wp = 1; f.max_prop = 99; break; }   // pathological depth: take the safe answer
+    stack[sp++] = nd.lchild; stack[sp++] = nd.rchild;
+  }
+  return f;
+}
+
+// Decode the channels of one modular stream (lane 0 only).  `chans[i].d` are dense w*h int32 planes in HBM.
+// Channels up to kModMaxW wide keep their three live rows in LDS; wider ones (the count x 2 block-info channel
+// of HF metadata) read their neighbourhood back from the plane itself.  Returns 0 or error bits.
+JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
+                                         int tree_count, const DevWP &wp, DevModScratch &S,
+                                         const DevChanOut *chans, int nch, int stream_id) {
+  int32_t *props = S.props;
+  props[1] = stream_id;
+  for (int ci = 0; ci < nch; ci++) {
+    const DevChanOut &c = chans[ci];
+    const int w = c.w, h = c.h;
+    if (w == 0 || h == 0) continue;
+    const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id);
+    if (tf.max_prop > 15) return kErrUnsupportedTransform;   // previous-channel properties: not on device yet
+    const bool wide = w > kModMaxW;
+    if (wide && tf.uses_wp) return kErrUnsupportedTransform;
+    props[0] = ci;
+    WPState wst;
+    if (tf.uses_wp) {
+      for (int i = 0; i < 2 * (w + 2); i++) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
+    }
+    for (int y = 0; y < h; y++) {
+      int32_t *out = c.d + (size_t)y * (size_t)w;
+      int32_t *row = wide ? out : S.rows[y % 3];
+      const int32_t *rN = wide ? out - w : S.rows[(y + 2) % 3];
+      const int32_t *rNN = wide ? out - 2 * w : S.rows[(y + 1) % 3];
+      int64_t prev_prop9 = 0;
+      props[2] = y;
+      for (int x = 0; x < w; x++) {
+        int64_t W = x > 0 ? row[x - 1] : (y > 0 ? rN[x] : 0);
+        int64_t N = y > 0 ? rN[x] : W;
+        int64_t NW = (x > 0 && y > 0) ? rN[x - 1] : W;
+        int64_t NE = (x + 1 < w && y > 0) ? rN[x + 1] : N;
+        int64_t NN = y > 1 ? rNN[x] : N;
+        int64_t NEE = (x + 2 < w && y > 0) ? rN[x + 2] : NE;
+        int64_t WW = x > 1 ? row[x - 2] : W;
+        props[3] = x;
+        props[4] = (int32_t)iabs64(N);
+        props[5] = (int32_t)iabs64(W);
+        props[6] = (int32_t)N;
+        props[7] = (int32_t)W;
+        props[8] = (int32_t)(W - prev_prop9);
+        props[9] = (int32_t)(W + N - NW);
+        prev_prop9 = props[9];
+        props[10] = (int32_t)(W - NW);
+        props[11] = (int32_t)(NW - N);
+        props[12] = (int32_t)(N - NE);
+        props[13] = (int32_t)(N - NN);
+        props[14] = (int32_t)(W - WW);
+        int64_t wp_pred = 0;
+        if (tf.uses_wp) { int32_t me; wp_pred = wp_predict(S, wst, wp, x, y, w, N, W, NE, NW, NN, me); props[15] = me; }
+        else props[15] = 0;
+        const DevTreeNode *nd = &S.tree[0];
+        while (nd->prop >= 0) {
+          int idx = props[nd->prop] > nd->splitval ? nd->lchild : nd->rchild;
+          nd = idx < kTreeLds ? &S.tree[idx] : &gtree[idx];
+        }
+        int64_t guess = predict_plain(nd->lchild, W, N, NW, NE, NN, WW, NEE, wp_pred);
+        uint32_t u = ec_read(ev, b, state, (uint32_t)nd->splitval);
+        int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)nd->rchild + nd->offset + guess;
+        row[x] = (int32_t)val;
+        if (!wide) out[x] = (int32_t)val;
+        if (tf.uses_wp) wp_update(S, wst, val, x, y, w);
+      }
+    }
+  }
+  return 0;
+}
+
+// GroupHeader of a modular stream (H.2): use_global_tree, WP header, transforms.
+JXL_DEV uint32_t modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms) {
+  uint32_t err = 0;
+  if (!bits_read(b, 1)) err |= kErrTreeLocal;          // local MA tree: host-side feature, not on device
+  wp.p1 = 16; wp.p2 = 10; wp.p3a = 7; wp.p3b = 7; wp.p3c = 7; wp.p3d = 0; wp.p3e = 0;
+  wp.w[0] = 13; wp.w[1] = 12; wp.w[2] = 12; wp.w[3] = 12;
+  if (!bits_read(b, 1)) {
+    wp.p1 = (int)bits_read(b, 5); wp.p2 = (int)bits_read(b, 5);
+    wp.p3a = (int)bits_read(b, 5); wp.p3b = (int)bits_read(b, 5); wp.p3c = (int)bits_read(b, 5);
+    wp.p3d = (int)bits_read(b, 5); wp.p3e = (int)bits_read(b, 5);
+    for (int i = 0; i < 4; i++) wp.w[i] = (int)bits_read(b, 4);
+  }
+  nb_transforms = (int)bits_u32(b, -1, 0, -1, 1, 4, 2, 8, 18);
+  return err;
+}
+
+}  // namespace jxlamd

@@ -1,0 +1,108 @@
+// jxl_coder_amd/csrc/dev_types.h — plain-old-data layouts shared by the host parser (which packs them) and the
+// HIP kernels (which read them from HBM).  Everything a kernel needs for one frame lives in ONE byte blob
+// ("frame tables") + the codestream bytes + per-frame work buffers, so a frame costs two H2D copies.
+#pragma once
+#include <stdint.h>
+
+namespace jxlamd {
+
+// ---- entropy code (ISO/IEC 18181-1 Annex C) as the kernels see it
+struct DevAlias {            // 8 bytes per alias-table entry: ONE 64-bit load yields everything an rANS step needs
+  uint8_t cutoff;            // position within the bucket at which the "right" symbol starts (< bucket <= 128)
+  uint8_t right;             // right_value symbol
+  uint16_t off1;             // offsets1 added to pos for the right symbol
+  uint16_t freq0;            // frequency of the bucket's own symbol (index i)
+  uint16_t freq1;            // frequency of the right symbol
+};
+struct DevPrefix {           // canonical prefix code, decoded bit by bit (rare path: low-effort streams)
+  uint16_t cnt[16];
+  uint32_t sorted_off;       // into the u16 symbol pool
+  int32_t single;            // >=0: code has a single symbol, no bits read
+};
+struct DevEC {
+  uint32_t ctx_map_off;      // u8[num_ctx]           (byte offsets into the tables blob)
+  uint32_t cfg_off;          // u32[num_clusters]: split_exp | msb<<8 | lsb<<16
+  uint32_t alias_off;        // DevAlias[num_clusters << log_alpha]
+  uint32_t prefix_off;       // DevPrefix[num_clusters]
+  uint32_t pool_off;         // u16 pool for prefix symbols
+  int32_t num_ctx, num_clusters, use_prefix, log_alpha;
+};
+
+// ---- MA tree node (Annex H.4), 32 bytes
+struct DevTreeNode {
+  int32_t prop;              // -1: leaf
+  int32_t splitval;          // leaf: context id
+  int32_t lchild;            // leaf: predictor
+  int32_t rchild;            // leaf: multiplier
+  int32_t offset;            // leaf only
+  int32_t pad[3];
+};
+
+struct DevSection { uint32_t off, size; };   // byte range inside the codestream buffer
+
+// ---- per-frame parameters (host -> device, by value in the tables blob header)
+struct DevFrame {
+  // geometry
+  int32_t width, height;           // frame pixels
+  int32_t xb, yb;                  // 8x8 cells
+  int32_t pw, ph;                  // padded plane dims (xb*8, yb*8)
+  int32_t tiles_x, tiles_y;        // 64x64 colour tiles
+  int32_t xgroups, ygroups, num_groups;      // 256x256
+  int32_t xlfg, ylfg, num_lf_groups;         // 2048x2048
+  int32_t num_passes;
+  int32_t pass_shift[12];
+  // quantiser / LF
+  float lf_fac[3];                 // lf_dequant[c] * 65536/(global_scale*quant_lf)
+  float cfl_dc_x, cfl_dc_b;
+  float inv_global_scale;          // 65536/global_scale
+  float quant_scale;               // global_scale/65536
+  float dm[3];                     // x_dm, 1, b_dm multipliers
+  float base_x, base_b, inv_color_factor;
+  float quant_bias[4];
+  int32_t skip_lf_smoothing;
+  // block context
+  int32_t nb_lf_thr[3]; int32_t lf_thr[3][16];
+  int32_t nb_qf_thr; uint32_t qf_thr[16];
+  int32_t num_bctx;
+  uint32_t bctx_map_off;           // u8[]
+  int32_t num_presets;
+  // global MA tree + its code
+  int32_t tree_count;
+  uint32_t tree_off;               // DevTreeNode[]
+  DevEC tree_ec;
+  uint32_t single_lf_bit;          // single-section frames: bit offset of LfGroup 0 / of the PassGroup inside section 0
+  uint32_t single_pass_bit;
+  // HF
+  DevEC hf_ec[4];                  // per pass (up to 4 passes supported on device)
+  uint32_t order_off[4][13][3];    // u16/u32 orders: offset of u32 array in blob
+  // sections
+  uint32_t sec_off;                // DevSection[nsec]: [0]=LfGlobal, 1..=LfGroup, then HfGlobal, then PassGroups
+  int32_t nsec;
+  // loop filter
+  int32_t gab; float gab_w[3][2];
+  int32_t epf_iters; float epf_sharp[8], epf_chscale[3], epf_quant_mul, epf_pass0, epf_pass2, epf_border_sad;
+  // colour
+  float opsin_inv[9];              // already scaled by 255/intensity_target and target-primaries matrix
+  float opsin_bias[3], opsin_bias_cbrt[3];
+  int32_t transfer;                // 13 sRGB, 8 linear, 16 PQ, 1 bt709, -1 gamma
+  float gamma, intensity_target;
+  int32_t orientation;
+  int32_t out_w, out_h;            // oriented
+};
+
+// static (per-process) tables uploaded once: inverse quant weights, cosine bases, AFV basis, dither LUT
+struct DevStatic {
+  uint32_t qw_off[17][3];      // float[rows*cols] of 1/weight per quant table & channel (storage layout)
+  uint32_t cos_off[9];         // float[n*n], n = 1<<i: c_k cos((2i+1)k pi/2n), row k
+  uint32_t afv_off;            // float[16*16]
+  uint32_t dither_off;         // float[32*32]
+  uint32_t llf_off;            // float[6][32]: 1/(cos t cos 2t cos 4t), t = k pi/(16 N), N = 1<<i
+};
+
+// device error flags (bit set by kernels, checked by host after the frame)
+enum : uint32_t {
+  kErrBitstream = 1, kErrUnsupportedTransform = 2, kErrUnsupportedBlock = 4, kErrAnsFinal = 8, kErrLz77 = 16,
+  kErrTreeLocal = 32, kErrSqueeze = 64, kErrPalette = 128,
+};
+
+}  // namespace jxlamd

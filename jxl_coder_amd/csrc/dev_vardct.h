@@ -1,0 +1,239 @@
+// jxl_coder_amd/csrc/dev_vardct.h — device-side VarDCT section decoders:
+//   * LfGroup  (2048x2048 px): LF coefficients + HF metadata (CfL maps, block strategies, quant field, EPF
+//     sharpness) — two Modular streams — then varblock placement and LF dequantisation;
+//   * PassGroup (256x256 px): per-block nonzero counts and AC coefficients (ISO/IEC 18181-1 Annex C.8 / I).
+// These are the entropy-decode stages that libjxl runs per group under JxlDecoderProcessInput (reference call
+// site jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75).  One wavefront per section; lane 0 is the serial
+// bitstream walker, the whole wave does the data-parallel epilogues.
+#pragma once
+#include "dev_modular.h"
+#include "dev_tables.h"
+
+namespace jxlamd {
+
+struct DevBuffers {
+  const uint8_t *codestream;
+  const uint8_t *tables;        // blob; DevFrame at offset 0
+  uint8_t *strategy;            // per 8x8 cell: raw AcStrategy of the covering varblock (0xFF = unset)
+  uint8_t *first;               // per cell: 1 = top-left cell of its varblock
+  uint8_t *qfm1;                // per cell: quant field - 1
+  uint8_t *sharp;               // per cell: EPF sharpness 0..7
+  uint8_t *lf_idx;              // per cell: LF-threshold bucket for the block context
+  int8_t *xfromy, *bfromy;      // per 64x64 tile
+  float *lf[3];                 // dequantised LF (xb*yb)
+  float *lf_s[3];               // after adaptive smoothing
+  uint32_t *coef_off;           // per first-cell: offset (in coefficients) inside its group's pool
+  int32_t *coef[3];             // [num_groups][65536]
+  float *plane_a[3], *plane_b[3];
+  int32_t *lf_scratch;          // [num_lf_groups][kLfScratchInts]
+  uint32_t *err;
+  uint8_t *out;                 // RGBA8 / RGBA16
+};
+
+constexpr int kLfScratchInts = 6 * 65536 + 2048;
+
+JXL_DEV const DevFrame &frame_of(const DevBuffers &B) { return *(const DevFrame *)B.tables; }
+JXL_DEV int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
+
+// ------------------------------------------------------------------ LfGroup, serial part (lane 0)
+JXL_DEV uint32_t lf_group_serial(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
+  const DevFrame &F = frame_of(B);
+  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+  const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
+  // In a single-section frame the LfGroup follows LfGlobal in the same byte stream: the host stores the BIT
+  // offset where LfGroup 0 starts in secs[0].size's upper meaning — see host_parse (single_section_lf_bit).
+  DevBits b;
+  bits_init(b, B.codestream, sec.off);
+  if (F.nsec == 1) {   // skip LfGlobal bits parsed by the host
+    uint32_t skip = F.single_lf_bit;
+    while (skip >= 32) { bits_read(b, 32); skip -= 32; }
+    bits_read(b, (int)skip);
+  }
+  const int gx = g % F.xlfg, gy = g / F.xlfg;
+  const int bx0 = gx * 256, by0 = gy * 256;
+  const int bw = F.xb - bx0 < 256 ? F.xb - bx0 : 256, bh = F.yb - by0 < 256 ? F.yb - by0 : 256;
+  int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  const DevTreeNode *gtree = (const DevTreeNode *)(B.tables + F.tree_off);
+  DevECView ev = ec_view(B.tables, F.tree_ec);
+  uint32_t err = 0;
+  // --- LF coefficients: extra_precision u(2), Modular stream (channels Y, X, B)
+  uint32_t extra = bits_read(b, 2);
+  scr[kLfScratchInts - 1] = (int32_t)extra;
+  {
+    DevWP wp; int ntr;
+    err |= modular_read_header(b, wp, ntr);
+    if (ntr != 0) err |= kErrUnsupportedTransform;
+    if (err) return err;
+    uint32_t state = ans_init(ev, b);
+    DevChanOut ch[3];
+    for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = bw; ch[c].h = bh; }
+    err |= modular_decode_channels(ev, b, state, gtree, F.tree_count, wp, S, ch, 3, 1 + g);
+    if (state != 0x130000u) err |= kErrAnsFinal;
+    if (err) return err;
+  }
+  // --- HF metadata
+  const int nblocks = bw * bh;
+  const int count = 1 + (int)bits_read(b, ceil_log2u((uint32_t)nblocks));
+  if (count > nblocks) return kErrBitstream;
+  const int tw = (bw + 7) / 8, th = (bh + 7) / 8;
+  int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
+  {
+    DevWP wp; int ntr;
+    err |= modular_read_header(b, wp, ntr);
+    if (ntr != 0) err |= kErrUnsupportedTransform;
+    if (err) return err;
+    uint32_t state = ans_init(ev, b);
+    DevChanOut ch[4];
+    ch[0].d = m_x; ch[0].w = tw; ch[0].h = th;
+    ch[1].d = m_b; ch[1].w = tw; ch[1].h = th;
+    ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
+    ch[3].d = m_sharp; ch[3].w = bw; ch[3].h = bh;
+    err |= modular_decode_channels(ev, b, state, gtree, F.tree_count, wp, S, ch, 4, 1 + 2 * F.num_lf_groups + g);
+    if (state != 0x130000u) err |= kErrAnsFinal;
+    if (err) return err;
+  }
+  if (end_bits) end_bits[g] = b.consumed;
+  if (b.consumed > (uint64_t)sec.size * 8 + 64 && F.nsec != 1) return kErrBitstream;
+  // --- varblock placement: raster scan, next block goes to the first unoccupied cell
+  int num = 0;
+  for (int y = 0; y < bh; y++)
+    for (int x = 0; x < bw; x++) {
+      size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+      if (B.strategy[o] != 0xFF) continue;
+      if (num >= count) return kErrBitstream;
+      int st = m_blk[num], q = m_blk[count + num];
+      num++;
+      if (st < 0 || st > 26 || q < 0 || q > 255) return kErrBitstream;
+      int cx = kCoveredX[st], cy = kCoveredY[st];
+      if (x + cx > bw || y + cy > bh) return kErrBitstream;
+      if ((x & 31) + cx > 32 || (y & 31) + cy > 32) return kErrBitstream;   // must not straddle a 256x256 group
+      for (int iy = 0; iy < cy; iy++)
+        for (int ix = 0; ix < cx; ix++) {
+          size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
+          if (B.strategy[oo] != 0xFF) return kErrBitstream;
+          B.strategy[oo] = (uint8_t)st; B.first[oo] = 0; B.qfm1[oo] = (uint8_t)q;
+        }
+      B.first[o] = 1;
+    }
+  return 0;
+}
+
+// ------------------------------------------------------------------ LfGroup, parallel epilogue (all lanes)
+JXL_DEV void lf_group_epilogue(const DevBuffers &B, int g, int lane, int nlanes) {
+  const DevFrame &F = frame_of(B);
+  const int gx = g % F.xlfg, gy = g / F.xlfg;
+  const int bx0 = gx * 256, by0 = gy * 256;
+  const int bw = F.xb - bx0 < 256 ? F.xb - bx0 : 256, bh = F.yb - by0 < 256 ? F.yb - by0 : 256;
+  const int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  const float mul = 1.0f / (float)(1 << scr[kLfScratchInts - 1]);
+  const float fx = F.lf_fac[0] * mul, fy = F.lf_fac[1] * mul, fb = F.lf_fac[2] * mul;
+  const int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_sharp = m_b + 1024 + 2 * 65536;
+  for (int i = lane; i < bw * bh; i += nlanes) {
+    int y = i / bw, x = i - y * bw;
+    size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+    int32_t qy = scr[i], qx = scr[65536 + i], qb = scr[2 * 65536 + i];
+    float Y = (float)qy * fy;
+    B.lf[1][o] = Y;
+    B.lf[0][o] = (float)qx * fx + F.cfl_dc_x * Y;
+    B.lf[2][o] = (float)qb * fb + F.cfl_dc_b * Y;
+    int ix = 0, iy = 0, ib = 0;
+    for (int t = 0; t < F.nb_lf_thr[0]; t++) if (qx > F.lf_thr[0][t]) ix++;
+    for (int t = 0; t < F.nb_lf_thr[1]; t++) if (qy > F.lf_thr[1][t]) iy++;
+    for (int t = 0; t < F.nb_lf_thr[2]; t++) if (qb > F.lf_thr[2][t]) ib++;
+    int bucket = ix; bucket = bucket * (F.nb_lf_thr[2] + 1) + ib; bucket = bucket * (F.nb_lf_thr[1] + 1) + iy;
+    B.lf_idx[o] = (uint8_t)bucket;
+    int sh = m_sharp[i];
+    B.sharp[o] = (uint8_t)(sh < 0 ? 0 : sh > 7 ? 7 : sh);
+  }
+  const int tw = (bw + 7) / 8, th = (bh + 7) / 8;
+  for (int i = lane; i < tw * th; i += nlanes) {
+    int y = i / tw, x = i - y * tw;
+    size_t o = (size_t)(by0 / 8 + y) * (size_t)F.tiles_x + (size_t)(bx0 / 8 + x);
+    int vx = m_x[i], vb = m_b[i];
+    B.xfromy[o] = (int8_t)(vx < -128 ? -128 : vx > 127 ? 127 : vx);
+    B.bfromy[o] = (int8_t)(vb < -128 ? -128 : vb > 127 ? 127 : vb);
+  }
+}
+
+// ------------------------------------------------------------------ PassGroup (lane 0)
+struct DevPassScratch { uint8_t nz[3][32 * 32]; };
+
+JXL_DEV uint32_t pass_group_serial(const DevBuffers &B, DevPassScratch &S, int pass, int g) {
+  const DevFrame &F = frame_of(B);
+  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+  const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
+  DevBits b;
+  bits_init(b, B.codestream, sec.off);
+  if (F.nsec == 1) {
+    uint32_t skip = F.single_pass_bit;
+    while (skip >= 32) { bits_read(b, 32); skip -= 32; }
+    bits_read(b, (int)skip);
+  }
+  const int gx = g % F.xgroups, gy = g / F.xgroups;
+  const int bx0 = gx * 32, by0 = gy * 32;
+  const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
+  const int sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
+  if (sel >= F.num_presets) return kErrBitstream;
+  const int ctx_offset = sel * 495 * F.num_bctx;
+  DevECView ev = ec_view(B.tables, F.hf_ec[pass]);
+  uint32_t state = ans_init(ev, b);
+  const int shift = F.pass_shift[pass];
+  const uint8_t *bctx_map = B.tables + F.bctx_map_off;
+  const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
+  uint32_t pool = 0;
+  for (int i = 0; i < 3 * 32 * 32; i++) S.nz[0][i] = 0;
+  for (int y = 0; y < bh; y++)
+    for (int x = 0; x < bw; x++) {
+      const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+      if (!B.first[o]) continue;
+      const int st = B.strategy[o];
+      const int cx = kCoveredX[st], cy = kCoveredY[st];
+      const int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
+      const int size = covered * 64;
+      const int ord = kStrategyOrder[st];
+      uint32_t off;
+      if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
+      const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
+      int qf_idx = 0;
+      for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
+      const int lfi = B.lf_idx[o];
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+        uint8_t *nzc = S.nz[c];
+        int predicted;
+        if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
+        else if (y == 0) predicted = nzc[x - 1];
+        else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
+        int idx = c < 2 ? c ^ 1 : 2;
+        idx = idx * 13 + ord;
+        idx = idx * (F.nb_qf_thr + 1) + qf_idx;
+        idx = idx * nlf + lfi;
+        const int bctx = bctx_map[idx];
+        const int nzp = predicted >= 64 ? 64 : predicted;
+        const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx + ctx_offset;
+        int nzeros = (int)ec_read(ev, b, state, (uint32_t)nzctx);
+        if (nzeros > size - covered) return kErrBitstream;
+        const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
+        const int histo = ctx_offset + F.num_bctx * 37 + 458 * bctx;
+        const uint32_t *order = (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+        int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
+        int prev = nzeros > size / 16 ? 0 : 1;
+        for (int k = covered; k < size && nzeros != 0; k++) {
+          const int nl = (nzeros + covered - 1) >> log2c;
+          const int kk = k >> log2c;
+          const int ctx = histo + (kCoeffNumNonzeroContext[nl] + kCoeffFreqContext[kk]) * 2 + prev;
+          const uint32_t u = ec_read(ev, b, state, (uint32_t)ctx);
+          if (u) blk[order[k]] += unpack_signed(u) * (1 << shift);
+          prev = u != 0;
+          nzeros -= prev;
+        }
+        if (nzeros != 0) return kErrBitstream;
+      }
+    }
+  if (state != 0x130000u) return kErrAnsFinal;
+  if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
+  return 0;
+}
+
+}  // namespace jxlamd

@@ -1,14 +1,14 @@
-/* oracle/jxo_entropy.c — bit reader, field codes, ANS / prefix entropy decoder (ISO/IEC 18181-1 Annex C/D).
+/* oracle/hx_entropy.c — bit reader, field codes, ANS / prefix entropy decoder (ISO/IEC 18181-1 Annex C/D).
  * CPU restatement used only as a checker (see jxo.h). Pinned against the reference's libjxl 0.12.0
  * (jxlcoder/src/main/cpp/lib/x86_64/libjxl.so) via oracle/_ref on whole-image outputs. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "jxo.h"
+#include "host_bits.h"
 
-void jxo_br_init(jxo_br *br, const uint8_t *p, size_t len) { br->p = p; br->len = len; br->pos = 0; br->err = 0; }
+void hx_br_init(hx_br *br, const uint8_t *p, size_t len) { br->p = p; br->len = len; br->pos = 0; br->err = 0; }
 
-uint32_t jxo_bits(jxo_br *br, int n) {
+uint32_t hx_bits(hx_br *br, int n) {
   if (n == 0) return 0;
   size_t byte = br->pos >> 3;
   int sh = (int)(br->pos & 7);
@@ -23,33 +23,33 @@ uint32_t jxo_bits(jxo_br *br, int n) {
   return (uint32_t)(n == 32 ? v : (v & ((1ull << n) - 1)));
 }
 
-void jxo_align(jxo_br *br) { br->pos = (br->pos + 7) & ~(size_t)7; }
+void hx_align(hx_br *br) { br->pos = (br->pos + 7) & ~(size_t)7; }
 
-uint32_t jxo_u32(jxo_br *br, int b0, uint32_t o0, int b1, uint32_t o1, int b2, uint32_t o2, int b3, uint32_t o3) {
-  uint32_t sel = jxo_bits(br, 2);
+uint32_t hx_u32(hx_br *br, int b0, uint32_t o0, int b1, uint32_t o1, int b2, uint32_t o2, int b3, uint32_t o3) {
+  uint32_t sel = hx_bits(br, 2);
   int b = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
   uint32_t o = sel == 0 ? o0 : sel == 1 ? o1 : sel == 2 ? o2 : o3;
   if (b < 0) return o;
-  return jxo_bits(br, b) + o;
+  return hx_bits(br, b) + o;
 }
 
-uint64_t jxo_u64(jxo_br *br) {
-  uint32_t sel = jxo_bits(br, 2);
+uint64_t hx_u64(hx_br *br) {
+  uint32_t sel = hx_bits(br, 2);
   if (sel == 0) return 0;
-  if (sel == 1) return 1 + jxo_bits(br, 4);
-  if (sel == 2) return 17 + jxo_bits(br, 8);
-  uint64_t v = jxo_bits(br, 12);
+  if (sel == 1) return 1 + hx_bits(br, 4);
+  if (sel == 2) return 17 + hx_bits(br, 8);
+  uint64_t v = hx_bits(br, 12);
   int shift = 12;
-  while (jxo_bits(br, 1)) {
-    if (shift == 60) { v |= (uint64_t)jxo_bits(br, 4) << shift; break; }
-    v |= (uint64_t)jxo_bits(br, 8) << shift;
+  while (hx_bits(br, 1)) {
+    if (shift == 60) { v |= (uint64_t)hx_bits(br, 4) << shift; break; }
+    v |= (uint64_t)hx_bits(br, 8) << shift;
     shift += 8;
   }
   return v;
 }
 
-float jxo_f16(jxo_br *br) {
-  uint32_t h = jxo_bits(br, 16);
+float hx_f16(hx_br *br) {
+  uint32_t h = hx_bits(br, 16);
   uint32_t sign = h >> 15, exp = (h >> 10) & 31, mant = h & 1023;
   float v;
   if (exp == 0) v = (float)mant * (1.0f / 16777216.0f);           /* subnormal: mant * 2^-24 */
@@ -61,54 +61,54 @@ float jxo_f16(jxo_br *br) {
   return sign ? -v : v;
 }
 
-uint32_t jxo_enum(jxo_br *br) { return jxo_u32(br, -1, 0, -1, 1, 4, 2, 6, 18); }
+uint32_t hx_enum(hx_br *br) { return hx_u32(br, -1, 0, -1, 1, 4, 2, 6, 18); }
 
 /* ------------------------------------------------------------------------------------------------ */
 static int ceil_log2(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }   /* x>=1 */
 
-static void read_huc(jxo_br *br, jxo_huc *c, int log_alpha) {
-  c->split_exp = (uint8_t)jxo_bits(br, ceil_log2((uint32_t)log_alpha + 1));
+static void read_huc(hx_br *br, hx_huc *c, int log_alpha) {
+  c->split_exp = (uint8_t)hx_bits(br, ceil_log2((uint32_t)log_alpha + 1));
   c->msb = c->lsb = 0;
   if (c->split_exp != log_alpha) {
-    c->msb = (uint8_t)jxo_bits(br, ceil_log2((uint32_t)c->split_exp + 1));
+    c->msb = (uint8_t)hx_bits(br, ceil_log2((uint32_t)c->split_exp + 1));
     if (c->msb > c->split_exp) { br->err = 1; c->msb = c->split_exp; }
-    c->lsb = (uint8_t)jxo_bits(br, ceil_log2((uint32_t)(c->split_exp - c->msb) + 1));
+    c->lsb = (uint8_t)hx_bits(br, ceil_log2((uint32_t)(c->split_exp - c->msb) + 1));
     if (c->lsb + c->msb > c->split_exp) { br->err = 1; c->lsb = 0; }
   }
 }
 
-static uint32_t read_varlen_u8(jxo_br *br) {
-  if (!jxo_bits(br, 1)) return 0;
-  int n = (int)jxo_bits(br, 3);
+static uint32_t read_varlen_u8(hx_br *br) {
+  if (!hx_bits(br, 1)) return 0;
+  int n = (int)hx_bits(br, 3);
   if (n == 0) return 1;
-  return jxo_bits(br, n) + (1u << n);
+  return hx_bits(br, n) + (1u << n);
 }
 
 /* ANS histogram, 12-bit precision */
-static int read_ans_histogram(jxo_br *br, uint16_t *D, int table_size) {
+static int read_ans_histogram(hx_br *br, uint16_t *D, int table_size) {
   memset(D, 0, sizeof(uint16_t) * (size_t)table_size);
-  if (jxo_bits(br, 1)) {                         /* simple */
-    int ns = (int)jxo_bits(br, 1) + 1;
+  if (hx_bits(br, 1)) {                         /* simple */
+    int ns = (int)hx_bits(br, 1) + 1;
     uint32_t s0 = read_varlen_u8(br), s1 = 0;
     if (ns == 2) s1 = read_varlen_u8(br);
     if ((int)s0 >= table_size || (int)s1 >= table_size) return -1;
     if (ns == 1) D[s0] = 4096;
     else {
       if (s0 == s1) return -1;
-      D[s0] = (uint16_t)jxo_bits(br, 12);
+      D[s0] = (uint16_t)hx_bits(br, 12);
       D[s1] = (uint16_t)(4096 - D[s0]);
     }
     return 0;
   }
-  if (jxo_bits(br, 1)) {                         /* flat */
+  if (hx_bits(br, 1)) {                         /* flat */
     int n = (int)read_varlen_u8(br) + 1;
     if (n > table_size) return -1;
     for (int i = 0; i < n; i++) D[i] = (uint16_t)(4096 / n + (i < 4096 % n ? 1 : 0));
     return 0;
   }
   int len = 0;
-  while (len < 3 && jxo_bits(br, 1)) len++;
-  int shift = (int)((jxo_bits(br, len) | (1u << len)) - 1);
+  while (len < 3 && hx_bits(br, 1)) len++;
+  int shift = (int)((hx_bits(br, len) | (1u << len)) - 1);
   if (shift > 13) return -1;
   int n = (int)read_varlen_u8(br) + 3;
   if (n > table_size) return -1;
@@ -118,8 +118,8 @@ static int read_ans_histogram(jxo_br *br, uint16_t *D, int table_size) {
   int omit_log = -1, omit_pos = -1;
   for (int i = 0; i < n; i++) {
     /* peek 7 bits */
-    jxo_br save = *br;
-    uint32_t idx = jxo_bits(br, 7);
+    hx_br save = *br;
+    uint32_t idx = hx_bits(br, 7);
     *br = save;
     int l, v;
     uint32_t lo = idx & 15;
@@ -130,7 +130,7 @@ static int read_ans_histogram(jxo_br *br, uint16_t *D, int table_size) {
     else if (idx & 32) { l = 6; v = 11; }
     else if (idx & 64) { l = 7; v = 13; }
     else { l = 7; v = 12; }
-    (void)jxo_bits(br, l);
+    (void)hx_bits(br, l);
     logc[i] = v;
     if (v == 13) {
       int rle = (int)read_varlen_u8(br);
@@ -157,7 +157,7 @@ static int read_ans_histogram(jxo_br *br, uint16_t *D, int table_size) {
         int bc = shift - ((12 - lc) >> 1);
         if (bc > lc) bc = lc;
         if (bc < 0) bc = 0;
-        cnt[i] = (1 << lc) + (int)(jxo_bits(br, bc) << (lc - bc));
+        cnt[i] = (1 << lc) + (int)(hx_bits(br, bc) << (lc - bc));
       }
     }
     total += cnt[i];
@@ -168,7 +168,7 @@ static int read_ans_histogram(jxo_br *br, uint16_t *D, int table_size) {
   return 0;
 }
 
-static void build_alias(jxo_cluster *c, int log_alpha) {
+static void build_alias(hx_cluster *c, int log_alpha) {
   int table = 1 << log_alpha;
   int bucket = 4096 >> log_alpha;
   c->a_sym = (uint8_t *)calloc((size_t)table, 1);
@@ -206,7 +206,7 @@ static void build_alias(jxo_cluster *c, int log_alpha) {
 }
 
 /* ---- prefix codes (Brotli-style, RFC 7932 §3.4/3.5) */
-static int build_canonical(jxo_cluster *c, const uint8_t *lens, int n) {
+static int build_canonical(hx_cluster *c, const uint8_t *lens, int n) {
   memset(c->cnt, 0, sizeof(c->cnt));
   int nz = 0, last = -1;
   for (int i = 0; i < n; i++) if (lens[i]) { c->cnt[lens[i]]++; nz++; last = i; }
@@ -220,11 +220,11 @@ static int build_canonical(jxo_cluster *c, const uint8_t *lens, int n) {
   return 0;
 }
 
-static int prefix_decode(const jxo_cluster *c, jxo_br *br) {
+static int prefix_decode(const hx_cluster *c, hx_br *br) {
   if (c->single >= 0) return c->single;
   int code = 0, first = 0, index = 0;
   for (int len = 1; len <= 15; len++) {
-    code |= (int)jxo_bits(br, 1);
+    code |= (int)hx_bits(br, 1);
     int count = c->cnt[len];
     if (code - first < count) return c->sorted[index + (code - first)];
     index += count; first += count; first <<= 1; code <<= 1;
@@ -233,24 +233,24 @@ static int prefix_decode(const jxo_cluster *c, jxo_br *br) {
   return 0;
 }
 
-static int read_prefix_code(jxo_br *br, jxo_cluster *c, int alphabet) {
+static int read_prefix_code(hx_br *br, hx_cluster *c, int alphabet) {
   uint8_t *lens = (uint8_t *)calloc((size_t)alphabet + 1, 1);
   int rc = 0;
   if (alphabet == 1) { lens[0] = 0; build_canonical(c, lens, 1); c->single = 0; free(lens); return 0; }
-  int hskip = (int)jxo_bits(br, 2);
+  int hskip = (int)hx_bits(br, 2);
   if (hskip == 1) {                              /* simple code */
     int max_bits = 0;
     for (int t = alphabet - 1; t; t >>= 1) max_bits++;
-    int ns = (int)jxo_bits(br, 2) + 1;
+    int ns = (int)hx_bits(br, 2) + 1;
     int sym[4];
-    for (int i = 0; i < ns; i++) { sym[i] = (int)jxo_bits(br, max_bits); if (sym[i] >= alphabet) rc = -1; }
+    for (int i = 0; i < ns; i++) { sym[i] = (int)hx_bits(br, max_bits); if (sym[i] >= alphabet) rc = -1; }
     for (int i = 0; i < ns && !rc; i++) for (int j = i + 1; j < ns; j++) if (sym[i] == sym[j]) rc = -1;
     if (!rc) {
       if (ns == 1) { build_canonical(c, lens, alphabet); c->single = sym[0]; free(lens); return 0; }
       if (ns == 2) { lens[sym[0]] = 1; lens[sym[1]] = 1; }
       else if (ns == 3) { lens[sym[0]] = 1; lens[sym[1]] = 2; lens[sym[2]] = 2; }
       else {
-        if (jxo_bits(br, 1)) { lens[sym[0]] = 1; lens[sym[1]] = 2; lens[sym[2]] = 3; lens[sym[3]] = 3; }
+        if (hx_bits(br, 1)) { lens[sym[0]] = 1; lens[sym[1]] = 2; lens[sym[2]] = 3; lens[sym[3]] = 3; }
         else { lens[sym[0]] = lens[sym[1]] = lens[sym[2]] = lens[sym[3]] = 2; }
       }
       build_canonical(c, lens, alphabet);
@@ -266,16 +266,16 @@ static int read_prefix_code(jxo_br *br, jxo_cluster *c, int alphabet) {
   memset(cll, 0, sizeof(cll));
   int space = 32, num_codes = 0;
   for (int i = hskip; i < 18 && space > 0; i++) {
-    jxo_br save = *br;
-    uint32_t p = jxo_bits(br, 4);
+    hx_br save = *br;
+    uint32_t p = hx_bits(br, 4);
     *br = save;
-    (void)jxo_bits(br, cl_len[p]);
+    (void)hx_bits(br, cl_len[p]);
     int v = cl_val[p];
     cll[order[i]] = (uint8_t)v;
     if (v) { space -= 32 >> v; num_codes++; }
   }
   if (!(num_codes == 1 || space == 0)) { free(lens); return -1; }
-  jxo_cluster clc;
+  hx_cluster clc;
   memset(&clc, 0, sizeof(clc));
   build_canonical(&clc, cll, 18);
   int symbol = 0, prev_len = 8, repeat = 0, repeat_len = 0;
@@ -292,7 +292,7 @@ static int read_prefix_code(jxo_br *br, jxo_cluster *c, int alphabet) {
       if (repeat_len != new_len) { repeat = 0; repeat_len = new_len; }
       int old = repeat;
       if (repeat > 0) { repeat -= 2; repeat <<= extra; }
-      repeat += (int)jxo_bits(br, extra) + 3;
+      repeat += (int)hx_bits(br, extra) + 3;
       int delta = repeat - old;
       if (symbol + delta > alphabet) { rc = -1; break; }
       for (int i = 0; i < delta; i++) lens[symbol++] = (uint8_t)repeat_len;
@@ -308,22 +308,22 @@ static int read_prefix_code(jxo_br *br, jxo_cluster *c, int alphabet) {
 }
 
 /* ---- context map */
-int jxo__read_ctx_map(jxo_br *br, uint8_t *map, int n, int *num_clusters) {
-  if (jxo_bits(br, 1)) {                         /* simple */
-    int b = (int)jxo_bits(br, 2);
-    for (int i = 0; i < n; i++) map[i] = (uint8_t)jxo_bits(br, b);
+int hx__read_ctx_map(hx_br *br, uint8_t *map, int n, int *num_clusters) {
+  if (hx_bits(br, 1)) {                         /* simple */
+    int b = (int)hx_bits(br, 2);
+    for (int i = 0; i < n; i++) map[i] = (uint8_t)hx_bits(br, b);
   } else {
-    int use_mtf = (int)jxo_bits(br, 1);
-    jxo_ec ec;
-    if (jxo_ec_read_header(&ec, br, 1)) return -1;
-    jxo_ec_begin(&ec, br, 0);
+    int use_mtf = (int)hx_bits(br, 1);
+    hx_ec ec;
+    if (hx_ec_read_header(&ec, br, 1)) return -1;
+    hx_ec_begin(&ec, br, 0);
     for (int i = 0; i < n; i++) {
-      uint32_t v = jxo_ec_read(&ec, br, 0);
-      if (v > 255) { jxo_ec_free(&ec); return -1; }
+      uint32_t v = hx_ec_read(&ec, br, 0);
+      if (v > 255) { hx_ec_free(&ec); return -1; }
       map[i] = (uint8_t)v;
     }
-    int ok = jxo_ec_final_ok(&ec);
-    jxo_ec_free(&ec);
+    int ok = hx_ec_final_ok(&ec);
+    hx_ec_free(&ec);
     if (!ok) return -1;
     if (use_mtf) {
       uint8_t mtf[256];
@@ -347,30 +347,30 @@ int jxo__read_ctx_map(jxo_br *br, uint8_t *map, int n, int *num_clusters) {
   return br->err ? -1 : 0;
 }
 
-int jxo_ec_read_header(jxo_ec *ec, jxo_br *br, int num_ctx) {
+int hx_ec_read_header(hx_ec *ec, hx_br *br, int num_ctx) {
   memset(ec, 0, sizeof(*ec));
   ec->num_ctx = num_ctx;
-  ec->lz77 = (int)jxo_bits(br, 1);
+  ec->lz77 = (int)hx_bits(br, 1);
   int n = num_ctx;
   if (ec->lz77) {
-    ec->lz_min_symbol = (int)jxo_u32(br, -1, 224, -1, 512, -1, 4096, 15, 8);
-    ec->lz_min_length = (int)jxo_u32(br, -1, 3, -1, 4, 2, 5, 8, 9);
+    ec->lz_min_symbol = (int)hx_u32(br, -1, 224, -1, 512, -1, 4096, 15, 8);
+    ec->lz_min_length = (int)hx_u32(br, -1, 3, -1, 4, 2, 5, 8, 9);
     read_huc(br, &ec->lz_len_cfg, 8);
     n++;
   }
   ec->ctx_map = (uint8_t *)calloc((size_t)n, 1);
   ec->num_clusters = 1;
-  if (n > 1 && jxo__read_ctx_map(br, ec->ctx_map, n, &ec->num_clusters)) return -1;
-  ec->use_prefix = (int)jxo_bits(br, 1);
-  ec->log_alpha = ec->use_prefix ? 15 : 5 + (int)jxo_bits(br, 2);
-  ec->cfg = (jxo_huc *)calloc((size_t)ec->num_clusters, sizeof(jxo_huc));
-  ec->cl = (jxo_cluster *)calloc((size_t)ec->num_clusters, sizeof(jxo_cluster));
+  if (n > 1 && hx__read_ctx_map(br, ec->ctx_map, n, &ec->num_clusters)) return -1;
+  ec->use_prefix = (int)hx_bits(br, 1);
+  ec->log_alpha = ec->use_prefix ? 15 : 5 + (int)hx_bits(br, 2);
+  ec->cfg = (hx_huc *)calloc((size_t)ec->num_clusters, sizeof(hx_huc));
+  ec->cl = (hx_cluster *)calloc((size_t)ec->num_clusters, sizeof(hx_cluster));
   for (int i = 0; i < ec->num_clusters; i++) read_huc(br, &ec->cfg[i], ec->log_alpha);
   if (ec->use_prefix) {
     int *counts = (int *)malloc(sizeof(int) * (size_t)ec->num_clusters);
     for (int i = 0; i < ec->num_clusters; i++) {
-      if (!jxo_bits(br, 1)) counts[i] = 1;
-      else { int nb = (int)jxo_bits(br, 4); counts[i] = 1 + (1 << nb) + (int)jxo_bits(br, nb); }
+      if (!hx_bits(br, 1)) counts[i] = 1;
+      else { int nb = (int)hx_bits(br, 4); counts[i] = 1 + (1 << nb) + (int)hx_bits(br, nb); }
       if (counts[i] > (1 << 15)) { free(counts); return -1; }
     }
     for (int i = 0; i < ec->num_clusters; i++) {
@@ -387,20 +387,19 @@ int jxo_ec_read_header(jxo_ec *ec, jxo_br *br, int num_ctx) {
     }
   }
   if (ec->lz77) ec->window = (uint32_t *)calloc(1u << 20, 4);
-  { extern int jxo_debug; if (jxo_debug > 1) fprintf(stderr, "ec: nctx=%d clusters=%d prefix=%d log_alpha=%d lz77=%d\n", num_ctx, ec->num_clusters, ec->use_prefix, ec->log_alpha, ec->lz77); }
   return br->err ? -1 : 0;
 }
 
-void jxo_ec_begin(jxo_ec *ec, jxo_br *br, uint32_t dist_mult) {
+void hx_ec_begin(hx_ec *ec, hx_br *br, uint32_t dist_mult) {
   ec->dist_mult = dist_mult;
   ec->num_to_copy = ec->copy_pos = ec->num_decoded = 0;
-  ec->state = ec->use_prefix ? 0x130000u : jxo_bits(br, 32);
+  ec->state = ec->use_prefix ? 0x130000u : hx_bits(br, 32);
 }
 
-int jxo_ec_final_ok(const jxo_ec *ec) { return ec->state == 0x130000u; }
+int hx_ec_final_ok(const hx_ec *ec) { return ec->state == 0x130000u; }
 
-static inline uint32_t read_token(jxo_ec *ec, jxo_br *br, int cluster) {
-  jxo_cluster *c = &ec->cl[cluster];
+static inline uint32_t read_token(hx_ec *ec, hx_br *br, int cluster) {
+  hx_cluster *c = &ec->cl[cluster];
   if (ec->use_prefix) return (uint32_t)prefix_decode(c, br);
   int log_bucket = 12 - ec->log_alpha;
   uint32_t res = ec->state & 0xfff;
@@ -409,18 +408,18 @@ static inline uint32_t read_token(jxo_ec *ec, jxo_br *br, int cluster) {
   if (pos >= c->a_cutoff[i]) { sym = c->a_sym[i]; off = c->a_off[i] + pos; }
   else { sym = i; off = pos; }
   ec->state = c->D[sym] * (ec->state >> 12) + off;
-  if (ec->state < (1u << 16)) ec->state = (ec->state << 16) | jxo_bits(br, 16);
+  if (ec->state < (1u << 16)) ec->state = (ec->state << 16) | hx_bits(br, 16);
   return sym;
 }
 
-static inline uint32_t read_hybrid(jxo_br *br, const jxo_huc *c, uint32_t token) {
+static inline uint32_t read_hybrid(hx_br *br, const hx_huc *c, uint32_t token) {
   uint32_t split = 1u << c->split_exp;
   if (token < split) return token;
   uint32_t nbits = c->split_exp - (c->msb + c->lsb) + ((token - split) >> (c->msb + c->lsb));
   if (nbits > 31) { br->err = 1; return 0; }
   uint32_t low = token & ((1u << c->lsb) - 1);
   token >>= c->lsb;
-  uint32_t bits = jxo_bits(br, (int)nbits);
+  uint32_t bits = hx_bits(br, (int)nbits);
   return (((((1u << c->msb) | (token & ((1u << c->msb) - 1))) << nbits) | bits) << c->lsb) | low;
 }
 
@@ -436,7 +435,7 @@ static const int8_t kSpecialDist[120][2] = {
     {8, 0},  {4, 7},  {-4, 7}, {7, 4},  {-7, 4}, {8, 1},  {8, 2},  {6, 6},  {-6, 6}, {8, 3},  {5, 7},  {-5, 7},
     {7, 5},  {-7, 5}, {8, 4},  {6, 7},  {-6, 7}, {7, 6},  {-7, 6}, {8, 5},  {7, 7},  {-7, 7}, {8, 6},  {8, 7}};
 
-uint32_t jxo_ec_read(jxo_ec *ec, jxo_br *br, int ctx) {
+uint32_t hx_ec_read(hx_ec *ec, hx_br *br, int ctx) {
   const uint32_t mask = (1u << 20) - 1;
   if (ec->num_to_copy > 0) {
     uint32_t r = ec->window[(ec->copy_pos++) & mask];
@@ -464,14 +463,14 @@ uint32_t jxo_ec_read(jxo_ec *ec, jxo_br *br, int ctx) {
       memset(ec->window, 0, n * 4);
     }
     if (ec->num_to_copy < (uint32_t)ec->lz_min_length || br->err) { br->err = 1; ec->num_to_copy = 0; return 0; }
-    return jxo_ec_read(ec, br, ctx);
+    return hx_ec_read(ec, br, ctx);
   }
   uint32_t r = read_hybrid(br, &ec->cfg[cluster], token);
   if (ec->lz77) ec->window[(ec->num_decoded++) & mask] = r;
   return r;
 }
 
-void jxo_ec_free(jxo_ec *ec) {
+void hx_ec_free(hx_ec *ec) {
   if (ec->cl)
     for (int i = 0; i < ec->num_clusters; i++) {
       free(ec->cl[i].D); free(ec->cl[i].a_sym); free(ec->cl[i].a_cutoff); free(ec->cl[i].a_off); free(ec->cl[i].sorted);
@@ -480,14 +479,14 @@ void jxo_ec_free(jxo_ec *ec) {
   memset(ec, 0, sizeof(*ec));
 }
 
-int jxo_read_permutation(jxo_ec *ec, jxo_br *br, uint32_t *out, uint32_t size, uint32_t skip) {
+int hx_read_permutation(hx_ec *ec, hx_br *br, uint32_t *out, uint32_t size, uint32_t skip) {
   uint32_t *lehmer = (uint32_t *)calloc(size ? size : 1, 4);
   #define PCTX(v) ({ uint32_t _v = (v); int _b = 0; while (_v) { _b++; _v >>= 1; } _b > 7 ? 7 : _b; })
-  uint32_t end = jxo_ec_read(ec, br, PCTX(size));
+  uint32_t end = hx_ec_read(ec, br, PCTX(size));
   if (end > size - skip) { free(lehmer); return -1; }
   uint32_t last = 0;
   for (uint32_t i = skip; i < end + skip; i++) {
-    lehmer[i] = jxo_ec_read(ec, br, PCTX(last));
+    lehmer[i] = hx_ec_read(ec, br, PCTX(last));
     last = lehmer[i];
     if (lehmer[i] >= size - i) { free(lehmer); return -1; }
   }
@@ -505,3 +504,8 @@ int jxo_read_permutation(jxo_ec *ec, jxo_br *br, uint32_t *out, uint32_t size, u
   free(tmp); free(lehmer);
   return br->err ? -1 : 0;
 }
+
+#include <stdarg.h>
+static thread_local char g_hx_err[512];
+void hx_set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_hx_err, sizeof(g_hx_err), fmt, ap); va_end(ap); }
+const char *hx_last_error(void) { return g_hx_err; }

@@ -1,0 +1,368 @@
+// jxl_coder_amd/csrc/host_parse.cpp — see host_parse.h.
+#include "host_parse.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "host_bits.h"
+
+namespace {
+#define PI 3.14159265358979323846
+typedef struct { int prop; int32_t splitval; int lchild, rchild; int predictor; int64_t offset; uint32_t multiplier; int ctx; } hx_tnode;
+typedef struct { hx_tnode *n; int count; int num_leaves; hx_ec code; int valid; } hx_tree;
+typedef struct {
+  uint32_t xsize, ysize, bits_per_sample, exp_bits, num_color_channels, num_extra_channels, alpha_bits, alpha_premultiplied;
+  uint32_t orientation, have_animation, xyb_encoded;
+  float intensity_target;
+  uint32_t want_icc, color_space, white_point, primaries, transfer_function, rendering_intent, have_gamma;
+  float gamma;
+} hx_info;
+typedef struct { int nbands; float b[3][8]; } hx_dctparams;
+#include "host_format.inc"
+#include "dither_lut.h"
+}  // namespace
+
+namespace jxlamd {
+
+namespace {
+
+struct Blob {
+  std::vector<uint8_t> &v;
+  explicit Blob(std::vector<uint8_t> &vv) : v(vv) {}
+  uint32_t append(const void *p, size_t n) {
+    size_t off = (v.size() + 15) & ~(size_t)15;
+    v.resize(off + n);
+    if (n) memcpy(v.data() + off, p, n);
+    return (uint32_t)off;
+  }
+};
+
+static int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
+
+// pack a parsed entropy code into the device layout
+static int pack_ec(const hx_ec &ec, Blob &b, DevEC *out, std::string *err) {
+  if (ec.lz77) { *err = "unsupported: LZ77 in a group-level entropy code"; return -1; }
+  memset(out, 0, sizeof(*out));
+  out->num_ctx = ec.num_ctx; out->num_clusters = ec.num_clusters; out->use_prefix = ec.use_prefix; out->log_alpha = ec.log_alpha;
+  out->ctx_map_off = b.append(ec.ctx_map, (size_t)ec.num_ctx);
+  std::vector<uint32_t> cfg((size_t)ec.num_clusters);
+  for (int i = 0; i < ec.num_clusters; i++) cfg[(size_t)i] = ec.cfg[i].split_exp | (ec.cfg[i].msb << 8) | (ec.cfg[i].lsb << 16);
+  out->cfg_off = b.append(cfg.data(), cfg.size() * 4);
+  if (!ec.use_prefix) {
+    const int table = 1 << ec.log_alpha;
+    std::vector<DevAlias> al((size_t)ec.num_clusters * (size_t)table);
+    for (int c = 0; c < ec.num_clusters; c++)
+      for (int i = 0; i < table; i++) {
+        DevAlias &a = al[(size_t)c * (size_t)table + (size_t)i];
+        const hx_cluster &cl = ec.cl[c];
+        a.cutoff = (uint8_t)cl.a_cutoff[i]; a.right = cl.a_sym[i]; a.off1 = (uint16_t)cl.a_off[i];
+        a.freq0 = cl.D[i]; a.freq1 = cl.D[cl.a_sym[i]];
+        // a single-symbol distribution keeps freq 4096 for every bucket (state must not change)
+        if (cl.D[cl.a_sym[i]] == 4096) { a.freq0 = 4096; a.freq1 = 4096; }
+      }
+    out->alias_off = b.append(al.data(), al.size() * sizeof(DevAlias));
+    out->prefix_off = out->pool_off = 0;
+  } else {
+    std::vector<DevPrefix> pf((size_t)ec.num_clusters);
+    std::vector<uint16_t> pool;
+    for (int c = 0; c < ec.num_clusters; c++) {
+      const hx_cluster &cl = ec.cl[c];
+      DevPrefix &p = pf[(size_t)c];
+      memcpy(p.cnt, cl.cnt, sizeof(p.cnt));
+      p.single = cl.single;
+      p.sorted_off = (uint32_t)pool.size();
+      int nz = 0; for (int l = 1; l < 16; l++) nz += cl.cnt[l];
+      for (int i = 0; i < nz; i++) pool.push_back(cl.sorted[i]);
+    }
+    out->prefix_off = b.append(pf.data(), pf.size() * sizeof(DevPrefix));
+    out->pool_off = b.append(pool.data(), pool.size() * 2);
+    out->alias_off = 0;
+  }
+  return 0;
+}
+
+struct Priv {                 // state between phase 1 and phase 2
+  img_meta m;
+  frame_hdr f;
+  DevFrame F;
+  std::vector<DevSection> secs;
+};
+
+static void fill_info(const img_meta &m, ImageInfo *i) {
+  const hx_info &p = m.pub;
+  i->xsize = p.xsize; i->ysize = p.ysize; i->bits_per_sample = p.bits_per_sample; i->exp_bits = p.exp_bits;
+  i->num_color_channels = p.num_color_channels; i->num_extra_channels = p.num_extra_channels; i->alpha_bits = p.alpha_bits;
+  i->alpha_premultiplied = p.alpha_premultiplied; i->orientation = 1; i->have_animation = p.have_animation;
+  i->xyb_encoded = p.xyb_encoded; i->uses_original_profile = !p.xyb_encoded; i->intensity_target = p.intensity_target;
+  i->want_icc = p.want_icc; i->color_space = p.color_space; i->white_point = p.white_point; i->primaries = p.primaries;
+  i->transfer_function = p.transfer_function; i->rendering_intent = p.rendering_intent; i->have_gamma = p.have_gamma; i->gamma = p.gamma;
+}
+
+static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
+  DevFrame &F = pv->F;
+  const frame_hdr &f = pv->f;
+  Blob blob(plan->tables);
+  if (!hx_bool(br)) { plan->error = "unsupported: custom dequant matrices"; return -1; }
+  F.num_presets = 1 + (int)hx_bits(br, ceil_log2u((uint32_t)f.num_groups));
+  if (f.num_passes > 4) { plan->error = "unsupported: more than 4 passes"; return -1; }
+  for (int p = 0; p < f.num_passes; p++) {
+    uint32_t used = hx_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
+    hx_ec oc; int have_oc = 0;
+    if (used) { if (hx_ec_read_header(&oc, br, 8)) { plan->error = "bad coefficient-order code"; return -1; } hx_ec_begin(&oc, br, 0); have_oc = 1; }
+    for (int o = 0; o < 13; o++) {
+      int st = kOrderStrategy[o];
+      uint32_t size = (uint32_t)kCoveredX[st] * kCoveredY[st] * 64;
+      std::vector<uint32_t> nat(size), ord(size), perm(size);
+      natural_order(st, nat.data());
+      for (int c = 0; c < 3; c++) {
+        if (used & (1u << o)) {
+          if (hx_read_permutation(&oc, br, perm.data(), size, size / 64)) { hx_ec_free(&oc); plan->error = "bad coefficient order"; return -1; }
+          for (uint32_t i = 0; i < size; i++) ord[i] = nat[perm[i]];
+        } else ord = nat;
+        F.order_off[p][o][c] = blob.append(ord.data(), (size_t)size * 4);
+      }
+    }
+    if (have_oc) { int ok = hx_ec_final_ok(&oc); hx_ec_free(&oc); if (!ok) { plan->error = "coefficient orders: ANS final state"; return -1; } }
+    hx_ec hf;
+    if (hx_ec_read_header(&hf, br, 495 * F.num_presets * F.num_bctx)) { plan->error = "bad HF histograms"; return -1; }
+    int rc = pack_ec(hf, blob, &F.hf_ec[p], &plan->error);
+    hx_ec_free(&hf);
+    if (rc) return -1;
+  }
+  if (br->err) { plan->error = "truncated HfGlobal"; return -1; }
+  plan->hf_parsed = true;
+  return 0;
+}
+
+static void finish_blob(FramePlan *plan, Priv *pv) { memcpy(plan->tables.data(), &pv->F, sizeof(DevFrame)); }
+
+}  // namespace
+
+int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error) {
+  uint8_t *cs; size_t csn; int owned;
+  if (extract_codestream(data, size, &cs, &csn, &owned)) { if (error) *error = hx_last_error(); return -1; }
+  hx_br br; hx_br_init(&br, cs, csn);
+  img_meta m;
+  int rc = read_image_header(&br, &m);
+  if (rc) { if (error) *error = hx_last_error(); }
+  else fill_info(m, info);
+  if (owned) free(cs);
+  return rc;
+}
+
+int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
+  plan->error.clear();
+  uint8_t *cs; size_t csn; int owned;
+  if (extract_codestream(data, size, &cs, &csn, &owned)) { plan->error = hx_last_error(); return -1; }
+  if (owned) { plan->cs_owned.assign(cs, cs + csn); free(cs); plan->cs = plan->cs_owned.data(); }
+  else plan->cs = data;
+  plan->cs_size = csn;
+  std::shared_ptr<Priv> pvs = std::make_shared<Priv>();
+  plan->priv = pvs;
+  Priv *pv = pvs.get();
+  hx_br br; hx_br_init(&br, plan->cs, csn);
+  img_meta &m = pv->m;
+  if (read_image_header(&br, &m)) { plan->error = hx_last_error(); return -1; }
+  fill_info(m, &plan->info);
+  if (m.pub.want_icc) { plan->error = "unsupported: embedded ICC profile"; return -1; }
+  if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
+  if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
+  if (m.num_extra) { plan->error = "unsupported: extra channels (alpha) on the device path"; return -1; }
+  if (!m.pub.xyb_encoded) { plan->error = "unsupported: non-XYB (Modular / lossless) frames on the device path"; return -1; }
+  uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
+  hx_align(&br);
+  frame_hdr &f = pv->f;
+  if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { plan->error = hx_last_error(); return -1; }
+  if (f.frame_type != 0 || !f.is_last) { plan->error = "unsupported: multi-frame / non-regular frame"; return -1; }
+  if (f.encoding != 0) { plan->error = "unsupported: Modular-encoded frame on the device path"; return -1; }
+  if (f.upsampling != 1) { plan->error = "unsupported: upsampling"; return -1; }
+  if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) { plan->error = "unsupported: cropped frame"; return -1; }
+  if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
+  if (f.flags & (1 | 2 | 16 | 32)) { plan->error = "unsupported: patches/splines/noise/LF frame"; return -1; }
+  if (f.group_dim != 256) { plan->error = "unsupported: group size"; return -1; }
+  // ---- TOC
+  int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
+  std::vector<uint32_t> perm;
+  if (hx_bool(&br)) {
+    hx_ec tc;
+    if (hx_ec_read_header(&tc, &br, 8)) { plan->error = "bad TOC permutation code"; return -1; }
+    hx_ec_begin(&tc, &br, 0);
+    perm.resize((size_t)nsec);
+    int e = hx_read_permutation(&tc, &br, perm.data(), (uint32_t)nsec, 0);
+    int ok = hx_ec_final_ok(&tc);
+    hx_ec_free(&tc);
+    if (e || !ok) { plan->error = "bad TOC permutation"; return -1; }
+  }
+  hx_align(&br);
+  std::vector<uint32_t> sz((size_t)nsec);
+  for (int i = 0; i < nsec; i++) sz[(size_t)i] = hx_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
+  hx_align(&br);
+  std::vector<DevSection> &secs = pv->secs;
+  secs.resize((size_t)nsec);
+  {
+    size_t base = br.pos / 8, acc = 0;
+    std::vector<size_t> phys((size_t)nsec);
+    for (int i = 0; i < nsec; i++) { phys[(size_t)i] = base + acc; acc += sz[(size_t)i]; }
+    if (base + acc > csn || br.err) { plan->error = "truncated file (TOC exceeds input)"; return -1; }
+    for (int i = 0; i < nsec; i++) {
+      size_t src = perm.empty() ? (size_t)i : perm[(size_t)i];
+      secs[(size_t)i].off = (uint32_t)phys[src]; secs[(size_t)i].size = sz[src];
+    }
+  }
+  // ---- DevFrame
+  DevFrame &F = pv->F;
+  memset(&F, 0, sizeof(F));
+  F.width = f.width; F.height = f.height;
+  F.xb = (f.width + 7) / 8; F.yb = (f.height + 7) / 8; F.pw = F.xb * 8; F.ph = F.yb * 8;
+  F.tiles_x = (F.xb + 7) / 8; F.tiles_y = (F.yb + 7) / 8;
+  F.xgroups = f.xgroups; F.ygroups = f.ygroups; F.num_groups = f.num_groups;
+  F.xlfg = f.xlfg; F.ylfg = f.ylfg; F.num_lf_groups = f.num_lf_groups;
+  F.num_passes = f.num_passes;
+  for (int i = 0; i < 12; i++) F.pass_shift[i] = i < f.num_passes - 1 ? f.pass_shift[i] : 0;
+  F.nsec = nsec;
+  plan->tables.assign(((sizeof(DevFrame) + 15) / 16) * 16, 0);
+  Blob blob(plan->tables);
+  F.sec_off = blob.append(secs.data(), secs.size() * sizeof(DevSection));
+  // ---- LfGlobal (section 0)
+  hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
+  float lf_dequant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  if (!hx_bool(&sb)) for (int c = 0; c < 3; c++) lf_dequant[c] = hx_f16(&sb) * (1.0f / 128);
+  uint32_t global_scale = hx_u32(&sb, 11, 1, 11, 2049, 12, 4097, 16, 8193);
+  uint32_t quant_lf = hx_u32(&sb, -1, 16, 5, 1, 8, 1, 16, 1);
+  std::vector<uint8_t> bctx;
+  if (hx_bool(&sb)) { bctx.assign(kDefaultBlockCtxMap, kDefaultBlockCtxMap + 39); F.num_bctx = 15; }
+  else {
+    int nlf = 1;
+    for (int c = 0; c < 3; c++) {
+      F.nb_lf_thr[c] = (int)hx_bits(&sb, 4);
+      for (int i = 0; i < F.nb_lf_thr[c]; i++) F.lf_thr[c][i] = hx_unpack_signed(hx_u32(&sb, 4, 0, 8, 16, 16, 272, 32, 65808));
+      nlf *= F.nb_lf_thr[c] + 1;
+    }
+    F.nb_qf_thr = (int)hx_bits(&sb, 4);
+    for (int i = 0; i < F.nb_qf_thr; i++) F.qf_thr[i] = 1 + hx_u32(&sb, 2, 0, 3, 4, 5, 12, 8, 44);
+    size_t n = (size_t)39 * (size_t)(F.nb_qf_thr + 1) * (size_t)nlf;
+    if (n > 39 * 64 || nlf > 64) { plan->error = "block ctx map too large"; return -1; }
+    bctx.assign(n, 0);
+    if (hx__read_ctx_map(&sb, bctx.data(), (int)n, &F.num_bctx)) { plan->error = "bad block ctx map"; return -1; }
+  }
+  F.bctx_map_off = blob.append(bctx.data(), bctx.size());
+  uint32_t color_factor = 84; float base_x = 0.0f, base_b = 1.0f; int ytox_dc = 0, ytob_dc = 0;
+  if (!hx_bool(&sb)) {
+    color_factor = hx_u32(&sb, -1, 84, -1, 256, 8, 2, 16, 258);
+    base_x = hx_f16(&sb); base_b = hx_f16(&sb);
+    ytox_dc = (int)hx_bits(&sb, 8) - 128; ytob_dc = (int)hx_bits(&sb, 8) - 128;
+  }
+  // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
+  hx_tree tree; memset(&tree, 0, sizeof(tree));
+  if (hx_bool(&sb)) {
+    if (hx_tree_read(&tree, &sb)) { plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
+  } else { plan->error = "unsupported: VarDCT frame without a global MA tree"; return -1; }
+  if (sb.err) { hx_tree_free(&tree); plan->error = "truncated LfGlobal"; return -1; }
+  {
+    std::vector<DevTreeNode> nodes((size_t)tree.count);
+    for (int i = 0; i < tree.count; i++) {
+      DevTreeNode &d = nodes[(size_t)i]; const hx_tnode &s = tree.n[i];
+      memset(&d, 0, sizeof(d));
+      if (s.prop < 0) { d.prop = -1; d.splitval = s.ctx; d.lchild = s.predictor; d.rchild = (int32_t)s.multiplier; d.offset = (int32_t)s.offset; }
+      else { d.prop = s.prop; d.splitval = s.splitval; d.lchild = s.lchild; d.rchild = s.rchild; }
+    }
+    F.tree_count = tree.count;
+    F.tree_off = blob.append(nodes.data(), nodes.size() * sizeof(DevTreeNode));
+    int rc = pack_ec(tree.code, blob, &F.tree_ec, &plan->error);
+    hx_tree_free(&tree);
+    if (rc) return -1;
+  }
+  plan->lf_global_end_bit = (uint32_t)sb.pos;
+  F.single_lf_bit = (uint32_t)sb.pos;
+  // quantiser-derived constants
+  float inv_quant_dc = 65536.0f / ((float)global_scale * (float)quant_lf);
+  for (int c = 0; c < 3; c++) F.lf_fac[c] = lf_dequant[c] * inv_quant_dc;
+  F.cfl_dc_x = base_x + (float)ytox_dc / (float)color_factor;
+  F.cfl_dc_b = base_b + (float)ytob_dc / (float)color_factor;
+  F.inv_global_scale = 65536.0f / (float)global_scale;
+  F.quant_scale = (float)global_scale / 65536.0f;
+  F.dm[0] = powf(1.0f / 1.25f, (float)f.x_qm - 2.0f); F.dm[1] = 1.0f; F.dm[2] = powf(1.0f / 1.25f, (float)f.b_qm - 2.0f);
+  F.base_x = base_x; F.base_b = base_b; F.inv_color_factor = 1.0f / (float)color_factor;
+  memcpy(F.quant_bias, m.quant_bias, sizeof(F.quant_bias));
+  F.skip_lf_smoothing = (f.flags & 128) ? 1 : 0;
+  F.gab = f.gab; memcpy(F.gab_w, f.gab_w, sizeof(F.gab_w));
+  F.epf_iters = f.epf_iters; memcpy(F.epf_sharp, f.epf_sharp, sizeof(F.epf_sharp)); memcpy(F.epf_chscale, f.epf_chscale, sizeof(F.epf_chscale));
+  F.epf_quant_mul = f.epf_quant_mul; F.epf_pass0 = f.epf_pass0; F.epf_pass2 = f.epf_pass2; F.epf_border_sad = f.epf_border_sad;
+  // colour: opsin inverse scaled to display-relative linear, then to the data profile's primaries
+  {
+    double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (m.pub.white_point != 1) { plan->error = "unsupported: non-D65 white point"; return -1; }
+    if (m.pub.primaries != 1) {
+      static const double srgb[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
+      double dst[8];
+      if (m.pub.primaries == 9) { double t[8] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
+      else if (m.pub.primaries == 11) { double t[8] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
+      else { plan->error = "unsupported: custom primaries"; return -1; }
+      double A[9], Bm[9], Bi[9];
+      primaries_to_xyz(srgb, A); primaries_to_xyz(dst, Bm); inv3(Bm, Bi);
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { T[r * 3 + c] = 0; for (int k = 0; k < 3; k++) T[r * 3 + c] += Bi[r * 3 + k] * A[k * 3 + c]; }
+    }
+    float itscale = 255.0f / m.pub.intensity_target;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+      double s = 0; for (int k = 0; k < 3; k++) s += T[r * 3 + k] * (double)m.opsin_inv[k * 3 + c];
+      F.opsin_inv[r * 3 + c] = (float)(s * itscale);
+    }
+    for (int c = 0; c < 3; c++) { F.opsin_bias[c] = m.opsin_bias[c]; F.opsin_bias_cbrt[c] = cbrtf(m.opsin_bias[c]); }
+    F.transfer = m.pub.have_gamma ? -1 : (int)m.pub.transfer_function;
+    if (!m.pub.have_gamma && F.transfer != 13 && F.transfer != 8 && F.transfer != 16 && F.transfer != 1) { plan->error = "unsupported: transfer function"; return -1; }
+    F.gamma = m.pub.gamma; F.intensity_target = m.pub.intensity_target;
+  }
+  F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;
+  plan->single_section = nsec == 1;
+  plan->xb = F.xb; plan->yb = F.yb; plan->num_groups = F.num_groups; plan->num_lf_groups = F.num_lf_groups;
+  plan->num_passes = F.num_passes; plan->width = F.width; plan->height = F.height;
+  if (!plan->single_section) {
+    hx_br hb; hx_br_init(&hb, plan->cs + secs[(size_t)(1 + f.num_lf_groups)].off, secs[(size_t)(1 + f.num_lf_groups)].size);
+    if (parse_hf_global(plan, pv, &hb)) return -1;
+  }
+  finish_blob(plan, pv);
+  return 0;
+}
+
+int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit) {
+  Priv *pv = (Priv *)plan->priv.get();
+  hx_br hb; hx_br_init(&hb, plan->cs + pv->secs[0].off, plan->cs_size - pv->secs[0].off);
+  hb.pos = (size_t)lf_end_bit;
+  if (parse_hf_global(plan, pv, &hb)) return -1;
+  pv->F.single_pass_bit = (uint32_t)hb.pos;
+  finish_blob(plan, pv);
+  return 0;
+}
+
+const std::vector<uint8_t> &static_tables() {
+  static std::vector<uint8_t> tab;
+  if (!tab.empty()) return tab;
+  std::vector<uint8_t> v(((sizeof(DevStatic) + 15) / 16) * 16, 0);
+  Blob blob(v);
+  DevStatic ST; memset(&ST, 0, sizeof(ST));
+  init_quant_tables();
+  for (int t = 0; t < 17; t++) {
+    size_t n = (size_t)kQTRows[t] * 8 * (size_t)kQTCols[t] * 8;
+    for (int c = 0; c < 3; c++) {
+      std::vector<float> inv(n);
+      for (size_t i = 0; i < n; i++) inv[i] = 1.0f / qt_weights[t][c][i];
+      ST.qw_off[t][c] = blob.append(inv.data(), n * 4);
+    }
+  }
+  for (int l = 0; l < 9; l++) {
+    int n = 1 << l;
+    std::vector<float> c((size_t)n * (size_t)n);
+    for (int k = 0; k < n; k++) for (int i = 0; i < n; i++) c[(size_t)k * n + i] = (float)((k ? sqrt(2.0) : 1.0) * cos((2 * i + 1) * k * PI / (2.0 * n)));
+    ST.cos_off[l] = blob.append(c.data(), c.size() * 4);
+  }
+  { float a[256]; for (int j = 0; j < 16; j++) for (int i = 0; i < 16; i++) a[j * 16 + i] = (float)kAFVBasis[j][i]; ST.afv_off = blob.append(a, sizeof(a)); }
+  ST.dither_off = blob.append(kDither32, sizeof(kDither32));
+  { float l[6 * 32]; memset(l, 0, sizeof(l));
+    for (int i = 0; i < 6; i++) { int N = 1 << i; for (int k = 0; k < N; k++) { double t = k * PI / (16.0 * N); l[i * 32 + k] = (float)(1.0 / (cos(t) * cos(2 * t) * cos(4 * t))); } }
+    ST.llf_off = blob.append(l, sizeof(l)); }
+  memcpy(v.data(), &ST, sizeof(ST));
+  tab.swap(v);
+  return tab;
+}
+
+}  // namespace jxlamd

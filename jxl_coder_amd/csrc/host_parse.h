@@ -1,0 +1,51 @@
+// jxl_coder_amd/csrc/host_parse.h — host side of the decode: parses container, codestream headers, TOC and the
+// global sections (LfGlobal, HfGlobal) and packs everything the kernels need into one "frame tables" blob
+// (dev_types.h).  No pixel work happens on the host.
+#pragma once
+#include <stdint.h>
+#include <memory>
+#include <string>
+#include <vector>
+#include "dev_types.h"
+
+namespace jxlamd {
+
+struct ImageInfo {            // what DecodeJpegXlOneShot / DecodeBasicInfo report (JxlBasicInfo + colour encoding subset)
+  uint32_t xsize = 0, ysize = 0;          // oriented
+  uint32_t bits_per_sample = 8, exp_bits = 0;
+  uint32_t num_color_channels = 3, num_extra_channels = 0, alpha_bits = 0, alpha_premultiplied = 0;
+  uint32_t orientation = 1;               // reported AFTER re-orientation, like libjxl (always 1)
+  uint32_t have_animation = 0, xyb_encoded = 1, uses_original_profile = 0;
+  float intensity_target = 255.f;
+  uint32_t want_icc = 0;
+  uint32_t color_space = 0, white_point = 1, primaries = 1, transfer_function = 13, rendering_intent = 1;
+  uint32_t have_gamma = 0; float gamma = 0;
+};
+
+struct FramePlan {
+  ImageInfo info;
+  const uint8_t *cs = nullptr; size_t cs_size = 0;      // codestream bytes (may alias the input)
+  std::vector<uint8_t> cs_owned;                         // assembled from jxlp boxes when needed
+  std::vector<uint8_t> tables;                           // blob: DevFrame at 0
+  bool single_section = false;
+  bool hf_parsed = false;
+  uint32_t lf_global_end_bit = 0;                        // single-section: where LfGroup 0 begins
+  // geometry copies for the launcher
+  int xb = 0, yb = 0, num_groups = 0, num_lf_groups = 0, num_passes = 1, width = 0, height = 0;
+  std::string error;
+  // internal parse state kept between phase 1 and 2 (single-section frames)
+  std::shared_ptr<void> priv;
+};
+
+// Phase 1: everything up to and including LfGlobal; for multi-section frames also HfGlobal (phase 2 implicit).
+// Returns 0 on success; on failure plan->error says why (unsupported feature or corrupt stream).
+int plan_parse(const uint8_t *data, size_t size, FramePlan *plan);
+// Phase 2 for single-section frames: HfGlobal starts at `lf_end_bit` (reported by the LF kernel).
+int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit);
+// Header-only parse (DecodeBasicInfo).
+int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error);
+
+// Per-process constant tables (inverse quant weights, cosine bases, AFV basis, dither LUT); header DevStatic at 0.
+const std::vector<uint8_t> &static_tables();
+
+}  // namespace jxlamd

@@ -1,0 +1,13 @@
+// jxl_coder_amd/csrc/kernels.h — launch interface of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_bodies.h"
+namespace jxlamd {
+void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, hipStream_t s);
+void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);
+void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);
+void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s);
+// filters ping-pong between plane_a and plane_b; `src_is_a` tells where the current image is; returns the new flag
+bool launch_filters(const DevBuffers &B, int width, int height, int gab, int epf_iters, bool src_is_a, hipStream_t s);
+void launch_write(const DevBuffers &B, const uint8_t *stat, int width, int height, int out_bits, bool src_is_a, hipStream_t s);
+}  // namespace jxlamd

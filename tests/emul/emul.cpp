@@ -1,0 +1,82 @@
+// tests/emul/emul.cpp — TEST-ONLY harness: runs the product's device code (jxl_coder_amd/csrc/dev_*.h, the
+// exact functions the HIP kernels wrap) on the CPU, one "workgroup" at a time as a single serial thread
+// (nthreads = 1, barriers are no-ops).  It lets the CPU test suite check the bitstream logic and the table
+// packing of the product's host parser without a GPU.  It is never linked into libjxlamd.so and is not a
+// fallback: the product fails loudly without a HIP device.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../jxl_coder_amd/csrc/dev_bodies.h"
+#include "../../jxl_coder_amd/csrc/host_parse.h"
+
+using namespace jxlamd;
+struct NoSync { void operator()() const {} };
+static std::string g_err;
+
+extern "C" const char *emul_last_error() { return g_err.c_str(); }
+
+extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t *out, size_t out_cap, uint32_t *w, uint32_t *h, uint32_t *bits) {
+  FramePlan plan;
+  if (plan_parse(jxl, size, &plan)) { g_err = plan.error; return -1; }
+  const int out_bits = (plan.info.bits_per_sample > 8 && allow16) ? 16 : 8;
+  *w = plan.info.xsize; *h = plan.info.ysize; *bits = (uint32_t)out_bits;
+  const size_t out_bytes = (size_t)plan.info.xsize * plan.info.ysize * 4 * (out_bits / 8);
+  if (out_cap < out_bytes) { g_err = "buffer"; return -5; }
+  const size_t ncell = (size_t)plan.xb * plan.yb, ntile = (size_t)((plan.xb + 7) / 8) * ((plan.yb + 7) / 8), npx = ncell * 64;
+  std::vector<uint8_t> cs(plan.cs, plan.cs + plan.cs_size); cs.resize(cs.size() + 64, 0);
+  std::vector<uint8_t> c8[5]; for (auto &v : c8) v.assign(ncell, 0);
+  std::vector<int8_t> tl[2]; for (auto &v : tl) v.assign(ntile, 0);
+  std::vector<float> lf[6]; for (auto &v : lf) v.assign(ncell, 0.f);
+  std::vector<uint32_t> coef_off(ncell, 0);
+  std::vector<int32_t> coef[3]; for (auto &v : coef) v.assign((size_t)plan.num_groups * 65536, 0);
+  std::vector<float> pl[6]; for (auto &v : pl) v.assign(npx, 0.f);
+  std::vector<int32_t> scr((size_t)plan.num_lf_groups * kLfScratchInts, 0);
+  std::vector<uint64_t> endbits((size_t)plan.num_lf_groups, 0);
+  uint32_t err = 0;
+  std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
+  DevBuffers B; memset(&B, 0, sizeof(B));
+  B.codestream = cs.data(); B.tables = tables.data();
+  memset(c8[0].data(), 0xFF, ncell);
+  B.strategy = c8[0].data(); B.first = c8[1].data(); B.qfm1 = c8[2].data(); B.sharp = c8[3].data(); B.lf_idx = c8[4].data();
+  B.xfromy = tl[0].data(); B.bfromy = tl[1].data();
+  for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
+  B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = &err; B.out = out;
+  DevAux A; A.lf_end_bits = endbits.data();
+  const std::vector<uint8_t> &stat = static_tables();
+  DevModScratch *MS = new DevModScratch();
+  for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
+  delete MS;
+  if (err) { g_err = "device flags " + std::to_string(err) + " (LfGroup)"; return -2; }
+  if (plan.single_section) {
+    if (plan_parse_hf_single(&plan, endbits[0])) { g_err = plan.error; return -1; }
+    tables = plan.tables; B.tables = tables.data();
+  }
+  for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) lf_smooth_cell(B, x, y);
+  DevPassScratch *PS = new DevPassScratch();
+  for (int g = 0; g < plan.num_groups; g++) pass_group_body(B, *PS, g, 0, 1, NoSync());
+  delete PS;
+  if (err) { g_err = "device flags " + std::to_string(err) + " (PassGroup)"; return -2; }
+  std::vector<float> S(3 * 4096), T(4096);
+  for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
+    recon_block_body(B, stat.data(), S.data(), T.data(), x, y, false, 0, 1, NoSync());
+    recon_block_body(B, stat.data(), S.data(), T.data(), x, y, true, 0, 1, NoSync());
+  }
+  if (err) { g_err = "device flags " + std::to_string(err) + " (recon)"; return -2; }
+  const DevFrame &F = *(const DevFrame *)tables.data();
+  bool a = true;
+  auto planes = [&](bool isa, float *p[3]) { for (int c = 0; c < 3; c++) p[c] = isa ? B.plane_a[c] : B.plane_b[c]; };
+  float *src[3], *dst[3];
+  if (F.gab) { planes(a, src); planes(!a, dst); for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) gab_pixel(F, src, dst, x, y); a = !a; }
+  for (int pass = 0; pass < 3; pass++) {
+    bool run = pass == 0 ? F.epf_iters >= 3 : pass == 1 ? F.epf_iters >= 1 : F.epf_iters >= 2;
+    if (!run) continue;
+    planes(a, src); planes(!a, dst);
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) epf_pixel(B, F, src, dst, pass, x, y);
+    a = !a;
+  }
+  planes(a, src);
+  for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) xyb_write_pixel(B, stat.data(), *(const DevStatic *)stat.data(), src, out_bits, x, y);
+  return 0;
+}

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ (run in the build container, where /root/reference exists).
+
+Inputs : seeded synthetic images (tools/synth.py) encoded by the reference's own libjxl encoder through
+         oracle/_ref with the reference's call sequence (interop/JxlEncoding.cpp:54-192); "q90" = distance 1.0
+         (JXLGetDistance, interop/JxlEncoding.cpp:38-46).
+Expected: RGBA output + the DecodeJpegXlOneShot out-params of the reference's libjxl decoder (oracle/_ref),
+         stored as compressed .npz next to each .jxl.  Data only; the reference itself does not travel.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import jxl_ref  # noqa: E402
+import synth  # noqa: E402
+
+CASES = {
+    # name: (w, h, synth kwargs, encode kwargs)
+    "v64_e3_gab0_epf0": (64, 64, dict(seed=1), dict(effort=3, gaborish=0, epf=0)),
+    "v256_e3_gab0_epf0": (256, 256, dict(seed=1), dict(effort=3, gaborish=0, epf=0)),
+    "v256_e3_gab1_epf0": (256, 256, dict(seed=1), dict(effort=3, gaborish=1, epf=0)),
+    "v256_e3_gab0_epf1": (256, 256, dict(seed=1), dict(effort=3, gaborish=0, epf=1)),
+    "v256_e3_gab0_epf2": (256, 256, dict(seed=1), dict(effort=3, gaborish=0, epf=2)),
+    "v256_e3_gab0_epf3": (256, 256, dict(seed=1), dict(effort=3, gaborish=0, epf=3)),
+    "v256_e7": (256, 256, dict(seed=1), dict(effort=7)),
+    "v264x520_e7": (264, 520, dict(seed=1), dict(effort=7)),
+    "v267x131_e7": (267, 131, dict(seed=2), dict(effort=7)),
+    "v300x300_e7_d3": (300, 300, dict(seed=3), dict(effort=7, distance=3.0)),
+    "v64_hard_e7": (64, 64, dict(seed=4, hard=True), dict(effort=7)),
+    "l64_e1": (64, 64, dict(seed=1), dict(lossless=True, effort=1)),
+    "l64_e3": (64, 64, dict(seed=1), dict(lossless=True, effort=3)),
+    "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),
+    "l200x120_e7": (200, 120, dict(seed=5), dict(lossless=True, effort=7)),
+}
+
+
+def main():
+    meta = {}
+    for name, (w, h, sk, ek) in CASES.items():
+        img = synth.photo_like(w, h, **sk)
+        data = jxl_ref.encode(img, **ek)
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
+        info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, encode=ek, synth=sk)
+        print(name, len(data), out.shape)
+    # the bench frame: 4K q90 (BASELINE.json configs[1]); expected pixels are too large to commit -> hash only
+    img = synth.photo_like(3840, 2160, seed=0)
+    data = jxl_ref.encode(img, effort=7, distance=1.0)
+    os.makedirs(os.path.join(ROOT, "bench_data"), exist_ok=True)
+    open(os.path.join(ROOT, "bench_data", "syn4k_q90_seed0.jxl"), "wb").write(data)
+    out, info, _ = jxl_ref.decode(data)
+    import hashlib
+    meta["syn4k_q90_seed0"] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype),
+                                   sha256=hashlib.sha256(out.tobytes()).hexdigest(),
+                                   row_sums=[int(x) for x in out[::240].astype(np.int64).sum(axis=(1, 2))])
+    json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
