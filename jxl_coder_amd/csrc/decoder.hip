@@ -36,7 +36,7 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem cs, tables, stat, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, misc, out;
+  DevMem cs, tables, stat, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out;
   bool stat_uploaded = false;
   float timing[5] = {0, 0, 0, 0, 0};
   void set_error(const std::string &e) { error = e; g_tls_error = e; }
@@ -113,6 +113,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   for (int c = 0; c < 3; c++) HIPCHECK(coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
   for (int i = 0; i < 6; i++) HIPCHECK(planes[i].ensure(npx * 4));
   HIPCHECK(lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
+  HIPCHECK(local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
   HIPCHECK(misc.ensure(4096 + (size_t)plan.num_lf_groups * 8));
   void *d_out = out_ptr;
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(out.ensure(out_bytes)); d_out = out.p; }
@@ -124,7 +125,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   B.xfromy = (int8_t *)tiles[0].p; B.bfromy = (int8_t *)tiles[1].p;
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)lf[c].p; B.lf_s[c] = (float *)lf[3 + c].p; B.coef[c] = (int32_t *)coef[c].p;
                                 B.plane_a[c] = (float *)planes[c].p; B.plane_b[c] = (float *)planes[3 + c].p; }
-  B.coef_off = (uint32_t *)coef_off.p; B.lf_scratch = (int32_t *)lf_scratch.p;
+  B.coef_off = (uint32_t *)coef_off.p; B.lf_scratch = (int32_t *)lf_scratch.p; B.local = (LocalTreeScratch *)local.p;
   B.err = (uint32_t *)misc.p; B.out = (uint8_t *)d_out;
   DevAux A; A.lf_end_bits = (uint64_t *)((uint8_t *)misc.p + 4096);
   HIPCHECK(hipMemsetAsync(misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 8, stream));
@@ -190,7 +191,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  DevMem *all[] = {&d->cs, &d->tables, &d->stat, &d->coef_off, &d->lf_scratch, &d->misc, &d->out};
+  DevMem *all[] = {&d->cs, &d->tables, &d->stat, &d->coef_off, &d->lf_scratch, &d->local, &d->misc, &d->out};
   for (auto *m : all) m->release();
   for (auto &m : d->cells8) m.release();
   for (auto &m : d->tiles) m.release();

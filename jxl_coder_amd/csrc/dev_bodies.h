@@ -13,11 +13,6 @@ struct DevAux {
 // ---- LfGroup: one workgroup (one wave) per 2048x2048 LF group
 template <class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
-  const DevFrame &F = frame_of(B);
-  const DevTreeNode *gtree = (const DevTreeNode *)(B.tables + F.tree_off);
-  const int ncache = F.tree_count < kTreeLds ? F.tree_count : kTreeLds;
-  for (int i = tid; i < ncache; i += nthreads) S.tree[i] = gtree[i];
-  sync();
   if (tid == 0) {
     uint32_t err = lf_group_serial(B, S, g, A.lf_end_bits);
     if (err) *B.err |= err;   // benign race: any set bit fails the frame

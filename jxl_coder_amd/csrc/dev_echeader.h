@@ -1,0 +1,367 @@
+// jxl_coder_amd/csrc/dev_echeader.h — device-side parser for entropy-code HEADERS and MA trees that live INSIDE
+// group sections (ISO/IEC 18181-1 Annex C.2 / D.3 / H.4.2): libjxl's streaming encoder (used for frames of
+// 2048x2048 and up, i.e. the 4K benchmark frame) gives every LfGroup stream its own MA tree and histograms
+// instead of a global one, and the second stream's header sits behind the first stream's data — so its bit
+// position is only known on the device.  Lane 0 of the section's wavefront parses: LZ77 flag (must be off),
+// context map (simple / entropy-coded + MTF), prefix (Brotli-style) or ANS histograms, alias tables, and the
+// tree itself, into per-section scratch memory in HBM.
+#pragma once
+#include "dev_entropy.h"
+
+namespace jxlamd {
+
+constexpr int kLocMaxClusters = 64;
+constexpr int kLocMaxCtx = 4096;
+constexpr int kLocMaxNodes = 2 * kLocMaxCtx;
+constexpr int kLocPool = 1 << 16;
+
+struct LocalEC {
+  uint8_t ctx_map[kLocMaxCtx + 8];
+  uint32_t cfg[kLocMaxClusters];
+  DevAlias alias[kLocMaxClusters * 256];
+  DevPrefix prefix[kLocMaxClusters];
+  uint16_t pool[kLocPool];
+  uint32_t pool_used;
+  int32_t num_ctx, num_clusters, use_prefix, log_alpha;
+};
+
+struct LocalTreeScratch {       // per LF group, reused by its two streams
+  LocalEC tree_code;            // 6 contexts
+  LocalEC leaf_code;
+  LocalEC nested;               // for entropy-coded context maps
+  DevTreeNode nodes[kLocMaxNodes];
+  uint8_t lens[1 << 15];        // prefix-code lengths scratch
+  int32_t count;
+};
+
+JXL_DEV DevECView local_view(const LocalEC &e) {
+  DevECView v;
+  v.ctx_map = e.ctx_map; v.cfg = e.cfg; v.alias = e.alias; v.prefix = e.prefix; v.pool = e.pool;
+  v.use_prefix = e.use_prefix; v.log_alpha = e.log_alpha;
+  return v;
+}
+
+JXL_DEV int dceil_log2(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
+
+JXL_DEV uint32_t d_read_huc(DevBits &b, int log_alpha, uint32_t &err) {
+  uint32_t split = bits_read(b, dceil_log2((uint32_t)log_alpha + 1)), msb = 0, lsb = 0;
+  if ((int)split != log_alpha) {
+    msb = bits_read(b, dceil_log2(split + 1));
+    if (msb > split) { err |= kErrBitstream; msb = split; }
+    lsb = bits_read(b, dceil_log2(split - msb + 1));
+    if (lsb + msb > split) { err |= kErrBitstream; lsb = 0; }
+  }
+  return split | (msb << 8) | (lsb << 16);
+}
+
+JXL_DEV uint32_t d_varlen_u8(DevBits &b) {
+  if (!bits_read(b, 1)) return 0;
+  int n = (int)bits_read(b, 3);
+  if (n == 0) return 1;
+  return bits_read(b, n) + (1u << n);
+}
+
+// ANS histogram (12-bit) into D[table]; returns error bits
+JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table) {
+  for (int i = 0; i < table; i++) D[i] = 0;
+  if (bits_read(b, 1)) {
+    int ns = (int)bits_read(b, 1) + 1;
+    uint32_t s0 = d_varlen_u8(b), s1 = 0;
+    if (ns == 2) s1 = d_varlen_u8(b);
+    if ((int)s0 >= table || (int)s1 >= table) return kErrBitstream;
+    if (ns == 1) D[s0] = 4096;
+    else { if (s0 == s1) return kErrBitstream; D[s0] = (uint16_t)bits_read(b, 12); D[s1] = (uint16_t)(4096 - D[s0]); }
+    return 0;
+  }
+  if (bits_read(b, 1)) {
+    int n = (int)d_varlen_u8(b) + 1;
+    if (n > table) return kErrBitstream;
+    for (int i = 0; i < n; i++) D[i] = (uint16_t)(4096 / n + (i < 4096 % n ? 1 : 0));
+    return 0;
+  }
+  int len = 0;
+  while (len < 3 && bits_read(b, 1)) len++;
+  int shift = (int)((bits_read(b, len) | (1u << len)) - 1);
+  if (shift > 13) return kErrBitstream;
+  int n = (int)d_varlen_u8(b) + 3;
+  if (n > table) return kErrBitstream;
+  uint8_t logc[258]; uint16_t same[258]; int16_t cnt[258];
+  for (int i = 0; i < n; i++) { same[i] = 0; cnt[i] = 0; logc[i] = 0; }
+  int omit_log = -1, omit_pos = -1;
+  for (int i = 0; i < n; i++) {
+    uint32_t idx = bits_peek(b, 7);
+    int l, v;
+    uint32_t lo = idx & 15;
+    const uint32_t len_tab = 0x43334343u, len_tab2 = 0x43334303u;   // nibble tables: lengths for lo = 8..15 / 0..7
+    const uint64_t val_tab = 0x2986174A5986370Aull;                 // values (hex digits) for lo = 0..15
+    if (lo != 1) { l = (int)(((lo < 8 ? len_tab2 : len_tab) >> (4 * (lo & 7))) & 15); v = (int)((val_tab >> (4 * lo)) & 15); }
+    else if (idx & 16) { l = 5; v = 0; }
+    else if (idx & 32) { l = 6; v = 11; }
+    else if (idx & 64) { l = 7; v = 13; }
+    else { l = 7; v = 12; }
+    bits_skip(b, l);
+    logc[i] = (uint8_t)v;
+    if (v == 13) {
+      int rle = (int)d_varlen_u8(b);
+      same[i] = (uint16_t)(rle + 5);
+      i += rle + 3;
+      continue;
+    }
+    if (v > omit_log) { omit_log = v; omit_pos = i; }
+  }
+  if (omit_pos < 0) return kErrBitstream;
+  if (omit_pos + 1 < n && logc[omit_pos + 1] == 13) return kErrBitstream;
+  int prev = 0, numsame = 0, total = 0;
+  for (int i = 0; i < n; i++) {
+    if (same[i]) { numsame = same[i] - 1; prev = i > 0 ? cnt[i - 1] : 0; }
+    if (numsame > 0) { cnt[i] = (int16_t)prev; numsame--; }
+    else {
+      int code = logc[i];
+      if (i == omit_pos || code == 0) continue;
+      if (code == 1) cnt[i] = 1;
+      else {
+        int lc = code - 1;
+        int bc = shift - ((12 - lc) >> 1);
+        if (bc > lc) bc = lc;
+        if (bc < 0) bc = 0;
+        cnt[i] = (int16_t)((1 << lc) + (int)(bits_read(b, bc) << (lc - bc)));
+      }
+    }
+    total += cnt[i];
+  }
+  int rest = 4096 - total;
+  if (rest <= 0) return kErrBitstream;
+  cnt[omit_pos] = (int16_t)rest;
+  for (int i = 0; i < n; i++) D[i] = (uint16_t)cnt[i];
+  return 0;
+}
+
+JXL_DEV void d_build_alias(const uint16_t *D, int log_alpha, DevAlias *a) {
+  const int table = 1 << log_alpha, bucket = 4096 >> log_alpha;
+  for (int s = 0; s < table; s++)
+    if (D[s] == 4096) {
+      for (int i = 0; i < table; i++) { a[i].cutoff = 0; a[i].right = (uint8_t)s; a[i].off1 = (uint16_t)(bucket * i); a[i].freq0 = 4096; a[i].freq1 = 4096; }
+      return;
+    }
+  uint16_t cut[256]; uint16_t under[512], over[512]; uint8_t right[256]; uint16_t off[256];
+  int nu = 0, no = 0;
+  int n = table;
+  while (n > 0 && D[n - 1] == 0) n--;
+  for (int i = 0; i < table; i++) { right[i] = 0; off[i] = 0; }
+  for (int i = 0; i < n; i++) { cut[i] = D[i]; if (cut[i] > bucket) over[no++] = (uint16_t)i; else if (cut[i] < bucket) under[nu++] = (uint16_t)i; }
+  for (int i = n; i < table; i++) { cut[i] = 0; under[nu++] = (uint16_t)i; }
+  while (no > 0 && nu > 0) {
+    int o = over[--no], u = under[--nu];
+    int by = bucket - cut[u];
+    cut[o] = (uint16_t)(cut[o] - by);
+    right[u] = (uint8_t)o; off[u] = cut[o];
+    if (cut[o] < bucket) under[nu++] = (uint16_t)o; else if (cut[o] > bucket) over[no++] = (uint16_t)o;
+  }
+  for (int i = 0; i < table; i++) {
+    if (cut[i] == bucket) { a[i].right = (uint8_t)i; a[i].off1 = 0; a[i].cutoff = 0; }
+    else { a[i].right = right[i]; a[i].off1 = (uint16_t)(off[i] - cut[i]); a[i].cutoff = (uint8_t)cut[i]; }
+    a[i].freq0 = D[i];
+    a[i].freq1 = D[a[i].right];
+  }
+}
+
+// canonical code from lengths -> DevPrefix (+ symbols appended to the pool)
+JXL_DEV uint32_t d_build_canonical(LocalEC &ec, DevPrefix &p, const uint8_t *lens, int n) {
+  for (int l = 0; l < 16; l++) p.cnt[l] = 0;
+  int nz = 0, last = -1;
+  for (int i = 0; i < n; i++) if (lens[i]) { p.cnt[lens[i]]++; nz++; last = i; }
+  if (ec.pool_used + (uint32_t)nz > (uint32_t)kLocPool) return kErrUnsupportedTransform;
+  p.sorted_off = ec.pool_used;
+  uint32_t offs[17]; offs[1] = 0;
+  for (int l = 1; l < 16; l++) offs[l + 1] = offs[l] + p.cnt[l];
+  for (int i = 0; i < n; i++) if (lens[i]) ec.pool[p.sorted_off + offs[lens[i]]++] = (uint16_t)i;
+  ec.pool_used += (uint32_t)nz;
+  p.single = nz == 1 ? last : nz == 0 ? 0 : -1;
+  return 0;
+}
+
+JXL_DEV int d_prefix_decode_raw(const DevPrefix &p, const uint16_t *pool, DevBits &b) {
+  if (p.single >= 0) return p.single;
+  int code = 0, first = 0, index = 0;
+  for (int len = 1; len <= 15; len++) {
+    code |= (int)bits_read(b, 1);
+    int count = p.cnt[len];
+    if (code - first < count) return pool[p.sorted_off + (uint32_t)(index + code - first)];
+    index += count; first += count; first <<= 1; code <<= 1;
+  }
+  return 0;
+}
+
+JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8_t *lens, int alphabet) {
+  for (int i = 0; i < alphabet; i++) lens[i] = 0;
+  if (alphabet == 1) { uint32_t e = d_build_canonical(ec, p, lens, 1); p.single = 0; return e; }
+  int hskip = (int)bits_read(b, 2);
+  if (hskip == 1) {
+    int max_bits = 0;
+    for (int t = alphabet - 1; t; t >>= 1) max_bits++;
+    int ns = (int)bits_read(b, 2) + 1;
+    int sym[4] = {0, 0, 0, 0};
+    for (int i = 0; i < ns; i++) { sym[i] = (int)bits_read(b, max_bits); if (sym[i] >= alphabet) return kErrBitstream; }
+    for (int i = 0; i < ns; i++) for (int j = i + 1; j < ns; j++) if (sym[i] == sym[j]) return kErrBitstream;
+    if (ns == 1) { uint32_t e = d_build_canonical(ec, p, lens, alphabet); p.single = sym[0]; return e; }
+    if (ns == 2) { lens[sym[0]] = 1; lens[sym[1]] = 1; }
+    else if (ns == 3) { lens[sym[0]] = 1; lens[sym[1]] = 2; lens[sym[2]] = 2; }
+    else if (bits_read(b, 1)) { lens[sym[0]] = 1; lens[sym[1]] = 2; lens[sym[2]] = 3; lens[sym[3]] = 3; }
+    else { lens[sym[0]] = lens[sym[1]] = lens[sym[2]] = lens[sym[3]] = 2; }
+    return d_build_canonical(ec, p, lens, alphabet);
+  }
+  const uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  const uint8_t cl_len[16] = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4};
+  const uint8_t cl_val[16] = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2, 0, 4, 3, 5};
+  uint8_t cll[18];
+  for (int i = 0; i < 18; i++) cll[i] = 0;
+  int space = 32, num_codes = 0;
+  for (int i = hskip; i < 18 && space > 0; i++) {
+    uint32_t pk = bits_peek(b, 4);
+    bits_skip(b, cl_len[pk]);
+    int v = cl_val[pk];
+    cll[order[i]] = (uint8_t)v;
+    if (v) { space -= 32 >> v; num_codes++; }
+  }
+  if (!(num_codes == 1 || space == 0)) return kErrBitstream;
+  // code-length code: tiny canonical decoder kept local
+  DevPrefix clp; uint16_t clsorted[18];
+  {
+    for (int l = 0; l < 16; l++) clp.cnt[l] = 0;
+    int nz = 0, last = -1;
+    for (int i = 0; i < 18; i++) if (cll[i]) { clp.cnt[cll[i]]++; nz++; last = i; }
+    uint32_t offs[17]; offs[1] = 0;
+    for (int l = 1; l < 16; l++) offs[l + 1] = offs[l] + clp.cnt[l];
+    for (int i = 0; i < 18; i++) if (cll[i]) clsorted[offs[cll[i]]++] = (uint16_t)i;
+    clp.sorted_off = 0; clp.single = nz == 1 ? last : nz == 0 ? 0 : -1;
+  }
+  int symbol = 0, prev_len = 8, repeat = 0, repeat_len = 0, sp = 32768;
+  while (symbol < alphabet && sp > 0) {
+    int cl = d_prefix_decode_raw(clp, clsorted, b);
+    if (cl < 16) {
+      repeat = 0;
+      lens[symbol++] = (uint8_t)cl;
+      if (cl) { prev_len = cl; sp -= 32768 >> cl; }
+    } else {
+      int extra = cl - 14;
+      int new_len = cl == 16 ? prev_len : 0;
+      if (repeat_len != new_len) { repeat = 0; repeat_len = new_len; }
+      int old = repeat;
+      if (repeat > 0) { repeat -= 2; repeat <<= extra; }
+      repeat += (int)bits_read(b, extra) + 3;
+      int delta = repeat - old;
+      if (symbol + delta > alphabet) return kErrBitstream;
+      for (int i = 0; i < delta; i++) lens[symbol++] = (uint8_t)repeat_len;
+      if (repeat_len) sp -= delta << (15 - repeat_len);
+    }
+  }
+  if (sp != 0) return kErrBitstream;
+  return d_build_canonical(ec, p, lens, alphabet);
+}
+
+JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens);
+
+JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_clusters, LocalEC *nested, uint8_t *lens) {
+  uint32_t err = 0;
+  if (bits_read(b, 1)) {
+    int nb = (int)bits_read(b, 2);
+    for (int i = 0; i < n; i++) map[i] = (uint8_t)bits_read(b, nb);
+  } else {
+    int use_mtf = (int)bits_read(b, 1);
+    if (!nested) return kErrBitstream;
+    err |= d_ec_read_header(b, 1, *nested, nullptr, lens);
+    if (err) return err;
+    DevECView v = local_view(*nested);
+    uint32_t state = ans_init(v, b);
+    for (int i = 0; i < n; i++) {
+      uint32_t val = ec_read(v, b, state, 0);
+      if (val > 255) return kErrBitstream;
+      map[i] = (uint8_t)val;
+    }
+    if (state != 0x130000u) return kErrAnsFinal;
+    if (use_mtf) {
+      uint8_t mtf[256];
+      for (int i = 0; i < 256; i++) mtf[i] = (uint8_t)i;
+      for (int i = 0; i < n; i++) {
+        uint8_t idx = map[i], val = mtf[idx];
+        map[i] = val;
+        for (; idx; idx--) mtf[idx] = mtf[idx - 1];
+        mtf[0] = val;
+      }
+    }
+  }
+  int mx = 0;
+  for (int i = 0; i < n; i++) if (map[i] > mx) mx = map[i];
+  num_clusters = mx + 1;
+  return err;
+}
+
+JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens) {
+  uint32_t err = 0;
+  if (num_ctx > kLocMaxCtx) return kErrUnsupportedTransform;
+  ec.num_ctx = num_ctx; ec.pool_used = 0;
+  if (bits_read(b, 1)) return kErrLz77;          // LZ77 inside a group-level code: not on the device
+  ec.num_clusters = 1;
+  for (int i = 0; i < num_ctx; i++) ec.ctx_map[i] = 0;
+  if (num_ctx > 1) { err |= d_read_ctx_map(b, ec.ctx_map, num_ctx, ec.num_clusters, nested, lens); if (err) return err; }
+  if (ec.num_clusters > kLocMaxClusters) return kErrUnsupportedTransform;
+  ec.use_prefix = (int)bits_read(b, 1);
+  ec.log_alpha = ec.use_prefix ? 15 : 5 + (int)bits_read(b, 2);
+  for (int i = 0; i < ec.num_clusters; i++) ec.cfg[i] = d_read_huc(b, ec.log_alpha, err);
+  if (ec.use_prefix) {
+    uint16_t counts[kLocMaxClusters];
+    for (int i = 0; i < ec.num_clusters; i++) {
+      if (!bits_read(b, 1)) counts[i] = 1;
+      else { int nb = (int)bits_read(b, 4); uint32_t c = 1 + (1u << nb) + bits_read(b, nb); if (c > (1u << 15)) return kErrBitstream; counts[i] = (uint16_t)c; }
+    }
+    for (int i = 0; i < ec.num_clusters; i++) { err |= d_read_prefix_code(b, ec, ec.prefix[i], lens, counts[i]); if (err) return err; }
+  } else {
+    const int table = 1 << ec.log_alpha;
+    uint16_t D[256];
+    for (int i = 0; i < ec.num_clusters; i++) {
+      err |= d_read_histogram(b, D, table);
+      if (err) return err;
+      d_build_alias(D, ec.log_alpha, ec.alias + (size_t)i * (size_t)table);
+    }
+  }
+  return err;
+}
+
+// MA tree (H.4.2) + its leaf code
+JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L) {
+  uint32_t err = d_ec_read_header(b, 6, L.tree_code, &L.nested, L.lens);
+  if (err) return err;
+  DevECView v = local_view(L.tree_code);
+  uint32_t state = ans_init(v, b);
+  int to_decode = 1, leaf = 0, count = 0;
+  while (to_decode > 0) {
+    to_decode--;
+    if (count >= kLocMaxNodes) return kErrUnsupportedTransform;
+    DevTreeNode &nd = L.nodes[count];
+    int prop = (int)ec_read(v, b, state, 1) - 1;
+    if (prop < 0) {
+      nd.prop = -1;
+      nd.lchild = (int32_t)ec_read(v, b, state, 2);                     // predictor
+      nd.offset = unpack_signed(ec_read(v, b, state, 3));
+      uint32_t mul_log = ec_read(v, b, state, 4), mul_bits = ec_read(v, b, state, 5);
+      if (nd.lchild > 13 || mul_log > 30) return kErrBitstream;
+      nd.rchild = (int32_t)((mul_bits + 1u) << mul_log);                // multiplier
+      nd.splitval = leaf++;                                             // context
+      count++;
+      continue;
+    }
+    nd.prop = prop;
+    nd.splitval = unpack_signed(ec_read(v, b, state, 0));
+    nd.lchild = count + to_decode + 1;
+    nd.rchild = count + to_decode + 2;
+    nd.offset = 0;
+    count++;
+    to_decode += 2;
+    if (b.consumed > (1ull << 34)) return kErrBitstream;
+  }
+  if (state != 0x130000u) return kErrAnsFinal;
+  L.count = count;
+  return d_ec_read_header(b, leaf, L.leaf_code, &L.nested, L.lens);
+}
+
+}  // namespace jxlamd

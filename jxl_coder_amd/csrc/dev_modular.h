@@ -8,7 +8,7 @@
 // state, the property vector and the head of the MA tree live in LDS so that the serial lane never waits on
 // HBM for its neighbourhood.
 #pragma once
-#include "dev_entropy.h"
+#include "dev_echeader.h"
 
 namespace jxlamd {
 
@@ -217,9 +217,8 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
 }
 
 // GroupHeader of a modular stream (H.2): use_global_tree, WP header, transforms.
-JXL_DEV uint32_t modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms) {
-  uint32_t err = 0;
-  if (!bits_read(b, 1)) err |= kErrTreeLocal;          // local MA tree: host-side feature, not on device
+JXL_DEV void modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms, int &use_global) {
+  use_global = (int)bits_read(b, 1);
   wp.p1 = 16; wp.p2 = 10; wp.p3a = 7; wp.p3b = 7; wp.p3c = 7; wp.p3d = 0; wp.p3e = 0;
   wp.w[0] = 13; wp.w[1] = 12; wp.w[2] = 12; wp.w[3] = 12;
   if (!bits_read(b, 1)) {
@@ -229,6 +228,28 @@ JXL_DEV uint32_t modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms) 
     for (int i = 0; i < 4; i++) wp.w[i] = (int)bits_read(b, 4);
   }
   nb_transforms = (int)bits_u32(b, -1, 0, -1, 1, 4, 2, 8, 18);
+}
+
+// One complete modular stream: header, (global | local) MA tree, channels, final-state check.
+JXL_DEV uint32_t modular_decode_stream(const uint8_t *tables, const DevFrame &F, LocalTreeScratch &L, DevBits &b,
+                                       DevModScratch &S, const DevChanOut *chans, int nch, int stream_id) {
+  DevWP wp; int ntr, use_global;
+  modular_read_header(b, wp, ntr, use_global);
+  if (ntr != 0) return kErrUnsupportedTransform;
+  const DevTreeNode *tree; int count; DevECView ev;
+  if (use_global) {
+    if (F.tree_count <= 0) return kErrBitstream;
+    tree = (const DevTreeNode *)(tables + F.tree_off); count = F.tree_count; ev = ec_view(tables, F.tree_ec);
+  } else {
+    uint32_t e = d_read_local_tree(b, L);
+    if (e) return e;
+    tree = L.nodes; count = L.count; ev = local_view(L.leaf_code);
+  }
+  const int ncache = count < kTreeLds ? count : kTreeLds;
+  for (int i = 0; i < ncache; i++) S.tree[i] = tree[i];
+  uint32_t state = ans_init(ev, b);
+  uint32_t err = modular_decode_channels(ev, b, state, tree, count, wp, S, chans, nch, stream_id);
+  if (!err && state != 0x130000u) err |= kErrAnsFinal;
   return err;
 }
 

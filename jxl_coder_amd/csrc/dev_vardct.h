@@ -26,11 +26,12 @@ struct DevBuffers {
   int32_t *coef[3];             // [num_groups][65536]
   float *plane_a[3], *plane_b[3];
   int32_t *lf_scratch;          // [num_lf_groups][kLfScratchInts]
+  LocalTreeScratch *local;      // [num_lf_groups]: local MA trees / histograms parsed on the device
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
 };
 
-constexpr int kLfScratchInts = 6 * 65536 + 2048;
+constexpr int kLfScratchInts = 6 * 65536 + 2048 + 16;   // LF ints (3 planes) + CfL maps + block info + sharpness + [last] extra_precision
 
 JXL_DEV const DevFrame &frame_of(const DevBuffers &B) { return *(const DevFrame *)B.tables; }
 JXL_DEV int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
@@ -53,22 +54,15 @@ JXL_DEV uint32_t lf_group_serial(const DevBuffers &B, DevModScratch &S, int g, u
   const int bx0 = gx * 256, by0 = gy * 256;
   const int bw = F.xb - bx0 < 256 ? F.xb - bx0 : 256, bh = F.yb - by0 < 256 ? F.yb - by0 : 256;
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
-  const DevTreeNode *gtree = (const DevTreeNode *)(B.tables + F.tree_off);
-  DevECView ev = ec_view(B.tables, F.tree_ec);
+  LocalTreeScratch &L = B.local[g];
   uint32_t err = 0;
   // --- LF coefficients: extra_precision u(2), Modular stream (channels Y, X, B)
   uint32_t extra = bits_read(b, 2);
   scr[kLfScratchInts - 1] = (int32_t)extra;
   {
-    DevWP wp; int ntr;
-    err |= modular_read_header(b, wp, ntr);
-    if (ntr != 0) err |= kErrUnsupportedTransform;
-    if (err) return err;
-    uint32_t state = ans_init(ev, b);
     DevChanOut ch[3];
     for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = bw; ch[c].h = bh; }
-    err |= modular_decode_channels(ev, b, state, gtree, F.tree_count, wp, S, ch, 3, 1 + g);
-    if (state != 0x130000u) err |= kErrAnsFinal;
+    err = modular_decode_stream(B.tables, F, L, b, S, ch, 3, 1 + g);
     if (err) return err;
   }
   // --- HF metadata
@@ -78,18 +72,12 @@ JXL_DEV uint32_t lf_group_serial(const DevBuffers &B, DevModScratch &S, int g, u
   const int tw = (bw + 7) / 8, th = (bh + 7) / 8;
   int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
   {
-    DevWP wp; int ntr;
-    err |= modular_read_header(b, wp, ntr);
-    if (ntr != 0) err |= kErrUnsupportedTransform;
-    if (err) return err;
-    uint32_t state = ans_init(ev, b);
     DevChanOut ch[4];
     ch[0].d = m_x; ch[0].w = tw; ch[0].h = th;
     ch[1].d = m_b; ch[1].w = tw; ch[1].h = th;
     ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
     ch[3].d = m_sharp; ch[3].w = bw; ch[3].h = bh;
-    err |= modular_decode_channels(ev, b, state, gtree, F.tree_count, wp, S, ch, 4, 1 + 2 * F.num_lf_groups + g);
-    if (state != 0x130000u) err |= kErrAnsFinal;
+    err = modular_decode_stream(B.tables, F, L, b, S, ch, 4, 1 + 2 * F.num_lf_groups + g);
     if (err) return err;
   }
   if (end_bits) end_bits[g] = b.consumed;

@@ -254,11 +254,10 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   }
   // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
   hx_tree tree; memset(&tree, 0, sizeof(tree));
-  if (hx_bool(&sb)) {
-    if (hx_tree_read(&tree, &sb)) { plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
-  } else { plan->error = "unsupported: VarDCT frame without a global MA tree"; return -1; }
+  const bool have_tree = hx_bool(&sb);
+  if (have_tree && hx_tree_read(&tree, &sb)) { plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
   if (sb.err) { hx_tree_free(&tree); plan->error = "truncated LfGlobal"; return -1; }
-  {
+  if (have_tree) {
     std::vector<DevTreeNode> nodes((size_t)tree.count);
     for (int i = 0; i < tree.count; i++) {
       DevTreeNode &d = nodes[(size_t)i]; const hx_tnode &s = tree.n[i];
@@ -271,7 +270,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     int rc = pack_ec(tree.code, blob, &F.tree_ec, &plan->error);
     hx_tree_free(&tree);
     if (rc) return -1;
-  }
+  } else F.tree_count = 0;     // streaming-encoded frames: every LfGroup stream carries its own tree (parsed on the device)
   plan->lf_global_end_bit = (uint32_t)sb.pos;
   F.single_lf_bit = (uint32_t)sb.pos;
   // quantiser-derived constants

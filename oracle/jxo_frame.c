@@ -486,6 +486,7 @@ static int read_lf_global(fstate *s, jxo_br *br) {
       extern int jxo__read_ctx_map(jxo_br *, uint8_t *, int, int *);
       if (jxo__read_ctx_map(br, s->bctx_map, s->bctx_size, &s->num_bctx)) JXO_FAIL("bad block ctx map");
     }
+    if (jxo_debug) fprintf(stderr, "lfglobal dbg: gs=%u qlf=%u after bctx bit=%zu nbctx=%d\n", s->global_scale, s->quant_lf, br->pos, s->num_bctx);
     /* CfL */
     s->color_factor = 84; s->base_x = 0.0f; s->base_b = 1.0f; s->ytox_dc = 0; s->ytob_dc = 0;
     if (!jxo_bool(br)) {

@@ -1,0 +1,76 @@
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_meta():
+    return json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def load_case(name):
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    exp = np.load(os.path.join(GOLDEN, name + ".npz"))["rgba"]
+    return data, exp
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C CPU restatement (oracle/libjxo.so); built on demand with gcc."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libjxo.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "libjxo.so"], check=True)
+    import jxl_oracle
+    return jxl_oracle
+
+
+@pytest.fixture(scope="session")
+def emul():
+    """tests/emul: the product's device functions compiled for the CPU (test-only harness)."""
+    so = os.path.join(ROOT, "tests", "emul", "libjxlemul.so")
+    srcs = [os.path.join(ROOT, "tests", "emul", "emul.cpp"), os.path.join(ROOT, "jxl_coder_amd", "csrc", "host_parse.cpp"),
+            os.path.join(ROOT, "jxl_coder_amd", "csrc", "host_bits.cpp")]
+    csrc = os.path.join(ROOT, "jxl_coder_amd", "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+    if not os.path.exists(so) or os.path.getmtime(so) < max(newest, os.path.getmtime(srcs[0])):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-unused-function", "-o", so] + srcs, check=True)
+    import ctypes as C
+    lib = C.CDLL(so)
+    lib.emul_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32),
+                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.emul_last_error.restype = C.c_char_p
+
+    def decode(data, allow16=True):
+        cap = 1 << 20
+        import jxl_coder_amd as J
+        w, h = J.JxlCoder.getSize(data)
+        buf = np.zeros(w * h * 8, np.uint8)
+        cw, ch, cb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = lib.emul_decode(data, len(data), int(allow16), buf.ctypes.data, buf.nbytes, C.byref(cw), C.byref(ch), C.byref(cb))
+        if rc:
+            raise ValueError(lib.emul_last_error().decode())
+        n = cw.value * ch.value * 4 * (cb.value // 8)
+        return buf[:n].view(np.uint16 if cb.value == 16 else np.uint8).reshape(ch.value, cw.value, 4)
+    return decode
+
+
+VARDCT_CASES = ["v64_e3_gab0_epf0", "v256_e3_gab0_epf0", "v256_e3_gab1_epf0", "v256_e3_gab0_epf1", "v256_e3_gab0_epf2",
+                "v256_e3_gab0_epf3", "v256_e7", "v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "v64_hard_e7"]
+LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7"]
+
+# Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.1
+# (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).
+VARDCT_MAX_ABS = 1
+VARDCT_MEAN_ABS = 0.1

@@ -1,0 +1,95 @@
+"""CPU tests of the product's host side: C-ABI exports, header parsing, error behaviour, and the device code run
+through the test-only CPU harness (tests/emul) against the oracle and the golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, load_case
+
+import jxl_coder_amd as J
+
+
+@pytest.fixture(scope="module")
+def built():
+    J.build()
+    return J.library_path()
+
+
+def test_cabi_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "jxl_amd.h")).read()
+    declared = set(re.findall(r"\b(jxlamd_[a-z0-9_]+)\s*\(", hdr))
+    assert {"jxlamd_decode", "jxlamd_basic_info", "jxlamd_decoder_create", "jxlamd_decode_batch"} <= declared
+    lib = C.CDLL(built)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_basic_info_matches_reference(built, golden_meta):
+    for name in VARDCT_CASES + LOSSLESS_CASES:
+        data, _ = load_case(name)
+        ref = golden_meta[name]["info"]
+        assert J.JxlCoder.getSize(data) == (ref["xsize"], ref["ysize"])
+        info = J.api.Info()
+        assert J.api.lib().jxlamd_basic_info(data, len(data), C.byref(info)) == 0
+        assert info.bits_per_sample == ref["bits_per_sample"]
+        assert info.prefer_encoding == ref["prefer_encoding"]
+        assert info.transfer_function == ref["transfer_function"] and info.primaries == ref["primaries"]
+        assert abs(info.intensity_target - ref["intensity_target"]) < 1e-3
+        assert info.has_alpha_in_origin == int(ref["num_extra_channels"] > 0 and ref["alpha_bits"] > 0)
+
+
+def test_isjxl_and_invalid_inputs(built):
+    data, _ = load_case("v256_e7")
+    assert J.JxlCoder.isJXL(data)
+    assert not J.JxlCoder.isJXL(b"\x89PNG\r\n")
+    with pytest.raises(J.InvalidJXLException):
+        J.JxlCoder.getSize(b"\x89PNG\r\n\x1a\n")
+    with pytest.raises(J.InvalidJXLException):
+        J.JxlCoder.getSize(data[:3])
+
+
+def test_preconditions_mirror_reference(built):
+    data, _ = load_case("v64_e3_gab0_epf0")
+    with pytest.raises(ValueError):
+        J.JxlCoder.decodeSampled(data, -1, -1, 0, J.ScaleMode.FIT)        # Support.cpp:35-92: invalid colour config
+    with pytest.raises(ValueError):
+        J.JxlCoder.decodeSampled(data, -1, -1, J.PreferredColorConfig.DEFAULT, 7)
+
+
+def test_no_cpu_fallback_without_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        J.JxlDecoder(0)
+
+
+@pytest.mark.parametrize("name", VARDCT_CASES)
+def test_device_code_on_cpu_harness(emul, oracle, name):
+    data, exp = load_case(name)
+    out = emul(data)
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS
+    ora, _ = oracle.decode(data, 8)
+    d2 = np.abs(out.astype(int) - ora.astype(int))
+    assert d2.max() <= 1 and (d2 > 0).mean() < 1e-3      # same algorithm, different summation order
+
+
+def test_harness_rejects_what_the_device_path_does_not_support(emul):
+    data, _ = load_case("l64_e7")
+    with pytest.raises(ValueError, match="unsupported"):
+        emul(data)
+
+
+def test_harness_flags_corrupt_streams(emul):
+    data, _ = load_case("v264x520_e7")
+    bad = bytearray(data)
+    for i in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[i] ^= 0x5A
+    with pytest.raises(ValueError):
+        emul(bytes(bad))
+    with pytest.raises(ValueError):
+        emul(data[: len(data) - 2000])

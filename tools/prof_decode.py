@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Decode the 4K bench frame a few times (for rocprofv3 runs)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import jxl_coder_amd as J
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+dec = J.JxlDecoder(0)
+data = open(os.path.join(ROOT, "bench_data/syn4k_q90_seed0.jxl"), "rb").read()
+for i in range(n):
+    t = time.time(); out, info = dec.decode_one_shot(data); dt = time.time() - t
+    print("4k %.1f ms wall" % (dt * 1e3), dec.last_timing())
