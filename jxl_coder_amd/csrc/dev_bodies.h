@@ -13,11 +13,18 @@ struct DevAux {
 // ---- LfGroup: one workgroup (one wave) per 2048x2048 LF group
 template <class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
-  if (tid == 0) {
-    uint32_t err = lf_group_serial(B, S, g, A.lf_end_bits);
-    if (err) *B.err |= err;   // benign race: any set bit fails the frame
-  }
+  if (tid == 0) lf_phase_open(B, S, g);
   sync();
+  modular_stream_stage(S, tid, nthreads);
+  sync();
+  if (tid == 0) { uint32_t e = lf_phase_coeffs(B, S, g); if (e) { S.st.err = e; *B.err |= e; } }
+  sync();
+  if (S.st.err) return;                      // uniform: read from LDS after the barrier
+  modular_stream_stage(S, tid, nthreads);
+  sync();
+  if (tid == 0) { uint32_t e = lf_phase_meta(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e; } }
+  sync();
+  if (S.st.err) return;
   lf_group_epilogue(B, g, tid, nthreads);
 }
 
@@ -25,14 +32,15 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
 template <class Sync>
 JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
-  if (tid == 0) {
-    for (int p = 0; p < F.num_passes; p++) {
-      uint32_t err = pass_group_serial(B, S, p, g);
-      if (err) { *B.err |= err; break; }
-    }
+  for (int p = 0; p < F.num_passes; p++) {
+    if (tid == 0) pass_phase_open(B, S, p, g);
+    sync();
+    pass_phase_stage(B, S, tid, nthreads);
+    sync();
+    if (tid == 0) { uint32_t e = pass_phase_decode(B, S, g); if (e) { S.err = e; *B.err |= e; } }
+    sync();
+    if (S.err) return;
   }
-  sync();
-  (void)nthreads;
 }
 
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]

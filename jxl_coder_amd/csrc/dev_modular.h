@@ -14,19 +14,37 @@ namespace jxlamd {
 
 constexpr int kModMaxW = 256;         // widest channel a device stream may carry (LF group = 256 LF samples; 256-px lossless groups)
 constexpr int kWpMaxW = 256;
-constexpr int kTreeLds = 448;         // MA-tree nodes cached in LDS
+constexpr int kTreeLds = 256;         // MA-tree nodes cached in LDS
+
+struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
+struct DevChanOut { int32_t *d; int32_t w, h; };
+
+constexpr int kLdsClusters = 16;      // leaf-code clusters whose alias tables are cached in LDS
+constexpr int kLdsCtx = 4096;
+
+struct DevModStream {                 // what lane 0 hands to the other lanes / to the next phase of a stream
+  DevBits b;
+  DevWP wp;
+  const DevTreeNode *tree; int32_t count;
+  DevECView ev;
+  int32_t num_ctx, num_clusters;
+  uint32_t err;
+};
 
 struct DevModScratch {                // per-wave working memory (LDS on the GPU)
   int32_t rows[3][kModMaxW + 8];      // cur / prev / prevprev rows
   uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
   int32_t wp_err[2 * (kWpMaxW + 2)];
   int32_t props[32];
+  uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
   DevTreeNode tree[kTreeLds];
+  uint8_t ctx_map[kLdsCtx];
+  uint32_t cfg[kLocMaxClusters];
+  DevAlias alias[kLdsClusters * 256];
+  DevModStream st;
 };
 
-struct DevChanOut { int32_t *d; int32_t w, h; };
 
-struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
 
 JXL_DEV int32_t floor_log2_u32(uint32_t x) { return 31 - __builtin_clz(x); }
 JXL_DEV int64_t iabs64(int64_t v) { return v < 0 ? -v : v; }
@@ -36,11 +54,10 @@ struct WPState {
   int64_t pred;
 };
 
-JXL_DEV uint32_t wp_error_weight(uint32_t x, uint32_t maxweight) {
+JXL_DEV uint32_t wp_error_weight(const uint32_t *divlut, uint32_t x, uint32_t maxweight) {
   int shift = floor_log2_u32(x + 1) - 5;
   if (shift < 0) shift = 0;
-  uint32_t d = (1u << 24) / ((x >> shift) + 1);
-  return 4 + ((maxweight * d) >> shift);
+  return 4 + ((maxweight * divlut[x >> shift]) >> shift);
 }
 
 JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x, int y, int xs, int64_t N, int64_t W,
@@ -53,7 +70,7 @@ JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x,
   uint32_t w[4];
   for (int i = 0; i < 4; i++) {
     uint32_t e = S.wp_pred_err[i][pos_N] + S.wp_pred_err[i][pos_NE] + S.wp_pred_err[i][pos_NW];
-    w[i] = wp_error_weight(e, (uint32_t)h.w[i]);
+    w[i] = wp_error_weight(S.divlut, e, (uint32_t)h.w[i]);
   }
   N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
   int64_t teW = x == 0 ? 0 : S.wp_err[cur_row + x - 1];
@@ -74,7 +91,7 @@ JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x,
   for (int i = 0; i < 4; i++) { w[i] >>= lw - 4; wsum += w[i]; }
   int64_t sum = (int64_t)(wsum >> 1) - 1;
   for (int i = 0; i < 4; i++) sum += st.prediction[i] * (int64_t)w[i];
-  st.pred = (sum * (int64_t)((1u << 24) / wsum)) >> 24;
+  st.pred = (sum * (int64_t)S.divlut[wsum - 1]) >> 24;
   if (((teN ^ teW) | (teN ^ teNW)) > 0) return (st.pred + 3) >> 3;
   int64_t mx = W > NE ? W : NE; if (N > mx) mx = N;
   int64_t mn = W < NE ? W : NE; if (N < mn) mn = N;
@@ -160,6 +177,9 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     const int w = c.w, h = c.h;
     if (w == 0 || h == 0) continue;
     const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id);
+#ifdef JXL_EMUL_TRACE
+    fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop);
+#endif
     if (tf.max_prop > 15) return kErrUnsupportedTransform;   // previous-channel properties: not on device yet
     const bool wide = w > kModMaxW;
     if (wide && tf.uses_wp) return kErrUnsupportedTransform;
@@ -230,26 +250,53 @@ JXL_DEV void modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms, int 
   nb_transforms = (int)bits_u32(b, -1, 0, -1, 1, 4, 2, 8, 18);
 }
 
-// One complete modular stream: header, (global | local) MA tree, channels, final-state check.
-JXL_DEV uint32_t modular_decode_stream(const uint8_t *tables, const DevFrame &F, LocalTreeScratch &L, DevBits &b,
-                                       DevModScratch &S, const DevChanOut *chans, int nch, int stream_id) {
-  DevWP wp; int ntr, use_global;
-  modular_read_header(b, wp, ntr, use_global);
-  if (ntr != 0) return kErrUnsupportedTransform;
-  const DevTreeNode *tree; int count; DevECView ev;
+// One modular stream in three phases so that the whole wave can stage the stream's tables in LDS:
+//   begin (lane 0): GroupHeader, (global | local) MA tree + leaf code;  stage (all lanes): tree head, context map,
+//   hybrid-uint configs and alias tables -> LDS;  decode (lane 0): channels + final-state check.
+JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, LocalTreeScratch &L, DevModScratch &S) {
+  DevModStream &st = S.st;
+  int ntr, use_global;
+  modular_read_header(st.b, st.wp, ntr, use_global);
+  st.err = 0;
+  if (ntr != 0) { st.err = kErrUnsupportedTransform; return; }
   if (use_global) {
-    if (F.tree_count <= 0) return kErrBitstream;
-    tree = (const DevTreeNode *)(tables + F.tree_off); count = F.tree_count; ev = ec_view(tables, F.tree_ec);
+    if (F.tree_count <= 0) { st.err = kErrBitstream; return; }
+    st.tree = (const DevTreeNode *)(tables + F.tree_off); st.count = F.tree_count; st.ev = ec_view(tables, F.tree_ec);
+    st.num_ctx = F.tree_ec.num_ctx; st.num_clusters = F.tree_ec.num_clusters;
   } else {
-    uint32_t e = d_read_local_tree(b, L);
-    if (e) return e;
-    tree = L.nodes; count = L.count; ev = local_view(L.leaf_code);
+    uint32_t e = d_read_local_tree(st.b, L);
+    if (e) { st.err = e; return; }
+    st.tree = L.nodes; st.count = L.count; st.ev = local_view(L.leaf_code);
+    st.num_ctx = L.leaf_code.num_ctx; st.num_clusters = L.leaf_code.num_clusters;
   }
-  const int ncache = count < kTreeLds ? count : kTreeLds;
-  for (int i = 0; i < ncache; i++) S.tree[i] = tree[i];
+}
+
+JXL_DEV void modular_stream_stage(DevModScratch &S, int tid, int nthreads) {
+  DevModStream &st = S.st;
+  if (st.err) return;
+  const int ncache = st.count < kTreeLds ? st.count : kTreeLds;
+  for (int i = tid; i < ncache; i += nthreads) S.tree[i] = st.tree[i];
+  for (int i = tid; i < 64; i += nthreads) S.divlut[i] = (1u << 24) / (uint32_t)(i + 1);
+  if (st.num_ctx <= kLdsCtx) for (int i = tid; i < st.num_ctx; i += nthreads) S.ctx_map[i] = st.ev.ctx_map[i];
+  for (int i = tid; i < st.num_clusters && i < kLocMaxClusters; i += nthreads) S.cfg[i] = st.ev.cfg[i];
+  if (!st.ev.use_prefix && st.num_clusters <= kLdsClusters) {
+    const int n = st.num_clusters << st.ev.log_alpha;
+    for (int i = tid; i < n; i += nthreads) S.alias[i] = st.ev.alias[i];
+  }
+}
+
+JXL_DEV uint32_t modular_stream_decode(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id) {
+  DevModStream &st = S.st;
+  if (st.err) return st.err;
+  DevECView ev = st.ev;
+  if (st.num_ctx <= kLdsCtx) ev.ctx_map = S.ctx_map;
+  if (st.num_clusters <= kLocMaxClusters) ev.cfg = S.cfg;
+  if (!ev.use_prefix && st.num_clusters <= kLdsClusters) ev.alias = S.alias;
+  DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
-  uint32_t err = modular_decode_channels(ev, b, state, tree, count, wp, S, chans, nch, stream_id);
+  uint32_t err = modular_decode_channels(ev, b, state, st.tree, st.count, st.wp, S, chans, nch, stream_id);
   if (!err && state != 0x130000u) err |= kErrAnsFinal;
+  st.b = b;
   return err;
 }
 

@@ -36,50 +36,69 @@ constexpr int kLfScratchInts = 6 * 65536 + 2048 + 16;   // LF ints (3 planes) + 
 JXL_DEV const DevFrame &frame_of(const DevBuffers &B) { return *(const DevFrame *)B.tables; }
 JXL_DEV int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
 
-// ------------------------------------------------------------------ LfGroup, serial part (lane 0)
-JXL_DEV uint32_t lf_group_serial(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
+// ------------------------------------------------------------------ LfGroup (serial phases run by lane 0)
+struct LfGeom { int bx0, by0, bw, bh, tw, th; };
+JXL_DEV LfGeom lf_geom(const DevFrame &F, int g) {
+  LfGeom q;
+  const int gx = g % F.xlfg, gy = g / F.xlfg;
+  q.bx0 = gx * 256; q.by0 = gy * 256;
+  q.bw = F.xb - q.bx0 < 256 ? F.xb - q.bx0 : 256; q.bh = F.yb - q.by0 < 256 ? F.yb - q.by0 : 256;
+  q.tw = (q.bw + 7) / 8; q.th = (q.bh + 7) / 8;
+  return q;
+}
+
+// phase 1: open the section, read extra_precision, begin the LF-coefficient stream
+JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
   const DevFrame &F = frame_of(B);
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
-  // In a single-section frame the LfGroup follows LfGlobal in the same byte stream: the host stores the BIT
-  // offset where LfGroup 0 starts in secs[0].size's upper meaning — see host_parse (single_section_lf_bit).
   DevBits b;
   bits_init(b, B.codestream, sec.off);
-  if (F.nsec == 1) {   // skip LfGlobal bits parsed by the host
+  if (F.nsec == 1) {   // single-section frame: skip the LfGlobal bits the host parsed
     uint32_t skip = F.single_lf_bit;
     while (skip >= 32) { bits_read(b, 32); skip -= 32; }
     bits_read(b, (int)skip);
   }
-  const int gx = g % F.xlfg, gy = g / F.xlfg;
-  const int bx0 = gx * 256, by0 = gy * 256;
-  const int bw = F.xb - bx0 < 256 ? F.xb - bx0 : 256, bh = F.yb - by0 < 256 ? F.yb - by0 : 256;
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
-  LocalTreeScratch &L = B.local[g];
-  uint32_t err = 0;
-  // --- LF coefficients: extra_precision u(2), Modular stream (channels Y, X, B)
-  uint32_t extra = bits_read(b, 2);
-  scr[kLfScratchInts - 1] = (int32_t)extra;
-  {
-    DevChanOut ch[3];
-    for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = bw; ch[c].h = bh; }
-    err = modular_decode_stream(B.tables, F, L, b, S, ch, 3, 1 + g);
-    if (err) return err;
-  }
-  // --- HF metadata
-  const int nblocks = bw * bh;
-  const int count = 1 + (int)bits_read(b, ceil_log2u((uint32_t)nblocks));
-  if (count > nblocks) return kErrBitstream;
-  const int tw = (bw + 7) / 8, th = (bh + 7) / 8;
+  scr[kLfScratchInts - 1] = (int32_t)bits_read(b, 2);      // extra_precision
+  S.st.b = b;
+  modular_stream_begin(B.tables, F, B.local[g], S);
+}
+// phase 2: decode LF coefficients (channels Y, X, B), then begin the HF-metadata stream
+JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g) {
+  const DevFrame &F = frame_of(B);
+  const LfGeom q = lf_geom(F, g);
+  int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  DevChanOut ch[3];
+  for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
+  uint32_t err = modular_stream_decode(S, ch, 3, 1 + g);
+  if (err) return err;
+  const int count = 1 + (int)bits_read(S.st.b, ceil_log2u((uint32_t)(q.bw * q.bh)));
+  if (count > q.bw * q.bh) return kErrBitstream;
+  scr[kLfScratchInts - 2] = count;
+  modular_stream_begin(B.tables, F, B.local[g], S);
+  return 0;
+}
+// phase 3: decode HF metadata, place the varblocks
+JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
+  const DevFrame &F = frame_of(B);
+  const LfGeom q = lf_geom(F, g);
+  const int bx0 = q.bx0, by0 = q.by0, bw = q.bw, bh = q.bh;
+  int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  const int count = scr[kLfScratchInts - 2];
   int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
   {
     DevChanOut ch[4];
-    ch[0].d = m_x; ch[0].w = tw; ch[0].h = th;
-    ch[1].d = m_b; ch[1].w = tw; ch[1].h = th;
+    ch[0].d = m_x; ch[0].w = q.tw; ch[0].h = q.th;
+    ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
     ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
     ch[3].d = m_sharp; ch[3].w = bw; ch[3].h = bh;
-    err = modular_decode_stream(B.tables, F, L, b, S, ch, 4, 1 + 2 * F.num_lf_groups + g);
+    uint32_t err = modular_stream_decode(S, ch, 4, 1 + 2 * F.num_lf_groups + g);
     if (err) return err;
   }
+  const DevBits &b = S.st.b;
+  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+  const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
   if (end_bits) end_bits[g] = b.consumed;
   if (b.consumed > (uint64_t)sec.size * 8 + 64 && F.nsec != 1) return kErrBitstream;
   // --- varblock placement: raster scan, next block goes to the first unoccupied cell
@@ -144,9 +163,20 @@ JXL_DEV void lf_group_epilogue(const DevBuffers &B, int g, int lane, int nlanes)
 }
 
 // ------------------------------------------------------------------ PassGroup (lane 0)
-struct DevPassScratch { uint8_t nz[3][32 * 32]; };
+constexpr int kPassCtxLds = 495 * 24;     // context-map slice of one HF preset cached in LDS (num_bctx <= 24)
+struct DevPassScratch {
+  uint8_t nz[3][32 * 32];
+  uint8_t ctx_map[kPassCtxLds];
+  uint32_t cfg[256];
+  uint16_t freq_ctx[64], nnz_ctx[64];
+  uint32_t order8[2][3][64];              // coefficient orders of the two 64-coefficient order ids (DCT8 / other 8x8)
+  DevBits b;
+  int32_t sel, pass;
+  uint32_t err;
+};
 
-JXL_DEV uint32_t pass_group_serial(const DevBuffers &B, DevPassScratch &S, int pass, int g) {
+// phase 1 (lane 0): open the section, read the HF preset selector
+JXL_DEV void pass_phase_open(const DevBuffers &B, DevPassScratch &S, int pass, int g) {
   const DevFrame &F = frame_of(B);
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
@@ -157,19 +187,49 @@ JXL_DEV uint32_t pass_group_serial(const DevBuffers &B, DevPassScratch &S, int p
     while (skip >= 32) { bits_read(b, 32); skip -= 32; }
     bits_read(b, (int)skip);
   }
+  S.sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
+  S.err = S.sel >= F.num_presets ? (uint32_t)kErrBitstream : 0u;
+  S.b = b; S.pass = pass;
+}
+// phase 2 (all lanes): stage this preset's context-map slice, the hybrid-uint configs and small tables in LDS
+JXL_DEV void pass_phase_stage(const DevBuffers &B, DevPassScratch &S, int tid, int nthreads) {
+  const DevFrame &F = frame_of(B);
+  if (S.err) return;
+  const DevEC &e = F.hf_ec[S.pass];
+  const int n = 495 * F.num_bctx;
+  const uint8_t *src = B.tables + e.ctx_map_off + (size_t)S.sel * (size_t)n;
+  if (n <= kPassCtxLds) for (int i = tid; i < n; i += nthreads) S.ctx_map[i] = src[i];
+  const uint32_t *cfg = (const uint32_t *)(B.tables + e.cfg_off);
+  for (int i = tid; i < e.num_clusters && i < 256; i += nthreads) S.cfg[i] = cfg[i];
+  for (int i = tid; i < 64; i += nthreads) { S.freq_ctx[i] = kCoeffFreqContext[i]; S.nnz_ctx[i] = kCoeffNumNonzeroContext[i]; }
+  for (int i = tid; i < 2 * 3 * 64; i += nthreads) {
+    const int o = i / 192, c = (i / 64) % 3, k = i & 63;
+    S.order8[o][c][k] = ((const uint32_t *)(B.tables + F.order_off[S.pass][o][c]))[k];
+  }
+  { uint8_t *nzflat = &S.nz[0][0]; for (int i = tid; i < 3 * 32 * 32; i += nthreads) nzflat[i] = 0; }
+}
+// phase 3 (lane 0): the serial rANS walk over the group's varblocks
+JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g) {
+  const DevFrame &F = frame_of(B);
+  if (S.err) return S.err;
+  const int pass = S.pass;
+  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+  const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
+  DevBits b = S.b;
   const int gx = g % F.xgroups, gy = g / F.xgroups;
   const int bx0 = gx * 32, by0 = gy * 32;
   const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
-  const int sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
-  if (sel >= F.num_presets) return kErrBitstream;
-  const int ctx_offset = sel * 495 * F.num_bctx;
+  const int nslice = 495 * F.num_bctx;
   DevECView ev = ec_view(B.tables, F.hf_ec[pass]);
+  // contexts below are relative to the preset's slice
+  if (nslice <= kPassCtxLds) ev.ctx_map = S.ctx_map; else ev.ctx_map += (size_t)S.sel * (size_t)nslice;
+  if (F.hf_ec[pass].num_clusters <= 256) ev.cfg = S.cfg;
   uint32_t state = ans_init(ev, b);
   const int shift = F.pass_shift[pass];
+  const bool accumulate = F.num_passes > 1;
   const uint8_t *bctx_map = B.tables + F.bctx_map_off;
   const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
   uint32_t pool = 0;
-  for (int i = 0; i < 3 * 32 * 32; i++) S.nz[0][i] = 0;
   for (int y = 0; y < bh; y++)
     for (int x = 0; x < bw; x++) {
       const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
@@ -198,21 +258,24 @@ JXL_DEV uint32_t pass_group_serial(const DevBuffers &B, DevPassScratch &S, int p
         idx = idx * nlf + lfi;
         const int bctx = bctx_map[idx];
         const int nzp = predicted >= 64 ? 64 : predicted;
-        const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx + ctx_offset;
+        const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
         int nzeros = (int)ec_read(ev, b, state, (uint32_t)nzctx);
         if (nzeros > size - covered) return kErrBitstream;
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
         for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
-        const int histo = ctx_offset + F.num_bctx * 37 + 458 * bctx;
-        const uint32_t *order = (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+        const int histo = F.num_bctx * 37 + 458 * bctx;
+        const uint32_t *order = ord < 2 ? S.order8[ord][c] : (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
         int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
         int prev = nzeros > size / 16 ? 0 : 1;
         for (int k = covered; k < size && nzeros != 0; k++) {
           const int nl = (nzeros + covered - 1) >> log2c;
           const int kk = k >> log2c;
-          const int ctx = histo + (kCoeffNumNonzeroContext[nl] + kCoeffFreqContext[kk]) * 2 + prev;
+          const int ctx = histo + (S.nnz_ctx[nl] + S.freq_ctx[kk]) * 2 + prev;
           const uint32_t u = ec_read(ev, b, state, (uint32_t)ctx);
-          if (u) blk[order[k]] += unpack_signed(u) * (1 << shift);
+          if (u) {
+            const int32_t v = unpack_signed(u) * (1 << shift);
+            if (accumulate) blk[order[k]] += v; else blk[order[k]] = v;
+          }
           prev = u != 0;
           nzeros -= prev;
         }
