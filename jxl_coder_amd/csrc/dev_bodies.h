@@ -17,12 +17,14 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   sync();
   modular_stream_stage(S, tid, nthreads);
   sync();
-  if (tid == 0) { uint32_t e = lf_phase_coeffs(B, S, g); if (e) { S.st.err = e; *B.err |= e; } }
+  uint32_t e = lf_phase_coeffs(B, S, g, tid);                 // whole wave on the GPU
+  if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e; } }
   sync();
-  if (S.st.err) return;                      // uniform: read from LDS after the barrier
+  if (S.st.err) return;                                       // uniform: read from LDS after the barrier
   modular_stream_stage(S, tid, nthreads);
   sync();
-  if (tid == 0) { uint32_t e = lf_phase_meta(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e; } }
+  e = lf_phase_meta(B, S, g, tid);
+  if (tid == 0) { if (!e) e = lf_phase_place(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e; } }
   sync();
   if (S.st.err) return;
   lf_group_epilogue(B, g, tid, nthreads);

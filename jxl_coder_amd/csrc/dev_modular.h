@@ -31,6 +31,13 @@ struct DevModStream {                 // what lane 0 hands to the other lanes / 
   uint32_t err;
 };
 
+struct DevWaveTree {                  // LDS: the pruned tree of one channel in ballot form
+  int32_t int_prop[64], int_split[64];
+  uint64_t leaf_need1[64], leaf_need0[64];
+  int32_t leaf_ctx[64], leaf_pred[64], leaf_off[64], leaf_mul[64];
+  int32_t ni, nl, ok, uses_wp;
+};
+
 struct DevModScratch {                // per-wave working memory (LDS on the GPU)
   int32_t rows[3][kModMaxW + 8];      // cur / prev / prevprev rows
   uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
@@ -42,6 +49,8 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   uint32_t cfg[kLocMaxClusters];
   DevAlias alias[kLdsClusters * 256];
   DevModStream st;
+  DevWaveTree wt;
+  uint32_t fallback_err;
 };
 
 

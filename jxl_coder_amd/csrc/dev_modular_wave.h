@@ -1,0 +1,214 @@
+// jxl_coder_amd/csrc/dev_modular_wave.h — wave-cooperative Modular channel decoder (gfx950 only).
+//
+// The bit stream is serial, but the cost per sample is dominated by CONTEXT MODELLING, not by the rANS step:
+// an MA-tree walk is depth x (node load + property load) of dependent LDS round trips.  Here the whole wavefront
+// decodes one stream in lock-step:
+//   * every lane keeps the (wave-uniform) bit reader, rANS state and a sliding window of the neighbourhood in
+//     registers; only lane 0 stores;
+//   * lane i evaluates decision node i of the MA tree (pruned for this channel/stream): one compare per lane,
+//     one 64-bit ballot for all decisions; lane j then tests leaf j's (must-be-1, must-be-0) masks and a second
+//     ballot names the leaf — 2 ballots instead of a pointer-chasing walk;
+//   * the weighted predictor's error state slides through registers (5 LDS loads + 5 stores per sample instead
+//     of 21 + 9), divisions are table lookups.
+// Falls back to the serial walker (dev_modular.h) when the pruned tree has more than 64 decision nodes or leaves.
+// Bit-exact with the serial path (same integer arithmetic); the CPU harness exercises the serial path, the
+// -m gpu parity tests exercise this one.
+#pragma once
+#include "dev_modular.h"
+
+#ifdef __HIPCC__
+namespace jxlamd {
+
+// lane 0: flatten the tree reachable for (chan, stream) into ballot form
+__device__ inline void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W) {
+  W.ni = 0; W.nl = 0; W.ok = 1; W.uses_wp = 0;
+  int stack_node[64]; uint64_t stack_n1[64], stack_n0[64];
+  int sp = 0;
+  stack_node[0] = 0; stack_n1[0] = 0; stack_n0[0] = 0; sp = 1;
+  int guard = 0;
+  while (sp > 0) {
+    if (++guard > 4 * count + 16) { W.ok = 0; return; }
+    --sp;
+    const int idx = stack_node[sp]; const uint64_t n1 = stack_n1[sp], n0 = stack_n0[sp];
+    const DevTreeNode nd = tree[idx];
+    if (nd.prop < 0) {
+      if (W.nl >= 64) { W.ok = 0; return; }
+      const int j = W.nl++;
+      W.leaf_need1[j] = n1; W.leaf_need0[j] = n0;
+      W.leaf_ctx[j] = nd.splitval; W.leaf_pred[j] = nd.lchild; W.leaf_off[j] = nd.offset; W.leaf_mul[j] = nd.rchild;
+      if (nd.lchild == 6) W.uses_wp = 1;
+      continue;
+    }
+    if (nd.prop == 0 || nd.prop == 1) {
+      const int v = nd.prop == 0 ? chan : stream;
+      stack_node[sp] = v > nd.splitval ? nd.lchild : nd.rchild; stack_n1[sp] = n1; stack_n0[sp] = n0; sp++;
+      continue;
+    }
+    if (nd.prop > 15) { W.ok = 0; return; }
+    if (nd.prop == 15) W.uses_wp = 1;
+    if (W.ni >= 64 || sp + 2 > 64) { W.ok = 0; return; }
+    const int i = W.ni++;
+    W.int_prop[i] = nd.prop; W.int_split[i] = nd.splitval;
+    stack_node[sp] = nd.lchild; stack_n1[sp] = n1 | (1ull << i); stack_n0[sp] = n0; sp++;   // decision true  -> left
+    stack_node[sp] = nd.rchild; stack_n1[sp] = n1; stack_n0[sp] = n0 | (1ull << i); sp++;   // decision false -> right
+  }
+}
+
+__device__ inline uint32_t wave_ec_read(const DevECView &v, DevBits &b, uint32_t &state, uint32_t ctx) {
+  return ec_read(v, b, state, ctx);
+}
+
+// All 64 lanes call this with identical arguments.  Returns error bits (uniform).
+__device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
+                                                        int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
+                                                        const DevChanOut *chans, int nch, int stream_id, int lane) {
+  for (int ci = 0; ci < nch; ci++) {
+    const DevChanOut c = chans[ci];
+    const int w = c.w, h = c.h;
+    if (w == 0 || h == 0) continue;
+    __syncthreads();
+    if (lane == 0) wave_tree_build(gtree, tree_count, ci, stream_id, WT);
+    __syncthreads();
+    if (!WT.ok) return kErrWaveFallback;                    // caller re-runs the stream with the serial walker
+    const bool uses_wp = WT.uses_wp != 0;
+    const bool wide = w > kModMaxW;
+    if (wide && uses_wp) return kErrUnsupportedTransform;
+    const int ni = WT.ni, nl = WT.nl;
+    const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
+    const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+    const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull;
+    const uint64_t my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+    if (uses_wp) {
+      for (int i = lane; i < 2 * (w + 2); i += 64) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
+    }
+    __syncthreads();
+    for (int y = 0; y < h; y++) {
+      int32_t *out = c.d + (size_t)y * (size_t)w;
+      int32_t *row = wide ? out : S.rows[y % 3];
+      const int32_t *rN = wide ? out - w : S.rows[(y + 2) % 3];
+      const int32_t *rNN = wide ? out - 2 * w : S.rows[(y + 1) % 3];
+      // sliding neighbourhood (registers)
+      int32_t vW = 0, vWW = 0;
+      int32_t vN = y > 0 ? rN[0] : 0, vNW = vN, vNE = (y > 0 && w > 1) ? rN[1] : vN, vNEE = (y > 0 && w > 2) ? rN[2] : vNE;
+      // weighted-predictor sliding state: pred_err of (NW, N, NE) in the previous row incl. the current row's carry
+      const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
+      uint32_t peNW[4], peN[4], peNE[4];
+      int32_t teNW = 0, teN = 0, teNE = 0, teW = 0;
+      if (uses_wp) {
+        for (int k = 0; k < 4; k++) { peN[k] = S.wp_pred_err[k][prev_row]; peNW[k] = peN[k]; peNE[k] = w > 1 ? S.wp_pred_err[k][prev_row + 1] : peN[k]; }
+        teN = S.wp_err[prev_row]; teNW = teN; teNE = w > 1 ? S.wp_err[prev_row + 1] : teN;
+      }
+      int32_t prev_prop9 = 0;
+      for (int x = 0; x < w; x++) {
+        const int64_t W_ = x > 0 ? vW : (y > 0 ? vN : 0);
+        const int64_t N_ = y > 0 ? vN : W_;
+        const int64_t NW_ = (x > 0 && y > 0) ? vNW : W_;
+        const int64_t NE_ = (x + 1 < w && y > 0) ? vNE : N_;
+        const int64_t NN_ = y > 1 ? rNN[x] : N_;
+        const int64_t NEE_ = (x + 2 < w && y > 0) ? vNEE : NE_;
+        const int64_t WW_ = x > 1 ? vWW : W_;
+        // prefetch next window element (independent of this sample's value)
+        const int32_t nextNEE = (y > 0 && x + 3 < w) ? rN[x + 3] : 0;
+        // properties
+        const int32_t p9 = (int32_t)(W_ + N_ - NW_);
+        int32_t pv[16];
+        pv[2] = y; pv[3] = x;
+        pv[4] = (int32_t)(N_ < 0 ? -N_ : N_); pv[5] = (int32_t)(W_ < 0 ? -W_ : W_);
+        pv[6] = (int32_t)N_; pv[7] = (int32_t)W_;
+        pv[8] = (int32_t)(W_ - prev_prop9); pv[9] = p9; prev_prop9 = p9;
+        pv[10] = (int32_t)(W_ - NW_); pv[11] = (int32_t)(NW_ - N_); pv[12] = (int32_t)(N_ - NE_);
+        pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_); pv[15] = 0;
+        // weighted predictor (uniform across lanes)
+        int64_t wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
+        if (uses_wp) {
+          uint32_t wgt[4];
+          for (int k = 0; k < 4; k++) {
+            const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
+            wgt[k] = wp_error_weight(S.divlut, e, (uint32_t)wp.w[k]);
+          }
+          const int64_t N8 = N_ * 8, W8 = W_ * 8, NE8 = NE_ * 8, NW8 = NW_ * 8, NN8 = NN_ * 8;
+          const int64_t tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
+          const int64_t sumWN = tN + tW;
+          int64_t p = tW;
+          if (iabs64(tN) > iabs64(p)) p = tN;
+          if (iabs64(tNW) > iabs64(p)) p = tNW;
+          if (iabs64(tNE) > iabs64(p)) p = tNE;
+          pv[15] = (int32_t)p;
+          wpred[0] = W8 + NE8 - N8;
+          wpred[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
+          wpred[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
+          wpred[3] = N8 - ((tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + (NW8 - W8) * wp.p3e) >> 5);
+          uint32_t wsum = wgt[0] + wgt[1] + wgt[2] + wgt[3];
+          const int lw = floor_log2_u32(wsum);
+          wsum = 0;
+          for (int k = 0; k < 4; k++) { wgt[k] >>= lw - 4; wsum += wgt[k]; }
+          int64_t sum = (int64_t)(wsum >> 1) - 1;
+          for (int k = 0; k < 4; k++) sum += wpred[k] * (int64_t)wgt[k];
+          wp_raw = (sum * (int64_t)S.divlut[wsum - 1]) >> 24;
+          if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
+            int64_t mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
+            int64_t mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
+            if (wp_raw > mx) wp_raw = mx;
+            if (wp_raw < mn) wp_raw = mn;
+          }
+          wp_pred = (wp_raw + 3) >> 3;
+        }
+        // MA tree by ballot: lane i decides node i, lane j tests leaf j
+        int32_t myv = pv[2];
+        #pragma unroll
+        for (int k = 3; k < 16; k++) myv = my_prop == k ? pv[k] : myv;
+        const uint64_t dec = __ballot(lane < ni && myv > my_split);
+        const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
+        const int leaf = lm ? __builtin_ctzll(lm) : 0;
+        const int l_ctx = WT.leaf_ctx[leaf], l_pred = WT.leaf_pred[leaf], l_off = WT.leaf_off[leaf], l_mul = WT.leaf_mul[leaf];
+        const int64_t guess = predict_plain(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
+        const uint32_t u = wave_ec_read(ev, b, state, (uint32_t)l_ctx);
+        const int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)l_mul + l_off + guess;
+        if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
+        // slide
+        vWW = vW; vW = (int32_t)val;
+        vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
+        if (uses_wp) {
+          const int64_t v8 = val * 8;
+          const int32_t terr = (int32_t)(wp_raw - v8);
+          uint32_t err[4];
+          for (int k = 0; k < 4; k++) err[k] = (uint32_t)((iabs64(wpred[k] - v8) + 3) >> 3);
+          if (lane == 0) { S.wp_err[cur_row + x] = terr; for (int k = 0; k < 4; k++) S.wp_pred_err[k][cur_row + x] = err[k]; }
+          // the error of this sample is carried to position x+1 of the previous row (= N of the next sample)
+          for (int k = 0; k < 4; k++) { peNW[k] = peN[k]; peN[k] = peNE[k] + err[k]; }
+          teNW = teN; teN = teNE; teW = terr;
+          if (x + 2 < w) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
+          else { for (int k = 0; k < 4; k++) peNE[k] = peN[k]; teNE = teN; }
+        }
+      }
+      __syncthreads();     // row[] written by lane 0 is read by every lane in the next row
+    }
+  }
+  return 0;
+}
+
+// Stream-level wrapper: every lane calls it; falls back to the serial walker when the tree is too large.
+__device__ inline uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
+  DevModStream &st = S.st;
+  if (st.err) return st.err;
+  DevECView ev = st.ev;
+  if (st.num_ctx <= kLdsCtx) ev.ctx_map = S.ctx_map;
+  if (st.num_clusters <= kLocMaxClusters) ev.cfg = S.cfg;
+  if (!ev.use_prefix && st.num_clusters <= kLdsClusters) ev.alias = S.alias;
+  DevBits b = st.b;
+  uint32_t state = ans_init(ev, b);
+  uint32_t err = modular_decode_channels_wave(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane);
+  __syncthreads();
+  if (err == kErrWaveFallback) {
+    if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);
+    __syncthreads();
+    return S.fallback_err;
+  }
+  if (!err && state != 0x130000u) err |= kErrAnsFinal;
+  if (lane == 0) st.b = b;
+  __syncthreads();
+  return err;
+}
+
+}  // namespace jxlamd
+#endif

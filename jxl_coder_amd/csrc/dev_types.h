@@ -102,7 +102,7 @@ struct DevStatic {
 // device error flags (bit set by kernels, checked by host after the frame)
 enum : uint32_t {
   kErrBitstream = 1, kErrUnsupportedTransform = 2, kErrUnsupportedBlock = 4, kErrAnsFinal = 8, kErrLz77 = 16,
-  kErrTreeLocal = 32, kErrSqueeze = 64, kErrPalette = 128,
+  kErrTreeLocal = 32, kErrSqueeze = 64, kErrPalette = 128, kErrWaveFallback = 256,
 };
 
 }  // namespace jxlamd

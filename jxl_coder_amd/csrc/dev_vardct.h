@@ -7,6 +7,7 @@
 // bitstream walker, the whole wave does the data-parallel epilogues.
 #pragma once
 #include "dev_modular.h"
+#include "dev_modular_wave.h"
 #include "dev_tables.h"
 
 namespace jxlamd {
@@ -64,38 +65,56 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
   S.st.b = b;
   modular_stream_begin(B.tables, F, B.local[g], S);
 }
-// phase 2: decode LF coefficients (channels Y, X, B), then begin the HF-metadata stream
-JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g) {
+// one stream's channels: the whole wave on the GPU (dev_modular_wave.h), lane 0 alone in the CPU harness
+JXL_DEV uint32_t lf_decode_stream(DevModScratch &S, const DevChanOut *ch, int nch, int stream_id, int tid) {
+#ifdef __HIPCC__
+  return modular_stream_decode_wave(S, ch, nch, stream_id, tid);
+#else
+  return tid == 0 ? modular_stream_decode(S, ch, nch, stream_id) : 0;
+#endif
+}
+// phase 2a (all lanes): decode LF coefficients (channels Y, X, B)
+JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g, int tid) {
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   DevChanOut ch[3];
   for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
-  uint32_t err = modular_stream_decode(S, ch, 3, 1 + g);
-  if (err) return err;
+  return lf_decode_stream(S, ch, 3, 1 + g, tid);
+}
+// phase 2b (lane 0): block count, begin the HF-metadata stream
+JXL_DEV uint32_t lf_phase_meta_open(const DevBuffers &B, DevModScratch &S, int g) {
+  const DevFrame &F = frame_of(B);
+  const LfGeom q = lf_geom(F, g);
+  int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   const int count = 1 + (int)bits_read(S.st.b, ceil_log2u((uint32_t)(q.bw * q.bh)));
   if (count > q.bw * q.bh) return kErrBitstream;
   scr[kLfScratchInts - 2] = count;
   modular_stream_begin(B.tables, F, B.local[g], S);
   return 0;
 }
-// phase 3: decode HF metadata, place the varblocks
-JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
+// phase 3a (all lanes): decode HF metadata
+JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int tid) {
+  const DevFrame &F = frame_of(B);
+  const LfGeom q = lf_geom(F, g);
+  int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  const int count = scr[kLfScratchInts - 2];
+  int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
+  DevChanOut ch[4];
+  ch[0].d = m_x; ch[0].w = q.tw; ch[0].h = q.th;
+  ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
+  ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
+  ch[3].d = m_sharp; ch[3].w = q.bw; ch[3].h = q.bh;
+  return lf_decode_stream(S, ch, 4, 1 + 2 * F.num_lf_groups + g, tid);
+}
+// phase 3b (lane 0): place the varblocks
+JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
   const int bx0 = q.bx0, by0 = q.by0, bw = q.bw, bh = q.bh;
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   const int count = scr[kLfScratchInts - 2];
-  int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
-  {
-    DevChanOut ch[4];
-    ch[0].d = m_x; ch[0].w = q.tw; ch[0].h = q.th;
-    ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
-    ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
-    ch[3].d = m_sharp; ch[3].w = bw; ch[3].h = bh;
-    uint32_t err = modular_stream_decode(S, ch, 4, 1 + 2 * F.num_lf_groups + g);
-    if (err) return err;
-  }
+  int32_t *m_blk = scr + 3 * 65536 + 2048;
   const DevBits &b = S.st.b;
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];

@@ -1,6 +1,7 @@
 // jxl_coder_amd/csrc/host_parse.cpp — see host_parse.h.
 #include "host_parse.h"
 #include <math.h>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -333,9 +334,14 @@ int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit) {
   return 0;
 }
 
+static void build_static_tables(std::vector<uint8_t> &tab);
 const std::vector<uint8_t> &static_tables() {
   static std::vector<uint8_t> tab;
-  if (!tab.empty()) return tab;
+  static std::once_flag once;
+  std::call_once(once, [] { build_static_tables(tab); });      // decodes may start concurrently on many threads
+  return tab;
+}
+static void build_static_tables(std::vector<uint8_t> &tab) {
   std::vector<uint8_t> v(((sizeof(DevStatic) + 15) / 16) * 16, 0);
   Blob blob(v);
   DevStatic ST; memset(&ST, 0, sizeof(ST));
@@ -361,7 +367,6 @@ const std::vector<uint8_t> &static_tables() {
     ST.llf_off = blob.append(l, sizeof(l)); }
   memcpy(v.data(), &ST, sizeof(ST));
   tab.swap(v);
-  return tab;
 }
 
 }  // namespace jxlamd
