@@ -8,6 +8,8 @@ the RGBA output are resident in HBM (jxlamd_decode_resident + JXLAMD_OUT_DEVICE)
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank decodes its own frames — independent
 units, no data-path collective — weak scaling; value = frames of all ranks / max-over-ranks time.
 """
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # more hardware queues: decoder contexts = HIP streams that must overlap (default is 4)
 import argparse
 import json
 import os

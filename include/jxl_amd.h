@@ -82,6 +82,11 @@ int jxlamd_decode_batch(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, c
  * [0]=LF groups, [1]=pass groups, [2]=reconstruction, [3]=filters+write, [4]=total device time. */
 int jxlamd_last_timing(const jxlamd_decoder *dec, float ms[5]);
 
+/* Profiling aid: per-LF-group phase timestamps (100 MHz device wall clock), 8 x uint64 per LF group:
+ * [0] start, [1] LF stream staged, [2] LF coefficients decoded, [3] metadata stream staged, [4] metadata decoded,
+ * [5] varblocks placed, [6] epilogue done. */
+int jxlamd_debug_lf_phases(jxlamd_decoder *dec, int num_lf_groups, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,7 +114,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   for (int i = 0; i < 6; i++) HIPCHECK(planes[i].ensure(npx * 4));
   HIPCHECK(lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
   HIPCHECK(local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
-  HIPCHECK(misc.ensure(4096 + (size_t)plan.num_lf_groups * 8));
+  HIPCHECK(misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
   void *d_out = out_ptr;
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(out.ensure(out_bytes)); d_out = out.p; }
   DevBuffers B;
@@ -127,8 +127,8 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
                                 B.plane_a[c] = (float *)planes[c].p; B.plane_b[c] = (float *)planes[3 + c].p; }
   B.coef_off = (uint32_t *)coef_off.p; B.lf_scratch = (int32_t *)lf_scratch.p; B.local = (LocalTreeScratch *)local.p;
   B.err = (uint32_t *)misc.p; B.out = (uint8_t *)d_out;
-  DevAux A; A.lf_end_bits = (uint64_t *)((uint8_t *)misc.p + 4096);
-  HIPCHECK(hipMemsetAsync(misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 8, stream));
+  DevAux A; A.lf_end_bits = (uint64_t *)((uint8_t *)misc.p + 4096); A.lf_times = (uint64_t *)((uint8_t *)misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
+  HIPCHECK(hipMemsetAsync(misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   HIPCHECK(hipMemsetAsync(B.strategy, 0xFF, ncell, stream));
   HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
   for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, (size_t)plan.num_groups * 65536 * 4, stream));
@@ -241,6 +241,11 @@ int jxlamd_decode_batch(jxlamd_decoder *d, int n, const uint8_t *const *jxl, con
     if (rc) return rc;
   }
   return JXLAMD_OK;
+}
+
+int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) {
+  if (!d || !d->misc.p) return JXLAMD_ERR_DEVICE;
+  return hipMemcpy(out, (uint8_t *)d->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
 }
 
 int jxlamd_last_timing(const jxlamd_decoder *d, float ms[5]) {

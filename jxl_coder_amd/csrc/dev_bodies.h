@@ -8,26 +8,39 @@ namespace jxlamd {
 
 struct DevAux {
   uint64_t *lf_end_bits;     // [num_lf_groups]: bits consumed by each LfGroup section (single-section frames need it)
+  uint64_t *lf_times;        // [num_lf_groups][8]: phase timestamps (100 MHz wall clock) for profiling
 };
 
 // ---- LfGroup: one workgroup (one wave) per 2048x2048 LF group
+#ifdef __HIPCC__
+#define JXL_STAMP(i) do { if (tid == 0 && A.lf_times) A.lf_times[g * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define JXL_STAMP(i) do { } while (0)
+#endif
 template <class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  JXL_STAMP(0);
   if (tid == 0) lf_phase_open(B, S, g);
   sync();
   modular_stream_stage(S, tid, nthreads);
   sync();
+  JXL_STAMP(1);
   uint32_t e = lf_phase_coeffs(B, S, g, tid);                 // whole wave on the GPU
+  JXL_STAMP(2);
   if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e; } }
   sync();
   if (S.st.err) return;                                       // uniform: read from LDS after the barrier
   modular_stream_stage(S, tid, nthreads);
   sync();
+  JXL_STAMP(3);
   e = lf_phase_meta(B, S, g, tid);
+  JXL_STAMP(4);
   if (tid == 0) { if (!e) e = lf_phase_place(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e; } }
   sync();
   if (S.st.err) return;
+  JXL_STAMP(5);
   lf_group_epilogue(B, g, tid, nthreads);
+  JXL_STAMP(6);
 }
 
 // ---- PassGroup: one workgroup (one wave) per 256x256 group; passes are sequential inside

@@ -28,6 +28,7 @@ struct DevModStream {                 // what lane 0 hands to the other lanes / 
   const DevTreeNode *tree; int32_t count;
   DevECView ev;
   int32_t num_ctx, num_clusters;
+  int32_t m16;
   uint32_t err;
 };
 
@@ -266,7 +267,7 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
   DevModStream &st = S.st;
   int ntr, use_global;
   modular_read_header(st.b, st.wp, ntr, use_global);
-  st.err = 0;
+  st.err = 0; st.m16 = F.modular_16bit;
   if (ntr != 0) { st.err = kErrUnsupportedTransform; return; }
   if (use_global) {
     if (F.tree_count <= 0) { st.err = kErrBitstream; return; }

@@ -54,14 +54,31 @@ __device__ inline void wave_tree_build(const DevTreeNode *tree, int count, int c
   }
 }
 
-__device__ inline uint32_t wave_ec_read(const DevECView &v, DevBits &b, uint32_t &state, uint32_t ctx) {
-  return ec_read(v, b, state, ctx);
+// rANS symbol + hybrid uint with every table addressed directly in LDS (ds_read instead of flat loads through
+// generic pointers); used when the stream's code fits the LDS staging area, which is the case for libjxl's streams.
+template <bool kLds>
+__device__ inline uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx) {
+  if (!kLds) return ec_read(v, b, state, ctx);
+  const uint32_t cluster = S.ctx_map[ctx];
+  const int lb = 12 - v.log_alpha;
+  const uint32_t res = state & 0xfff;
+  const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
+  const DevAlias e = S.alias[(cluster << v.log_alpha) + i];
+  const uint32_t cfg = S.cfg[cluster];
+  const bool right = pos >= e.cutoff;
+  const uint32_t sym = right ? e.right : i;
+  const uint32_t off = right ? (uint32_t)e.off1 + pos : pos;
+  const uint32_t freq = right ? e.freq1 : e.freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | bits_read(b, 16);
+  return ec_hybrid(b, cfg, sym);
 }
 
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
+template <bool kLds>
 __device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
                                                         int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
-                                                        const DevChanOut *chans, int nch, int stream_id, int lane) {
+                                                        const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
   for (int ci = 0; ci < nch; ci++) {
     const DevChanOut c = chans[ci];
     const int w = c.w, h = c.h;
@@ -120,7 +137,44 @@ __device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, Dev
         pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_); pv[15] = 0;
         // weighted predictor (uniform across lanes)
         int64_t wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
-        if (uses_wp) {
+        if (uses_wp && m16) {
+          // 32-bit weighted predictor: valid because modular_16bit_buffers guarantees |sample| < 2^15, so every
+          // intermediate below stays under 2^31 (predictions < 2^19, weights < 2^5 after normalisation, 4 terms).
+          uint32_t wgt[4];
+          for (int k = 0; k < 4; k++) {
+            const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
+            wgt[k] = wp_error_weight(S.divlut, e, (uint32_t)wp.w[k]);
+          }
+          const int32_t N8 = (int32_t)N_ * 8, W8 = (int32_t)W_ * 8, NE8 = (int32_t)NE_ * 8, NW8 = (int32_t)NW_ * 8, NN8 = (int32_t)NN_ * 8;
+          const int32_t tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
+          const int32_t sumWN = tN + tW;
+          int32_t p = tW;
+          if (abs(tN) > abs(p)) p = tN;
+          if (abs(tNW) > abs(p)) p = tNW;
+          if (abs(tNE) > abs(p)) p = tNE;
+          pv[15] = p;
+          int32_t q[4];
+          q[0] = W8 + NE8 - N8;
+          q[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
+          q[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
+          q[3] = N8 - ((tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + (NW8 - W8) * wp.p3e) >> 5);
+          uint32_t wsum = wgt[0] + wgt[1] + wgt[2] + wgt[3];
+          const int lw = floor_log2_u32(wsum);
+          wsum = 0;
+          for (int k = 0; k < 4; k++) { wgt[k] >>= lw - 4; wsum += wgt[k]; }
+          int32_t sum = (int32_t)(wsum >> 1) - 1;
+          for (int k = 0; k < 4; k++) sum += q[k] * (int32_t)wgt[k];
+          int32_t raw = (int32_t)(((int64_t)sum * (int64_t)S.divlut[wsum - 1]) >> 24);
+          if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
+            int32_t mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
+            int32_t mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
+            if (raw > mx) raw = mx;
+            if (raw < mn) raw = mn;
+          }
+          wp_raw = raw;
+          for (int k = 0; k < 4; k++) wpred[k] = q[k];
+          wp_pred = (raw + 3) >> 3;
+        } else if (uses_wp) {
           uint32_t wgt[4];
           for (int k = 0; k < 4; k++) {
             const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
@@ -162,7 +216,7 @@ __device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, Dev
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int l_ctx = WT.leaf_ctx[leaf], l_pred = WT.leaf_pred[leaf], l_off = WT.leaf_off[leaf], l_mul = WT.leaf_mul[leaf];
         const int64_t guess = predict_plain(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
-        const uint32_t u = wave_ec_read(ev, b, state, (uint32_t)l_ctx);
+        const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx);
         const int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)l_mul + l_off + guess;
         if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
         // slide
@@ -197,7 +251,9 @@ __device__ inline uint32_t modular_stream_decode_wave(DevModScratch &S, const De
   if (!ev.use_prefix && st.num_clusters <= kLdsClusters) ev.alias = S.alias;
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
-  uint32_t err = modular_decode_channels_wave(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane);
+  const bool lds = st.num_ctx <= kLdsCtx && st.num_clusters <= kLdsClusters && !ev.use_prefix;
+  uint32_t err = lds ? modular_decode_channels_wave<true>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
+                     : modular_decode_channels_wave<false>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
   __syncthreads();
   if (err == kErrWaveFallback) {
     if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);

@@ -60,6 +60,7 @@ struct DevFrame {
   float base_x, base_b, inv_color_factor;
   float quant_bias[4];
   int32_t skip_lf_smoothing;
+  int32_t modular_16bit;           // ImageMetadata.modular_16bit_buffers: every Modular sample fits int16 (enables 32-bit WP math)
   // block context
   int32_t nb_lf_thr[3]; int32_t lf_thr[3][16];
   int32_t nb_qf_thr; uint32_t qf_thr[16];

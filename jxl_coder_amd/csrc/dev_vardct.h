@@ -120,27 +120,41 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
   if (end_bits) end_bits[g] = b.consumed;
   if (b.consumed > (uint64_t)sec.size * 8 + 64 && F.nsec != 1) return kErrBitstream;
-  // --- varblock placement: raster scan, next block goes to the first unoccupied cell
+  // --- varblock placement: the next block goes to the first unoccupied cell in raster order.  Occupancy is a
+  // bitmap in LDS (the alias-table area is free once the streams are decoded), scanned a 32-bit word at a time, so
+  // the serial cost scales with the number of varblocks, not with the 65 536 cells.
+  uint32_t *occ = (uint32_t *)S.alias;                 // 256 rows x 8 words
+  for (int i = 0; i < 256 * 8; i++) occ[i] = 0;
   int num = 0;
-  for (int y = 0; y < bh; y++)
-    for (int x = 0; x < bw; x++) {
-      size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
-      if (B.strategy[o] != 0xFF) continue;
-      if (num >= count) return kErrBitstream;
-      int st = m_blk[num], q = m_blk[count + num];
-      num++;
-      if (st < 0 || st > 26 || q < 0 || q > 255) return kErrBitstream;
-      int cx = kCoveredX[st], cy = kCoveredY[st];
-      if (x + cx > bw || y + cy > bh) return kErrBitstream;
-      if ((x & 31) + cx > 32 || (y & 31) + cy > 32) return kErrBitstream;   // must not straddle a 256x256 group
-      for (int iy = 0; iy < cy; iy++)
-        for (int ix = 0; ix < cx; ix++) {
-          size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
-          if (B.strategy[oo] != 0xFF) return kErrBitstream;
-          B.strategy[oo] = (uint8_t)st; B.first[oo] = 0; B.qfm1[oo] = (uint8_t)q;
+  for (int y = 0; y < bh; y++) {
+    for (int wx = 0; wx < (bw + 31) / 32; wx++) {
+      for (;;) {
+        uint32_t freebits = ~occ[y * 8 + wx];
+        if (wx * 32 + 32 > bw) freebits &= (1u << (bw - wx * 32)) - 1u;
+        if (!freebits) break;
+        const int x = wx * 32 + __builtin_ctz(freebits);
+        if (num >= count) return kErrBitstream;
+        const int st = m_blk[num], q = m_blk[count + num];
+        num++;
+        if (st < 0 || st > 26 || q < 0 || q > 255) return kErrBitstream;
+        const int cx = kCoveredX[st], cy = kCoveredY[st];
+        if (x + cx > bw || y + cy > bh) return kErrBitstream;
+        if ((x & 31) + cx > 32 || (y & 31) + cy > 32) return kErrBitstream;   // must not straddle a 256x256 group
+        const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1u)) << (x & 31);
+        const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+        for (int iy = 0; iy < cy; iy++) {
+          uint32_t &wd = occ[(y + iy) * 8 + wx];
+          if (wd & mask) return kErrBitstream;               // overlapping varblocks
+          wd |= mask;
+          for (int ix = 0; ix < cx; ix++) {
+            const size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
+            B.strategy[oo] = (uint8_t)st; B.first[oo] = 0; B.qfm1[oo] = (uint8_t)q;
+          }
         }
-      B.first[o] = 1;
+        B.first[o] = 1;
+      }
     }
+  }
   return 0;
 }
 

@@ -285,6 +285,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   F.base_x = base_x; F.base_b = base_b; F.inv_color_factor = 1.0f / (float)color_factor;
   memcpy(F.quant_bias, m.quant_bias, sizeof(F.quant_bias));
   F.skip_lf_smoothing = (f.flags & 128) ? 1 : 0;
+  F.modular_16bit = m.modular_16;
   F.gab = f.gab; memcpy(F.gab_w, f.gab_w, sizeof(F.gab_w));
   F.epf_iters = f.epf_iters; memcpy(F.epf_sharp, f.epf_sharp, sizeof(F.epf_sharp)); memcpy(F.epf_chscale, f.epf_chscale, sizeof(F.epf_chscale));
   F.epf_quant_mul = f.epf_quant_mul; F.epf_pass0 = f.epf_pass0; F.epf_pass2 = f.epf_pass2; F.epf_border_sad = f.epf_border_sad;

@@ -44,7 +44,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = &err; B.out = out;
   std::vector<LocalTreeScratch> loc((size_t)plan.num_lf_groups); B.local = loc.data();
-  DevAux A; A.lf_end_bits = endbits.data();
+  DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
   const std::vector<uint8_t> &stat = static_tables();
   DevModScratch *MS = new DevModScratch();
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());

@@ -10,3 +10,13 @@ data = open(os.path.join(ROOT, "bench_data/syn4k_q90_seed0.jxl"), "rb").read()
 for i in range(n):
     t = time.time(); out, info = dec.decode_one_shot(data); dt = time.time() - t
     print("4k %.1f ms wall" % (dt * 1e3), dec.last_timing())
+
+import ctypes as C, numpy as np
+L = J.api.lib()
+L.jxlamd_debug_lf_phases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+t = np.zeros((4, 8), np.uint64)
+L.jxlamd_debug_lf_phases(dec._h, 4, t.ctypes.data)
+names = ["open+stage", "LF coeffs", "meta open+stage", "meta decode", "place", "epilogue"]
+for g in range(4):
+    d = (t[g, 1:7].astype(np.int64) - t[g, 0:6].astype(np.int64)) / 1e5
+    print("lf group", g, {n: round(float(v), 2) for n, v in zip(names, d)}, "ms")
