@@ -74,9 +74,15 @@ int jxlamd_decode_resident(jxlamd_decoder *dec, const uint8_t *jxl, size_t size,
                            void *out, size_t out_capacity, jxlamd_info *info);
 
 /* Batch extension (BASELINE configs 3/5): n independent files, outputs[i] sized by jxlamd_output_size.
- * Equivalent to n jxlamd_decode calls; returns the first failing status. */
+ * Produces exactly what n jxlamd_decode calls would; the entropy stages of all frames share one launch each so that
+ * their serial streams run side by side.  Returns the first failing status. */
 int jxlamd_decode_batch(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes, uint32_t flags,
                         void *const *outs, const size_t *out_capacities, jxlamd_info *infos);
+
+/* Batch with the compressed bytes of frame i also resident in HBM at jxl_dev[i] (may be NULL per frame). */
+int jxlamd_decode_batch_resident(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes,
+                                 const void *const *jxl_dev, uint32_t flags, void *const *outs, const size_t *out_capacities,
+                                 jxlamd_info *infos);
 
 /* Timing of the last decode in milliseconds (HIP events on the decoder's stream):
  * [0]=LF groups, [1]=pass groups, [2]=reconstruction, [3]=filters+write, [4]=total device time. */

@@ -103,6 +103,7 @@ def lib():
         L.jxlamd_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 5)]
+        L.jxlamd_decode_batch_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -160,6 +161,22 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return info.as_dict()
+
+    def decode_batch_to_device(self, datas, out_ptrs, out_capacities, data_dev_ptrs=None, allowed_floats=True):
+        """jxlamd_decode_batch_resident: n independent frames; the entropy stages of the whole batch share one launch each."""
+        n = len(datas)
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE
+        bufs = [C.c_char_p(d) for d in datas]
+        a_jxl = (C.c_char_p * n)(*bufs)
+        a_sz = (C.c_size_t * n)(*[len(d) for d in datas])
+        a_dev = (C.c_void_p * n)(*[C.c_void_p(p) for p in (data_dev_ptrs or [0] * n)])
+        a_out = (C.c_void_p * n)(*[C.c_void_p(p) for p in out_ptrs])
+        a_cap = (C.c_size_t * n)(*out_capacities)
+        infos = (Info * n)()
+        rc = lib().jxlamd_decode_batch_resident(self._h, n, a_jxl, a_sz, a_dev, flags, a_out, a_cap, infos)
+        if rc:
+            _raise(rc, self._h)
+        return [i.as_dict() for i in infos]
 
     def last_timing(self):
         t = (C.c_float * 5)()

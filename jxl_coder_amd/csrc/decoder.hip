@@ -31,17 +31,44 @@ struct DevMem {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct FrameSlot {             // HBM work buffers of one in-flight frame
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out;
+  FramePlan plan;
+  DevBuffers B;
+  DevAux A;
+  jxlamd_info pi;
+  size_t out_bytes = 0;
+  void *d_out = nullptr; void *host_out = nullptr;
+  void release() {
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out};
+    for (auto *m : all) m->release();
+    for (auto &m : cells8) m.release();
+    for (auto &m : tiles) m.release();
+    for (auto &m : lf) m.release();
+    for (auto &m : coef) m.release();
+    for (auto &m : planes) m.release();
+  }
+};
+
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem cs, tables, stat, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out;
+  DevMem stat, batch_tab;
+  std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
   float timing[5] = {0, 0, 0, 0, 0};
   void set_error(const std::string &e) { error = e; g_tls_error = e; }
+  FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
 
+  int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int finish_single_section(FrameSlot &S);
+  int launch_rest(FrameSlot &S);
+  int collect(FrameSlot &S, uint32_t flags);
   int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
+                   const size_t *caps, jxlamd_info *infos);
 };
 
 static void fill_public_info(const ImageInfo &i, uint32_t flags, jxlamd_info *o) {
@@ -72,23 +99,22 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
   return 0;
 }
 
-int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
-  HIPCHECK(hipSetDevice(device));
-  FramePlan plan;
-  if (plan_parse(jxl, size, &plan)) {
-    set_error(plan.error);
-    return plan.error.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID;
-  }
-  jxlamd_info pi;
-  fill_public_info(plan.info, flags, &pi);
-  if (info) *info = pi;
-  { std::string e; int rc = size_guard(pi, flags, &e); if (rc) { set_error(e); return rc; } }
-  const size_t out_bytes = (size_t)pi.xsize * pi.ysize * 4 * (pi.out_bits == 16 ? 2 : 1);
-  if (out_cap < out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
+static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
+static int dev_err_class(uint32_t derr) { return (derr & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
+
+// host parse + buffers + H2D + clears for one frame (everything before the first kernel)
+int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+  FramePlan &plan = S.plan;
+  plan = FramePlan();
+  if (plan_parse(jxl, size, &plan)) { set_error(plan.error); return err_class(plan.error); }
+  fill_public_info(plan.info, flags, &S.pi);
+  if (info) *info = S.pi;
+  { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }
+  S.out_bytes = (size_t)S.pi.xsize * S.pi.ysize * 4 * (S.pi.out_bits == 16 ? 2 : 1);
+  if (out_cap < S.out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
   const size_t ncell = (size_t)plan.xb * plan.yb;
   const size_t ntile = (size_t)((plan.xb + 7) / 8) * ((plan.yb + 7) / 8);
   const size_t npx = ncell * 64;
-  // ---- buffers
   if (!stat_uploaded) {
     const std::vector<uint8_t> &st = static_tables();
     HIPCHECK(stat.ensure(st.size()));
@@ -99,75 +125,151 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   const uint8_t *d_cs;
   if (cs_alias) d_cs = (const uint8_t *)jxl_dev + (plan.cs - jxl);
   else {
-    HIPCHECK(cs.ensure(plan.cs_size + 64));
-    HIPCHECK(hipMemcpyAsync(cs.p, plan.cs, plan.cs_size, hipMemcpyHostToDevice, stream));
-    HIPCHECK(hipMemsetAsync((uint8_t *)cs.p + plan.cs_size, 0, 64, stream));
-    d_cs = (const uint8_t *)cs.p;
+    HIPCHECK(S.cs.ensure(plan.cs_size + 64));
+    HIPCHECK(hipMemcpyAsync(S.cs.p, plan.cs, plan.cs_size, hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
+    d_cs = (const uint8_t *)S.cs.p;
   }
-  HIPCHECK(tables.ensure(plan.tables.size() + (8u << 20)));     // room for the phase-2 (HfGlobal) tables
-  HIPCHECK(hipMemcpyAsync(tables.p, plan.tables.data(), plan.tables.size(), hipMemcpyHostToDevice, stream));
-  for (int i = 0; i < 5; i++) HIPCHECK(cells8[i].ensure(ncell));
-  for (int i = 0; i < 2; i++) HIPCHECK(tiles[i].ensure(ntile));
-  for (int i = 0; i < 6; i++) HIPCHECK(lf[i].ensure(ncell * 4));
-  HIPCHECK(coef_off.ensure(ncell * 4));
-  for (int c = 0; c < 3; c++) HIPCHECK(coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
-  for (int i = 0; i < 6; i++) HIPCHECK(planes[i].ensure(npx * 4));
-  HIPCHECK(lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
-  HIPCHECK(local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
-  HIPCHECK(misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
-  void *d_out = out_ptr;
-  if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(out.ensure(out_bytes)); d_out = out.p; }
-  DevBuffers B;
+  HIPCHECK(S.tables.ensure(plan.tables.size() + (8u << 20)));     // room for the phase-2 (HfGlobal) tables
+  HIPCHECK(hipMemcpyAsync(S.tables.p, plan.tables.data(), plan.tables.size(), hipMemcpyHostToDevice, stream));
+  for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
+  for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
+  for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
+  HIPCHECK(S.coef_off.ensure(ncell * 4));
+  for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
+  for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));
+  HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
+  HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
+  HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
+  S.host_out = nullptr; S.d_out = out_ptr;
+  if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(S.out_bytes)); S.d_out = S.out.p; S.host_out = out_ptr; }
+  DevBuffers &B = S.B;
   memset(&B, 0, sizeof(B));
-  B.codestream = d_cs; B.tables = (const uint8_t *)tables.p;
-  B.strategy = (uint8_t *)cells8[0].p; B.first = (uint8_t *)cells8[1].p; B.qfm1 = (uint8_t *)cells8[2].p;
-  B.sharp = (uint8_t *)cells8[3].p; B.lf_idx = (uint8_t *)cells8[4].p;
-  B.xfromy = (int8_t *)tiles[0].p; B.bfromy = (int8_t *)tiles[1].p;
-  for (int c = 0; c < 3; c++) { B.lf[c] = (float *)lf[c].p; B.lf_s[c] = (float *)lf[3 + c].p; B.coef[c] = (int32_t *)coef[c].p;
-                                B.plane_a[c] = (float *)planes[c].p; B.plane_b[c] = (float *)planes[3 + c].p; }
-  B.coef_off = (uint32_t *)coef_off.p; B.lf_scratch = (int32_t *)lf_scratch.p; B.local = (LocalTreeScratch *)local.p;
-  B.err = (uint32_t *)misc.p; B.out = (uint8_t *)d_out;
-  DevAux A; A.lf_end_bits = (uint64_t *)((uint8_t *)misc.p + 4096); A.lf_times = (uint64_t *)((uint8_t *)misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
-  HIPCHECK(hipMemsetAsync(misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
-  HIPCHECK(hipMemsetAsync(B.strategy, 0xFF, ncell, stream));
+  B.codestream = d_cs; B.tables = (const uint8_t *)S.tables.p;
+  B.strategy = (uint8_t *)S.cells8[0].p; B.first = (uint8_t *)S.cells8[1].p; B.qfm1 = (uint8_t *)S.cells8[2].p;
+  B.sharp = (uint8_t *)S.cells8[3].p; B.lf_idx = (uint8_t *)S.cells8[4].p;
+  B.xfromy = (int8_t *)S.tiles[0].p; B.bfromy = (int8_t *)S.tiles[1].p;
+  for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
+                                B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
+  B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
+  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out;
+  S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
+  S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
+  HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
   for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, (size_t)plan.num_groups * 65536 * 4, stream));
-  // ---- kernels
-  HIPCHECK(hipEventRecord(ev[0], stream));
-  launch_lf_groups(B, A, plan.num_lf_groups, stream);
-  if (plan.single_section) {
-    // HfGlobal follows LfGroup 0 in the same section: its bit position is only known now.
-    uint64_t end_bit = 0; uint32_t derr = 0;
-    HIPCHECK(hipMemcpyAsync(&end_bit, A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipMemcpyAsync(&derr, B.err, 4, hipMemcpyDeviceToHost, stream));
-    HIPCHECK(hipStreamSynchronize(stream));
-    if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return (derr & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
-    if (plan_parse_hf_single(&plan, end_bit)) { set_error(plan.error); return plan.error.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
-    HIPCHECK(tables.ensure(plan.tables.size()));
-    HIPCHECK(hipMemcpyAsync(tables.p, plan.tables.data(), plan.tables.size(), hipMemcpyHostToDevice, stream));
-  }
-  HIPCHECK(hipEventRecord(ev[1], stream));
-  launch_lf_smooth(B, plan.xb, plan.yb, stream);
-  launch_pass_groups(B, plan.num_groups, stream);
-  HIPCHECK(hipEventRecord(ev[2], stream));
-  launch_recon(B, (const uint8_t *)stat.p, plan.xb, plan.yb, stream);
-  HIPCHECK(hipEventRecord(ev[3], stream));
+  return JXLAMD_OK;
+}
+
+// single-section frames: HfGlobal follows LfGroup 0 in the same section; its bit position is only known after the LF kernel
+int jxlamd_decoder::finish_single_section(FrameSlot &S) {
+  uint64_t end_bit = 0; uint32_t derr = 0;
+  HIPCHECK(hipMemcpyAsync(&end_bit, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipStreamSynchronize(stream));
+  if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
+  if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
+  HIPCHECK(S.tables.ensure(S.plan.tables.size()));
+  HIPCHECK(hipMemcpyAsync(S.tables.p, S.plan.tables.data(), S.plan.tables.size(), hipMemcpyHostToDevice, stream));
+  return JXLAMD_OK;
+}
+
+// everything after the entropy stages: reconstruction, loop filters, RGBA writer, D2H of the output if asked
+int jxlamd_decoder::launch_rest(FrameSlot &S) {
+  const FramePlan &plan = S.plan;
+  launch_recon(S.B, (const uint8_t *)stat.p, plan.xb, plan.yb, stream);
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  bool src_a = launch_filters(B, plan.width, plan.height, F->gab, F->epf_iters, true, stream);
-  launch_write(B, (const uint8_t *)stat.p, plan.width, plan.height, (int)pi.out_bits, src_a, stream);
-  HIPCHECK(hipEventRecord(ev[4], stream));
+  bool src_a = launch_filters(S.B, plan.width, plan.height, F->gab, F->epf_iters, true, stream);
+  launch_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, (int)S.pi.out_bits, src_a, stream);
+  return JXLAMD_OK;
+}
+
+int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   uint32_t derr = 0;
-  HIPCHECK(hipMemcpyAsync(&derr, B.err, 4, hipMemcpyDeviceToHost, stream));
-  if (!(flags & JXLAMD_OUT_DEVICE)) HIPCHECK(hipMemcpyAsync(out_ptr, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
+  (void)flags;
+  if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
+  return JXLAMD_OK;
+}
+
+int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  int rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
+  if (rc) return rc;
+  HIPCHECK(hipEventRecord(ev[0], stream));
+  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
+  if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
+  HIPCHECK(hipEventRecord(ev[1], stream));
+  launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
+  launch_pass_groups(S.B, S.plan.num_groups, stream);
+  HIPCHECK(hipEventRecord(ev[2], stream));
+  launch_recon(S.B, (const uint8_t *)stat.p, S.plan.xb, S.plan.yb, stream);
+  HIPCHECK(hipEventRecord(ev[3], stream));
+  const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+  bool src_a = launch_filters(S.B, S.plan.width, S.plan.height, F->gab, F->epf_iters, true, stream);
+  launch_write(S.B, (const uint8_t *)stat.p, S.plan.width, S.plan.height, (int)S.pi.out_bits, src_a, stream);
+  HIPCHECK(hipEventRecord(ev[4], stream));
+  rc = collect(S, flags);
   for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);
   (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
-  if (derr) {
-    set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")");
-    return (derr & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID;
+  return rc;
+}
+
+// n independent frames: the entropy stages of ALL frames go into ONE launch each (grid = sum of LF groups / groups
+// over the batch), so that their serial streams run side by side on the chip; the cheap data-parallel stages follow
+// per frame on the same stream.  Frames that need the single-section round trip are decoded one by one.
+int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
+                                 void *const *outs, const size_t *caps, jxlamd_info *infos) {
+  HIPCHECK(hipSetDevice(device));
+  std::vector<int> batched;
+  for (int i = 0; i < n; i++) {
+    FrameSlot &S = slot((size_t)i);
+    int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
+                     outs[i], caps[i], infos ? &infos[i] : nullptr);
+    if (rc) return rc;
+    if (S.plan.single_section) {
+      launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
+      rc = finish_single_section(S); if (rc) return rc;
+      launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
+      launch_pass_groups(S.B, S.plan.num_groups, stream);
+      launch_rest(S);
+      rc = collect(S, flags); if (rc) return rc;
+    } else batched.push_back(i);
   }
-  return JXLAMD_OK;
+  if (batched.empty()) return JXLAMD_OK;
+  // device tables of the batch: DevBuffers[], DevAux[], (frame, local index) per block for both entropy kernels
+  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map;
+  for (size_t k = 0; k < batched.size(); k++) {
+    FrameSlot &S = slot((size_t)batched[k]);
+    hb.push_back(S.B); ha.push_back(S.A);
+    for (int g = 0; g < S.plan.num_lf_groups; g++) { lf_map.push_back((int)k); lf_map.push_back(g); }
+    for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back((int)k); pg_map.push_back(g); }
+  }
+  const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
+               o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, total = o_pg + pg_map.size() * 4;
+  HIPCHECK(batch_tab.ensure(total));
+  uint8_t *bt = (uint8_t *)batch_tab.p;
+  HIPCHECK(hipMemcpyAsync(bt + o_b, hb.data(), hb.size() * sizeof(DevBuffers), hipMemcpyHostToDevice, stream));
+  HIPCHECK(hipMemcpyAsync(bt + o_a, ha.data(), ha.size() * sizeof(DevAux), hipMemcpyHostToDevice, stream));
+  HIPCHECK(hipMemcpyAsync(bt + o_lf, lf_map.data(), lf_map.size() * 4, hipMemcpyHostToDevice, stream));
+  HIPCHECK(hipMemcpyAsync(bt + o_pg, pg_map.data(), pg_map.size() * 4, hipMemcpyHostToDevice, stream));
+  HIPCHECK(hipEventRecord(ev[0], stream));
+  launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
+  HIPCHECK(hipEventRecord(ev[1], stream));
+  for (int i : batched) { FrameSlot &S = slot((size_t)i); launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream); }
+  launch_pass_groups_batch((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
+  HIPCHECK(hipEventRecord(ev[2], stream));
+  for (int i : batched) launch_rest(slot((size_t)i));
+  HIPCHECK(hipEventRecord(ev[4], stream));
+  int first_rc = JXLAMD_OK;
+  for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }
+  (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);
+  (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
+  return first_rc;
 }
 
 extern "C" {
@@ -191,13 +293,8 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  DevMem *all[] = {&d->cs, &d->tables, &d->stat, &d->coef_off, &d->lf_scratch, &d->local, &d->misc, &d->out};
-  for (auto *m : all) m->release();
-  for (auto &m : d->cells8) m.release();
-  for (auto &m : d->tiles) m.release();
-  for (auto &m : d->lf) m.release();
-  for (auto &m : d->coef) m.release();
-  for (auto &m : d->planes) m.release();
+  d->stat.release(); d->batch_tab.release();
+  for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
   delete d;
@@ -236,16 +333,18 @@ int jxlamd_decode_resident(jxlamd_decoder *d, const uint8_t *jxl, size_t size, c
 int jxlamd_decode_batch(jxlamd_decoder *d, int n, const uint8_t *const *jxl, const size_t *sizes, uint32_t flags, void *const *outs,
                         const size_t *caps, jxlamd_info *infos) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  for (int i = 0; i < n; i++) {
-    int rc = d->decode(jxl[i], sizes[i], nullptr, flags & ~JXLAMD_IN_DEVICE, outs[i], caps[i], infos ? &infos[i] : nullptr);
-    if (rc) return rc;
-  }
-  return JXLAMD_OK;
+  return d->decode_batch(n, jxl, sizes, nullptr, flags & ~JXLAMD_IN_DEVICE, outs, caps, infos);
+}
+
+int jxlamd_decode_batch_resident(jxlamd_decoder *d, int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev,
+                                 uint32_t flags, void *const *outs, const size_t *caps, jxlamd_info *infos) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  return d->decode_batch(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
 }
 
 int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) {
-  if (!d || !d->misc.p) return JXLAMD_ERR_DEVICE;
-  return hipMemcpy(out, (uint8_t *)d->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
+  if (!d || d->slots.empty() || !d->slots[0]->misc.p) return JXLAMD_ERR_DEVICE;
+  return hipMemcpy(out, (uint8_t *)d->slots[0]->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
 }
 
 int jxlamd_last_timing(const jxlamd_decoder *d, float ms[5]) {

@@ -4,6 +4,8 @@
 #include "dev_bodies.h"
 namespace jxlamd {
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, hipStream_t s);
+void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
+void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);
 void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);
 void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s);

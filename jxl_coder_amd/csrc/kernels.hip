@@ -21,6 +21,18 @@ __global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
   pass_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
 }
 
+// batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
+__global__ void __launch_bounds__(64) k_lf_group_batch(const DevBuffers *Bs, const DevAux *As, const int *map) {
+  __shared__ DevModScratch S;
+  const int f = map[2 * blockIdx.x], g = map[2 * blockIdx.x + 1];
+  lf_group_body(Bs[f], As[f], S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, const int *map) {
+  __shared__ DevPassScratch S;
+  const int f = map[2 * blockIdx.x], g = map[2 * blockIdx.x + 1];
+  pass_group_body(Bs[f], S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+
 __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb) {
   int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= xb * yb) return;
@@ -62,6 +74,8 @@ __global__ void __launch_bounds__(256) k_write(DevBuffers B, const uint8_t *stat
 
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
+void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map); }
+void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B, xb, yb);
 }

@@ -87,3 +87,17 @@ def test_jxlcoder_surface(dec):
     px = J.JxlCoder.decode(data)
     assert np.abs(px.astype(int) - exp.astype(int)).max() <= 1
     assert J.JxlCoder.getSize(data) == (256, 256)
+
+
+def test_batch_equals_single_decodes(dec):
+    """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
+    import torch
+    names = ["v264x520_e7", "v256_e7", "v264x520_e7", "v300x300_e7_d3"]      # multi-section and single-section mixed
+    datas = [load_case(n)[0] for n in names]
+    singles = [dec.decode_one_shot(d)[0] for d in datas]
+    outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+    infos = dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+    torch.cuda.synchronize()
+    for s, o, i in zip(singles, outs, infos):
+        assert (i["ysize"], i["xsize"]) == s.shape[:2]
+        assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
