@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <limits>
+#include <thread>
 #include <string>
 #include <vector>
 #include "../../include/jxl_amd.h"
@@ -62,7 +64,8 @@ struct jxlamd_decoder {
   void set_error(const std::string &e) { error = e; g_tls_error = e; }
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
 
-  int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
+              bool parsed = false);
   int finish_single_section(FrameSlot &S);
   int launch_rest(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
@@ -103,10 +106,11 @@ static int err_class(const std::string &e) { return e.rfind("unsupported", 0) ==
 static int dev_err_class(uint32_t derr) { return (derr & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host parse + buffers + H2D + clears for one frame (everything before the first kernel)
-int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
+                            bool parsed) {
   FramePlan &plan = S.plan;
-  plan = FramePlan();
-  if (plan_parse(jxl, size, &plan)) { set_error(plan.error); return err_class(plan.error); }
+  if (!parsed) { plan = FramePlan(); (void)plan_parse(jxl, size, &plan); }
+  if (!plan.error.empty() || plan.tables.empty()) { set_error(plan.error); return err_class(plan.error); }
   fill_public_info(plan.info, flags, &S.pi);
   if (info) *info = S.pi;
   { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }
@@ -226,10 +230,19 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   HIPCHECK(hipSetDevice(device));
   std::vector<int> batched;
+  // host parse of all frames in parallel (pure CPU work, independent per frame)
+  for (int i = 0; i < n; i++) { slot((size_t)i).plan = FramePlan(); }
+  {
+    const int nthr = n < 16 ? n : 16;
+    std::vector<std::thread> th;
+    std::atomic<int> next{0};
+    for (int t = 0; t < nthr; t++) th.emplace_back([&] { for (;;) { int i = next.fetch_add(1); if (i >= n) return; (void)plan_parse(jxl[i], sizes[i], &slots[(size_t)i]->plan); } });
+    for (auto &t : th) t.join();
+  }
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
-                     outs[i], caps[i], infos ? &infos[i] : nullptr);
+                     outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true);
     if (rc) return rc;
     if (S.plan.single_section) {
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);

@@ -153,6 +153,7 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
 
 int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   plan->error.clear();
+  plan->tables.clear();
   uint8_t *cs; size_t csn; int owned;
   if (extract_codestream(data, size, &cs, &csn, &owned)) { plan->error = hx_last_error(); return -1; }
   if (owned) { plan->cs_owned.assign(cs, cs + csn); free(cs); plan->cs = plan->cs_owned.data(); }

@@ -46,12 +46,18 @@ __global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t 
   int cell = (int)blockIdx.x;
   recon_block_body(B, stat, S, T, cell % xb, cell / xb, false, (int)threadIdx.x, 64, SyncBlock());
 }
-// large varblocks (512..4096 coefficients): 256 threads per block, LDS 64 KiB
-__global__ void __launch_bounds__(256) k_recon_big(DevBuffers B, const uint8_t *stat, int xb) {
+// large varblocks (512..4096 coefficients): 256 threads per block, LDS 64 KiB.  Large blocks are sparse among the
+// cells, so each workgroup scans kBigScan consecutive cells instead of launching one (mostly empty) workgroup per cell.
+constexpr int kBigScan = 16;
+__global__ void __launch_bounds__(256) k_recon_big(DevBuffers B, const uint8_t *stat, int xb, int ncell) {
   __shared__ float S[3 * 4096];
   __shared__ float T[4096];
-  int cell = (int)blockIdx.x;
-  recon_block_body(B, stat, S, T, cell % xb, cell / xb, true, (int)threadIdx.x, 256, SyncBlock());
+  for (int i = 0; i < kBigScan; i++) {
+    const int cell = (int)blockIdx.x * kBigScan + i;
+    if (cell >= ncell) return;
+    recon_block_body(B, stat, S, T, cell % xb, cell / xb, true, (int)threadIdx.x, 256, SyncBlock());
+    __syncthreads();
+  }
 }
 
 struct Planes { float *p[3]; };
@@ -81,7 +87,7 @@ void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
 }
 void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_recon_small, dim3(xb * yb), dim3(64), 0, s, B, stat, xb);
-  hipLaunchKernelGGL(k_recon_big, dim3(xb * yb), dim3(256), 0, s, B, stat, xb);
+  hipLaunchKernelGGL(k_recon_big, dim3((xb * yb + kBigScan - 1) / kBigScan), dim3(256), 0, s, B, stat, xb, xb * yb);
 }
 static Planes planes_of(const DevBuffers &B, bool a) {
   Planes p;
