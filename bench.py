@@ -50,9 +50,10 @@ def cpu_baseline(data, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=2, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
 
@@ -76,31 +77,52 @@ def main():
     # AC wavefronts for one 4K frame) and leave the chip almost empty; a decode service fills it with frames in
     # flight.  --inflight 1 gives the strictly sequential single-frame number (also reported below).
     P = max(1, min(args.inflight, args.steps))
-    dec = J.JxlDecoder(local)
+    NCTX = max(1, min(args.contexts, (args.steps + P - 1) // P))
+    decs = [J.JxlDecoder(local) for _ in range(NCTX)]
+    dec = decs[0]
     d_in = torch.frombuffer(bytearray(data) + bytearray(64), dtype=torch.uint8).to(f"cuda:{local}")   # compressed bytes resident in HBM
-    d_outs = [torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)]
+    d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
+    import threading
 
     def run_steps(n):
+        """n full decodes.  Flights of P frames; NCTX decoder contexts (own HIP stream + HBM buffers each) take flights
+        alternately so that one flight's LF stage (256 wavefronts on the whole chip) overlaps another's later stages."""
         acc = {}
+        lock = threading.Lock()
+        todo = []
         done = 0
         while done < n:
-            p = min(P, n - done)
-            if p == 1:
-                dec.decode_to_device(data, d_outs[0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr())
-            else:
-                dec.decode_batch_to_device([data] * p, [t.data_ptr() for t in d_outs[:p]], [out_bytes] * p, [d_in.data_ptr()] * p)
-            for k, v in dec.last_timing().items():
-                acc[k] = acc.get(k, 0.0) + v
-            acc["flights"] = acc.get("flights", 0) + 1
-            done += p
-        return acc
-    decs = [dec]
+            p = min(P, n - done); todo.append(p); done += p
 
-    run_steps(max(args.warmup, 0))
+        def worker(c):
+            torch.cuda.set_device(local)
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    p = todo.pop()
+                if p == 1:
+                    decs[c].decode_to_device(data, d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr())
+                else:
+                    decs[c].decode_batch_to_device([data] * p, [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p, [d_in.data_ptr()] * p)
+                t = decs[c].last_timing()
+                with lock:
+                    for k, v in t.items():
+                        acc[k] = acc.get(k, 0.0) + v
+                    acc["flights"] = acc.get("flights", 0) + 1
+        th = [threading.Thread(target=worker, args=(c,)) for c in range(NCTX)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return acc
+
+    run_steps(P * NCTX)              # untimed setup: every context allocates the HBM work buffers of a full flight
+    run_steps(max(args.warmup, 0))   # W untimed warmup steps
     # sequential single-frame latency (one context), reported next to the throughput
     lat = []
     for _ in range(3):
-        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr()); lat.append(time.perf_counter() - t)
+        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr()); lat.append(time.perf_counter() - t)
     seq_stage = decs[0].last_timing()
     if world > 1:
         dist.barrier()
@@ -135,7 +157,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: single 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frame -> RGBA8 per step, "
                                    "compressed input and RGBA output resident in HBM; steps issued in flights of frames_in_flight frames",
-                       "frame_bytes": len(data), "frames_per_step_per_gpu": 1, "frames_in_flight": P,
+                       "frame_bytes": len(data), "frames_per_step_per_gpu": 1, "frames_in_flight": P, "decoder_contexts": NCTX,
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
