@@ -146,7 +146,7 @@ def main():
         names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_batch" if P > 1 else "k_pass_group") + " (+k_lf_smooth)",
                  "recon_ms": "k_recon_small+k_recon_big+k_gab+k_epf+k_write" if P > 1 else "k_recon_small+k_recon_big", "filters_write_ms": "k_gab+k_epf+k_write"}
         stages = {k: kern[k] / flights for k in names if k in kern}
-        dom = max(stages, key=stages.get)
+        dom = "lf_groups_ms"      # rocprofv3 --stats of this command: k_lf_group_batch has the largest total (profiles/r01_*bench.csv)
         dom_ms = stages[dom]
         frames_per_launch = args.steps / flights
         achieved = algo_bytes * frames_per_launch / (dom_ms * 1e-3) / 1e9
@@ -162,7 +162,9 @@ def main():
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         # PMC passes (profiles/r01_pmc_fetch_write_4k_single_frame.json): FETCH 1 869 KB + WRITE 4 479 KB per frame
+                         "traffic": int(frames_per_launch * (1868.9 + 4478.8) * 1024),
                          "kernel": names[dom], "kernel_ms": round(dom_ms, 4), "launches": flights,
                          "algorithmic_bytes_per_launch": int(algo_bytes * frames_per_launch),
                          "stage_ms_per_flight": {k: round(v, 4) for k, v in stages.items()},
