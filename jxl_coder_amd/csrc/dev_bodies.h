@@ -60,7 +60,7 @@ JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int 
 
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]
 template <class Sync>
-JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, bool want_big,
+JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int nmin, int nmax,
                               int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
   const DevStatic &ST = *(const DevStatic *)stat;
@@ -69,9 +69,8 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   const int st = B.strategy[o];
   const int cx = kCoveredX[st], cy = kCoveredY[st];
   const int n = cx * cy * 64;
-  const bool big = n > 256;
-  if (big != want_big) return;
-  if (n > 4096) { if (tid == 0) *B.err |= kErrUnsupportedBlock; return; }   // DCT128+/256: not emitted by libjxl's encoder
+  if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock; return; }   // DCT128+/256
+  if (n < nmin || n > nmax) return;                 // another size class' launch handles it
   recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();
   recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads);

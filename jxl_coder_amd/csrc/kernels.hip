@@ -39,23 +39,25 @@ __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb)
   lf_smooth_cell(B, i % xb, i / xb);
 }
 
-// small varblocks (<= 256 coefficients): one wave per 8x8 cell, LDS 4 KiB
+// Varblock reconstruction in three size classes so that the LDS budget (and with it the occupancy) fits the block:
+//   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
+//   medium (512, 1024):            256 threads, 16 KiB LDS, scans kScan consecutive cells per workgroup
+//   large  (2048, 4096):           256 threads, 64 KiB LDS, scans kScan consecutive cells per workgroup
+constexpr int kScan = 16;
 __global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t *stat, int xb) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
   int cell = (int)blockIdx.x;
-  recon_block_body(B, stat, S, T, cell % xb, cell / xb, false, (int)threadIdx.x, 64, SyncBlock());
+  recon_block_body(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
 }
-// large varblocks (512..4096 coefficients): 256 threads per block, LDS 64 KiB.  Large blocks are sparse among the
-// cells, so each workgroup scans kBigScan consecutive cells instead of launching one (mostly empty) workgroup per cell.
-constexpr int kBigScan = 16;
-__global__ void __launch_bounds__(256) k_recon_big(DevBuffers B, const uint8_t *stat, int xb, int ncell) {
-  __shared__ float S[3 * 4096];
-  __shared__ float T[4096];
-  for (int i = 0; i < kBigScan; i++) {
-    const int cell = (int)blockIdx.x * kBigScan + i;
+template <int NMIN, int NMAX>
+__global__ void __launch_bounds__(256) k_recon_scan(DevBuffers B, const uint8_t *stat, int xb, int ncell) {
+  __shared__ float S[3 * NMAX];
+  __shared__ float T[NMAX];
+  for (int i = 0; i < kScan; i++) {
+    const int cell = (int)blockIdx.x * kScan + i;
     if (cell >= ncell) return;
-    recon_block_body(B, stat, S, T, cell % xb, cell / xb, true, (int)threadIdx.x, 256, SyncBlock());
+    recon_block_body(B, stat, S, T, cell % xb, cell / xb, NMIN, NMAX, (int)threadIdx.x, 256, SyncBlock());
     __syncthreads();
   }
 }
@@ -87,7 +89,8 @@ void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
 }
 void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_recon_small, dim3(xb * yb), dim3(64), 0, s, B, stat, xb);
-  hipLaunchKernelGGL(k_recon_big, dim3((xb * yb + kBigScan - 1) / kBigScan), dim3(256), 0, s, B, stat, xb, xb * yb);
+  hipLaunchKernelGGL((k_recon_scan<257, 1024>), dim3((xb * yb + kScan - 1) / kScan), dim3(256), 0, s, B, stat, xb, xb * yb);
+  hipLaunchKernelGGL((k_recon_scan<1025, 4096>), dim3((xb * yb + kScan - 1) / kScan), dim3(256), 0, s, B, stat, xb, xb * yb);
 }
 static Planes planes_of(const DevBuffers &B, bool a) {
   Planes p;

@@ -61,8 +61,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   if (err) { g_err = "device flags " + std::to_string(err) + " (PassGroup)"; return -2; }
   std::vector<float> S(3 * 4096), T(4096);
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
-    recon_block_body(B, stat.data(), S.data(), T.data(), x, y, false, 0, 1, NoSync());
-    recon_block_body(B, stat.data(), S.data(), T.data(), x, y, true, 0, 1, NoSync());
+    recon_block_body(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());
   }
   if (err) { g_err = "device flags " + std::to_string(err) + " (recon)"; return -2; }
   const DevFrame &F = *(const DevFrame *)tables.data();
