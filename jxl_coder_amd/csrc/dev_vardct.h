@@ -241,6 +241,25 @@ JXL_DEV void pass_phase_stage(const DevBuffers &B, DevPassScratch &S, int tid, i
   }
   { uint8_t *nzflat = &S.nz[0][0]; for (int i = tid; i < 3 * 32 * 32; i += nthreads) nzflat[i] = 0; }
 }
+// rANS symbol + hybrid uint with the context map and configs read straight from LDS (ds_read) and one 64-bit alias
+// load from the (L2-resident) frame tables
+JXL_DEV uint32_t pass_ec_read(const DevPassScratch &S, const DevAlias *alias, int log_alpha, bool lds_ctx, const uint8_t *gctx,
+                              DevBits &b, uint32_t &state, uint32_t ctx) {
+  const uint32_t cluster = lds_ctx ? S.ctx_map[ctx] : gctx[ctx];
+  const int lb = 12 - log_alpha;
+  const uint32_t res = state & 0xfff;
+  const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
+  const DevAlias e = alias[(cluster << log_alpha) + i];
+  const uint32_t cfg = S.cfg[cluster & 255];
+  const bool right = pos >= e.cutoff;
+  const uint32_t sym = right ? e.right : i;
+  const uint32_t off = right ? (uint32_t)e.off1 + pos : pos;
+  const uint32_t freq = right ? e.freq1 : e.freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | bits_read(b, 16);
+  return ec_hybrid(b, cfg, sym);
+}
+
 // phase 3 (lane 0): the serial rANS walk over the group's varblocks
 JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g) {
   const DevFrame &F = frame_of(B);
@@ -258,6 +277,9 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
   if (nslice <= kPassCtxLds) ev.ctx_map = S.ctx_map; else ev.ctx_map += (size_t)S.sel * (size_t)nslice;
   if (F.hf_ec[pass].num_clusters <= 256) ev.cfg = S.cfg;
   uint32_t state = ans_init(ev, b);
+  const bool fast = !ev.use_prefix && F.hf_ec[pass].num_clusters <= 256;
+  const bool lds_ctx = nslice <= kPassCtxLds;
+  const uint8_t *gctx = ev.ctx_map;
   const int shift = F.pass_shift[pass];
   const bool accumulate = F.num_passes > 1;
   const uint8_t *bctx_map = B.tables + F.bctx_map_off;
@@ -292,7 +314,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
         const int bctx = bctx_map[idx];
         const int nzp = predicted >= 64 ? 64 : predicted;
         const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
-        int nzeros = (int)ec_read(ev, b, state, (uint32_t)nzctx);
+        int nzeros = (int)(fast ? pass_ec_read(S, ev.alias, ev.log_alpha, lds_ctx, gctx, b, state, (uint32_t)nzctx) : ec_read(ev, b, state, (uint32_t)nzctx));
         if (nzeros > size - covered) return kErrBitstream;
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
         for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
@@ -304,7 +326,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
           const int nl = (nzeros + covered - 1) >> log2c;
           const int kk = k >> log2c;
           const int ctx = histo + (S.nnz_ctx[nl] + S.freq_ctx[kk]) * 2 + prev;
-          const uint32_t u = ec_read(ev, b, state, (uint32_t)ctx);
+          const uint32_t u = fast ? pass_ec_read(S, ev.alias, ev.log_alpha, lds_ctx, gctx, b, state, (uint32_t)ctx) : ec_read(ev, b, state, (uint32_t)ctx);
           if (u) {
             const int32_t v = unpack_signed(u) * (1 << shift);
             if (accumulate) blk[order[k]] += v; else blk[order[k]] = v;
