@@ -33,6 +33,8 @@ CASES = {
     "v267x131_e7": (267, 131, dict(seed=2), dict(effort=7)),
     "v300x300_e7_d3": (300, 300, dict(seed=3), dict(effort=7, distance=3.0)),
     "v64_hard_e7": (64, 64, dict(seed=4, hard=True), dict(effort=7)),
+    "v160x120_16bit_e7": (160, 120, dict(seed=21, bits=16), dict(effort=7)),
+    "v160x120_16bit_pq2100_epf3": (160, 120, dict(seed=21, bits=16), dict(effort=7, epf=3, primaries=9, transfer=16, intensity_target=10000.0)),
     "l64_e1": (64, 64, dict(seed=1), dict(lossless=True, effort=1)),
     "l64_e3": (64, 64, dict(seed=1), dict(lossless=True, effort=3)),
     "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),

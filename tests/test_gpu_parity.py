@@ -6,7 +6,8 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, load_case
+from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS, U16_MEAN_ABS,
+                      load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -101,3 +102,19 @@ def test_batch_equals_single_decodes(dec):
     for s, o, i in zip(singles, outs, infos):
         assert (i["ysize"], i["xsize"]) == s.shape[:2]
         assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+
+
+@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES)
+def test_16bit_output(dec, name):
+    """bits_per_sample > 8 && allowedFloats -> RGBA u16 (interop/JxlDecoding.cpp:92-101); PQ / Rec.2100 data profile kept."""
+    data, exp = load_case(name)
+    out, info = dec.decode_one_shot(data, allowed_floats=True)
+    assert out.dtype == np.uint16 and info["out_bits"] == 16
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert d.mean() <= U16_MEAN_ABS
+    if name in U16_CASES:
+        assert d.max() <= U16_MAX_ABS
+    else:
+        assert (d > U16_MAX_ABS).mean() < 2e-3 and info["transfer_function"] == 16 and info["primaries"] == 9
+    out8, info8 = dec.decode_one_shot(data, allowed_floats=False)       # API < 26 branch: 8-bit output
+    assert out8.dtype == np.uint8 and info8["out_bits"] == 8

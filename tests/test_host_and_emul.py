@@ -7,7 +7,8 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, load_case
+from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
+                      U16_MEAN_ABS, load_case)
 
 import jxl_coder_amd as J
 
@@ -93,3 +94,16 @@ def test_harness_flags_corrupt_streams(emul):
         emul(bytes(bad))
     with pytest.raises(ValueError):
         emul(data[: len(data) - 2000])
+
+
+@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES)
+def test_device_code_16bit_on_cpu_harness(emul, name):
+    data, exp = load_case(name)
+    out = emul(data)
+    assert out.dtype == np.uint16 and out.shape == exp.shape
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert d.mean() <= U16_MEAN_ABS
+    if name in U16_CASES:
+        assert d.max() <= U16_MAX_ABS
+    else:
+        assert (d > U16_MAX_ABS).mean() < 2e-3

@@ -2,7 +2,8 @@
 import numpy as np
 import pytest
 
-from conftest import LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, load_case
+from conftest import (LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
+                      U16_MEAN_ABS, load_case)
 
 
 @pytest.mark.parametrize("name", LOSSLESS_CASES)
@@ -61,3 +62,16 @@ def test_oracle_against_live_reference_when_present(oracle):
             assert d.max() == 0
         else:
             assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS
+
+
+@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES)
+def test_oracle_16bit_output(oracle, name):
+    data, exp = load_case(name)
+    assert exp.dtype == np.uint16
+    out, info = oracle.decode(data, 16)
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert d.mean() <= U16_MEAN_ABS
+    if name in U16_CASES:
+        assert d.max() <= U16_MAX_ABS
+    else:
+        assert (d > U16_MAX_ABS).mean() < 2e-3
