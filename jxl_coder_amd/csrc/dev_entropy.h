@@ -22,14 +22,17 @@ namespace jxlamd {
 // ------------------------------------------------------------------ bit reader (LSB first)
 struct DevBits {
   const uint32_t *next;     // next aligned word to fetch
+  const uint32_t *end;      // first word past the (padded) codestream: reads beyond it yield zeros, never a fault
   uint64_t buf;             // valid bits in the low `n` positions
   uint32_t ahead;           // word fetched one refill early (hides the load latency of the serial lane)
   int32_t n;
   uint64_t consumed;        // bits consumed since the section start
 };
 
-JXL_DEV void bits_init(DevBits &b, const uint8_t *base, uint64_t byte_off) {
+JXL_DEV void bits_init(DevBits &b, const uint8_t *base, uint64_t byte_off, uint64_t total_bytes) {
+  if (byte_off > total_bytes) byte_off = total_bytes;
   const uint8_t *p = base + byte_off;
+  b.end = (const uint32_t *)(base + ((total_bytes + 48) & ~(uint64_t)3));   // buffers carry >= 64 zero bytes of padding
   uint64_t mis = (uint64_t)(uintptr_t)p & 3;
   b.next = (const uint32_t *)(p - mis);
   b.buf = (uint64_t)b.next[0] | ((uint64_t)b.next[1] << 32);
@@ -43,7 +46,8 @@ JXL_DEV void bits_refill(DevBits &b) {     // guarantees >= 32 valid bits
   if (b.n <= 32) {
     b.buf |= (uint64_t)b.ahead << b.n;
     b.n += 32;
-    b.ahead = *b.next++;
+    b.ahead = b.next < b.end ? *b.next : 0u;
+    b.next++;
   }
 }
 JXL_DEV uint32_t bits_peek(DevBits &b, int n) {   // n <= 32

@@ -77,6 +77,7 @@ struct DevFrame {
   DevEC hf_ec[4];                  // per pass (up to 4 passes supported on device)
   uint32_t order_off[4][13][3];    // u16/u32 orders: offset of u32 array in blob
   // sections
+  uint32_t cs_size;                // bytes of the codestream buffer (device copy carries >= 64 B of zero padding)
   uint32_t sec_off;                // DevSection[nsec]: [0]=LfGlobal, 1..=LfGroup, then HfGlobal, then PassGroups
   int32_t nsec;
   // loop filter

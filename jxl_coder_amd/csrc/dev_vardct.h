@@ -54,7 +54,7 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
   DevBits b;
-  bits_init(b, B.codestream, sec.off);
+  bits_init(b, B.codestream, sec.off, F.cs_size);
   if (F.nsec == 1) {   // single-section frame: skip the LfGlobal bits the host parsed
     uint32_t skip = F.single_lf_bit;
     while (skip >= 32) { bits_read(b, 32); skip -= 32; }
@@ -214,7 +214,7 @@ JXL_DEV void pass_phase_open(const DevBuffers &B, DevPassScratch &S, int pass, i
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
   DevBits b;
-  bits_init(b, B.codestream, sec.off);
+  bits_init(b, B.codestream, sec.off, F.cs_size);
   if (F.nsec == 1) {
     uint32_t skip = F.single_pass_bit;
     while (skip >= 32) { bits_read(b, 32); skip -= 32; }

@@ -222,6 +222,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   F.num_passes = f.num_passes;
   for (int i = 0; i < 12; i++) F.pass_shift[i] = i < f.num_passes - 1 ? f.pass_shift[i] : 0;
   F.nsec = nsec;
+  F.cs_size = (uint32_t)csn;
   plan->tables.assign(((sizeof(DevFrame) + 15) / 16) * 16, 0);
   Blob blob(plan->tables);
   F.sec_off = blob.append(secs.data(), secs.size() * sizeof(DevSection));
