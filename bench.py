@@ -94,7 +94,15 @@ def main():
         while done < n:
             p = min(P, n - done); todo.append(p); done += p
 
+        errors = []
+
         def worker(c):
+            try:
+                _worker(c)
+            except BaseException as e:  # noqa: BLE001 — re-raised in the main thread: a failed flight must fail the bench
+                errors.append(e)
+
+        def _worker(c):
             torch.cuda.set_device(local)
             while True:
                 with lock:
@@ -110,11 +118,15 @@ def main():
                     for k, v in t.items():
                         acc[k] = acc.get(k, 0.0) + v
                     acc["flights"] = acc.get("flights", 0) + 1
+                    acc["frames"] = acc.get("frames", 0) + p
         th = [threading.Thread(target=worker, args=(c,)) for c in range(NCTX)]
         for t in th:
             t.start()
         for t in th:
             t.join()
+        if errors:
+            raise errors[0]
+        assert acc.get("frames", 0) == n, (acc.get("frames", 0), n)
         return acc
 
     run_steps(P * NCTX)              # untimed setup: every context allocates the HBM work buffers of a full flight
