@@ -33,7 +33,22 @@ struct DevMem {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+struct PinnedMem {             // page-locked host staging: true async DMA, no shared pageable-copy staging in the runtime
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct FrameSlot {             // HBM work buffers of one in-flight frame
+  PinnedMem h_tables, h_cs;
   DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out;
   FramePlan plan;
   DevBuffers B;
@@ -49,6 +64,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
     for (auto &m : lf) m.release();
     for (auto &m : coef) m.release();
     for (auto &m : planes) m.release();
+    h_tables.release(); h_cs.release();
   }
 };
 
@@ -58,6 +74,7 @@ struct jxlamd_decoder {
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab;
+  PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
   float timing[5] = {0, 0, 0, 0, 0};
@@ -122,7 +139,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (!stat_uploaded) {
     const std::vector<uint8_t> &st = static_tables();
     HIPCHECK(stat.ensure(st.size()));
-    HIPCHECK(hipMemcpyAsync(stat.p, st.data(), st.size(), hipMemcpyHostToDevice, stream));
+    HIPCHECK(hipMemcpy(stat.p, st.data(), st.size(), hipMemcpyHostToDevice));   // one-time, synchronous (shared host source)
     stat_uploaded = true;
   }
   const bool cs_alias = (flags & JXLAMD_IN_DEVICE) && jxl_dev && plan.cs_owned.empty();
@@ -130,12 +147,16 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (cs_alias) d_cs = (const uint8_t *)jxl_dev + (plan.cs - jxl);
   else {
     HIPCHECK(S.cs.ensure(plan.cs_size + 64));
-    HIPCHECK(hipMemcpyAsync(S.cs.p, plan.cs, plan.cs_size, hipMemcpyHostToDevice, stream));
+    HIPCHECK(S.h_cs.ensure(plan.cs_size));
+    memcpy(S.h_cs.p, plan.cs, plan.cs_size);
+    HIPCHECK(hipMemcpyAsync(S.cs.p, S.h_cs.p, plan.cs_size, hipMemcpyHostToDevice, stream));
     HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
     d_cs = (const uint8_t *)S.cs.p;
   }
   HIPCHECK(S.tables.ensure(plan.tables.size() + (8u << 20)));     // room for the phase-2 (HfGlobal) tables
-  HIPCHECK(hipMemcpyAsync(S.tables.p, plan.tables.data(), plan.tables.size(), hipMemcpyHostToDevice, stream));
+  HIPCHECK(S.h_tables.ensure(plan.tables.size()));
+  memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
+  HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
   for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
   for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
   for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
@@ -174,7 +195,9 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
   HIPCHECK(S.tables.ensure(S.plan.tables.size()));
-  HIPCHECK(hipMemcpyAsync(S.tables.p, S.plan.tables.data(), S.plan.tables.size(), hipMemcpyHostToDevice, stream));
+  HIPCHECK(S.h_tables.ensure(S.plan.tables.size()));
+  memcpy(S.h_tables.p, S.plan.tables.data(), S.plan.tables.size());
+  HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, S.plan.tables.size(), hipMemcpyHostToDevice, stream));
   return JXLAMD_OK;
 }
 
@@ -265,11 +288,13 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
                o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, total = o_pg + pg_map.size() * 4;
   HIPCHECK(batch_tab.ensure(total));
-  uint8_t *bt = (uint8_t *)batch_tab.p;
-  HIPCHECK(hipMemcpyAsync(bt + o_b, hb.data(), hb.size() * sizeof(DevBuffers), hipMemcpyHostToDevice, stream));
-  HIPCHECK(hipMemcpyAsync(bt + o_a, ha.data(), ha.size() * sizeof(DevAux), hipMemcpyHostToDevice, stream));
-  HIPCHECK(hipMemcpyAsync(bt + o_lf, lf_map.data(), lf_map.size() * 4, hipMemcpyHostToDevice, stream));
-  HIPCHECK(hipMemcpyAsync(bt + o_pg, pg_map.data(), pg_map.size() * 4, hipMemcpyHostToDevice, stream));
+  HIPCHECK(h_batch.ensure(total));
+  uint8_t *bt = (uint8_t *)batch_tab.p, *hbt = (uint8_t *)h_batch.p;
+  memcpy(hbt + o_b, hb.data(), hb.size() * sizeof(DevBuffers));
+  memcpy(hbt + o_a, ha.data(), ha.size() * sizeof(DevAux));
+  memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
+  memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
+  HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
@@ -306,7 +331,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release();
+  d->stat.release(); d->batch_tab.release(); d->h_batch.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);

@@ -14,12 +14,12 @@ namespace jxlamd {
 
 constexpr int kModMaxW = 256;         // widest channel a device stream may carry (LF group = 256 LF samples; 256-px lossless groups)
 constexpr int kWpMaxW = 256;
-constexpr int kTreeLds = 256;         // MA-tree nodes cached in LDS
+constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
 struct DevChanOut { int32_t *d; int32_t w, h; };
 
-constexpr int kLdsClusters = 16;      // leaf-code clusters whose alias tables are cached in LDS
+constexpr int kLdsClusters = 12;      // leaf-code clusters whose alias tables are cached in LDS (24 KB)
 constexpr int kLdsCtx = 4096;
 
 struct DevModStream {                 // what lane 0 hands to the other lanes / to the next phase of a stream
