@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--steps", type=int, default=768)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contexts", type=int, default=3, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
+    ap.add_argument("--contexts", type=int, default=2, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
 
@@ -109,10 +109,21 @@ def main():
                     if not todo:
                         return
                     p = todo.pop()
-                if p == 1:
-                    decs[c].decode_to_device(data, d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr())
-                else:
-                    decs[c].decode_batch_to_device([data] * p, [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p, [d_in.data_ptr()] * p)
+                for attempt in (0, 1):
+                    try:
+                        if p == 1:
+                            decs[c].decode_to_device(data, d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr())
+                        else:
+                            decs[c].decode_batch_to_device([data] * p, [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p, [d_in.data_ptr()] * p)
+                        break
+                    except J.InvalidJXLException:
+                        # Known round-1 issue: with >= 3 contexts in flight a flight is occasionally rejected by the
+                        # decoder's own rANS final-state checks (never silently wrong pixels).  The flight is decoded again inside
+                        # the timed region and counted in "retried_flights".
+                        if attempt:
+                            raise
+                        with lock:
+                            acc["retried_flights"] = acc.get("retried_flights", 0) + 1
                 t = decs[c].last_timing()
                 with lock:
                     for k, v in t.items():
@@ -169,7 +180,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: single 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frame -> RGBA8 per step, "
                                    "compressed input and RGBA output resident in HBM; steps issued in flights of frames_in_flight frames",
-                       "frame_bytes": len(data), "frames_per_step_per_gpu": 1, "frames_in_flight": P, "decoder_contexts": NCTX,
+                       "frame_bytes": len(data), "frames_per_step_per_gpu": 1, "frames_in_flight": P, "decoder_contexts": NCTX, "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), no collective"},
