@@ -120,7 +120,7 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
 }
 
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
-static int dev_err_class(uint32_t derr) { return (derr & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
+static int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host parse + buffers + H2D + clears for one frame (everything before the first kernel)
 int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,

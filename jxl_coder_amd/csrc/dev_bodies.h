@@ -27,7 +27,7 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   JXL_STAMP(1);
   uint32_t e = lf_phase_coeffs(B, S, g, tid);                 // whole wave on the GPU
   JXL_STAMP(2);
-  if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e; } }
+  if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e | kErrStageLf; } }
   sync();
   if (S.st.err) return;                                       // uniform: read from LDS after the barrier
   modular_stream_stage(S, tid, nthreads);
@@ -35,7 +35,7 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   JXL_STAMP(3);
   e = lf_phase_meta(B, S, g, tid);
   JXL_STAMP(4);
-  if (tid == 0) { if (!e) e = lf_phase_place(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e; } }
+  if (tid == 0) { if (!e) e = lf_phase_place(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e | kErrStageLf | (1u << 20); } }
   sync();
   if (S.st.err) return;
   JXL_STAMP(5);
@@ -52,7 +52,7 @@ JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int 
     sync();
     pass_phase_stage(B, S, tid, nthreads);
     sync();
-    if (tid == 0) { uint32_t e = pass_phase_decode(B, S, g); if (e) { S.err = e; *B.err |= e; } }
+    if (tid == 0) { uint32_t e = pass_phase_decode(B, S, g); if (e) { S.err = e; *B.err |= e | kErrStagePass; } }
     sync();
     if (S.err) return;
   }
@@ -69,7 +69,7 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   const int st = B.strategy[o];
   const int cx = kCoveredX[st], cy = kCoveredY[st];
   const int n = cx * cy * 64;
-  if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock; return; }   // DCT128+/256
+  if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock | kErrStageRecon; return; }   // DCT128+/256
   if (n < nmin || n > nmax) return;                 // another size class' launch handles it
   recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();

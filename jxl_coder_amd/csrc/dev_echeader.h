@@ -7,6 +7,7 @@
 // tree itself, into per-section scratch memory in HBM.
 #pragma once
 #include "dev_entropy.h"
+#include "dev_tables.h"
 
 namespace jxlamd {
 
@@ -15,7 +16,19 @@ constexpr int kLocMaxCtx = 4096;
 constexpr int kLocMaxNodes = 2 * kLocMaxCtx;
 constexpr int kLocPool = 1 << 16;
 
+// Working arrays of the header parser.  They live in HBM next to the tables they produce, NOT in per-lane private
+// (scratch) memory: kernels of several decoder contexts run side by side and the runtime's scratch backing proved
+// unreliable under that concurrency on this stack (tables came out corrupted), so the entropy kernels use no scratch.
+struct LocalTmp {
+  uint8_t logc[258]; uint16_t same[258]; int16_t cnt[258];
+  uint16_t cut[256], under[512], over[512]; uint8_t right[256]; uint16_t off[256];
+  uint32_t offs[17], cloffs[17]; int32_t sym[4]; uint8_t cll[18]; uint16_t clsorted[18];
+  uint8_t mtf[256]; uint16_t counts[kLocMaxClusters]; uint16_t D[256];
+  DevPrefix clp;
+};
+
 struct LocalEC {
+  LocalTmp tmp;
   uint8_t ctx_map[kLocMaxCtx + 8];
   uint32_t cfg[kLocMaxClusters];
   DevAlias alias[kLocMaxClusters * 256];
@@ -62,7 +75,7 @@ JXL_DEV uint32_t d_varlen_u8(DevBits &b) {
 }
 
 // ANS histogram (12-bit) into D[table]; returns error bits
-JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table) {
+JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table, LocalTmp &T) {
   for (int i = 0; i < table; i++) D[i] = 0;
   if (bits_read(b, 1)) {
     int ns = (int)bits_read(b, 1) + 1;
@@ -85,7 +98,7 @@ JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table) {
   if (shift > 13) return kErrBitstream;
   int n = (int)d_varlen_u8(b) + 3;
   if (n > table) return kErrBitstream;
-  uint8_t logc[258]; uint16_t same[258]; int16_t cnt[258];
+  uint8_t *logc = T.logc; uint16_t *same = T.same; int16_t *cnt = T.cnt;
   for (int i = 0; i < n; i++) { same[i] = 0; cnt[i] = 0; logc[i] = 0; }
   int omit_log = -1, omit_pos = -1;
   for (int i = 0; i < n; i++) {
@@ -136,14 +149,14 @@ JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table) {
   return 0;
 }
 
-JXL_DEV void d_build_alias(const uint16_t *D, int log_alpha, DevAlias *a) {
+JXL_DEV void d_build_alias(const uint16_t *D, int log_alpha, DevAlias *a, LocalTmp &T) {
   const int table = 1 << log_alpha, bucket = 4096 >> log_alpha;
   for (int s = 0; s < table; s++)
     if (D[s] == 4096) {
       for (int i = 0; i < table; i++) { a[i].cutoff = 0; a[i].right = (uint8_t)s; a[i].off1 = (uint16_t)(bucket * i); a[i].freq0 = 4096; a[i].freq1 = 4096; }
       return;
     }
-  uint16_t cut[256]; uint16_t under[512], over[512]; uint8_t right[256]; uint16_t off[256];
+  uint16_t *cut = T.cut, *under = T.under, *over = T.over; uint8_t *right = T.right; uint16_t *off = T.off;
   int nu = 0, no = 0;
   int n = table;
   while (n > 0 && D[n - 1] == 0) n--;
@@ -172,7 +185,7 @@ JXL_DEV uint32_t d_build_canonical(LocalEC &ec, DevPrefix &p, const uint8_t *len
   for (int i = 0; i < n; i++) if (lens[i]) { p.cnt[lens[i]]++; nz++; last = i; }
   if (ec.pool_used + (uint32_t)nz > (uint32_t)kLocPool) return kErrUnsupportedTransform;
   p.sorted_off = ec.pool_used;
-  uint32_t offs[17]; offs[1] = 0;
+  uint32_t *offs = ec.tmp.offs; offs[1] = 0;
   for (int l = 1; l < 16; l++) offs[l + 1] = offs[l] + p.cnt[l];
   for (int i = 0; i < n; i++) if (lens[i]) ec.pool[p.sorted_off + offs[lens[i]]++] = (uint16_t)i;
   ec.pool_used += (uint32_t)nz;
@@ -200,7 +213,7 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
     int max_bits = 0;
     for (int t = alphabet - 1; t; t >>= 1) max_bits++;
     int ns = (int)bits_read(b, 2) + 1;
-    int sym[4] = {0, 0, 0, 0};
+    int32_t *sym = ec.tmp.sym; sym[0] = sym[1] = sym[2] = sym[3] = 0;
     for (int i = 0; i < ns; i++) { sym[i] = (int)bits_read(b, max_bits); if (sym[i] >= alphabet) return kErrBitstream; }
     for (int i = 0; i < ns; i++) for (int j = i + 1; j < ns; j++) if (sym[i] == sym[j]) return kErrBitstream;
     if (ns == 1) { uint32_t e = d_build_canonical(ec, p, lens, alphabet); p.single = sym[0]; return e; }
@@ -210,10 +223,8 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
     else { lens[sym[0]] = lens[sym[1]] = lens[sym[2]] = lens[sym[3]] = 2; }
     return d_build_canonical(ec, p, lens, alphabet);
   }
-  const uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
-  const uint8_t cl_len[16] = {2, 2, 2, 3, 2, 2, 2, 4, 2, 2, 2, 3, 2, 2, 2, 4};
-  const uint8_t cl_val[16] = {0, 4, 3, 2, 0, 4, 3, 1, 0, 4, 3, 2, 0, 4, 3, 5};
-  uint8_t cll[18];
+  const uint8_t *order = kClOrder, *cl_len = kClLen, *cl_val = kClVal;   // constant memory (dev_tables.h)
+  uint8_t *cll = ec.tmp.cll;
   for (int i = 0; i < 18; i++) cll[i] = 0;
   int space = 32, num_codes = 0;
   for (int i = hskip; i < 18 && space > 0; i++) {
@@ -225,12 +236,12 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
   }
   if (!(num_codes == 1 || space == 0)) return kErrBitstream;
   // code-length code: tiny canonical decoder kept local
-  DevPrefix clp; uint16_t clsorted[18];
+  DevPrefix &clp = ec.tmp.clp; uint16_t *clsorted = ec.tmp.clsorted;
   {
     for (int l = 0; l < 16; l++) clp.cnt[l] = 0;
     int nz = 0, last = -1;
     for (int i = 0; i < 18; i++) if (cll[i]) { clp.cnt[cll[i]]++; nz++; last = i; }
-    uint32_t offs[17]; offs[1] = 0;
+    uint32_t *offs = ec.tmp.cloffs; offs[1] = 0;
     for (int l = 1; l < 16; l++) offs[l + 1] = offs[l] + clp.cnt[l];
     for (int i = 0; i < 18; i++) if (cll[i]) clsorted[offs[cll[i]]++] = (uint16_t)i;
     clp.sorted_off = 0; clp.single = nz == 1 ? last : nz == 0 ? 0 : -1;
@@ -259,7 +270,10 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
   return d_build_canonical(ec, p, lens, alphabet);
 }
 
-JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens);
+// The nested code of an entropy-coded context map has a single context, so it never carries a context map itself:
+// two template instances instead of recursion keep everything inlined (no call stack, no scratch).
+template <bool kNested>
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens);
 
 JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_clusters, LocalEC *nested, uint8_t *lens) {
   uint32_t err = 0;
@@ -269,7 +283,7 @@ JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_cluste
   } else {
     int use_mtf = (int)bits_read(b, 1);
     if (!nested) return kErrBitstream;
-    err |= d_ec_read_header(b, 1, *nested, nullptr, lens);
+    err |= d_ec_read_header_t<true>(b, 1, *nested, nullptr, lens);
     if (err) return err;
     DevECView v = local_view(*nested);
     uint32_t state = ans_init(v, b);
@@ -280,7 +294,7 @@ JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_cluste
     }
     if (state != 0x130000u) return kErrAnsFinal;
     if (use_mtf) {
-      uint8_t mtf[256];
+      uint8_t *mtf = nested->tmp.mtf;
       for (int i = 0; i < 256; i++) mtf[i] = (uint8_t)i;
       for (int i = 0; i < n; i++) {
         uint8_t idx = map[i], val = mtf[idx];
@@ -296,20 +310,22 @@ JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_cluste
   return err;
 }
 
-JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens) {
+template <bool kNested>
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens) {
   uint32_t err = 0;
+  if (kNested && num_ctx != 1) return kErrBitstream;
   if (num_ctx > kLocMaxCtx) return kErrUnsupportedTransform;
   ec.num_ctx = num_ctx; ec.pool_used = 0;
   if (bits_read(b, 1)) return kErrLz77;          // LZ77 inside a group-level code: not on the device
   ec.num_clusters = 1;
   for (int i = 0; i < num_ctx; i++) ec.ctx_map[i] = 0;
-  if (num_ctx > 1) { err |= d_read_ctx_map(b, ec.ctx_map, num_ctx, ec.num_clusters, nested, lens); if (err) return err; }
+  if (!kNested && num_ctx > 1) { err |= d_read_ctx_map(b, ec.ctx_map, num_ctx, ec.num_clusters, nested, lens); if (err) return err; }
   if (ec.num_clusters > kLocMaxClusters) return kErrUnsupportedTransform;
   ec.use_prefix = (int)bits_read(b, 1);
   ec.log_alpha = ec.use_prefix ? 15 : 5 + (int)bits_read(b, 2);
   for (int i = 0; i < ec.num_clusters; i++) ec.cfg[i] = d_read_huc(b, ec.log_alpha, err);
   if (ec.use_prefix) {
-    uint16_t counts[kLocMaxClusters];
+    uint16_t *counts = ec.tmp.counts;
     for (int i = 0; i < ec.num_clusters; i++) {
       if (!bits_read(b, 1)) counts[i] = 1;
       else { int nb = (int)bits_read(b, 4); uint32_t c = 1 + (1u << nb) + bits_read(b, nb); if (c > (1u << 15)) return kErrBitstream; counts[i] = (uint16_t)c; }
@@ -317,11 +333,11 @@ JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC 
     for (int i = 0; i < ec.num_clusters; i++) { err |= d_read_prefix_code(b, ec, ec.prefix[i], lens, counts[i]); if (err) return err; }
   } else {
     const int table = 1 << ec.log_alpha;
-    uint16_t D[256];
+    uint16_t *D = ec.tmp.D;
     for (int i = 0; i < ec.num_clusters; i++) {
-      err |= d_read_histogram(b, D, table);
+      err |= d_read_histogram(b, D, table, ec.tmp);
       if (err) return err;
-      d_build_alias(D, ec.log_alpha, ec.alias + (size_t)i * (size_t)table);
+      d_build_alias(D, ec.log_alpha, ec.alias + (size_t)i * (size_t)table, ec.tmp);
     }
   }
   return err;
@@ -329,7 +345,7 @@ JXL_DEV uint32_t d_ec_read_header(DevBits &b, int num_ctx, LocalEC &ec, LocalEC 
 
 // MA tree (H.4.2) + its leaf code
 JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L) {
-  uint32_t err = d_ec_read_header(b, 6, L.tree_code, &L.nested, L.lens);
+  uint32_t err = d_ec_read_header_t<false>(b, 6, L.tree_code, &L.nested, L.lens);
   if (err) return err;
   DevECView v = local_view(L.tree_code);
   uint32_t state = ans_init(v, b);
@@ -361,7 +377,7 @@ JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L) {
   }
   if (state != 0x130000u) return kErrAnsFinal;
   L.count = count;
-  return d_ec_read_header(b, leaf, L.leaf_code, &L.nested, L.lens);
+  return d_ec_read_header_t<false>(b, leaf, L.leaf_code, &L.nested, L.lens);
 }
 
 }  // namespace jxlamd

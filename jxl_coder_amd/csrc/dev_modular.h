@@ -37,6 +37,7 @@ struct DevWaveTree {                  // LDS: the pruned tree of one channel in 
   uint64_t leaf_need1[64], leaf_need0[64];
   int32_t leaf_ctx[64], leaf_pred[64], leaf_off[64], leaf_mul[64];
   int32_t ni, nl, ok, uses_wp;
+  int32_t stack_node[64]; uint64_t stack_n1[64], stack_n0[64];   // DFS stacks of the builders (LDS, not scratch)
 };
 
 struct DevModScratch {                // per-wave working memory (LDS on the GPU)
@@ -50,6 +51,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   uint32_t cfg[kLocMaxClusters];
   DevAlias alias[kLdsClusters * 256];
   DevModStream st;
+  DevChanOut ch[4];                   // channel descriptors of the current stream (LDS: keeps the kernel free of scratch)
   DevWaveTree wt;
   uint32_t fallback_err;
 };
@@ -153,9 +155,9 @@ JXL_DEV int64_t predict_plain(int predictor, int64_t W, int64_t N, int64_t NW, i
 // predictor 6), and which is the largest property it tests?  Properties 0 and 1 are static per channel, so the
 // unreachable branches are pruned exactly as libjxl's tree filtering does.
 struct TreeFacts { int uses_wp; int max_prop; };
-JXL_DEV TreeFacts tree_facts(const DevTreeNode *tree, int count, int chan, int stream) {
+JXL_DEV TreeFacts tree_facts(const DevTreeNode *tree, int count, int chan, int stream, int32_t *stack) {
   TreeFacts f; f.uses_wp = 0; f.max_prop = 0;
-  int stack[64]; int sp = 0;
+  int sp = 0;
   stack[sp++] = 0;
   int guard = 0;
   while (sp > 0 && guard++ < 4 * count + 8) {
@@ -186,7 +188,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     const DevChanOut &c = chans[ci];
     const int w = c.w, h = c.h;
     if (w == 0 || h == 0) continue;
-    const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id);
+    const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id, S.wt.stack_node);
 #ifdef JXL_EMUL_TRACE
     fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop);
 #endif

@@ -22,7 +22,7 @@ namespace jxlamd {
 // lane 0: flatten the tree reachable for (chan, stream) into ballot form
 __device__ inline void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W) {
   W.ni = 0; W.nl = 0; W.ok = 1; W.uses_wp = 0;
-  int stack_node[64]; uint64_t stack_n1[64], stack_n0[64];
+  int32_t *stack_node = W.stack_node; uint64_t *stack_n1 = W.stack_n1, *stack_n0 = W.stack_n0;
   int sp = 0;
   stack_node[0] = 0; stack_n1[0] = 0; stack_n0[0] = 0; sp = 1;
   int guard = 0;

@@ -105,6 +105,7 @@ struct DevStatic {
 enum : uint32_t {
   kErrBitstream = 1, kErrUnsupportedTransform = 2, kErrUnsupportedBlock = 4, kErrAnsFinal = 8, kErrLz77 = 16,
   kErrTreeLocal = 32, kErrSqueeze = 64, kErrPalette = 128, kErrWaveFallback = 256,
+  kErrStageLf = 1u << 16, kErrStagePass = 1u << 17, kErrStageRecon = 1u << 18,   // which kernel raised the flag
 };
 
 }  // namespace jxlamd

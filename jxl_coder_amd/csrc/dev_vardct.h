@@ -78,7 +78,7 @@ JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g, i
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
-  DevChanOut ch[3];
+  DevChanOut *ch = S.ch;
   for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
   return lf_decode_stream(S, ch, 3, 1 + g, tid);
 }
@@ -100,7 +100,7 @@ JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   const int count = scr[kLfScratchInts - 2];
   int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
-  DevChanOut ch[4];
+  DevChanOut *ch = S.ch;
   ch[0].d = m_x; ch[0].w = q.tw; ch[0].h = q.th;
   ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
   ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
