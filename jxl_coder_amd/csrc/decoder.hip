@@ -49,7 +49,7 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
 
 struct FrameSlot {             // HBM work buffers of one in-flight frame
   PinnedMem h_tables, h_cs;
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out;
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch;
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -57,7 +57,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   size_t out_bytes = 0;
   void *d_out = nullptr; void *host_out = nullptr;
   void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out};
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch};
     for (auto *m : all) m->release();
     for (auto &m : cells8) m.release();
     for (auto &m : tiles) m.release();
@@ -85,6 +85,7 @@ struct jxlamd_decoder {
               bool parsed = false);
   int finish_single_section(FrameSlot &S);
   int launch_rest(FrameSlot &S);
+  int launch_modular(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
   int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
   int decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
@@ -157,14 +158,20 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   HIPCHECK(S.h_tables.ensure(plan.tables.size()));
   memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
   HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
-  for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
-  for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
-  for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
-  HIPCHECK(S.coef_off.ensure(ncell * 4));
-  for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
-  for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));
-  HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
-  HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
+  if (!plan.modular) {
+    for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
+    for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
+    for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
+    HIPCHECK(S.coef_off.ensure(ncell * 4));
+    for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
+    for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));
+    HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
+    HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
+  } else {
+    HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
+    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
+    HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
+  }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
   S.host_out = nullptr; S.d_out = out_ptr;
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(S.out_bytes)); S.d_out = S.out.p; S.host_out = out_ptr; }
@@ -177,12 +184,15 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
                                 B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
   B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p;
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out;
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
-  HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
-  for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, (size_t)plan.num_groups * 65536 * 4, stream));
+  if (!plan.modular) {
+    HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
+    for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, (size_t)plan.num_groups * 65536 * 4, stream));
+  }
   return JXLAMD_OK;
 }
 
@@ -211,6 +221,17 @@ int jxlamd_decoder::launch_rest(FrameSlot &S) {
   return JXLAMD_OK;
 }
 
+// Modular-encoded (lossless) frame: GlobalModular stream, per-group streams, inverse global transforms, writer
+int jxlamd_decoder::launch_modular(FrameSlot &S) {
+  const FramePlan &plan = S.plan;
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  launch_mod_global(S.B, stream);
+  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
+  for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
+  launch_mod_write(S.B, plan.width, plan.height, (int)S.pi.out_bits, stream);
+  return JXLAMD_OK;
+}
+
 int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   uint32_t derr = 0;
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
@@ -228,6 +249,14 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   int rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
   if (rc) return rc;
   HIPCHECK(hipEventRecord(ev[0], stream));
+  if (S.plan.modular) {
+    launch_modular(S);
+    for (int i = 1; i <= 4; i++) HIPCHECK(hipEventRecord(ev[i], stream));
+    rc = collect(S, flags);
+    for (int i = 0; i < 4; i++) timing[i] = 0;
+    (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
+    return rc;
+  }
   launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
@@ -267,6 +296,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true);
     if (rc) return rc;
+    if (S.plan.modular) { launch_modular(S); rc = collect(S, flags); if (rc) return rc; continue; }
     if (S.plan.single_section) {
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
       rc = finish_single_section(S); if (rc) return rc;

@@ -1,0 +1,177 @@
+// jxl_coder_amd/csrc/dev_modframe.h — Modular-ENCODED frames (lossless path, BASELINE config 1) on the device:
+// GlobalModular stream, per-group Modular streams with their own RCTs, inverse global transforms (RCT, channel
+// palette) and the integer -> RGBA writer.  Integer-exact (ISO/IEC 18181-1 Annex H); what libjxl's
+// ModularFrameDecoder does under JxlDecoderProcessInput (reference call site interop/JxlDecoding.cpp:75).
+#pragma once
+#include "dev_vardct.h"
+
+namespace jxlamd {
+
+constexpr int kModGroupScratchInts = 8 * 65536;       // per group: up to 8 channels of 256x256
+
+JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
+
+// one stream's channels: whole wave on the GPU, lane 0 alone in the CPU harness
+JXL_DEV uint32_t mod_decode_stream(DevModScratch &S, const DevChanOut *ch, int nch, int stream_id, int tid) {
+#ifdef __HIPCC__
+  return modular_stream_decode_wave(S, ch, nch, stream_id, tid);
+#else
+  return tid == 0 ? modular_stream_decode(S, ch, nch, stream_id) : 0;
+#endif
+}
+
+// inverse RCT on three equally sized int32 planes (H.6.3), in place; work split over the lanes
+JXL_DEV void inv_rct_planes(int32_t *p0, int32_t *p1, int32_t *p2, size_t n, int rct_type, int tid, int nthreads) {
+  const int perm = rct_type / 7, type = rct_type % 7;
+  int32_t *src[3] = {p0, p1, p2};
+  const int dst[3] = {perm % 3, (perm + 1 + perm / 3) % 3, (perm + 2 - perm / 3) % 3};
+  for (size_t i = (size_t)tid; i < n; i += (size_t)nthreads) {
+    int32_t F = p0[i], Sx = p1[i], T = p2[i];
+    if (type == 6) {
+      int32_t tmp = F - (T >> 1);
+      int32_t G = T + tmp;
+      int32_t Bc = tmp - (Sx >> 1);
+      int32_t R = Bc + Sx;
+      F = R; Sx = G; T = Bc;
+    } else {
+      if (type & 1) T += F;
+      if ((type >> 1) == 1) Sx += F;
+      else if ((type >> 1) == 2) Sx += (F + T) >> 1;
+    }
+    src[dst[0]][i] = F; src[dst[1]][i] = Sx; src[dst[2]][i] = T;
+  }
+}
+
+// ---- GlobalModular: one workgroup; decodes the meta channels and every channel that fits one group
+template <class Sync>
+JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  if (tid == 0) {
+    const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+    DevBits b;
+    bits_init(b, B.codestream, secs[0].off, F.cs_size);
+    uint32_t skip = F.mod_global_bit;
+    while (skip >= 32) { bits_read(b, 32); skip -= 32; }
+    bits_read(b, (int)skip);
+    S.st.b = b;
+    modular_stream_begin(B.tables, F, B.local[0], S, &S.trs);
+  }
+  sync();
+  modular_stream_stage(S, tid, nthreads);
+  sync();
+  const int n = F.mod_first_group_ch;
+  for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; }
+  sync();
+  uint32_t e = mod_decode_stream(S, S.ch, n, 0, tid);
+  if (tid == 0 && e) *B.err |= e | kErrStageLf;
+  sync();
+}
+
+// ---- one 256x256 group of the remaining channels
+template <class Sync>
+JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  const int gx = g % F.xgroups, gy = g / F.xgroups;
+  const int x0 = gx * 256, y0 = gy * 256;
+  const int nch = F.mod_nch - F.mod_first_group_ch;
+  int32_t *scr = B.mod_scratch + (size_t)g * kModGroupScratchInts;
+  if (tid == 0) {
+    const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+    const DevSection sec = secs[2 + F.num_lf_groups + g];
+    DevBits b;
+    bits_init(b, B.codestream, sec.off, F.cs_size);
+    S.st.b = b;
+    modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
+    for (int i = 0; i < S.trs.n && !S.st.err; i++) {
+      const DevTr &t = S.trs.t[i];
+      if (t.id != 0) S.st.err = kErrPalette;                         // group-level palettes: not on the device yet
+      else if (t.begin_c + 3 > nch) S.st.err = kErrBitstream;
+    }
+    if (S.st.err) *B.err |= S.st.err | kErrStagePass;
+  }
+  sync();
+  if (S.st.err) return;
+  modular_stream_stage(S, tid, nthreads);
+  sync();
+  for (int c = tid; c < nch; c += nthreads) {
+    const int fc = F.mod_first_group_ch + c;
+    int rw = F.mod_w[fc] - x0, rh = F.mod_h[fc] - y0;
+    rw = rw < 0 ? 0 : rw > 256 ? 256 : rw; rh = rh < 0 ? 0 : rh > 256 ? 256 : rh;
+    S.ch[c].d = scr + (size_t)c * 65536; S.ch[c].w = rw; S.ch[c].h = rh;
+  }
+  sync();
+  const int sid = 1 + 3 * F.num_lf_groups + 17 + g;
+  uint32_t e = mod_decode_stream(S, S.ch, nch, sid, tid);
+  if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
+  sync();
+  if (S.st.err) return;
+  // undo this group's own RCTs (last transform first), then copy the rectangles into the full planes
+  for (int i = S.trs.n - 1; i >= 0; i--) {
+    const DevTr t = S.trs.t[i];
+    const DevChanOut a = S.ch[t.begin_c], b2 = S.ch[t.begin_c + 1], c2 = S.ch[t.begin_c + 2];
+    if (a.w == b2.w && a.w == c2.w && a.h == b2.h && a.h == c2.h)
+      inv_rct_planes(a.d, b2.d, c2.d, (size_t)a.w * (size_t)a.h, t.rct_type, tid, nthreads);
+    else if (tid == 0) *B.err |= kErrBitstream | kErrStagePass;
+    sync();
+  }
+  for (int c = 0; c < nch; c++) {
+    const int fc = F.mod_first_group_ch + c;
+    const DevChanOut ch = S.ch[c];
+    int32_t *dst = mod_plane(B, F, fc);
+    for (int i = tid; i < ch.w * ch.h; i += nthreads) {
+      const int y = i / ch.w, x = i - y * ch.w;
+      dst[(size_t)(y0 + y) * (size_t)F.mod_w[fc] + (size_t)(x0 + x)] = ch.d[i];
+    }
+  }
+}
+
+// ---- inverse global transforms (one element per work-item)
+JXL_DEV void mod_op_element(const DevBuffers &B, const DevFrame &F, int op, size_t i) {
+  if (F.mod_op_kind[op] == 0) {            // RCT on planes a, b, c (x = rct_type)
+    inv_rct_planes(mod_plane(B, F, F.mod_op_a[op]) + i, mod_plane(B, F, F.mod_op_b[op]) + i, mod_plane(B, F, F.mod_op_c[op]) + i, 1,
+                   F.mod_op_x[op], 0, 1);
+  } else {                                  // channel palette: plane a = index/values, plane b = palette (x = nb_colours, y = bit depth)
+    int32_t *v = mod_plane(B, F, F.mod_op_a[op]) + i;
+    const int32_t *pal = mod_plane(B, F, F.mod_op_b[op]);
+    int index = *v;
+    const int psize = F.mod_op_x[op], bit_depth = F.mod_op_y[op] < 24 ? F.mod_op_y[op] : 24;
+    if (index < 0) index = 0;               // (delta-palette entries are rejected on the host: nb_deltas must be 0)
+    if (index > psize - 1) index = psize - 1;   // single-channel palette without deltas clamps the index (H.6.4)
+    *v = pal[index];
+    (void)bit_depth;
+  }
+}
+
+// ---- writer: integer planes -> RGBA u8 / u16 with orientation
+JXL_DEV void mod_write_pixel(const DevBuffers &B, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  const int w = F.width, h = F.height;
+  const size_t si = (size_t)y * (size_t)w + (size_t)x;
+  const float sc = 1.0f / (float)((1u << F.mod_bits) - 1);
+  const float maxv = out_bits == 16 ? 65535.0f : 255.0f;
+  uint32_t px[4];
+  for (int c = 0; c < 4; c++) {
+    float t;
+    if (F.mod_out[c] < 0) t = 1.0f;
+    else if (c == 3) t = (float)mod_plane(B, F, F.mod_out[c])[si] / (float)((1u << F.mod_alpha_bits) - 1);
+    else t = (float)mod_plane(B, F, F.mod_out[c])[si] * sc;
+    t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
+    px[c] = (uint32_t)(int)rintf(t * maxv);
+  }
+  int ox = x, oy = y;
+  switch (F.orientation) {
+    case 2: ox = w - 1 - x; break;
+    case 3: ox = w - 1 - x; oy = h - 1 - y; break;
+    case 4: oy = h - 1 - y; break;
+    case 5: ox = y; oy = x; break;
+    case 6: ox = h - 1 - y; oy = x; break;
+    case 7: ox = h - 1 - y; oy = w - 1 - x; break;
+    case 8: ox = y; oy = w - 1 - x; break;
+    default: break;
+  }
+  const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
+  if (out_bits == 8) *(uint32_t *)(B.out + di) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+  else { uint16_t *o = (uint16_t *)B.out + di; for (int c = 0; c < 4; c++) o[c] = (uint16_t)px[c]; }
+}
+
+}  // namespace jxlamd

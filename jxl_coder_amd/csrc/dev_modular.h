@@ -22,6 +22,9 @@ struct DevChanOut { int32_t *d; int32_t w, h; };
 constexpr int kLdsClusters = 12;      // leaf-code clusters whose alias tables are cached in LDS (24 KB)
 constexpr int kLdsCtx = 4096;
 
+struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
+struct DevTrList { DevTr t[4]; int32_t n; };
+
 struct DevModStream {                 // what lane 0 hands to the other lanes / to the next phase of a stream
   DevBits b;
   DevWP wp;
@@ -51,7 +54,8 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   uint32_t cfg[kLocMaxClusters];
   DevAlias alias[kLdsClusters * 256];
   DevModStream st;
-  DevChanOut ch[4];                   // channel descriptors of the current stream (LDS: keeps the kernel free of scratch)
+  DevChanOut ch[12];                  // channel descriptors of the current stream (LDS: keeps the kernel free of scratch)
+  DevTrList trs;                      // transforms of the current stream header
   DevWaveTree wt;
   uint32_t fallback_err;
 };
@@ -265,12 +269,37 @@ JXL_DEV void modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms, int 
 // One modular stream in three phases so that the whole wave can stage the stream's tables in LDS:
 //   begin (lane 0): GroupHeader, (global | local) MA tree + leaf code;  stage (all lanes): tree head, context map,
 //   hybrid-uint configs and alias tables -> LDS;  decode (lane 0): channels + final-state check.
-JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, LocalTreeScratch &L, DevModScratch &S) {
+// Transform list of a stream header (H.6): RCT and palette are parsed, squeeze is flagged.
+JXL_DEV uint32_t modular_read_transforms(DevBits &b, int ntr, DevTrList *out) {
+  if (ntr > 0 && (!out || ntr > 4)) return kErrUnsupportedTransform;
+  if (out) out->n = ntr;
+  for (int i = 0; i < ntr; i++) {
+    DevTr &t = out->t[i];
+    t.id = (int)bits_read(b, 2);
+    t.begin_c = t.rct_type = t.num_c = t.nb_colours = t.nb_deltas = t.d_pred = 0;
+    if (t.id == 0) {
+      t.begin_c = (int)bits_u32(b, 3, 0, 6, 8, 10, 72, 13, 1096);
+      t.rct_type = (int)bits_u32(b, -1, 6, 2, 0, 4, 2, 6, 10);
+      if (t.rct_type >= 42) return kErrBitstream;
+    } else if (t.id == 1) {
+      t.begin_c = (int)bits_u32(b, 3, 0, 6, 8, 10, 72, 13, 1096);
+      t.num_c = (int)bits_u32(b, -1, 1, -1, 3, -1, 4, 13, 1);
+      t.nb_colours = (int)bits_u32(b, 8, 0, 10, 256, 12, 1280, 16, 5376);
+      t.nb_deltas = (int)bits_u32(b, -1, 0, 8, 1, 10, 257, 16, 1281);
+      t.d_pred = (int)bits_read(b, 4);
+    } else if (t.id == 2) return kErrSqueeze;
+    else return kErrBitstream;
+  }
+  return 0;
+}
+
+JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, LocalTreeScratch &L, DevModScratch &S, DevTrList *trs = nullptr) {
   DevModStream &st = S.st;
   int ntr, use_global;
   modular_read_header(st.b, st.wp, ntr, use_global);
   st.err = 0; st.m16 = F.modular_16bit;
-  if (ntr != 0) { st.err = kErrUnsupportedTransform; return; }
+  if (trs) trs->n = 0;
+  { uint32_t e = modular_read_transforms(st.b, ntr, trs); if (e) { st.err = e; return; } }
   if (use_global) {
     if (F.tree_count <= 0) { st.err = kErrBitstream; return; }
     st.tree = (const DevTreeNode *)(tables + F.tree_off); st.count = F.tree_count; st.ev = ec_view(tables, F.tree_ec);

@@ -20,7 +20,7 @@
 namespace jxlamd {
 
 // lane 0: flatten the tree reachable for (chan, stream) into ballot form
-__device__ inline void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W) {
+__device__ __forceinline__ void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W) {
   W.ni = 0; W.nl = 0; W.ok = 1; W.uses_wp = 0;
   int32_t *stack_node = W.stack_node; uint64_t *stack_n1 = W.stack_n1, *stack_n0 = W.stack_n0;
   int sp = 0;
@@ -57,7 +57,7 @@ __device__ inline void wave_tree_build(const DevTreeNode *tree, int count, int c
 // rANS symbol + hybrid uint with every table addressed directly in LDS (ds_read instead of flat loads through
 // generic pointers); used when the stream's code fits the LDS staging area, which is the case for libjxl's streams.
 template <bool kLds>
-__device__ inline uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx) {
+__device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx) {
   if (!kLds) return ec_read(v, b, state, ctx);
   const uint32_t cluster = S.ctx_map[ctx];
   const int lb = 12 - v.log_alpha;
@@ -76,7 +76,7 @@ __device__ inline uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, De
 
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 template <bool kLds>
-__device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
+__device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
                                                         int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
                                                         const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
   for (int ci = 0; ci < nch; ci++) {
@@ -242,7 +242,7 @@ __device__ inline uint32_t modular_decode_channels_wave(const DevECView &ev, Dev
 }
 
 // Stream-level wrapper: every lane calls it; falls back to the serial walker when the tree is too large.
-__device__ inline uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
+__device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
   DevModStream &st = S.st;
   if (st.err) return st.err;
   DevECView ev = st.ev;

@@ -80,6 +80,14 @@ struct DevFrame {
   uint32_t cs_size;                // bytes of the codestream buffer (device copy carries >= 64 B of zero padding)
   uint32_t sec_off;                // DevSection[nsec]: [0]=LfGlobal, 1..=LfGroup, then HfGlobal, then PassGroups
   int32_t nsec;
+  // Modular-encoded frames (lossless): stream channels after the GLOBAL transforms' meta-apply, planes in one pool
+  int32_t is_modular, mod_nch, mod_nb_meta, mod_first_group_ch;   // channels [mod_first_group_ch, mod_nch) are decoded per group
+  int32_t mod_w[12], mod_h[12]; uint32_t mod_plane_off[12];        // int32 planes (offsets in samples into the pool)
+  uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
+  int32_t mod_nops;                // inverse global transforms, in execution order, with resolved plane indices
+  int32_t mod_op_kind[8], mod_op_a[8], mod_op_b[8], mod_op_c[8], mod_op_x[8], mod_op_y[8];
+  int32_t mod_out[4];              // planes feeding R, G, B, A (-1: opaque / replicate grey is done by repeating the index)
+  int32_t mod_bits, mod_alpha_bits;
   // loop filter
   int32_t gab; float gab_w[3][2];
   int32_t epf_iters; float epf_sharp[8], epf_chscale[3], epf_quant_mul, epf_pass0, epf_pass2, epf_border_sad;

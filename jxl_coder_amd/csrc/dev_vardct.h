@@ -27,7 +27,9 @@ struct DevBuffers {
   int32_t *coef[3];             // [num_groups][65536]
   float *plane_a[3], *plane_b[3];
   int32_t *lf_scratch;          // [num_lf_groups][kLfScratchInts]
-  LocalTreeScratch *local;      // [num_lf_groups]: local MA trees / histograms parsed on the device
+  LocalTreeScratch *local;      // [max(num_lf_groups, num_groups)]: local MA trees / histograms parsed on the device
+  int32_t *mod_pool;            // Modular-encoded frames: int32 channel planes (DevFrame::mod_plane_off)
+  int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
 };

@@ -137,6 +137,94 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
 
 static void finish_blob(FramePlan *plan, Priv *pv) { memcpy(plan->tables.data(), &pv->F, sizeof(DevFrame)); }
 
+
+// GlobalModular of a Modular-encoded frame: parse the stream header (transforms) on the host, derive the channel list
+// the device decodes and the inverse-transform program with resolved plane indices.  Sample data stays on the device.
+static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb) {
+  DevFrame &F = pv->F; const frame_hdr &f = pv->f; const img_meta &m = pv->m;
+  F.is_modular = 1;
+  F.mod_global_bit = (uint32_t)sb->pos;
+  F.mod_bits = (int)m.pub.bits_per_sample;
+  if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
+  const int ncol = m.pub.num_color_channels == 1 ? 1 : 3;
+  struct Ch { int w, h, plane; };
+  std::vector<Ch> L;
+  int nplanes = 0;
+  for (int i = 0; i < ncol + m.num_extra; i++) {
+    if (i >= ncol && m.ec[i - ncol].dim_shift) { plan->error = "unsupported: extra channel dim_shift"; return -1; }
+    L.push_back({f.width, f.height, nplanes++});
+  }
+  int nb_meta = 0;
+  // GroupHeader (H.2): use_global_tree, WP header (skipped here, the device parses it again), transforms
+  if (!hx_bool(sb)) { plan->error = "unsupported: GlobalModular stream with a local MA tree"; return -1; }
+  if (F.tree_count <= 0) { plan->error = "modular frame: missing global MA tree"; return -1; }
+  if (!hx_bool(sb)) { for (int i = 0; i < 7; i++) (void)hx_bits(sb, 5); for (int i = 0; i < 4; i++) (void)hx_bits(sb, 4); }
+  const int ntr = (int)hx_u32(sb, -1, 0, -1, 1, 4, 2, 8, 18);
+  if (ntr > 4) { plan->error = "unsupported: more than 4 global transforms"; return -1; }
+  struct Tr { int id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
+  std::vector<Tr> trs;
+  for (int i = 0; i < ntr; i++) {
+    Tr t{}; t.id = (int)hx_bits(sb, 2);
+    if (t.id == 0) {
+      t.begin_c = (int)hx_u32(sb, 3, 0, 6, 8, 10, 72, 13, 1096);
+      t.rct_type = (int)hx_u32(sb, -1, 6, 2, 0, 4, 2, 6, 10);
+      if (t.rct_type >= 42 || t.begin_c + 3 > (int)L.size()) { plan->error = "bad RCT transform"; return -1; }
+    } else if (t.id == 1) {
+      t.begin_c = (int)hx_u32(sb, 3, 0, 6, 8, 10, 72, 13, 1096);
+      t.num_c = (int)hx_u32(sb, -1, 1, -1, 3, -1, 4, 13, 1);
+      t.nb_colours = (int)hx_u32(sb, 8, 0, 10, 256, 12, 1280, 16, 5376);
+      t.nb_deltas = (int)hx_u32(sb, -1, 0, 8, 1, 10, 257, 16, 1281);
+      t.d_pred = (int)hx_bits(sb, 4);
+      if (t.num_c != 1 || t.nb_deltas != 0 || t.d_pred != 0) { plan->error = "unsupported: multi-channel / delta palette"; return -1; }
+      if (t.begin_c + t.num_c > (int)L.size() || t.nb_colours < 1 || t.nb_colours > 256 || t.begin_c < nb_meta) { plan->error = "unsupported: palette layout"; return -1; }
+      // meta-apply: one index channel stays at begin_c, the palette (nb_colours x num_c) becomes meta channel 0
+      L.insert(L.begin(), {t.nb_colours, t.num_c, nplanes++});
+      nb_meta++;
+    } else { plan->error = "unsupported: squeeze transform"; return -1; }
+    trs.push_back(t);
+  }
+  if (sb->err) { plan->error = "truncated GlobalModular header"; return -1; }
+  if ((int)L.size() > 12) { plan->error = "unsupported: more than 12 modular channels"; return -1; }
+  F.mod_nch = (int)L.size(); F.mod_nb_meta = nb_meta;
+  uint32_t off = 0;
+  int first_group = F.mod_nch;
+  for (int i = 0; i < F.mod_nch; i++) {
+    F.mod_w[i] = L[(size_t)i].w; F.mod_h[i] = L[(size_t)i].h;
+    if (first_group == F.mod_nch && i >= nb_meta && (L[(size_t)i].w > f.group_dim || L[(size_t)i].h > f.group_dim)) first_group = i;
+  }
+  // planes are indexed by stream channel position (the device decodes "channel i" into plane i)
+  for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }
+  F.mod_first_group_ch = first_group;
+  plan->mod_pool_ints = off;
+  if (F.mod_nch - first_group > 8) { plan->error = "unsupported: more than 8 group channels"; return -1; }
+  // inverse program (last transform first)
+  F.mod_nops = 0;
+  for (int i = ntr - 1; i >= 0; i--) {
+    const Tr &t = trs[(size_t)i];
+    int o = F.mod_nops++;
+    if (t.id == 0) {
+      F.mod_op_kind[o] = 0;
+      F.mod_op_a[o] = L[(size_t)t.begin_c].plane; F.mod_op_b[o] = L[(size_t)t.begin_c + 1].plane; F.mod_op_c[o] = L[(size_t)t.begin_c + 2].plane;
+      F.mod_op_x[o] = t.rct_type;
+      const Ch &a = L[(size_t)t.begin_c], &b2 = L[(size_t)t.begin_c + 1], &c2 = L[(size_t)t.begin_c + 2];
+      if (a.w != b2.w || a.w != c2.w || a.h != b2.h || a.h != c2.h) { plan->error = "RCT over channels of different size"; return -1; }
+      F.mod_op_y[o] = a.w * a.h;
+    } else {
+      F.mod_op_kind[o] = 1;
+      F.mod_op_a[o] = L[(size_t)t.begin_c + 1].plane;     // index channel (after the meta channel was inserted at 0)
+      F.mod_op_b[o] = L[0].plane;
+      F.mod_op_x[o] = t.nb_colours; F.mod_op_y[o] = F.mod_bits;
+      F.mod_op_c[o] = L[(size_t)t.begin_c + 1].w * L[(size_t)t.begin_c + 1].h;
+      L.erase(L.begin());
+    }
+  }
+  if ((int)L.size() != ncol + m.num_extra) { plan->error = "modular channel bookkeeping"; return -1; }
+  for (int c = 0; c < 3; c++) F.mod_out[c] = L[(size_t)(ncol == 1 ? 0 : c)].plane;
+  F.mod_out[3] = -1; F.mod_alpha_bits = 8;
+  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits; break; }
+  return 0;
+}
+
 }  // namespace
 
 int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error) {
@@ -169,19 +257,21 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   if (m.pub.want_icc) { plan->error = "unsupported: embedded ICC profile"; return -1; }
   if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
   if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
-  if (m.num_extra) { plan->error = "unsupported: extra channels (alpha) on the device path"; return -1; }
-  if (!m.pub.xyb_encoded) { plan->error = "unsupported: non-XYB (Modular / lossless) frames on the device path"; return -1; }
   uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
   hx_align(&br);
   frame_hdr &f = pv->f;
   if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { plan->error = hx_last_error(); return -1; }
   if (f.frame_type != 0 || !f.is_last) { plan->error = "unsupported: multi-frame / non-regular frame"; return -1; }
-  if (f.encoding != 0) { plan->error = "unsupported: Modular-encoded frame on the device path"; return -1; }
+  if (f.encoding == 0 && m.num_extra) { plan->error = "unsupported: extra channels (alpha) on VarDCT frames"; return -1; }
+  if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
+  if (f.encoding == 1 && m.pub.xyb_encoded) { plan->error = "unsupported: lossy (XYB) Modular frame"; return -1; }
+  if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
+  if (f.encoding == 1 && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
   if (f.upsampling != 1) { plan->error = "unsupported: upsampling"; return -1; }
   if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) { plan->error = "unsupported: cropped frame"; return -1; }
   if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
   if (f.flags & (1 | 2 | 16 | 32)) { plan->error = "unsupported: patches/splines/noise/LF frame"; return -1; }
-  if (f.group_dim != 256) { plan->error = "unsupported: group size"; return -1; }
+  if (f.group_dim != 256 && !(f.encoding == 1 && f.num_groups == 1 && f.width <= 256 && f.height <= 256)) { plan->error = "unsupported: group size"; return -1; }
   // ---- TOC
   int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   std::vector<uint32_t> perm;
@@ -230,8 +320,11 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
   float lf_dequant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   if (!hx_bool(&sb)) for (int c = 0; c < 3; c++) lf_dequant[c] = hx_f16(&sb) * (1.0f / 128);
-  uint32_t global_scale = hx_u32(&sb, 11, 1, 11, 2049, 12, 4097, 16, 8193);
-  uint32_t quant_lf = hx_u32(&sb, -1, 16, 5, 1, 8, 1, 16, 1);
+  uint32_t global_scale = 1, quant_lf = 1;
+  uint32_t color_factor = 84; float base_x = 0.0f, base_b = 1.0f; int ytox_dc = 0, ytob_dc = 0;
+  if (f.encoding == 0) {
+  global_scale = hx_u32(&sb, 11, 1, 11, 2049, 12, 4097, 16, 8193);
+  quant_lf = hx_u32(&sb, -1, 16, 5, 1, 8, 1, 16, 1);
   std::vector<uint8_t> bctx;
   if (hx_bool(&sb)) { bctx.assign(kDefaultBlockCtxMap, kDefaultBlockCtxMap + 39); F.num_bctx = 15; }
   else {
@@ -249,11 +342,11 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     if (hx__read_ctx_map(&sb, bctx.data(), (int)n, &F.num_bctx)) { plan->error = "bad block ctx map"; return -1; }
   }
   F.bctx_map_off = blob.append(bctx.data(), bctx.size());
-  uint32_t color_factor = 84; float base_x = 0.0f, base_b = 1.0f; int ytox_dc = 0, ytob_dc = 0;
   if (!hx_bool(&sb)) {
     color_factor = hx_u32(&sb, -1, 84, -1, 256, 8, 2, 16, 258);
     base_x = hx_f16(&sb); base_b = hx_f16(&sb);
     ytox_dc = (int)hx_bits(&sb, 8) - 128; ytob_dc = (int)hx_bits(&sb, 8) - 128;
+  }
   }
   // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
   hx_tree tree; memset(&tree, 0, sizeof(tree));
@@ -276,6 +369,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   } else F.tree_count = 0;     // streaming-encoded frames: every LfGroup stream carries its own tree (parsed on the device)
   plan->lf_global_end_bit = (uint32_t)sb.pos;
   F.single_lf_bit = (uint32_t)sb.pos;
+  if (f.encoding == 1 && parse_modular_global(plan, pv, &sb)) return -1;
   // quantiser-derived constants
   float inv_quant_dc = 65536.0f / ((float)global_scale * (float)quant_lf);
   for (int c = 0; c < 3; c++) F.lf_fac[c] = lf_dequant[c] * inv_quant_dc;
@@ -319,7 +413,9 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   plan->single_section = nsec == 1;
   plan->xb = F.xb; plan->yb = F.yb; plan->num_groups = F.num_groups; plan->num_lf_groups = F.num_lf_groups;
   plan->num_passes = F.num_passes; plan->width = F.width; plan->height = F.height;
-  if (!plan->single_section) {
+  plan->modular = f.encoding == 1;
+  if (f.encoding == 1) plan->single_section = false;    // nothing to re-parse on the host: no HfGlobal
+  if (!plan->single_section && f.encoding == 0) {
     hx_br hb; hx_br_init(&hb, plan->cs + secs[(size_t)(1 + f.num_lf_groups)].off, secs[(size_t)(1 + f.num_lf_groups)].size);
     if (parse_hf_global(plan, pv, &hb)) return -1;
   }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dev_bodies.h"
+#include "dev_modframe.h"
 namespace jxlamd {
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, hipStream_t s);
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
@@ -12,4 +13,9 @@ void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipS
 // filters ping-pong between plane_a and plane_b; `src_is_a` tells where the current image is; returns the new flag
 bool launch_filters(const DevBuffers &B, int width, int height, int gab, int epf_iters, bool src_is_a, hipStream_t s);
 void launch_write(const DevBuffers &B, const uint8_t *stat, int width, int height, int out_bits, bool src_is_a, hipStream_t s);
+// Modular-encoded (lossless) frames
+void launch_mod_global(const DevBuffers &B, hipStream_t s);
+void launch_mod_groups(const DevBuffers &B, int num_groups, hipStream_t s);
+void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s);
+void launch_mod_write(const DevBuffers &B, int width, int height, int out_bits, hipStream_t s);
 }  // namespace jxlamd

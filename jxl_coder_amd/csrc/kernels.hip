@@ -80,6 +80,31 @@ __global__ void __launch_bounds__(256) k_write(DevBuffers B, const uint8_t *stat
   xyb_write_pixel(B, stat, *(const DevStatic *)stat, src.p, out_bits, x, y);
 }
 
+// ---- Modular-encoded frames
+__global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
+  __shared__ DevModScratch S;
+  mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
+  __shared__ DevModScratch S;
+  mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(256) k_mod_op(DevBuffers B, int op, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mod_op_element(B, frame_of(B), op, i);
+}
+__global__ void __launch_bounds__(256) k_mod_write(DevBuffers B, int out_bits, int w, int h) {
+  int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= w || y >= h) return;
+  mod_write_pixel(B, out_bits, x, y);
+}
+void launch_mod_global(const DevBuffers &B, hipStream_t s) { hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), 0, s, B); }
+void launch_mod_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_group, dim3(n), dim3(64), 0, s, B); }
+void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_mod_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, op, n); }
+void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream_t s) {
+  hipLaunchKernelGGL(k_mod_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, out_bits, w, h);
+}
+
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map); }

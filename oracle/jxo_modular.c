@@ -204,6 +204,7 @@ static int decode_channel(jxo_br *br, jxo_ec *ec, const jxo_tree *tree, const jx
     if (tree->n[i].prop == 15) uses_wp = 1;
     if (tree->n[i].prop < 0 && tree->n[i].predictor == 6) uses_wp = 1;
   }
+  { extern int jxo_debug; if (jxo_debug > 1 && chan == 0) fprintf(stderr, "dbg tree: stream %d nodes %d max_prop %d uses_wp %d w %d h %d\n", stream_id, tree->count, max_prop, uses_wp, w, h); }
   int nprops = max_prop + 1;
   int32_t *props = (int32_t *)calloc((size_t)nprops + 4, 4);
   /* reference channels for props >= 16 */
@@ -428,6 +429,7 @@ int jxo_modular_decode(jxo_br *br, jxo_modimg *img, int stream_id, int max_chan_
       JXO_FAIL("unsupported: squeeze transform");
     } else JXO_FAIL("bad transform id");
     if (br->err) JXO_FAIL("truncated modular header");
+    { extern int jxo_debug; if (jxo_debug > 1) fprintf(stderr, "dbg transforms: stream %d id %d begin_c %d rct %d num_c %d nbcol %d\n", stream_id, t->id, t->begin_c, t->rct_type, t->num_c, t->nb_colours); }
     if (meta_apply(img, t)) return -1;
     img->ntr++;
   }

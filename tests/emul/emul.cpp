@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "../../jxl_coder_amd/csrc/dev_bodies.h"
+#include "../../jxl_coder_amd/csrc/dev_modframe.h"
 #include "../../jxl_coder_amd/csrc/host_parse.h"
 
 using namespace jxlamd;
@@ -43,9 +44,22 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   B.xfromy = tl[0].data(); B.bfromy = tl[1].data();
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = &err; B.out = out;
-  std::vector<LocalTreeScratch> loc((size_t)plan.num_lf_groups); B.local = loc.data();
+  std::vector<LocalTreeScratch> loc((size_t)(plan.modular ? (plan.num_groups > 1 ? plan.num_groups : 1) : plan.num_lf_groups)); B.local = loc.data();
+  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr(plan.modular ? (size_t)plan.num_groups * kModGroupScratchInts : 1, 0);
+  B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
   const std::vector<uint8_t> &stat = static_tables();
+  if (plan.modular) {
+    const DevFrame &F = *(const DevFrame *)tables.data();
+    DevModScratch *MS = new DevModScratch();
+    mod_global_body(B, *MS, 0, 1, NoSync());
+    if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS, g, 0, 1, NoSync());
+    delete MS;
+    if (err) { g_err = "device flags " + std::to_string(err) + " (Modular)"; return -2; }
+    for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) mod_write_pixel(B, out_bits, x, y);
+    return 0;
+  }
   DevModScratch *MS = new DevModScratch();
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
   delete MS;

@@ -39,6 +39,9 @@ CASES = {
     "l64_e3": (64, 64, dict(seed=1), dict(lossless=True, effort=3)),
     "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),
     "l200x120_e7": (200, 120, dict(seed=5), dict(lossless=True, effort=7)),
+    "l512_e7": (512, 512, dict(seed=1), dict(lossless=True, effort=7)),          # BASELINE config 1
+    "l300x260_e5": (300, 260, dict(seed=6), dict(lossless=True, effort=5)),        # single 512-px group (device: rejected, oracle: exact)
+    "l700x500_e7": (700, 500, dict(seed=7), dict(lossless=True, effort=7)),        # 3x2 groups with ragged edges
 }
 
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS, U16_MEAN_ABS,
-                      load_case)
+                      LOSSLESS_DEVICE_CASES, load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -75,9 +75,9 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    lossless, _ = load_case("l64_e7")
+    fast_lossless, _ = load_case("l64_e1")                                    # effort-1 stream: LZ77 inside group streams
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
-        dec.decode_one_shot(lossless)
+        dec.decode_one_shot(fast_lossless)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
     assert out.shape == (520, 264, 4)
 
@@ -118,3 +118,12 @@ def test_16bit_output(dec, name):
         assert (d > U16_MAX_ABS).mean() < 2e-3 and info["transfer_function"] == 16 and info["primaries"] == 9
     out8, info8 = dec.decode_one_shot(data, allowed_floats=False)       # API < 26 branch: 8-bit output
     assert out8.dtype == np.uint8 and info8["out_bits"] == 8
+
+
+@pytest.mark.parametrize("name", LOSSLESS_DEVICE_CASES)
+def test_lossless_bit_exact(dec, name):
+    """BASELINE config 1 class: Modular-encoded lossless frames decode bit-exact on the GPU (integer path)."""
+    data, exp = load_case(name)
+    out, info = dec.decode_one_shot(data)
+    assert out.dtype == exp.dtype and np.array_equal(out, exp)
+    assert info["uses_original_profile"] == 1

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, load_case)
+                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, load_case)
 
 import jxl_coder_amd as J
 
@@ -80,7 +80,7 @@ def test_device_code_on_cpu_harness(emul, oracle, name):
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
-    data, _ = load_case("l64_e7")
+    data, _ = load_case("l64_e1")
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
 
@@ -107,3 +107,25 @@ def test_device_code_16bit_on_cpu_harness(emul, name):
         assert d.max() <= U16_MAX_ABS
     else:
         assert (d > U16_MAX_ABS).mean() < 2e-3
+
+
+@pytest.mark.parametrize("name", LOSSLESS_DEVICE_CASES)
+def test_device_code_lossless_bit_exact_on_cpu_harness(emul, name):
+    """Modular-encoded frames (BASELINE config 1) through the product's device functions: bit-exact."""
+    data, exp = load_case(name)
+    out = emul(data)
+    assert out.dtype == exp.dtype and np.array_equal(out, exp)
+
+
+def test_entropy_kernels_use_no_scratch():
+    """Per-lane scratch corrupted tables when several decoder contexts ran side by side: keep it at 0."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "jxl_coder_amd", "csrc", "kernels.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", os.devnull,
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sizes = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)
+    assert sizes and all(int(x) == 0 for x in sizes), sizes
