@@ -15,6 +15,7 @@
 // -m gpu parity tests exercise this one.
 #pragma once
 #include "dev_modular.h"
+#include <type_traits>
 
 #ifdef __HIPCC__
 namespace jxlamd {
@@ -74,6 +75,153 @@ __device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScrat
   return ec_hybrid(b, cfg, sym);
 }
 
+template <class T> __device__ __forceinline__ T tabs(T v) { return v < 0 ? -v : v; }
+template <class T>
+__device__ __forceinline__ T predict_plain_t(int predictor, T W, T N, T NW, T NE, T NN, T WW, T NEE, T wp) {
+  switch (predictor) {
+    case 0: return 0;
+    case 1: return W;
+    case 2: return N;
+    case 3: return (W + N) / 2;
+    case 4: { T p = W + N - NW; return tabs<T>(p - W) < tabs<T>(p - N) ? W : N; }
+    case 5: { T m = N < W ? N : W, M = N < W ? W : N, g = N + W - NW; return g < m ? m : g > M ? M : g; }
+    case 6: return wp;
+    case 7: return NE;
+    case 8: return NW;
+    case 9: return WW;
+    case 10: return (W + NW) / 2;
+    case 11: return (N + NW) / 2;
+    case 12: return (N + NE) / 2;
+    case 13: return (6 * N - 2 * NN + 7 * W + WW + NEE + 3 * NE + 8) / 16;
+  }
+  return 0;
+}
+
+// One channel, all 64 lanes in lock-step.  kM16: every sample fits int16 (ImageMetadata.modular_16bit_buffers), so the
+// neighbourhood, the properties, the predictors and the weighted predictor run in 32-bit arithmetic (exactly the
+// same results as the 64-bit reference arithmetic, half the vector instructions).  kWP: this channel's pruned tree
+// uses the weighted predictor (property 15 or predictor 6).
+template <bool kLds, bool kM16, bool kWP>
+__device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
+                                                    DevWaveTree &WT, const DevChanOut c, int lane) {
+  typedef typename std::conditional<kM16, int32_t, int64_t>::type T;
+  const int w = c.w, h = c.h;
+  const bool wide = w > kModMaxW;
+  const int ni = WT.ni, nl = WT.nl;
+  const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
+  const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+  const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull;
+  const uint64_t my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+  // lane j keeps leaf j's record in registers; the selected leaf's record is fetched with v_readlane (no LDS trip)
+  const int my_lctx = lane < nl ? WT.leaf_ctx[lane] : 0, my_lpred = lane < nl ? WT.leaf_pred[lane] : 0;
+  const int my_loff = lane < nl ? WT.leaf_off[lane] : 0, my_lmul = lane < nl ? WT.leaf_mul[lane] : 1;
+  // the WP's reciprocal table (1<<24)/(i+1), i < 64: lane i holds entry i; lookups are v_readlane with a uniform index
+  const int my_div = (int)S.divlut[lane];
+  #define WAVE_DIV(idx) ((uint32_t)__builtin_amdgcn_readlane(my_div, __builtin_amdgcn_readfirstlane((int)(idx))))
+  if (kWP) {
+    for (int i = lane; i < 2 * (w + 2); i += 64) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
+  }
+  __syncthreads();
+  for (int y = 0; y < h; y++) {
+    int32_t *out = c.d + (size_t)y * (size_t)w;
+    int32_t *row = wide ? out : S.rows[y % 3];
+    const int32_t *rN = wide ? out - w : S.rows[(y + 2) % 3];
+    const int32_t *rNN = wide ? out - 2 * w : S.rows[(y + 1) % 3];
+    int32_t vW = 0, vWW = 0;
+    int32_t vN = y > 0 ? rN[0] : 0, vNW = vN, vNE = (y > 0 && w > 1) ? rN[1] : vN, vNEE = (y > 0 && w > 2) ? rN[2] : vNE;
+    const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
+    uint32_t peNW[4] = {0, 0, 0, 0}, peN[4] = {0, 0, 0, 0}, peNE[4] = {0, 0, 0, 0};
+    int32_t teNW = 0, teN = 0, teNE = 0, teW = 0;
+    if (kWP) {
+      for (int k = 0; k < 4; k++) { peN[k] = S.wp_pred_err[k][prev_row]; peNW[k] = peN[k]; peNE[k] = w > 1 ? S.wp_pred_err[k][prev_row + 1] : peN[k]; }
+      teN = S.wp_err[prev_row]; teNW = teN; teNE = w > 1 ? S.wp_err[prev_row + 1] : teN;
+    }
+    int32_t prev_prop9 = 0;
+    for (int x = 0; x < w; x++) {
+      const T W_ = x > 0 ? vW : (y > 0 ? vN : 0);
+      const T N_ = y > 0 ? vN : W_;
+      const T NW_ = (x > 0 && y > 0) ? vNW : W_;
+      const T NE_ = (x + 1 < w && y > 0) ? vNE : N_;
+      const T NN_ = y > 1 ? rNN[x] : N_;
+      const T NEE_ = (x + 2 < w && y > 0) ? vNEE : NE_;
+      const T WW_ = x > 1 ? vWW : W_;
+      const int32_t nextNEE = (y > 0 && x + 3 < w) ? rN[x + 3] : 0;     // independent of this sample: issued early
+      const int32_t p9 = (int32_t)(W_ + N_ - NW_);
+      int32_t pv[16];
+      pv[2] = y; pv[3] = x;
+      pv[4] = (int32_t)tabs<T>(N_); pv[5] = (int32_t)tabs<T>(W_);
+      pv[6] = (int32_t)N_; pv[7] = (int32_t)W_;
+      pv[8] = (int32_t)(W_ - prev_prop9); pv[9] = p9; prev_prop9 = p9;
+      pv[10] = (int32_t)(W_ - NW_); pv[11] = (int32_t)(NW_ - N_); pv[12] = (int32_t)(N_ - NE_);
+      pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_); pv[15] = 0;
+      T wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
+      if (kWP) {
+        uint32_t wgt[4];
+        for (int k = 0; k < 4; k++) {
+          const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
+          int shift = floor_log2_u32(e + 1) - 5;
+          if (shift < 0) shift = 0;
+          wgt[k] = 4 + (((uint32_t)wp.w[k] * WAVE_DIV(e >> shift)) >> shift);
+        }
+        const T N8 = N_ * 8, W8 = W_ * 8, NE8 = NE_ * 8, NW8 = NW_ * 8, NN8 = NN_ * 8;
+        const T tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
+        const T sumWN = tN + tW;
+        T p = tW;
+        if (tabs<T>(tN) > tabs<T>(p)) p = tN;
+        if (tabs<T>(tNW) > tabs<T>(p)) p = tNW;
+        if (tabs<T>(tNE) > tabs<T>(p)) p = tNE;
+        pv[15] = (int32_t)p;
+        wpred[0] = W8 + NE8 - N8;
+        wpred[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
+        wpred[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
+        wpred[3] = N8 - ((tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + (NW8 - W8) * wp.p3e) >> 5);
+        uint32_t wsum = wgt[0] + wgt[1] + wgt[2] + wgt[3];
+        const int lw = floor_log2_u32(wsum);
+        wsum = 0;
+        for (int k = 0; k < 4; k++) { wgt[k] >>= lw - 4; wsum += wgt[k]; }
+        T sum = (T)(wsum >> 1) - 1;
+        for (int k = 0; k < 4; k++) sum += wpred[k] * (T)wgt[k];
+        wp_raw = (T)(((int64_t)sum * (int64_t)WAVE_DIV(wsum - 1)) >> 24);
+        if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
+          T mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
+          T mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
+          if (wp_raw > mx) wp_raw = mx;
+          if (wp_raw < mn) wp_raw = mn;
+        }
+        wp_pred = (wp_raw + 3) >> 3;
+      }
+      // MA tree by ballot: lane i decides node i, lane j tests leaf j, the chosen leaf's record comes by readlane
+      int32_t myv = pv[2];
+      #pragma unroll
+      for (int k = 3; k < 16; k++) myv = my_prop == k ? pv[k] : myv;
+      const uint64_t dec = __ballot(lane < ni && myv > my_split);
+      const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
+      const int leaf = lm ? __builtin_ctzll(lm) : 0;
+      const int l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf), l_pred = __builtin_amdgcn_readlane(my_lpred, leaf);
+      const int l_off = __builtin_amdgcn_readlane(my_loff, leaf), l_mul = __builtin_amdgcn_readlane(my_lmul, leaf);
+      const T guess = predict_plain_t<T>(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
+      const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx);
+      const T val = (T)unpack_signed(u) * (T)l_mul + (T)l_off + guess;
+      if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
+      vWW = vW; vW = (int32_t)val;
+      vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
+      if (kWP) {
+        const T v8 = val * 8;
+        const int32_t terr = (int32_t)(wp_raw - v8);
+        uint32_t err[4];
+        for (int k = 0; k < 4; k++) err[k] = (uint32_t)((tabs<T>(wpred[k] - v8) + 3) >> 3);
+        if (lane == 0) { S.wp_err[cur_row + x] = terr; for (int k = 0; k < 4; k++) S.wp_pred_err[k][cur_row + x] = err[k]; }
+        for (int k = 0; k < 4; k++) { peNW[k] = peN[k]; peN[k] = peNE[k] + err[k]; }   // carry to (x+1) of the previous row
+        teNW = teN; teN = teNE; teW = terr;
+        if (x + 2 < w) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
+        else { for (int k = 0; k < 4; k++) peNE[k] = peN[k]; teNE = teN; }
+      }
+    }
+    __syncthreads();     // row[] written by lane 0 is read by every lane in the next row
+  }
+  #undef WAVE_DIV
+}
+
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 template <bool kLds>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
@@ -81,162 +229,15 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
                                                         const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
   for (int ci = 0; ci < nch; ci++) {
     const DevChanOut c = chans[ci];
-    const int w = c.w, h = c.h;
-    if (w == 0 || h == 0) continue;
+    if (c.w == 0 || c.h == 0) continue;
     __syncthreads();
     if (lane == 0) wave_tree_build(gtree, tree_count, ci, stream_id, WT);
     __syncthreads();
     if (!WT.ok) return kErrWaveFallback;                    // caller re-runs the stream with the serial walker
     const bool uses_wp = WT.uses_wp != 0;
-    const bool wide = w > kModMaxW;
-    if (wide && uses_wp) return kErrUnsupportedTransform;
-    const int ni = WT.ni, nl = WT.nl;
-    const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
-    const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
-    const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull;
-    const uint64_t my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
-    if (uses_wp) {
-      for (int i = lane; i < 2 * (w + 2); i += 64) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
-    }
-    __syncthreads();
-    for (int y = 0; y < h; y++) {
-      int32_t *out = c.d + (size_t)y * (size_t)w;
-      int32_t *row = wide ? out : S.rows[y % 3];
-      const int32_t *rN = wide ? out - w : S.rows[(y + 2) % 3];
-      const int32_t *rNN = wide ? out - 2 * w : S.rows[(y + 1) % 3];
-      // sliding neighbourhood (registers)
-      int32_t vW = 0, vWW = 0;
-      int32_t vN = y > 0 ? rN[0] : 0, vNW = vN, vNE = (y > 0 && w > 1) ? rN[1] : vN, vNEE = (y > 0 && w > 2) ? rN[2] : vNE;
-      // weighted-predictor sliding state: pred_err of (NW, N, NE) in the previous row incl. the current row's carry
-      const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
-      uint32_t peNW[4], peN[4], peNE[4];
-      int32_t teNW = 0, teN = 0, teNE = 0, teW = 0;
-      if (uses_wp) {
-        for (int k = 0; k < 4; k++) { peN[k] = S.wp_pred_err[k][prev_row]; peNW[k] = peN[k]; peNE[k] = w > 1 ? S.wp_pred_err[k][prev_row + 1] : peN[k]; }
-        teN = S.wp_err[prev_row]; teNW = teN; teNE = w > 1 ? S.wp_err[prev_row + 1] : teN;
-      }
-      int32_t prev_prop9 = 0;
-      for (int x = 0; x < w; x++) {
-        const int64_t W_ = x > 0 ? vW : (y > 0 ? vN : 0);
-        const int64_t N_ = y > 0 ? vN : W_;
-        const int64_t NW_ = (x > 0 && y > 0) ? vNW : W_;
-        const int64_t NE_ = (x + 1 < w && y > 0) ? vNE : N_;
-        const int64_t NN_ = y > 1 ? rNN[x] : N_;
-        const int64_t NEE_ = (x + 2 < w && y > 0) ? vNEE : NE_;
-        const int64_t WW_ = x > 1 ? vWW : W_;
-        // prefetch next window element (independent of this sample's value)
-        const int32_t nextNEE = (y > 0 && x + 3 < w) ? rN[x + 3] : 0;
-        // properties
-        const int32_t p9 = (int32_t)(W_ + N_ - NW_);
-        int32_t pv[16];
-        pv[2] = y; pv[3] = x;
-        pv[4] = (int32_t)(N_ < 0 ? -N_ : N_); pv[5] = (int32_t)(W_ < 0 ? -W_ : W_);
-        pv[6] = (int32_t)N_; pv[7] = (int32_t)W_;
-        pv[8] = (int32_t)(W_ - prev_prop9); pv[9] = p9; prev_prop9 = p9;
-        pv[10] = (int32_t)(W_ - NW_); pv[11] = (int32_t)(NW_ - N_); pv[12] = (int32_t)(N_ - NE_);
-        pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_); pv[15] = 0;
-        // weighted predictor (uniform across lanes)
-        int64_t wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
-        if (uses_wp && m16) {
-          // 32-bit weighted predictor: valid because modular_16bit_buffers guarantees |sample| < 2^15, so every
-          // intermediate below stays under 2^31 (predictions < 2^19, weights < 2^5 after normalisation, 4 terms).
-          uint32_t wgt[4];
-          for (int k = 0; k < 4; k++) {
-            const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
-            wgt[k] = wp_error_weight(S.divlut, e, (uint32_t)wp.w[k]);
-          }
-          const int32_t N8 = (int32_t)N_ * 8, W8 = (int32_t)W_ * 8, NE8 = (int32_t)NE_ * 8, NW8 = (int32_t)NW_ * 8, NN8 = (int32_t)NN_ * 8;
-          const int32_t tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
-          const int32_t sumWN = tN + tW;
-          int32_t p = tW;
-          if (abs(tN) > abs(p)) p = tN;
-          if (abs(tNW) > abs(p)) p = tNW;
-          if (abs(tNE) > abs(p)) p = tNE;
-          pv[15] = p;
-          int32_t q[4];
-          q[0] = W8 + NE8 - N8;
-          q[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
-          q[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
-          q[3] = N8 - ((tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + (NW8 - W8) * wp.p3e) >> 5);
-          uint32_t wsum = wgt[0] + wgt[1] + wgt[2] + wgt[3];
-          const int lw = floor_log2_u32(wsum);
-          wsum = 0;
-          for (int k = 0; k < 4; k++) { wgt[k] >>= lw - 4; wsum += wgt[k]; }
-          int32_t sum = (int32_t)(wsum >> 1) - 1;
-          for (int k = 0; k < 4; k++) sum += q[k] * (int32_t)wgt[k];
-          int32_t raw = (int32_t)(((int64_t)sum * (int64_t)S.divlut[wsum - 1]) >> 24);
-          if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
-            int32_t mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
-            int32_t mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
-            if (raw > mx) raw = mx;
-            if (raw < mn) raw = mn;
-          }
-          wp_raw = raw;
-          for (int k = 0; k < 4; k++) wpred[k] = q[k];
-          wp_pred = (raw + 3) >> 3;
-        } else if (uses_wp) {
-          uint32_t wgt[4];
-          for (int k = 0; k < 4; k++) {
-            const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
-            wgt[k] = wp_error_weight(S.divlut, e, (uint32_t)wp.w[k]);
-          }
-          const int64_t N8 = N_ * 8, W8 = W_ * 8, NE8 = NE_ * 8, NW8 = NW_ * 8, NN8 = NN_ * 8;
-          const int64_t tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
-          const int64_t sumWN = tN + tW;
-          int64_t p = tW;
-          if (iabs64(tN) > iabs64(p)) p = tN;
-          if (iabs64(tNW) > iabs64(p)) p = tNW;
-          if (iabs64(tNE) > iabs64(p)) p = tNE;
-          pv[15] = (int32_t)p;
-          wpred[0] = W8 + NE8 - N8;
-          wpred[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
-          wpred[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
-          wpred[3] = N8 - ((tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + (NW8 - W8) * wp.p3e) >> 5);
-          uint32_t wsum = wgt[0] + wgt[1] + wgt[2] + wgt[3];
-          const int lw = floor_log2_u32(wsum);
-          wsum = 0;
-          for (int k = 0; k < 4; k++) { wgt[k] >>= lw - 4; wsum += wgt[k]; }
-          int64_t sum = (int64_t)(wsum >> 1) - 1;
-          for (int k = 0; k < 4; k++) sum += wpred[k] * (int64_t)wgt[k];
-          wp_raw = (sum * (int64_t)S.divlut[wsum - 1]) >> 24;
-          if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
-            int64_t mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
-            int64_t mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
-            if (wp_raw > mx) wp_raw = mx;
-            if (wp_raw < mn) wp_raw = mn;
-          }
-          wp_pred = (wp_raw + 3) >> 3;
-        }
-        // MA tree by ballot: lane i decides node i, lane j tests leaf j
-        int32_t myv = pv[2];
-        #pragma unroll
-        for (int k = 3; k < 16; k++) myv = my_prop == k ? pv[k] : myv;
-        const uint64_t dec = __ballot(lane < ni && myv > my_split);
-        const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
-        const int leaf = lm ? __builtin_ctzll(lm) : 0;
-        const int l_ctx = WT.leaf_ctx[leaf], l_pred = WT.leaf_pred[leaf], l_off = WT.leaf_off[leaf], l_mul = WT.leaf_mul[leaf];
-        const int64_t guess = predict_plain(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
-        const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx);
-        const int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)l_mul + l_off + guess;
-        if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
-        // slide
-        vWW = vW; vW = (int32_t)val;
-        vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
-        if (uses_wp) {
-          const int64_t v8 = val * 8;
-          const int32_t terr = (int32_t)(wp_raw - v8);
-          uint32_t err[4];
-          for (int k = 0; k < 4; k++) err[k] = (uint32_t)((iabs64(wpred[k] - v8) + 3) >> 3);
-          if (lane == 0) { S.wp_err[cur_row + x] = terr; for (int k = 0; k < 4; k++) S.wp_pred_err[k][cur_row + x] = err[k]; }
-          // the error of this sample is carried to position x+1 of the previous row (= N of the next sample)
-          for (int k = 0; k < 4; k++) { peNW[k] = peN[k]; peN[k] = peNE[k] + err[k]; }
-          teNW = teN; teN = teNE; teW = terr;
-          if (x + 2 < w) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
-          else { for (int k = 0; k < 4; k++) peNE[k] = peN[k]; teNE = teN; }
-        }
-      }
-      __syncthreads();     // row[] written by lane 0 is read by every lane in the next row
-    }
+    if (c.w > kModMaxW && uses_wp) return kErrUnsupportedTransform;
+    if (m16) { if (uses_wp) wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, true, false>(ev, b, state, wp, S, WT, c, lane); }
+    else { if (uses_wp) wave_decode_channel<kLds, false, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, false, false>(ev, b, state, wp, S, WT, c, lane); }
   }
   return 0;
 }

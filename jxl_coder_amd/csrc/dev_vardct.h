@@ -198,7 +198,7 @@ JXL_DEV void lf_group_epilogue(const DevBuffers &B, int g, int lane, int nlanes)
 }
 
 // ------------------------------------------------------------------ PassGroup (lane 0)
-constexpr int kPassCtxLds = 495 * 24;     // context-map slice of one HF preset cached in LDS (num_bctx <= 24)
+constexpr int kPassCtxLds = 495 * 16;     // context-map slice of one HF preset cached in LDS (num_bctx <= 16; larger maps stay in HBM/L2)
 struct DevPassScratch {
   uint8_t nz[3][32 * 32];
   uint8_t ctx_map[kPassCtxLds];
@@ -262,6 +262,12 @@ JXL_DEV uint32_t pass_ec_read(const DevPassScratch &S, const DevAlias *alias, in
   return ec_hybrid(b, cfg, sym);
 }
 
+#ifdef JXL_EMUL_TRACE
+static long g_pass_syms = 0, g_pass_blocks = 0, g_pass_nz = 0;
+#define PASS_COUNT(v, n) ((v) += (n))
+#else
+#define PASS_COUNT(v, n) ((void)0)
+#endif
 // phase 3 (lane 0): the serial rANS walk over the group's varblocks
 JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g) {
   const DevFrame &F = frame_of(B);
@@ -316,6 +322,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
         const int bctx = bctx_map[idx];
         const int nzp = predicted >= 64 ? 64 : predicted;
         const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
+        PASS_COUNT(g_pass_syms, 1); PASS_COUNT(g_pass_blocks, 1);
         int nzeros = (int)(fast ? pass_ec_read(S, ev.alias, ev.log_alpha, lds_ctx, gctx, b, state, (uint32_t)nzctx) : ec_read(ev, b, state, (uint32_t)nzctx));
         if (nzeros > size - covered) return kErrBitstream;
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
@@ -328,6 +335,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
           const int nl = (nzeros + covered - 1) >> log2c;
           const int kk = k >> log2c;
           const int ctx = histo + (S.nnz_ctx[nl] + S.freq_ctx[kk]) * 2 + prev;
+          PASS_COUNT(g_pass_syms, 1);
           const uint32_t u = fast ? pass_ec_read(S, ev.alias, ev.log_alpha, lds_ctx, gctx, b, state, (uint32_t)ctx) : ec_read(ev, b, state, (uint32_t)ctx);
           if (u) {
             const int32_t v = unpack_signed(u) * (1 << shift);
@@ -339,6 +347,9 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
         if (nzeros != 0) return kErrBitstream;
       }
     }
+#ifdef JXL_EMUL_TRACE
+  if (g == F.num_groups - 1) fprintf(stderr, "pass stage: %ld symbols, %ld block-channels over %d groups\n", g_pass_syms, g_pass_blocks, F.num_groups);
+#endif
   if (state != 0x130000u) return kErrAnsFinal;
   if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
   return 0;
