@@ -3,7 +3,9 @@
 // Host counterpart of the reference's DecodeJpegXlOneShot driver loop (interop/JxlDecoding.cpp:36-176).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <atomic>
 #include <limits>
 #include <thread>
@@ -49,7 +51,7 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
 
 struct FrameSlot {             // HBM work buffers of one in-flight frame
   PinnedMem h_tables, h_cs;
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch;
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, big_list[2];
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -57,13 +59,14 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   size_t out_bytes = 0;
   void *d_out = nullptr; void *host_out = nullptr;
   void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch};
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz};
     for (auto *m : all) m->release();
     for (auto &m : cells8) m.release();
     for (auto &m : tiles) m.release();
     for (auto &m : lf) m.release();
     for (auto &m : coef) m.release();
     for (auto &m : planes) m.release();
+    for (auto &m : big_list) m.release();
     h_tables.release(); h_cs.release();
   }
 };
@@ -77,6 +80,7 @@ struct jxlamd_decoder {
   PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
+  int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
   void set_error(const std::string &e) { error = e; g_tls_error = e; }
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
@@ -167,6 +171,9 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));
     HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
     HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
+    HIPCHECK(S.pass_nz.ensure((size_t)plan.num_groups * 3072));
+    HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
+    HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
   } else {
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
@@ -184,8 +191,9 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
                                 B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
   B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
-  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p;
-  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p;
+  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out; B.out_bits = (int32_t)S.pi.out_bits;
+  B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
@@ -328,10 +336,23 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
-  for (int i : batched) { FrameSlot &S = slot((size_t)i); launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream); }
-  launch_pass_groups_batch((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
+  int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 1 << 4;
+  for (int i : batched) {
+    const FrameSlot &S = slot((size_t)i);
+    const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+    max_cells = std::max(max_cells, S.plan.xb * S.plan.yb); max_w = std::max(max_w, S.plan.width); max_h = std::max(max_h, S.plan.height);
+    if (F->gab) stage_mask |= 1;
+    if (F->epf_iters >= 3) stage_mask |= 2;
+    if (F->epf_iters >= 1) stage_mask |= 4;
+    if (F->epf_iters >= 2) stage_mask |= 8;
+  }
+  launch_lf_smooth_batch((const DevBuffers *)(bt + o_b), (int)batched.size(), max_cells, stream);
+  // >= simt_min_groups groups in the flight: one LANE per group (64 streams per wavefront); below that the one-wave-per-group
+  // kernel has the shorter critical path
+  if ((int)pg_map.size() / 2 >= simt_min_groups) launch_pass_groups_simt((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
+  else launch_pass_groups_batch((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[2], stream));
-  for (int i : batched) launch_rest(slot((size_t)i));
+  launch_rest_batch((const DevBuffers *)(bt + o_b), (const uint8_t *)stat.p, (int)batched.size(), max_cells, max_w, max_h, stage_mask, stream);
   HIPCHECK(hipEventRecord(ev[4], stream));
   int first_rc = JXLAMD_OK;
   for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }

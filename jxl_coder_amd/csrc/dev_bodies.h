@@ -59,7 +59,7 @@ JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int 
 }
 
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]
-template <class Sync>
+template <bool kSpecial, class Sync>     // kSpecial: the 8x8 special transforms can occur (small-block launch only)
 JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int nmin, int nmax,
                               int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
@@ -77,7 +77,7 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   sync();
   float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};
   const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
-  if (strategy_is_special(st)) {
+  if (kSpecial && strategy_is_special(st)) {
     for (int c = tid; c < 3; c += nthreads) recon_special(stat, ST, st, S + c * n, dst[c] + po, F.pw);
     return;
   }

@@ -30,8 +30,12 @@ struct DevBuffers {
   LocalTreeScratch *local;      // [max(num_lf_groups, num_groups)]: local MA trees / histograms parsed on the device
   int32_t *mod_pool;            // Modular-encoded frames: int32 channel planes (DevFrame::mod_plane_off)
   int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
+  uint32_t *big_list[2];        // cell indices of the varblocks with 512..1024 / 2048..4096 coefficients (filled at placement)
+  uint32_t *big_count;          // [2] their counts
+  uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
+  int32_t out_bits;             // 8 or 16 (used by the batched writer)
 };
 
 constexpr int kLfScratchInts = 6 * 65536 + 2048 + 16;   // LF ints (3 planes) + CfL maps + block info + sharpness + [last] extra_precision
@@ -154,6 +158,16 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
           }
         }
         B.first[o] = 1;
+        const int ncoef = cx * cy * 64;
+        if (ncoef > 256 && ncoef <= 4096) {      // remember the large varblocks: their reconstruction kernels walk these lists
+          const int cls = ncoef <= 1024 ? 0 : 1;
+#ifdef __HIPCC__
+          const uint32_t slot = atomicAdd(&B.big_count[cls], 1u);
+#else
+          const uint32_t slot = B.big_count[cls]++;
+#endif
+          B.big_list[cls][slot] = (uint32_t)o;
+        }
       }
     }
   }
@@ -352,6 +366,96 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
 #endif
   if (state != 0x130000u) return kErrAnsFinal;
   if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
+  return 0;
+}
+
+// ------------------------------------------------------------------ PassGroup, lane-per-stream (SIMT) form
+// Batch mode: every LANE of a wavefront decodes its own 256x256 group (of any frame of the flight), so one vector
+// instruction advances up to 64 rANS streams.  All per-stream state is per-lane registers; the per-group nonzero map
+// lives in HBM/L2 (3 KiB per group, touched once per block), the code's tables are read through L2.  Same arithmetic
+// as pass_phase_decode; used by k_pass_group_simt and by the CPU harness (one lane at a time).
+JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, const uint16_t *nnz_ctx, uint8_t *nz, int g) {
+  const DevFrame &F = frame_of(B);
+  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+  const int gx = g % F.xgroups, gy = g / F.xgroups;
+  const int bx0 = gx * 32, by0 = gy * 32;
+  const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
+  const int nslice = 495 * F.num_bctx;
+  const uint8_t *bctx_map = B.tables + F.bctx_map_off;
+  const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
+  const bool accumulate = F.num_passes > 1;
+  for (int pass = 0; pass < F.num_passes; pass++) {
+    const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
+    DevBits b;
+    bits_init(b, B.codestream, sec.off, F.cs_size);
+    if (F.nsec == 1) {
+      uint32_t skip = F.single_pass_bit;
+      while (skip >= 32) { bits_read(b, 32); skip -= 32; }
+      bits_read(b, (int)skip);
+    }
+    const int sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
+    if (sel >= F.num_presets) return kErrBitstream;
+    DevECView ev = ec_view(B.tables, F.hf_ec[pass]);
+    ev.ctx_map += (size_t)sel * (size_t)nslice;
+    uint32_t state = ans_init(ev, b);
+    const int shift = F.pass_shift[pass];
+    for (int i = 0; i < 3 * 32 * 32; i++) nz[i] = 0;
+    uint32_t pool = 0;
+    for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++) {
+        const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+        if (!B.first[o]) continue;
+        const int st = B.strategy[o];
+        const int cx = kCoveredX[st], cy = kCoveredY[st];
+        const int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
+        const int size = covered * 64;
+        const int ord = kStrategyOrder[st];
+        uint32_t off;
+        if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
+        const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
+        int qf_idx = 0;
+        for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
+        const int lfi = B.lf_idx[o];
+        for (int ci = 0; ci < 3; ci++) {
+          const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
+          uint8_t *nzc = nz + c * 1024;
+          int predicted;
+          if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
+          else if (y == 0) predicted = nzc[x - 1];
+          else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
+          int idx = c < 2 ? c ^ 1 : 2;
+          idx = idx * 13 + ord;
+          idx = idx * (F.nb_qf_thr + 1) + qf_idx;
+          idx = idx * nlf + lfi;
+          const int bctx = bctx_map[idx];
+          const int nzp = predicted >= 64 ? 64 : predicted;
+          const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
+          int nzeros = (int)ec_read(ev, b, state, (uint32_t)nzctx);
+          if (nzeros > size - covered) return kErrBitstream;
+          const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
+          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
+          const int histo = F.num_bctx * 37 + 458 * bctx;
+          const uint32_t *order = (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+          int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
+          int prev = nzeros > size / 16 ? 0 : 1;
+          for (int k = covered; k < size && nzeros != 0; k++) {
+            const int nl = (nzeros + covered - 1) >> log2c;
+            const int kk = k >> log2c;
+            const int ctx = histo + (nnz_ctx[nl] + freq_ctx[kk]) * 2 + prev;
+            const uint32_t u = ec_read(ev, b, state, (uint32_t)ctx);
+            if (u) {
+              const int32_t v = unpack_signed(u) * (1 << shift);
+              if (accumulate) blk[order[k]] += v; else blk[order[k]] = v;
+            }
+            prev = u != 0;
+            nzeros -= prev;
+          }
+          if (nzeros != 0) return kErrBitstream;
+        }
+      }
+    if (state != 0x130000u) return kErrAnsFinal;
+    if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
+  }
   return 0;
 }
 

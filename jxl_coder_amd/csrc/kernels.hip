@@ -33,6 +33,19 @@ __global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, c
   pass_group_body(Bs[f], S, g, (int)threadIdx.x, 64, SyncBlock());
 }
 
+// lane-per-stream PassGroup kernel (batch mode): lane l of block b decodes group map[b*64+l]
+__global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, const int *map, int total) {
+  __shared__ uint16_t freq_ctx[64], nnz_ctx[64];
+  freq_ctx[threadIdx.x] = kCoeffFreqContext[threadIdx.x]; nnz_ctx[threadIdx.x] = kCoeffNumNonzeroContext[threadIdx.x];
+  __syncthreads();
+  const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (i >= total) return;
+  const int f = map[2 * i], g = map[2 * i + 1];
+  const DevBuffers &B = Bs[f];
+  uint32_t e = pass_group_lane(B, freq_ctx, nnz_ctx, B.pass_nz + (size_t)g * 3072, g);
+  if (e) atomicOr(B.err, e | kErrStagePass);
+}
+
 __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb) {
   int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i >= xb * yb) return;
@@ -41,25 +54,97 @@ __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb)
 
 // Varblock reconstruction in three size classes so that the LDS budget (and with it the occupancy) fits the block:
 //   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
-//   medium (512, 1024):            256 threads, 16 KiB LDS, scans kScan consecutive cells per workgroup
-//   large  (2048, 4096):           256 threads, 64 KiB LDS, scans kScan consecutive cells per workgroup
-constexpr int kScan = 16;
+//   medium (512, 1024):            256 threads, 16 KiB LDS, walks the list of such blocks recorded at placement
+//   large  (2048, 4096):           256 threads, 64 KiB LDS, walks its list
 __global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t *stat, int xb) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
   int cell = (int)blockIdx.x;
-  recon_block_body(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  recon_block_body<true>(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+}
+// medium / large varblocks: the placement step recorded their cells; a fixed-size grid walks the list.
+//
+// DCT32x32 (the dominant transform of smooth 4K content) takes a register-blocked path: the 32-point cosine table sits in
+// LDS for the lifetime of the workgroup, the three channels go through each 1-D pass together, and every work-item owns
+// a 4 (frequencies / rows) x 3 (channels) tile of outputs for one column x, so that one b128 LDS broadcast feeds 4 FMAs:
+//   pass 1: T[c][v][x] = sum_u S[c][u][v] * cc[u][x]      pass 2: out[c][y][x] = sum_v T[c][v][x] * cc[v][y]
+// 12 FMAs per 4 LDS reads instead of 1 FMA per (LDS + global) read of the generic path.
+constexpr int kStrategyDct32 = 5;
+template <int NMAX>
+struct ReconLds {
+  float S[3 * NMAX];
+  float T[NMAX > 1024 ? NMAX : 3 * 1024];
+  float CC[1024];
+};
+
+__device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const int x = tid & 31, q0 = (tid >> 5) * 4;
+  float acc[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[c][j] = 0.0f;
+#pragma unroll 4
+  for (int u = 0; u < 32; u++) {
+    const float ccv = CC[u * 32 + x];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float4 s4 = *(const float4 *)&S[c * 1024 + u * 32 + q0];
+      acc[c][0] += s4.x * ccv; acc[c][1] += s4.y * ccv; acc[c][2] += s4.z * ccv; acc[c][3] += s4.w * ccv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) { T[c * 1024 + (q0 + j) * 32 + x] = acc[c][j]; acc[c][j] = 0.0f; }
+  __syncthreads();
+#pragma unroll 4
+  for (int v = 0; v < 32; v++) {
+    const float4 c4 = *(const float4 *)&CC[v * 32 + q0];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float tv = T[c * 1024 + v * 32 + x];
+      acc[c][0] += tv * c4.x; acc[c][1] += tv * c4.y; acc[c][2] += tv * c4.z; acc[c][3] += tv * c4.w;
+    }
+  }
+  const size_t po = (size_t)(by * 8 + q0) * (size_t)F.pw + (size_t)(bx * 8 + x);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
+}
+
+template <int NMIN, int NMAX>
+__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb) {
+  __shared__ __attribute__((aligned(16))) ReconLds<NMAX> L;
+  const int tid = (int)threadIdx.x;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const uint32_t count = B.big_count[cls];
+  if (blockIdx.x >= count) return;
+  if (NMAX == 1024) {
+    const float *cc = st_f(stat, ST.cos_off[5]);
+    for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
+  }
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[cls][i];
+    const int bx = cell % xb, by = cell / xb;
+    if (NMAX == 1024 && B.strategy[cell] == kStrategyDct32) {
+      __syncthreads();                               // previous item's pass 2 has finished reading T; CC is in place
+      recon_phaseA(B, stat, ST, L.S, 1024, bx, by, tid, 256);
+      __syncthreads();
+      recon_phaseB(B, stat, ST, L.S, 1024, bx, by, tid, 256);
+      __syncthreads();
+      recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
+    } else {
+      __syncthreads();
+      recon_block_body<false>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
+    }
+  }
 }
 template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) k_recon_scan(DevBuffers B, const uint8_t *stat, int xb, int ncell) {
-  __shared__ float S[3 * NMAX];
-  __shared__ float T[NMAX];
-  for (int i = 0; i < kScan; i++) {
-    const int cell = (int)blockIdx.x * kScan + i;
-    if (cell >= ncell) return;
-    recon_block_body(B, stat, S, T, cell % xb, cell / xb, NMIN, NMAX, (int)threadIdx.x, 256, SyncBlock());
-    __syncthreads();
-  }
+__global__ void __launch_bounds__(256) k_recon_list(DevBuffers B, const uint8_t *stat, int cls, int xb) {
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, xb);
 }
 
 struct Planes { float *p[3]; };
@@ -105,17 +190,79 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
   hipLaunchKernelGGL(k_mod_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, out_bits, w, h);
 }
 
+// ---- batched data-parallel stages: blockIdx.z = frame of the flight (per-frame dims come from its DevFrame)
+// Which plane set holds the image before filter stage `stage` (0 gab, 1 epf0, 2 epf1, 3 epf2, 4 write), and does the
+// frame run that stage at all?
+__device__ __forceinline__ bool stage_runs(const DevFrame &F, int stage) {
+  return stage == 0 ? F.gab != 0 : stage == 1 ? F.epf_iters >= 3 : stage == 2 ? F.epf_iters >= 1 : stage == 3 ? F.epf_iters >= 2 : true;
+}
+__device__ __forceinline__ bool stage_src_is_a(const DevFrame &F, int stage) {
+  int n = 0;
+  for (int s = 0; s < stage; s++) n += stage_runs(F, s) ? 1 : 0;
+  return (n & 1) == 0;
+}
+__global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular) return;
+  int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= F.xb * F.yb) return;
+  lf_smooth_cell(B, i % F.xb, i / F.xb);
+}
+__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ float S[3 * 256];
+  __shared__ float T[256];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  const int cell = (int)blockIdx.x;
+  if (F.is_modular || cell >= F.xb * F.yb) return;
+  recon_block_body<true>(B, stat, S, T, cell % F.xb, cell / F.xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+}
+template <int NMIN, int NMAX>
+__global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular) return;
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb);
+}
+__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int stage) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || !stage_runs(F, stage)) return;
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height) return;
+  const bool a = stage_src_is_a(F, stage);
+  float *src[3], *dst[3];
+  for (int c = 0; c < 3; c++) { src[c] = a ? B.plane_a[c] : B.plane_b[c]; dst[c] = a ? B.plane_b[c] : B.plane_a[c]; }
+  if (stage == 0) gab_pixel(F, src, dst, x, y);
+  else if (stage <= 3) epf_pixel(B, F, src, dst, stage - 1, x, y);
+  else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
+}
+
+void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, hipStream_t s) {
+  hipLaunchKernelGGL(k_recon_small_b, dim3(max_cells, 1, nframes), dim3(64), 0, s, Bs, stat);
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(256, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(64, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
+  for (int stage = 0; stage <= 4; stage++)
+    if (stage_mask & (1 << stage)) hipLaunchKernelGGL(k_filter_b, grid, dim3(256), 0, s, Bs, stat, stage);
+}
+void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_lf_smooth_b, dim3((max_cells + 255) / 256, 1, nframes), dim3(256), 0, s, Bs);
+}
+
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map); }
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
+void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B, xb, yb);
 }
 void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_recon_small, dim3(xb * yb), dim3(64), 0, s, B, stat, xb);
-  hipLaunchKernelGGL((k_recon_scan<257, 1024>), dim3((xb * yb + kScan - 1) / kScan), dim3(256), 0, s, B, stat, xb, xb * yb);
-  hipLaunchKernelGGL((k_recon_scan<1025, 4096>), dim3((xb * yb + kScan - 1) / kScan), dim3(256), 0, s, B, stat, xb, xb * yb);
+  hipLaunchKernelGGL((k_recon_list<257, 1024>), dim3(2048), dim3(256), 0, s, B, stat, 0, xb);
+  hipLaunchKernelGGL((k_recon_list<1025, 4096>), dim3(512), dim3(256), 0, s, B, stat, 1, xb);
 }
 static Planes planes_of(const DevBuffers &B, bool a) {
   Planes p;
