@@ -19,8 +19,7 @@ constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
 struct DevChanOut { int32_t *d; int32_t w, h; };
 
-constexpr int kLdsClusters = 12;      // leaf-code clusters whose alias tables are cached in LDS (24 KB)
-constexpr int kLdsCtx = 4096;
+constexpr int kModPoolBytes = 20480;  // LDS table pool of one stream (alias tables, context map, tree head)
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
 struct DevTrList { DevTr t[4]; int32_t n; };
@@ -49,10 +48,15 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t wp_err[2 * (kWpMaxW + 2)];
   int32_t props[32];
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
-  DevTreeNode tree[kTreeLds];
-  uint8_t ctx_map[kLdsCtx];
   uint32_t cfg[kLocMaxClusters];
-  DevAlias alias[kLdsClusters * 256];
+  // Table pool, carved per stream by modular_stream_stage: [alias tables | context map | head of the MA tree].  A part
+  // that does not fit stays in HBM (the pointers below then address the HBM copy).  libjxl's LF streams need
+  // 9 clusters x 256 alias entries = 18 KiB; 20 KiB keeps the workgroup under 40 KiB LDS => 4 streams per CU.
+  uint64_t pool[kModPoolBytes / 8];
+  const DevAlias *alias;              // LDS when alias_lds
+  const uint8_t *ctx_map;             // LDS when ctx_lds
+  const DevTreeNode *tree;            // first tree_ncache nodes of the stream's tree
+  int32_t alias_lds, ctx_lds, tree_ncache, ctx_off;   // ctx_off: byte offset of the context map inside the pool
   DevModStream st;
   DevChanOut ch[12];                  // channel descriptors of the current stream (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header
@@ -235,10 +239,10 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         int64_t wp_pred = 0;
         if (tf.uses_wp) { int32_t me; wp_pred = wp_predict(S, wst, wp, x, y, w, N, W, NE, NW, NN, me); props[15] = me; }
         else props[15] = 0;
-        const DevTreeNode *nd = &S.tree[0];
+        const DevTreeNode *nd = S.tree_ncache > 0 ? &S.tree[0] : &gtree[0];
         while (nd->prop >= 0) {
           int idx = props[nd->prop] > nd->splitval ? nd->lchild : nd->rchild;
-          nd = idx < kTreeLds ? &S.tree[idx] : &gtree[idx];
+          nd = idx < S.tree_ncache ? &S.tree[idx] : &gtree[idx];
         }
         int64_t guess = predict_plain(nd->lchild, W, N, NW, NE, NN, WW, NEE, wp_pred);
         uint32_t u = ec_read(ev, b, state, (uint32_t)nd->splitval);
@@ -315,14 +319,33 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
 JXL_DEV void modular_stream_stage(DevModScratch &S, int tid, int nthreads) {
   DevModStream &st = S.st;
   if (st.err) return;
-  const int ncache = st.count < kTreeLds ? st.count : kTreeLds;
-  for (int i = tid; i < ncache; i += nthreads) S.tree[i] = st.tree[i];
+#ifdef JXL_EMUL_TRACE
+  if (tid == 0 && getenv("JXLEMUL_STATS")) fprintf(stderr, "stream: tree %d nodes, %d ctx, %d clusters, log_alpha %d, prefix %d\n", st.count, st.num_ctx, st.num_clusters, st.ev.log_alpha, st.ev.use_prefix);
+#endif
+  // carve the pool (every work-item computes the same layout; the stores of the descriptors are benign duplicates)
+  uint8_t *pool = (uint8_t *)S.pool;
+  int used = 0;
+  const int alias_bytes = st.ev.use_prefix ? 0 : (int)((st.num_clusters << st.ev.log_alpha) * sizeof(DevAlias));
+  const bool alias_lds = !st.ev.use_prefix && st.num_clusters <= kLocMaxClusters && alias_bytes <= kModPoolBytes;
+  DevAlias *l_alias = (DevAlias *)pool;
+  if (alias_lds) used = alias_bytes;
+  const int ctx_bytes = (st.num_ctx + 7) & ~7;
+  const bool ctx_lds = used + ctx_bytes <= kModPoolBytes;
+  uint8_t *l_ctx = pool + used;
+  if (ctx_lds) used += ctx_bytes;
+  DevTreeNode *l_tree = (DevTreeNode *)(pool + used);
+  int ncache = (kModPoolBytes - used) / (int)sizeof(DevTreeNode);
+  if (ncache > st.count) ncache = st.count;
+  S.alias = alias_lds ? l_alias : st.ev.alias; S.alias_lds = alias_lds;
+  S.ctx_map = ctx_lds ? l_ctx : st.ev.ctx_map; S.ctx_lds = ctx_lds; S.ctx_off = (int32_t)(l_ctx - pool);
+  S.tree = l_tree; S.tree_ncache = ncache;
+  for (int i = tid; i < ncache; i += nthreads) l_tree[i] = st.tree[i];
   for (int i = tid; i < 64; i += nthreads) S.divlut[i] = (1u << 24) / (uint32_t)(i + 1);
-  if (st.num_ctx <= kLdsCtx) for (int i = tid; i < st.num_ctx; i += nthreads) S.ctx_map[i] = st.ev.ctx_map[i];
+  if (ctx_lds) for (int i = tid; i < st.num_ctx; i += nthreads) l_ctx[i] = st.ev.ctx_map[i];
   for (int i = tid; i < st.num_clusters && i < kLocMaxClusters; i += nthreads) S.cfg[i] = st.ev.cfg[i];
-  if (!st.ev.use_prefix && st.num_clusters <= kLdsClusters) {
+  if (alias_lds) {
     const int n = st.num_clusters << st.ev.log_alpha;
-    for (int i = tid; i < n; i += nthreads) S.alias[i] = st.ev.alias[i];
+    for (int i = tid; i < n; i += nthreads) l_alias[i] = st.ev.alias[i];
   }
 }
 
@@ -330,9 +353,9 @@ JXL_DEV uint32_t modular_stream_decode(DevModScratch &S, const DevChanOut *chans
   DevModStream &st = S.st;
   if (st.err) return st.err;
   DevECView ev = st.ev;
-  if (st.num_ctx <= kLdsCtx) ev.ctx_map = S.ctx_map;
+  ev.ctx_map = S.ctx_map;
   if (st.num_clusters <= kLocMaxClusters) ev.cfg = S.cfg;
-  if (!ev.use_prefix && st.num_clusters <= kLdsClusters) ev.alias = S.alias;
+  if (!ev.use_prefix) ev.alias = S.alias;
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
   uint32_t err = modular_decode_channels(ev, b, state, st.tree, st.count, st.wp, S, chans, nch, stream_id);

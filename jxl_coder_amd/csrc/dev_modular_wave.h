@@ -60,11 +60,11 @@ __device__ __forceinline__ void wave_tree_build(const DevTreeNode *tree, int cou
 template <bool kLds>
 __device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx) {
   if (!kLds) return ec_read(v, b, state, ctx);
-  const uint32_t cluster = S.ctx_map[ctx];
+  const uint32_t cluster = ((const uint8_t *)S.pool)[S.ctx_off + ctx];
   const int lb = 12 - v.log_alpha;
   const uint32_t res = state & 0xfff;
   const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
-  const DevAlias e = S.alias[(cluster << v.log_alpha) + i];
+  const DevAlias e = ((const DevAlias *)S.pool)[(cluster << v.log_alpha) + i];   // the alias tables open the pool
   const uint32_t cfg = S.cfg[cluster];
   const bool right = pos >= e.cutoff;
   const uint32_t sym = right ? e.right : i;
@@ -247,12 +247,12 @@ __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S,
   DevModStream &st = S.st;
   if (st.err) return st.err;
   DevECView ev = st.ev;
-  if (st.num_ctx <= kLdsCtx) ev.ctx_map = S.ctx_map;
+  ev.ctx_map = S.ctx_map;
   if (st.num_clusters <= kLocMaxClusters) ev.cfg = S.cfg;
-  if (!ev.use_prefix && st.num_clusters <= kLdsClusters) ev.alias = S.alias;
+  if (!ev.use_prefix) ev.alias = S.alias;
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
-  const bool lds = st.num_ctx <= kLdsCtx && st.num_clusters <= kLdsClusters && !ev.use_prefix;
+  const bool lds = S.ctx_lds && S.alias_lds && !ev.use_prefix;
   uint32_t err = lds ? modular_decode_channels_wave<true>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
                      : modular_decode_channels_wave<false>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
   __syncthreads();

@@ -129,7 +129,7 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
   // --- varblock placement: the next block goes to the first unoccupied cell in raster order.  Occupancy is a
   // bitmap in LDS (the alias-table area is free once the streams are decoded), scanned a 32-bit word at a time, so
   // the serial cost scales with the number of varblocks, not with the 65 536 cells.
-  uint32_t *occ = (uint32_t *)S.alias;                 // 256 rows x 8 words
+  uint32_t *occ = (uint32_t *)S.pool;                  // 256 rows x 8 words (8 KiB <= kModPoolBytes)
   for (int i = 0; i < 256 * 8; i++) occ[i] = 0;
   int num = 0;
   for (int y = 0; y < bh; y++) {

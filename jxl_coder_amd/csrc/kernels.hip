@@ -5,6 +5,7 @@
 //   k_recon_*    : dequant + chroma-from-luma + LLF + inverse var-size DCT, LDS-staged per varblock
 //   k_gab/k_epf  : loop filters, one thread per pixel;  k_write : XYB -> RGB -> RGBA8/16
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace jxlamd {
@@ -253,7 +254,10 @@ void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hi
 
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
-void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map); }
+void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) {
+  static const int pad = getenv("JXLAMD_LF_PAD_LDS") ? atoi(getenv("JXLAMD_LF_PAD_LDS")) : 0;   // experiment knob: extra dynamic LDS per LfGroup workgroup
+  hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), pad, s, Bs, As, map);
+}
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
