@@ -50,11 +50,11 @@ def cpu_baseline(data, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=768)
+    ap.add_argument("--steps", type=int, default=4096)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contexts", type=int, default=3, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
-    ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
+    ap.add_argument("--contexts", type=int, default=8, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
+    ap.add_argument("--inflight", type=int, default=128, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
 
     import torch

@@ -7,7 +7,9 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -20,6 +22,37 @@ using namespace jxlamd;
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); return JXLAMD_ERR_DEVICE; } } while (0)
 
 static thread_local std::string g_tls_error;
+
+// Stage gates (optional): decoder contexts of one process (one HIP stream each) decode flights concurrently and their
+// stages may collide (several contexts in the slot-limited LF stage, then several in the throughput-bound
+// reconstruction stage).  JXLAMD_STAGE_GATES="lf,pass,rest" installs a counting gate per stage and device that admits
+// a bounded number of flights into each stage (0 = unlimited, the default: on MI355X every setting tried landed within
+// the run-to-run noise of the ungated pipeline once the data-parallel kernels stopped starving for registers).
+struct StageGate {
+  std::mutex m; std::condition_variable cv; int in_use = 0, limit = 0;
+  void acquire() { if (limit <= 0) return; std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return in_use < limit; }); in_use++; }
+  void release() { if (limit <= 0) return; { std::lock_guard<std::mutex> l(m); in_use--; } cv.notify_one(); }
+};
+struct StageGates { StageGate g[3]; };
+static StageGates &stage_gates(int device) {
+  static std::mutex m; static std::vector<StageGates *> all;
+  std::lock_guard<std::mutex> l(m);
+  if ((int)all.size() <= device) all.resize((size_t)device + 1, nullptr);
+  if (!all[(size_t)device]) {
+    StageGates *G = new StageGates();
+    int lim[3] = {0, 0, 0};        // default: no admission control (measured within noise of the best gate settings)
+    if (const char *e = getenv("JXLAMD_STAGE_GATES")) (void)sscanf(e, "%d,%d,%d", &lim[0], &lim[1], &lim[2]);
+    for (int i = 0; i < 3; i++) G->g[i].limit = lim[i];
+    all[(size_t)device] = G;
+  }
+  return *all[(size_t)device];
+}
+struct GateHold {                  // RAII: leaves the gate on every exit path
+  StageGate *g = nullptr;
+  void enter(StageGate &x) { leave(); x.acquire(); g = &x; }
+  void leave() { if (g) { g->release(); g = nullptr; } }
+  ~GateHold() { leave(); }
+};
 
 struct DevMem {
   void *p = nullptr; size_t cap = 0;
@@ -49,9 +82,10 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-struct FrameSlot {             // HBM work buffers of one in-flight frame
+struct FrameSlot {
+  bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};             // HBM work buffers of one in-flight frame
   PinnedMem h_tables, h_cs;
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, big_list[2];
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, big_list[3];
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -76,7 +110,7 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab;
+  DevMem stat, batch_tab, plane_pool;     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
@@ -86,7 +120,7 @@ struct jxlamd_decoder {
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
 
   int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
-              bool parsed = false);
+              bool parsed = false, bool own_planes = true);
   int finish_single_section(FrameSlot &S);
   int launch_rest(FrameSlot &S);
   int launch_modular(FrameSlot &S);
@@ -129,7 +163,7 @@ static int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstre
 
 // host parse + buffers + H2D + clears for one frame (everything before the first kernel)
 int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
-                            bool parsed) {
+                            bool parsed, bool own_planes) {
   FramePlan &plan = S.plan;
   if (!parsed) { plan = FramePlan(); (void)plan_parse(jxl, size, &plan); }
   if (!plan.error.empty() || plan.tables.empty()) { set_error(plan.error); return err_class(plan.error); }
@@ -168,12 +202,13 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
     HIPCHECK(S.coef_off.ensure(ncell * 4));
     for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
-    for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));
+    if (own_planes) for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));   // flights borrow sets of the decoder's plane pool instead
     HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
     HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
     HIPCHECK(S.pass_nz.ensure((size_t)plan.num_groups * 3072));
     HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
     HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
+    HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
   } else {
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
@@ -193,13 +228,22 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
   B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p;
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out; B.out_bits = (int32_t)S.pi.out_bits;
-  B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
+  B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   if (!plan.modular) {
     HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
-    for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, (size_t)plan.num_groups * 65536 * 4, stream));
+    // The reconstruction kernels clear every coefficient they consume, so a slot whose previous decode completed is
+    // already all-zero; only fresh / regrown / failed slots are cleared here.
+    const size_t coef_bytes = (size_t)plan.num_groups * 65536 * 4;
+    const bool clean = S.coef_clean && S.coef_clean_bytes >= coef_bytes && S.coef_clean_ptr[0] == B.coef[0] && S.coef_clean_ptr[1] == B.coef[1] &&
+                       S.coef_clean_ptr[2] == B.coef[2];
+    static const bool force_clear = getenv("JXLAMD_FORCE_COEF_MEMSET") != nullptr;   // A/B knob
+    if (!clean || force_clear) for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, S.coef[c].cap, stream));
+    S.coef_clean = false;                              // until collect() has seen this decode succeed
+    for (int c = 0; c < 3; c++) S.coef_clean_ptr[c] = B.coef[c];
+    S.coef_clean_bytes = std::min(std::min(S.coef[0].cap, S.coef[1].cap), S.coef[2].cap);
   }
   return JXLAMD_OK;
 }
@@ -248,6 +292,7 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   HIPCHECK(hipGetLastError());
   (void)flags;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
+  S.coef_clean = !S.plan.modular;
   return JXLAMD_OK;
 }
 
@@ -302,7 +347,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
-                     outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true);
+                     outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
+                     /*own_planes=*/S.plan.modular || S.plan.single_section);
     if (rc) return rc;
     if (S.plan.modular) { launch_modular(S); rc = collect(S, flags); if (rc) return rc; continue; }
     if (S.plan.single_section) {
@@ -316,9 +362,17 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   }
   if (batched.empty()) return JXLAMD_OK;
   // device tables of the batch: DevBuffers[], DevAux[], (frame, local index) per block for both entropy kernels
+  // The f32 working planes (6 per frame, 200 MB at 4K) are only alive from reconstruction to the writer, and those
+  // stages run in sub-batches of plane_sets frames: the flight shares plane_sets sets instead of owning one each.
+  static const int plane_sets = getenv("JXLAMD_PLANE_SETS") ? std::max(1, atoi(getenv("JXLAMD_PLANE_SETS"))) : 16;
+  size_t max_npx = 0;
+  for (int i : batched) max_npx = std::max(max_npx, (size_t)slot((size_t)i).plan.xb * slot((size_t)i).plan.yb * 64);
+  HIPCHECK(plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
   std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map;
   for (size_t k = 0; k < batched.size(); k++) {
     FrameSlot &S = slot((size_t)batched[k]);
+    float *set = (float *)plane_pool.p + (k % (size_t)plane_sets) * 6 * max_npx;
+    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; }
     hb.push_back(S.B); ha.push_back(S.A);
     for (int g = 0; g < S.plan.num_lf_groups; g++) { lf_map.push_back((int)k); lf_map.push_back(g); }
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back((int)k); pg_map.push_back(g); }
@@ -333,9 +387,14 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
   memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
   HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
+  StageGates &gates = stage_gates(device);
+  GateHold gate;
+  gate.enter(gates.g[0]);
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
+  HIPCHECK(hipEventSynchronize(ev[1]));
+  gate.enter(gates.g[1]);
   int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 1 << 4;
   for (int i : batched) {
     const FrameSlot &S = slot((size_t)i);
@@ -352,10 +411,15 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   if ((int)pg_map.size() / 2 >= simt_min_groups) launch_pass_groups_simt((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
   else launch_pass_groups_batch((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[2], stream));
-  launch_rest_batch((const DevBuffers *)(bt + o_b), (const uint8_t *)stat.p, (int)batched.size(), max_cells, max_w, max_h, stage_mask, stream);
+  HIPCHECK(hipEventSynchronize(ev[2]));
+  gate.enter(gates.g[2]);
+  for (int k0 = 0; k0 < (int)batched.size(); k0 += plane_sets)
+    launch_rest_batch((const DevBuffers *)(bt + o_b) + k0, (const uint8_t *)stat.p, std::min(plane_sets, (int)batched.size() - k0), max_cells, max_w, max_h,
+                      stage_mask, stream);
   HIPCHECK(hipEventRecord(ev[4], stream));
   int first_rc = JXLAMD_OK;
   for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }
+  gate.leave();
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
   return first_rc;
@@ -382,7 +446,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->h_batch.release();
+  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);

@@ -59,7 +59,8 @@ JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int 
 }
 
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]
-template <bool kSpecial, class Sync>     // kSpecial: the 8x8 special transforms can occur (small-block launch only)
+// kSpecial: the 8x8 special transforms can occur (small-block launch only); kPerChannel: S holds ONE channel (LDS: S[n] + T[n])
+template <bool kSpecial, bool kPerChannel = false, class Sync>
 JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int nmin, int nmax,
                               int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
@@ -71,12 +72,26 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   const int n = cx * cy * 64;
   if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock | kErrStageRecon; return; }   // DCT128+/256
   if (n < nmin || n > nmax) return;                 // another size class' launch handles it
+  float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};
+  const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
+  if (kPerChannel) {
+    const int R = cy * 8, C = cx * 8;
+    for (int c = 0; c < 3; c++) {
+      recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads, c);
+      sync();
+      recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads, c);
+      sync();
+      recon_idct_pass1(stat, ST, S, T, R, C, tid, nthreads);
+      sync();
+      recon_idct_pass2(stat, ST, T, dst[c] + po, F.pw, R, C, tid, nthreads);
+      sync();
+    }
+    return;
+  }
   recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();
   recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();
-  float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};
-  const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
   if (kSpecial && strategy_is_special(st)) {
     for (int c = tid; c < 3; c += nthreads) recon_special(stat, ST, st, S + c * n, dst[c] + po, F.pw);
     return;

@@ -43,8 +43,9 @@ JXL_DEV void lf_smooth_cell(const DevBuffers &B, int x, int y) {
 // ------------------------------------------------------------------ varblock reconstruction
 // LDS layout for one varblock: S[3][n] dequantised coefficients (storage layout), T[n] scratch.
 // Phase A (tid over n): dequant + CfL.  Phase B: LLF from LF.  Phase C/D per channel: two 1-D passes.
+// only_c < 0: all three channels into S[3][n]; only_c = 0..2: that channel alone into S[n] (large blocks, LDS diet)
 JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, int n, int bx, int by,
-                          int tid, int nthreads) {
+                          int tid, int nthreads, int only_c = -1) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
   const int st = B.strategy[o];
@@ -58,7 +59,13 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
   for (int k = tid; k < n; k += nthreads) {
     float v[3];
     for (int c = 0; c < 3; c++) {
-      int q = B.coef[c][(size_t)g * 65536 + off + (uint32_t)k];
+      if (only_c >= 0 && c != 1 && c != only_c) { v[c] = 0.0f; continue; }
+      int32_t *qp = &B.coef[c][(size_t)g * 65536 + off + (uint32_t)k];
+      const int q = *qp;
+      // Each coefficient is consumed exactly once: the last reader clears it, which leaves the frame slot's coefficient
+      // planes all-zero for the next frame (no 106 MB memset per 4K frame).  With only_c the Y channel is read by all
+      // three per-channel rounds; the last one (only_c == 2) clears it.
+      if (q != 0 && (only_c < 0 || (c != 1 && c == only_c) || (c == 1 && only_c == 2))) *qp = 0;
       float a;
       if (q == 0) a = 0.0f;
       else if (q == 1) a = F.quant_bias[c];
@@ -66,6 +73,7 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
       else a = (float)q - F.quant_bias[3] / (float)q;
       v[c] = a * (mul * F.dm[c] * st_f(stat, ST.qw_off[qt][c])[k]);
     }
+    if (only_c >= 0) { S[k] = only_c == 0 ? v[0] + kx * v[1] : only_c == 1 ? v[1] : v[2] + kb * v[1]; continue; }
     S[k] = v[0] + kx * v[1];
     S[n + k] = v[1];
     S[2 * n + k] = v[2] + kb * v[1];
@@ -73,17 +81,18 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
 }
 
 JXL_DEV void recon_phaseB(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, int n, int bx, int by,
-                          int tid, int nthreads) {
+                          int tid, int nthreads, int only_c = -1) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
   const int st = B.strategy[o];
   const int cx = kCoveredX[st], cy = kCoveredY[st];
   const int srows = cy < cx ? cy : cx, scols = cy < cx ? cx : cy;
-  const int total = 3 * cx * cy;
+  const int total = (only_c >= 0 ? 1 : 3) * cx * cy;
   const float *ccx = st_f(stat, ST.cos_off[ilog2(cx)]), *ccy = st_f(stat, ST.cos_off[ilog2(cy)]);
   const float *lsx = st_f(stat, ST.llf_off) + 32 * ilog2(cx), *lsy = st_f(stat, ST.llf_off) + 32 * ilog2(cy);
   for (int i = tid; i < total; i += nthreads) {
-    const int c = i / (cx * cy), r = i - c * cx * cy;
+    const int ci = i / (cx * cy), r = i - ci * cx * cy;
+    const int c = only_c >= 0 ? only_c : ci;
     const int a = r / scols, b = r - a * scols;       // storage position
     const int u = cy >= cx ? a : b, v = cy >= cx ? b : a;   // horizontal / vertical frequency
     float s = 0.0f;
@@ -93,7 +102,7 @@ JXL_DEV void recon_phaseB(const DevBuffers &B, const uint8_t *stat, const DevSta
       s += rs * ccy[v * cy + iy];
     }
     s *= (1.0f / (float)(cx * cy)) * lsx[u] * lsy[v];
-    S[c * n + a * scols * 8 + b] = s;
+    S[ci * n + a * scols * 8 + b] = s;
   }
   (void)srows;
 }
@@ -241,59 +250,89 @@ JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y
   return 1.0f / sigma;
 }
 
-JXL_DEV void epf_pixel(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int pass, int x, int y) {
+// kInterior: every tap lies inside the image (x, y at least 3 pixels from each edge): plain indexing, which also lets the
+// compiler share the overlapping loads of the 5-pixel SAD patterns; the border version mirrors every coordinate.
+// kPass: 0 = the 12-tap first iteration, 1 = 4 taps with the 5-pixel SAD, 2 = 4 taps with the 1-pixel SAD.
+template <bool kInterior, int kPass>
+JXL_DEV void epf_pixel_t(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
   const int w = F.width, h = F.height, pw = F.pw;
   const size_t po = (size_t)y * (size_t)pw + (size_t)x;
   const float is = epf_inv_sigma(B, F, x, y);
   if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) dst[c][po] = src[c][po]; return; }
-  const float sm = 1.65f * (pass == 0 ? F.epf_pass0 : pass == 2 ? F.epf_pass2 : 1.0f);
+  const float sm = 1.65f * (kPass == 0 ? F.epf_pass0 : kPass == 2 ? F.epf_pass2 : 1.0f);
   const bool border = ((y & 7) == 0 || (y & 7) == 7 || (x & 7) == 0 || (x & 7) == 7);
   const float isig = is * (border ? sm * F.epf_border_sad : sm);
-  const int px[5] = {0, 0, -1, 1, 0}, py[5] = {0, -1, 0, 0, 1};
-  const int t0x[12] = {0, -1, 0, 1, -2, -1, 1, 2, -1, 0, 1, 0}, t0y[12] = {-2, -1, -1, -1, 0, 0, 0, 0, 1, 1, 1, 2};
-  const int t1x[4] = {0, -1, 1, 0}, t1y[4] = {-1, 0, 0, 1};
-  const int ntaps = pass == 0 ? 12 : 4;
-  #define PX(c, yy, xx) src[c][(size_t)mirror((yy), h) * (size_t)pw + (size_t)mirror((xx), w)]
+  constexpr int px[5] = {0, 0, -1, 1, 0}, py[5] = {0, -1, 0, 0, 1};
+  constexpr int t0x[12] = {0, -1, 0, 1, -2, -1, 1, 2, -1, 0, 1, 0}, t0y[12] = {-2, -1, -1, -1, 0, 0, 0, 0, 1, 1, 1, 2};
+  constexpr int t1x[4] = {0, -1, 1, 0}, t1y[4] = {-1, 0, 0, 1};
+  constexpr int ntaps = kPass == 0 ? 12 : 4;
+  #define PX(c, dy, dx) (kInterior ? src[c][(int64_t)po + (int64_t)(dy) * (int64_t)pw + (int64_t)(dx)] \
+                                   : src[c][(size_t)mirror(y + (dy), h) * (size_t)pw + (size_t)mirror(x + (dx), w)])
   float wsum = 1.0f, acc[3];
   for (int c = 0; c < 3; c++) acc[c] = src[c][po];
+#ifdef __HIPCC__
+  #pragma unroll
+#endif
   for (int t = 0; t < ntaps; t++) {
-    const int tx = pass == 0 ? t0x[t] : t1x[t], ty = pass == 0 ? t0y[t] : t1y[t];
+    const int tx = kPass == 0 ? t0x[t] : t1x[t], ty = kPass == 0 ? t0y[t] : t1y[t];
     float sad = 0.0f;
-    if (pass == 2) {
-      for (int c = 0; c < 3; c++) sad += fabsf(src[c][po] - PX(c, y + ty, x + tx)) * F.epf_chscale[c];
+    if (kPass == 2) {
+      for (int c = 0; c < 3; c++) sad += fabsf(src[c][po] - PX(c, ty, tx)) * F.epf_chscale[c];
     } else {
       for (int c = 0; c < 3; c++) {
         float sc = 0.0f;
-        for (int k = 0; k < 5; k++) sc += fabsf(PX(c, y + py[k], x + px[k]) - PX(c, y + ty + py[k], x + tx + px[k]));
+#ifdef __HIPCC__
+        #pragma unroll
+#endif
+        for (int k = 0; k < 5; k++) sc += fabsf(PX(c, py[k], px[k]) - PX(c, ty + py[k], tx + px[k]));
         sad += sc * F.epf_chscale[c];
       }
     }
     float wgt = 1.0f + sad * isig;
     if (wgt < 0.0f) wgt = 0.0f;
     wsum += wgt;
-    for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, y + ty, x + tx);
+    for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, ty, tx);
   }
   #undef PX
   const float inv = 1.0f / wsum;
   for (int c = 0; c < 3; c++) dst[c][po] = acc[c] * inv;
 }
+template <int kPass>
+JXL_DEV void epf_pixel_p(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
+  if (x >= 3 && y >= 3 && x + 3 < F.width && y + 3 < F.height) epf_pixel_t<true, kPass>(B, F, src, dst, x, y);
+  else epf_pixel_t<false, kPass>(B, F, src, dst, x, y);
+}
+JXL_DEV void epf_pixel(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int pass, int x, int y) {
+  if (pass == 0) epf_pixel_p<0>(B, F, src, dst, x, y);
+  else if (pass == 1) epf_pixel_p<1>(B, F, src, dst, x, y);
+  else epf_pixel_p<2>(B, F, src, dst, x, y);
+}
 
 // ------------------------------------------------------------------ XYB -> RGB -> RGBA writer (one pixel)
+// a^e for a >= 0: on the GPU two transcendental instructions (v_log_f32 / v_exp_f32, ~1 ulp each: the result moves
+// by < 1e-6 relative, far below half an 8-bit or 16-bit step); the CPU harness uses libm.
+JXL_DEV float pow_pos(float a, float e) {
+#ifdef __HIPCC__
+  return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(a));
+#else
+  return powf(a, e);
+#endif
+}
 JXL_DEV float tf_srgb(float v) {
   float a = fabsf(v);
-  float r = a <= 0.0031308f ? 12.92f * a : 1.055f * powf(a, 1.0f / 2.4f) - 0.055f;
+  float r = a <= 0.0031308f ? 12.92f * a : 1.055f * pow_pos(a, 1.0f / 2.4f) - 0.055f;
   return v < 0 ? -r : r;
 }
 JXL_DEV float tf_pq(float v, float intensity_target) {
   float a = fabsf(v) * (intensity_target * 1e-4f);
   const float m1 = 2610.0f / 16384, m2 = 2523.0f / 4096 * 128, c1 = 3424.0f / 4096, c2 = 2413.0f / 4096 * 32, c3 = 2392.0f / 4096 * 32;
-  float p = powf(a, m1);
-  float r = powf((c1 + c2 * p) / (1 + c3 * p), m2);
+  float p = pow_pos(a, m1);
+  float r = pow_pos((c1 + c2 * p) / (1 + c3 * p), m2);
   return v < 0 ? -r : r;
 }
 JXL_DEV float tf_709(float v) {
   float a = fabsf(v);
-  float r = a < 0.018f ? 4.5f * a : 1.099f * powf(a, 0.45f) - 0.099f;
+  float r = a < 0.018f ? 4.5f * a : 1.099f * pow_pos(a, 0.45f) - 0.099f;
   return v < 0 ? -r : r;
 }
 
@@ -310,7 +349,7 @@ JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const Dev
       case 13: lin = tf_srgb(lin); break;
       case 16: lin = tf_pq(lin, F.intensity_target); break;
       case 1: lin = tf_709(lin); break;
-      case -1: { float a = powf(fabsf(lin), F.gamma); lin = lin < 0 ? -a : a; } break;
+      case -1: { float a = pow_pos(fabsf(lin), F.gamma); lin = lin < 0 ? -a : a; } break;
       default: break;   // 8 = linear
     }
     v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;

@@ -30,8 +30,8 @@ struct DevBuffers {
   LocalTreeScratch *local;      // [max(num_lf_groups, num_groups)]: local MA trees / histograms parsed on the device
   int32_t *mod_pool;            // Modular-encoded frames: int32 channel planes (DevFrame::mod_plane_off)
   int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
-  uint32_t *big_list[2];        // cell indices of the varblocks with 512..1024 / 2048..4096 coefficients (filled at placement)
-  uint32_t *big_count;          // [2] their counts
+  uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
+  uint32_t *big_count;          // [3] their counts
   uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
@@ -159,8 +159,8 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
         }
         B.first[o] = 1;
         const int ncoef = cx * cy * 64;
-        if (ncoef > 256 && ncoef <= 4096) {      // remember the large varblocks: their reconstruction kernels walk these lists
-          const int cls = ncoef <= 1024 ? 0 : 1;
+        if (ncoef <= 4096) {                     // size-class lists: the reconstruction kernels walk them
+          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
 #ifdef __HIPCC__
           const uint32_t slot = atomicAdd(&B.big_count[cls], 1u);
 #else

@@ -6,6 +6,7 @@
 //   k_gab/k_epf  : loop filters, one thread per pixel;  k_write : XYB -> RGB -> RGBA8/16
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
 #include <stdlib.h>
+#include <algorithm>
 #include "kernels.h"
 
 namespace jxlamd {
@@ -23,14 +24,16 @@ __global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
 }
 
 // batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
-__global__ void __launch_bounds__(64) k_lf_group_batch(const DevBuffers *Bs, const DevAux *As, const int *map) {
+__global__ void __launch_bounds__(64) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map) {
   __shared__ DevModScratch S;
-  const int f = map[2 * blockIdx.x], g = map[2 * blockIdx.x + 1];
+  // readfirstlane: the frame index is wave-uniform, so the DevBuffers fields come through scalar loads into SGPRs
+  // (as with the by-value kernel argument of k_lf_group) instead of occupying ~60 VGPRs
+  const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   lf_group_body(Bs[f], As[f], S, g, (int)threadIdx.x, 64, SyncBlock());
 }
 __global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, const int *map) {
   __shared__ DevPassScratch S;
-  const int f = map[2 * blockIdx.x], g = map[2 * blockIdx.x + 1];
+  const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   pass_group_body(Bs[f], S, g, (int)threadIdx.x, 64, SyncBlock());
 }
 
@@ -55,13 +58,17 @@ __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb)
 
 // Varblock reconstruction in three size classes so that the LDS budget (and with it the occupancy) fits the block:
 //   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
-//   medium (512, 1024):            256 threads, 16 KiB LDS, walks the list of such blocks recorded at placement
-//   large  (2048, 4096):           256 threads, 64 KiB LDS, walks its list
+//   medium (512, 1024):            256 threads, 28 KiB LDS, walks the list of such blocks recorded at placement
+//   large  (2048, 4096):           256 threads, 32 KiB LDS (one channel at a time), walks its list
 __global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t *stat, int xb) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
-  int cell = (int)blockIdx.x;
-  recon_block_body<true>(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  const uint32_t count = B.big_count[2];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[2][i];
+    __syncthreads();
+    recon_block_body<true>(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  }
 }
 // medium / large varblocks: the placement step recorded their cells; a fixed-size grid walks the list.
 //
@@ -72,10 +79,10 @@ __global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t 
 // 12 FMAs per 4 LDS reads instead of 1 FMA per (LDS + global) read of the generic path.
 constexpr int kStrategyDct32 = 5;
 template <int NMAX>
-struct ReconLds {
-  float S[3 * NMAX];
+struct ReconLds {                       // medium: S[3][1024] T[3][1024] CC (28 KiB); large: one channel at a time, S[4096] T[4096] (32 KiB)
+  float S[NMAX > 1024 ? NMAX : 3 * NMAX];
   float T[NMAX > 1024 ? NMAX : 3 * 1024];
-  float CC[1024];
+  float CC[NMAX > 1024 ? 4 : 1024];
 };
 
 __device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
@@ -139,7 +146,7 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
       recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
     } else {
       __syncthreads();
-      recon_block_body<false>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
+      recon_block_body<false, (NMAX > 1024)>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
     }
   }
 }
@@ -215,9 +222,13 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
   __shared__ float T[256];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
-  const int cell = (int)blockIdx.x;
-  if (F.is_modular || cell >= F.xb * F.yb) return;
-  recon_block_body<true>(B, stat, S, T, cell % F.xb, cell / F.xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  if (F.is_modular) return;
+  const uint32_t count = B.big_count[2];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[2][i];
+    __syncthreads();
+    recon_block_body<true>(B, stat, S, T, cell % F.xb, cell / F.xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  }
 }
 template <int NMIN, int NMAX>
 __global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls) {
@@ -226,27 +237,34 @@ __global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, cons
   if (F.is_modular) return;
   recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb);
 }
-__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int stage) {
+// One instantiation per stage (0 = Gaborish, 1..3 = EPF iterations 0..2, 4 = XYB -> RGBA writer): the writer needs 14
+// VGPRs and Gaborish 48, so they must not inherit the unrolled EPF's register footprint — these kernels share the
+// SIMDs with resident entropy-decode waves, and their occupancy is what is left of the register file.
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
-  if (F.is_modular || !stage_runs(F, stage)) return;
+  if (F.is_modular || !stage_runs(F, STAGE)) return;
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   if (x >= F.width || y >= F.height) return;
-  const bool a = stage_src_is_a(F, stage);
+  const bool a = stage_src_is_a(F, STAGE);
   float *src[3], *dst[3];
   for (int c = 0; c < 3; c++) { src[c] = a ? B.plane_a[c] : B.plane_b[c]; dst[c] = a ? B.plane_b[c] : B.plane_a[c]; }
-  if (stage == 0) gab_pixel(F, src, dst, x, y);
-  else if (stage <= 3) epf_pixel(B, F, src, dst, stage - 1, x, y);
+  if (STAGE == 0) gab_pixel(F, src, dst, x, y);
+  else if (STAGE <= 3) epf_pixel_p<(STAGE >= 1 && STAGE <= 3 ? STAGE - 1 : 0)>(B, F, src, dst, x, y);
   else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
 }
 
 void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, hipStream_t s) {
-  hipLaunchKernelGGL(k_recon_small_b, dim3(max_cells, 1, nframes), dim3(64), 0, s, Bs, stat);
+  hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
   hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(256, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
   hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(64, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
-  for (int stage = 0; stage <= 4; stage++)
-    if (stage_mask & (1 << stage)) hipLaunchKernelGGL(k_filter_b, grid, dim3(256), 0, s, Bs, stat, stage);
+  if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat);
+  if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat);
+  if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat);
+  if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat);
+  if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat);
 }
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth_b, dim3((max_cells + 255) / 256, 1, nframes), dim3(256), 0, s, Bs);
@@ -264,7 +282,7 @@ void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B, xb, yb);
 }
 void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s) {
-  hipLaunchKernelGGL(k_recon_small, dim3(xb * yb), dim3(64), 0, s, B, stat, xb);
+  hipLaunchKernelGGL(k_recon_small, dim3(std::min(xb * yb, 8192)), dim3(64), 0, s, B, stat, xb);
   hipLaunchKernelGGL((k_recon_list<257, 1024>), dim3(2048), dim3(256), 0, s, B, stat, 0, xb);
   hipLaunchKernelGGL((k_recon_list<1025, 4096>), dim3(512), dim3(256), 0, s, B, stat, 1, xb);
 }

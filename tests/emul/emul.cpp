@@ -35,7 +35,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   std::vector<float> pl[6]; for (auto &v : pl) v.assign(npx, 0.f);
   std::vector<int32_t> scr((size_t)plan.num_lf_groups * kLfScratchInts, 0);
   std::vector<uint64_t> endbits((size_t)plan.num_lf_groups, 0);
-  std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16); uint32_t bcount[2] = {0, 0};
+  std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16), bl2(ncell + 16); uint32_t bcount[3] = {0, 0, 0};
   uint32_t err = 0;
   std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
   DevBuffers B; memset(&B, 0, sizeof(B));
@@ -48,7 +48,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   std::vector<LocalTreeScratch> loc((size_t)(plan.modular ? (plan.num_groups > 1 ? plan.num_groups : 1) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr(plan.modular ? (size_t)plan.num_groups * kModGroupScratchInts : 1, 0);
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
-  B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_count = bcount;
+  B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_list[2] = bl2.data(); B.big_count = bcount;
   DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
   const std::vector<uint8_t> &stat = static_tables();
   if (plan.modular) {
@@ -77,7 +77,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     int hist[32] = {0};
     for (size_t o = 0; o < ncell; o++) if (B.first[o]) hist[B.strategy[o] & 31]++;
     for (int i = 0; i < 27; i++) if (hist[i]) fprintf(stderr, "strategy %d (%dx%d cells): %d blocks\n", i, kCoveredX[i], kCoveredY[i], hist[i]);
-    fprintf(stderr, "big lists: %u medium, %u large\n", bcount[0], bcount[1]);
+    fprintf(stderr, "lists: %u medium, %u large, %u small\n", bcount[0], bcount[1], bcount[2]);
   }
   if (getenv("JXLEMUL_SIMT_PASS")) {       // exercise the lane-per-stream PassGroup code (one lane at a time)
     for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane(B, kCoeffFreqContext, kCoeffNumNonzeroContext, B.pass_nz + (size_t)g * 3072, g); if (e) err |= e; }
@@ -87,7 +87,10 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   if (err) { g_err = "device flags " + std::to_string(err) + " (PassGroup)"; return -2; }
   std::vector<float> S(3 * 4096), T(4096);
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
-    recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());
+    if (getenv("JXLEMUL_SIMT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
+      recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
+      recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
+    } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());
   }
   if (err) { g_err = "device flags " + std::to_string(err) + " (recon)"; return -2; }
   const DevFrame &F = *(const DevFrame *)tables.data();

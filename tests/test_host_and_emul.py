@@ -79,6 +79,17 @@ def test_device_code_on_cpu_harness(emul, oracle, name):
     assert d2.max() <= 1 and (d2 > 0).mean() < 1e-3      # same algorithm, different summation order
 
 
+@pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3"])
+def test_alternate_device_paths_give_identical_pixels(emul, monkeypatch, name):
+    """The lane-per-stream PassGroup decoder (k_pass_group_simt) and the one-channel-at-a-time reconstruction of the
+    large varblocks (k_recon_list<1025,4096>) must reproduce the default paths bit for bit."""
+    data, _ = load_case(name)
+    base = emul(data)
+    monkeypatch.setenv("JXLEMUL_SIMT_PASS", "1")
+    alt = emul(data)
+    assert np.array_equal(base, alt)
+
+
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
     data, _ = load_case("l64_e1")
     with pytest.raises(ValueError, match="unsupported"):
