@@ -231,9 +231,10 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
-  HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
+  const bool in_flight = !own_planes;                 // frames of a batched flight: one k_clear_b launch clears these for all of them
+  if (!in_flight) HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   if (!plan.modular) {
-    HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
+    if (!in_flight) HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
     // The reconstruction kernels clear every coefficient they consume, so a slot whose previous decode completed is
     // already all-zero; only fresh / regrown / failed slots are cleared here.
     const size_t coef_bytes = (size_t)plan.num_groups * 65536 * 4;
@@ -391,6 +392,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   GateHold gate;
   gate.enter(gates.g[0]);
   HIPCHECK(hipEventRecord(ev[0], stream));
+  { int mc = 0; for (int i : batched) mc = std::max(mc, slot((size_t)i).plan.xb * slot((size_t)i).plan.yb);
+    launch_clear_batch((const DevBuffers *)(bt + o_b), (int)batched.size(), mc, stream); }
   launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   HIPCHECK(hipEventSynchronize(ev[1]));

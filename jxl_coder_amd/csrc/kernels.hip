@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
 }
 
 // batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
-__global__ void __launch_bounds__(64) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map) {
   __shared__ DevModScratch S;
   // readfirstlane: the frame index is wave-uniform, so the DevBuffers fields come through scalar loads into SGPRs
   // (as with the by-value kernel argument of k_lf_group) instead of occupying ~60 VGPRs
@@ -265,6 +265,25 @@ void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, i
   if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat);
   if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat);
   if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat);
+}
+// one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
+__global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular) return;
+  if (blockIdx.x == 0) {
+    uint32_t *m = B.err;                                   // misc block: 4096 bytes of flags + 72 bytes per LF group
+    const int words = (4096 + F.num_lf_groups * 72) / 4;
+    for (int i = (int)threadIdx.x; i < words; i += 256) m[i] = 0;
+    return;
+  }
+  const int ncell = F.xb * F.yb;
+  const int i = (int)((blockIdx.x - 1) * 256 + threadIdx.x) * 16;
+  if (i + 16 <= ncell) { uint4 z = {0, 0, 0, 0}; *(uint4 *)(B.first + i) = z; }       // cell arrays are 256-byte aligned allocations
+  else for (int k = i; k < ncell; k++) B.first[k] = 0;
+}
+void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_clear_b, dim3((max_cells + 4095) / 4096 + 1, 1, nframes), dim3(256), 0, s, Bs);
 }
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth_b, dim3((max_cells + 255) / 256, 1, nframes), dim3(256), 0, s, Bs);
