@@ -93,6 +93,49 @@ int jxlamd_last_timing(const jxlamd_decoder *dec, float ms[5]);
  * [5] varblocks placed, [6] epilogue done. */
 int jxlamd_debug_lf_phases(jxlamd_decoder *dec, int num_lf_groups, uint64_t *out);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Post-decode stages of the reference's JNI layer, on buffers that stay in HBM.
+ * They run after jxlamd_decode*(…, JXLAMD_OUT_DEVICE) in the reference's order (cpp/JniDecoding.cpp:45-331):
+ *   [A8 ICC, A9 rescale: not here]  ->  A10 jxlamd_color_matrix  ->  A11 jxlamd_reformat.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* PreferredColorConfig, the reference's values (cpp/Support.h:37-44, kt/PreferredColorConfig.kt) */
+enum { JXLAMD_CFG_DEFAULT = 1, JXLAMD_CFG_RGBA_8888 = 2, JXLAMD_CFG_RGBA_F16 = 3, JXLAMD_CFG_RGB_565 = 4, JXLAMD_CFG_RGBA_1010102 = 5,
+       JXLAMD_CFG_HARDWARE = 6 };
+/* pixel layout of a reformatted buffer */
+enum { JXLAMD_FMT_RGBA_8888 = 1, JXLAMD_FMT_RGBA_F16 = 2, JXLAMD_FMT_RGB_565 = 3, JXLAMD_FMT_RGBA_1010102 = 4 };
+
+typedef struct jxlamd_reformat_info {
+  uint32_t stride;            /* bytes per row of the destination (64-byte aligned rows for F16-from-u8 / 565 / 1010102, ReformatBitmap.cpp:105-107) */
+  uint32_t format;            /* JXLAMD_FMT_* */
+  uint32_t use_floats;        /* the reference's *useFloats after the stage */
+  uint32_t resolved_config;   /* DEFAULT resolved as ReformatBitmap.cpp:52-63 does (needs the Android API level) */
+  uint64_t bytes;             /* stride * height */
+} jxlamd_reformat_info;
+
+/* Destination geometry of jxlamd_reformat for a decoded w x h RGBA8 (src_is_u16 = 0) or RGBA16 (1) image.
+ * Replaces the sizing logic of ReformatColorConfig (cpp/ReformatBitmap.cpp:46-263). */
+int jxlamd_reformat_query(uint32_t w, uint32_t h, int src_is_u16, int color_config, int has_alpha_in_origin, int api_level,
+                          jxlamd_reformat_info *out);
+
+/* ReformatColorConfig (cpp/ReformatBitmap.cpp:46-263) on device buffers: premultiplies src IN PLACE when
+ * !alpha_premultiplied && has_alpha_in_origin (imagebit/RGBAlpha.cpp:67-117), then converts into dst
+ * (imagebit/RgbaU16toHF.cpp, Rgba8ToF16.cpp, Rgba16.cpp, Rgb565.cpp, Rgb1010102.cpp — including the reference's second
+ * attenuation of u8 sources when !alpha_premultiplied).  src rows are tight (w*4 or w*8 bytes, what jxlamd_decode writes).
+ * depth = the bitDepth DecodeJpegXlOneShot reports (8 or 16). */
+int jxlamd_reformat(jxlamd_decoder *dec, void *src_dev, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int color_config,
+                    int alpha_premultiplied, int has_alpha_in_origin, int api_level, void *dst_dev, size_t dst_capacity,
+                    jxlamd_reformat_info *out);
+
+/* applyColorMatrix / applyColorMatrix16Bit (cpp/colorspaces/ColorMatrix.cpp:35-219) with the set-up of the call site
+ * (cpp/JniDecoding.cpp:138-228): linearise with the image's transfer function, Rec.2408 tone map for PQ / HLG
+ * (colorspaces/Rec2408ToneMapper.cpp:80-100), source primaries -> Rec.709, sRGB OETF; in place, alpha untouched.
+ * primaries / transfer_function: jxlamd_info values; xy8 = {rx,ry,gx,gy,bx,by,wx,wy} for custom primaries (may be NULL otherwise).
+ * Returns JXLAMD_OK without touching the pixels when the reference would skip the stage for this transfer function
+ * (the caller checks preferEncoding / colour space / API level < 34 as JniDecoding.cpp:131-137 does). */
+int jxlamd_color_matrix(jxlamd_decoder *dec, void *pixels_dev, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries,
+                        uint32_t transfer_function, const double *xy8, float intensity_target);
+
 #ifdef __cplusplus
 }
 #endif

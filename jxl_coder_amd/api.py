@@ -61,10 +61,16 @@ class Info(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class ReformatInfo(C.Structure):               # jxlamd_reformat_info (include/jxl_amd.h)
+    _fields_ = [("stride", C.c_uint32), ("format", C.c_uint32), ("use_floats", C.c_uint32), ("resolved_config", C.c_uint32), ("bytes", C.c_uint64)]
+
+
+FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
+
 JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
-SOURCES = ["kernels.hip", "decoder.hip", "host_parse.cpp", "host_bits.cpp"]
+SOURCES = ["kernels.hip", "decoder.hip", "post.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
 
 
 def library_path():
@@ -104,6 +110,11 @@ def lib():
         L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 5)]
         L.jxlamd_decode_batch_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jxlamd_reformat_query.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ReformatInfo)]
+        L.jxlamd_reformat.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
+        L.jxlamd_color_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_float]
         _lib = L
     return _lib
 
@@ -161,6 +172,31 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return info.as_dict()
+
+    def color_matrix_device(self, ptr: int, w: int, h: int, is_u16: bool, depth: int, primaries: int, transfer_function: int,
+                            intensity_target: float, xy8=None):
+        """A10 on a device buffer, in place (jxlamd_color_matrix; cpp/colorspaces/ColorMatrix.cpp:35-219)."""
+        xy = (C.c_double * 8)(*xy8) if xy8 is not None else None
+        rc = lib().jxlamd_color_matrix(self._h, ptr, w, h, int(is_u16), depth, primaries, transfer_function, xy, float(intensity_target))
+        if rc:
+            _raise(rc, self._h)
+
+    def reformat_query(self, w, h, is_u16, config, has_alpha_in_origin, api_level):
+        ri = ReformatInfo()
+        rc = lib().jxlamd_reformat_query(w, h, int(is_u16), int(config), int(has_alpha_in_origin), int(api_level), C.byref(ri))
+        if rc:
+            _raise(rc, None)
+        return ri
+
+    def reformat_device(self, src_ptr: int, w: int, h: int, is_u16: bool, depth: int, config, alpha_premultiplied: bool,
+                        has_alpha_in_origin: bool, api_level: int, dst_ptr: int, dst_capacity: int):
+        """A11 on device buffers (jxlamd_reformat; cpp/ReformatBitmap.cpp:46-263).  Premultiplies src in place when the reference does."""
+        ri = ReformatInfo()
+        rc = lib().jxlamd_reformat(self._h, src_ptr, w, h, int(is_u16), depth, int(config), int(alpha_premultiplied), int(has_alpha_in_origin),
+                                   int(api_level), dst_ptr, dst_capacity, C.byref(ri))
+        if rc:
+            _raise(rc, self._h)
+        return ri
 
     def decode_batch_to_device(self, datas, out_ptrs, out_capacities, data_dev_ptrs=None, allowed_floats=True):
         """jxlamd_decode_batch_resident: n independent frames; the entropy stages of the whole batch share one launch each."""
@@ -226,7 +262,62 @@ class JxlCoder:
         use_sampler = (width > 0 or height > 0) and (width != 0 and height != 0)      # JniDecoding.cpp:116-117
         if use_sampler:
             raise UnsupportedJXLFeature("decodeSampled resampling (weaver / pic-scale) is a 'next' row, SURVEY.md §8f")
-        px, info = cls._decoder().decode_one_shot(data, allowed_floats=True)
-        if info["has_alpha_in_origin"] and not info["alpha_premultiplied"]:
-            pass   # ReformatColorConfig premultiply (cpp/ReformatBitmap.cpp:65-77): alpha images are not on the device path yet
-        return px
+        return cls._decode_pipeline(data, preferredColorConfig).pixels_view()
+
+    # Android API level the mirror emulates: >= 34 tags the Bitmap with a ColorSpace and leaves the pixels alone, below 34 the
+    # reference converts to sRGB / Rec.709 with applyColorMatrix (cpp/JniDecoding.cpp:131-228).  ReformatColorConfig's
+    # DEFAULT also depends on it (cpp/ReformatBitmap.cpp:52-63).
+    api_level = 34
+
+    @classmethod
+    def decodeBitmap(cls, data: bytes, preferredColorConfig=PreferredColorConfig.DEFAULT, api_level=None):
+        """What decodeSampledImageImpl hands to Bitmap creation (cpp/JniDecoding.cpp:45-331): rows with the reference's stride,
+        config name, useFloats — decode (A5) -> colour matrix (A10, API < 34 only) -> reformat (A11), all on the GPU."""
+        _check_preconditions(preferredColorConfig, ScaleMode.FIT)
+        return cls._decode_pipeline(data, preferredColorConfig, api_level)
+
+    @classmethod
+    def _decode_pipeline(cls, data, config, api_level=None):
+        import numpy as np
+        import torch
+        api = cls.api_level if api_level is None else int(api_level)
+        dec = cls._decoder()
+        info = Info()
+        rc = lib().jxlamd_basic_info(data, len(data), C.byref(info))
+        if rc:
+            raise InvalidJXLException(lib().jxlamd_last_error(None).decode())
+        w, h, is16 = info.xsize, info.ysize, info.out_bits == 16
+        dev = f"cuda:{dec.device}"
+        raw = torch.empty(w * h * 4 * (2 if is16 else 1), dtype=torch.uint8, device=dev)
+        meta = dec.decode_to_device(data, raw.data_ptr(), raw.numel(), allowed_floats=True)
+        depth = 16 if is16 else 8                                  # bitDepth as DecodeJpegXlOneShot reports it (JxlDecoding.cpp:92-101)
+        tf = meta["transfer_function"]
+        if meta["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and meta["color_space"] == 0 and api < 34:   # JniDecoding.cpp:131-137
+            dec.color_matrix_device(raw.data_ptr(), w, h, is16, depth, meta["primaries"], tf, meta["intensity_target"])
+        ri = dec.reformat_query(w, h, is16, config, meta["has_alpha_in_origin"], api)
+        dst = torch.empty(int(ri.bytes), dtype=torch.uint8, device=dev)
+        ri = dec.reformat_device(raw.data_ptr(), w, h, is16, depth, config, bool(meta["alpha_premultiplied"]), bool(meta["has_alpha_in_origin"]),
+                                 api, dst.data_ptr(), dst.numel())
+        torch.cuda.synchronize()
+        rows = dst.cpu().numpy().reshape(h, ri.stride)
+        name = "HARDWARE" if ri.resolved_config == int(PreferredColorConfig.HARDWARE) else FMT_NAMES[ri.format]
+        return Bitmap(rows, w, h, int(ri.stride), name, bool(ri.use_floats), meta)
+
+
+class Bitmap:
+    """The buffer the reference copies into an android.graphics.Bitmap (cpp/JniDecoding.cpp:266-326): `rows` is (height, stride) u8."""
+
+    def __init__(self, rows, width, height, stride, config, use_floats, info):
+        self.rows, self.width, self.height, self.stride, self.config, self.use_floats, self.info = rows, width, height, stride, config, use_floats, info
+
+    def pixels_view(self):
+        """(h, w, 4) u8 for ARGB_8888, (h, w, 4) u16 bit patterns (half floats) for RGBA_F16, (h, w) u16 for RGB_565, (h, w) u32 for RGBA_1010102."""
+        import numpy as np
+        w, h = self.width, self.height
+        if self.config in ("ARGB_8888",) or (self.config == "HARDWARE" and not self.use_floats):
+            return self.rows[:, :w * 4].reshape(h, w, 4)
+        if self.config == "RGBA_F16" or self.config == "HARDWARE":
+            return np.ascontiguousarray(self.rows[:, :w * 8]).view(np.uint16).reshape(h, w, 4)
+        if self.config == "RGB_565":
+            return np.ascontiguousarray(self.rows[:, :w * 2]).view(np.uint16).reshape(h, w)
+        return np.ascontiguousarray(self.rows[:, :w * 4]).view(np.uint32).reshape(h, w)

@@ -16,6 +16,8 @@
 #include "../../include/jxl_amd.h"
 #include "host_parse.h"
 #include "kernels.h"
+#include "post.h"
+#include "host_post.h"
 
 using namespace jxlamd;
 
@@ -110,7 +112,7 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, plane_pool;     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
+  DevMem stat, batch_tab, plane_pool, post_lin_lut, post_gam_lut;   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
@@ -449,7 +451,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release();
+  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
@@ -496,6 +498,81 @@ int jxlamd_decode_batch_resident(jxlamd_decoder *d, int n, const uint8_t *const 
                                  uint32_t flags, void *const *outs, const size_t *caps, jxlamd_info *infos) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   return d->decode_batch(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+}
+
+// ---- post-decode stages (A10, A11)
+static uint32_t aligned64(uint32_t line) { return line + (64u - line % 64u) % 64u; }
+
+int jxlamd_reformat_query(uint32_t w, uint32_t h, int src_is_u16, int cfg, int has_alpha, int api_level, jxlamd_reformat_info *o) {
+  if (!o || cfg < JXLAMD_CFG_DEFAULT || cfg > JXLAMD_CFG_HARDWARE) { g_tls_error = "Invalid Color Config"; return JXLAMD_ERR_BUFFER; }
+  if (cfg == JXLAMD_CFG_DEFAULT) {                       // ReformatBitmap.cpp:52-63 (depth > 8 <=> the decode produced u16)
+    if (src_is_u16 && api_level >= 26) cfg = (api_level >= 33 && !has_alpha) ? JXLAMD_CFG_RGBA_1010102 : JXLAMD_CFG_RGBA_F16;
+    else cfg = JXLAMD_CFG_RGBA_8888;
+  }
+  o->resolved_config = (uint32_t)cfg;
+  switch (cfg) {
+    case JXLAMD_CFG_RGBA_8888: o->stride = w * 4; o->format = JXLAMD_FMT_RGBA_8888; o->use_floats = 0; break;
+    case JXLAMD_CFG_RGBA_F16: o->stride = src_is_u16 ? w * 8 : aligned64(w * 8); o->format = JXLAMD_FMT_RGBA_F16; o->use_floats = 1; break;
+    case JXLAMD_CFG_RGB_565: o->stride = aligned64(w * 2); o->format = JXLAMD_FMT_RGB_565; o->use_floats = 0; break;
+    case JXLAMD_CFG_RGBA_1010102: o->stride = aligned64(w * 4); o->format = JXLAMD_FMT_RGBA_1010102; o->use_floats = 0; break;
+    default: o->stride = src_is_u16 ? w * 8 : w * 4; o->format = src_is_u16 ? JXLAMD_FMT_RGBA_F16 : JXLAMD_FMT_RGBA_8888; o->use_floats = src_is_u16 ? 1 : 0; break;
+  }
+  o->bytes = (uint64_t)o->stride * h;
+  return JXLAMD_OK;
+}
+
+int jxlamd_reformat(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int cfg, int alpha_premultiplied,
+                    int has_alpha, int api_level, void *dst, size_t dst_cap, jxlamd_reformat_info *out) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  jxlamd_reformat_info info;
+  int rc = jxlamd_reformat_query(w, h, src_is_u16, cfg, has_alpha, api_level, &info);
+  if (rc) { d->error = g_tls_error; return rc; }
+  if (out) *out = info;
+  if (!src || !dst || dst_cap < info.bytes) { d->set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
+  if (src_is_u16 ? (depth < 10 || depth > 16) : depth != 8) { d->set_error("bit depth does not match the source format"); return JXLAMD_ERR_BUFFER; }
+  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
+  const hipStream_t s = d->stream;
+  const uint32_t ss = w * (src_is_u16 ? 8u : 4u);
+  if (!alpha_premultiplied && has_alpha) launch_post_premultiply(src, ss, w, h, src_is_u16 != 0, depth, s);
+  const bool att = !alpha_premultiplied;
+  const uint32_t line = info.format == JXLAMD_FMT_RGB_565 ? w * 2 : info.format == JXLAMD_FMT_RGBA_F16 ? w * 8 : w * 4;
+  if (info.stride != line && hipMemsetAsync(dst, 0, info.bytes, s) != hipSuccess) { d->set_error("HIP: memset failed"); return JXLAMD_ERR_DEVICE; }
+  PostKind k;
+  switch (info.resolved_config) {
+    case JXLAMD_CFG_RGBA_8888: k = src_is_u16 ? kPostRgba16To8 : kPostCopy8; break;
+    case JXLAMD_CFG_RGBA_F16: k = src_is_u16 ? kPostU16ToF16 : kPostRgba8ToF16; break;
+    case JXLAMD_CFG_RGB_565: k = src_is_u16 ? kPostRgba16To565 : kPostRgba8To565; break;
+    case JXLAMD_CFG_RGBA_1010102: k = src_is_u16 ? kPostRgba16To1010102 : kPostRgba8To1010102; break;
+    default: k = src_is_u16 ? kPostU16ToF16 : kPostCopy8; break;     // HARDWARE: ReformatBitmap.cpp:231-245
+  }
+  launch_post_convert(k, src, ss, dst, info.stride, w, h, depth, att, s);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: post stage failed"); return JXLAMD_ERR_DEVICE; }
+  return JXLAMD_OK;
+}
+
+int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
+                        const double *xy8, float intensity_target) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  if (!px || (is_u16 ? (depth < 9 || depth > 16) : depth != 8)) { d->set_error("bad pixel buffer / bit depth"); return JXLAMD_ERR_BUFFER; }
+  static const double zeros[8] = {0.64, 0.33, 0.30, 0.60, 0.15, 0.06, 0.3127, 0.3290};
+  ColorMatrixPlan P;
+  if (!plan_color_matrix(is_u16 != 0, depth, primaries, tf, xy8 ? xy8 : zeros, intensity_target, &P)) return JXLAMD_OK;
+  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
+  const hipStream_t s = d->stream;
+  if (d->post_lin_lut.ensure(P.lin_lut.size() * 4) != hipSuccess || d->post_gam_lut.ensure(P.gam_lut.size() * 2) != hipSuccess ||
+      hipMemcpyAsync(d->post_lin_lut.p, P.lin_lut.data(), P.lin_lut.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d->post_gam_lut.p, P.gam_lut.data(), P.gam_lut.size() * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {          // the LUT vectors are pageable and die with this call
+    d->set_error("HIP: LUT upload failed"); return JXLAMD_ERR_DEVICE;
+  }
+  ColorMatrixDev D;
+  memcpy(D.m, P.m, sizeof(D.m));
+  D.tone_map = P.tone_map; D.weight_a = P.weight_a; D.weight_b = P.weight_b;
+  D.lin_lut = (const float *)d->post_lin_lut.p; D.gam_lut = (const uint16_t *)d->post_gam_lut.p;
+  D.index_scale = P.index_scale; D.index_max = P.index_max;
+  launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, D, s);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
+  return JXLAMD_OK;
 }
 
 int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) {

@@ -1,0 +1,25 @@
+// jxl_coder_amd/csrc/post.h — launchers of the post-decode kernels (post.hip); buffers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jxlamd {
+
+enum PostKind {                  // one thread per pixel, src RGBA8 / RGBA16 -> dst
+  kPostU16ToF16 = 0, kPostRgba8ToF16, kPostRgba16To8, kPostRgba8To565, kPostRgba16To565, kPostRgba8To1010102, kPostRgba16To1010102,
+  kPostCopy8, kPostCopy16,
+};
+
+void launch_post_premultiply(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, uint32_t depth, hipStream_t s);
+void launch_post_convert(PostKind kind, const void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
+                         uint32_t depth, bool attenuate, hipStream_t s);
+
+struct ColorMatrixDev {
+  float m[9];
+  int tone_map; float weight_a, weight_b;
+  const float *lin_lut; const uint16_t *gam_lut;
+  float index_scale; uint32_t index_max;
+};
+void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const ColorMatrixDev &P, hipStream_t s);
+
+}  // namespace jxlamd

@@ -1,0 +1,148 @@
+// jxl_coder_amd/csrc/post.hip — the reference's first-party post-decode stages as HIP kernels (gfx950), on buffers that
+// stay in HBM after the decode:
+//   A11 ReformatColorConfig (jxlcoder/src/main/cpp/ReformatBitmap.cpp:46-263): premultiply (imagebit/RGBAlpha.cpp:67-117),
+//       u16 -> f16 (RgbaU16toHF.cpp:42-144), u8 -> f16 (Rgba8ToF16.cpp:44-138), u16 -> u8 (Rgba16.cpp:32-68),
+//       -> RGB565 (Rgb565.cpp:99-160), -> RGBA1010102 (Rgb1010102.cpp:177-249)
+//   A10 applyColorMatrix / applyColorMatrix16Bit (colorspaces/ColorMatrix.cpp:35-219) with the Rec.2408 tone mapper
+//       (colorspaces/Rec2408ToneMapper.cpp:80-100), including its stuck-pointer behaviour on zero-luma pixels.
+// All of them are streaming kernels (HBM-bound): one work-item per pixel, 4-16 bytes in, 2-8 bytes out.
+// Integer stages are bit-exact with the reference; the float stage keeps the reference's operation order with FMA
+// contraction disabled, so that it differs from the reference only through the host-built LUTs / matrix.
+#include "post.h"
+
+namespace jxlamd {
+
+__device__ __forceinline__ uint16_t half_bits(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }   // RNE
+
+__global__ void __launch_bounds__(256) k_post_premul8(uint8_t *px, uint32_t stride, uint32_t w, uint32_t h) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  uint32_t *p = (uint32_t *)(px + (size_t)y * stride) + x;
+  const uint32_t v = *p, a = v >> 24;
+  const uint32_t r = ((v & 0xff) * a) / 255u, g = (((v >> 8) & 0xff) * a) / 255u, b = (((v >> 16) & 0xff) * a) / 255u;
+  *p = r | (g << 8) | (b << 16) | (a << 24);
+}
+__global__ void __launch_bounds__(256) k_post_premul16(uint8_t *px, uint32_t stride, uint32_t w, uint32_t h, uint32_t maxv) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  ushort4 *p = (ushort4 *)(px + (size_t)y * stride) + x;
+  ushort4 v = *p;
+  const uint32_t a = v.w;
+  v.x = (uint16_t)(((uint32_t)v.x * a) / maxv); v.y = (uint16_t)(((uint32_t)v.y * a) / maxv); v.z = (uint16_t)(((uint32_t)v.z * a) / maxv);
+  *p = v;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
+                                                      uint32_t depth, int attenuate) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const uint8_t *srow = src + (size_t)y * src_stride;
+  uint8_t *drow = dst + (size_t)y * dst_stride;
+  constexpr bool kSrc16 = KIND == kPostU16ToF16 || KIND == kPostRgba16To8 || KIND == kPostRgba16To565 || KIND == kPostRgba16To1010102 || KIND == kPostCopy16;
+  uint32_t r, g, b, a;
+  if (kSrc16) { const ushort4 v = ((const ushort4 *)srow)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
+  else {
+    const uint32_t v = ((const uint32_t *)srow)[x];
+    r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24;
+    if (attenuate && (KIND == kPostRgba8ToF16 || KIND == kPostRgba8To565 || KIND == kPostRgba8To1010102)) { r = (r * a) / 255u; g = (g * a) / 255u; b = (b * a) / 255u; }
+  }
+  if (KIND == kPostU16ToF16 || KIND == kPostRgba8ToF16) {
+    const float scale = 1.0f / (float)((1u << (KIND == kPostU16ToF16 ? depth : 8u)) - 1u);
+    ushort4 o;
+    o.x = half_bits((float)r * scale); o.y = half_bits((float)g * scale); o.z = half_bits((float)b * scale); o.w = half_bits((float)a * scale);
+    ((ushort4 *)drow)[x] = o;
+  } else if (KIND == kPostRgba16To8) {
+    const uint32_t d = depth - 8;
+    ((uint32_t *)drow)[x] = ((r >> d) & 0xff) | (((g >> d) & 0xff) << 8) | (((b >> d) & 0xff) << 16) | (((a >> d) & 0xff) << 24);
+  } else if (KIND == kPostRgba8To565) {
+    ((uint16_t *)drow)[x] = (uint16_t)(((r >> 3) << 11) | ((g >> 2) << 5) | (b >> 3));
+  } else if (KIND == kPostRgba16To565) {
+    const uint32_t rb = depth - 8 + 3, gd = depth - 8 + 2;
+    ((uint16_t *)drow)[x] = (uint16_t)((((r >> rb) << 11) & 0xffffu) | (((g >> gd) << 5) & 0xffffu) | (b >> rb));
+  } else if (KIND == kPostRgba8To1010102) {
+    ((uint32_t *)drow)[x] = ((a >> 6) << 30) | ((b << 2) << 20) | ((g << 2) << 10) | (r << 2);
+  } else if (KIND == kPostRgba16To1010102) {
+    const uint32_t d = depth - 10, ad = depth - 2;
+    ((uint32_t *)drow)[x] = (((a >> ad) & 3u) << 30) | (((b >> d) & 0x3ffu) << 20) | (((g >> d) & 0x3ffu) << 10) | ((r >> d) & 0x3ffu);
+  } else if (KIND == kPostCopy8) {
+    ((uint32_t *)drow)[x] = r | (g << 8) | (b << 16) | (a << 24);
+  } else {
+    ushort4 o; o.x = (uint16_t)r; o.y = (uint16_t)g; o.z = (uint16_t)b; o.w = (uint16_t)a;
+    ((ushort4 *)drow)[x] = o;
+  }
+}
+
+// One workgroup per row.  Phase 1 (tone map only): the first pixel of the row whose linear luma is exactly 0 — the
+// reference's loop never advances past it, so pixels from there on stay un-mapped.  Phase 2: LUT -> tone map -> matrix -> LUT.
+template <bool kU16>
+__global__ void __launch_bounds__(256) k_post_color_matrix(uint8_t *px, uint32_t stride, uint32_t w, ColorMatrixDev P) {
+#pragma clang fp contract(off)
+  __shared__ uint32_t first_zero;
+  uint8_t *row = px + (size_t)blockIdx.x * stride;
+  if (threadIdx.x == 0) first_zero = w;
+  __syncthreads();
+  const uint32_t cap = kU16 ? P.index_max : 255u;
+  if (P.tone_map) {
+    uint32_t mine = w;
+    for (uint32_t x = threadIdx.x; x < w; x += 256) {
+      uint32_t r, g, b;
+      if (kU16) { const ushort4 v = ((const ushort4 *)row)[x]; r = v.x; g = v.y; b = v.z; }
+      else { const uint32_t v = ((const uint32_t *)row)[x]; r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; }
+      const float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
+      const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
+      if (y == 0.0f) { mine = x; break; }      // x ascends within a work-item: the first hit is its minimum
+    }
+    if (mine < w) atomicMin(&first_zero, mine);
+  }
+  __syncthreads();
+  const uint32_t fz = first_zero;
+  for (uint32_t x = threadIdx.x; x < w; x += 256) {
+    uint32_t r, g, b, a;
+    if (kU16) { const ushort4 v = ((const ushort4 *)row)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
+    else { const uint32_t v = ((const uint32_t *)row)[x]; r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24; }
+    float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
+    if (P.tone_map && x < fz) {
+      const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
+      const float scale = (1.0f + P.weight_a * y) / (1.0f + P.weight_b * y);
+      fr = fminf(fr * scale, 1.0f); fg = fminf(fg * scale, 1.0f); fb = fminf(fb * scale, 1.0f);
+    }
+    const float nr = fr * P.m[0] + fg * P.m[1] + fb * P.m[2];
+    const float ng = fr * P.m[3] + fg * P.m[4] + fb * P.m[5];
+    const float nb = fr * P.m[6] + fg * P.m[7] + fb * P.m[8];
+    #define IDX(v) ({ float c_ = (v) < 0.0f ? 0.0f : (v) > 1.0f ? 1.0f : (v); if (!((v) == (v))) c_ = 0.0f; uint32_t i_ = (uint32_t)(c_ * P.index_scale) & 0xffffu; i_ < P.index_max ? i_ : P.index_max; })
+    const uint32_t o0 = P.gam_lut[IDX(nr)], o1 = P.gam_lut[IDX(ng)], o2 = P.gam_lut[IDX(nb)];
+    #undef IDX
+    if (kU16) { ushort4 o; o.x = (uint16_t)o0; o.y = (uint16_t)o1; o.z = (uint16_t)o2; o.w = (uint16_t)a; ((ushort4 *)row)[x] = o; }
+    else ((uint32_t *)row)[x] = o0 | (o1 << 8) | (o2 << 16) | (a << 24);
+  }
+}
+
+void launch_post_premultiply(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, uint32_t depth, hipStream_t s) {
+  dim3 grid((w + 255) / 256, h);
+  if (is_u16) hipLaunchKernelGGL(k_post_premul16, grid, dim3(256), 0, s, (uint8_t *)px, stride, w, h, (1u << depth) - 1u);
+  else hipLaunchKernelGGL(k_post_premul8, grid, dim3(256), 0, s, (uint8_t *)px, stride, w, h);
+}
+
+void launch_post_convert(PostKind kind, const void *src, uint32_t ss, void *dst, uint32_t ds, uint32_t w, uint32_t h, uint32_t depth, bool att, hipStream_t s) {
+  dim3 grid((w + 255) / 256, h), block(256);
+  const uint8_t *a = (const uint8_t *)src; uint8_t *b = (uint8_t *)dst; const int at = att ? 1 : 0;
+  switch (kind) {
+    case kPostU16ToF16: hipLaunchKernelGGL(k_post_convert<kPostU16ToF16>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba8ToF16: hipLaunchKernelGGL(k_post_convert<kPostRgba8ToF16>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba16To8: hipLaunchKernelGGL(k_post_convert<kPostRgba16To8>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba8To565: hipLaunchKernelGGL(k_post_convert<kPostRgba8To565>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba16To565: hipLaunchKernelGGL(k_post_convert<kPostRgba16To565>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba8To1010102: hipLaunchKernelGGL(k_post_convert<kPostRgba8To1010102>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostRgba16To1010102: hipLaunchKernelGGL(k_post_convert<kPostRgba16To1010102>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostCopy8: hipLaunchKernelGGL(k_post_convert<kPostCopy8>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+    case kPostCopy16: hipLaunchKernelGGL(k_post_convert<kPostCopy16>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+  }
+}
+
+void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const ColorMatrixDev &P, hipStream_t s) {
+  if (is_u16) hipLaunchKernelGGL(k_post_color_matrix<true>, dim3(h), dim3(256), 0, s, (uint8_t *)px, stride, w, P);
+  else hipLaunchKernelGGL(k_post_color_matrix<false>, dim3(h), dim3(256), 0, s, (uint8_t *)px, stride, w, P);
+}
+
+}  // namespace jxlamd

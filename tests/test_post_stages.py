@@ -1,0 +1,174 @@
+"""Post-decode stages: the reference's applyColorMatrix (cpp/colorspaces/ColorMatrix.cpp) and
+ReformatColorConfig (cpp/ReformatBitmap.cpp) with the imagebit kernels.
+
+CPU part: the numpy oracle (oracle/post_oracle.py) against golden outputs of the reference's own sources
+(tests/golden/post_golden.npz, made by tests/golden/make_post_golden.py through oracle/_ref/libref_post.so).
+GPU part: the HIP kernels behind jxlamd_reformat / jxlamd_color_matrix against the oracle.
+
+Tolerances: every integer stage is BIT-EXACT.  The colour-matrix stage goes through LUTs built with powf (256 + 2049 entries
+for u8, 2 x 65 536 for u16); numpy's float32 pow, libm's powf and the float matrix inverse differ in the last ulp, which moves
+a sample sitting on a LUT-index boundary by one LUT step.  u8: at most 0.2 % of samples differ, by <= 2; u16: at most 2 %
+differ, by <= 16/65535 (one step of the sRGB LUT at its steepest)."""
+import os, sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import post_oracle as P   # noqa: E402  (test infrastructure)
+
+G = np.load(os.path.join(ROOT, "tests/golden/post_golden.npz"))
+CM_CASES = [(9, 16, 10000.0), (9, 18, 1000.0), (1, 13, 255.0), (11, 13, 255.0), (1, 1, 255.0), (2, 65535, 255.0), (11, 17, 255.0)]
+U16_LUT_MAX, U16_LUT_FRAC = 16, 0.02
+U8_LUT_MAX, U8_LUT_FRAC = 2, 0.002
+GPU_U16_LUT_MAX = 64       # GPU vs oracle: three independent pow implementations (numpy, host libm, reference) meet in the PQ case; <= 0.1 % of full scale
+
+
+def test_oracle_integer_stages_match_the_reference_bit_for_bit():
+    p8, p16 = G["p8"], G["p16"]
+    assert np.array_equal(P.associate8(p8), G["associate8"])
+    assert np.array_equal(P.associate16(p16, 16), G["associate16"])
+    assert np.array_equal(P.u16_to_f16(p16, 16), G["u16_to_f16"])
+    assert np.array_equal(P.rgba16_to_8(p16, 16), G["rgba16_to_8"])
+    assert np.array_equal(P.rgba16_to_565(p16, 16), G["rgba16_to_565"])
+    assert np.array_equal(P.rgba16_to_1010102(p16, 16), G["rgba16_to_1010102"])
+    for att in (0, 1):
+        assert np.array_equal(P.rgba8_to_f16(p8, att), G[f"rgba8_to_f16_{att}"])
+        assert np.array_equal(P.rgba8_to_565(p8, att), G[f"rgba8_to_565_{att}"])
+        assert np.array_equal(P.rgba8_to_1010102(p8, att), G[f"rgba8_to_1010102_{att}"])
+
+
+@pytest.mark.parametrize("prim,tf,target", CM_CASES)
+def test_oracle_colour_matrix_matches_the_reference(prim, tf, target):
+    xy = list(G["custom_xy"])
+    assert np.abs(P.conversion_matrix(prim, xy).ravel() - G[f"cm_matrix_{prim}"]).max() < 2e-6
+    d8 = np.abs(P.color_matrix(G["p8"], 8, prim, tf, xy, target).astype(int) - G[f"cm_{prim}_{tf}_8"].astype(int))   # rows with zero-luma pixels included
+    assert d8.max() <= U8_LUT_MAX and (d8 > 0).mean() <= U8_LUT_FRAC
+    d = np.abs(P.color_matrix(G["p16"], 16, prim, tf, xy, target).astype(int) - G[f"cm_{prim}_{tf}_16"].astype(int))
+    assert d.max() <= U16_LUT_MAX and (d > 0).mean() <= U16_LUT_FRAC
+
+
+def test_oracle_against_live_reference_library_when_present():
+    import ctypes as C
+    path = os.path.join(ROOT, "oracle/_ref/libref_post.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_post.so not built")
+    L = C.CDLL(path)
+    rng = np.random.default_rng(7)
+    for (h, w) in ((1, 1), (3, 17), (5, 64)):
+        p8 = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        a = p8.copy(); L.refpost_associate8(C.c_void_p(a.ctypes.data), w * 4, w, h)
+        assert np.array_equal(a, P.associate8(p8))
+        d = np.zeros((h, w), np.uint16); L.refpost_rgba8_to_565(C.c_void_p(p8.ctypes.data), w * 4, C.c_void_p(d.ctypes.data), w * 2, w, h, 1)
+        assert np.array_equal(d, P.rgba8_to_565(p8, True))
+
+
+def test_reformat_flow_mirrors_reformatcolorconfig():
+    """cpp/ReformatBitmap.cpp:46-263: DEFAULT resolution, premultiply rule, 64-byte row alignment, config names."""
+    rng = np.random.default_rng(3)
+    p8 = rng.integers(0, 256, (4, 37, 4), dtype=np.uint8); p16 = rng.integers(0, 65536, (4, 37, 4), dtype=np.uint16)
+    rows, stride, fl, name = P.reformat(p8, P.DEFAULT, 8, False, False, False, 34)
+    assert (stride, fl, name) == (37 * 4, False, "ARGB_8888") and np.array_equal(rows.reshape(4, 37, 4), p8)
+    rows, stride, fl, name = P.reformat(p16, P.DEFAULT, 16, True, False, False, 34)             # >8 bit, no alpha, API >= 33
+    assert (stride, name) == (192, "RGBA_1010102") and stride % 64 == 0
+    rows, stride, fl, name = P.reformat(p16, P.DEFAULT, 16, True, False, True, 34)              # alpha in origin -> F16, premultiplied first
+    assert (stride, fl, name) == (37 * 8, True, "RGBA_F16")
+    assert np.array_equal(rows.view(np.uint16).reshape(4, 37, 4), P.u16_to_f16(P.associate16(p16, 16), 16))
+    rows, stride, fl, name = P.reformat(p16, P.DEFAULT, 16, True, False, False, 25)             # API < 26
+    assert name == "ARGB_8888" and np.array_equal(rows.reshape(4, 37, 4), P.rgba16_to_8(p16, 16))
+    rows, stride, fl, name = P.reformat(p8, P.RGBA_F16, 8, False, False, True, 34)              # the reference attenuates twice here
+    assert stride == 320 and np.array_equal(rows[:, :37 * 8].copy().view(np.uint16).reshape(4, 37, 4), P.rgba8_to_f16(P.associate8(p8), True))
+    rows, stride, fl, name = P.reformat(p8, P.RGB_565, 8, False, True, True, 34)
+    assert (stride, name) == (128, "RGB_565") and np.array_equal(rows[:, :74].copy().view(np.uint16).reshape(4, 37), P.rgba8_to_565(p8, False))
+
+
+# ------------------------------------------------------------------------------------------------- GPU
+def _dev(arr):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy()).cuda()
+    torch.cuda.synchronize()
+    return t
+
+
+@pytest.fixture(scope="module")
+def dec():
+    import torch
+    torch.cuda.init()                      # torch first: it owns the device allocations of these tests
+    import jxl_coder_amd as J
+    d = J.JxlDecoder(0)
+    yield d
+    d.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is16", [False, True])
+@pytest.mark.parametrize("config", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("premult,has_alpha", [(False, False), (False, True), (True, True)])
+def test_gpu_reformat_is_bit_exact(dec, is16, config, premult, has_alpha):
+    import torch
+    rng = np.random.default_rng(11 + config)
+    h, w = 19, 203                                                      # rows not a multiple of 64 bytes in any format
+    px = rng.integers(0, 65536 if is16 else 256, (h, w, 4), dtype=np.uint16 if is16 else np.uint8)
+    px[3, :, 3] = 0
+    depth = 16 if is16 else 8
+    for api in (34, 29):
+        exp_rows, exp_stride, exp_fl, exp_name = P.reformat(px, config, depth, is16, premult, has_alpha, api)
+        src = _dev(px)
+        ri = dec.reformat_query(w, h, is16, config, has_alpha, api)
+        assert ri.stride == exp_stride and ri.bytes == exp_stride * h and bool(ri.use_floats) == exp_fl
+        dst = torch.full((int(ri.bytes),), 0xAB, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()             # torch's fill runs on torch's stream, the decoder context has its own
+        dec.reformat_device(src.data_ptr(), w, h, is16, depth, config, premult, has_alpha, api, dst.data_ptr(), dst.numel())
+        assert np.array_equal(dst.cpu().numpy().reshape(h, exp_stride), exp_rows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prim,tf,target", CM_CASES)
+def test_gpu_colour_matrix(dec, prim, tf, target):
+    rng = np.random.default_rng(5)
+    h, w = 33, 517
+    xy = list(G["custom_xy"])
+    for is16 in (False, True):
+        px = rng.integers(0, 65536 if is16 else 256, (h, w, 4), dtype=np.uint16 if is16 else np.uint8)
+        px[2, 100, :3] = 0; px[5, 0, :3] = 0; px[7, w - 1, :3] = 0        # zero-luma pixels: the rest of those rows stays un-mapped
+        exp = P.color_matrix(px, 16 if is16 else 8, prim, tf, xy, target)
+        buf = _dev(px)
+        dec.color_matrix_device(buf.data_ptr(), w, h, is16, 16 if is16 else 8, prim, tf, target, xy)
+        got = buf.cpu().numpy().view(np.uint16 if is16 else np.uint8).reshape(h, w, 4)
+        d = np.abs(got.astype(int) - exp.astype(int))
+        if is16:
+            assert d.max() <= GPU_U16_LUT_MAX and (d > 0).mean() <= U16_LUT_FRAC
+        else:
+            assert d.max() <= U8_LUT_MAX and (d > 0).mean() <= U8_LUT_FRAC
+        assert np.array_equal(got[..., 3], px[..., 3])
+
+
+@pytest.mark.gpu
+def test_gpu_colour_matrix_skips_what_the_reference_skips(dec):
+    px = np.random.default_rng(1).integers(0, 256, (4, 9, 4), dtype=np.uint8)
+    buf = _dev(px)
+    dec.color_matrix_device(buf.data_ptr(), 9, 4, False, 8, 1, 8, 255.0)          # linear transfer: stage not run (JniDecoding.cpp:131-137)
+    assert np.array_equal(buf.cpu().numpy().reshape(4, 9, 4), px)
+
+
+@pytest.mark.gpu
+def test_gpu_decode_bitmap_pipeline_on_pq_image():
+    """C5-shaped path end to end on the device: 16-bit PQ / Rec.2100 decode -> tone map + gamut + sRGB (API < 34) -> F16 / 1010102."""
+    import torch
+    import jxl_coder_amd as J
+    from conftest import load_case
+    data, _ = load_case("v160x120_16bit_pq2100_epf3")
+    raw, info = J.JxlCoder._decoder().decode_one_shot(data, allowed_floats=True)
+    assert raw.dtype == np.uint16 and info["transfer_function"] == 16 and info["primaries"] == 9
+    for api, cfg in ((34, J.PreferredColorConfig.DEFAULT), (29, J.PreferredColorConfig.DEFAULT), (29, J.PreferredColorConfig.RGBA_F16),
+                     (29, J.PreferredColorConfig.RGBA_8888), (33, J.PreferredColorConfig.RGB_565)):
+        bmp = J.JxlCoder.decodeBitmap(data, cfg, api_level=api)
+        px = raw
+        if api < 34:
+            px = P.color_matrix(raw, 16, info["primaries"], 16, None, info["intensity_target"])
+        rows, stride, fl, name = P.reformat(px, int(cfg), 16, True, bool(info["alpha_premultiplied"]), bool(info["has_alpha_in_origin"]), api)
+        assert (bmp.stride, bmp.use_floats, bmp.config) == (stride, fl, name)
+        if api >= 34:
+            assert np.array_equal(bmp.rows, rows)
+        else:                                                            # one LUT step of the u16 colour matrix, then an exact reformat
+            assert (bmp.rows != rows).mean() <= 0.03
