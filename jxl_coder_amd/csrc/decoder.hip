@@ -87,7 +87,7 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
 struct FrameSlot {
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};             // HBM work buffers of one in-flight frame
   PinnedMem h_tables, h_cs;
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, big_list[3];
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -95,7 +95,7 @@ struct FrameSlot {
   size_t out_bytes = 0;
   void *d_out = nullptr; void *host_out = nullptr;
   void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz};
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end};
     for (auto *m : all) m->release();
     for (auto &m : cells8) m.release();
     for (auto &m : tiles) m.release();
@@ -126,6 +126,7 @@ struct jxlamd_decoder {
   int finish_single_section(FrameSlot &S);
   int launch_rest(FrameSlot &S);
   int launch_modular(FrameSlot &S);
+  int launch_extra_channels(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
   int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
   int decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
@@ -211,6 +212,12 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
     HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
+    if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
+      HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
+      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
+      HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
+      HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
+    }
   } else {
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
@@ -228,7 +235,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
                                 B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
   B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
-  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p; B.pass_end_bits = (uint64_t *)S.pass_end.p;
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out; B.out_bits = (int32_t)S.pi.out_bits;
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
@@ -276,6 +283,17 @@ int jxlamd_decoder::launch_rest(FrameSlot &S) {
   return JXLAMD_OK;
 }
 
+// Extra channels of a VarDCT frame (alpha): GlobalModular part (meta channels, channels that fit one group), then the
+// ModularGroup stream that follows each group's AC stream, then the inverse global transforms.  The writer reads the planes.
+int jxlamd_decoder::launch_extra_channels(FrameSlot &S) {
+  const FramePlan &plan = S.plan;
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  launch_mod_global(S.B, stream);
+  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
+  for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
+  return JXLAMD_OK;
+}
+
 // Modular-encoded (lossless) frame: GlobalModular stream, per-group streams, inverse global transforms, writer
 int jxlamd_decoder::launch_modular(FrameSlot &S) {
   const FramePlan &plan = S.plan;
@@ -318,6 +336,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
   launch_pass_groups(S.B, S.plan.num_groups, stream);
+  if (S.plan.has_ec) launch_extra_channels(S);
   HIPCHECK(hipEventRecord(ev[2], stream));
   launch_recon(S.B, (const uint8_t *)stat.p, S.plan.xb, S.plan.yb, stream);
   HIPCHECK(hipEventRecord(ev[3], stream));
@@ -351,14 +370,15 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     FrameSlot &S = slot((size_t)i);
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
-                     /*own_planes=*/S.plan.modular || S.plan.single_section);
+                     /*own_planes=*/S.plan.modular || S.plan.single_section || S.plan.has_ec);
     if (rc) return rc;
     if (S.plan.modular) { launch_modular(S); rc = collect(S, flags); if (rc) return rc; continue; }
-    if (S.plan.single_section) {
+    if (S.plan.single_section || S.plan.has_ec) {
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
-      rc = finish_single_section(S); if (rc) return rc;
+      if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
       launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
       launch_pass_groups(S.B, S.plan.num_groups, stream);
+      if (S.plan.has_ec) launch_extra_channels(S);
       launch_rest(S);
       rc = collect(S, flags); if (rc) return rc;
     } else batched.push_back(i);

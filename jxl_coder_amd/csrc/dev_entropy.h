@@ -42,6 +42,13 @@ JXL_DEV void bits_init(DevBits &b, const uint8_t *base, uint64_t byte_off, uint6
   b.n = 64 - 8 * (int32_t)mis;
   b.consumed = 0;
 }
+// start `bit_off` bits into the section at byte_off (a stream that follows another one inside the same section)
+JXL_DEV void bits_init_at_bit(DevBits &b, const uint8_t *base, uint64_t byte_off, uint64_t bit_off, uint64_t total_bytes) {
+  bits_init(b, base, byte_off + (bit_off >> 3), total_bytes);
+  const int rem = (int)(bit_off & 7);
+  if (rem) { b.buf >>= rem; b.n -= rem; }
+  b.consumed = bit_off;
+}
 JXL_DEV void bits_refill(DevBits &b) {     // guarantees >= 32 valid bits
   if (b.n <= 32) {
     b.buf |= (uint64_t)b.ahead << b.n;

@@ -79,7 +79,8 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
     const DevSection sec = secs[2 + F.num_lf_groups + g];
     DevBits b;
-    bits_init(b, B.codestream, sec.off, F.cs_size);
+    if (F.is_modular) bits_init(b, B.codestream, sec.off, F.cs_size);
+    else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
     modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {

@@ -368,16 +368,22 @@ JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const Dev
     default: break;
   }
   const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
+  float alpha = 1.0f;                                  // extra channel of type alpha (Modular-coded, integer samples)
+  if (F.has_ec && F.mod_out[3] >= 0) {
+    const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)y * (size_t)F.width + (size_t)x];
+    alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
+    alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;
+  }
   if (out_bits == 8) {
     const float d = st_f(stat, ST.dither_off)[(oy & 31) * 32 + (ox & 31)];   // libjxl's 8-bit writer dither (oracle/README.md)
     uint8_t px[4];
     for (int c = 0; c < 3; c++) px[c] = (uint8_t)(int)rintf(v[c] * 255.0f + d);
-    px[3] = 255;
+    px[3] = (uint8_t)(int)rintf(alpha * 255.0f);
     *(uint32_t *)(B.out + di) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
   } else {
     uint16_t *o16 = (uint16_t *)B.out + di;
     for (int c = 0; c < 3; c++) o16[c] = (uint16_t)(int)rintf(v[c] * 65535.0f);
-    o16[3] = 65535;
+    o16[3] = (uint16_t)(int)rintf(alpha * 65535.0f);
   }
 }
 

@@ -82,6 +82,7 @@ struct DevFrame {
   int32_t nsec;
   // Modular-encoded frames (lossless): stream channels after the GLOBAL transforms' meta-apply, planes in one pool
   int32_t is_modular, mod_nch, mod_nb_meta, mod_first_group_ch;   // channels [mod_first_group_ch, mod_nch) are decoded per group
+  int32_t has_ec;                  // VarDCT frame with extra channels (alpha): the mod_* fields describe the extra-channel Modular image
   int32_t mod_w[12], mod_h[12]; uint32_t mod_plane_off[12];        // int32 planes (offsets in samples into the pool)
   uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
   int32_t mod_nops;                // inverse global transforms, in execution order, with resolved plane indices

@@ -32,6 +32,7 @@ struct DevBuffers {
   int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
   uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
   uint32_t *big_count;          // [3] their counts
+  uint64_t *pass_end_bits;      // [num_groups]: where the AC stream of a group ended (extra-channel frames: its ModularGroup stream starts there)
   uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
@@ -366,6 +367,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
 #endif
   if (state != 0x130000u) return kErrAnsFinal;
   if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
+  if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
   return 0;
 }
 
@@ -455,6 +457,7 @@ JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, 
       }
     if (state != 0x130000u) return kErrAnsFinal;
     if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
+    if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
   }
   return 0;
 }

@@ -140,13 +140,13 @@ static void finish_blob(FramePlan *plan, Priv *pv) { memcpy(plan->tables.data(),
 
 // GlobalModular of a Modular-encoded frame: parse the stream header (transforms) on the host, derive the channel list
 // the device decodes and the inverse-transform program with resolved plane indices.  Sample data stays on the device.
-static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb) {
+static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardct = false) {
   DevFrame &F = pv->F; const frame_hdr &f = pv->f; const img_meta &m = pv->m;
-  F.is_modular = 1;
+  F.is_modular = vardct ? 0 : 1; F.has_ec = vardct ? 1 : 0;      // vardct: the Modular image holds only the extra channels
   F.mod_global_bit = (uint32_t)sb->pos;
   F.mod_bits = (int)m.pub.bits_per_sample;
   if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
-  const int ncol = m.pub.num_color_channels == 1 ? 1 : 3;
+  const int ncol = vardct ? 0 : m.pub.num_color_channels == 1 ? 1 : 3;
   struct Ch { int w, h, plane; };
   std::vector<Ch> L;
   int nplanes = 0;
@@ -219,7 +219,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb) {
     }
   }
   if ((int)L.size() != ncol + m.num_extra) { plan->error = "modular channel bookkeeping"; return -1; }
-  for (int c = 0; c < 3; c++) F.mod_out[c] = L[(size_t)(ncol == 1 ? 0 : c)].plane;
+  for (int c = 0; c < 3; c++) F.mod_out[c] = vardct ? -1 : L[(size_t)(ncol == 1 ? 0 : c)].plane;
   F.mod_out[3] = -1; F.mod_alpha_bits = 8;
   for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits; break; }
   return 0;
@@ -262,7 +262,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   frame_hdr &f = pv->f;
   if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { plan->error = hx_last_error(); return -1; }
   if (f.frame_type != 0 || !f.is_last) { plan->error = "unsupported: multi-frame / non-regular frame"; return -1; }
-  if (f.encoding == 0 && m.num_extra) { plan->error = "unsupported: extra channels (alpha) on VarDCT frames"; return -1; }
+  if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
   if (f.encoding == 1 && m.pub.xyb_encoded) { plan->error = "unsupported: lossy (XYB) Modular frame"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
@@ -370,6 +370,11 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   plan->lf_global_end_bit = (uint32_t)sb.pos;
   F.single_lf_bit = (uint32_t)sb.pos;
   if (f.encoding == 1 && parse_modular_global(plan, pv, &sb)) return -1;
+  if (f.encoding == 0 && m.num_extra) {
+    if (nsec == 1) { plan->error = "unsupported: extra channels on a single-section (<= 256 px) VarDCT frame"; return -1; }
+    if (parse_modular_global(plan, pv, &sb, /*vardct=*/true)) return -1;
+    plan->has_ec = true;
+  }
   // quantiser-derived constants
   float inv_quant_dc = 65536.0f / ((float)global_scale * (float)quant_lf);
   for (int c = 0; c < 3; c++) F.lf_fac[c] = lf_dequant[c] * inv_quant_dc;

@@ -1173,6 +1173,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
   float *rgb[3] = {NULL, NULL, NULL};
   size_t npx = (size_t)w * (size_t)h;
   if (f->encoding == 0) {
+    if (m.num_extra && jxo_modular_undo_transforms(&s->gmod)) goto done;   /* extra channels (alpha): global palette etc. */
     if (!(f->flags & 128)) adaptive_lf_smoothing(s);
     reconstruct_vardct(s);
     if (jxo_debug) { FILE *fp = fopen("/tmp/jxo_xyb.bin", "wb"); for (int c = 0; c < 3; c++) fwrite(s->plane[c], 4, (size_t)s->pw * (size_t)s->ph, fp); fclose(fp); }

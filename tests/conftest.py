@@ -67,7 +67,8 @@ def emul():
 
 
 VARDCT_CASES = ["v64_e3_gab0_epf0", "v256_e3_gab0_epf0", "v256_e3_gab1_epf0", "v256_e3_gab0_epf1", "v256_e3_gab0_epf2",
-                "v256_e3_gab0_epf3", "v256_e7", "v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "v64_hard_e7"]
+                "v256_e3_gab0_epf3", "v256_e7", "v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "v64_hard_e7",
+                "va300x520_e7"]        # va*: RGBA, VarDCT colour + Modular-coded alpha (alpha must come out bit-exact)
 LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x260_e5", "l700x500_e7"]
 # lossless cases the DEVICE path decodes (l64_e1 is libjxl's effort-1 fast path: LZ77 inside group streams -> rejected loudly)
 LOSSLESS_DEVICE_CASES = ["l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l700x500_e7"]
@@ -80,7 +81,7 @@ VARDCT_MEAN_ABS = 0.1
 # 16-bit output (RGBA u16): max |diff| <= 256/65535 and mean <= 16/65535.  PQ-coded frames are checked
 # statistically: the PQ curve's slope near black turns 1e-5 of linear-light float noise into hundreds of code values on a
 # handful of near-zero samples (the reference's own SSE2 arithmetic differs from any other float ordering there).
-U16_CASES = ["v160x120_16bit_e7"]
+U16_CASES = ["v160x120_16bit_e7", "va530x270_16bit_e7"]
 U16_PQ_CASES = ["v160x120_16bit_pq2100_epf3"]
 U16_MAX_ABS = 256
 U16_MEAN_ABS = 16.0

@@ -3,6 +3,7 @@
 // (nthreads = 1, barriers are no-ops).  It lets the CPU test suite check the bitstream logic and the table
 // packing of the product's host parser without a GPU.  It is never linked into libjxlamd.so and is not a
 // fallback: the product fails loudly without a HIP device.
+#include <algorithm>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,8 +46,9 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   B.xfromy = tl[0].data(); B.bfromy = tl[1].data();
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = &err; B.out = out;
-  std::vector<LocalTreeScratch> loc((size_t)(plan.modular ? (plan.num_groups > 1 ? plan.num_groups : 1) : plan.num_lf_groups)); B.local = loc.data();
-  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr(plan.modular ? (size_t)plan.num_groups * kModGroupScratchInts : 1, 0);
+  std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
+  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? (size_t)plan.num_groups * kModGroupScratchInts : 1, 0);
+  std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_list[2] = bl2.data(); B.big_count = bcount;
   DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
@@ -85,6 +87,15 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   for (int g = 0; g < plan.num_groups; g++) pass_group_body(B, *PS, g, 0, 1, NoSync());
   delete PS;
   if (err) { g_err = "device flags " + std::to_string(err) + " (PassGroup)"; return -2; }
+  if (plan.has_ec) {                          // extra channels (alpha): same order as jxlamd_decoder::launch_extra_channels
+    const DevFrame &F = *(const DevFrame *)tables.data();
+    DevModScratch *MS2 = new DevModScratch();
+    mod_global_body(B, *MS2, 0, 1, NoSync());
+    if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS2, g, 0, 1, NoSync());
+    delete MS2;
+    if (err) { g_err = "device flags " + std::to_string(err) + " (extra channels)"; return -2; }
+    for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
+  }
   std::vector<float> S(3 * 4096), T(4096);
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
     if (getenv("JXLEMUL_SIMT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses

@@ -35,6 +35,9 @@ CASES = {
     "v64_hard_e7": (64, 64, dict(seed=4, hard=True), dict(effort=7)),
     "v160x120_16bit_e7": (160, 120, dict(seed=21, bits=16), dict(effort=7)),
     "v160x120_16bit_pq2100_epf3": (160, 120, dict(seed=21, bits=16), dict(effort=7, epf=3, primaries=9, transfer=16, intensity_target=10000.0)),
+    # RGBA through the reference's encoder call sequence: VarDCT colour + Modular-coded (lossless, no squeeze) alpha
+    "va300x520_e7": (300, 520, dict(seed=5, alpha=True), dict(effort=7)),
+    "va530x270_16bit_e7": (530, 270, dict(seed=8, bits=16, alpha=True), dict(effort=7)),
     "l64_e1": (64, 64, dict(seed=1), dict(lossless=True, effort=1)),
     "l64_e3": (64, 64, dict(seed=1), dict(lossless=True, effort=3)),
     "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),
@@ -45,10 +48,29 @@ CASES = {
 }
 
 
+def with_alpha(img):
+    """deterministic alpha plane: smooth waves plus fully transparent / fully opaque rectangles"""
+    h, w = img.shape[:2]
+    yy, xx = np.mgrid[0:h, 0:w]
+    mx = 65535 if img.dtype == np.uint16 else 255
+    a = (0.5 + 0.47 * np.sin(xx / 37.0) * np.cos(yy / 23.0)) * mx
+    a[: h // 8, : w // 5] = 0
+    a[h // 3: h // 3 + h // 8, w // 2: w // 2 + w // 5] = mx
+    return np.dstack([img[..., :3], a.astype(img.dtype)])
+
+
 def main():
-    meta = {}
+    only = set(sys.argv[1:])
+    meta = json.load(open(os.path.join(HERE, "golden.json"))) if only else {}
     for name, (w, h, sk, ek) in CASES.items():
+        if only and name not in only:
+            continue
+        sk = dict(sk)
+        alpha = sk.pop("alpha", False)
         img = synth.photo_like(w, h, **sk)
+        if alpha:
+            img = with_alpha(img)
+            sk["alpha"] = True
         data = jxl_ref.encode(img, **ek)
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
@@ -56,6 +78,9 @@ def main():
         info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, encode=ek, synth=sk)
         print(name, len(data), out.shape)
+    if only:
+        json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+        return
     # the bench frame: 4K q90 (BASELINE.json configs[1]); expected pixels are too large to commit -> hash only
     img = synth.photo_like(3840, 2160, seed=0)
     data = jxl_ref.encode(img, effort=7, distance=1.0)

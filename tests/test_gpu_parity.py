@@ -33,8 +33,9 @@ def test_golden_vectors(dec, oracle, name):
     ora, _ = oracle.decode(data, 8)
     d2 = np.abs(out.astype(int) - ora.astype(int))
     assert d2.max() <= 1 and (d2 > 0).mean() < 2e-3                           # vs the CPU oracle: same algorithm
-    assert np.all(out[..., 3] == 255)
+    assert np.array_equal(out[..., 3], exp[..., 3])                          # opaque 255, or the Modular-coded alpha bit for bit
     assert info["out_bits"] == 8 and info["prefer_encoding"] == 1
+    assert info["has_alpha_in_origin"] == int(name.startswith("va"))
 
 
 def test_4k_frame_full_size(dec, golden_meta):
@@ -93,7 +94,7 @@ def test_jxlcoder_surface(dec):
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
-    names = ["v264x520_e7", "v256_e7", "v264x520_e7", "v300x300_e7_d3"]      # multi-section and single-section mixed
+    names = ["v264x520_e7", "v256_e7", "va300x520_e7", "v264x520_e7", "v300x300_e7_d3"]      # multi-section, single-section and RGBA mixed
     datas = [load_case(n)[0] for n in names]
     singles = [dec.decode_one_shot(d)[0] for d in datas]
     outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
@@ -112,6 +113,7 @@ def test_16bit_output(dec, name):
     assert out.dtype == np.uint16 and info["out_bits"] == 16
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
+    assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
     if name in U16_CASES:
         assert d.max() <= U16_MAX_ABS
     else:

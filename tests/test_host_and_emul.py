@@ -77,6 +77,7 @@ def test_device_code_on_cpu_harness(emul, oracle, name):
     ora, _ = oracle.decode(data, 8)
     d2 = np.abs(out.astype(int) - ora.astype(int))
     assert d2.max() <= 1 and (d2 > 0).mean() < 1e-3      # same algorithm, different summation order
+    assert np.array_equal(out[..., 3], exp[..., 3])       # alpha (opaque, or Modular-coded) is integer-exact
 
 
 @pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3"])
@@ -114,6 +115,7 @@ def test_device_code_16bit_on_cpu_harness(emul, name):
     assert out.dtype == np.uint16 and out.shape == exp.shape
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
+    assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
     if name in U16_CASES:
         assert d.max() <= U16_MAX_ABS
     else:

@@ -71,6 +71,7 @@ def test_oracle_16bit_output(oracle, name):
     out, info = oracle.decode(data, 16)
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
+    assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
     if name in U16_CASES:
         assert d.max() <= U16_MAX_ABS
     else:

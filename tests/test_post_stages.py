@@ -172,3 +172,20 @@ def test_gpu_decode_bitmap_pipeline_on_pq_image():
             assert np.array_equal(bmp.rows, rows)
         else:                                                            # one LUT step of the u16 colour matrix, then an exact reformat
             assert (bmp.rows != rows).mean() <= 0.03
+
+
+@pytest.mark.gpu
+def test_gpu_decode_bitmap_premultiplies_real_alpha():
+    """RGBA VarDCT file (alpha in origin, not premultiplied): ReformatColorConfig associates alpha before the writers
+    (cpp/ReformatBitmap.cpp:65-77) — on decoded pixels, bit for bit against the oracle's reformat of the same decode."""
+    import jxl_coder_amd as J
+    from conftest import load_case
+    for name, is16 in (("va300x520_e7", False), ("va530x270_16bit_e7", True)):
+        data, _ = load_case(name)
+        raw, info = J.JxlCoder._decoder().decode_one_shot(data, allowed_floats=True)
+        assert info["has_alpha_in_origin"] == 1 and info["alpha_premultiplied"] == 0 and raw[..., 3].min() == 0
+        for cfg in (J.PreferredColorConfig.DEFAULT, J.PreferredColorConfig.RGBA_8888, J.PreferredColorConfig.RGBA_F16, J.PreferredColorConfig.RGBA_1010102):
+            bmp = J.JxlCoder.decodeBitmap(data, cfg, api_level=34)
+            rows, stride, fl, cfgname = P.reformat(raw, int(cfg), 16 if is16 else 8, is16, False, True, 34)
+            assert (bmp.stride, bmp.use_floats, bmp.config) == (stride, fl, cfgname)
+            assert np.array_equal(bmp.rows, rows)

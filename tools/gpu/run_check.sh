@@ -1,2 +1,3 @@
 ulimit -c 0
-for i in 1 2 3; do timeout 900 python -m pytest tests/test_post_stages.py -x -q 2>&1 | tail -2; done
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-120
