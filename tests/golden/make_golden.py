@@ -59,6 +59,20 @@ def with_alpha(img):
     return np.dstack([img[..., :3], a.astype(img.dtype)])
 
 
+ASSETS = {"asset_first_jxl": "first_jxl.jxl", "asset_wide_gamut": "wide_gamut.jxl"}     # data files of the reference (app/src/main/assets)
+
+
+def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
+    """Real photographs: the reference's own demo assets (inputs) + what the reference's libjxl decodes them to."""
+    for name, src in ASSETS.items():
+        data = open(os.path.join(asset_dir, src), "rb").read()
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
+        info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src)
+
+
 def main():
     only = set(sys.argv[1:])
     meta = json.load(open(os.path.join(HERE, "golden.json"))) if only else {}
@@ -78,6 +92,8 @@ def main():
         info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, encode=ek, synth=sk)
         print(name, len(data), out.shape)
+    if not only or "assets" in only:
+        add_assets(meta)
     if only:
         json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
         return
