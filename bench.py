@@ -165,8 +165,8 @@ def main():
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
         flights = max(int(kern.get("flights", 1)), 1)
-        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_batch" if P > 1 else "k_pass_group") + " (+k_lf_smooth)",
-                 "recon_ms": "k_recon_small+k_recon_big+k_gab+k_epf+k_write" if P > 1 else "k_recon_small+k_recon_big", "filters_write_ms": "k_gab+k_epf+k_write"}
+        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt of the first sub-flight" if P > 1 else "k_pass_group") + " (+k_lf_smooth)",
+                 "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt, k_recon_*, k_filter_b<*>" if P > 1 else "k_recon_small+k_recon_list", "filters_write_ms": "k_gab+k_epf+k_write"}
         stages = {k: kern[k] / flights for k in names if k in kern}
         dom = "lf_groups_ms"      # rocprofv3 --stats of this command: k_lf_group_batch has the largest total (profiles/r01_*bench.csv)
         dom_ms = stages[dom]

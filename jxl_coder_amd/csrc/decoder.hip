@@ -7,9 +7,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
 #include <limits>
-#include <mutex>
 #include <thread>
 #include <string>
 #include <vector>
@@ -25,36 +23,6 @@ using namespace jxlamd;
 
 static thread_local std::string g_tls_error;
 
-// Stage gates (optional): decoder contexts of one process (one HIP stream each) decode flights concurrently and their
-// stages may collide (several contexts in the slot-limited LF stage, then several in the throughput-bound
-// reconstruction stage).  JXLAMD_STAGE_GATES="lf,pass,rest" installs a counting gate per stage and device that admits
-// a bounded number of flights into each stage (0 = unlimited, the default: on MI355X every setting tried landed within
-// the run-to-run noise of the ungated pipeline once the data-parallel kernels stopped starving for registers).
-struct StageGate {
-  std::mutex m; std::condition_variable cv; int in_use = 0, limit = 0;
-  void acquire() { if (limit <= 0) return; std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return in_use < limit; }); in_use++; }
-  void release() { if (limit <= 0) return; { std::lock_guard<std::mutex> l(m); in_use--; } cv.notify_one(); }
-};
-struct StageGates { StageGate g[3]; };
-static StageGates &stage_gates(int device) {
-  static std::mutex m; static std::vector<StageGates *> all;
-  std::lock_guard<std::mutex> l(m);
-  if ((int)all.size() <= device) all.resize((size_t)device + 1, nullptr);
-  if (!all[(size_t)device]) {
-    StageGates *G = new StageGates();
-    int lim[3] = {0, 0, 0};        // default: no admission control (measured within noise of the best gate settings)
-    if (const char *e = getenv("JXLAMD_STAGE_GATES")) (void)sscanf(e, "%d,%d,%d", &lim[0], &lim[1], &lim[2]);
-    for (int i = 0; i < 3; i++) G->g[i].limit = lim[i];
-    all[(size_t)device] = G;
-  }
-  return *all[(size_t)device];
-}
-struct GateHold {                  // RAII: leaves the gate on every exit path
-  StageGate *g = nullptr;
-  void enter(StageGate &x) { leave(); x.acquire(); g = &x; }
-  void leave() { if (g) { g->release(); g = nullptr; } }
-  ~GateHold() { leave(); }
-};
 
 struct DevMem {
   void *p = nullptr; size_t cap = 0;
@@ -112,7 +80,8 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, plane_pool, post_lin_lut, post_gam_lut;   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
+  DevMem stat, batch_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
@@ -195,7 +164,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
     d_cs = (const uint8_t *)S.cs.p;
   }
-  HIPCHECK(S.tables.ensure(plan.tables.size() + (8u << 20)));     // room for the phase-2 (HfGlobal) tables
+  HIPCHECK(S.tables.ensure(plan.tables.size() + (plan.single_section ? (8u << 20) : 0u)));     // single-section frames: room for the phase-2 (HfGlobal) tables
   HIPCHECK(S.h_tables.ensure(plan.tables.size()));
   memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
   HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
@@ -204,7 +173,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
     for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
     HIPCHECK(S.coef_off.ensure(ncell * 4));
-    for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));
+    if (own_planes) for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));   // flights: the decoder's coefficient pool
     if (own_planes) for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));   // flights borrow sets of the decoder's plane pool instead
     HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
     HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
@@ -246,6 +215,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     if (!in_flight) HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
     // The reconstruction kernels clear every coefficient they consume, so a slot whose previous decode completed is
     // already all-zero; only fresh / regrown / failed slots are cleared here.
+    if (in_flight) return JXLAMD_OK;                    // flights use the decoder's coefficient pool (decode_batch)
     const size_t coef_bytes = (size_t)plan.num_groups * 65536 * 4;
     const bool clean = S.coef_clean && S.coef_clean_bytes >= coef_bytes && S.coef_clean_ptr[0] == B.coef[0] && S.coef_clean_ptr[1] == B.coef[1] &&
                        S.coef_clean_ptr[2] == B.coef[2];
@@ -384,22 +354,58 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     } else batched.push_back(i);
   }
   if (batched.empty()) return JXLAMD_OK;
-  // device tables of the batch: DevBuffers[], DevAux[], (frame, local index) per block for both entropy kernels
-  // The f32 working planes (6 per frame, 200 MB at 4K) are only alive from reconstruction to the writer, and those
-  // stages run in sub-batches of plane_sets frames: the flight shares plane_sets sets instead of owning one each.
+  // ---- the flight.  Two phases with different buffer lifetimes:
+  //   LF phase : ONE launch decodes the LfGroup streams of all frames of the flight.  Its outputs are small (per-cell planes,
+  //              LF image: ~4 MB per 4K frame), so a flight can be long (hundreds of frames) — which is what the
+  //              latency-bound entropy kernel needs.  (A lane-per-stream variant of this kernel — 64 streams per
+  //              wavefront, state in HBM, no LDS — was measured in round 1: 1.5 s per launch alone, 3-3.8 s next to
+  //              other flights' kernels, i.e. not yet enough frames in flight to win)
+  //   HF phase : PassGroup decode + reconstruction + filters + writer in sub-flights of hf_sets frames that share a pool
+  //              of coefficient sets (106 MB per 4K frame) and, inside, sub-batches of plane_sets frames that share the
+  //              f32 pixel planes (200 MB per frame).  Everything is stream-ordered, so a set is reused only after its
+  //              previous user has been reconstructed (and the reconstruction leaves the coefficient planes all-zero).
   static const int plane_sets = getenv("JXLAMD_PLANE_SETS") ? std::max(1, atoi(getenv("JXLAMD_PLANE_SETS"))) : 16;
-  size_t max_npx = 0;
-  for (int i : batched) max_npx = std::max(max_npx, (size_t)slot((size_t)i).plan.xb * slot((size_t)i).plan.yb * 64);
-  HIPCHECK(plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
-  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map;
-  for (size_t k = 0; k < batched.size(); k++) {
-    FrameSlot &S = slot((size_t)batched[k]);
-    float *set = (float *)plane_pool.p + (k % (size_t)plane_sets) * 6 * max_npx;
-    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; }
-    hb.push_back(S.B); ha.push_back(S.A);
-    for (int g = 0; g < S.plan.num_lf_groups; g++) { lf_map.push_back((int)k); lf_map.push_back(g); }
-    for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back((int)k); pg_map.push_back(g); }
+  static const int hf_sets = std::max(plane_sets, (getenv("JXLAMD_HF_SETS") ? atoi(getenv("JXLAMD_HF_SETS")) : 128) / plane_sets * plane_sets);
+  const int nb = (int)batched.size();
+  size_t max_npx = 0, max_coef = 0;
+  int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 1 << 4;
+  for (int i : batched) {
+    const FrameSlot &S = slot((size_t)i);
+    const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+    max_npx = std::max(max_npx, (size_t)S.plan.xb * S.plan.yb * 64);
+    max_coef = std::max(max_coef, (size_t)S.plan.num_groups * 65536);
+    max_cells = std::max(max_cells, S.plan.xb * S.plan.yb); max_w = std::max(max_w, S.plan.width); max_h = std::max(max_h, S.plan.height);
+    if (F->gab) stage_mask |= 1;
+    if (F->epf_iters >= 3) stage_mask |= 2;
+    if (F->epf_iters >= 1) stage_mask |= 4;
+    if (F->epf_iters >= 2) stage_mask |= 8;
   }
+  HIPCHECK(plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
+  const int used_sets = std::min(hf_sets, nb);
+  const size_t coef_need = (size_t)used_sets * 3 * max_coef * 4;
+  if (coef_need > coef_pool.cap || !coef_pool_clean) {      // (re)allocated or left dirty by a failed flight: clear once
+    HIPCHECK(coef_pool.ensure(coef_need));
+    HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));
+  }
+  coef_pool_clean = false;                                   // until every frame of this flight has been collected without error
+  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map;
+  std::vector<size_t> pg_off;                                // per sub-flight: first entry of its PassGroup map
+  for (int k = 0; k < nb; k++) {
+    FrameSlot &S = slot((size_t)batched[(size_t)k]);
+    float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * 6 * max_npx;
+    int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
+    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = cset + (size_t)c * max_coef; }
+    hb.push_back(S.B); ha.push_back(S.A);
+    if (k % hf_sets == 0) pg_off.push_back(pg_map.size() / 2);
+    for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
+  }
+  pg_off.push_back(pg_map.size() / 2);
+  // LF map: group-major — the long streams (full 256x256-cell LF groups, 240 ms) are dispatched first and the short edge
+  // groups (15 ms) fill the slots they leave, instead of long and short workgroups alternating
+  int max_lfg = 0;
+  for (int i : batched) max_lfg = std::max(max_lfg, slot((size_t)i).plan.num_lf_groups);
+  for (int g = 0; g < max_lfg; g++)
+    for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
                o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, total = o_pg + pg_map.size() * 4;
   HIPCHECK(batch_tab.ensure(total));
@@ -410,42 +416,30 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
   memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
   HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
-  StageGates &gates = stage_gates(device);
-  GateHold gate;
-  gate.enter(gates.g[0]);
+  const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
+  const DevAux *dA = (const DevAux *)(bt + o_a);
   HIPCHECK(hipEventRecord(ev[0], stream));
-  { int mc = 0; for (int i : batched) mc = std::max(mc, slot((size_t)i).plan.xb * slot((size_t)i).plan.yb);
-    launch_clear_batch((const DevBuffers *)(bt + o_b), (int)batched.size(), mc, stream); }
-  launch_lf_groups_batch((const DevBuffers *)(bt + o_b), (const DevAux *)(bt + o_a), (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
+  launch_clear_batch(dB, nb, max_cells, stream);
+  launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
-  HIPCHECK(hipEventSynchronize(ev[1]));
-  gate.enter(gates.g[1]);
-  int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 1 << 4;
-  for (int i : batched) {
-    const FrameSlot &S = slot((size_t)i);
-    const DevFrame *F = (const DevFrame *)S.plan.tables.data();
-    max_cells = std::max(max_cells, S.plan.xb * S.plan.yb); max_w = std::max(max_w, S.plan.width); max_h = std::max(max_h, S.plan.height);
-    if (F->gab) stage_mask |= 1;
-    if (F->epf_iters >= 3) stage_mask |= 2;
-    if (F->epf_iters >= 1) stage_mask |= 4;
-    if (F->epf_iters >= 2) stage_mask |= 8;
+  launch_lf_smooth_batch(dB, nb, max_cells, stream);
+  for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
+    const int cnt = std::min(hf_sets, nb - k0);
+    const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
+    const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
+    // >= simt_min_groups groups: one LANE per group (64 streams per wavefront); below that the one-wave-per-group kernel has
+    // the shorter critical path
+    if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
+    else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
+    if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
+    for (int j0 = 0; j0 < cnt; j0 += plane_sets)
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, stream);
   }
-  launch_lf_smooth_batch((const DevBuffers *)(bt + o_b), (int)batched.size(), max_cells, stream);
-  // >= simt_min_groups groups in the flight: one LANE per group (64 streams per wavefront); below that the one-wave-per-group
-  // kernel has the shorter critical path
-  if ((int)pg_map.size() / 2 >= simt_min_groups) launch_pass_groups_simt((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
-  else launch_pass_groups_batch((const DevBuffers *)(bt + o_b), (const int *)(bt + o_pg), (int)pg_map.size() / 2, stream);
-  HIPCHECK(hipEventRecord(ev[2], stream));
-  HIPCHECK(hipEventSynchronize(ev[2]));
-  gate.enter(gates.g[2]);
-  for (int k0 = 0; k0 < (int)batched.size(); k0 += plane_sets)
-    launch_rest_batch((const DevBuffers *)(bt + o_b) + k0, (const uint8_t *)stat.p, std::min(plane_sets, (int)batched.size() - k0), max_cells, max_w, max_h,
-                      stage_mask, stream);
   HIPCHECK(hipEventRecord(ev[4], stream));
   int first_rc = JXLAMD_OK;
   for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }
-  gate.leave();
-  (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);
+  coef_pool_clean = first_rc == JXLAMD_OK;
+  (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
   return first_rc;
 }
@@ -471,7 +465,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
+  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release(); d->coef_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);

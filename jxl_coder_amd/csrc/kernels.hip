@@ -26,6 +26,10 @@ __global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
 // batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map) {
   __shared__ DevModScratch S;
+  // Issue priority: this wave walks one long dependency chain (one instruction in flight at a time) next to data-parallel
+  // waves with many ready instructions; without priority it waits for an issue slot each time it becomes ready, which
+  // stretches the 240 ms it holds its LDS / register footprint.  It uses < 1/4 of the SIMD's issue slots at full speed.
+  __builtin_amdgcn_s_setprio(3);
   // readfirstlane: the frame index is wave-uniform, so the DevBuffers fields come through scalar loads into SGPRs
   // (as with the by-value kernel argument of k_lf_group) instead of occupying ~60 VGPRs
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
@@ -40,6 +44,7 @@ __global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, c
 // lane-per-stream PassGroup kernel (batch mode): lane l of block b decodes group map[b*64+l]
 __global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, const int *map, int total) {
   __shared__ uint16_t freq_ctx[64], nnz_ctx[64];
+  __builtin_amdgcn_s_setprio(2);           // latency-bound like the LF waves (see k_lf_group_batch), but 64 streams per wave
   freq_ctx[threadIdx.x] = kCoeffFreqContext[threadIdx.x]; nnz_ctx[threadIdx.x] = kCoeffNumNonzeroContext[threadIdx.x];
   __syncthreads();
   const int i = (int)(blockIdx.x * 64 + threadIdx.x);
