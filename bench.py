@@ -139,8 +139,8 @@ def main():
         assert acc.get("frames", 0) == n, (acc.get("frames", 0), n)
         return acc
 
-    run_steps(P * NCTX)              # untimed setup: every context allocates the HBM work buffers of a full flight
-    run_steps(max(args.warmup, 0))   # W untimed warmup steps
+    prime = run_steps(P * NCTX)              # untimed setup: every context allocates the HBM work buffers of a full flight
+    warm = run_steps(max(args.warmup, 0)) if args.warmup > 0 else {}   # W untimed warmup steps
     # sequential single-frame latency (one context), reported next to the throughput
     lat = []
     for _ in range(3):
@@ -188,6 +188,10 @@ def main():
                          # PMC passes (profiles/r01_pmc_fetch_write_4k_single_frame.json): FETCH 1 869 KB + WRITE 4 479 KB per frame
                          "traffic": int(frames_per_launch * (1868.9 + 4478.8) * 1024),
                          "kernel": names[dom], "kernel_ms": round(dom_ms, 4), "launches": flights,
+                         # the same HIP-event average over EVERY batched launch of the process (priming + warm-up + timed): the
+                         # figure to hold against the rocprofv3 --stats average of this command, which cannot tell them apart
+                         "kernel_ms_all_launches": round(sum(a.get(dom, 0.0) for a in (prime, warm, kern) if a.get("frames", 0) > 1 or a is kern) /
+                                                         max(sum(int(a.get("flights", 0)) for a in (prime, warm, kern) if a.get("frames", 0) > 1 or a is kern), 1), 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes * frames_per_launch),
                          "stage_ms_per_flight": {k: round(v, 4) for k, v in stages.items()},
                          "note": "the entropy-decode kernels are latency/occupancy-bound (one wavefront per serial rANS stream), not "
