@@ -81,6 +81,7 @@ struct jxlamd_decoder {
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch;
   std::vector<FrameSlot *> slots;
@@ -277,11 +278,14 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
 
 int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   uint32_t derr = 0;
-  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  uint32_t head[20] = {0};                              // flags word and, at byte 64, the size-class block counters
+  HIPCHECK(hipMemcpyAsync(head, S.B.err, sizeof(head), hipMemcpyDeviceToHost, stream));
   if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
   (void)flags;
+  derr = head[0];
+  if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
   return JXLAMD_OK;
@@ -433,12 +437,14 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, stream);
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, stream);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   int first_rc = JXLAMD_OK;
+  large_blocks_seen = false;
   for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }
   coef_pool_clean = first_rc == JXLAMD_OK;
+  large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
   return first_rc;

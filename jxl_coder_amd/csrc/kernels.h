@@ -8,7 +8,8 @@ void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, h
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
-void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, hipStream_t s);
+void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
+                       hipStream_t s);
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);

@@ -260,10 +260,13 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
   else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
 }
 
-void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, hipStream_t s) {
+void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
+                       hipStream_t s) {
   hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
   hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(256, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(64, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
+  // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? 64 : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
   if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat);
   if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat);
