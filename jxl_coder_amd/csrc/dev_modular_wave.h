@@ -57,10 +57,10 @@ __device__ __forceinline__ void wave_tree_build(const DevTreeNode *tree, int cou
 
 // rANS symbol + hybrid uint with every table addressed directly in LDS (ds_read instead of flat loads through
 // generic pointers); used when the stream's code fits the LDS staging area, which is the case for libjxl's streams.
+// `cluster` = ctx_map[ctx], resolved once per leaf at channel start (it used to be a dependent LDS round trip per sample)
 template <bool kLds>
-__device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx) {
+__device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t ctx, uint32_t cluster) {
   if (!kLds) return ec_read(v, b, state, ctx);
-  const uint32_t cluster = ((const uint8_t *)S.pool)[S.ctx_off + ctx];
   const int lb = 12 - v.log_alpha;
   const uint32_t res = state & 0xfff;
   const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
@@ -115,7 +115,31 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
   // lane j keeps leaf j's record in registers; the selected leaf's record is fetched with v_readlane (no LDS trip)
   const int my_lctx = lane < nl ? WT.leaf_ctx[lane] : 0, my_lpred = lane < nl ? WT.leaf_pred[lane] : 0;
   const int my_loff = lane < nl ? WT.leaf_off[lane] : 0, my_lmul = lane < nl ? WT.leaf_mul[lane] : 1;
+  const int my_lclu = (kLds && lane < nl) ? (int)((const uint8_t *)S.pool)[S.ctx_off + my_lctx] : 0;
   // the WP's reciprocal table (1<<24)/(i+1), i < 64: lane i holds entry i; lookups are v_readlane with a uniform index
+  // kM16: every MA property is a signed sum of per-sample inputs (W, N, NW, NE, NN, WW, the previous sample's property 9,
+  // x, y, the WP's max error), two of them under |.|.  Lane i keeps the coefficient row of ITS decision node and splits
+  // the sum into the part that is known before the previous sample's value arrives (everything but W and the WP error)
+  // and two 24-bit multiply-adds on the critical path — the 13-deep select chain over all properties used to sit there.
+  int cW = 0, cN = 0, cNW = 0, cNE = 0, cNN = 0, cWW = 0, cP9 = 0, cX = 0, cY = 0, cE = 0;
+  bool cAbs = false;
+  switch (my_prop) {
+    case 2: cY = 1; break;
+    case 3: cX = 1; break;
+    case 4: cN = 1; cAbs = true; break;
+    case 5: cW = 1; cAbs = true; break;
+    case 6: cN = 1; break;
+    case 7: cW = 1; break;
+    case 8: cW = 1; cP9 = -1; break;
+    case 9: cW = 1; cN = 1; cNW = -1; break;
+    case 10: cW = 1; cNW = -1; break;
+    case 11: cNW = 1; cN = -1; break;
+    case 12: cN = 1; cNE = -1; break;
+    case 13: cN = 1; cNN = -1; break;
+    case 14: cW = 1; cWW = -1; break;
+    case 15: cE = 1; break;
+    default: break;
+  }
   const int my_div = (int)S.divlut[lane];
   #define WAVE_DIV(idx) ((uint32_t)__builtin_amdgcn_readlane(my_div, __builtin_amdgcn_readfirstlane((int)(idx))))
   if (kWP) {
@@ -147,13 +171,23 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       const T WW_ = x > 1 ? vWW : W_;
       const int32_t nextNEE = (y > 0 && x + 3 < w) ? rN[x + 3] : 0;     // independent of this sample: issued early
       const int32_t p9 = (int32_t)(W_ + N_ - NW_);
+      const int32_t p9_prev = prev_prop9;
       int32_t pv[16];
-      pv[2] = y; pv[3] = x;
-      pv[4] = (int32_t)tabs<T>(N_); pv[5] = (int32_t)tabs<T>(W_);
-      pv[6] = (int32_t)N_; pv[7] = (int32_t)W_;
-      pv[8] = (int32_t)(W_ - prev_prop9); pv[9] = p9; prev_prop9 = p9;
-      pv[10] = (int32_t)(W_ - NW_); pv[11] = (int32_t)(NW_ - N_); pv[12] = (int32_t)(N_ - NE_);
-      pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_); pv[15] = 0;
+      #define M24(a, b) __mul24((a), (int)(b))
+      int32_t early = 0;
+      if (kM16) {
+        // the raw window registers, not the edge-substituted W_/N_/...: at the image edges the substitutes ARE late values
+        early = (M24(cN, N_) + M24(cNW, NW_)) + (M24(cNE, NE_) + M24(cNN, NN_)) + (M24(cWW, WW_) + M24(cP9, p9_prev)) + (M24(cX, x) + M24(cY, y));
+      } else {
+        pv[2] = y; pv[3] = x;
+        pv[4] = (int32_t)tabs<T>(N_); pv[5] = (int32_t)tabs<T>(W_);
+        pv[6] = (int32_t)N_; pv[7] = (int32_t)W_;
+        pv[8] = (int32_t)(W_ - prev_prop9); pv[9] = p9;
+        pv[10] = (int32_t)(W_ - NW_); pv[11] = (int32_t)(NW_ - N_); pv[12] = (int32_t)(N_ - NE_);
+        pv[13] = (int32_t)(N_ - NN_); pv[14] = (int32_t)(W_ - WW_);
+      }
+      pv[15] = 0;
+      prev_prop9 = p9;
       T wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
       if (kWP) {
         uint32_t wgt[4];
@@ -191,17 +225,26 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         wp_pred = (wp_raw + 3) >> 3;
       }
       // MA tree by ballot: lane i decides node i, lane j tests leaf j, the chosen leaf's record comes by readlane
-      int32_t myv = pv[2];
-      #pragma unroll
-      for (int k = 3; k < 16; k++) myv = my_prop == k ? pv[k] : myv;
+      int32_t myv;
+      if (kM16) {
+        myv = early + M24(cW, W_) + M24(cE, pv[15]);
+        if (cAbs) myv = myv < 0 ? -myv : myv;
+      } else {
+        myv = pv[2];
+        #pragma unroll
+        for (int k = 3; k < 16; k++) myv = my_prop == k ? pv[k] : myv;
+      }
+      #undef M24
       const uint64_t dec = __ballot(lane < ni && myv > my_split);
       const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
       const int leaf = lm ? __builtin_ctzll(lm) : 0;
       const int l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf), l_pred = __builtin_amdgcn_readlane(my_lpred, leaf);
       const int l_off = __builtin_amdgcn_readlane(my_loff, leaf), l_mul = __builtin_amdgcn_readlane(my_lmul, leaf);
       const T guess = predict_plain_t<T>(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
-      const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx);
-      const T val = (T)unpack_signed(u) * (T)l_mul + (T)l_off + guess;
+      const int l_clu = __builtin_amdgcn_readlane(my_lclu, leaf);
+      const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
+      const T res = (T)unpack_signed(u);
+      const T val = (l_mul == 1 ? res : res * (T)l_mul) + (T)l_off + guess;      // l_mul is wave-uniform: the multiply is branched around
       if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
       vWW = vW; vW = (int32_t)val;
       vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
