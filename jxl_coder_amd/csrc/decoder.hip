@@ -52,8 +52,8 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
-struct FrameSlot {
-  bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};             // HBM work buffers of one in-flight frame
+struct FrameSlot {             // HBM work buffers of one in-flight frame
+  bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
   PinnedMem h_tables, h_cs;
   DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
   FramePlan plan;
