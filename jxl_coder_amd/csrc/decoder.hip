@@ -205,7 +205,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
                                 B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
   B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
-  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p; B.pass_end_bits = (uint64_t *)S.pass_end.p;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p; B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out; B.out_bits = (int32_t)S.pi.out_bits;
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
@@ -254,12 +254,12 @@ int jxlamd_decoder::launch_rest(FrameSlot &S) {
   return JXLAMD_OK;
 }
 
-// Extra channels of a VarDCT frame (alpha): GlobalModular part (meta channels, channels that fit one group), then the
-// ModularGroup stream that follows each group's AC stream, then the inverse global transforms.  The writer reads the planes.
+// Extra channels of a VarDCT frame (alpha).  The GlobalModular part (meta channels, channels that fit one group) is decoded
+// BEFORE the LF stage (launch_mod_global at the call sites: in a single-section frame LfGroup 0 starts where it ends); this is the
+// rest: the ModularGroup stream that follows each group's AC stream, then the inverse global transforms.  The writer reads the planes.
 int jxlamd_decoder::launch_extra_channels(FrameSlot &S) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  launch_mod_global(S.B, stream);
   if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
   return JXLAMD_OK;
@@ -305,6 +305,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
     (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
     return rc;
   }
+  if (S.plan.has_ec) launch_mod_global(S.B, stream);
   launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
@@ -348,6 +349,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (rc) return rc;
     if (S.plan.modular) { launch_modular(S); rc = collect(S, flags); if (rc) return rc; continue; }
     if (S.plan.single_section || S.plan.has_ec) {
+      if (S.plan.has_ec) launch_mod_global(S.B, stream);
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
       if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
       launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);

@@ -64,6 +64,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
   sync();
   uint32_t e = mod_decode_stream(S, S.ch, n, 0, tid);
   if (tid == 0 && e) *B.err |= e | kErrStageLf;
+  if (tid == 0 && F.has_ec) *B.mod_end_bit = S.st.b.consumed;      // absolute: the reader started at the section and skipped mod_global_bit
   sync();
 }
 

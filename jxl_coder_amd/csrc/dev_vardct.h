@@ -32,6 +32,7 @@ struct DevBuffers {
   int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
   uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
   uint32_t *big_count;          // [3] their counts
+  uint64_t *mod_end_bit;        // [1]: where the GlobalModular stream of an extra-channel frame ended (single-section frames: LfGroup 0 starts there)
   uint64_t *pass_end_bits;      // [num_groups]: where the AC stream of a group ended (extra-channel frames: its ModularGroup stream starts there)
   uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
   uint32_t *err;
@@ -61,12 +62,9 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
   DevBits b;
-  bits_init(b, B.codestream, sec.off, F.cs_size);
-  if (F.nsec == 1) {   // single-section frame: skip the LfGlobal bits the host parsed
-    uint32_t skip = F.single_lf_bit;
-    while (skip >= 32) { bits_read(b, 32); skip -= 32; }
-    bits_read(b, (int)skip);
-  }
+  if (F.nsec == 1) {   // single-section frame: LfGroup 0 follows LfGlobal (host-parsed) and, with extra channels, the GlobalModular stream the device decoded
+    bits_init_at_bit(b, B.codestream, sec.off, F.has_ec ? *B.mod_end_bit : (uint64_t)F.single_lf_bit, F.cs_size);
+  } else bits_init(b, B.codestream, sec.off, F.cs_size);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   scr[kLfScratchInts - 1] = (int32_t)bits_read(b, 2);      // extra_precision
   S.st.b = b;

@@ -371,7 +371,6 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   F.single_lf_bit = (uint32_t)sb.pos;
   if (f.encoding == 1 && parse_modular_global(plan, pv, &sb)) return -1;
   if (f.encoding == 0 && m.num_extra) {
-    if (nsec == 1) { plan->error = "unsupported: extra channels on a single-section (<= 256 px) VarDCT frame"; return -1; }
     if (parse_modular_global(plan, pv, &sb, /*vardct=*/true)) return -1;
     plan->has_ec = true;
   }

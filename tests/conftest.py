@@ -68,7 +68,7 @@ def emul():
 
 VARDCT_CASES = ["v64_e3_gab0_epf0", "v256_e3_gab0_epf0", "v256_e3_gab1_epf0", "v256_e3_gab0_epf1", "v256_e3_gab0_epf2",
                 "v256_e3_gab0_epf3", "v256_e7", "v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "v64_hard_e7",
-                "va300x520_e7",        # va*: RGBA, VarDCT colour + Modular-coded alpha (alpha must come out bit-exact)
+                "va300x520_e7", "va200x150_e7",        # va*: RGBA, VarDCT colour + Modular-coded alpha (alpha must come out bit-exact)
                 "asset_first_jxl", "asset_wide_gamut"]   # real photographs: two of the reference's demo assets (app/src/main/assets)
 LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x260_e5", "l700x500_e7"]
 # lossless cases the DEVICE path decodes (l64_e1 is libjxl's effort-1 fast path: LZ77 inside group streams -> rejected loudly)

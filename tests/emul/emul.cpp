@@ -65,6 +65,8 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     return 0;
   }
   DevModScratch *MS = new DevModScratch();
+  uint64_t mod_end = 0; B.mod_end_bit = &mod_end;
+  if (plan.has_ec) mod_global_body(B, *MS, 0, 1, NoSync());       // GlobalModular part of the extra channels: before LfGroup 0
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
   delete MS;
   if (err) { g_err = "device flags " + std::to_string(err) + " (LfGroup)"; return -2; }
@@ -90,7 +92,6 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   if (plan.has_ec) {                          // extra channels (alpha): same order as jxlamd_decoder::launch_extra_channels
     const DevFrame &F = *(const DevFrame *)tables.data();
     DevModScratch *MS2 = new DevModScratch();
-    mod_global_body(B, *MS2, 0, 1, NoSync());
     if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS2, g, 0, 1, NoSync());
     delete MS2;
     if (err) { g_err = "device flags " + std::to_string(err) + " (extra channels)"; return -2; }

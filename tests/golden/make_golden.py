@@ -38,6 +38,7 @@ CASES = {
     # RGBA through the reference's encoder call sequence: VarDCT colour + Modular-coded (lossless, no squeeze) alpha
     "va300x520_e7": (300, 520, dict(seed=5, alpha=True), dict(effort=7)),
     "va530x270_16bit_e7": (530, 270, dict(seed=8, bits=16, alpha=True), dict(effort=7)),
+    "va200x150_e7": (200, 150, dict(seed=9, alpha=True), dict(effort=7)),         # single-section frame: alpha lives in GlobalModular, LfGroup 0 starts where it ends
     "l64_e1": (64, 64, dict(seed=1), dict(lossless=True, effort=1)),
     "l64_e3": (64, 64, dict(seed=1), dict(lossless=True, effort=3)),
     "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),
