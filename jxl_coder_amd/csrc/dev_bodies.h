@@ -35,7 +35,11 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   JXL_STAMP(3);
   e = lf_phase_meta<kWave>(B, S, g, tid);
   JXL_STAMP(4);
-  if (tid == 0) { if (!e) e = lf_phase_place(B, S, g, A.lf_end_bits); if (e) { S.st.err = e; *B.err |= e | kErrStageLf | (1u << 20); } }
+  if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStageLf | (1u << 20); }
+  sync();
+  if (S.st.err) return;
+  e = lf_phase_place(B, S, g, A.lf_end_bits, tid, nthreads, sync);      // uniform result
+  if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStageLf | (1u << 20); }
   sync();
   if (S.st.err) return;
   JXL_STAMP(5);

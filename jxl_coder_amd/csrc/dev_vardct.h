@@ -117,8 +117,12 @@ JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int
   ch[3].d = m_sharp; ch[3].w = q.bw; ch[3].h = q.bh;
   return lf_decode_stream<kWave>(S, ch, 4, 1 + 2 * F.num_lf_groups + g, tid);
 }
-// phase 3b (lane 0): place the varblocks
-JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits) {
+// phase 3b (all lanes in lock-step): place the varblocks.  The raster scan over the occupancy bitmap is serial by definition
+// (a block goes to the first cell still free) and every lane walks it identically; what the lanes share out is the
+// per-cell bookkeeping of each block (up to 64 covered cells x 3 byte planes).  Lane 0 owns the bitmap and the lists;
+// a wavefront's LDS accesses complete in program order, so the other lanes read what it wrote the iteration before.
+template <class Sync>
+JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, uint64_t *end_bits, int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
   const int bx0 = q.bx0, by0 = q.by0, bw = q.bw, bh = q.bh;
@@ -128,13 +132,14 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
   const DevBits &b = S.st.b;
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
   const DevSection sec = secs[F.nsec == 1 ? 0 : 1 + g];
-  if (end_bits) end_bits[g] = b.consumed;
+  if (end_bits && tid == 0) end_bits[g] = b.consumed;
   if (b.consumed > (uint64_t)sec.size * 8 + 64 && F.nsec != 1) return kErrBitstream;
   // --- varblock placement: the next block goes to the first unoccupied cell in raster order.  Occupancy is a
   // bitmap in LDS (the alias-table area is free once the streams are decoded), scanned a 32-bit word at a time, so
   // the serial cost scales with the number of varblocks, not with the 65 536 cells.
   uint32_t *occ = (uint32_t *)S.pool;                  // 256 rows x 8 words (8 KiB <= kModPoolBytes)
-  for (int i = 0; i < 256 * 8; i++) occ[i] = 0;
+  for (int i = tid; i < 256 * 8; i += nthreads) occ[i] = 0;
+  sync();
   int num = 0;
   for (int y = 0; y < bh; y++) {
     for (int wx = 0; wx < (bw + 31) / 32; wx++) {
@@ -153,17 +158,18 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
         const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1u)) << (x & 31);
         const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
         for (int iy = 0; iy < cy; iy++) {
-          uint32_t &wd = occ[(y + iy) * 8 + wx];
-          if (wd & mask) return kErrBitstream;               // overlapping varblocks
-          wd |= mask;
-          for (int ix = 0; ix < cx; ix++) {
-            const size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
-            B.strategy[oo] = (uint8_t)st; B.first[oo] = 0; B.qfm1[oo] = (uint8_t)q;
-          }
+          if (occ[(y + iy) * 8 + wx] & mask) return kErrBitstream;               // overlapping varblocks (uniform: every lane sees the same word)
         }
-        B.first[o] = 1;
+        sync();                                    // all lanes have read the words before lane 0 updates them
+        if (tid == 0) for (int iy = 0; iy < cy; iy++) occ[(y + iy) * 8 + wx] |= mask;
+        sync();
+        for (int c = tid; c < cx * cy; c += nthreads) {
+          const int iy = c / cx, ix = c - iy * cx;
+          const size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
+          B.strategy[oo] = (uint8_t)st; B.first[oo] = (uint8_t)(c == 0); B.qfm1[oo] = (uint8_t)q;
+        }
         const int ncoef = cx * cy * 64;
-        if (ncoef <= 4096) {                     // size-class lists: the reconstruction kernels walk them
+        if (tid == 0 && ncoef <= 4096) {         // size-class lists: the reconstruction kernels walk them
           const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
 #ifdef __HIPCC__
           const uint32_t slot = atomicAdd(&B.big_count[cls], 1u);
