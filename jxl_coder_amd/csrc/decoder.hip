@@ -220,8 +220,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     const size_t coef_bytes = (size_t)plan.num_groups * 65536 * 4;
     const bool clean = S.coef_clean && S.coef_clean_bytes >= coef_bytes && S.coef_clean_ptr[0] == B.coef[0] && S.coef_clean_ptr[1] == B.coef[1] &&
                        S.coef_clean_ptr[2] == B.coef[2];
-    static const bool force_clear = getenv("JXLAMD_FORCE_COEF_MEMSET") != nullptr;   // A/B knob
-    if (!clean || force_clear) for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, S.coef[c].cap, stream));
+    if (!clean) for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, S.coef[c].cap, stream));
     S.coef_clean = false;                              // until collect() has seen this decode succeed
     for (int c = 0; c < 3; c++) S.coef_clean_ptr[c] = B.coef[c];
     S.coef_clean_bytes = std::min(std::min(S.coef[0].cap, S.coef[1].cap), S.coef[2].cap);

@@ -300,8 +300,7 @@ void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hi
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) {
-  static const int pad = getenv("JXLAMD_LF_PAD_LDS") ? atoi(getenv("JXLAMD_LF_PAD_LDS")) : 0;   // experiment knob: extra dynamic LDS per LfGroup workgroup
-  hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), pad, s, Bs, As, map);
+  hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map);
 }
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }
