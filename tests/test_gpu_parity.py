@@ -129,3 +129,31 @@ def test_lossless_bit_exact(dec, name):
     out, info = dec.decode_one_shot(data)
     assert out.dtype == exp.dtype and np.array_equal(out, exp)
     assert info["uses_original_profile"] == 1
+
+
+def test_flight_subflights_and_pools_in_a_small_configuration():
+    """decode_batch runs its HF phase in sub-flights over shared coefficient / pixel-plane pools (128 / 16 sets by default, far more
+    than a test batch).  A child process with JXLAMD_HF_SETS=2, JXLAMD_PLANE_SETS=1 forces 3 sub-flights and 5 plane sub-batches for
+    5 frames of different sizes; the pixels must equal the single decodes bit for bit (the knobs are read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from conftest import load_case
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        names = ["v264x520_e7", "asset_first_jxl", "v267x131_e7", "v264x520_e7", "v300x300_e7_d3"]
+        datas = [load_case(n)[0] for n in names]
+        singles = [dec.decode_one_shot(d)[0] for d in datas]
+        for rep in range(2):                                   # second flight reuses the (now dirty-then-cleared) pools
+            outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+            torch.cuda.synchronize()
+            dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            torch.cuda.synchronize()
+            for s, o in zip(singles, outs):
+                assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+        print("subflights ok")
+    """) % (ROOT, ROOT + "/tests")
+    env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "subflights ok" in r.stdout, r.stdout + r.stderr
