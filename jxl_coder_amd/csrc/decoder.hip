@@ -80,10 +80,10 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
-  PinnedMem h_batch;
+  PinnedMem h_batch, h_mod_tab;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
   int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
@@ -330,7 +330,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   HIPCHECK(hipSetDevice(device));
-  std::vector<int> batched;
+  std::vector<int> batched, mod_batched;
   // host parse of all frames in parallel (pure CPU work, independent per frame)
   for (int i = 0; i < n; i++) { slot((size_t)i).plan = FramePlan(); }
   {
@@ -346,7 +346,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
                      /*own_planes=*/S.plan.modular || S.plan.single_section || S.plan.has_ec);
     if (rc) return rc;
-    if (S.plan.modular) { launch_modular(S); rc = collect(S, flags); if (rc) return rc; continue; }
+    if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section || S.plan.has_ec) {
       if (S.plan.has_ec) launch_mod_global(S.B, stream);
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
@@ -357,6 +357,29 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
       launch_rest(S);
       rc = collect(S, flags); if (rc) return rc;
     } else batched.push_back(i);
+  }
+  // ---- Modular-encoded (lossless) frames of the batch: their streams are as serial as the LF streams, so they too go into one
+  // launch per stage over all of them (GlobalModular streams, then every 256x256 group stream, inverse transforms, writer)
+  if (!mod_batched.empty()) {
+    std::vector<DevBuffers> hb; std::vector<int> gmap;
+    int max_ops = 0, mw = 0, mh = 0;
+    for (size_t k = 0; k < mod_batched.size(); k++) {
+      const FrameSlot &S = slot((size_t)mod_batched[k]);
+      const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+      hb.push_back(S.B);
+      if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { gmap.push_back((int)k); gmap.push_back(g); }
+      max_ops = std::max(max_ops, (int)F->mod_nops); mw = std::max(mw, S.plan.width); mh = std::max(mh, S.plan.height);
+    }
+    const size_t o_g = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, total = o_g + gmap.size() * 4 + 4;
+    HIPCHECK(mod_tab.ensure(total));
+    HIPCHECK(h_mod_tab.ensure(total));
+    memcpy(h_mod_tab.p, hb.data(), hb.size() * sizeof(DevBuffers));
+    if (!gmap.empty()) memcpy((uint8_t *)h_mod_tab.p + o_g, gmap.data(), gmap.size() * 4);
+    HIPCHECK(hipMemcpyAsync(mod_tab.p, h_mod_tab.p, total, hipMemcpyHostToDevice, stream));
+    launch_modular_batch((const DevBuffers *)mod_tab.p, (const int *)((uint8_t *)mod_tab.p + o_g), (int)hb.size(), (int)gmap.size() / 2, max_ops, mw, mh, stream);
+    int first_mod_rc = JXLAMD_OK;
+    for (int i : mod_batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_mod_rc) first_mod_rc = rc; }
+    if (first_mod_rc) return first_mod_rc;
   }
   if (batched.empty()) return JXLAMD_OK;
   // ---- the flight.  Two phases with different buffer lifetimes:
@@ -472,7 +495,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->h_batch.release(); d->plane_pool.release(); d->coef_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
+  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);

@@ -203,6 +203,40 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
   hipLaunchKernelGGL(k_mod_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, out_bits, w, h);
 }
 
+// ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
+__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
+  __shared__ DevModScratch S;
+  mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map) {
+  __shared__ DevModScratch S;
+  const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
+  const DevBuffers &B = Bs[f];
+  const DevFrame &F = frame_of(B);
+  if (F.mod_first_group_ch >= F.mod_nch) return;
+  mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (op >= F.mod_nops) return;
+  const size_t n = (size_t)(F.mod_op_kind[op] == 0 ? F.mod_op_y[op] : F.mod_op_c[op]);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mod_op_element(B, F, op, i);
+}
+__global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height) return;
+  mod_write_pixel(B, B.out_bits, x, y);
+}
+void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s) {
+  hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);
+  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+  for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
+  hipLaunchKernelGGL(k_mod_write_b, dim3((max_w + 63) / 64, (max_h + 3) / 4, nframes), dim3(256), 0, s, Bs);
+}
+
 // ---- batched data-parallel stages: blockIdx.z = frame of the flight (per-frame dims come from its DevFrame)
 // Which plane set holds the image before filter stage `stage` (0 gab, 1 epf0, 2 epf1, 3 epf2, 4 write), and does the
 // frame run that stage at all?

@@ -94,7 +94,7 @@ def test_jxlcoder_surface(dec):
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
-    names = ["v264x520_e7", "v256_e7", "va300x520_e7", "v264x520_e7", "v300x300_e7_d3"]      # multi-section, single-section and RGBA mixed
+    names = ["v264x520_e7", "l700x500_e7", "v256_e7", "va300x520_e7", "l200x120_e7", "v264x520_e7", "l64_e7", "v300x300_e7_d3"]   # multi-/single-section VarDCT, RGBA and Modular (lossless) mixed
     datas = [load_case(n)[0] for n in names]
     singles = [dec.decode_one_shot(d)[0] for d in datas]
     outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
