@@ -184,13 +184,13 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
     if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
+      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(((const DevFrame *)plan.tables.data())->mod_nch - ((const DevFrame *)plan.tables.data())->mod_first_group_ch) * 65536 * 4 + 256));
       HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * kModGroupScratchInts * 4));
+    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(((const DevFrame *)plan.tables.data())->mod_nch - ((const DevFrame *)plan.tables.data())->mod_first_group_ch) * 65536 * 4 + 256));
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
@@ -344,10 +344,10 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     FrameSlot &S = slot((size_t)i);
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
-                     /*own_planes=*/S.plan.modular || S.plan.single_section || S.plan.has_ec);
+                     /*own_planes=*/S.plan.modular || S.plan.single_section);
     if (rc) return rc;
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
-    if (S.plan.single_section || S.plan.has_ec) {
+    if (S.plan.single_section) {
       if (S.plan.has_ec) launch_mod_global(S.B, stream);
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
       if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
@@ -416,18 +416,26 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));
   }
   coef_pool_clean = false;                                   // until every frame of this flight has been collected without error
-  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map;
-  std::vector<size_t> pg_off;                                // per sub-flight: first entry of its PassGroup map
+  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map;
+  std::vector<size_t> pg_off, ec_off;                        // per sub-flight: first entry of its PassGroup map / extra-channel group map
+  std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
+  bool any_ec = false;
   for (int k = 0; k < nb; k++) {
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * 6 * max_npx;
     int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
     for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = cset + (size_t)c * max_coef; }
     hb.push_back(S.B); ha.push_back(S.A);
-    if (k % hf_sets == 0) pg_off.push_back(pg_map.size() / 2);
+    if (k % hf_sets == 0) { pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); }
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
+    if (S.plan.has_ec) {
+      const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+      any_ec = true;
+      ec_ops.back() = std::max(ec_ops.back(), (int)F->mod_nops);
+      if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { ec_map.push_back(k - k / hf_sets * hf_sets); ec_map.push_back(g); }
+    }
   }
-  pg_off.push_back(pg_map.size() / 2);
+  pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2);
   // LF map: group-major — the long streams (full 256x256-cell LF groups, 240 ms) are dispatched first and the short edge
   // groups (15 ms) fill the slots they leave, instead of long and short workgroups alternating
   int max_lfg = 0;
@@ -435,7 +443,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   for (int g = 0; g < max_lfg; g++)
     for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
-               o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, total = o_pg + pg_map.size() * 4;
+               o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, o_ec = (o_pg + pg_map.size() * 4 + 255) & ~(size_t)255,
+               total = o_ec + ec_map.size() * 4 + 4;
   HIPCHECK(batch_tab.ensure(total));
   HIPCHECK(h_batch.ensure(total));
   uint8_t *bt = (uint8_t *)batch_tab.p, *hbt = (uint8_t *)h_batch.p;
@@ -443,11 +452,13 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   memcpy(hbt + o_a, ha.data(), ha.size() * sizeof(DevAux));
   memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
   memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
+  if (!ec_map.empty()) memcpy(hbt + o_ec, ec_map.data(), ec_map.size() * 4);
   HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_clear_batch(dB, nb, max_cells, stream);
+  if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
   launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth_batch(dB, nb, max_cells, stream);
@@ -459,6 +470,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     // the shorter critical path
     if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
+    if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
+                                       ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
       launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, stream);

@@ -7,7 +7,8 @@
 
 namespace jxlamd {
 
-constexpr int kModGroupScratchInts = 8 * 65536;       // per group: up to 8 channels of 256x256
+constexpr int kModGroupMaxCh = 8;                      // per group: up to 8 channels of 256x256 (host_parse rejects more)
+JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) { return (size_t)(F.mod_nch - F.mod_first_group_ch) * 65536; }   // per group
 
 JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
 
@@ -75,7 +76,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   const int gx = g % F.xgroups, gy = g / F.xgroups;
   const int x0 = gx * 256, y0 = gy * 256;
   const int nch = F.mod_nch - F.mod_first_group_ch;
-  int32_t *scr = B.mod_scratch + (size_t)g * kModGroupScratchInts;
+  int32_t *scr = B.mod_scratch + (size_t)g * mod_group_scratch_ints(F);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
     const DevSection sec = secs[2 + F.num_lf_groups + g];

@@ -29,7 +29,7 @@ struct DevBuffers {
   int32_t *lf_scratch;          // [num_lf_groups][kLfScratchInts]
   LocalTreeScratch *local;      // [max(num_lf_groups, num_groups)]: local MA trees / histograms parsed on the device
   int32_t *mod_pool;            // Modular-encoded frames: int32 channel planes (DevFrame::mod_plane_off)
-  int32_t *mod_scratch;         // [num_groups][kModGroupScratchInts]: per-group channel rectangles
+  int32_t *mod_scratch;         // [num_groups][group channels x 65536]: per-group channel rectangles
   uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
   uint32_t *big_count;          // [3] their counts
   uint64_t *mod_end_bit;        // [1]: where the GlobalModular stream of an extra-channel frame ended (single-section frames: LfGroup 0 starts there)

@@ -23,5 +23,7 @@ void launch_mod_global(const DevBuffers &B, hipStream_t s);
 void launch_mod_groups(const DevBuffers &B, int num_groups, hipStream_t s);
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s);
 void launch_mod_write(const DevBuffers &B, int width, int height, int out_bits, hipStream_t s);
+void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s);
+void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s);
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s);
 }  // namespace jxlamd

@@ -206,6 +206,8 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
 // ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
 __global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
   __shared__ DevModScratch S;
+  const DevFrame &F = frame_of(Bs[blockIdx.x]);
+  if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
   mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
 }
 __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map) {
@@ -219,7 +221,7 @@ __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const 
 __global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
-  if (op >= F.mod_nops) return;
+  if ((!F.is_modular && !F.has_ec) || op >= F.mod_nops) return;
   const size_t n = (size_t)(F.mod_op_kind[op] == 0 ? F.mod_op_y[op] : F.mod_op_c[op]);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mod_op_element(B, F, op, i);
 }
@@ -229,6 +231,13 @@ __global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   if (x >= F.width || y >= F.height) return;
   mod_write_pixel(B, B.out_bits, x, y);
+}
+// extra channels (alpha) of the VarDCT frames of a flight: GlobalModular parts before the LF stage, the per-group streams and the
+// inverse transforms after the PassGroup stage of each sub-flight
+void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s) { hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs); }
+void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s) {
+  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+  for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
 }
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s) {
   hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);

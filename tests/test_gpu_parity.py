@@ -133,8 +133,8 @@ def test_lossless_bit_exact(dec, name):
 
 def test_flight_subflights_and_pools_in_a_small_configuration():
     """decode_batch runs its HF phase in sub-flights over shared coefficient / pixel-plane pools (128 / 16 sets by default, far more
-    than a test batch).  A child process with JXLAMD_HF_SETS=2, JXLAMD_PLANE_SETS=1 forces 3 sub-flights and 5 plane sub-batches for
-    5 frames of different sizes; the pixels must equal the single decodes bit for bit (the knobs are read once per process)."""
+    than a test batch).  A child process with JXLAMD_HF_SETS=2, JXLAMD_PLANE_SETS=1 forces 4 sub-flights and 7 plane sub-batches for
+    7 frames of different sizes (two of them RGBA: their extra-channel streams ride in the flight); the pixels must equal the single decodes bit for bit (the knobs are read once per process)."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np, torch
@@ -142,7 +142,7 @@ def test_flight_subflights_and_pools_in_a_small_configuration():
         from conftest import load_case
         import jxl_coder_amd as J
         dec = J.JxlDecoder(0)
-        names = ["v264x520_e7", "asset_first_jxl", "v267x131_e7", "v264x520_e7", "v300x300_e7_d3"]
+        names = ["v264x520_e7", "asset_first_jxl", "va300x520_e7", "v267x131_e7", "va300x520_e7", "v264x520_e7", "v300x300_e7_d3"]
         datas = [load_case(n)[0] for n in names]
         singles = [dec.decode_one_shot(d)[0] for d in datas]
         for rep in range(2):                                   # second flight reuses the (now dirty-then-cleared) pools
