@@ -54,7 +54,8 @@ struct PinnedMem {             // page-locked host staging: true async DMA, no s
 
 struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
-  PinnedMem h_tables, h_cs;
+  PinnedMem h_tables, h_cs, h_B;
+  DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
   DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
   FramePlan plan;
   DevBuffers B;
@@ -71,7 +72,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
     for (auto &m : coef) m.release();
     for (auto &m : planes) m.release();
     for (auto &m : big_list) m.release();
-    h_tables.release(); h_cs.release();
+    h_tables.release(); h_cs.release(); h_B.release(); dB.release();
   }
 };
 
@@ -94,7 +95,7 @@ struct jxlamd_decoder {
   int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
               bool parsed = false, bool own_planes = true);
   int finish_single_section(FrameSlot &S);
-  int launch_rest(FrameSlot &S);
+  int launch_rest(FrameSlot &S, int parts = 3);     // parts: 1 = reconstruction, 2 = filters + writer
   int launch_modular(FrameSlot &S);
   int launch_extra_channels(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
@@ -244,12 +245,22 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
 }
 
 // everything after the entropy stages: reconstruction, loop filters, RGBA writer, D2H of the output if asked
-int jxlamd_decoder::launch_rest(FrameSlot &S) {
+int jxlamd_decoder::launch_rest(FrameSlot &S, int parts) {
   const FramePlan &plan = S.plan;
-  launch_recon(S.B, (const uint8_t *)stat.p, plan.xb, plan.yb, stream);
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  bool src_a = launch_filters(S.B, plan.width, plan.height, F->gab, F->epf_iters, true, stream);
-  launch_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, (int)S.pi.out_bits, src_a, stream);
+  if (parts & 1) {                 // the buffer table goes up once per decode (page-locked staging)
+    HIPCHECK(S.dB.ensure(sizeof(DevBuffers)));
+    HIPCHECK(S.h_B.ensure(sizeof(DevBuffers)));
+    memcpy(S.h_B.p, &S.B, sizeof(DevBuffers));
+    HIPCHECK(hipMemcpyAsync(S.dB.p, S.h_B.p, sizeof(DevBuffers), hipMemcpyHostToDevice, stream));
+  }
+  int stage_mask = 0;
+  if (F->gab) stage_mask |= 1;
+  if (F->epf_iters >= 3) stage_mask |= 2;
+  if (F->epf_iters >= 1) stage_mask |= 4;
+  if (F->epf_iters >= 2) stage_mask |= 8;
+  if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
+  launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
   return JXLAMD_OK;
 }
 
@@ -312,11 +323,9 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   launch_pass_groups(S.B, S.plan.num_groups, stream);
   if (S.plan.has_ec) launch_extra_channels(S);
   HIPCHECK(hipEventRecord(ev[2], stream));
-  launch_recon(S.B, (const uint8_t *)stat.p, S.plan.xb, S.plan.yb, stream);
+  rc = launch_rest(S, 1); if (rc) return rc;
   HIPCHECK(hipEventRecord(ev[3], stream));
-  const DevFrame *F = (const DevFrame *)S.plan.tables.data();
-  bool src_a = launch_filters(S.B, S.plan.width, S.plan.height, F->gab, F->epf_iters, true, stream);
-  launch_write(S.B, (const uint8_t *)stat.p, S.plan.width, S.plan.height, (int)S.pi.out_bits, src_a, stream);
+  rc = launch_rest(S, 2); if (rc) return rc;
   HIPCHECK(hipEventRecord(ev[4], stream));
   rc = collect(S, flags);
   for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);
@@ -396,10 +405,11 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   static const int hf_sets = std::max(plane_sets, (getenv("JXLAMD_HF_SETS") ? atoi(getenv("JXLAMD_HF_SETS")) : 128) / plane_sets * plane_sets);
   const int nb = (int)batched.size();
   size_t max_npx = 0, max_coef = 0;
-  int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 1 << 4;
+  int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 0;
   for (int i : batched) {
     const FrameSlot &S = slot((size_t)i);
     const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+    if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;       // no filter stage to fuse the writer into: stand-alone writer launch
     max_npx = std::max(max_npx, (size_t)S.plan.xb * S.plan.yb * 64);
     max_coef = std::max(max_coef, (size_t)S.plan.num_groups * 65536);
     max_cells = std::max(max_cells, S.plan.xb * S.plan.yb); max_w = std::max(max_w, S.plan.width); max_h = std::max(max_h, S.plan.height);
@@ -474,7 +484,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, stream);
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   int first_rc = JXLAMD_OK;

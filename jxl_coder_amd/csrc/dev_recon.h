@@ -227,7 +227,9 @@ JXL_DEV int mirror(int x, int n) {
   return x;
 }
 
-JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
+// the filtered XYB value of one pixel (the *_pixel wrappers store it into the destination planes; the fused last stage of a
+// flight hands it straight to the writer)
+JXL_DEV void gab_value(const DevFrame &F, float *const src[3], int x, int y, float out[3]) {
   const int w = F.width, h = F.height, pw = F.pw;
   const int ym = mirror(y - 1, h), yp = mirror(y + 1, h), xm = mirror(x - 1, w), xp = mirror(x + 1, w);
   for (int c = 0; c < 3; c++) {
@@ -237,9 +239,14 @@ JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[
     #define P(yy, xx) p[(size_t)(yy) * (size_t)pw + (size_t)(xx)]
     float side = P(ym, x) + P(yp, x) + P(y, xm) + P(y, xp);
     float diag = P(ym, xm) + P(ym, xp) + P(yp, xm) + P(yp, xp);
-    dst[c][(size_t)y * (size_t)pw + (size_t)x] = P(y, x) * norm + side * (w1 * norm) + diag * (w2 * norm);
+    out[c] = P(y, x) * norm + side * (w1 * norm) + diag * (w2 * norm);
     #undef P
   }
+}
+JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
+  float v[3];
+  gab_value(F, src, x, y, v);
+  for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
 }
 
 JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y) {
@@ -254,11 +261,11 @@ JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y
 // compiler share the overlapping loads of the 5-pixel SAD patterns; the border version mirrors every coordinate.
 // kPass: 0 = the 12-tap first iteration, 1 = 4 taps with the 5-pixel SAD, 2 = 4 taps with the 1-pixel SAD.
 template <bool kInterior, int kPass>
-JXL_DEV void epf_pixel_t(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
+JXL_DEV void epf_value_t(const DevBuffers &B, const DevFrame &F, float *const src[3], int x, int y, float out[3]) {
   const int w = F.width, h = F.height, pw = F.pw;
   const size_t po = (size_t)y * (size_t)pw + (size_t)x;
   const float is = epf_inv_sigma(B, F, x, y);
-  if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) dst[c][po] = src[c][po]; return; }
+  if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) out[c] = src[c][po]; return; }
   const float sm = 1.65f * (kPass == 0 ? F.epf_pass0 : kPass == 2 ? F.epf_pass2 : 1.0f);
   const bool border = ((y & 7) == 0 || (y & 7) == 7 || (x & 7) == 0 || (x & 7) == 7);
   const float isig = is * (border ? sm * F.epf_border_sad : sm);
@@ -295,12 +302,18 @@ JXL_DEV void epf_pixel_t(const DevBuffers &B, const DevFrame &F, float *const sr
   }
   #undef PX
   const float inv = 1.0f / wsum;
-  for (int c = 0; c < 3; c++) dst[c][po] = acc[c] * inv;
+  for (int c = 0; c < 3; c++) out[c] = acc[c] * inv;
+}
+template <int kPass>
+JXL_DEV void epf_value_p(const DevBuffers &B, const DevFrame &F, float *const src[3], int x, int y, float out[3]) {
+  if (x >= 3 && y >= 3 && x + 3 < F.width && y + 3 < F.height) epf_value_t<true, kPass>(B, F, src, x, y, out);
+  else epf_value_t<false, kPass>(B, F, src, x, y, out);
 }
 template <int kPass>
 JXL_DEV void epf_pixel_p(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int x, int y) {
-  if (x >= 3 && y >= 3 && x + 3 < F.width && y + 3 < F.height) epf_pixel_t<true, kPass>(B, F, src, dst, x, y);
-  else epf_pixel_t<false, kPass>(B, F, src, dst, x, y);
+  float v[3];
+  epf_value_p<kPass>(B, F, src, x, y, v);
+  for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
 }
 JXL_DEV void epf_pixel(const DevBuffers &B, const DevFrame &F, float *const src[3], float *const dst[3], int pass, int x, int y) {
   if (pass == 0) epf_pixel_p<0>(B, F, src, dst, x, y);
@@ -336,10 +349,13 @@ JXL_DEV float tf_709(float v) {
   return v < 0 ? -r : r;
 }
 
+JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y);
 JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *const src[3], int out_bits, int x, int y) {
+  const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
+  xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
+}
+JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y) {
   const DevFrame &F = frame_of(B);
-  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x;
-  const float X = src[0][po], Y = src[1][po], Bc = src[2][po];
   const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
   const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
   float v[3];

@@ -9,15 +9,12 @@ void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *m
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
 void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
-                       hipStream_t s);
+                       int parts, hipStream_t s);     // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);
 void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);
-void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s);
 // filters ping-pong between plane_a and plane_b; `src_is_a` tells where the current image is; returns the new flag
-bool launch_filters(const DevBuffers &B, int width, int height, int gab, int epf_iters, bool src_is_a, hipStream_t s);
-void launch_write(const DevBuffers &B, const uint8_t *stat, int width, int height, int out_bits, bool src_is_a, hipStream_t s);
 // Modular-encoded (lossless) frames
 void launch_mod_global(const DevBuffers &B, hipStream_t s);
 void launch_mod_groups(const DevBuffers &B, int num_groups, hipStream_t s);

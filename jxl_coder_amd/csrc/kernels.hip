@@ -3,7 +3,7 @@
 //   k_pass_group : rANS decode of AC coefficients, one wave per 256x256 group
 //   k_lf_smooth  : adaptive LF smoothing, one thread per 8x8 cell
 //   k_recon_*    : dequant + chroma-from-luma + LLF + inverse var-size DCT, LDS-staged per varblock
-//   k_gab/k_epf  : loop filters, one thread per pixel;  k_write : XYB -> RGB -> RGBA8/16
+//   k_filter_b<stage> : Gaborish / EPF iterations (one thread per pixel), the last one fused with the XYB -> RGB -> RGBA8/16 writer
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
 #include <stdlib.h>
 #include <algorithm>
@@ -65,16 +65,6 @@ __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B, int xb, int yb)
 //   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
 //   medium (512, 1024):            256 threads, 28 KiB LDS, walks the list of such blocks recorded at placement
 //   large  (2048, 4096):           256 threads, 32 KiB LDS (one channel at a time), walks its list
-__global__ void __launch_bounds__(64) k_recon_small(DevBuffers B, const uint8_t *stat, int xb) {
-  __shared__ float S[3 * 256];
-  __shared__ float T[256];
-  const uint32_t count = B.big_count[2];
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[2][i];
-    __syncthreads();
-    recon_block_body<true>(B, stat, S, T, cell % xb, cell / xb, 0, 256, (int)threadIdx.x, 64, SyncBlock());
-  }
-}
 // medium / large varblocks: the placement step recorded their cells; a fixed-size grid walks the list.
 //
 // DCT32x32 (the dominant transform of smooth 4K content) takes a register-blocked path: the 32-point cosine table sits in
@@ -155,29 +145,6 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
     }
   }
 }
-template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) k_recon_list(DevBuffers B, const uint8_t *stat, int cls, int xb) {
-  recon_list_walk<NMIN, NMAX>(B, stat, cls, xb);
-}
-
-struct Planes { float *p[3]; };
-
-__global__ void __launch_bounds__(256) k_gab(DevBuffers B, Planes src, Planes dst, int w, int h) {
-  int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (x >= w || y >= h) return;
-  gab_pixel(frame_of(B), src.p, dst.p, x, y);
-}
-__global__ void __launch_bounds__(256) k_epf(DevBuffers B, Planes src, Planes dst, int pass, int w, int h) {
-  int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (x >= w || y >= h) return;
-  epf_pixel(B, frame_of(B), src.p, dst.p, pass, x, y);
-}
-__global__ void __launch_bounds__(256) k_write(DevBuffers B, const uint8_t *stat, Planes src, int out_bits, int w, int h) {
-  int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (x >= w || y >= h) return;
-  xyb_write_pixel(B, stat, *(const DevStatic *)stat, src.p, out_bits, x, y);
-}
-
 // ---- Modular-encoded frames
 __global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
   __shared__ DevModScratch S;
@@ -288,34 +255,53 @@ __global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, cons
 // One instantiation per stage (0 = Gaborish, 1..3 = EPF iterations 0..2, 4 = XYB -> RGBA writer): the writer needs 14
 // VGPRs and Gaborish 48, so they must not inherit the unrolled EPF's register footprint — these kernels share the
 // SIMDs with resident entropy-decode waves, and their occupancy is what is left of the register file.
+// The last filter stage of a frame (EPF iteration 1 or 2, or Gaborish when there is no EPF) is fused with the writer: its
+// XYB value goes straight through the colour transform into the RGBA buffer (no plane store + reload, no writer launch).
+__device__ __forceinline__ int last_filter_stage(const DevFrame &F) { return F.epf_iters >= 2 ? 3 : F.epf_iters == 1 ? 2 : F.gab ? 0 : -1; }
 template <int STAGE>
 __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || !stage_runs(F, STAGE)) return;
+  const int last = last_filter_stage(F);
+  if (STAGE == 4 && last >= 0) return;                       // the writer was fused into stage `last`
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   if (x >= F.width || y >= F.height) return;
   const bool a = stage_src_is_a(F, STAGE);
   float *src[3], *dst[3];
   for (int c = 0; c < 3; c++) { src[c] = a ? B.plane_a[c] : B.plane_b[c]; dst[c] = a ? B.plane_b[c] : B.plane_a[c]; }
-  if (STAGE == 0) gab_pixel(F, src, dst, x, y);
-  else if (STAGE <= 3) epf_pixel_p<(STAGE >= 1 && STAGE <= 3 ? STAGE - 1 : 0)>(B, F, src, dst, x, y);
-  else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
+  if (STAGE == 4) { xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y); return; }
+  float v[3];
+  if (STAGE == 0) gab_value(F, src, x, y, v);
+  else epf_value_p<(STAGE >= 1 && STAGE <= 3 ? STAGE - 1 : 0)>(B, F, src, x, y, v);
+  if (STAGE == last) {
+    // keep the filter's last multiply and the writer's first add apart (no FMA contraction across the fusion seam): the fused
+    // path must give the very pixels of the stage-by-stage path (single decodes, tests/test_gpu_parity.py batch == single)
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    xyb_write_value(B, stat, *(const DevStatic *)stat, v[0], v[1], v[2], B.out_bits, x, y);
+  }
+  else for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
 }
 
 void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
-                       hipStream_t s) {
-  hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(256, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
-  // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
-  // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? 64 : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
-  dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
-  if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat);
+                       int parts, hipStream_t s) {
+  if (parts & 1) {
+    // a single decode has the chip to itself: more, shorter workgroups for the list walkers
+    const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
+    hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
+    hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
+    // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
+    // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
+    hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  }
+  if (parts & 2) {
+    dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
+    if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat);
+    if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat);
+    if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat);
+    if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat);
+    if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat);
+  }
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
@@ -349,28 +335,6 @@ void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipSt
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B, xb, yb);
-}
-void launch_recon(const DevBuffers &B, const uint8_t *stat, int xb, int yb, hipStream_t s) {
-  hipLaunchKernelGGL(k_recon_small, dim3(std::min(xb * yb, 8192)), dim3(64), 0, s, B, stat, xb);
-  hipLaunchKernelGGL((k_recon_list<257, 1024>), dim3(2048), dim3(256), 0, s, B, stat, 0, xb);
-  hipLaunchKernelGGL((k_recon_list<1025, 4096>), dim3(512), dim3(256), 0, s, B, stat, 1, xb);
-}
-static Planes planes_of(const DevBuffers &B, bool a) {
-  Planes p;
-  for (int c = 0; c < 3; c++) p.p[c] = a ? B.plane_a[c] : B.plane_b[c];
-  return p;
-}
-bool launch_filters(const DevBuffers &B, int w, int h, int gab, int epf_iters, bool src_is_a, hipStream_t s) {
-  dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
-  if (gab) { hipLaunchKernelGGL(k_gab, grid, block, 0, s, B, planes_of(B, src_is_a), planes_of(B, !src_is_a), w, h); src_is_a = !src_is_a; }
-  if (epf_iters >= 3) { hipLaunchKernelGGL(k_epf, grid, block, 0, s, B, planes_of(B, src_is_a), planes_of(B, !src_is_a), 0, w, h); src_is_a = !src_is_a; }
-  if (epf_iters >= 1) { hipLaunchKernelGGL(k_epf, grid, block, 0, s, B, planes_of(B, src_is_a), planes_of(B, !src_is_a), 1, w, h); src_is_a = !src_is_a; }
-  if (epf_iters >= 2) { hipLaunchKernelGGL(k_epf, grid, block, 0, s, B, planes_of(B, src_is_a), planes_of(B, !src_is_a), 2, w, h); src_is_a = !src_is_a; }
-  return src_is_a;
-}
-void launch_write(const DevBuffers &B, const uint8_t *stat, int w, int h, int out_bits, bool src_is_a, hipStream_t s) {
-  dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
-  hipLaunchKernelGGL(k_write, grid, block, 0, s, B, stat, planes_of(B, src_is_a), out_bits, w, h);
 }
 
 }  // namespace jxlamd
