@@ -157,3 +157,24 @@ def test_flight_subflights_and_pools_in_a_small_configuration():
     env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "subflights ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's fields plus `roofline` and `cpu_baseline` (short run, CPU leg skipped)."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "256", "--warmup", "2", "--inflight", "64", "--contexts", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "MP/s" and line["n_gpus"] == 1 and line["steps"] == 256 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    assert line["value"] > 100 and abs(line["ms_per_step"] * line["value"] / (3840 * 2160 / 1e3) - 1) < 0.02      # value == MP per step / time per step
+    rf = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernel_ms"] > 0
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert line["config"]["retried_flights"] == 0
