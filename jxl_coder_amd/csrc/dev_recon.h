@@ -231,18 +231,6 @@ JXL_DEV int mirror(int x, int n) {
 // flight hands it straight to the writer)
 JXL_DEV void gab_value(const DevFrame &F, float *const src[3], int x, int y, float out[3]) {
   const int w = F.width, h = F.height, pw = F.pw;
-  if (x >= 1 && y >= 1 && x + 1 < w && y + 1 < h) {        // interior: plain offsets from one base address (same sums, same order)
-    const int64_t po = (int64_t)y * pw + x;
-    for (int c = 0; c < 3; c++) {
-      const float w1 = F.gab_w[c][0], w2 = F.gab_w[c][1];
-      const float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
-      const float *p = src[c] + po;
-      float side = p[-pw] + p[pw] + p[-1] + p[1];
-      float diag = p[-pw - 1] + p[-pw + 1] + p[pw - 1] + p[pw + 1];
-      out[c] = p[0] * norm + side * (w1 * norm) + diag * (w2 * norm);
-    }
-    return;
-  }
   const int ym = mirror(y - 1, h), yp = mirror(y + 1, h), xm = mirror(x - 1, w), xp = mirror(x + 1, w);
   for (int c = 0; c < 3; c++) {
     const float w1 = F.gab_w[c][0], w2 = F.gab_w[c][1];
