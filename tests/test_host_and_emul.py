@@ -142,3 +142,34 @@ def test_entropy_kernels_use_no_scratch():
     assert r.returncode == 0, r.stderr[-2000:]
     sizes = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)
     assert sizes and all(int(x) == 0 for x in sizes), sizes
+
+
+def test_corrupted_streams_never_crash_the_device_code(emul):
+    """Seeded fuzz over the host parser + the device functions (CPU harness): bit flips, byte stomps, truncations and random
+    windows on five kinds of files.  Every variant must either decode or be rejected with an error — no crash, no hang
+    (the same code under AddressSanitizer went through 10 000 such variants clean in round 1)."""
+    import random
+    rnd = random.Random(20260928)
+    decoded = rejected = 0
+    for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7"):
+        d0 = load_case(name)[0]
+        for it in range(40):
+            d = bytearray(d0)
+            mode = rnd.randrange(4)
+            if mode == 0:
+                for _ in range(rnd.randrange(1, 4)):
+                    d[rnd.randrange(len(d))] ^= 1 << rnd.randrange(8)
+            elif mode == 1:
+                for _ in range(rnd.randrange(1, 8)):
+                    d[rnd.randrange(len(d))] = rnd.randrange(256)
+            elif mode == 2:
+                d = d[:rnd.randrange(1, len(d))]
+            else:
+                a = rnd.randrange(len(d)); b = min(len(d), a + rnd.randrange(1, 64))
+                d[a:b] = bytes(rnd.randrange(256) for _ in range(b - a))
+            try:
+                emul(bytes(d))
+                decoded += 1
+            except ValueError:
+                rejected += 1
+    assert decoded + rejected == 200 and rejected > 150        # the rANS final-state checks catch nearly every corruption

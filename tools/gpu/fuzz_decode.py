@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Seeded corruption fuzz of the MI355X decode path (one-off robustness run, not part of pytest): every variant must either decode
+or raise a JXL exception; afterwards the untouched file must still decode to the very same pixels (context survives)."""
+import os, random, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_case
+import jxl_coder_amd as J
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rnd = random.Random(seed)
+dec = J.JxlDecoder(0)
+dec_ok = rej = 0
+t0 = time.time()
+for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7", "l700x500_e7", "asset_first_jxl"):
+    d0, _ = load_case(name)
+    ref = dec.decode_one_shot(d0)[0]
+    for it in range(n):
+        d = bytearray(d0)
+        mode = rnd.randrange(4)
+        if mode == 0:
+            for _ in range(rnd.randrange(1, 4)): d[rnd.randrange(len(d))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            for _ in range(rnd.randrange(1, 8)): d[rnd.randrange(len(d))] = rnd.randrange(256)
+        elif mode == 2:
+            d = d[:rnd.randrange(1, len(d))]
+        else:
+            a = rnd.randrange(len(d)); b = min(len(d), a + rnd.randrange(1, 64)); d[a:b] = bytes(rnd.randrange(256) for _ in range(b - a))
+        try:
+            dec.decode_one_shot(bytes(d)); dec_ok += 1
+        except (J.InvalidJXLException, J.UnsupportedJXLFeature, J.InvalidImageSizeException, ValueError):
+            rej += 1
+    again = dec.decode_one_shot(d0)[0]
+    assert np.array_equal(again, ref), name
+print("fuzz seed", seed, ": decoded", dec_ok, "rejected", rej, "in %.1f s; context intact" % (time.time() - t0))
