@@ -82,6 +82,7 @@ struct jxlamd_decoder {
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch, h_mod_tab;
@@ -622,10 +623,23 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   if (!px || (is_u16 ? (depth < 9 || depth > 16) : depth != 8)) { d->set_error("bad pixel buffer / bit depth"); return JXLAMD_ERR_BUFFER; }
   static const double zeros[8] = {0.64, 0.33, 0.30, 0.60, 0.15, 0.06, 0.3127, 0.3290};
-  ColorMatrixPlan P;
-  if (!plan_color_matrix(is_u16 != 0, depth, primaries, tf, xy8 ? xy8 : zeros, intensity_target, &P)) return JXLAMD_OK;
+  // the LUTs (2 x 65 536 powf for u16) only depend on these parameters: a decoder context keeps the last set on the device
+  double key[13] = {(double)(is_u16 != 0), (double)depth, (double)primaries, (double)tf, (double)intensity_target};
+  for (int i = 0; i < 8; i++) key[5 + i] = (primaries == 1 || primaries == 9 || primaries == 11 || !xy8) ? 0.0 : xy8[i];
   if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
   const hipStream_t s = d->stream;
+  if (d->post_key_valid && memcmp(key, d->post_key, sizeof(key)) == 0) {
+    if (!d->post_plan_runs) return JXLAMD_OK;
+    launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, d->post_dev, s);
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
+    return JXLAMD_OK;
+  }
+  d->post_key_valid = false;
+  ColorMatrixPlan P;
+  if (!plan_color_matrix(is_u16 != 0, depth, primaries, tf, xy8 ? xy8 : zeros, intensity_target, &P)) {
+    memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = false;
+    return JXLAMD_OK;
+  }
   if (d->post_lin_lut.ensure(P.lin_lut.size() * 4) != hipSuccess || d->post_gam_lut.ensure(P.gam_lut.size() * 2) != hipSuccess ||
       hipMemcpyAsync(d->post_lin_lut.p, P.lin_lut.data(), P.lin_lut.size() * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(d->post_gam_lut.p, P.gam_lut.data(), P.gam_lut.size() * 2, hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -639,6 +653,7 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
   D.index_scale = P.index_scale; D.index_max = P.index_max;
   launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, D, s);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
+  d->post_dev = D; memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = true;
   return JXLAMD_OK;
 }
 
