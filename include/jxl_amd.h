@@ -51,7 +51,8 @@ enum {
 #define JXLAMD_ALLOW_16BIT 1u     /* "allowedFloats": bits_per_sample > 8 -> RGBA u16 (JxlDecoding.cpp:92-101) */
 #define JXLAMD_OUT_DEVICE 2u      /* `out` is a device pointer (HBM-resident output, no D2H) */
 #define JXLAMD_NO_SIZE_GUARD 4u   /* skip the INT32_MAX guard (BASELINE config 4: 32768^2 below the Bitmap layer) */
-#define JXLAMD_IN_DEVICE 8u       /* `jxl_dev` passed to jxlamd_decode_resident holds the same bytes in HBM */
+#define JXLAMD_IN_DEVICE 8u       /* `jxl_dev` passed to jxlamd_decode_resident holds the same bytes in HBM (any alignment, no padding needed:
+                                     the decoder copies them device-to-device into its own padded stream buffer) */
 
 jxlamd_decoder *jxlamd_decoder_create(int device);        /* NULL if the HIP device cannot be opened */
 void jxlamd_decoder_destroy(jxlamd_decoder *dec);
@@ -83,6 +84,31 @@ int jxlamd_decode_batch(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, c
 int jxlamd_decode_batch_resident(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes,
                                  const void *const *jxl_dev, uint32_t flags, void *const *outs, const size_t *out_capacities,
                                  jxlamd_info *infos);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Band-sharded decode of ONE frame (BASELINE config 4; SURVEY.md §8b "decode_sharded", §8e).  Not in the reference: libjxl decodes a
+ * frame in one process; the boundary this sits under is DecodeJpegXlOneShot's size guard (interop/JxlDecoding.cpp:103-109).
+ * A band = group rows [group_row0, group_row1) (256-pixel rows of groups; use multiples of 8 to keep 2048x2048 LF groups whole —
+ * other splits work but decode the shared LF groups on both sides).  `out` receives ONLY the band's pixel rows
+ * [group_row0*256, min(group_row1*256, ysize)), tight RGBA.  Protocol per band context (every call returns with its work complete):
+ *   jxlamd_band_begin        parse, upload, LF-group entropy stage of the band
+ *   jxlamd_band_export/import(JXLAMD_HALO_LF, ...)      one cell row of LF / quant-field / sharpness per border
+ *   jxlamd_band_reconstruct  LF smoothing, PassGroup entropy decode, dequant + inverse DCT
+ *   jxlamd_band_export/import(JXLAMD_HALO_PIXELS, ...)  H rows of pre-filter XYB per border (H = 1 Gaborish + 3/2/1 per EPF iteration)
+ *   jxlamd_band_finish       Gaborish / EPF / XYB->RGBA writer for the band's rows
+ * export side 0 = this band's top edge (goes to the band above), 1 = its bottom edge; import side 0 = rows above this band (the
+ * upper neighbour's side-1 export), 1 = rows below.  Bands at the image edge skip that side.  Halo buffers are device memory
+ * (jxlamd_band_halo_bytes bytes) that the caller moves between GPUs (ncclSend/ncclRecv) or hands to the neighbour context directly.
+ * The pixels of a band equal the same rows of jxlamd_decode of the whole frame bit for bit.
+ * Supported: single-frame VarDCT without extra channels, orientation 1.  flags: JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE. */
+enum { JXLAMD_HALO_LF = 0, JXLAMD_HALO_PIXELS = 1 };
+int jxlamd_band_begin(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t flags, int group_row0, int group_row1, void *out,
+                      size_t out_capacity, jxlamd_info *info);
+int jxlamd_band_halo_bytes(jxlamd_decoder *dec, int kind, size_t *bytes);
+int jxlamd_band_export(jxlamd_decoder *dec, int kind, int side, void *halo_dev, size_t capacity);
+int jxlamd_band_import(jxlamd_decoder *dec, int kind, int side, const void *halo_dev, size_t size);
+int jxlamd_band_reconstruct(jxlamd_decoder *dec);
+int jxlamd_band_finish(jxlamd_decoder *dec);
 
 /* Timing of the last decode in milliseconds (HIP events on the decoder's stream):
  * [0]=LF groups, [1]=pass groups, [2]=reconstruction, [3]=filters+write, [4]=total device time. */

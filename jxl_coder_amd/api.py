@@ -70,7 +70,7 @@ FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
 JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
-SOURCES = ["kernels.hip", "decoder.hip", "post.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
+SOURCES = ["kernels_lf.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
 
 
 def library_path():
@@ -78,17 +78,33 @@ def library_path():
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    src = [os.path.join(_HERE, "csrc", s) for s in SOURCES]
-    deps = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + \
-           [os.path.join(os.path.dirname(_HERE), "include", "jxl_amd.h")]
-    if not force and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return _LIB_PATH
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU): one object per source, compiled in
+    parallel and only when the source or a header changed, then linked into libjxlamd.so."""
+    from concurrent.futures import ThreadPoolExecutor
+    csrc = os.path.join(_HERE, "csrc")
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".inc"))] + \
+              [os.path.join(os.path.dirname(_HERE), "include", "jxl_amd.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", _LIB_PATH] + src
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    jobs, objs = [], []
+    for sname in SOURCES:
+        src = os.path.join(csrc, sname)
+        obj = os.path.join(objdir, sname + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-c", src, "-o", obj])
+    if not jobs and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return _LIB_PATH
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB_PATH] + objs)
     return _LIB_PATH
 
 
@@ -115,6 +131,12 @@ def lib():
                                       C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
         L.jxlamd_color_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_float]
+        L.jxlamd_band_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_band_halo_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        L.jxlamd_band_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.jxlamd_band_import.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.jxlamd_band_reconstruct.argtypes = [C.c_void_p]
+        L.jxlamd_band_finish.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -213,6 +235,42 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return [i.as_dict() for i in infos]
+
+    # ---- band-sharded decode of one frame (include/jxl_amd.h "Band-sharded decode"; jxl_coder_amd/shard.py drives it)
+    def band_begin(self, data: bytes, group_row0: int, group_row1: int, out_ptr: int, out_capacity: int, allowed_floats=True):
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE
+        info = Info()
+        rc = lib().jxlamd_band_begin(self._h, data, len(data), flags, group_row0, group_row1, out_ptr, out_capacity, C.byref(info))
+        if rc:
+            _raise(rc, self._h)
+        return info.as_dict()
+
+    def band_halo_bytes(self, kind: int) -> int:
+        n = C.c_size_t()
+        rc = lib().jxlamd_band_halo_bytes(self._h, kind, C.byref(n))
+        if rc:
+            _raise(rc, self._h)
+        return n.value
+
+    def band_export(self, kind: int, side: int, ptr: int, capacity: int):
+        rc = lib().jxlamd_band_export(self._h, kind, side, ptr, capacity)
+        if rc:
+            _raise(rc, self._h)
+
+    def band_import(self, kind: int, side: int, ptr: int, size: int):
+        rc = lib().jxlamd_band_import(self._h, kind, side, ptr, size)
+        if rc:
+            _raise(rc, self._h)
+
+    def band_reconstruct(self):
+        rc = lib().jxlamd_band_reconstruct(self._h)
+        if rc:
+            _raise(rc, self._h)
+
+    def band_finish(self):
+        rc = lib().jxlamd_band_finish(self._h)
+        if rc:
+            _raise(rc, self._h)
 
     def last_timing(self):
         t = (C.c_float * 5)()

@@ -1,0 +1,168 @@
+// jxl_coder_amd/csrc/band.hip — band-sharded decode of ONE frame (BASELINE config 4: a 32768x32768 VarDCT image whose 256x256
+// groups are sharded over the GPUs of a node, RCCL used only for the loop-filter halo at the band borders).
+//
+// A band = the group rows [gr0, gr1) of the frame.  PassGroups are independently entropy-decodable and reconstructable; only the
+// image-space stages look across group borders:
+//   * adaptive LF smoothing reads the LF sample above / below        -> "LF halo":    one cell row (3 x xb f32 LF + the quant-field
+//     and EPF-sharpness bytes the EPF sigma of the first halo rows needs), exchanged after the LF stage;
+//   * Gaborish (+-1 row) and EPF (+-3 / +-2 / +-1 rows per iteration) -> "pixel halo": H = gab + 3 + 2 + 1 (as configured) rows of the
+//     PRE-filter XYB planes, exchanged after reconstruction.  Each later filter stage then recomputes a shrinking margin
+//     around the band (k_filter_b: stage_halo_after), so the band's own rows come out bit-identical to a whole-frame decode.
+// The decoder context runs the protocol  begin -> [LF halo export / import] -> reconstruct -> [pixel halo export / import] -> finish;
+// halo buffers are plain device memory so that the caller moves them with ncclSend/ncclRecv (jxl_coder_amd/shard.py) or, for bands
+// on the same GPU, hands one context's export straight to its neighbour's import.
+// The reference has no counterpart (libjxl decodes a frame in one process); the boundary it sits under is the size guard of
+// DecodeJpegXlOneShot (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:103-109): a band is smaller than a Bitmap.
+#include "decoder_ctx.h"
+
+namespace {
+constexpr int kHaloLf = 0, kHaloPixels = 1;
+size_t lf_halo_bytes(const FramePlan &plan) { return (((size_t)plan.xb * (3 * 4 + 2)) + 15) & ~(size_t)15; }
+size_t px_halo_bytes(const FramePlan &plan, const BandGeom &q) { return (size_t)q.halo * (size_t)plan.xb * 8 * 3 * 4; }
+}  // namespace
+
+int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, int gr0, int gr1, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  S.band_stage = 0;
+  const int rows[2] = {gr0, gr1};
+  int rc = prepare(S, jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out_ptr, out_cap, info, false, true, rows);
+  if (rc) return rc;
+  const BandGeom &q = S.band;
+  // the band runs the flight kernels over a one-frame array: DevBuffers, DevAux and the (frame 0, group) maps of its LF groups / groups
+  std::vector<int> maps;
+  for (int g = q.lfg0; g < q.lfg0 + q.nlfg; g++) { maps.push_back(0); maps.push_back(g); }
+  for (int g = q.g0; g < q.g0 + q.ng; g++) { maps.push_back(0); maps.push_back(g); }
+  const size_t o_a = (sizeof(DevBuffers) + 255) & ~(size_t)255, o_m = (o_a + sizeof(DevAux) + 255) & ~(size_t)255, total = o_m + maps.size() * 4;
+  HIPCHECK(batch_tab.ensure(total));
+  HIPCHECK(h_batch.ensure(total));
+  uint8_t *hb = (uint8_t *)h_batch.p, *db = (uint8_t *)batch_tab.p;
+  memcpy(hb, &S.B, sizeof(DevBuffers)); memcpy(hb + o_a, &S.A, sizeof(DevAux)); memcpy(hb + o_m, maps.data(), maps.size() * 4);
+  HIPCHECK(hipMemcpyAsync(db, hb, total, hipMemcpyHostToDevice, stream));
+  bandtab.dB = (const DevBuffers *)db; bandtab.dA = (const DevAux *)(db + o_a);
+  bandtab.lf_map = (const int *)(db + o_m); bandtab.pg_map = bandtab.lf_map + 2 * q.nlfg; bandtab.flags = flags;
+  HIPCHECK(hipEventRecord(ev[0], stream));
+  launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, stream);
+  HIPCHECK(hipEventRecord(ev[1], stream));
+  uint32_t derr = 0;
+  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipStreamSynchronize(stream));
+  HIPCHECK(hipGetLastError());
+  if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup of a band)"); return dev_err_class(derr); }
+  S.band_stage = 1;
+  return JXLAMD_OK;
+}
+
+int jxlamd_decoder::band_halo_bytes(int kind, size_t *bytes) {
+  FrameSlot &S = slot(0);
+  if (S.band_stage < 1 || !bytes || (kind != kHaloLf && kind != kHaloPixels)) { set_error("band: no band decode in progress"); return JXLAMD_ERR_BUFFER; }
+  *bytes = kind == kHaloLf ? lf_halo_bytes(S.plan) : px_halo_bytes(S.plan, S.band);
+  return JXLAMD_OK;
+}
+
+// side 0 = this band's TOP edge (sent to the band above), 1 = its BOTTOM edge (sent to the band below)
+int jxlamd_decoder::band_export(int kind, int side, void *dev_buf, size_t cap) {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  const BandGeom &q = S.band; const FramePlan &plan = S.plan;
+  const size_t xb = (size_t)plan.xb, pw = xb * 8;
+  uint8_t *dst = (uint8_t *)dev_buf;
+  if (kind == kHaloLf) {
+    if (S.band_stage < 1) { set_error("band: LF halo exported before the LF stage"); return JXLAMD_ERR_BUFFER; }
+    if (!dev_buf || cap < lf_halo_bytes(plan)) { set_error("band: halo buffer too small"); return JXLAMD_ERR_BUFFER; }
+    const size_t r = (size_t)(side == 0 ? q.cy0 : q.cy1 - 1);
+    for (int c = 0; c < 3; c++) HIPCHECK(hipMemcpyAsync(dst + (size_t)c * xb * 4, S.B.lf[c] + r * xb, xb * 4, hipMemcpyDeviceToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(dst + 12 * xb, S.B.qfm1 + r * xb, xb, hipMemcpyDeviceToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(dst + 13 * xb, S.B.sharp + r * xb, xb, hipMemcpyDeviceToDevice, stream));
+  } else if (kind == kHaloPixels) {
+    if (S.band_stage < 2) { set_error("band: pixel halo exported before reconstruction"); return JXLAMD_ERR_BUFFER; }
+    if (q.halo == 0) return JXLAMD_OK;
+    if (!dev_buf || cap < px_halo_bytes(plan, q)) { set_error("band: halo buffer too small"); return JXLAMD_ERR_BUFFER; }
+    const size_t r = (size_t)(side == 0 ? q.py0 : q.cy1 * 8 - q.halo), n = (size_t)q.halo * pw;
+    for (int c = 0; c < 3; c++) HIPCHECK(hipMemcpyAsync(dst + (size_t)c * n * 4, S.B.plane_a[c] + r * pw, n * 4, hipMemcpyDeviceToDevice, stream));
+  } else { set_error("band: unknown halo kind"); return JXLAMD_ERR_BUFFER; }
+  HIPCHECK(hipStreamSynchronize(stream));               // the buffer is complete when the call returns (the caller's send may use another stream)
+  return JXLAMD_OK;
+}
+
+// side 0 = the rows ABOVE this band (the upper neighbour's bottom-edge export), 1 = the rows BELOW it
+int jxlamd_decoder::band_import(int kind, int side, const void *dev_buf, size_t size) {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  const BandGeom &q = S.band; const FramePlan &plan = S.plan;
+  const size_t xb = (size_t)plan.xb, pw = xb * 8;
+  const uint8_t *src = (const uint8_t *)dev_buf;
+  if ((side == 0 && q.gr0 == 0) || (side == 1 && q.cy1 >= plan.yb)) { set_error("band: no neighbour on that side (image edge)"); return JXLAMD_ERR_BUFFER; }
+  if (kind == kHaloLf) {
+    if (S.band_stage != 1) { set_error("band: LF halo must be imported between begin and reconstruct"); return JXLAMD_ERR_BUFFER; }
+    if (!dev_buf || size < lf_halo_bytes(plan)) { set_error("band: halo message too small"); return JXLAMD_ERR_BUFFER; }
+    const size_t r = (size_t)(side == 0 ? q.cy0 - 1 : q.cy1);
+    for (int c = 0; c < 3; c++) HIPCHECK(hipMemcpyAsync(S.B.lf[c] + r * xb, src + (size_t)c * xb * 4, xb * 4, hipMemcpyDeviceToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(S.B.qfm1 + r * xb, src + 12 * xb, xb, hipMemcpyDeviceToDevice, stream));
+    HIPCHECK(hipMemcpyAsync(S.B.sharp + r * xb, src + 13 * xb, xb, hipMemcpyDeviceToDevice, stream));
+  } else if (kind == kHaloPixels) {
+    if (S.band_stage != 2) { set_error("band: pixel halo must be imported between reconstruct and finish"); return JXLAMD_ERR_BUFFER; }
+    if (q.halo == 0) return JXLAMD_OK;
+    if (!dev_buf || size < px_halo_bytes(plan, q)) { set_error("band: halo message too small"); return JXLAMD_ERR_BUFFER; }
+    const size_t r = (size_t)(side == 0 ? q.py0 - q.halo : q.cy1 * 8), n = (size_t)q.halo * pw;
+    for (int c = 0; c < 3; c++) HIPCHECK(hipMemcpyAsync(S.B.plane_a[c] + r * pw, src + (size_t)c * n * 4, n * 4, hipMemcpyDeviceToDevice, stream));
+  } else { set_error("band: unknown halo kind"); return JXLAMD_ERR_BUFFER; }
+  HIPCHECK(hipStreamSynchronize(stream));               // the caller may reuse / free the message buffer
+  return JXLAMD_OK;
+}
+
+// LF smoothing, PassGroup entropy decode, dequant + inverse DCT of the band's groups
+int jxlamd_decoder::band_reconstruct() {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  if (S.band_stage != 1) { set_error("band: reconstruct needs a band whose LF stage is done"); return JXLAMD_ERR_BUFFER; }
+  const BandGeom &q = S.band; const FramePlan &plan = S.plan;
+  launch_lf_smooth(S.B, plan.xb, q.cy1 - q.cy0, stream);
+  if (q.ng >= simt_min_groups) launch_pass_groups_simt(bandtab.dB, bandtab.pg_map, q.ng, stream);
+  else launch_pass_groups_batch(bandtab.dB, bandtab.pg_map, q.ng, stream);
+  HIPCHECK(hipEventRecord(ev[2], stream));
+  launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream);
+  HIPCHECK(hipEventRecord(ev[3], stream));
+  uint32_t derr = 0;
+  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipStreamSynchronize(stream));
+  HIPCHECK(hipGetLastError());
+  if (derr) { S.band_stage = 0; set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", band)"); return dev_err_class(derr); }
+  S.band_stage = 2;
+  return JXLAMD_OK;
+}
+
+// Gaborish / EPF over the band (+ the margins the later stages need) and the RGBA writer for the band's rows
+int jxlamd_decoder::band_finish() {
+  HIPCHECK(hipSetDevice(device));
+  FrameSlot &S = slot(0);
+  if (S.band_stage != 2) { set_error("band: finish needs a reconstructed band"); return JXLAMD_ERR_BUFFER; }
+  const BandGeom &q = S.band; const FramePlan &plan = S.plan;
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  int stage_mask = 0;
+  if (F->gab) stage_mask |= 1;
+  if (F->epf_iters >= 3) stage_mask |= 2;
+  if (F->epf_iters >= 1) stage_mask |= 4;
+  if (F->epf_iters >= 2) stage_mask |= 8;
+  if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
+  launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, (q.py1 - q.py0) + 2 * q.halo, stage_mask, true, 2, stream);
+  HIPCHECK(hipEventRecord(ev[4], stream));
+  S.band_stage = 0;
+  int rc = collect(S, bandtab.flags);
+  for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);      // LF | halo wait + PassGroup | reconstruction | halo wait + filters
+  (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
+  return rc;
+}
+
+extern "C" {
+int jxlamd_band_begin(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t flags, int group_row0, int group_row1, void *out, size_t cap,
+                      jxlamd_info *info) {
+  if (!d) { tls_error() = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  return d->band_begin(jxl, size, flags, group_row0, group_row1, out, cap, info);
+}
+int jxlamd_band_halo_bytes(jxlamd_decoder *d, int kind, size_t *bytes) { return d ? d->band_halo_bytes(kind, bytes) : JXLAMD_ERR_DEVICE; }
+int jxlamd_band_export(jxlamd_decoder *d, int kind, int side, void *dev_buf, size_t cap) { return d ? d->band_export(kind, side, dev_buf, cap) : JXLAMD_ERR_DEVICE; }
+int jxlamd_band_import(jxlamd_decoder *d, int kind, int side, const void *dev_buf, size_t size) { return d ? d->band_import(kind, side, dev_buf, size) : JXLAMD_ERR_DEVICE; }
+int jxlamd_band_reconstruct(jxlamd_decoder *d) { return d ? d->band_reconstruct() : JXLAMD_ERR_DEVICE; }
+int jxlamd_band_finish(jxlamd_decoder *d) { return d ? d->band_finish() : JXLAMD_ERR_DEVICE; }
+}  // extern "C"

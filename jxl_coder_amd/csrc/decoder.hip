@@ -1,109 +1,15 @@
 // jxl_coder_amd/csrc/decoder.hip — decoder context: device buffers, H2D of the codestream + frame tables,
 // kernel sequencing on one HIP stream, error collection; and the C-ABI of include/jxl_amd.h.
 // Host counterpart of the reference's DecodeJpegXlOneShot driver loop (interop/JxlDecoding.cpp:36-176).
-#include <hip/hip_runtime.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <algorithm>
 #include <atomic>
 #include <limits>
 #include <thread>
-#include <string>
-#include <vector>
-#include "../../include/jxl_amd.h"
-#include "host_parse.h"
-#include "kernels.h"
-#include "post.h"
-#include "host_post.h"
+#include "decoder_ctx.h"
 
-using namespace jxlamd;
-
-#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); return JXLAMD_ERR_DEVICE; } } while (0)
-
-static thread_local std::string g_tls_error;
-
-
-struct DevMem {
-  void *p = nullptr; size_t cap = 0;
-  hipError_t ensure(size_t n) {
-    if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
-    size_t want = n + n / 8 + 4096;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-struct PinnedMem {             // page-locked host staging: true async DMA, no shared pageable-copy staging in the runtime
-  void *p = nullptr; size_t cap = 0;
-  hipError_t ensure(size_t n) {
-    if (n <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr; cap = 0;
-    size_t want = n + n / 4 + 4096;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct FrameSlot {             // HBM work buffers of one in-flight frame
-  bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
-  PinnedMem h_tables, h_cs, h_B;
-  DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
-  FramePlan plan;
-  DevBuffers B;
-  DevAux A;
-  jxlamd_info pi;
-  size_t out_bytes = 0;
-  void *d_out = nullptr; void *host_out = nullptr;
-  void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end};
-    for (auto *m : all) m->release();
-    for (auto &m : cells8) m.release();
-    for (auto &m : tiles) m.release();
-    for (auto &m : lf) m.release();
-    for (auto &m : coef) m.release();
-    for (auto &m : planes) m.release();
-    for (auto &m : big_list) m.release();
-    h_tables.release(); h_cs.release(); h_B.release(); dB.release();
-  }
-};
-
-struct jxlamd_decoder {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {};
-  std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
-  ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
-  bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
-  bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
-  PinnedMem h_batch, h_mod_tab;
-  std::vector<FrameSlot *> slots;
-  bool stat_uploaded = false;
-  int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
-  float timing[5] = {0, 0, 0, 0, 0};
-  void set_error(const std::string &e) { error = e; g_tls_error = e; }
-  FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
-
-  int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
-              bool parsed = false, bool own_planes = true);
-  int finish_single_section(FrameSlot &S);
-  int launch_rest(FrameSlot &S, int parts = 3);     // parts: 1 = reconstruction, 2 = filters + writer
-  int launch_modular(FrameSlot &S);
-  int launch_extra_channels(FrameSlot &S);
-  int collect(FrameSlot &S, uint32_t flags);
-  int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
-  int decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
-                   const size_t *caps, jxlamd_info *infos);
-};
+namespace jxlamd {
+std::string &tls_error() { static thread_local std::string e; return e; }
+}
+#define g_tls_error (tls_error())
 
 static void fill_public_info(const ImageInfo &i, uint32_t flags, jxlamd_info *o) {
   memset(o, 0, sizeof(*o));
@@ -134,40 +40,71 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
 }
 
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
-static int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
+int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
-// host parse + buffers + H2D + clears for one frame (everything before the first kernel)
+BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
+  BandGeom q;
+  q.gr0 = gr0; q.gr1 = gr1;
+  q.cy0 = gr0 * 32; q.cy1 = std::min(gr1 * 32, (int)F.yb);
+  q.py0 = gr0 * 256; q.py1 = std::min(gr1 * 256, (int)F.height);
+  q.lr0 = gr0 / 8; q.lr1 = std::min((gr1 + 7) / 8, (int)F.ylfg);
+  q.scy0 = std::max(0, q.lr0 * 256 - 1); q.scy1 = std::min((int)F.yb, q.lr1 * 256 + 1);
+  q.st0 = q.scy0 / 8; q.st1 = (q.scy1 + 7) / 8;
+  q.g0 = gr0 * F.xgroups; q.ng = (gr1 - gr0) * F.xgroups;
+  q.lfg0 = q.lr0 * F.xlfg; q.nlfg = (q.lr1 - q.lr0) * F.xlfg;
+  q.prow0 = std::max(0, q.py0 - 8); q.prow1 = std::min((int)F.ph, q.cy1 * 8 + 8);
+  q.halo = (F.gab ? 1 : 0) + (F.epf_iters >= 3 ? 3 : 0) + (F.epf_iters >= 1 ? 2 : 0) + (F.epf_iters >= 2 ? 1 : 0);
+  q.whole = gr0 == 0 && gr1 == F.ygroups;
+  return q;
+}
+
+// host parse + buffers + H2D + clears for one frame (everything before the first kernel).  band_rows = {first, last+1} group row
+// for a band decode (band.hip): the same buffers, sized for the band's rows and addressed through biased pointers.
 int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
-                            bool parsed, bool own_planes) {
+                            bool parsed, bool own_planes, const int *band_rows) {
   FramePlan &plan = S.plan;
   if (!parsed) { plan = FramePlan(); (void)plan_parse(jxl, size, &plan); }
   if (!plan.error.empty() || plan.tables.empty()) { set_error(plan.error); return err_class(plan.error); }
   fill_public_info(plan.info, flags, &S.pi);
   if (info) *info = S.pi;
-  { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }
-  S.out_bytes = (size_t)S.pi.xsize * S.pi.ysize * 4 * (S.pi.out_bits == 16 ? 2 : 1);
+  DevFrame *Fh = (DevFrame *)plan.tables.data();       // host copy of the frame parameters: the band fields are patched in before the upload
+  if (band_rows) {
+    if (plan.modular || plan.has_ec || plan.single_section) { set_error("unsupported: band decode of a Modular / extra-channel / single-group frame"); return JXLAMD_ERR_UNSUPPORTED; }
+    if (Fh->orientation != 1) { set_error("unsupported: band decode of a frame with a non-identity orientation"); return JXLAMD_ERR_UNSUPPORTED; }
+    if (band_rows[0] < 0 || band_rows[1] <= band_rows[0] || band_rows[1] > Fh->ygroups) { set_error("band rows outside the frame"); return JXLAMD_ERR_BUFFER; }
+  }
+  const BandGeom q = band_geometry(*Fh, band_rows ? band_rows[0] : 0, band_rows ? band_rows[1] : Fh->ygroups);
+  S.band = q;
+  Fh->band_gr0 = q.gr0; Fh->band_gr1 = q.gr1; Fh->band_cy0 = q.cy0; Fh->band_cy1 = q.cy1; Fh->band_py0 = q.py0; Fh->band_py1 = q.py1;
+  Fh->band_scy0 = q.scy0; Fh->band_scy1 = q.scy1; Fh->band_g0 = q.g0; Fh->band_lfg0 = q.lfg0;
+  const size_t bpp = S.pi.out_bits == 16 ? 8 : 4;
+  if (q.whole) { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }     // a band is below the Bitmap layer (BASELINE config 4)
+  S.out_bytes = q.whole ? (size_t)S.pi.xsize * S.pi.ysize * bpp : (size_t)S.pi.xsize * (size_t)(q.py1 - q.py0) * bpp;
   if (out_cap < S.out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
-  const size_t ncell = (size_t)plan.xb * plan.yb;
-  const size_t ntile = (size_t)((plan.xb + 7) / 8) * ((plan.yb + 7) / 8);
-  const size_t npx = ncell * 64;
+  const size_t ncell = (size_t)plan.xb * (size_t)(q.scy1 - q.scy0);
+  const size_t ntile = (size_t)((plan.xb + 7) / 8) * (size_t)(q.st1 - q.st0);
+  const size_t npx = (size_t)plan.xb * 8 * (size_t)(q.prow1 - q.prow0);
   if (!stat_uploaded) {
     const std::vector<uint8_t> &st = static_tables();
     HIPCHECK(stat.ensure(st.size()));
     HIPCHECK(hipMemcpy(stat.p, st.data(), st.size(), hipMemcpyHostToDevice));   // one-time, synchronous (shared host source)
     stat_uploaded = true;
   }
-  const bool cs_alias = (flags & JXLAMD_IN_DEVICE) && jxl_dev && plan.cs_owned.empty();
-  const uint8_t *d_cs;
-  if (cs_alias) d_cs = (const uint8_t *)jxl_dev + (plan.cs - jxl);
+  // The kernels' bit reader fetches aligned words and relies on >= 64 zero bytes after the codestream, so the stream always goes
+  // through the slot's own padded buffer: H2D from page-locked staging, or — JXLAMD_IN_DEVICE — a device-to-device copy of the
+  // caller's resident bytes (no requirement on the caller's buffer: neither alignment nor padding).
+  const bool cs_resident = (flags & JXLAMD_IN_DEVICE) && jxl_dev && plan.cs_owned.empty();
+  HIPCHECK(S.cs.ensure(plan.cs_size + 64));
+  if (cs_resident) HIPCHECK(hipMemcpyAsync(S.cs.p, (const uint8_t *)jxl_dev + (plan.cs - jxl), plan.cs_size, hipMemcpyDeviceToDevice, stream));
   else {
-    HIPCHECK(S.cs.ensure(plan.cs_size + 64));
     HIPCHECK(S.h_cs.ensure(plan.cs_size));
     memcpy(S.h_cs.p, plan.cs, plan.cs_size);
     HIPCHECK(hipMemcpyAsync(S.cs.p, S.h_cs.p, plan.cs_size, hipMemcpyHostToDevice, stream));
-    HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
-    d_cs = (const uint8_t *)S.cs.p;
   }
-  HIPCHECK(S.tables.ensure(plan.tables.size() + (plan.single_section ? (8u << 20) : 0u)));     // single-section frames: room for the phase-2 (HfGlobal) tables
+  HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
+  const uint8_t *d_cs = (const uint8_t *)S.cs.p;
+  // single-section frames: room for the phase-2 (HfGlobal) tables — orders of all 13 order ids x 3 channels x passes + histograms
+  HIPCHECK(S.tables.ensure(plan.tables.size() + (plan.single_section ? (size_t)(12u << 20) : 0u)));
   HIPCHECK(S.h_tables.ensure(plan.tables.size()));
   memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
   HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
@@ -176,23 +113,23 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
     for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
     HIPCHECK(S.coef_off.ensure(ncell * 4));
-    if (own_planes) for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)plan.num_groups * 65536 * 4));   // flights: the decoder's coefficient pool
+    if (own_planes) for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)q.ng * 65536 * 4));   // flights: the decoder's coefficient pool
     if (own_planes) for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));   // flights borrow sets of the decoder's plane pool instead
-    HIPCHECK(S.lf_scratch.ensure((size_t)plan.num_lf_groups * kLfScratchInts * 4));
-    HIPCHECK(S.local.ensure((size_t)plan.num_lf_groups * sizeof(LocalTreeScratch)));
-    HIPCHECK(S.pass_nz.ensure((size_t)plan.num_groups * 3072));
+    HIPCHECK(S.lf_scratch.ensure((size_t)q.nlfg * kLfScratchInts * 4));
+    HIPCHECK(S.local.ensure((size_t)q.nlfg * sizeof(LocalTreeScratch)));
+    HIPCHECK(S.pass_nz.ensure((size_t)q.ng * 3072));
     HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
     HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
     if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(((const DevFrame *)plan.tables.data())->mod_nch - ((const DevFrame *)plan.tables.data())->mod_first_group_ch) * 65536 * 4 + 256));
+      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
       HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(((const DevFrame *)plan.tables.data())->mod_nch - ((const DevFrame *)plan.tables.data())->mod_first_group_ch) * 65536 * 4 + 256));
+    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
@@ -200,31 +137,36 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(S.out_bytes)); S.d_out = S.out.p; S.host_out = out_ptr; }
   DevBuffers &B = S.B;
   memset(&B, 0, sizeof(B));
+  // pointer biases: element [frame coordinate] lands at [frame coordinate - band origin] of the allocation
+  const ptrdiff_t cb = (ptrdiff_t)q.scy0 * plan.xb, tb = (ptrdiff_t)q.st0 * ((plan.xb + 7) / 8), pb = (ptrdiff_t)q.prow0 * plan.xb * 8;
   B.codestream = d_cs; B.tables = (const uint8_t *)S.tables.p;
-  B.strategy = (uint8_t *)S.cells8[0].p; B.first = (uint8_t *)S.cells8[1].p; B.qfm1 = (uint8_t *)S.cells8[2].p;
-  B.sharp = (uint8_t *)S.cells8[3].p; B.lf_idx = (uint8_t *)S.cells8[4].p;
-  B.xfromy = (int8_t *)S.tiles[0].p; B.bfromy = (int8_t *)S.tiles[1].p;
-  for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p; B.lf_s[c] = (float *)S.lf[3 + c].p; B.coef[c] = (int32_t *)S.coef[c].p;
-                                B.plane_a[c] = (float *)S.planes[c].p; B.plane_b[c] = (float *)S.planes[3 + c].p; }
-  B.coef_off = (uint32_t *)S.coef_off.p; B.lf_scratch = (int32_t *)S.lf_scratch.p; B.local = (LocalTreeScratch *)S.local.p;
-  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p; B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
-  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out; B.out_bits = (int32_t)S.pi.out_bits;
+  B.strategy = (uint8_t *)S.cells8[0].p - cb; B.first = (uint8_t *)S.cells8[1].p - cb; B.qfm1 = (uint8_t *)S.cells8[2].p - cb;
+  B.sharp = (uint8_t *)S.cells8[3].p - cb; B.lf_idx = (uint8_t *)S.cells8[4].p - cb;
+  B.xfromy = (int8_t *)S.tiles[0].p - tb; B.bfromy = (int8_t *)S.tiles[1].p - tb;
+  for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p - cb; B.lf_s[c] = (float *)S.lf[3 + c].p - cb;
+                                B.coef[c] = (int32_t *)S.coef[c].p - (ptrdiff_t)q.g0 * 65536;
+                                B.plane_a[c] = (float *)S.planes[c].p - pb; B.plane_b[c] = (float *)S.planes[3 + c].p - pb; }
+  B.coef_off = (uint32_t *)S.coef_off.p - cb; B.lf_scratch = (int32_t *)S.lf_scratch.p - (ptrdiff_t)q.lfg0 * kLfScratchInts;
+  B.local = (LocalTreeScratch *)S.local.p - q.lfg0;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * 3072;
+  B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
+  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits;
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   const bool in_flight = !own_planes;                 // frames of a batched flight: one k_clear_b launch clears these for all of them
   if (!in_flight) HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   if (!plan.modular) {
-    if (!in_flight) HIPCHECK(hipMemsetAsync(B.first, 0, ncell, stream));
+    if (!in_flight) HIPCHECK(hipMemsetAsync(S.cells8[1].p, 0, ncell, stream));
     // The reconstruction kernels clear every coefficient they consume, so a slot whose previous decode completed is
     // already all-zero; only fresh / regrown / failed slots are cleared here.
     if (in_flight) return JXLAMD_OK;                    // flights use the decoder's coefficient pool (decode_batch)
-    const size_t coef_bytes = (size_t)plan.num_groups * 65536 * 4;
-    const bool clean = S.coef_clean && S.coef_clean_bytes >= coef_bytes && S.coef_clean_ptr[0] == B.coef[0] && S.coef_clean_ptr[1] == B.coef[1] &&
-                       S.coef_clean_ptr[2] == B.coef[2];
-    if (!clean) for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(B.coef[c], 0, S.coef[c].cap, stream));
+    const size_t coef_bytes = (size_t)q.ng * 65536 * 4;
+    const bool clean = S.coef_clean && S.coef_clean_bytes >= coef_bytes && S.coef_clean_ptr[0] == S.coef[0].p && S.coef_clean_ptr[1] == S.coef[1].p &&
+                       S.coef_clean_ptr[2] == S.coef[2].p;
+    if (!clean) for (int c = 0; c < 3; c++) HIPCHECK(hipMemsetAsync(S.coef[c].p, 0, S.coef[c].cap, stream));
     S.coef_clean = false;                              // until collect() has seen this decode succeed
-    for (int c = 0; c < 3; c++) S.coef_clean_ptr[c] = B.coef[c];
+    for (int c = 0; c < 3; c++) S.coef_clean_ptr[c] = S.coef[c].p;
     S.coef_clean_bytes = std::min(std::min(S.coef[0].cap, S.coef[1].cap), S.coef[2].cap);
   }
   return JXLAMD_OK;
@@ -239,6 +181,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
   HIPCHECK(S.tables.ensure(S.plan.tables.size()));
+  S.B.tables = (const uint8_t *)S.tables.p;              // ensure() may have moved the buffer
   HIPCHECK(S.h_tables.ensure(S.plan.tables.size()));
   memcpy(S.h_tables.p, S.plan.tables.data(), S.plan.tables.size());
   HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, S.plan.tables.size(), hipMemcpyHostToDevice, stream));
@@ -659,6 +602,7 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
 
 int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) {
   if (!d || d->slots.empty() || !d->slots[0]->misc.p) return JXLAMD_ERR_DEVICE;
+  if (num_lf_groups < 0 || num_lf_groups > d->slots[0]->plan.num_lf_groups) return JXLAMD_ERR_BUFFER;
   return hipMemcpy(out, (uint8_t *)d->slots[0]->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
 }
 

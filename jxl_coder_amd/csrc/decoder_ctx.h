@@ -1,0 +1,135 @@
+// jxl_coder_amd/csrc/decoder_ctx.h — the decoder context shared by decoder.hip (whole-frame / flight decode, C-ABI) and band.hip
+// (band-sharded decode of one frame, BASELINE config 4): device buffers, page-locked staging, per-frame slot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "../../include/jxl_amd.h"
+#include "host_parse.h"
+#include "kernels.h"
+#include "post.h"
+#include "host_post.h"
+
+namespace jxlamd {
+std::string &tls_error();
+}
+using namespace jxlamd;
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); return JXLAMD_ERR_DEVICE; } } while (0)
+
+
+
+struct DevMem {
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct PinnedMem {             // page-locked host staging: true async DMA, no shared pageable-copy staging in the runtime
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+// Rows of a frame one decode covers and the storage that backs them.  Kernels address cells / groups / pixels with FRAME
+// coordinates; the buffer pointers in DevBuffers are biased by the *_0 origins below, so a band of a 32768^2 frame only allocates
+// its own rows (+ halo).  Whole-frame decode: every origin 0.
+struct BandGeom {
+  int gr0 = 0, gr1 = 0;          // group rows
+  int cy0 = 0, cy1 = 0;          // cell rows reconstructed here
+  int py0 = 0, py1 = 0;          // pixel rows written here
+  int lr0 = 0, lr1 = 0;          // LF-group rows decoded here (superset of the band when it is not LF-group aligned)
+  int scy0 = 0, scy1 = 0;        // cell rows backed by storage: the LF-group rows + one halo row each side
+  int st0 = 0, st1 = 0;          // 64x64 tile rows backed by storage
+  int g0 = 0, ng = 0;            // first group / number of groups
+  int lfg0 = 0, nlfg = 0;        // first LF group / number of LF groups
+  int prow0 = 0, prow1 = 0;      // plane rows backed by storage (band + 8 rows of halo each side, clipped to the padded plane)
+  int halo = 0;                  // H: pre-filter rows the loop filters read beyond the band (Gaborish 1 + EPF 3 / 2 / 1 per iteration)
+  bool whole = true;
+};
+BandGeom band_geometry(const DevFrame &F, int gr0, int gr1);
+int dev_err_class(uint32_t derr);
+
+struct FrameSlot {             // HBM work buffers of one in-flight frame
+  bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
+  PinnedMem h_tables, h_cs, h_B;
+  DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
+  FramePlan plan;
+  DevBuffers B;
+  DevAux A;
+  jxlamd_info pi;
+  size_t out_bytes = 0;
+  void *d_out = nullptr; void *host_out = nullptr;
+  BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
+  int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
+  void release() {
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end};
+    for (auto *m : all) m->release();
+    for (auto &m : cells8) m.release();
+    for (auto &m : tiles) m.release();
+    for (auto &m : lf) m.release();
+    for (auto &m : coef) m.release();
+    for (auto &m : planes) m.release();
+    for (auto &m : big_list) m.release();
+    h_tables.release(); h_cs.release(); h_B.release(); dB.release();
+  }
+};
+
+struct jxlamd_decoder {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  std::string error;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
+  bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
+  bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
+  PinnedMem h_batch, h_mod_tab;
+  std::vector<FrameSlot *> slots;
+  bool stat_uploaded = false;
+  struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
+  int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
+  float timing[5] = {0, 0, 0, 0, 0};
+  void set_error(const std::string &e) { error = e; tls_error() = e; }
+  FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
+
+  int prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
+              bool parsed = false, bool own_planes = true, const int *band_rows = nullptr);
+  // band-sharded decode of one frame (band.hip)
+  int band_begin(const uint8_t *jxl, size_t size, uint32_t flags, int gr0, int gr1, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int band_halo_bytes(int kind, size_t *bytes);
+  int band_export(int kind, int side, void *dev_buf, size_t cap);
+  int band_import(int kind, int side, const void *dev_buf, size_t size);
+  int band_reconstruct();
+  int band_finish();
+  int finish_single_section(FrameSlot &S);
+  int launch_rest(FrameSlot &S, int parts = 3);     // parts: 1 = reconstruction, 2 = filters + writer
+  int launch_modular(FrameSlot &S);
+  int launch_extra_channels(FrameSlot &S);
+  int collect(FrameSlot &S, uint32_t flags);
+  int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
+                   const size_t *caps, jxlamd_info *infos);
+};
+

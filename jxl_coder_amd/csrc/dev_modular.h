@@ -314,6 +314,18 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
     st.tree = L.nodes; st.count = L.count; st.ev = local_view(L.leaf_code);
     st.num_ctx = L.leaf_code.num_ctx; st.num_clusters = L.leaf_code.num_clusters;
   }
+#ifdef JXL_EMUL_TRACE
+  if (getenv("JXLEMUL_TREE")) {
+    fprintf(stderr, "stream tree: %d nodes (global %d), %d ctx, %d clusters, log_alpha %d, prefix %d; wp p1 %d p2 %d p3 %d %d %d %d %d w %d %d %d %d\n", st.count, use_global, st.num_ctx,
+            st.num_clusters, st.ev.log_alpha, st.ev.use_prefix, st.wp.p1, st.wp.p2, st.wp.p3a, st.wp.p3b, st.wp.p3c, st.wp.p3d, st.wp.p3e, st.wp.w[0], st.wp.w[1], st.wp.w[2], st.wp.w[3]);
+    for (int i = 0; i < st.count && i < 300; i++) {
+      const DevTreeNode &t = st.tree[i];
+      if (t.prop < 0) fprintf(stderr, "  %3d leaf ctx %d (cluster %d) pred %d mul %d off %d\n", i, t.splitval, st.ev.ctx_map[t.splitval], t.lchild, t.rchild, t.offset);
+      else fprintf(stderr, "  %3d prop %d > %d ? %d : %d\n", i, t.prop, t.splitval, t.lchild, t.rchild);
+    }
+    for (int i = 0; i < st.num_clusters; i++) fprintf(stderr, "  cfg[%d] split_exp %d msb %d lsb %d\n", i, st.ev.cfg[i] & 255, (st.ev.cfg[i] >> 8) & 255, (st.ev.cfg[i] >> 16) & 255);
+  }
+#endif
 }
 
 JXL_DEV void modular_stream_stage(DevModScratch &S, int tid, int nthreads) {

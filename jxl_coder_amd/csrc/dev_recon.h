@@ -51,7 +51,10 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
   const int st = B.strategy[o];
   const int qt = kQuantTableOf[st];
   const int g = (by / 32) * F.xgroups + (bx / 32);
-  const uint32_t off = B.coef_off[o];
+  uint32_t off = B.coef_off[o];
+  // coef_off is only written by pass 0 of a PassGroup stream that reached this block: anything else (a stream that stopped early is
+  // flagged, but a stale value must still not index outside the group's 65 536-coefficient pool)
+  if (off + (uint32_t)n > 65536u) { if (tid == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }
   const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
   const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
   const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;

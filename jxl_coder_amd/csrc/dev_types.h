@@ -99,6 +99,15 @@ struct DevFrame {
   float gamma, intensity_target;
   int32_t orientation;
   int32_t out_w, out_h;            // oriented
+  // Band decode (BASELINE config 4, one frame sharded over GPUs): this decode covers group rows [band_gr0, band_gr1) only.
+  // Every kernel keeps addressing cells / groups / pixels with FRAME coordinates; the host biases the buffer pointers so that
+  // only the band's rows (+ halo) are backed by memory.  Whole-frame decode: [0, ygroups), [0, yb), [0, height).
+  int32_t band_gr0, band_gr1;      // group rows decoded here
+  int32_t band_cy0, band_cy1;      // = cell rows reconstructed / smoothed here
+  int32_t band_py0, band_py1;      // = pixel rows written here
+  int32_t band_scy0, band_scy1;    // cell rows backed by storage (LF-group aligned superset + one halo row each side)
+  int32_t band_g0;                 // first group index / first LF group index backed by storage
+  int32_t band_lfg0;
 };
 
 // static (per-process) tables uploaded once: inverse quant weights, cosine bases, AFV basis, dither LUT

@@ -328,6 +328,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
       const int ord = kStrategyOrder[st];
       uint32_t off;
       if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
+      if (off + (uint32_t)size > 65536u) return kErrBitstream;      // a group holds at most 32x32 cells of coefficients (stale / corrupt placement data)
       const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
       int qf_idx = 0;
       for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
@@ -423,6 +424,7 @@ JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, 
         const int ord = kStrategyOrder[st];
         uint32_t off;
         if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
+        if (off + (uint32_t)size > 65536u) return kErrBitstream;      // a group holds at most 32x32 cells of coefficients (stale / corrupt placement data)
         const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
         int qf_idx = 0;
         for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;

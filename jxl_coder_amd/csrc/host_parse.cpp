@@ -351,7 +351,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
   hx_tree tree; memset(&tree, 0, sizeof(tree));
   const bool have_tree = hx_bool(&sb);
-  if (have_tree && hx_tree_read(&tree, &sb)) { plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
+  if (have_tree && hx_tree_read(&tree, &sb)) { hx_tree_free(&tree); plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
   if (sb.err) { hx_tree_free(&tree); plan->error = "truncated LfGlobal"; return -1; }
   if (have_tree) {
     std::vector<DevTreeNode> nodes((size_t)tree.count);
@@ -414,6 +414,8 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     F.gamma = m.pub.gamma; F.intensity_target = m.pub.intensity_target;
   }
   F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;
+  F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;
+  F.band_scy0 = 0; F.band_scy1 = F.yb; F.band_g0 = 0; F.band_lfg0 = 0;
   plan->single_section = nsec == 1;
   plan->xb = F.xb; plan->yb = F.yb; plan->num_groups = F.num_groups; plan->num_lf_groups = F.num_lf_groups;
   plan->num_passes = F.num_passes; plan->width = F.width; plan->height = F.height;

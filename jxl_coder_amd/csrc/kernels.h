@@ -8,8 +8,14 @@ void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, h
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
-void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
-                       int parts, hipStream_t s);     // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
+void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);
+void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s);
+// parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
+inline void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
+                              int parts, hipStream_t s) {
+  if (parts & 1) launch_recon_batch(Bs, stat, nframes, max_cells, expect_large, s);
+  if (parts & 2) launch_filters_batch(Bs, stat, nframes, max_w, max_h, stage_mask, s);
+}
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);

@@ -1,0 +1,78 @@
+// jxl_coder_amd/csrc/kernels_mod.hip — HIP kernels (gfx950): Modular-encoded (lossless) frames and the Modular-coded extra channels
+// (alpha) of VarDCT frames: k_mod_global / k_mod_group (MA-tree + rANS stream decode, one wave per stream), k_mod_op (inverse
+// RCT / palette), k_mod_write (int -> RGBA), and their flight forms.
+// Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
+#include "kernels_common.h"
+
+namespace jxlamd {
+
+// ---- Modular-encoded frames
+__global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
+  __shared__ DevModScratch S;
+  mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
+  __shared__ DevModScratch S;
+  mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(256) k_mod_op(DevBuffers B, int op, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mod_op_element(B, frame_of(B), op, i);
+}
+__global__ void __launch_bounds__(256) k_mod_write(DevBuffers B, int out_bits, int w, int h) {
+  int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= w || y >= h) return;
+  mod_write_pixel(B, out_bits, x, y);
+}
+void launch_mod_global(const DevBuffers &B, hipStream_t s) { hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), 0, s, B); }
+void launch_mod_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_group, dim3(n), dim3(64), 0, s, B); }
+void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_mod_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, op, n); }
+void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream_t s) {
+  hipLaunchKernelGGL(k_mod_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, out_bits, w, h);
+}
+
+// ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
+__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
+  __shared__ DevModScratch S;
+  const DevFrame &F = frame_of(Bs[blockIdx.x]);
+  if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
+  mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map) {
+  __shared__ DevModScratch S;
+  const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
+  const DevBuffers &B = Bs[f];
+  const DevFrame &F = frame_of(B);
+  if (F.mod_first_group_ch >= F.mod_nch) return;
+  mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if ((!F.is_modular && !F.has_ec) || op >= F.mod_nops) return;
+  const size_t n = (size_t)(F.mod_op_kind[op] == 0 ? F.mod_op_y[op] : F.mod_op_c[op]);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mod_op_element(B, F, op, i);
+}
+__global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height) return;
+  mod_write_pixel(B, B.out_bits, x, y);
+}
+// extra channels (alpha) of the VarDCT frames of a flight: GlobalModular parts before the LF stage, the per-group streams and the
+// inverse transforms after the PassGroup stage of each sub-flight
+void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s) { hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs); }
+void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s) {
+  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+  for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
+}
+void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s) {
+  hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);
+  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+  for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
+  hipLaunchKernelGGL(k_mod_write_b, dim3((max_w + 63) / 64, (max_h + 3) / 4, nframes), dim3(256), 0, s, Bs);
+}
+
+
+}  // namespace jxlamd

@@ -1,0 +1,40 @@
+// jxl_coder_amd/csrc/kernels_pass.hip — HIP kernels (gfx950): rANS decode of AC coefficients — k_pass_group[_batch] (one wave per 256x256 group) and
+// k_pass_group_simt (one LANE per group, flights).
+// Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
+#include "kernels_common.h"
+
+namespace jxlamd {
+
+__global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
+  __shared__ DevPassScratch S;
+  if (frame_failed(B)) return;
+  pass_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
+}
+
+__global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, const int *map) {
+  __shared__ DevPassScratch S;
+  const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
+  if (frame_failed(Bs[f])) return;
+  pass_group_body(Bs[f], S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+
+// lane-per-stream PassGroup kernel (batch mode): lane l of block b decodes group map[b*64+l]
+__global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, const int *map, int total) {
+  __shared__ uint16_t freq_ctx[64], nnz_ctx[64];
+  __builtin_amdgcn_s_setprio(2);           // latency-bound like the LF waves (see k_lf_group_batch), but 64 streams per wave
+  freq_ctx[threadIdx.x] = kCoeffFreqContext[threadIdx.x]; nnz_ctx[threadIdx.x] = kCoeffNumNonzeroContext[threadIdx.x];
+  __syncthreads();
+  const int i = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (i >= total) return;
+  const int f = map[2 * i], g = map[2 * i + 1];
+  const DevBuffers &B = Bs[f];
+  if (frame_failed(B)) return;
+  uint32_t e = pass_group_lane(B, freq_ctx, nnz_ctx, B.pass_nz + (size_t)g * 3072, g);
+  if (e) atomicOr(B.err, e | kErrStagePass);
+}
+
+void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
+void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
+void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }
+
+}  // namespace jxlamd

@@ -1,0 +1,175 @@
+// jxl_coder_amd/csrc/kernels_recon.hip — HIP kernels (gfx950): adaptive LF smoothing, dequant + chroma-from-luma + LLF + inverse var-size DCT (LDS-staged per varblock),
+// per-flight clears.
+// Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
+#include "kernels_common.h"
+
+namespace jxlamd {
+
+__global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= F.xb * (F.band_cy1 - F.band_cy0) || frame_failed(B)) return;
+  lf_smooth_cell(B, i % F.xb, F.band_cy0 + i / F.xb);
+}
+
+// Varblock reconstruction in three size classes so that the LDS budget (and with it the occupancy) fits the block:
+//   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
+//   medium (512, 1024):            256 threads, 28 KiB LDS, walks the list of such blocks recorded at placement
+//   large  (2048, 4096):           256 threads, 32 KiB LDS (one channel at a time), walks its list
+// medium / large varblocks: the placement step recorded their cells; a fixed-size grid walks the list.
+//
+// DCT32x32 (the dominant transform of smooth 4K content) takes a register-blocked path: the 32-point cosine table sits in
+// LDS for the lifetime of the workgroup, the three channels go through each 1-D pass together, and every work-item owns
+// a 4 (frequencies / rows) x 3 (channels) tile of outputs for one column x, so that one b128 LDS broadcast feeds 4 FMAs:
+//   pass 1: T[c][v][x] = sum_u S[c][u][v] * cc[u][x]      pass 2: out[c][y][x] = sum_v T[c][v][x] * cc[v][y]
+// 12 FMAs per 4 LDS reads instead of 1 FMA per (LDS + global) read of the generic path.
+constexpr int kStrategyDct32 = 5;
+template <int NMAX>
+struct ReconLds {                       // medium: S[3][1024] T[3][1024] CC (28 KiB); large: one channel at a time, S[4096] T[4096] (32 KiB)
+  float S[NMAX > 1024 ? NMAX : 3 * NMAX];
+  float T[NMAX > 1024 ? NMAX : 3 * 1024];
+  float CC[NMAX > 1024 ? 4 : 1024];
+};
+
+__device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const int x = tid & 31, q0 = (tid >> 5) * 4;
+  float acc[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[c][j] = 0.0f;
+#pragma unroll 4
+  for (int u = 0; u < 32; u++) {
+    const float ccv = CC[u * 32 + x];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float4 s4 = *(const float4 *)&S[c * 1024 + u * 32 + q0];
+      acc[c][0] += s4.x * ccv; acc[c][1] += s4.y * ccv; acc[c][2] += s4.z * ccv; acc[c][3] += s4.w * ccv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) { T[c * 1024 + (q0 + j) * 32 + x] = acc[c][j]; acc[c][j] = 0.0f; }
+  __syncthreads();
+#pragma unroll 4
+  for (int v = 0; v < 32; v++) {
+    const float4 c4 = *(const float4 *)&CC[v * 32 + q0];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float tv = T[c * 1024 + v * 32 + x];
+      acc[c][0] += tv * c4.x; acc[c][1] += tv * c4.y; acc[c][2] += tv * c4.z; acc[c][3] += tv * c4.w;
+    }
+  }
+  const size_t po = (size_t)(by * 8 + q0) * (size_t)F.pw + (size_t)(bx * 8 + x);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
+}
+
+template <int NMIN, int NMAX>
+__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb) {
+  __shared__ __attribute__((aligned(16))) ReconLds<NMAX> L;
+  const int tid = (int)threadIdx.x;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const DevFrame &F = frame_of(B);
+  const uint32_t count = B.big_count[cls];
+  if (blockIdx.x >= count) return;
+  if (NMAX == 1024) {
+    const float *cc = st_f(stat, ST.cos_off[5]);
+    for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
+  }
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[cls][i];
+    const int bx = cell % xb, by = cell / xb;
+    if (by < F.band_cy0 || by >= F.band_cy1) continue;       // band decode: the LF groups placed here may reach beyond the band's rows
+    if (NMAX == 1024 && B.strategy[cell] == kStrategyDct32) {
+      __syncthreads();                               // previous item's pass 2 has finished reading T; CC is in place
+      recon_phaseA(B, stat, ST, L.S, 1024, bx, by, tid, 256);
+      __syncthreads();
+      recon_phaseB(B, stat, ST, L.S, 1024, bx, by, tid, 256);
+      __syncthreads();
+      recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
+    } else {
+      __syncthreads();
+      recon_block_body<false, (NMAX > 1024)>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i >= F.xb * (F.band_cy1 - F.band_cy0)) return;
+  lf_smooth_cell(B, i % F.xb, F.band_cy0 + i / F.xb);
+}
+__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ float S[3 * 256];
+  __shared__ float T[256];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular) return;
+  if (frame_failed(B)) {
+    // A PassGroup stream that stopped early leaves coefficients nobody will consume: the set must be all-zero again before its next
+    // user (the frame hf_sets later in this flight, or the next decode), so the failed frame's launch clears it instead.
+    const size_t g0 = (size_t)F.band_gr0 * (size_t)F.xgroups * 65536, g1 = (size_t)F.band_gr1 * (size_t)F.xgroups * 65536;
+    for (int c = 0; c < 3; c++)
+      for (size_t i = g0 + (size_t)blockIdx.x * 64 + threadIdx.x; i < g1; i += (size_t)gridDim.x * 64) B.coef[c][i] = 0;
+    return;
+  }
+  const uint32_t count = B.big_count[2];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[2][i];
+    const int by = cell / F.xb;
+    if (by < F.band_cy0 || by >= F.band_cy1) continue;
+    __syncthreads();
+    recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+  }
+}
+template <int NMIN, int NMAX>
+__global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb);
+}
+void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
+  // a single decode has the chip to itself: more, shorter workgroups for the list walkers
+  const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
+  hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
+  // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
+  // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+}
+// one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
+__global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular) return;
+  if (blockIdx.x == 0) {
+    uint32_t *m = B.err;                                   // misc block: 4096 bytes of flags + 72 bytes per LF group
+    const int words = (4096 + F.num_lf_groups * 72) / 4;
+    for (int i = (int)threadIdx.x; i < words; i += 256) m[i] = 0;
+    return;
+  }
+  const int ncell = F.xb * (F.band_scy1 - F.band_scy0);        // the rows backed by storage (whole frame unless this is a band decode)
+  uint8_t *first = B.first + (size_t)F.band_scy0 * (size_t)F.xb;
+  const int i = (int)((blockIdx.x - 1) * 256 + threadIdx.x) * 16;
+  if (i + 16 <= ncell) { uint4 z = {0, 0, 0, 0}; *(uint4 *)(first + i) = z; }       // cell arrays are 256-byte aligned allocations
+  else for (int k = i; k < ncell; k++) first[k] = 0;
+}
+void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_clear_b, dim3((max_cells + 4095) / 4096 + 1, 1, nframes), dim3(256), 0, s, Bs);
+}
+void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
+  hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B);
+}
+void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_lf_smooth_b, dim3((max_cells + 255) / 256, 1, nframes), dim3(256), 0, s, Bs);
+}
+
+}  // namespace jxlamd

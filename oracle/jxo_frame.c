@@ -1043,7 +1043,7 @@ static int extract_codestream(const uint8_t *d, size_t n, uint8_t **cs, size_t *
       sz = 0; for (int i = 0; i < 8; i++) sz = (sz << 8) | d[pos + 8 + i];
       hdr = 16;
     } else if (sz == 0) sz = n - pos;
-    if (sz < hdr || pos + sz > n) { free(buf); JXO_FAIL("bad box size"); }
+    if (sz < hdr || sz > (uint64_t)(n - pos)) { free(buf); JXO_FAIL("bad box size"); }
     if (!memcmp(ty, "jxlc", 4)) { memcpy(buf + out, d + pos + hdr, sz - hdr); out += sz - hdr; }
     else if (!memcmp(ty, "jxlp", 4)) { if (sz - hdr < 4) { free(buf); JXO_FAIL("bad jxlp"); } memcpy(buf + out, d + pos + hdr + 4, sz - hdr - 4); out += sz - hdr - 4; }
     pos += sz;

@@ -49,6 +49,27 @@ CASES = {
 }
 
 
+# Tall multi-LF-group frames for the band-sharded decode (BASELINE config 4 in miniature): 17 group rows = 3 LF-group rows.
+# Expected pixels are too large to commit: the .jxl + per-row sums of the reference's output (the band test's main assertion is
+# bit-identity with the whole-frame decode, which these sums pin to the reference).
+ROWSUM_CASES = {
+    "vb264x4200_e7_epf3": (264, 4200, dict(seed=11), dict(effort=7, epf=3)),      # Gaborish + 3 EPF iterations: halo H = 7 rows
+    "vb520x4400_e7": (520, 4400, dict(seed=12), dict(effort=7)),                  # encoder defaults at d = 1: Gaborish + 1 iteration, H = 3
+}
+
+
+def add_rowsum_cases(meta, only):
+    for name, (w, h, sk, ek) in ROWSUM_CASES.items():
+        if only and name not in only:
+            continue
+        data = jxl_ref.encode(synth.photo_like(w, h, **sk), **ek)
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), encode=ek, synth=sk,
+                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))])
+        print(name, len(data), out.shape)
+
+
 def with_alpha(img):
     """deterministic alpha plane: smooth waves plus fully transparent / fully opaque rectangles"""
     h, w = img.shape[:2]
@@ -95,6 +116,7 @@ def main():
         print(name, len(data), out.shape)
     if not only or "assets" in only:
         add_assets(meta)
+    add_rowsum_cases(meta, only)
     if only:
         json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
         return
