@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — decoded MP/s of the JPEG XL decode hot path on MI355X (BASELINE.json metric).
 
-Workload at N=1: BASELINE.json configs[1] — one 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frame -> RGBA8.
-A "step" = one full decode of that frame: host header/TOC/global-table parse, H2D of the frame tables, all HIP
-kernels (LF/modular + AC entropy decode, dequant + inverse DCT, Gaborish/EPF, XYB->RGBA).  The compressed bytes and
-the RGBA output are resident in HBM (jxlamd_decode_resident + JXLAMD_OUT_DEVICE); nothing is cached between steps.
+Workload at N=1: BASELINE.json configs[2] — a batch of 256 x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8
+(8 distinct seeded frames cycled).  A "step" = one such batch; every frame is a full decode: host header/TOC/global-table parse,
+H2D of the frame tables, all HIP kernels (LF/modular + AC entropy decode, dequant + inverse DCT, Gaborish/EPF, XYB->RGBA).  The
+compressed bytes and the RGBA output are resident in HBM (jxlamd_decode_batch_resident + JXLAMD_OUT_DEVICE); nothing is cached
+between frames or steps.  The strictly sequential single-frame latency (configs[1]) is reported in `config`.
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank decodes its own frames — independent
 units, no data-path collective — weak scaling; value = frames of all ranks / max-over-ranks time.
 """
@@ -19,7 +20,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FRAME = os.path.join(ROOT, "bench_data", "syn4k_q90_seed0.jxl")
+FRAMES = [os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{i}.jxl") for i in range(8)]
+FRAMES = [f for f in FRAMES if os.path.exists(f)]
+FRAME = FRAMES[0]
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
 
@@ -63,15 +66,30 @@ def cpu_baseline(data, budget_s=12.0):
         return {"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": f"CPU baseline unavailable: {e}"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = one batch of --batch 4K frames")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step (BASELINE configs[2]: 256 x 3840x2160 q90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=8, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=128, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
 
     import torch
     import torch.distributed as dist
@@ -84,32 +102,36 @@ def main():
     import jxl_coder_amd as J
     from jxl_coder_amd.shard import max_over_ranks
 
-    data = open(FRAME, "rb").read()
+    # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
+    datas = [open(f, "rb").read() for f in FRAMES]
+    data = datas[0]
     w, h = J.JxlCoder.getSize(data)
+    assert all(J.JxlCoder.getSize(d) == (w, h) for d in datas)
     out_bytes = w * h * 4
-    # Steps are issued in flights of P frames through jxlamd_decode_batch_resident: every frame is parsed, uploaded,
-    # decoded and written separately (nothing is shared or cached between steps), but the entropy stages of the P
+    B = max(1, args.batch)
+    total_frames = args.steps * B
+    # A step's frames are issued in flights of P frames through jxlamd_decode_batch_resident: every frame is parsed, uploaded,
+    # decoded and written separately (nothing is shared or cached between frames or steps), but the entropy stages of the P
     # frames of a flight go into ONE launch each.  A frame's entropy stages are serial per stream (4 LF-group + 135
     # AC wavefronts for one 4K frame) and leave the chip almost empty; a decode service fills it with frames in
     # flight.  --inflight 1 gives the strictly sequential single-frame number (also reported below).
-    P = max(1, min(args.inflight, args.steps))
-    NCTX = max(1, min(args.contexts, (args.steps + P - 1) // P))
+    P = max(1, min(args.inflight, B))
+    NCTX = max(1, min(args.contexts, (total_frames + P - 1) // P))
     decs = [J.JxlDecoder(local) for _ in range(NCTX)]
-    dec = decs[0]
-    d_in = torch.frombuffer(bytearray(data) + bytearray(64), dtype=torch.uint8).to(f"cuda:{local}")   # compressed bytes resident in HBM
+    d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(f"cuda:{local}") for d in datas]   # compressed bytes resident in HBM
     d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
     import threading
 
-    def run_steps(n):
+    def run_frames(n):
         """n full decodes.  Flights of P frames; NCTX decoder contexts (own HIP stream + HBM buffers each) take flights
-        alternately so that one flight's LF stage (256 wavefronts on the whole chip) overlaps another's later stages."""
+        alternately so that one flight's entropy stages overlap another's data-parallel stages."""
         acc = {}
         lock = threading.Lock()
         todo = []
         done = 0
         while done < n:
-            p = min(P, n - done); todo.append(p); done += p
-
+            p = min(P, n - done); todo.append((done, p)); done += p
+        todo.reverse()
         errors = []
 
         def worker(c):
@@ -124,13 +146,15 @@ def main():
                 with lock:
                     if not todo:
                         return
-                    p = todo.pop()
+                    first, p = todo.pop()
+                ids = [(rank + first + j) % len(datas) for j in range(p)]
                 for attempt in (0, 1):
                     try:
                         if p == 1:
-                            decs[c].decode_to_device(data, d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr())
+                            decs[c].decode_to_device(datas[ids[0]], d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[ids[0]].data_ptr())
                         else:
-                            decs[c].decode_batch_to_device([data] * p, [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p, [d_in.data_ptr()] * p)
+                            decs[c].decode_batch_to_device([datas[i] for i in ids], [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p,
+                                                           [d_ins[i].data_ptr() for i in ids])
                         break
                     except J.InvalidJXLException:
                         # Safety net: a flight rejected by the decoder's own rANS final-state checks is decoded again
@@ -155,28 +179,29 @@ def main():
         assert acc.get("frames", 0) == n, (acc.get("frames", 0), n)
         return acc
 
-    prime = run_steps(P * NCTX)              # untimed setup: every context allocates the HBM work buffers of a full flight
-    warm = run_steps(max(args.warmup, 0)) if args.warmup > 0 else {}   # W untimed warmup steps
-    # sequential single-frame latency (one context), reported next to the throughput
+    prime = run_frames(P * NCTX)             # untimed setup: every context allocates the HBM work buffers of a full flight
+    warm = run_frames(args.warmup * B) if args.warmup > 0 else {}   # W untimed warmup steps
+    # sequential single-frame latency (one context; BASELINE configs[1]), reported next to the throughput
     lat = []
     for _ in range(3):
-        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_in.data_ptr()); lat.append(time.perf_counter() - t)
+        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[0].data_ptr()); lat.append(time.perf_counter() - t)
     seq_stage = decs[0].last_timing()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern = run_steps(args.steps)     # every C-ABI call returns when its pixels are in HBM
+    kern = run_frames(total_frames)     # every C-ABI call returns when its pixels are in HBM
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
     if rank == 0:
-        frames = args.steps * world
+        frames = total_frames * world
         mp = w * h / 1e6
         value = frames * mp / elapsed
-        algo_bytes = len(data) + out_bytes                       # compressed read + RGBA written, per frame
+        mean_in = sum(len(d) for d in datas) / len(datas)
+        algo_bytes = mean_in + out_bytes                         # compressed read + RGBA written, per frame
         # dominant kernel of the TIMED region: the batched LF-group kernel (one launch per flight of P frames), timed
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
@@ -184,33 +209,41 @@ def main():
         names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt of the first sub-flight" if P > 1 else "k_pass_group") + " (+k_lf_smooth)",
                  "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt, k_recon_*, k_filter_b<*>" if P > 1 else "k_recon_small_b+k_recon_list_b", "filters_write_ms": "k_filter_b<0..4>"}
         stages = {k: kern[k] / flights for k in names if k in kern}
-        dom = "lf_groups_ms"      # rocprofv3 --stats of this command: k_lf_group_batch has the largest total (profiles/r01_*bench.csv)
+        dom = "lf_groups_ms"      # rocprofv3 --stats of this command: the batched LF-group kernel has the largest total (profiles/)
         dom_ms = stages[dom]
-        frames_per_launch = args.steps / flights
+        frames_per_launch = total_frames / flights
         achieved = algo_bytes * frames_per_launch / (dom_ms * 1e-3) / 1e9
         seq = {k: round(v, 4) for k, v in seq_stage.items()}
+        # HBM traffic of the dominant kernel from the PMC passes kept under profiles/ (FETCH_SIZE + WRITE_SIZE per frame, collected as
+        # MI355X_MICROARCH.md prescribes: separate --pmc runs); null until a pass for this round's kernel is committed
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = int(tj["dominant_kernel_bytes_per_frame"] * frames_per_launch); traffic_src = tj.get("source")
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": "decoded MP/s (4K VarDCT q90 -> RGBA8)", "value": round(value, 2), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: single 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frame -> RGBA8 per step, "
-                                   "compressed input and RGBA output resident in HBM; steps issued in flights of frames_in_flight frames",
-                       "frame_bytes": len(data), "frames_per_step_per_gpu": 1, "frames_in_flight": P, "decoder_contexts": NCTX, "retried_flights": int(kern.get("retried_flights", 0)),
+            "config": {"workload": f"configs[2]: one step = a batch of {B} x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8 per GPU "
+                                   f"({len(datas)} distinct seeded frames cycled), every frame a complete decode (host parse, table upload, all kernels); compressed "
+                                   "bytes resident in HBM when the timed region starts (PCIe H2D excluded, DESIGN.md §7), RGBA output stays in HBM",
+                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
-                       "parallelism": f"frames sharded over {world} GPU(s), no collective"},
+                       "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         # PMC passes (profiles/r01_pmc_fetch_write_4k_single_frame.json): FETCH 1 869 KB + WRITE 4 479 KB per frame
-                         "traffic": int(frames_per_launch * (1868.9 + 4478.8) * 1024),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": names[dom], "kernel_ms": round(dom_ms, 4), "launches": flights,
                          # the same HIP-event average over EVERY batched launch of the process (priming + warm-up + timed): the
                          # figure to hold against the rocprofv3 --stats average of this command, which cannot tell them apart
-                         "kernel_ms_all_launches": round(sum(a.get(dom, 0.0) for a in (prime, warm, kern) if a.get("frames", 0) > 1 or a is kern) /
-                                                         max(sum(int(a.get("flights", 0)) for a in (prime, warm, kern) if a.get("frames", 0) > 1 or a is kern), 1), 4),
+                         "kernel_ms_all_launches": round(sum(a.get(dom, 0.0) for a in (prime, warm, kern) if a) /
+                                                         max(sum(int(a.get("flights", 0)) for a in (prime, warm, kern) if a), 1), 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes * frames_per_launch),
+                         "whole_pipeline_GBps": round(value * 1e6 * (algo_bytes / (w * h)) / 1e9 / world, 2),
                          "stage_ms_per_flight": {k: round(v, 4) for k, v in stages.items()},
-                         "note": "the entropy-decode kernels are latency/occupancy-bound (one wavefront per serial rANS stream), not "
+                         "note": "the entropy-decode kernels are latency/occupancy-bound (serial rANS streams), not "
                                  "bandwidth-bound; achieved = algorithmic bytes / duration of the dominant kernel"},
         }
         line["cpu_baseline"] = ({"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": "skipped"}

@@ -162,19 +162,71 @@ def test_flight_subflights_and_pools_in_a_small_configuration():
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the driver's fields plus `roofline` and `cpu_baseline` (short run, CPU leg skipped)."""
     import json, subprocess, sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "256", "--warmup", "2", "--inflight", "64", "--contexts", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "96", "--inflight", "48", "--contexts", "2",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in line, k
-    assert line["unit"] == "MP/s" and line["n_gpus"] == 1 and line["steps"] == 256 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["unit"] == "MP/s" and line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["higher_is_better"] is True
     assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
-    assert line["value"] > 100 and abs(line["ms_per_step"] * line["value"] / (3840 * 2160 / 1e3) - 1) < 0.02      # value == MP per step / time per step
+    assert line["value"] > 100 and abs(line["ms_per_step"] * line["value"] / (96 * 3840 * 2160 / 1e3) - 1) < 0.02      # value == MP per step / time per step
     rf = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
         assert k in rf, k
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 and rf["kernel_ms"] > 0
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert line["config"]["retried_flights"] == 0
+
+
+def test_config3_flight_of_distinct_4k_frames_equals_single_decodes(dec, golden_meta):
+    """BASELINE configs[2] at full frame size: a flight of DISTINCT seeded 4K q90 frames through jxlamd_decode_batch_resident gives the
+    very pixels of single decodes, and every frame matches the reference's row sums (committed; tools/make_bench_frames.py)."""
+    import torch
+    names = [f"syn4k_q90_seed{i}" for i in range(8)]
+    datas = [open(os.path.join(ROOT, "bench_data", n + ".jxl"), "rb").read() for n in names]
+    order = [3, 0, 7, 1, 6, 2, 5, 4, 0, 3]
+    outs = [torch.zeros(3840 * 2160 * 4, dtype=torch.uint8, device="cuda") for _ in order]
+    d_in = [torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda() for d in datas]      # unpadded resident input: the decoder pads its own copy
+    dec.decode_batch_to_device([datas[i] for i in order], [o.data_ptr() for o in outs], [o.numel() for o in outs], [d_in[i].data_ptr() for i in order])
+    torch.cuda.synchronize()
+    singles = {}
+    for k, i in enumerate(order):
+        if i not in singles:
+            singles[i] = dec.decode_one_shot(datas[i])[0]
+            rs = [int(x) for x in singles[i][::240].astype(np.int64).sum(axis=(1, 2))]
+            assert max(abs(a - b) / b for a, b in zip(rs, golden_meta[names[i]]["row_sums"])) < 1e-4, names[i]
+        assert np.array_equal(outs[k].cpu().numpy().reshape(2160, 3840, 4), singles[i]), (k, i)
+
+
+def test_config5_full_size_pq16_epf3_tone_map_f16(dec):
+    """BASELINE configs[4] shape at full frame size: 4K Rec.2100 PQ 16-bit, EPF = 3, from the reference's encoder -> RGBA16 in HBM ->
+    API<34 colour pipeline (PQ -> Rec.2408 tone map -> Rec.709 -> sRGB; cpp/colorspaces/ColorMatrix.cpp) -> RGBA_F16 reformat
+    (cpp/ReformatBitmap.cpp), as a flight of 4; decode vs the reference's libjxl run live, post stages vs the numpy oracle."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("oracle/_ref (the reference's libjxl) did not travel to this box")
+    import synth, post_oracle as P
+    import jxl_coder_amd as J
+    w, h, n = 3840, 2160, 4
+    data = jxl_ref.encode(synth.photo_like(w, h, seed=21, bits=16), effort=7, distance=1.0, epf=3, primaries=9, transfer=16, intensity_target=10000.0, threads=0)
+    ref = jxl_ref.decode(data, threads=0, allow16=True)[0]
+    out1, info = dec.decode_one_shot(data, allowed_floats=True)
+    assert out1.dtype == np.uint16 and info["transfer_function"] == 16 and info["primaries"] == 9
+    d = np.abs(out1.astype(np.int32) - ref.astype(np.int32))
+    assert d.mean() <= U16_MEAN_ABS and (d > U16_MAX_ABS).mean() < 2e-3          # PQ: statistical bound (conftest.py)
+    outs = [torch.empty(w * h * 8, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    f16 = [torch.empty(w * h * 8, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    dec.decode_batch_to_device([data] * n, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+    for o, f in zip(outs, f16):
+        dec.color_matrix_device(o.data_ptr(), w, h, True, 16, 9, 16, info["intensity_target"])
+        dec.reformat_device(o.data_ptr(), w, h, True, 16, J.PreferredColorConfig.RGBA_F16, False, False, 29, f.data_ptr(), f.numel())
+    torch.cuda.synchronize()
+    exp = P.u16_to_f16(P.color_matrix(out1, 16, 9, 16, None, info["intensity_target"]), 16)
+    for f in (f16[0], f16[-1]):
+        got = f.cpu().numpy().view(np.uint16).reshape(h, w, 4)
+        assert (got != exp).mean() < 5e-3                                        # LUT-entry +-1 (oracle built without -ffast-math)
+        assert np.abs(got.view(np.float16).astype(np.float32) - exp.view(np.float16).astype(np.float32)).max() < 2e-2
