@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libjxlamd.so")
+_LIB_PATH = os.environ.get("JXLAMD_LIB") or os.path.join(_HERE, "libjxlamd.so")     # JXLAMD_LIB: an experimental build of the same sources (tools/build_variant.sh)
 _lib = None
 
 

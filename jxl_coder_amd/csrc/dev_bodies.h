@@ -20,6 +20,9 @@ struct DevAux {
 template <bool kWave = true, class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
   JXL_STAMP(0);
+#ifdef __HIPCC__
+  const uint64_t cyc0 = __builtin_readcyclecounter();      // shader clock (s_memtime): with the 100 MHz wall stamps it gives the effective clock
+#endif
   if (tid == 0) lf_phase_open(B, S, g);
   sync();
   modular_stream_stage(S, tid, nthreads);
@@ -45,6 +48,9 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   JXL_STAMP(5);
   lf_group_epilogue(B, g, tid, nthreads);
   JXL_STAMP(6);
+#ifdef __HIPCC__
+  if (tid == 0 && A.lf_times) A.lf_times[g * 8 + 7] = __builtin_readcyclecounter() - cyc0;
+#endif
 }
 
 // ---- PassGroup: one workgroup (one wave) per 256x256 group; passes are sequential inside

@@ -34,7 +34,7 @@ struct DevModStream {                 // what lane 0 hands to the other lanes / 
   uint32_t err;
 };
 
-struct DevWaveTree {                  // LDS: the pruned tree of one channel in ballot form
+struct alignas(16) DevWaveTree {      // LDS: the pruned tree of one channel in ballot form (16-byte aligned: the WP-only loop overlays b128 records)
   int32_t int_prop[64], int_split[64];
   uint64_t leaf_need1[64], leaf_need0[64];
   int32_t leaf_ctx[64], leaf_pred[64], leaf_off[64], leaf_mul[64];
@@ -48,6 +48,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t wp_err[2 * (kWpMaxW + 2)];
   int32_t props[32];
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
+  uint32_t wdiv[4][64];               // divlut pre-multiplied by the WP header weights (wave_decode_channel_wpfixed)
   uint32_t cfg[kLocMaxClusters];
   // Table pool, carved per stream by modular_stream_stage: [alias tables | context map | head of the MA tree].  A part
   // that does not fit stays in HBM (the pointers below then address the HBM copy).  libjxl's LF streams need

@@ -103,9 +103,9 @@ __device__ __forceinline__ T predict_plain_t(int predictor, T W, T N, T NW, T NE
 // uses the weighted predictor (property 15 or predictor 6).
 template <bool kLds, bool kM16, bool kWP>
 __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
-                                                    DevWaveTree &WT, const DevChanOut c, int lane) {
+                                                    DevWaveTree &WT, const DevChanOut c, int lane, int y_end = 0x7fffffff) {
   typedef typename std::conditional<kM16, int32_t, int64_t>::type T;
-  const int w = c.w, h = c.h;
+  const int w = c.w, h = c.h < y_end ? c.h : y_end;      // rows [0, y_end): the specialised loops below take over from there
   const bool wide = w > kModMaxW;
   const int ni = WT.ni, nl = WT.nl;
   const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
@@ -265,6 +265,197 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
   #undef WAVE_DIV
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Specialised loop for libjxl's LF-coefficient streams (effort >= 7 "kWPFixedDC": every decision node of the channel's tree tests
+// property 15 — the weighted predictor's max error — and every leaf uses the weighted predictor, multiplier 1, offset 0).
+// That is 73 % of the Modular samples of a 4K VarDCT frame and the longest dependency chain of the whole decode.
+//   * context: the decision nodes are thresholds on ONE value, so the leaf is a function of how many thresholds lie below it:
+//     one v_cmp + s_bcnt1 + v_readlane (lane c keeps the cluster / hybrid-uint config of "c thresholds below") instead of two
+//     ballots and five readlanes;
+//   * weighted predictor: lane l evaluates sub-predictor k = l & 3 (error weight, prediction, product), the sums over k are two
+//     DPP quad-permute adds each — the four-fold scalar repetition of the generic loop is gone;
+//   * everything that only depends on the PREVIOUS row (neighbour values and errors, error-sum bases, the parts of the four
+//     predictions that do not involve W, clamp bounds, the max-error candidate) is computed for 32 samples at a time by 32 lanes
+//     in parallel and handed to the serial loop through LDS records (3 ds_reads per sample);
+//   * the reciprocal table is pre-multiplied by the header weights (S.wdiv), the row is copied to HBM once per row.
+// Same integer arithmetic as wave_decode_channel<true, true, true> (bit-exact); rows [0, 1) still go through the generic loop
+// (in row 0 every neighbour is the late value W).
+struct DevWpFixedLds {                   // overlays DevWaveTree (dead once the channel's tree sits in registers)
+  int32_t U[32][8];                      // per sample of the chunk: q, |q|, tN, tN ^ tNW, max(N8, NE8), min(N8, NE8)
+  int32_t K[32][4][4];                   // per sample and sub-predictor k: error-sum base, A_k, B_k
+};
+static_assert(sizeof(DevWpFixedLds) <= sizeof(DevWaveTree), "the chunk records live in the tree's LDS");
+
+__device__ __forceinline__ int quad_sum_i32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  return v;
+}
+// lane l takes `keep` from lane l - 1 (wave_shr:1) / l - 4 within its row of 16 (row_shr:4); the lanes without a source take `fresh`
+__device__ __forceinline__ int shift_in_wave1(int fresh, int keep) { return __builtin_amdgcn_update_dpp(fresh, keep, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ int shift_in_row4(int fresh, int keep) { return __builtin_amdgcn_update_dpp(fresh, keep, 0x114, 0xF, 0xF, false); }
+__device__ __forceinline__ int med3_i32(int v, int lo, int hi) { int r; asm volatile("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi)); return r; }
+
+// Bit reader of the lock-step loops: every lane holds the same reader, so its conditions are wave-uniform — branching on a ballot
+// gives scalar branches (no exec save / restore around the rarely taken refill).
+__device__ __forceinline__ void ubits_refill(DevBits &b) {
+  if (__ballot(b.n <= 32)) {
+    b.buf |= (uint64_t)b.ahead << b.n;
+    b.n += 32;
+    b.ahead = __ballot(b.next < b.end) ? *b.next : 0u;
+    b.next++;
+  }
+}
+__device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <= 32, uniform; n == 0 reads nothing
+  ubits_refill(b);
+  const uint32_t v = (uint32_t)(b.buf & ((1ull << n) - 1));
+  b.buf >>= n; b.n -= n; b.consumed += (uint64_t)n;
+  return v;
+}
+
+__device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
+                                                            const DevChanOut c, int lane, int my_split, int my_off, int my_cfg, int y_begin) {
+  const int w = c.w, h = c.h;
+  DevWpFixedLds &R = *(DevWpFixedLds *)&S.wt;
+  const int k = lane & 3;
+  const int PT = k == 1 ? wp.p1 : k == 2 ? wp.p2 : 0;
+  const int PW = k == 3 ? -wp.p3e : 0;
+  const int cWmask = (k & 1) ? 0 : -1;         // sub-predictors 0 and 2 start from W
+  const bool use_pw = wp.p3e != 0;             // uniform
+  const uint32_t *wdiv = S.wdiv[k];
+  const int la = ev.log_alpha, lb = 12 - la;
+  const uint8_t *alias = (const uint8_t *)S.pool;          // DevAlias as one 64-bit word: cutoff | right << 8 | off1 << 16 | freq0 << 32 | freq1 << 48
+  for (int i = lane; i < 256; i += 64) S.wdiv[i >> 6][i & 63] = (uint32_t)wp.w[i >> 6] * S.divlut[i & 63];
+  __syncthreads();
+  for (int y = y_begin; y < h; y++) {
+    int32_t *row = S.rows[y % 3];
+    const int32_t *rN = S.rows[(y + 2) % 3];
+    const int32_t *rNN = S.rows[(y + 1) % 3];
+    const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
+    int32_t W8 = rN[0] * 8, tW = 0;           // x = 0: W is replaced by N, its error by 0
+    uint32_t e1 = 0, e2 = 0;                  // this lane's sub-predictor error of the previous / second previous sample
+    for (int x0 = 0; x0 < w; x0 += 32) {
+      const int n = w - x0 < 32 ? w - x0 : 32;
+      if (lane < n) {                         // ---- parallel part: everything sample x0 + lane takes from the previous rows
+        const int x = x0 + lane, pos = prev_row + x;
+        const bool has_l = x > 0, has_r = x + 1 < w;
+        const int32_t N = rN[x], NE = has_r ? rN[x + 1] : N, NW = has_l ? rN[x - 1] : N, NN = y > 1 ? rNN[x] : N;
+        const int32_t tN = S.wp_err[pos], tNE = has_r ? S.wp_err[pos + 1] : tN, tNW = has_l ? S.wp_err[pos - 1] : tN;
+        const int32_t N8 = N * 8, NE8 = NE * 8, NW8 = NW * 8, NN8 = NN * 8;
+        int32_t q = tN;
+        if (tabs<int32_t>(tNW) > tabs<int32_t>(q)) q = tNW;
+        if (tabs<int32_t>(tNE) > tabs<int32_t>(q)) q = tNE;
+        int4 u0; int2 u1;
+        u0.x = q; u0.y = tabs<int32_t>(q); u0.z = tN; u0.w = tN ^ tNW; u1.x = N8 > NE8 ? N8 : NE8; u1.y = N8 < NE8 ? N8 : NE8;
+        *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.U[lane][4] = u1;
+        #pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const uint32_t EN = S.wp_pred_err[kk][pos], ENE = has_r ? S.wp_pred_err[kk][pos + 1] : EN, ENW = has_l ? S.wp_pred_err[kk][pos - 1] : EN;
+          int4 r;
+          r.x = (int32_t)(EN + ENE + ENW);
+          r.y = kk == 0 ? NE8 - N8 : kk == 2 ? 0 : N8;
+          r.z = kk == 0 ? 0 : kk == 1 ? (tN + tNE) * wp.p1 : kk == 2 ? (tN + tNW) * wp.p2
+                            : tNW * wp.p3a + tN * wp.p3b + tNE * wp.p3c + (NN8 - N8) * wp.p3d + NW8 * wp.p3e;
+          r.w = 0;
+          *(int4 *)&R.K[lane][kk][0] = r;
+        }
+      }
+      __syncthreads();
+      // ---- serial part.  The results leave through lane shift registers (one DPP move each per sample, no masked stores): after the
+      // chunk lane l holds value and true error of sample n - 1 - l; lanes 0..15 hold the sub-predictor errors of the last four samples.
+      int32_t keep_val = 0, keep_te = 0, keep_e = 0;
+      int4 u0 = *(const int4 *)&R.U[0][0]; int2 u1 = *(const int2 *)&R.U[0][4];
+      int4 kr = *(const int4 *)&R.K[0][k][0];
+      auto step = [&](const int i, auto last_tag) {
+        constexpr bool kLastOfRow = decltype(last_tag)::value;
+        // context: property 15 = the error of largest magnitude among W, N, NW, NE (first one wins ties); the leaf is a function of
+        // how many thresholds lie below it
+        const int32_t aW = tabs<int32_t>(tW);
+        const int32_t p = u0.y > aW ? u0.x : tW;
+        const int cnt = __builtin_popcountll(__ballot(p > my_split));
+        const uint32_t aoff = (uint32_t)__builtin_amdgcn_readlane(my_off, cnt);       // byte offset of the cluster's alias table
+        const uint32_t cfg = (uint32_t)__builtin_amdgcn_readlane(my_cfg, cnt);
+        const uint32_t ai = __builtin_amdgcn_ubfe(state, lb, la);
+        const uint64_t a = *(const uint64_t *)(alias + aoff + (ai << 3));             // LDS
+        // weighted predictor, sub-predictor k per lane: error weight
+        uint32_t e = (uint32_t)kr.x + e1 + e2;
+        if (kLastOfRow) e += e1;              // no NE: the N error sum (which carries e1) counts twice
+        int sh = 26 - __builtin_clz(e + 1);
+        sh = sh < 0 ? 0 : sh;
+        const uint32_t wd = wdiv[e >> sh];                                            // LDS
+        // records of the next sample: issued behind the two reads this sample waits for (LDS returns in order), used next step
+        const int inext = i + 1 < 32 ? i + 1 : 31;
+        const int4 u0n = *(const int4 *)&R.U[inext][0]; const int2 u1n = *(const int2 *)&R.U[inext][4];
+        const int4 krn = *(const int4 *)&R.K[inext][k][0];
+        __builtin_amdgcn_sched_barrier(0);
+        // ... prediction of sub-predictor k and the clamp bounds while the tables come in
+        int32_t inner = kr.z + __mul24(tW, PT);
+        if (use_pw) inner += __mul24(W8, PW);
+        const int32_t wpk = kr.y + (W8 & cWmask) - (inner >> 5);
+        const int32_t mx = u1.x > W8 ? u1.x : W8, mn = u1.y < W8 ? u1.y : W8;
+        const bool no_clamp = ((u0.z ^ tW) | u0.w) > 0;
+        uint32_t wgt = 4 + (wd >> sh);
+        const uint32_t wsum = (uint32_t)quad_sum_i32((int)wgt);
+        wgt >>= (27 - __builtin_clz(wsum));
+        const uint32_t wsum2 = (uint32_t)quad_sum_i32((int)wgt);
+        const uint32_t dv = S.divlut[wsum2 - 1];                                      // LDS; wsum2 in [13, 31]: dv < 2^21
+        const int32_t sum = quad_sum_i32(__mul24(wpk, (int32_t)wgt)) + (int32_t)(wsum2 >> 1) - 1;
+        // rANS symbol + hybrid uint
+        const uint32_t apos = state & ((1u << lb) - 1);
+        const uint32_t cutoff = (uint32_t)a & 0xff, rsym = ((uint32_t)a >> 8) & 0xff, off1 = (uint32_t)a >> 16;
+        const uint32_t freq0 = (uint32_t)(a >> 32) & 0xffff, freq1 = (uint32_t)(a >> 48);
+        const bool right = apos >= cutoff;
+        uint32_t u = right ? rsym : ai;
+        const uint32_t off = right ? off1 + apos : apos;
+        const uint32_t freq = right ? freq1 : freq0;
+        state = __umul24(freq, state >> 12) + off;                                    // freq <= 4096, state >> 12 < 2^20
+        if (__ballot(state < (1u << 16))) state = (state << 16) | ubits_read(b, 16);
+        const uint32_t split_exp = cfg & 0xff;
+        if (__ballot(u >= (1u << split_exp))) {                                       // hybrid uint: tokens below the split are the value
+          const uint32_t msb = (cfg >> 8) & 0xff, lsb = (cfg >> 16) & 0xff;
+          uint32_t nbits = split_exp - (msb + lsb) + ((u - (1u << split_exp)) >> (msb + lsb));
+          if (nbits > 31) nbits = 31;         // corrupt stream; the final-state check flags it
+          const uint32_t low = u & ((1u << lsb) - 1);
+          const uint32_t tok = u >> lsb;
+          const uint32_t bits = ubits_read(b, (int)nbits);
+          u = (((((1u << msb) | (tok & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+        }
+        // (sum * dv) >> 24 as the high half of sum * (dv << 8): one multiply instead of a 64-bit product
+        int32_t raw = __mulhi(sum, (int32_t)(dv << 8));
+        const int32_t cl = med3_i32(raw, mn, mx);
+        raw = no_clamp ? raw : cl;
+        const int32_t val = unpack_signed(u) + ((raw + 3) >> 3);
+        // this sample's errors feed the next one
+        const int32_t v8 = val * 8;
+        const int32_t d = wpk - v8;
+        const int32_t err = (tabs<int32_t>(d) + 3) >> 3;
+        tW = raw - v8; W8 = v8; e2 = e1; e1 = (uint32_t)err;
+        keep_val = shift_in_wave1(val, keep_val); keep_te = shift_in_wave1(tW, keep_te);
+        keep_e = shift_in_row4(err, keep_e);
+        u0 = u0n; u1 = u1n; kr = krn;
+      };
+      const bool row_ends = x0 + n == w;          // this chunk carries the row's last sample (no NE neighbour): its step is a separate instantiation
+      const int nn = row_ends ? n - 1 : n;
+      int i = 0;
+      #pragma unroll 1
+      for (; i + 4 <= nn; i += 4) {
+        step(i, std::false_type()); step(i + 1, std::false_type()); step(i + 2, std::false_type()); step(i + 3, std::false_type());
+        // lanes 4j + k, j = 0..3, hold the error of sub-predictor k for sample i + 3 - j
+        if (lane < 16) S.wp_pred_err[k][cur_row + x0 + i + 3 - (lane >> 2)] = (uint32_t)keep_e;
+      }
+      const int rem = n - i;                      // 0..4 samples left, the row's last one among them when row_ends
+      #pragma unroll 1
+      for (; i < nn; i++) step(i, std::false_type());
+      if (row_ends) step(i, std::true_type());
+      if (lane < 4 * rem) S.wp_pred_err[k][cur_row + x0 + n - 1 - (lane >> 2)] = (uint32_t)keep_e;
+      if (lane < n) { row[x0 + n - 1 - lane] = keep_val; S.wp_err[cur_row + x0 + n - 1 - lane] = keep_te; }
+      __syncthreads();
+    }
+    int32_t *out = c.d + (size_t)y * (size_t)w;
+    for (int x = lane; x < w; x += 64) out[x] = row[x];      // one coalesced copy per row
+  }
+}
+
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 template <bool kLds>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
@@ -279,6 +470,35 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     if (!WT.ok) return kErrWaveFallback;                    // caller re-runs the stream with the serial walker
     const bool uses_wp = WT.uses_wp != 0;
     if (c.w > kModMaxW && uses_wp) return kErrUnsupportedTransform;
+    // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
+    if (kLds && m16 && uses_wp && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
+        __ballot(lane < WT.ni && WT.int_prop[lane] != 15) == 0 &&
+        __ballot(lane < WT.nl && (WT.leaf_pred[lane] != 6 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
+      const int ni = WT.ni, nl = WT.nl;
+      const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+      const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+      const int my_lclu = lane < nl ? (int)((const uint8_t *)S.pool)[S.ctx_off + WT.leaf_ctx[lane]] : 0;
+      // rank the thresholds; lane c then holds a value with exactly c thresholds below it
+      int rank = 0;
+      for (int j = 0; j < ni; j++) { const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }
+      __syncthreads();
+      if (lane < ni) S.rows[0][rank] = my_split;     // rows[0] as 64-entry scratch (row 0 below rewrites it)
+      __syncthreads();
+      const int rep = lane == 0 ? S.rows[0][0] : (lane <= ni ? S.rows[0][lane - 1] + 1 : 0);
+      int my_off = 0, my_cfg = 0;
+      for (int cc = 0; cc <= ni; cc++) {
+        const int pc = __builtin_amdgcn_readlane(rep, cc);
+        const uint64_t dec = __ballot(lane < ni && pc > my_split);
+        const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
+        const int leaf = lm ? __builtin_ctzll(lm) : 0;
+        const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
+        if (lane == cc) { my_off = clu << (ev.log_alpha + 3); my_cfg = (int)S.cfg[clu]; }
+      }
+      __syncthreads();
+      wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
+      wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_cfg, /*y_begin=*/1);
+      continue;
+    }
     if (m16) { if (uses_wp) wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, true, false>(ev, b, state, wp, S, WT, c, lane); }
     else { if (uses_wp) wave_decode_channel<kLds, false, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, false, false>(ev, b, state, wp, S, WT, c, lane); }
   }
