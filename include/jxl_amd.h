@@ -118,6 +118,7 @@ int jxlamd_last_timing(const jxlamd_decoder *dec, float ms[5]);
  * [0] start, [1] LF stream staged, [2] LF coefficients decoded, [3] metadata stream staged, [4] metadata decoded,
  * [5] varblocks placed, [6] epilogue done. */
 int jxlamd_debug_lf_phases(jxlamd_decoder *dec, int num_lf_groups, uint64_t *out);
+int jxlamd_debug_lf_phases_frame(jxlamd_decoder *dec, int frame, int num_lf_groups, uint64_t *out);   /* same, frame `frame` of the last flight */
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Post-decode stages of the reference's JNI layer, on buffers that stay in HBM.

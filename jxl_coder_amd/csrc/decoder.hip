@@ -392,8 +392,27 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2);
   // LF map: group-major — the long streams (full 256x256-cell LF groups, 240 ms) are dispatched first and the short edge
   // groups (15 ms) fill the slots they leave, instead of long and short workgroups alternating
-  int max_lfg = 0;
-  for (int i : batched) max_lfg = std::max(max_lfg, slot((size_t)i).plan.num_lf_groups);
+  int max_lfg = 0, n_lf_streams = 0;
+  for (int i : batched) { max_lfg = std::max(max_lfg, slot((size_t)i).plan.num_lf_groups); n_lf_streams += slot((size_t)i).plan.num_lf_groups; }
+  const bool lf_simt = n_lf_streams >= simt_lf_min;
+  if (lf_simt) {
+    // lane-per-stream LF kernel: the 64 sections of a wavefront must share their geometry (lock-step over channel / y / x and
+    // coalesced rows of the lane-interleaved state), so the map is sorted by (cells, width), largest first
+    struct Ent { int key, k, g; };
+    std::vector<Ent> ents;
+    for (int k = 0; k < nb; k++) {
+      const FramePlan &P = slot((size_t)batched[(size_t)k]).plan;
+      const int xlfg = (P.xb + 255) / 256;
+      for (int g = 0; g < P.num_lf_groups; g++) {
+        const int bw = std::min(256, P.xb - (g % xlfg) * 256), bh = std::min(256, P.yb - (g / xlfg) * 256);
+        ents.push_back({(bw * bh) * 512 + bw, k, g});
+      }
+    }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key > b.key; });
+    for (const Ent &e : ents) { lf_map.push_back(e.k); lf_map.push_back(e.g); }
+    HIPCHECK(simt_waves.ensure((size_t)((n_lf_streams + 63) / 64) * lf_simt_wave_bytes()));
+    HIPCHECK(simt_scratch.ensure((size_t)n_lf_streams * lf_simt_scratch_bytes()));
+  } else
   for (int g = 0; g < max_lfg; g++)
     for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
@@ -413,7 +432,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
+  if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, stream);
+  else launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
@@ -462,7 +482,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
+  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
@@ -604,6 +624,13 @@ int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) 
   if (!d || d->slots.empty() || !d->slots[0]->misc.p) return JXLAMD_ERR_DEVICE;
   if (num_lf_groups < 0 || num_lf_groups > d->slots[0]->plan.num_lf_groups) return JXLAMD_ERR_BUFFER;
   return hipMemcpy(out, (uint8_t *)d->slots[0]->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
+}
+
+int jxlamd_debug_lf_phases_frame(jxlamd_decoder *d, int frame, int num_lf_groups, uint64_t *out) {     // frame = slot index inside the last flight
+  if (!d || frame < 0 || (size_t)frame >= d->slots.size() || !d->slots[(size_t)frame]->misc.p) return JXLAMD_ERR_DEVICE;
+  FrameSlot &S = *d->slots[(size_t)frame];
+  if (num_lf_groups < 0 || num_lf_groups > S.plan.num_lf_groups) return JXLAMD_ERR_BUFFER;
+  return hipMemcpy(out, (uint8_t *)S.misc.p + 4096 + (size_t)S.plan.num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
 }
 
 int jxlamd_last_timing(const jxlamd_decoder *d, float ms[5]) {

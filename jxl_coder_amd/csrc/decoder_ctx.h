@@ -101,7 +101,7 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
@@ -109,6 +109,7 @@ struct jxlamd_decoder {
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
+  int simt_lf_min = getenv("JXLAMD_SIMT_LF_MIN") ? atoi(getenv("JXLAMD_SIMT_LF_MIN")) : 0x7fffffff;     // LfGroup sections in a flight from which the lane-per-stream LF kernel takes over (off by default: measured slower)
   int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
   void set_error(const std::string &e) { error = e; tls_error() = e; }

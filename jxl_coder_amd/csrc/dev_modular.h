@@ -19,7 +19,7 @@ constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
 struct DevChanOut { int32_t *d; int32_t w, h; };
 
-constexpr int kModPoolBytes = 20480;  // LDS table pool of one stream (alias tables, context map, tree head)
+constexpr int kModPoolBytes = 30720;  // LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
 struct DevTrList { DevTr t[4]; int32_t n; };
@@ -49,6 +49,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t props[32];
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
   uint32_t wdiv[4][64];               // divlut pre-multiplied by the WP header weights (wave_decode_channel_wpfixed)
+  uint32_t ring[128];                 // the next 512 bytes of the stream, refilled half by half far ahead of the reader (wave_decode_channel_wpfixed)
   uint32_t cfg[kLocMaxClusters];
   // Table pool, carved per stream by modular_stream_stage: [alias tables | context map | head of the MA tree].  A part
   // that does not fit stays in HBM (the pointers below then address the HBM copy).  libjxl's LF streams need

@@ -313,8 +313,63 @@ __device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <
   return v;
 }
 
+// Alias tables of a whole stream in 1.25 KB per cluster instead of 2 KB: entry i -> 32 bits (cutoff | right symbol << 8 | offsets1 << 16),
+// the two frequencies of an entry are D[i] and D[right], so one table of D per cluster (u16 x 128 symbols) serves both — at the price
+// of a dependent LDS read on the rANS chain, which has slack next to the weighted predictor's.  libjxl's LF streams carry up to one
+// cluster per context (34); 23 fit the pool.  Returns false (pool untouched) when a symbol >= 128 can occur.
+constexpr int kPackedClusterBytes = 1024 + 256;
+__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, int num_clusters, int log_alpha, DevModScratch &S, int lane) {
+  if (log_alpha != 8 || num_clusters * kPackedClusterBytes > kModPoolBytes) return false;
+  const int n = num_clusters << 8;
+  bool bad = false;
+  for (int i = lane; i < n; i += 64) { const DevAlias e = galias[i]; bad |= ((i & 255) >= 128 && e.freq0 != 0) || e.right >= 128; }
+  if (__ballot(bad)) return false;
+  __syncthreads();
+  uint32_t *ent = (uint32_t *)S.pool;
+  uint16_t *D = (uint16_t *)((uint8_t *)S.pool + (size_t)num_clusters * 1024);
+  for (int i = lane; i < n; i += 64) {
+    const DevAlias e = galias[i];
+    ent[i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
+    if ((i & 255) < 128) D[((i >> 8) << 7) + (i & 127)] = e.freq0;
+  }
+  __syncthreads();
+  return true;
+}
+
+// Bit reader over an LDS ring (wave_decode_channel_wpfixed): the next 512 bytes of the stream sit in S.ring, refilled 256 bytes at a
+// time by all lanes ~450 samples before the reader gets there, so the serial loop never waits on a global load — next to the
+// memory-bound kernels of other decoder contexts such a load takes microseconds, and one was due every ~7 samples.
+struct RingBits {
+  uint64_t buf; int32_t n; uint32_t ahead; int32_t widx; uint64_t consumed;
+  const uint32_t *base, *end;         // word 0 of the ring's index space; first word past the padded stream
+};
+__device__ __forceinline__ void ring_fill_half(uint32_t *ring, const RingBits &r, int first_word, int lane) {
+  const uint32_t *p = r.base + first_word + lane;
+  ring[(first_word + lane) & 127] = p < r.end ? *p : 0u;
+}
+__device__ __forceinline__ void ring_open(uint32_t *ring, RingBits &r, const DevBits &b, int lane) {
+  r.buf = b.buf; r.n = b.n; r.ahead = b.ahead; r.widx = 0; r.consumed = b.consumed; r.base = b.next; r.end = b.end;
+  ring_fill_half(ring, r, 0, lane); ring_fill_half(ring, r, 64, lane);
+  __syncthreads();
+}
+__device__ __forceinline__ void ring_close(const RingBits &r, DevBits &b) {
+  b.buf = r.buf; b.n = r.n; b.ahead = r.ahead; b.next = r.base + r.widx; b.consumed = r.consumed;
+}
+__device__ __forceinline__ uint32_t ring_read(uint32_t *ring, RingBits &r, int n, int lane) {     // n <= 32, uniform
+  if (__ballot(r.n <= 32)) {
+    r.buf |= (uint64_t)r.ahead << r.n;
+    r.n += 32;
+    r.ahead = ring[r.widx & 127];
+    r.widx++;
+    if ((__builtin_amdgcn_readfirstlane(r.widx) & 63) == 0) ring_fill_half(ring, r, r.widx + 64, lane);      // the half just left behind
+  }
+  const uint32_t v = (uint32_t)(r.buf & ((1ull << n) - 1));
+  r.buf >>= n; r.n -= n; r.consumed += (uint64_t)n;
+  return v;
+}
+
 __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
-                                                            const DevChanOut c, int lane, int my_split, int my_off, int my_cfg, int y_begin) {
+                                                            const DevChanOut c, int lane, int my_split, int my_off, int my_doff, int my_cfg, int y_begin) {
   const int w = c.w, h = c.h;
   DevWpFixedLds &R = *(DevWpFixedLds *)&S.wt;
   const int k = lane & 3;
@@ -324,9 +379,10 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
   const bool use_pw = wp.p3e != 0;             // uniform
   const uint32_t *wdiv = S.wdiv[k];
   const int la = ev.log_alpha, lb = 12 - la;
-  const uint8_t *alias = (const uint8_t *)S.pool;          // DevAlias as one 64-bit word: cutoff | right << 8 | off1 << 16 | freq0 << 32 | freq1 << 48
+  const uint8_t *pool8 = (const uint8_t *)S.pool;          // packed alias entries + per-symbol frequencies (wave_pack_alias)
   for (int i = lane; i < 256; i += 64) S.wdiv[i >> 6][i & 63] = (uint32_t)wp.w[i >> 6] * S.divlut[i & 63];
-  __syncthreads();
+  RingBits rb;
+  ring_open(S.ring, rb, b, lane);
   for (int y = y_begin; y < h; y++) {
     int32_t *row = S.rows[y % 3];
     const int32_t *rN = S.rows[(y + 2) % 3];
@@ -373,10 +429,11 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         const int32_t aW = tabs<int32_t>(tW);
         const int32_t p = u0.y > aW ? u0.x : tW;
         const int cnt = __builtin_popcountll(__ballot(p > my_split));
-        const uint32_t aoff = (uint32_t)__builtin_amdgcn_readlane(my_off, cnt);       // byte offset of the cluster's alias table
+        const uint32_t aoff = (uint32_t)__builtin_amdgcn_readlane(my_off, cnt);       // byte offsets of the cluster's packed alias entries
+        const uint32_t doff = (uint32_t)__builtin_amdgcn_readlane(my_doff, cnt);      // ... and of its frequency table
         const uint32_t cfg = (uint32_t)__builtin_amdgcn_readlane(my_cfg, cnt);
         const uint32_t ai = __builtin_amdgcn_ubfe(state, lb, la);
-        const uint64_t a = *(const uint64_t *)(alias + aoff + (ai << 3));             // LDS
+        const uint32_t ent = *(const uint32_t *)(pool8 + aoff + (ai << 2));           // LDS: cutoff | right << 8 | off1 << 16
         // weighted predictor, sub-predictor k per lane: error weight
         uint32_t e = (uint32_t)kr.x + e1 + e2;
         if (kLastOfRow) e += e1;              // no NE: the N error sum (which carries e1) counts twice
@@ -402,14 +459,12 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         const int32_t sum = quad_sum_i32(__mul24(wpk, (int32_t)wgt)) + (int32_t)(wsum2 >> 1) - 1;
         // rANS symbol + hybrid uint
         const uint32_t apos = state & ((1u << lb) - 1);
-        const uint32_t cutoff = (uint32_t)a & 0xff, rsym = ((uint32_t)a >> 8) & 0xff, off1 = (uint32_t)a >> 16;
-        const uint32_t freq0 = (uint32_t)(a >> 32) & 0xffff, freq1 = (uint32_t)(a >> 48);
-        const bool right = apos >= cutoff;
-        uint32_t u = right ? rsym : ai;
-        const uint32_t off = right ? off1 + apos : apos;
-        const uint32_t freq = right ? freq1 : freq0;
+        const bool right = apos >= (ent & 0xff);
+        uint32_t u = right ? (ent >> 8) & 0xff : ai;
+        const uint32_t off = right ? (ent >> 16) + apos : apos;
+        const uint32_t freq = *(const uint16_t *)(pool8 + doff + (u << 1));           // LDS, dependent: the symbol's frequency
         state = __umul24(freq, state >> 12) + off;                                    // freq <= 4096, state >> 12 < 2^20
-        if (__ballot(state < (1u << 16))) state = (state << 16) | ubits_read(b, 16);
+        if (__ballot(state < (1u << 16))) state = (state << 16) | ring_read(S.ring, rb, 16, lane);
         const uint32_t split_exp = cfg & 0xff;
         if (__ballot(u >= (1u << split_exp))) {                                       // hybrid uint: tokens below the split are the value
           const uint32_t msb = (cfg >> 8) & 0xff, lsb = (cfg >> 16) & 0xff;
@@ -417,7 +472,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
           if (nbits > 31) nbits = 31;         // corrupt stream; the final-state check flags it
           const uint32_t low = u & ((1u << lsb) - 1);
           const uint32_t tok = u >> lsb;
-          const uint32_t bits = ubits_read(b, (int)nbits);
+          const uint32_t bits = ring_read(S.ring, rb, (int)nbits, lane);
           u = (((((1u << msb) | (tok & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
         }
         // (sum * dv) >> 24 as the high half of sum * (dv << 8): one multiply instead of a 64-bit product
@@ -454,6 +509,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
     int32_t *out = c.d + (size_t)y * (size_t)w;
     for (int x = lane; x < w; x += 64) out[x] = row[x];      // one coalesced copy per row
   }
+  ring_close(rb, b);
 }
 
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
@@ -461,6 +517,9 @@ template <bool kLds>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
                                                         int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
                                                         const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
+  DevECView evg = S.st.ev;                 // the stream's tables where the parser left them (HBM / L2)
+  if (S.st.num_clusters <= kLocMaxClusters) evg.cfg = S.cfg;
+  bool pool_packed = false;                // S.pool re-used for the packed alias tables of the weighted-predictor loop
   for (int ci = 0; ci < nch; ci++) {
     const DevChanOut c = chans[ci];
     if (c.w == 0 || c.h == 0) continue;
@@ -471,13 +530,14 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     const bool uses_wp = WT.uses_wp != 0;
     if (c.w > kModMaxW && uses_wp) return kErrUnsupportedTransform;
     // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
-    if (kLds && m16 && uses_wp && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
+    if (m16 && uses_wp && !ev.use_prefix && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
+        (pool_packed || (S.st.num_clusters <= kLocMaxClusters && S.st.num_clusters * kPackedClusterBytes <= kModPoolBytes && ev.log_alpha == 8)) &&
         __ballot(lane < WT.ni && WT.int_prop[lane] != 15) == 0 &&
         __ballot(lane < WT.nl && (WT.leaf_pred[lane] != 6 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
       const int ni = WT.ni, nl = WT.nl;
       const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
       const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
-      const int my_lclu = lane < nl ? (int)((const uint8_t *)S.pool)[S.ctx_off + WT.leaf_ctx[lane]] : 0;
+      const int my_lclu = lane < nl ? (int)evg.ctx_map[WT.leaf_ctx[lane]] : 0;
       // rank the thresholds; lane c then holds a value with exactly c thresholds below it
       int rank = 0;
       for (int j = 0; j < ni; j++) { const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }
@@ -485,18 +545,28 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       if (lane < ni) S.rows[0][rank] = my_split;     // rows[0] as 64-entry scratch (row 0 below rewrites it)
       __syncthreads();
       const int rep = lane == 0 ? S.rows[0][0] : (lane <= ni ? S.rows[0][lane - 1] + 1 : 0);
-      int my_off = 0, my_cfg = 0;
+      int my_off = 0, my_doff = 0, my_cfg = 0;
       for (int cc = 0; cc <= ni; cc++) {
         const int pc = __builtin_amdgcn_readlane(rep, cc);
         const uint64_t dec = __ballot(lane < ni && pc > my_split);
         const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
-        if (lane == cc) { my_off = clu << (ev.log_alpha + 3); my_cfg = (int)S.cfg[clu]; }
+        if (lane == cc) { my_off = clu << 10; my_doff = (S.st.num_clusters << 10) + (clu << 8); my_cfg = (int)S.cfg[clu]; }
       }
       __syncthreads();
-      wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
-      wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_cfg, /*y_begin=*/1);
+      // row 0 goes through the generic loop (every neighbour is the late value W there); once the pool holds the packed tables
+      // the generic loops of this stream read their tables through L2 instead
+      if (pool_packed) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane, /*y_end=*/1);
+      else wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
+      __syncthreads();
+      if (!pool_packed) pool_packed = wave_pack_alias(evg.alias, S.st.num_clusters, ev.log_alpha, S, lane);
+      if (pool_packed) { wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1); continue; }
+      return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
+    }
+    if (pool_packed) {            // the pool no longer holds this stream's 8-byte alias tables / context map
+      if (m16) { if (uses_wp) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane); else wave_decode_channel<false, true, false>(evg, b, state, wp, S, WT, c, lane); }
+      else { if (uses_wp) wave_decode_channel<false, false, true>(evg, b, state, wp, S, WT, c, lane); else wave_decode_channel<false, false, false>(evg, b, state, wp, S, WT, c, lane); }
       continue;
     }
     if (m16) { if (uses_wp) wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, true, false>(ev, b, state, wp, S, WT, c, lane); }

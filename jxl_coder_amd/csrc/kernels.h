@@ -6,6 +6,11 @@
 namespace jxlamd {
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, hipStream_t s);
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
+// lane-per-stream LfGroup decode (flights): map sorted so that the 64 sections of a wavefront share their geometry; `waves` holds
+// ceil(n / 64) x lf_simt_wave_bytes(), `scratch` n x lf_simt_scratch_bytes() of HBM
+size_t lf_simt_wave_bytes();
+size_t lf_simt_scratch_bytes();
+void launch_lf_groups_simt(const DevBuffers *Bs, const DevAux *As, const int *map, int n, void *waves, void *scratch, hipStream_t s);
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);

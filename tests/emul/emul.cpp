@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../jxl_coder_amd/csrc/dev_bodies.h"
 #include "../../jxl_coder_amd/csrc/dev_modframe.h"
+#include "../../jxl_coder_amd/csrc/dev_lf_simt.h"
 #include "../../jxl_coder_amd/csrc/host_parse.h"
 
 using namespace jxlamd;
@@ -67,6 +68,15 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   DevModScratch *MS = new DevModScratch();
   uint64_t mod_end = 0; B.mod_end_bit = &mod_end;
   if (plan.has_ec) mod_global_body(B, *MS, 0, 1, NoSync());       // GlobalModular part of the extra channels: before LfGroup 0
+  if (getenv("JXLEMUL_SIMT_LF")) {        // the lane-per-stream LfGroup decoder (k_lf_group_simt), one lane at a time
+    LfSimtWave *Wv = new LfSimtWave(); LfSimtLds *Lds = new LfSimtLds();
+    for (int i = 0; i < 64; i++) Lds->divlut[i] = (1u << 24) / (uint32_t)(i + 1);
+    for (int g = 0; g < plan.num_lf_groups; g++) {
+      const uint32_t e = lf_group_lane(B, A, *MS, *Wv, *Lds, g, (g * 7 + 3) % 64);
+      if (e) err |= e; else lf_group_epilogue(B, g, 0, 1);
+    }
+    delete Wv; delete Lds;
+  } else
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
   delete MS;
   if (err) { g_err = "device flags " + std::to_string(err) + " (LfGroup)"; return -2; }

@@ -89,6 +89,9 @@ def test_alternate_device_paths_give_identical_pixels(emul, monkeypatch, name):
     monkeypatch.setenv("JXLEMUL_SIMT_PASS", "1")
     alt = emul(data)
     assert np.array_equal(base, alt)
+    monkeypatch.setenv("JXLEMUL_SIMT_LF", "1")          # lane-per-stream LfGroup decoder (dev_lf_simt.h, k_lf_group_simt)
+    alt2 = emul(data)
+    assert np.array_equal(base, alt2)
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
