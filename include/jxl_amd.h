@@ -36,6 +36,11 @@ typedef struct {
   uint32_t out_bits;                /* 8 or 16: bitDepth out-param */
   uint32_t prefer_encoding;         /* JxlDecoding.cpp:126-133 (operator-precedence quirk reproduced) */
   uint32_t has_alpha_in_origin;     /* num_extra_channels > 0 && alpha_bits > 0 (JxlDecoding.cpp:111) */
+  /* JxlColorEncoding's chromaticities as libjxl fills them for every encoded profile (enum values resolved to their xy;
+   * JniDecoding.cpp:177-186 reads them for custom primaries): white_point_xy, primaries_red/green/blue_xy; zero for grey primaries */
+  double white_point_xy[2], primaries_red_xy[2], primaries_green_xy[2], primaries_blue_xy[2];
+  uint32_t icc_size;                /* bytes jxlamd_get_icc returns for this file (0: none obtainable) */
+  uint32_t reserved;
 } jxlamd_info;
 
 enum {
@@ -60,6 +65,12 @@ const char *jxlamd_last_error(const jxlamd_decoder *dec);  /* dec may be NULL: l
 
 /* DecodeBasicInfo: header-only parse, host only. */
 int jxlamd_basic_info(const uint8_t *jxl, size_t size, jxlamd_info *info);
+
+/* The ICC profile DecodeJpegXlOneShot hands back when !prefer_encoding (interop/JxlDecoding.cpp:135-141): the codestream's embedded ICC
+ * profile, decoded on the host (ISO/IEC 18181-1 Annex E.4).  info.icc_size = its size (0: none).  Host only, no decoder needed.
+ * Profiles libjxl would SYNTHESISE for an enum colour encoding that the reference does not 'prefer' (linear / unknown transfer) are not
+ * generated: icc_size stays 0 for those. */
+int jxlamd_get_icc(const uint8_t *jxl, size_t size, uint8_t *icc, size_t capacity, size_t *icc_size);
 
 /* Bytes needed for the RGBA output of this file under `flags`. */
 int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *bytes);
@@ -162,6 +173,16 @@ int jxlamd_reformat(jxlamd_decoder *dec, void *src_dev, uint32_t w, uint32_t h, 
  * (the caller checks preferEncoding / colour space / API level < 34 as JniDecoding.cpp:131-137 does). */
 int jxlamd_color_matrix(jxlamd_decoder *dec, void *pixels_dev, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries,
                         uint32_t transfer_function, const double *xy8, float intensity_target);
+
+/* RescaleImage of `decodeSampled` (cpp/SizeScaler.cpp:38-144 -> weaver/src/scale.rs): runs between jxlamd_decode and jxlamd_color_matrix
+ * (cpp/JniDecoding.cpp:116-136).  new_w / new_h: requested size, -1 = keep the aspect ratio, -2 = same rounded up to even
+ * (resolve_dimensions, scale.rs:94-130); scale_mode: 1 Fit, 2 Fill, 3 Resize (cpp/SizeScaler.h:36-40; Fit / Fill scale uniformly and centre-crop,
+ * scale.rs:202-234); sampler: XSampler 1..10 (cpp/XScaler.h).  premultiply_alpha = the reference's doesOriginHasAlpha.
+ * The geometry is integer-exact; the filter arithmetic restates the published filter definitions (pic-scale is not vendored). */
+typedef struct jxlamd_rescale_info { uint32_t scaled_w, scaled_h, crop_x, crop_y, out_w, out_h; } jxlamd_rescale_info;
+int jxlamd_rescale_query(uint32_t w, uint32_t h, int new_w, int new_h, int scale_mode, jxlamd_rescale_info *out);
+int jxlamd_rescale(jxlamd_decoder *dec, const void *src_dev, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int new_w, int new_h, int scale_mode,
+                   int sampler, int premultiply_alpha, void *dst_dev, size_t dst_capacity, jxlamd_rescale_info *out);
 
 #ifdef __cplusplus
 }

@@ -55,14 +55,20 @@ class Info(C.Structure):
                [(n, C.c_uint32) for n in ("have_encoded_profile", "color_space", "white_point", "primaries",
                                           "transfer_function", "rendering_intent")] + \
                [("gamma", C.c_double)] + \
-               [(n, C.c_uint32) for n in ("out_bits", "prefer_encoding", "has_alpha_in_origin")]
+               [(n, C.c_uint32) for n in ("out_bits", "prefer_encoding", "has_alpha_in_origin")] + \
+               [(n, C.c_double * 2) for n in ("white_point_xy", "primaries_red_xy", "primaries_green_xy", "primaries_blue_xy")] + \
+               [("icc_size", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n.endswith("_xy") else getattr(self, n)) for n, _ in self._fields_}
 
 
 class ReformatInfo(C.Structure):               # jxlamd_reformat_info (include/jxl_amd.h)
     _fields_ = [("stride", C.c_uint32), ("format", C.c_uint32), ("use_floats", C.c_uint32), ("resolved_config", C.c_uint32), ("bytes", C.c_uint64)]
+
+
+class RescaleInfo(C.Structure):                # jxlamd_rescale_info
+    _fields_ = [(n, C.c_uint32) for n in ("scaled_w", "scaled_h", "crop_x", "crop_y", "out_w", "out_h")]
 
 
 FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
@@ -70,7 +76,7 @@ FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
 JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
-SOURCES = ["kernels_lf.hip", "kernels_lf_simt.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
+SOURCES = ["kernels_lf.hip", "kernels_lf_simt.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
 
 
 def library_path():
@@ -114,6 +120,14 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise RuntimeError(f"{_LIB_PATH} is missing: run jxl_coder_amd.build() (python -c 'import __graft_entry__ as g; g.build()'). "
                                "There is no CPU fallback for the decode path.")
+        try:
+            # torch bundles its own libamdhip64 next to the system one libjxlamd.so links: when both live in one process the runtime
+            # that initialises FIRST must be torch's (the other order leaves torch with "No HIP GPUs are available")
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         L.jxlamd_decoder_create.restype = C.c_void_p
         L.jxlamd_decoder_create.argtypes = [C.c_int]
@@ -131,6 +145,9 @@ def lib():
                                       C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
         L.jxlamd_color_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_float]
+        L.jxlamd_rescale_query.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(RescaleInfo)]
+        L.jxlamd_rescale.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t, C.POINTER(RescaleInfo)]
         L.jxlamd_band_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_band_halo_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.jxlamd_band_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -236,6 +253,22 @@ class JxlDecoder:
             _raise(rc, self._h)
         return [i.as_dict() for i in infos]
 
+    def rescale_query(self, w, h, new_w, new_h, scale_mode):
+        ri = RescaleInfo()
+        rc = lib().jxlamd_rescale_query(w, h, int(new_w), int(new_h), int(scale_mode), C.byref(ri))
+        if rc:
+            _raise(rc, None)
+        return ri
+
+    def rescale_device(self, src_ptr, w, h, is_u16, depth, new_w, new_h, scale_mode, sampler, premultiply_alpha, dst_ptr, dst_capacity):
+        """A9 on device buffers (jxlamd_rescale; cpp/SizeScaler.cpp:38-144)."""
+        ri = RescaleInfo()
+        rc = lib().jxlamd_rescale(self._h, src_ptr, w, h, int(is_u16), depth, int(new_w), int(new_h), int(scale_mode), int(sampler), int(premultiply_alpha),
+                                  dst_ptr, dst_capacity, C.byref(ri))
+        if rc:
+            _raise(rc, self._h)
+        return ri
+
     # ---- band-sharded decode of one frame (include/jxl_amd.h "Band-sharded decode"; jxl_coder_amd/shard.py drives it)
     def band_begin(self, data: bytes, group_row0: int, group_row1: int, out_ptr: int, out_capacity: int, allowed_floats=True):
         flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE
@@ -278,12 +311,22 @@ class JxlDecoder:
         return dict(zip(("lf_groups_ms", "pass_groups_ms", "recon_ms", "filters_write_ms", "device_total_ms"), list(t)))
 
 
-def _check_preconditions(cfg, scale_mode):
-    """checkDecodePreconditions (cpp/Support.cpp:35-92): reject ints outside the enums."""
+def _check_preconditions(cfg, scale_mode, sampler=6, os_version=34):
+    """checkDecodePreconditions (cpp/Support.cpp:35-92), same order and messages: enum 0 / out-of-range config, the API-level gates of
+    RGBA_1010102 (33+), RGBA_F16 (26+), HARDWARE (29+), scale mode, sampler.  The reference throws java.lang.Exception with these
+    strings (throwException); the mirror raises ValueError."""
     if int(cfg) < 1 or int(cfg) > 6:
-        raise ValueError("Invalid Color Config")
+        raise ValueError(f"Invalid Color Config: {int(cfg)} was passed")
+    if int(cfg) == PreferredColorConfig.RGBA_1010102 and os_version < 33:
+        raise ValueError(f"Color Config RGBA_1010102 supported only 33+ OS version but current is: {os_version}")
+    if int(cfg) == PreferredColorConfig.RGBA_F16 and os_version < 26:
+        raise ValueError(f"Color Config RGBA_1010102 supported only 26+ OS version but current is: {os_version}")     # the reference's own wording (Support.cpp:57-61)
+    if int(cfg) == PreferredColorConfig.HARDWARE and os_version < 29:
+        raise ValueError(f"Color Config HARDWARE supported only 29+ OS version but current is: {os_version}")
     if int(scale_mode) < 1 or int(scale_mode) > 3:
         raise ValueError("Invalid Scale Mode was passed")
+    if int(sampler) < 1 or int(sampler) > 10:           # XSampler, cpp/SizeScaler.h
+        raise ValueError(f"Invalid Sampler: {int(sampler)} was passed")
 
 
 class JxlCoder:
@@ -316,11 +359,9 @@ class JxlCoder:
     @classmethod
     def decodeSampled(cls, data: bytes, width: int, height: int, preferredColorConfig=PreferredColorConfig.DEFAULT,
                       scaleMode=ScaleMode.FIT, jxlResizeFilter=6):
-        _check_preconditions(preferredColorConfig, scaleMode)
+        _check_preconditions(preferredColorConfig, scaleMode, jxlResizeFilter, cls.api_level)
         use_sampler = (width > 0 or height > 0) and (width != 0 and height != 0)      # JniDecoding.cpp:116-117
-        if use_sampler:
-            raise UnsupportedJXLFeature("decodeSampled resampling (weaver / pic-scale) is a 'next' row, SURVEY.md §8f")
-        return cls._decode_pipeline(data, preferredColorConfig).pixels_view()
+        return cls._decode_pipeline(data, preferredColorConfig, None, (width, height, scaleMode, jxlResizeFilter) if use_sampler else None).pixels_view()
 
     # Android API level the mirror emulates: >= 34 tags the Bitmap with a ColorSpace and leaves the pixels alone, below 34 the
     # reference converts to sRGB / Rec.709 with applyColorMatrix (cpp/JniDecoding.cpp:131-228).  ReformatColorConfig's
@@ -335,7 +376,7 @@ class JxlCoder:
         return cls._decode_pipeline(data, preferredColorConfig, api_level)
 
     @classmethod
-    def _decode_pipeline(cls, data, config, api_level=None):
+    def _decode_pipeline(cls, data, config, api_level=None, sampling=None):
         import numpy as np
         import torch
         api = cls.api_level if api_level is None else int(api_level)
@@ -349,6 +390,12 @@ class JxlCoder:
         raw = torch.empty(w * h * 4 * (2 if is16 else 1), dtype=torch.uint8, device=dev)
         meta = dec.decode_to_device(data, raw.data_ptr(), raw.numel(), allowed_floats=True)
         depth = 16 if is16 else 8                                  # bitDepth as DecodeJpegXlOneShot reports it (JxlDecoding.cpp:92-101)
+        if sampling is not None:                                   # A9 RescaleImage (JniDecoding.cpp:116-136), before the colour matrix
+            sw, sh, mode, sampler = sampling
+            q = dec.rescale_query(w, h, sw, sh, mode)
+            scaled = torch.empty(q.out_w * q.out_h * 4 * (2 if is16 else 1), dtype=torch.uint8, device=dev)
+            dec.rescale_device(raw.data_ptr(), w, h, is16, depth, sw, sh, mode, sampler, bool(meta["has_alpha_in_origin"]), scaled.data_ptr(), scaled.numel())
+            raw, w, h = scaled, q.out_w, q.out_h
         tf = meta["transfer_function"]
         if meta["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and meta["color_space"] == 0 and api < 34:   # JniDecoding.cpp:131-137
             dec.color_matrix_device(raw.data_ptr(), w, h, is16, depth, meta["primaries"], tf, meta["intensity_target"])

@@ -28,6 +28,23 @@ static void fill_public_info(const ImageInfo &i, uint32_t flags, jxlamd_info *o)
   o->prefer_encoding = o->have_encoded_profile &&
                        ((o->color_space == 0 && tf == 18) || tf == 16 || tf == 17 || tf == 1 || tf == 13 || tf == 65535u);
   o->has_alpha_in_origin = i.num_extra_channels > 0 && i.alpha_bits > 0;
+  o->icc_size = i.icc_size;
+  if (o->have_encoded_profile) {          // chromaticities of the enum values, as libjxl's ColorEncoding reports them
+    static const double kWp[4][2] = {{0.3127, 0.3290}, {0, 0}, {1.0 / 3, 1.0 / 3}, {0.314, 0.351}};       // D65, custom, E (10), DCI (11)
+    const double *wp = i.white_point == 1 ? kWp[0] : i.white_point == 10 ? kWp[2] : i.white_point == 11 ? kWp[3] : nullptr;
+    if (wp) { o->white_point_xy[0] = wp[0]; o->white_point_xy[1] = wp[1]; }
+    else { o->white_point_xy[0] = i.wp_xy[0]; o->white_point_xy[1] = i.wp_xy[1]; }
+    if (i.color_space == 0 || i.color_space == 3) {      // RGB / unknown carry primaries
+      static const double kPr[3][6] = {{0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204},      // sRGB (1)
+                                       {0.708, 0.292, 0.170, 0.797, 0.131, 0.046},                                           // BT.2100 (9)
+                                       {0.680, 0.320, 0.265, 0.690, 0.150, 0.060}};                                          // P3 (11)
+      double pr[6];
+      const double *src = i.primaries == 1 ? kPr[0] : i.primaries == 9 ? kPr[1] : i.primaries == 11 ? kPr[2] : nullptr;
+      for (int k = 0; k < 6; k++) pr[k] = src ? src[k] : (double)i.prim_xy[k];
+      o->primaries_red_xy[0] = pr[0]; o->primaries_red_xy[1] = pr[1]; o->primaries_green_xy[0] = pr[2]; o->primaries_green_xy[1] = pr[3];
+      o->primaries_blue_xy[0] = pr[4]; o->primaries_blue_xy[1] = pr[5];
+    }
+  }
 }
 
 static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
@@ -482,7 +499,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
+  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->resample_tmp.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
@@ -495,6 +512,15 @@ int jxlamd_basic_info(const uint8_t *jxl, size_t size, jxlamd_info *info) {
   ImageInfo ii; std::string err;
   if (parse_basic_info(jxl, size, &ii, &err)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
   fill_public_info(ii, JXLAMD_ALLOW_16BIT, info);
+  return JXLAMD_OK;
+}
+
+int jxlamd_get_icc(const uint8_t *jxl, size_t size, uint8_t *icc, size_t capacity, size_t *icc_size) {
+  ImageInfo ii; std::string err; std::vector<uint8_t> bytes;
+  if (parse_basic_info(jxl, size, &ii, &err, &bytes)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
+  if (icc_size) *icc_size = bytes.size();
+  if (bytes.size() > capacity || (!icc && !bytes.empty())) { g_tls_error = "output buffer too small"; return JXLAMD_ERR_BUFFER; }
+  if (!bytes.empty()) memcpy(icc, bytes.data(), bytes.size());
   return JXLAMD_OK;
 }
 

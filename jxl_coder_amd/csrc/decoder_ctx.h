@@ -101,7 +101,7 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch, resample_tmp;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)

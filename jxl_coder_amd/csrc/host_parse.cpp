@@ -20,6 +20,8 @@ typedef struct {
 } hx_info;
 typedef struct { int nbands; float b[3][8]; } hx_dctparams;
 #include "host_format.inc"
+#include <algorithm>
+#include "host_icc.inc"
 #include "dither_lut.h"
 }  // namespace
 
@@ -97,6 +99,7 @@ static void fill_info(const img_meta &m, ImageInfo *i) {
   i->xyb_encoded = p.xyb_encoded; i->uses_original_profile = !p.xyb_encoded; i->intensity_target = p.intensity_target;
   i->want_icc = p.want_icc; i->color_space = p.color_space; i->white_point = p.white_point; i->primaries = p.primaries;
   i->transfer_function = p.transfer_function; i->rendering_intent = p.rendering_intent; i->have_gamma = p.have_gamma; i->gamma = p.gamma;
+  memcpy(i->wp_xy, m.wp_xy, sizeof(i->wp_xy)); memcpy(i->prim_xy, m.prim_xy, sizeof(i->prim_xy));
 }
 
 static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
@@ -227,14 +230,25 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
 
 }  // namespace
 
-int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error) {
+int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error, std::vector<uint8_t> *icc) {
   uint8_t *cs; size_t csn; int owned;
   if (extract_codestream(data, size, &cs, &csn, &owned)) { if (error) *error = hx_last_error(); return -1; }
   hx_br br; hx_br_init(&br, cs, csn);
   img_meta m;
   int rc = read_image_header(&br, &m);
   if (rc) { if (error) *error = hx_last_error(); }
-  else fill_info(m, info);
+  else {
+    fill_info(m, info);
+    info->icc_size = 0;
+    // only a non-XYB image reports its embedded profile (see plan_parse): the reference's libjxl outputs XYB + ICC images as sRGB
+    if (m.pub.want_icc && !m.pub.xyb_encoded) {
+      std::vector<uint8_t> tmp;
+      if (read_icc_stream(&br, &tmp) == 0) { info->icc_size = (uint32_t)tmp.size(); if (icc) icc->swap(tmp); }
+      else { rc = -1; if (error) *error = hx_last_error(); }
+    } else if (m.pub.want_icc) {
+      info->want_icc = 0; info->color_space = 0; info->white_point = 1; info->primaries = 1; info->transfer_function = 13; info->have_gamma = 0; info->rendering_intent = 1;
+    }
+  }
   if (owned) free(cs);
   return rc;
 }
@@ -254,7 +268,16 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   img_meta &m = pv->m;
   if (read_image_header(&br, &m)) { plan->error = hx_last_error(); return -1; }
   fill_info(m, &plan->info);
-  if (m.pub.want_icc) { plan->error = "unsupported: embedded ICC profile"; return -1; }
+  if (m.pub.want_icc) {
+    // The reference never hands libjxl a CMS (interop/JxlDecoding.cpp:46-75), so an XYB image with an embedded profile comes out in sRGB with
+    // an sRGB enum profile (probed on the reference's own assets: jxl_icc_12.bit.jxl, wide_gamut.jxl, ...): the stream is skipped here.
+    // A non-XYB (Modular) image keeps its samples in the profile's space; the bytes are available through jxlamd_get_icc.
+    std::vector<uint8_t> icc;
+    if (read_icc_stream(&br, m.pub.xyb_encoded ? nullptr : &icc)) { plan->error = hx_last_error(); return -1; }
+    if (m.pub.xyb_encoded) { m.pub.want_icc = 0; m.pub.color_space = 0; m.pub.white_point = 1; m.pub.primaries = 1; m.pub.transfer_function = 13; m.pub.have_gamma = 0; m.pub.rendering_intent = 1; }
+    fill_info(m, &plan->info);
+    plan->info.icc_size = (uint32_t)icc.size();
+  }
   if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
   if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
   uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;

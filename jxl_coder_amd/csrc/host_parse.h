@@ -18,8 +18,10 @@ struct ImageInfo {            // what DecodeJpegXlOneShot / DecodeBasicInfo repo
   uint32_t have_animation = 0, xyb_encoded = 1, uses_original_profile = 0;
   float intensity_target = 255.f;
   uint32_t want_icc = 0;
+  uint32_t icc_size = 0;                   // bytes of the embedded ICC profile a non-XYB image reports (jxlamd_get_icc)
   uint32_t color_space = 0, white_point = 1, primaries = 1, transfer_function = 13, rendering_intent = 1;
   uint32_t have_gamma = 0; float gamma = 0;
+  float wp_xy[2] = {0, 0}, prim_xy[6] = {0, 0, 0, 0, 0, 0};     // custom white point / primaries of the header (white_point == 2 / primaries == 2)
 };
 
 struct FramePlan {
@@ -46,7 +48,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan);
 // Phase 2 for single-section frames: HfGlobal starts at `lf_end_bit` (reported by the LF kernel).
 int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit);
 // Header-only parse (DecodeBasicInfo).
-int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error);
+int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::string *error, std::vector<uint8_t> *icc = nullptr);
 
 // Per-process constant tables (inverse quant weights, cosine bases, AFV basis, dither LUT); header DevStatic at 0.
 const std::vector<uint8_t> &static_tables();

@@ -19,10 +19,12 @@ class RefInfo(C.Structure):
         [("intensity_target", C.c_float), ("prefer_encoding", C.c_uint32), ("have_encoded_profile", C.c_uint32),
          ("color_space", C.c_uint32), ("white_point", C.c_uint32), ("primaries", C.c_uint32),
          ("transfer_function", C.c_uint32), ("rendering_intent", C.c_uint32), ("gamma", C.c_double),
-         ("icc_size", C.c_uint32), ("version", C.c_uint32)]
+         ("icc_size", C.c_uint32), ("version", C.c_uint32), ("xy", C.c_double * 8)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "xy"}
+        d["xy"] = [float(v) for v in self.xy]
+        return d
 
 
 class RefEncParams(C.Structure):
@@ -46,6 +48,7 @@ def lib():
         _lib.ref_encode.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(RefEncParams), C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_size_t)]
         _lib.ref_free.argtypes = [C.c_void_p]
+        _lib.ref_set_icc.argtypes = [C.c_char_p, C.c_size_t]
         _lib.ref_version.restype = C.c_int
     return _lib
 
@@ -70,7 +73,7 @@ def decode(data: bytes, threads=0, allow16=True, mode=0):
 
 
 def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
-           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=()):
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None):
     """pixels: [h,w,c] u8 or u16, c in 1,3,4. Same sequence as the reference's EncodeJxlOneshot."""
     pixels = np.ascontiguousarray(pixels)
     h, w, c = pixels.shape
@@ -86,7 +89,9 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
         p.extra[i][0], p.extra[i][1] = k, v
     out = C.c_void_p()
     n = C.c_size_t()
+    lib().ref_set_icc(icc or b"", len(icc) if icc else 0)      # JxlEncoderSetICCProfile (interop/JxlEncoding.cpp:125-129) instead of an enum profile
     rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
+    lib().ref_set_icc(b"", 0)
     if rc != 0:
         raise ValueError(f"ref_encode failed rc={rc}")
     data = C.string_at(out.value, n.value)

@@ -31,6 +31,7 @@ typedef struct {
   double gamma;
   uint32_t icc_size;
   uint32_t version;
+  double xy[8];                   /* white_point_xy, primaries_red/green/blue_xy as JxlDecoderGetColorAsEncodedProfile fills them */
 } RefInfo;
 
 static void *h_jxl, *h_thr;
@@ -127,6 +128,8 @@ int ref_decode(const uint8_t *jxl, size_t size, int threads, int allow16, int mo
         ri->have_encoded_profile = 1;
         ri->color_space = clr.color_space; ri->white_point = clr.white_point; ri->primaries = clr.primaries;
         ri->transfer_function = clr.transfer_function; ri->rendering_intent = clr.rendering_intent; ri->gamma = clr.gamma;
+        ri->xy[0] = clr.white_point_xy[0]; ri->xy[1] = clr.white_point_xy[1]; ri->xy[2] = clr.primaries_red_xy[0]; ri->xy[3] = clr.primaries_red_xy[1];
+        ri->xy[4] = clr.primaries_green_xy[0]; ri->xy[5] = clr.primaries_green_xy[1]; ri->xy[6] = clr.primaries_blue_xy[0]; ri->xy[7] = clr.primaries_blue_xy[1];
         if ((clr.color_space == JXL_COLOR_SPACE_RGB && clr.transfer_function == JXL_TRANSFER_FUNCTION_HLG) ||
             clr.transfer_function == JXL_TRANSFER_FUNCTION_PQ || clr.transfer_function == JXL_TRANSFER_FUNCTION_DCI ||
             clr.transfer_function == JXL_TRANSFER_FUNCTION_709 || clr.transfer_function == JXL_TRANSFER_FUNCTION_SRGB ||
@@ -167,8 +170,17 @@ typedef struct {
   int32_t extra[8][2];             /* further (JxlEncoderFrameSettingId, value) pairs; id<0 = unused */
 } RefEncParams;
 
+/* ICC bytes for the NEXT ref_encode call: the profile is set with JxlEncoderSetICCProfile instead of an enum colour encoding, as the
+ * reference's encoder does when the Bitmap carries a profile (interop/JxlEncoding.cpp:125-129).  size 0 clears it. */
+static uint8_t *g_icc; static size_t g_icc_size;
+void ref_set_icc(const uint8_t *icc, size_t size) {
+  free(g_icc); g_icc = NULL; g_icc_size = 0;
+  if (size) { g_icc = (uint8_t *)malloc(size); memcpy(g_icc, icc, size); g_icc_size = size; }
+}
+
 int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, uint8_t **out, size_t *out_size) {
   if (load_libs()) return -1;
+  SYM(h_jxl, JxlEncoderSetICCProfile);
   SYM(h_jxl, JxlEncoderCreate); SYM(h_jxl, JxlEncoderDestroy); SYM(h_jxl, JxlEncoderSetParallelRunner);
   SYM(h_jxl, JxlEncoderInitBasicInfo); SYM(h_jxl, JxlEncoderSetBasicInfo); SYM(h_jxl, JxlEncoderInitExtraChannelInfo);
   SYM(h_jxl, JxlEncoderSetExtraChannelInfo); SYM(h_jxl, JxlEncoderSetColorEncoding);
@@ -205,7 +217,8 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   p_JxlColorEncodingSetToSRGB(&ce, p->num_channels == 1);
   if (p->primaries) ce.primaries = (JxlPrimaries)p->primaries;
   if (p->transfer) ce.transfer_function = (JxlTransferFunction)p->transfer;
-  if (JXL_ENC_SUCCESS != p_JxlEncoderSetColorEncoding(enc, &ce)) { rc = -5; goto done; }
+  if (g_icc_size) { if (JXL_ENC_SUCCESS != p_JxlEncoderSetICCProfile(enc, g_icc, g_icc_size)) { rc = -5; goto done; } }
+  else if (JXL_ENC_SUCCESS != p_JxlEncoderSetColorEncoding(enc, &ce)) { rc = -5; goto done; }
   JxlEncoderFrameSettings *fs = p_JxlEncoderFrameSettingsCreate(enc, NULL);
   if (!p->lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameDistance(fs, p->distance)) { rc = -6; goto done; }
   if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_EFFORT, p->effort)) { rc = -7; goto done; }
