@@ -281,7 +281,15 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
-  launch_pass_groups(S.B, S.plan.num_groups, stream);
+  if (pass_frame_mode >= 2 && frame_has_hf_lds(S.plan)) {        // workgroup-per-frame PassGroup kernel (LDS-resident code) for a single decode
+    std::vector<int> wm;
+    for (int g = 0; g < S.plan.num_groups; g += 256) { wm.push_back(0); wm.push_back(g); wm.push_back(std::min(256, S.plan.num_groups - g)); }
+    const size_t o_w = (sizeof(DevBuffers) + 255) & ~(size_t)255, total = o_w + wm.size() * 4;
+    HIPCHECK(S.dB.ensure(total)); HIPCHECK(S.h_B.ensure(total));
+    memcpy(S.h_B.p, &S.B, sizeof(DevBuffers)); memcpy((uint8_t *)S.h_B.p + o_w, wm.data(), wm.size() * 4);
+    HIPCHECK(hipMemcpyAsync(S.dB.p, S.h_B.p, total, hipMemcpyHostToDevice, stream));
+    launch_pass_frames((const DevBuffers *)S.dB.p, (const int *)((uint8_t *)S.dB.p + o_w), (int)wm.size() / 3, stream);
+  } else launch_pass_groups(S.B, S.plan.num_groups, stream);
   if (S.plan.has_ec) launch_extra_channels(S);
   HIPCHECK(hipEventRecord(ev[2], stream));
   rc = launch_rest(S, 1); if (rc) return rc;
@@ -292,6 +300,14 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);
   (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
   return rc;
+}
+
+// k_pass_frame applies when every pass of the frame has its LDS image (host_parse.cpp pack_hf_lds_image)
+bool frame_has_hf_lds(const FramePlan &plan) {
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  if (plan.modular || plan.tables.empty()) return false;
+  for (int p = 0; p < F->num_passes; p++) if (!F->hf_lds[p].bytes || (int)F->hf_lds[p].bytes > pass_frame_lds_capacity()) return false;
+  return true;
 }
 
 // n independent frames: the entropy stages of ALL frames go into ONE launch each (grid = sum of LF groups / groups
@@ -387,8 +403,10 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));
   }
   coef_pool_clean = false;                                   // until every frame of this flight has been collected without error
-  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map;
-  std::vector<size_t> pg_off, ec_off;                        // per sub-flight: first entry of its PassGroup map / extra-channel group map
+  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map, w_map;
+  std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / workgroup map
+  bool all_hf_lds = pass_frame_mode >= 1;
+  for (int i : batched) all_hf_lds = all_hf_lds && frame_has_hf_lds(slot((size_t)i).plan);
   std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
   bool any_ec = false;
   for (int k = 0; k < nb; k++) {
@@ -397,8 +415,9 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
     for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = cset + (size_t)c * max_coef; }
     hb.push_back(S.B); ha.push_back(S.A);
-    if (k % hf_sets == 0) { pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); }
+    if (k % hf_sets == 0) { pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
+    for (int g = 0; g < S.plan.num_groups; g += 256) { w_map.push_back(k - k / hf_sets * hf_sets); w_map.push_back(g); w_map.push_back(std::min(256, S.plan.num_groups - g)); }
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
       any_ec = true;
@@ -406,7 +425,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
       if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { ec_map.push_back(k - k / hf_sets * hf_sets); ec_map.push_back(g); }
     }
   }
-  pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2);
+  pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); w_off.push_back(w_map.size() / 3);
   // LF map: group-major — the long streams (full 256x256-cell LF groups, 240 ms) are dispatched first and the short edge
   // groups (15 ms) fill the slots they leave, instead of long and short workgroups alternating
   int max_lfg = 0, n_lf_streams = 0;
@@ -434,7 +453,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
                o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, o_ec = (o_pg + pg_map.size() * 4 + 255) & ~(size_t)255,
-               total = o_ec + ec_map.size() * 4 + 4;
+               o_w = (o_ec + ec_map.size() * 4 + 255) & ~(size_t)255, total = o_w + w_map.size() * 4 + 4;
   HIPCHECK(batch_tab.ensure(total));
   HIPCHECK(h_batch.ensure(total));
   uint8_t *bt = (uint8_t *)batch_tab.p, *hbt = (uint8_t *)h_batch.p;
@@ -443,6 +462,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
   memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
   if (!ec_map.empty()) memcpy(hbt + o_ec, ec_map.data(), ec_map.size() * 4);
+  memcpy(hbt + o_w, w_map.data(), w_map.size() * 4);
   HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
@@ -459,7 +479,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
     // >= simt_min_groups groups: one LANE per group (64 streams per wavefront); below that the one-wave-per-group kernel has
     // the shorter critical path
-    if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
+    if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
+    else if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);

@@ -11,6 +11,10 @@ void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *m
 size_t lf_simt_wave_bytes();
 size_t lf_simt_scratch_bytes();
 void launch_lf_groups_simt(const DevBuffers *Bs, const DevAux *As, const int *map, int n, void *waves, void *scratch, hipStream_t s);
+// workgroup-per-frame PassGroup decode with the HF code in LDS; wmap = {frame, first group, groups} per workgroup.  Only for frames whose
+// DevFrame::hf_lds[pass].bytes is non-zero (and <= pass_frame_lds_capacity()) for every pass
+void launch_pass_frames(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
+int pass_frame_lds_capacity();
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);

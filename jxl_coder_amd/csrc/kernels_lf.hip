@@ -24,6 +24,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) k_lf
 }
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, hipStream_t s) { hipLaunchKernelGGL(k_lf_group, dim3(n), dim3(64), 0, s, B, A); }
 void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int n, hipStream_t s) {
-  hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), 0, s, Bs, As, map);
+  // JXLAMD_LF_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 50 KB — an occupancy knob (how many LF streams share a CU with
+  // the LDS-using kernels of other decoder contexts), no functional effect
+  static const unsigned extra = getenv("JXLAMD_LF_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_LF_EXTRA_LDS")) : 0u;
+  hipLaunchKernelGGL(k_lf_group_batch, dim3(n), dim3(64), extra, s, Bs, As, map);
 }
 }  // namespace jxlamd

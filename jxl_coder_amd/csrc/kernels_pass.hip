@@ -33,6 +33,33 @@ __global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, co
   if (e) atomicOr(B.err, e | kErrStagePass);
 }
 
+// One workgroup per frame (per 256 groups of a larger frame): the pass's HF code sits in LDS (DevFrame::hf_lds), every lane decodes one
+// 256x256 group.  wmap: {frame, first group, number of groups} per workgroup.
+constexpr int kHfLdsBytes = 150 * 1024;
+__global__ void __launch_bounds__(256) k_pass_frame(const DevBuffers *__restrict__ Bs, const int *__restrict__ wmap) {
+  __shared__ __attribute__((aligned(16))) uint8_t img[kHfLdsBytes];
+  __shared__ uint16_t freq_ctx[64], nnz_ctx[64];
+  const int tid = (int)threadIdx.x;
+  const int f = wmap[3 * blockIdx.x], g0 = wmap[3 * blockIdx.x + 1], n = wmap[3 * blockIdx.x + 2];
+  const DevBuffers &B = Bs[f];
+  if (frame_failed(B)) return;
+  const DevFrame &F = frame_of(B);
+  if (tid < 64) { freq_ctx[tid] = kCoeffFreqContext[tid]; nnz_ctx[tid] = kCoeffNumNonzeroContext[tid]; }
+  __builtin_amdgcn_s_setprio(2);
+  uint32_t e = 0;
+  for (int pass = 0; pass < F.num_passes; pass++) {
+    const uint32_t bytes = F.hf_lds[pass].bytes;
+    const uint4 *src = (const uint4 *)(B.tables + F.hf_lds[pass].off);
+    __syncthreads();                                   // the previous pass's lanes are done with the image
+    for (uint32_t i = (uint32_t)tid; i < (bytes + 15) / 16; i += 256) ((uint4 *)img)[i] = src[i];
+    __syncthreads();
+    if (tid < n && !e) e = pass_group_lane_lds(B, img, pass, freq_ctx, nnz_ctx, B.pass_nz + (size_t)(g0 + tid) * 3072, g0 + tid);
+  }
+  if (e) atomicOr(B.err, e | kErrStagePass);
+}
+void launch_pass_frames(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s) { hipLaunchKernelGGL(k_pass_frame, dim3(nwg), dim3(256), 0, s, Bs, wmap); }
+int pass_frame_lds_capacity() { return kHfLdsBytes; }
+
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_simt, dim3((n + 63) / 64), dim3(64), 0, s, Bs, map, n); }

@@ -93,6 +93,13 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     for (int i = 0; i < 27; i++) if (hist[i]) fprintf(stderr, "strategy %d (%dx%d cells): %d blocks\n", i, kCoveredX[i], kCoveredY[i], hist[i]);
     fprintf(stderr, "lists: %u medium, %u large, %u small\n", bcount[0], bcount[1], bcount[2]);
   }
+  if (getenv("JXLEMUL_LDS_PASS")) {        // the workgroup-per-frame PassGroup decoder (k_pass_frame): the packed LDS image of the HF code, one lane at a time
+    const DevFrame &F0 = *(const DevFrame *)tables.data();
+    for (int pass = 0; pass < F0.num_passes; pass++) {
+      if (!F0.hf_lds[pass].bytes) { g_err = "no LDS image for this frame"; return -3; }
+      for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane_lds(B, tables.data() + F0.hf_lds[pass].off, pass, kCoeffFreqContext, kCoeffNumNonzeroContext, B.pass_nz + (size_t)g * 3072, g); if (e) err |= e; }
+    }
+  } else
   if (getenv("JXLEMUL_SIMT_PASS")) {       // exercise the lane-per-stream PassGroup code (one lane at a time)
     for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane(B, kCoeffFreqContext, kCoeffNumNonzeroContext, B.pass_nz + (size_t)g * 3072, g); if (e) err |= e; }
   } else
