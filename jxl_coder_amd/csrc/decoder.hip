@@ -310,6 +310,15 @@ bool frame_has_hf_lds(const FramePlan &plan) {
   return true;
 }
 
+// host-side twin of simt2_frame_ok (dev_vardct.h)
+bool frame_simt2_ok(const FramePlan &plan) {
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  if (plan.modular || plan.tables.empty()) return false;
+  for (int p = 0; p < F->num_passes; p++)
+    if (F->hf_ec[p].use_prefix || F->hf_ec[p].num_clusters > 256 || 495 * F->num_bctx * F->num_presets > 495 * 16 * 4) return false;
+  return true;
+}
+
 // n independent frames: the entropy stages of ALL frames go into ONE launch each (grid = sum of LF groups / groups
 // over the batch), so that their serial streams run side by side on the chip; the cheap data-parallel stages follow
 // per frame on the same stream.  Frames that need the single-section round trip are decoded one by one.
@@ -407,6 +416,9 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / workgroup map
   bool all_hf_lds = pass_frame_mode >= 1;
   for (int i : batched) all_hf_lds = all_hf_lds && frame_has_hf_lds(slot((size_t)i).plan);
+  bool all_simt2 = simt2 != 0;
+  for (int i : batched) all_simt2 = all_simt2 && frame_simt2_ok(slot((size_t)i).plan);
+  const int wchunk = all_hf_lds ? 256 : 64;                  // groups per workgroup of the k_pass_frame / k_pass_group_simt2 map
   std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
   bool any_ec = false;
   for (int k = 0; k < nb; k++) {
@@ -417,7 +429,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     hb.push_back(S.B); ha.push_back(S.A);
     if (k % hf_sets == 0) { pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
-    for (int g = 0; g < S.plan.num_groups; g += 256) { w_map.push_back(k - k / hf_sets * hf_sets); w_map.push_back(g); w_map.push_back(std::min(256, S.plan.num_groups - g)); }
+    for (int g = 0; g < S.plan.num_groups; g += wchunk) { w_map.push_back(k - k / hf_sets * hf_sets); w_map.push_back(g); w_map.push_back(std::min(wchunk, S.plan.num_groups - g)); }
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
       any_ec = true;
@@ -480,6 +492,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     // >= simt_min_groups groups: one LANE per group (64 streams per wavefront); below that the one-wave-per-group kernel has
     // the shorter critical path
     if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
+    else if (all_simt2 && n_pg >= simt_min_groups) launch_pass_groups_simt2(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
     else if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),

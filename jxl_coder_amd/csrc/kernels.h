@@ -15,6 +15,8 @@ void launch_lf_groups_simt(const DevBuffers *Bs, const DevAux *As, const int *ma
 // DevFrame::hf_lds[pass].bytes is non-zero (and <= pass_frame_lds_capacity()) for every pass
 void launch_pass_frames(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
 int pass_frame_lds_capacity();
+// lane-per-group with LDS bit rings / context maps; wmap = {frame, first group, groups <= 64} per wavefront; frames must pass simt2_frame_ok
+void launch_pass_groups_simt2(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);

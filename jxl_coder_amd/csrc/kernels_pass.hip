@@ -33,6 +33,30 @@ __global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, co
   if (e) atomicOr(B.err, e | kErrStagePass);
 }
 
+// lane-per-group with the stall-free bit supply (dev_vardct.h pass_group_lane2): one wavefront = up to 64 groups of ONE frame.
+// wmap: {frame, first group, number of groups <= 64} per workgroup
+__global__ void __launch_bounds__(64) k_pass_group_simt2(const DevBuffers *__restrict__ Bs, const int *__restrict__ wmap, int ctx_in_lds) {
+  __shared__ SimtPassLds L;
+  const int lane = (int)threadIdx.x;
+  const int f = wmap[3 * blockIdx.x], g0 = wmap[3 * blockIdx.x + 1], n = wmap[3 * blockIdx.x + 2];
+  const DevBuffers &B = Bs[f];
+  if (frame_failed(B)) return;
+  const DevFrame &F = frame_of(B);
+  __builtin_amdgcn_s_setprio(2);
+  uint32_t e = 0;
+  for (int pass = 0; pass < F.num_passes; pass++) {
+    __syncthreads();
+    simt2_stage(B, L, pass, lane, 64, ctx_in_lds != 0);
+    __syncthreads();
+    if (lane < n && !e) e = pass_group_lane2(B, L, pass, B.pass_nz + (size_t)(g0 + lane) * 3072, g0 + lane, lane);
+  }
+  if (e) atomicOr(B.err, e | kErrStagePass);
+}
+void launch_pass_groups_simt2(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s) {
+  static const int ctx_in_lds = getenv("JXLAMD_SIMT2_CTX_LDS") ? atoi(getenv("JXLAMD_SIMT2_CTX_LDS")) : 1;
+  hipLaunchKernelGGL(k_pass_group_simt2, dim3(nwg), dim3(64), 0, s, Bs, wmap, ctx_in_lds);
+}
+
 // One workgroup per frame (per 256 groups of a larger frame): the pass's HF code sits in LDS (DevFrame::hf_lds), every lane decodes one
 // 256x256 group.  wmap: {frame, first group, number of groups} per workgroup.
 constexpr int kHfLdsBytes = 150 * 1024;

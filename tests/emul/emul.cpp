@@ -93,6 +93,16 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     for (int i = 0; i < 27; i++) if (hist[i]) fprintf(stderr, "strategy %d (%dx%d cells): %d blocks\n", i, kCoveredX[i], kCoveredY[i], hist[i]);
     fprintf(stderr, "lists: %u medium, %u large, %u small\n", bcount[0], bcount[1], bcount[2]);
   }
+  if (getenv("JXLEMUL_SIMT2_PASS")) {      // k_pass_group_simt2: bit rings / context maps in (emulated) LDS, one lane at a time
+    const DevFrame &F0 = *(const DevFrame *)tables.data();
+    if (!simt2_frame_ok(F0)) { g_err = "frame not eligible for the SIMT2 PassGroup path"; return -3; }
+    SimtPassLds *L2 = new SimtPassLds();
+    for (int pass = 0; pass < F0.num_passes; pass++) {
+      simt2_stage(B, *L2, pass, 0, 1, getenv("JXLEMUL_SIMT2_GLOBAL_CTX") == nullptr);
+      for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane2(B, *L2, pass, B.pass_nz + (size_t)g * 3072, g, (g * 5 + 1) % 64); if (e) err |= e; }
+    }
+    delete L2;
+  } else
   if (getenv("JXLEMUL_LDS_PASS")) {        // the workgroup-per-frame PassGroup decoder (k_pass_frame): the packed LDS image of the HF code, one lane at a time
     const DevFrame &F0 = *(const DevFrame *)tables.data();
     for (int pass = 0; pass < F0.num_passes; pass++) {

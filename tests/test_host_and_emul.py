@@ -96,6 +96,10 @@ def test_alternate_device_paths_give_identical_pixels(emul, monkeypatch, name):
     monkeypatch.setenv("JXLEMUL_LDS_PASS", "1")         # workgroup-per-frame PassGroup decoder over the packed LDS image (k_pass_frame)
     alt3 = emul(data)
     assert np.array_equal(base, alt3)
+    monkeypatch.delenv("JXLEMUL_LDS_PASS")
+    monkeypatch.setenv("JXLEMUL_SIMT2_PASS", "1")       # lane-per-group PassGroup decoder with LDS bit rings (k_pass_group_simt2)
+    alt4 = emul(data)
+    assert np.array_equal(base, alt4)
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
