@@ -324,6 +324,60 @@ JXL_DEV void epf_pixel(const DevBuffers &B, const DevFrame &F, float *const src[
   else epf_pixel_p<2>(B, F, src, dst, x, y);
 }
 
+// ------------------------------------------------------------------ the same filters over an accessor (fused LDS-tiled kernel)
+// acc(c, y, x) returns channel c at FRAME coordinates (y, x), which may lie up to 7 pixels outside the image: the accessor
+// hands back the mirrored sample.  Same expression order as gab_value / epf_value_t.
+template <class Acc>
+JXL_DEV void gab_value_acc(const DevFrame &F, const Acc &acc, int x, int y, float out[3]) {
+  for (int c = 0; c < 3; c++) {
+    const float w1 = F.gab_w[c][0], w2 = F.gab_w[c][1];
+    const float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
+    float side = acc(c, y - 1, x) + acc(c, y + 1, x) + acc(c, y, x - 1) + acc(c, y, x + 1);
+    float diag = acc(c, y - 1, x - 1) + acc(c, y - 1, x + 1) + acc(c, y + 1, x - 1) + acc(c, y + 1, x + 1);
+    out[c] = acc(c, y, x) * norm + side * (w1 * norm) + diag * (w2 * norm);
+  }
+}
+// (x, y): the pixel whose sigma / border class applies — inside the image; the taps go through acc
+template <int kPass, class Acc>
+JXL_DEV void epf_value_acc(const DevBuffers &B, const DevFrame &F, const Acc &acc, int x, int y, float out[3]) {
+  const float is = epf_inv_sigma(B, F, x, y);
+  if (is < -3.90524291751269967465540850526868f) { for (int c = 0; c < 3; c++) out[c] = acc(c, y, x); return; }
+  const float sm = 1.65f * (kPass == 0 ? F.epf_pass0 : kPass == 2 ? F.epf_pass2 : 1.0f);
+  const bool border = ((y & 7) == 0 || (y & 7) == 7 || (x & 7) == 0 || (x & 7) == 7);
+  const float isig = is * (border ? sm * F.epf_border_sad : sm);
+  constexpr int px[5] = {0, 0, -1, 1, 0}, py[5] = {0, -1, 0, 0, 1};
+  constexpr int t0x[12] = {0, -1, 0, 1, -2, -1, 1, 2, -1, 0, 1, 0}, t0y[12] = {-2, -1, -1, -1, 0, 0, 0, 0, 1, 1, 1, 2};
+  constexpr int t1x[4] = {0, -1, 1, 0}, t1y[4] = {-1, 0, 0, 1};
+  constexpr int ntaps = kPass == 0 ? 12 : 4;
+  float wsum = 1.0f, accv[3];
+  for (int c = 0; c < 3; c++) accv[c] = acc(c, y, x);
+#ifdef __HIPCC__
+  #pragma unroll
+#endif
+  for (int t = 0; t < ntaps; t++) {
+    const int tx = kPass == 0 ? t0x[t] : t1x[t], ty = kPass == 0 ? t0y[t] : t1y[t];
+    float sad = 0.0f;
+    if (kPass == 2) {
+      for (int c = 0; c < 3; c++) sad += fabsf(acc(c, y, x) - acc(c, y + ty, x + tx)) * F.epf_chscale[c];
+    } else {
+      for (int c = 0; c < 3; c++) {
+        float sc = 0.0f;
+#ifdef __HIPCC__
+        #pragma unroll
+#endif
+        for (int k = 0; k < 5; k++) sc += fabsf(acc(c, y + py[k], x + px[k]) - acc(c, y + ty + py[k], x + tx + px[k]));
+        sad += sc * F.epf_chscale[c];
+      }
+    }
+    float wgt = 1.0f + sad * isig;
+    if (wgt < 0.0f) wgt = 0.0f;
+    wsum += wgt;
+    for (int c = 0; c < 3; c++) accv[c] += wgt * acc(c, y + ty, x + tx);
+  }
+  const float inv = 1.0f / wsum;
+  for (int c = 0; c < 3; c++) out[c] = accv[c] * inv;
+}
+
 // ------------------------------------------------------------------ XYB -> RGB -> RGBA writer (one pixel)
 // a^e for a >= 0: on the GPU two transcendental instructions (v_log_f32 / v_exp_f32, ~1 ulp each: the result moves
 // by < 1e-6 relative, far below half an 8-bit or 16-bit step); the CPU harness uses libm.

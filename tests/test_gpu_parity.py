@@ -230,3 +230,35 @@ def test_config5_full_size_pq16_epf3_tone_map_f16(dec):
         got = f.cpu().numpy().view(np.uint16).reshape(h, w, 4)
         assert (got != exp).mean() < 5e-3                                        # LUT-entry +-1 (oracle built without -ffast-math)
         assert np.abs(got.view(np.float16).astype(np.float32) - exp.view(np.float16).astype(np.float32)).max() < 2e-2
+
+
+def test_alternative_kernels_keep_parity():
+    """The measured-and-parked alternatives stay correct: fused LDS-tiled Gaborish + EPF + writer (JXLAMD_FUSED_FILTERS=1), workgroup-per-frame
+    PassGroup decode with the HF code in LDS (JXLAMD_PASS_FRAME=1), LDS-ring PassGroup lanes (JXLAMD_SIMT2=1) and the lane-per-stream LF
+    kernel (JXLAMD_SIMT_LF_MIN=1): golden vectors within the stated tolerance, flights == single decodes (knobs are read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from conftest import load_case, VARDCT_CASES
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        for name in VARDCT_CASES:
+            data, exp = load_case(name)
+            out, _ = dec.decode_one_shot(data)
+            d = np.abs(out.astype(int) - exp.astype(int))
+            assert d.max() <= 1 and d.mean() <= 0.1, (name, d.max(), d.mean())
+        names = ["v264x520_e7", "asset_first_jxl", "va300x520_e7", "v267x131_e7", "v256_e3_gab0_epf3", "v300x300_e7_d3"]
+        datas = [load_case(n)[0] for n in names]
+        singles = [dec.decode_one_shot(d)[0] for d in datas]
+        outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+        dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for s, o in zip(singles, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+        print("alternatives ok")
+    """) % (ROOT, ROOT + "/tests")
+    for env in ({"JXLAMD_FUSED_FILTERS": "1"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"},
+                {"JXLAMD_SIMT_LF_MIN": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
