@@ -69,8 +69,50 @@ __device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const fl
     for (int j = 0; j < 4; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
 }
 
+// DCT32x32 on the matrix cores (north_star: "MFMA only for the >= 32x32 matrix-form blocks").  Both 1-D passes are 32x32x32 products
+//   pass 1: T_c = S_c^T x CC          pass 2: out_c = CC^T x T_c
+// issued as 16 v_mfma_f32_32x32x2_f32 each (f32 in, f32 accumulate: exact f32, the only MFMA precision that keeps the +-1 LSB parity);
+// waves 0..2 of the workgroup take one channel each.  Operand maps (cdna_hip_programming.md): lane l feeds A[i = l & 31][k = l >> 5] and
+// B[k = l >> 5][j = l & 31]; accumulator register r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+// On gfx950 the f32 MFMA peak equals the f32 VALU peak (157 TFLOP/s both), so this is a change of execution unit — it takes the
+// multiply-adds off the VALU that the co-resident entropy waves compete for — not a change of arithmetic throughput.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const int wave = tid >> 6, lane = tid & 63;
+  const int j = lane & 31, kh = lane >> 5;
+  const float *Sc = S + wave * 1024;
+  float *Tc = T + wave * 1024;
+  if (wave < 3) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < 16; st++) {
+      const int u = 2 * st + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Sc[u * 32 + j], CC[u * 32 + j], acc, 0, 0, 0);      // A[v][u] = S[u][v], B[u][x] = cc[u][x]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) Tc[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[r];
+  }
+  __syncthreads();
+  if (wave < 3) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < 16; st++) {
+      const int v = 2 * st + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(CC[v * 32 + j], Tc[v * 32 + j], acc, 0, 0, 0);      // A[y][v] = cc[v][y], B[v][x] = T[v][x]
+    }
+    float *out = B.plane_a[wave] + (size_t)(by * 8) * (size_t)F.pw + (size_t)(bx * 8 + j);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * kh) * (size_t)F.pw] = acc[r];
+  }
+}
+
 template <int NMIN, int NMAX>
-__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb) {
+__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma) {
   __shared__ __attribute__((aligned(16))) ReconLds<NMAX> L;
   const int tid = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
@@ -91,7 +133,7 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
       __syncthreads();
       recon_phaseB(B, stat, ST, L.S, 1024, bx, by, tid, 256);
       __syncthreads();
-      recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
+      if (use_mfma) recon_dct32_mfma(B, L.S, L.T, L.CC, bx, by, tid); else recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
     } else {
       __syncthreads();
       recon_block_body<false, (NMAX > 1024)>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
@@ -130,20 +172,21 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
   }
 }
 template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls) {
+__global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
-  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb);
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0);
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0);
+  static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0, use_mfma);
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1, 0);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
