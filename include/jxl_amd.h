@@ -174,6 +174,13 @@ int jxlamd_reformat(jxlamd_decoder *dec, void *src_dev, uint32_t w, uint32_t h, 
 int jxlamd_color_matrix(jxlamd_decoder *dec, void *pixels_dev, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries,
                         uint32_t transfer_function, const double *xy8, float intensity_target);
 
+/* convertUseDefinedColorSpace (cpp/colorspaces/colorspace.cpp:38-86; cpp/JniDecoding.cpp:103-114): runs right after jxlamd_decode when the ICC
+ * vector is non-empty, i.e. info.icc_size > 0 (jxlamd_get_icc).  Embedded profile -> sRGB with the reference's Little CMS parameters
+ * (perceptual, black-point compensation, no-white-on-white-fixup, alpha copied; RGBA8, or RGBA16 treated as premultiplied), in place on the
+ * device: the host samples the transform from the system's liblcms2 on a 256^3 lattice per profile (every 8-bit level a lattice point;
+ * cached per decoder context), the kernel looks up (RGBA8) / interpolates (RGBA16).  Like the reference, a profile Little CMS cannot open leaves the pixels untouched (JXLAMD_OK). */
+int jxlamd_icc_transform(jxlamd_decoder *dec, void *pixels_dev, uint32_t w, uint32_t h, int is_u16, const uint8_t *icc, size_t icc_size);
+
 /* RescaleImage of `decodeSampled` (cpp/SizeScaler.cpp:38-144 -> weaver/src/scale.rs): runs between jxlamd_decode and jxlamd_color_matrix
  * (cpp/JniDecoding.cpp:116-136).  new_w / new_h: requested size, -1 = keep the aspect ratio, -2 = same rounded up to even
  * (resolve_dimensions, scale.rs:94-130); scale_mode: 1 Fit, 2 Fill, 3 Resize (cpp/SizeScaler.h:36-40; Fit / Fill scale uniformly and centre-crop,

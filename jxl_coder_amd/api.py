@@ -76,7 +76,7 @@ FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
 JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
-SOURCES = ["kernels_lf.hip", "kernels_lf_simt.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp"]
+SOURCES = ["kernels_lf.hip", "kernels_lf_simt.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp", "host_icc_lut.cpp"]
 
 
 def library_path():
@@ -145,6 +145,8 @@ def lib():
                                       C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
         L.jxlamd_color_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_float]
+        L.jxlamd_get_icc.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.jxlamd_icc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_size_t]
         L.jxlamd_rescale_query.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(RescaleInfo)]
         L.jxlamd_rescale.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_size_t, C.POINTER(RescaleInfo)]
@@ -252,6 +254,12 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return [i.as_dict() for i in infos]
+
+    def icc_transform_device(self, ptr: int, w: int, h: int, is_u16: bool, icc: bytes):
+        """A8 on a device buffer, in place (jxlamd_icc_transform; cpp/colorspaces/colorspace.cpp:38-86)."""
+        rc = lib().jxlamd_icc_transform(self._h, ptr, w, h, int(is_u16), icc, len(icc))
+        if rc:
+            _raise(rc, self._h)
 
     def rescale_query(self, w, h, new_w, new_h, scale_mode):
         ri = RescaleInfo()
@@ -390,6 +398,10 @@ class JxlCoder:
         raw = torch.empty(w * h * 4 * (2 if is16 else 1), dtype=torch.uint8, device=dev)
         meta = dec.decode_to_device(data, raw.data_ptr(), raw.numel(), allowed_floats=True)
         depth = 16 if is16 else 8                                  # bitDepth as DecodeJpegXlOneShot reports it (JxlDecoding.cpp:92-101)
+        if meta["icc_size"] and not meta["prefer_encoding"]:       # A8 convertUseDefinedColorSpace (JniDecoding.cpp:103-114): the ICC vector is non-empty
+            buf = (C.c_uint8 * meta["icc_size"])(); n = C.c_size_t()
+            if lib().jxlamd_get_icc(data, len(data), buf, meta["icc_size"], C.byref(n)) == 0 and n.value:
+                dec.icc_transform_device(raw.data_ptr(), w, h, is16, bytes(buf[:n.value]))
         if sampling is not None:                                   # A9 RescaleImage (JniDecoding.cpp:116-136), before the colour matrix
             sw, sh, mode, sampler = sampling
             q = dec.rescale_query(w, h, sw, sh, mode)

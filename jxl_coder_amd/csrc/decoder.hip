@@ -533,7 +533,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->resample_tmp.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
+  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->resample_tmp.release(); d->icc_lut.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
@@ -677,6 +677,28 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
   launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, D, s);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
   d->post_dev = D; memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = true;
+  return JXLAMD_OK;
+}
+
+int jxlamd_icc_transform(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, const uint8_t *icc, size_t icc_size) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  if (!px || !icc || !icc_size) { d->set_error("bad pixel buffer / profile"); return JXLAMD_ERR_BUFFER; }
+  constexpr int kN = 256;               // every 8-bit level is a lattice point (100 MB of HBM per cached profile)
+  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
+  const hipStream_t s = d->stream;
+  if (d->icc_lut_key.size() != icc_size || memcmp(d->icc_lut_key.data(), icc, icc_size) != 0 || !d->icc_lut.p) {
+    std::vector<uint16_t> lut; std::string err;
+    if (!build_icc_lut(icc, icc_size, kN, &lut, &err)) {
+      if (err.rfind("unsupported", 0) == 0) { d->set_error(err); return JXLAMD_ERR_UNSUPPORTED; }
+      return JXLAMD_OK;              // colorspace.cpp:47-51, :70-74: "better proceed with invalid photo than crash"
+    }
+    if (d->icc_lut.ensure(lut.size() * 2) != hipSuccess || hipMemcpy(d->icc_lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      d->set_error("HIP: ICC lattice upload failed"); return JXLAMD_ERR_DEVICE;
+    }
+    d->icc_lut_key.assign(icc, icc + icc_size);
+  }
+  launch_post_icc_lut(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, (const uint16_t *)d->icc_lut.p, kN, s);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: ICC stage failed"); return JXLAMD_ERR_DEVICE; }
   return JXLAMD_OK;
 }
 

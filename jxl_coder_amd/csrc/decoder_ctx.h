@@ -103,13 +103,14 @@ struct jxlamd_decoder {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch, resample_tmp;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch, resample_tmp, icc_lut;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
   PinnedMem h_batch, h_mod_tab;
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
+  std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
   int simt_lf_min = getenv("JXLAMD_SIMT_LF_MIN") ? atoi(getenv("JXLAMD_SIMT_LF_MIN")) : 0x7fffffff;     // LfGroup sections in a flight from which the lane-per-stream LF kernel takes over (off by default: measured slower)
   int pass_frame_mode = getenv("JXLAMD_PASS_FRAME") ? atoi(getenv("JXLAMD_PASS_FRAME")) : 0;   // k_pass_frame (HF code in 100-150 KB of LDS per frame): 0 off (default: 30 % faster alone, but next to other decoder contexts its LDS appetite costs more than it saves), 1 flights and bands, 2 single decodes too

@@ -3,6 +3,7 @@
 // applyColorMatrix (jxlcoder/src/main/cpp/colorspaces/ColorMatrix.cpp:35-219, call site JniDecoding.cpp:138-228).
 #pragma once
 #include <stdint.h>
+#include <string>
 #include <vector>
 
 namespace jxlamd {
@@ -20,5 +21,9 @@ struct ColorMatrixPlan {
 // false when the reference does not run the stage for this transfer function (linear, unknown)
 bool plan_color_matrix(bool is_u16, uint32_t depth, uint32_t primaries, uint32_t transfer_function, const double xy[8],
                        float intensity_target, ColorMatrixPlan *plan);
+
+// A8: the embedded profile -> sRGB transform of convertUseDefinedColorSpace (cpp/colorspaces/colorspace.cpp:38-86) sampled from Little CMS
+// on an n^3 RGB16 lattice (host_icc_lut.cpp)
+bool build_icc_lut(const uint8_t *icc, size_t icc_size, int n, std::vector<uint16_t> *lut, std::string *err);
 
 }  // namespace jxlamd

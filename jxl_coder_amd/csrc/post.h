@@ -22,4 +22,8 @@ struct ColorMatrixDev {
 };
 void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const ColorMatrixDev &P, hipStream_t s);
 
+// A8 (cpp/colorspaces/colorspace.cpp:38-86): the profile -> sRGB transform as an n^3 RGB16 lattice (host_icc_lut.cpp), applied in place with
+// trilinear interpolation; alpha is copied (u8) / the colour is un-premultiplied around the transform (u16: the reference passes TYPE_RGBA_16_PREMUL)
+void launch_post_icc_lut(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const uint16_t *lut, int n, hipStream_t s);
+
 }  // namespace jxlamd

@@ -145,4 +145,48 @@ void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h,
   else hipLaunchKernelGGL(k_post_color_matrix<false>, dim3(h), dim3(256), 0, s, (uint8_t *)px, stride, w, P);
 }
 
+// ---- A8: ICC transform through a 3-D lattice
+__device__ __forceinline__ void icc_lut_sample(const uint16_t *__restrict__ lut, int n, float r, float g, float b, float out[3]) {      // r, g, b in [0, 1]
+  const float s = (float)(n - 1);
+  const float fr = r * s, fg = g * s, fb = b * s;
+  int ir = (int)fr, ig = (int)fg, ib = (int)fb;
+  ir = ir > n - 2 ? n - 2 : ir; ig = ig > n - 2 ? n - 2 : ig; ib = ib > n - 2 ? n - 2 : ib;
+  const float tr = fr - (float)ir, tg = fg - (float)ig, tb = fb - (float)ib;
+  const size_t sg = (size_t)n * 3, sb = (size_t)n * n * 3;
+  const uint16_t *p = lut + (size_t)ib * sb + (size_t)ig * sg + (size_t)ir * 3;
+  for (int c = 0; c < 3; c++) {
+    const float c000 = p[c], c100 = p[3 + c], c010 = p[sg + c], c110 = p[sg + 3 + c];
+    const float c001 = p[sb + c], c101 = p[sb + 3 + c], c011 = p[sb + sg + c], c111 = p[sb + sg + 3 + c];
+    const float a0 = c000 + (c100 - c000) * tr, a1 = c010 + (c110 - c010) * tr, a2 = c001 + (c101 - c001) * tr, a3 = c011 + (c111 - c011) * tr;
+    const float b0 = a0 + (a1 - a0) * tg, b1 = a2 + (a3 - a2) * tg;
+    out[c] = b0 + (b1 - b0) * tb;                              // 0 .. 65535
+  }
+}
+template <bool kU16>
+__global__ void __launch_bounds__(256) k_post_icc_lut(void *px, uint32_t stride, uint32_t w, uint32_t h, const uint16_t *__restrict__ lut, int n) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  float v[3];
+  if (kU16) {
+    uint16_t *p = (uint16_t *)((uint8_t *)px + (size_t)y * stride) + (size_t)x * 4;
+    const float a = (float)p[3];
+    if (a <= 0.0f) return;                                   // premultiplied by zero alpha: nothing to transform
+    const float ia = 1.0f / a;                               // TYPE_RGBA_16_PREMUL: the colour is divided by alpha before and multiplied back after
+    float r = (float)p[0] * ia, g = (float)p[1] * ia, b = (float)p[2] * ia;
+    r = r > 1.0f ? 1.0f : r; g = g > 1.0f ? 1.0f : g; b = b > 1.0f ? 1.0f : b;
+    icc_lut_sample(lut, n, r, g, b, v);
+    const float back = a * (1.0f / 65535.0f);
+    for (int c = 0; c < 3; c++) { float o = rintf(v[c] * back); p[c] = (uint16_t)(o < 0.0f ? 0.0f : o > 65535.0f ? 65535.0f : o); }
+  } else {
+    uint8_t *p = (uint8_t *)px + (size_t)y * stride + (size_t)x * 4;
+    icc_lut_sample(lut, n, (float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, v);          // n = 256: lands on lattice points
+    for (int c = 0; c < 3; c++) { float o = rintf(v[c] * (255.0f / 65535.0f)); p[c] = (uint8_t)(o < 0.0f ? 0.0f : o > 255.0f ? 255.0f : o); }
+  }
+}
+void launch_post_icc_lut(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const uint16_t *lut, int n, hipStream_t s) {
+  dim3 grid((w + 255) / 256, h);
+  if (is_u16) hipLaunchKernelGGL(k_post_icc_lut<true>, grid, dim3(256), 0, s, px, stride, w, h, lut, n);
+  else hipLaunchKernelGGL(k_post_icc_lut<false>, grid, dim3(256), 0, s, px, stride, w, h, lut, n);
+}
+
 }  // namespace jxlamd

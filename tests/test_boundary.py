@@ -160,3 +160,46 @@ def test_files_with_embedded_icc_decode(golden_meta):
     rs = out.astype(np.int64).sum(axis=(1, 2))
     assert np.abs(rs - np.array(ref["row_sums"])).max() <= 16.0 * out.shape[1] * 4          # mean |diff| <= 16/65535 per sample (conftest U16_MEAN_ABS), row by row
     dec.close()
+
+
+@pytest.mark.gpu
+def test_icc_stage_matches_little_cms(golden_meta):
+    """A8 convertUseDefinedColorSpace on the device (jxlamd_icc_transform: 129^3 lattice sampled from Little CMS with the reference's intent and
+    flags, trilinear on the GPU) against Little CMS itself run per pixel with the reference's parameters (oracle/icc_oracle.py).
+    Stated tolerance: u8 max |diff| <= 2, mean <= 0.25; u16 max <= 512/65535, mean <= 48/65535 (lattice interpolation vs the library's own
+    16-bit pipeline)."""
+    import torch
+    import jxl_coder_amd as J
+    from jxl_coder_amd import api
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import icc_oracle
+    if not icc_oracle.available():
+        pytest.skip("liblcms2.so.2 not present on this box")
+    data, exp = load_case("licc96x64_e3")
+    icc = np.zeros(golden_meta["licc96x64_e3"]["icc_size"], np.uint8); n = C.c_size_t()
+    assert api.lib().jxlamd_get_icc(data, len(data), icc.ctypes.data, icc.size, C.byref(n)) == 0
+    icc = icc.tobytes()
+    dec = J.JxlDecoder(0)
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:64, 0:96]
+    for is16 in (False, True):
+        maxv = 65535 if is16 else 255
+        img = np.stack([xx / 95 * maxv, yy / 63 * maxv, rng.uniform(0, maxv, (64, 96)), np.full((64, 96), maxv)], -1).astype(np.uint16 if is16 else np.uint8)
+        img[:8, :8, :3] = 0; img[-8:, -8:, :3] = maxv
+        want = icc_oracle.convert(img, icc)
+        buf = torch.from_numpy(img.view(np.uint8).reshape(-1).copy()).cuda()
+        dec.icc_transform_device(buf.data_ptr(), 96, 64, is16, icc)
+        got = buf.cpu().numpy().view(img.dtype).reshape(img.shape)
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert np.array_equal(got[..., 3], img[..., 3])
+        assert (want != img).any()                                                   # the profile (Rec.2100 PQ) really changes the pixels
+        if is16:
+            assert d.max() <= 512 and d.mean() <= 48, (d.max(), d.mean())
+        else:
+            assert d.max() <= 2 and d.mean() <= 0.25, (d.max(), d.mean())
+    # end to end: JxlCoder.decode of the lossless + ICC file runs the stage (the ICC vector is non-empty, preferEncoding false)
+    px = J.JxlCoder.decode(data, J.PreferredColorConfig.RGBA_8888)
+    ref = icc_oracle.convert(exp, icc)
+    d = np.abs(px.astype(int) - ref.astype(int))
+    assert d.max() <= 2 and d.mean() <= 0.25
+    dec.close()
