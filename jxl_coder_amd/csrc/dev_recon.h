@@ -400,6 +400,15 @@ JXL_DEV float tf_pq(float v, float intensity_target) {
   float r = pow_pos((c1 + c2 * p) / (1 + c3 * p), m2);
   return v < 0 ? -r : r;
 }
+JXL_DEV float tf_hlg(float v) {            // ARIB STD-B67 OETF on [0, 1] (after the inverse OOTF)
+  float a = fabsf(v);
+#ifdef __HIPCC__
+  float r = a <= (1.0f / 12.0f) ? sqrtf(3.0f * a) : 0.17883277f * (__builtin_amdgcn_logf(12.0f * a - 0.28466892f) * 0.69314718056f) + 0.5599107295f;
+#else
+  float r = a <= (1.0f / 12.0f) ? sqrtf(3.0f * a) : 0.17883277f * logf(12.0f * a - 0.28466892f) + 0.5599107295f;
+#endif
+  return v < 0 ? -r : r;
+}
 JXL_DEV float tf_709(float v) {
   float a = fabsf(v);
   float r = a < 0.018f ? 4.5f * a : 1.099f * pow_pos(a, 0.45f) - 0.099f;
@@ -416,9 +425,18 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
   const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
   float v[3];
+  float hlg_ratio = 1.0f;
+  if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
+    float lum = 0.0f;
+    for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * (F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2);
+    hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : 0.0f;
+    if (hlg_ratio > 1e9f) hlg_ratio = 1e9f;
+  }
   for (int c = 0; c < 3; c++) {
     float lin = F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2;
     switch (F.transfer) {
+      case 18: lin = tf_hlg(lin * hlg_ratio); break;
+      case 17: { float a = pow_pos(fabsf(lin), 1.0f / 2.6f); lin = lin < 0 ? -a : a; } break;
       case 13: lin = tf_srgb(lin); break;
       case 16: lin = tf_pq(lin, F.intensity_target); break;
       case 1: lin = tf_709(lin); break;

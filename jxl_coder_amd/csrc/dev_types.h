@@ -98,7 +98,8 @@ struct DevFrame {
   // colour
   float opsin_inv[9];              // already scaled by 255/intensity_target and target-primaries matrix
   float opsin_bias[3], opsin_bias_cbrt[3];
-  int32_t transfer;                // 13 sRGB, 8 linear, 16 PQ, 1 bt709, -1 gamma
+  int32_t transfer;                // 13 sRGB, 8 linear, 16 PQ, 1 bt709, 17 DCI, 18 HLG, -1 gamma
+  float hlg_lum[3], hlg_exponent;  // HLG target: luminance weights of the target primaries and (gamma - 1) of the inverse OOTF (0: not applied)
   float gamma, intensity_target;
   int32_t orientation;
   int32_t out_w, out_h;            // oriented

@@ -473,7 +473,20 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     }
     for (int c = 0; c < 3; c++) { F.opsin_bias[c] = m.opsin_bias[c]; F.opsin_bias_cbrt[c] = cbrtf(m.opsin_bias[c]); }
     F.transfer = m.pub.have_gamma ? -1 : (int)m.pub.transfer_function;
-    if (!m.pub.have_gamma && F.transfer != 13 && F.transfer != 8 && F.transfer != 16 && F.transfer != 1) { plan->error = "unsupported: transfer function"; return -1; }
+    if (!m.pub.have_gamma && F.transfer != 13 && F.transfer != 8 && F.transfer != 16 && F.transfer != 1 && F.transfer != 17 && F.transfer != 18) { plan->error = "unsupported: transfer function"; return -1; }
+    if (F.transfer == 18) {
+      // HLG encodes scene light: the display-referred linear values go through the inverse OOTF first — every channel is scaled by
+      // Y^(gamma - 1), gamma = (1 / 1.2) * 1.111^(-log2(intensity_target / 1000)), Y from the target primaries' luminance weights
+      static const double srgb8[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
+      double prim[8]; memcpy(prim, srgb8, sizeof(prim));
+      if (m.pub.primaries == 9) { const double t[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046}; memcpy(prim, t, sizeof(t)); }
+      else if (m.pub.primaries == 11) { const double t[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060}; memcpy(prim, t, sizeof(t)); }
+      double M[9]; primaries_to_xyz(prim, M);
+      for (int c = 0; c < 3; c++) F.hlg_lum[c] = (float)M[3 + c];
+      const float gamma = (1.0f / 1.2f) * powf(1.111f, -log2f(m.pub.intensity_target / 1000.0f));
+      F.hlg_exponent = gamma - 1.0f;
+      if (F.hlg_exponent > -0.01f && F.hlg_exponent < 0.01f) F.hlg_exponent = 0.0f;
+    }
     F.gamma = m.pub.gamma; F.intensity_target = m.pub.intensity_target;
   }
   F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;

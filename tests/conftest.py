@@ -84,5 +84,8 @@ VARDCT_MEAN_ABS = 0.1
 # handful of near-zero samples (the reference's own SSE2 arithmetic differs from any other float ordering there).
 U16_CASES = ["v160x120_16bit_e7", "va530x270_16bit_e7"]
 U16_PQ_CASES = ["v160x120_16bit_pq2100_epf3"]
+# further target transfer functions of the decoder proper (HLG with its inverse OOTF, DCI gamma 2.6 with P3 primaries): device code only
+# (the plain-C oracle restates sRGB / linear / PQ / 709 / gamma), same 16-bit bounds as U16_CASES
+U16_TF_CASES = ["v160x120_16bit_hlg2100", "v160x120_16bit_dci_p3"]
 U16_MAX_ABS = 256
 U16_MEAN_ABS = 16.0

@@ -35,6 +35,8 @@ CASES = {
     "v64_hard_e7": (64, 64, dict(seed=4, hard=True), dict(effort=7)),
     "v160x120_16bit_e7": (160, 120, dict(seed=21, bits=16), dict(effort=7)),
     "v160x120_16bit_pq2100_epf3": (160, 120, dict(seed=21, bits=16), dict(effort=7, epf=3, primaries=9, transfer=16, intensity_target=10000.0)),
+    "v160x120_16bit_hlg2100": (160, 120, dict(seed=22, bits=16), dict(effort=7, primaries=9, transfer=18, intensity_target=1000.0)),     # HLG: inverse OOTF + OETF in the decoder
+    "v160x120_16bit_dci_p3": (160, 120, dict(seed=23, bits=16), dict(effort=7, primaries=11, transfer=17)),                        # DCI gamma 2.6, P3 primaries
     # RGBA through the reference's encoder call sequence: VarDCT colour + Modular-coded (lossless, no squeeze) alpha
     "va300x520_e7": (300, 520, dict(seed=5, alpha=True), dict(effort=7)),
     "va530x270_16bit_e7": (530, 270, dict(seed=8, bits=16, alpha=True), dict(effort=7)),
@@ -91,7 +93,7 @@ def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
-        info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src)
 
 
@@ -111,7 +113,7 @@ def main():
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
-        info = {k: (float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, encode=ek, synth=sk)
         print(name, len(data), out.shape)
     if not only or "assets" in only:

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS, U16_MEAN_ABS,
+from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
                       LOSSLESS_DEVICE_CASES, load_case)
 
 pytestmark = pytest.mark.gpu
@@ -105,7 +105,7 @@ def test_batch_equals_single_decodes(dec):
         assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
 
 
-@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES)
+@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES + U16_TF_CASES)
 def test_16bit_output(dec, name):
     """bits_per_sample > 8 && allowedFloats -> RGBA u16 (interop/JxlDecoding.cpp:92-101); PQ / Rec.2100 data profile kept."""
     data, exp = load_case(name)
@@ -114,7 +114,7 @@ def test_16bit_output(dec, name):
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
     assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
-    if name in U16_CASES:
+    if name in U16_CASES + U16_TF_CASES:
         assert d.max() <= U16_MAX_ABS
     else:
         assert (d > U16_MAX_ABS).mean() < 2e-3 and info["transfer_function"] == 16 and info["primaries"] == 9

@@ -7,7 +7,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
+from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS,
                       U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, load_case)
 
 import jxl_coder_amd as J
@@ -119,7 +119,7 @@ def test_harness_flags_corrupt_streams(emul):
         emul(data[: len(data) - 2000])
 
 
-@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES)
+@pytest.mark.parametrize("name", U16_CASES + U16_PQ_CASES + U16_TF_CASES)
 def test_device_code_16bit_on_cpu_harness(emul, name):
     data, exp = load_case(name)
     out = emul(data)
@@ -127,7 +127,7 @@ def test_device_code_16bit_on_cpu_harness(emul, name):
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
     assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
-    if name in U16_CASES:
+    if name in U16_CASES + U16_TF_CASES:
         assert d.max() <= U16_MAX_ABS
     else:
         assert (d > U16_MAX_ABS).mean() < 2e-3
