@@ -206,10 +206,12 @@ def main():
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
         flights = max(int(kern.get("flights", 1)), 1)
-        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt of the first sub-flight" if P > 1 else "k_pass_group") + " (+k_lf_smooth)",
+        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt (first sub-flight of the flight; + k_lf_smooth)" if P > 1 else "k_pass_group (+ k_lf_smooth)"),
                  "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt, k_recon_*, k_filter_b<*>" if P > 1 else "k_recon_small_b+k_recon_list_b", "filters_write_ms": "k_filter_b<0..4>"}
         stages = {k: kern[k] / flights for k in names if k in kern}
-        dom = "lf_groups_ms"      # rocprofv3 --stats of this command: the batched LF-group kernel has the largest total (profiles/)
+        # the dominant kernel = the one with the largest total duration in rocprofv3 --stats of this command (profiles/): the two serial
+        # entropy stages compete for it; both are one launch per flight and both are timed by the HIP events, so the run itself decides
+        dom = "lf_groups_ms" if stages.get("lf_groups_ms", 0.0) >= stages.get("pass_groups_ms", 0.0) or P == 1 else "pass_groups_ms"
         dom_ms = stages[dom]
         frames_per_launch = total_frames / flights
         achieved = algo_bytes * frames_per_launch / (dom_ms * 1e-3) / 1e9
@@ -219,7 +221,7 @@ def main():
         traffic, traffic_src = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = int(tj["dominant_kernel_bytes_per_frame"] * frames_per_launch); traffic_src = tj.get("source")
+            traffic = int(tj["bytes_per_frame"][names[dom].split(" ")[0]] * frames_per_launch); traffic_src = tj.get("source")
         except Exception:  # noqa: BLE001
             pass
         line = {

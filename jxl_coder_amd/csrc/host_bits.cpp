@@ -1,6 +1,7 @@
-/* oracle/hx_entropy.c — bit reader, field codes, ANS / prefix entropy decoder (ISO/IEC 18181-1 Annex C/D).
- * CPU restatement used only as a checker (see jxo.h). Pinned against the reference's libjxl 0.12.0
- * (jxlcoder/src/main/cpp/lib/x86_64/libjxl.so) via oracle/_ref on whole-image outputs. */
+/* host_bits.cpp — PRODUCT host code: bit reader, field codes, ANS / prefix histogram + context-map reader (ISO/IEC 18181-1 Annex C/D)
+ * used by host_parse.cpp to read headers, the embedded ICC stream, the TOC and the LfGlobal / HfGlobal sections into the frame-tables
+ * blob.  It decodes no pixel data.  The test oracle has its own, separately compiled restatement of the same clauses (oracle/jxo_entropy.c);
+ * the two are deliberately independent so that a shared mistake cannot hide — nothing here includes or links anything under oracle/. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -1,9 +1,11 @@
 """CPU tests: the oracle (oracle/libjxo.so) against the golden vectors produced by the reference's own libjxl."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import (LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, load_case)
+                      U16_MEAN_ABS, ROOT, load_case)
 
 
 @pytest.mark.parametrize("name", LOSSLESS_CASES)
@@ -76,3 +78,13 @@ def test_oracle_16bit_output(oracle, name):
         assert d.max() <= U16_MAX_ABS
     else:
         assert (d > U16_MAX_ABS).mean() < 2e-3
+
+
+def test_reference_binary_is_the_pinned_one():
+    """oracle/_ref holds the reference's own prebuilt codec (libjxl 0.12.0, cpp/lib/x86_64/libjxl.so) as a binary; every golden vector was
+    generated through it.  Pin the file so a different build cannot silently become 'the reference'."""
+    import hashlib
+    p = os.path.join(ROOT, "oracle", "_ref", "libjxl.so")
+    if not os.path.exists(p):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    assert hashlib.sha256(open(p, "rb").read()).hexdigest() == "25bd94ff22ae13a62027e266e96fa040c05d116544a75816156d4c540b6c4abe"
