@@ -99,8 +99,15 @@ def build(force=False, verbose=False):
         src = os.path.join(csrc, sname)
         obj = os.path.join(objdir, sname + ".o")
         objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-c", src, "-o", obj])
+        dep_time = hdr_time                       # without a dependency file from an earlier compile: any header
+        try:
+            deps = open(obj + ".d").read().replace("\\\n", " ").split(":", 1)[1].split()
+            dep_time = max(os.path.getmtime(d) for d in deps if d.startswith(os.path.dirname(_HERE)))
+        except (OSError, IndexError, ValueError):
+            pass
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_time):
+            jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-MMD", "-MF", obj + ".d",
+                         "-c", src, "-o", obj])
     if not jobs and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return _LIB_PATH
 

@@ -29,6 +29,7 @@ struct ReconLds {                       // medium: S[3][1024] T[3][1024] CC (28 
   float S[NMAX > 1024 ? NMAX : 3 * NMAX];
   float T[NMAX > 1024 ? NMAX : 3 * 1024];
   float CC[NMAX > 1024 ? 4 : 1024];
+  float LL[32];                         // 4-point cosine table (16) + 4-point LLF scales (4): the LLF corner of DCT32x32 blocks
 };
 
 __device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
@@ -111,6 +112,77 @@ __device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const floa
   }
 }
 
+// Front end of a DCT32x32 varblock (dequantisation + chroma from luma into S, lowest frequencies from the LF image), written for
+// memory-level parallelism: recon_phaseA / recon_phaseB (dev_recon.h, the generic path) interleave dependent global loads with
+// conditional stores, one coefficient at a time per work-item — four round trips for the coefficients and sixteen more for the 48
+// work-items of the LLF corner, with a barrier in between.  Here every work-item first issues ALL its loads (12 coefficients and
+// their weights; wave 3 also the 16 LF samples of its LLF output), then computes; the LLF corner is skipped by the dequantiser
+// and written by wave 3, so the two need no barrier between them.  Same float operations in the same order as the generic path.
+__device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, const float *LL, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  const int qt = kQuantTableOf[kStrategyDct32];
+  const int g = (by / 32) * F.xgroups + (bx / 32);
+  uint32_t off = B.coef_off[o];
+  if (off + 1024u > 65536u) { if (tid == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
+  int32_t *qp[3]; const float *qw[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { qp[c] = &B.coef[c][(size_t)g * 65536 + off + (uint32_t)tid]; qw[c] = st_f(stat, ST.qw_off[qt][c]) + tid; }
+  int q[3][4]; float w[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { q[c][j] = qp[c][256 * j]; w[c][j] = qw[c][256 * j]; }
+  // LLF corner: work-item 192 + i, i < 48, produces coefficient (a, b) = (i / 4 % 4, i % 4) of channel i / 16
+  const int li = tid - 192;
+  const bool llf = li >= 0 && li < 48;
+  float lf[16];
+  if (llf) {
+    const float *src = B.lf_s[li >> 4] + o;
+#pragma unroll
+    for (int iy = 0; iy < 4; iy++)
+#pragma unroll
+      for (int ix = 0; ix < 4; ix++) lf[iy * 4 + ix] = src[(size_t)iy * (size_t)F.xb + (size_t)ix];
+  }
+  const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
+  const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
+  const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
+  const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = tid + 256 * j;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int qq = q[c][j];
+      if (qq != 0) qp[c][256 * j] = 0;                 // consumed exactly once: the reader clears it (see recon_phaseA)
+      float a;
+      if (qq == 0) a = 0.0f;
+      else if (qq == 1) a = F.quant_bias[c];
+      else if (qq == -1) a = -F.quant_bias[c];
+      else a = (float)qq - F.quant_bias[3] / (float)qq;
+      v[c] = a * (mul * F.dm[c] * w[c][j]);
+    }
+    if ((k >> 5) < 4 && (k & 31) < 4) continue;        // the LLF corner belongs to wave 3
+    S[k] = v[0] + kx * v[1];
+    S[1024 + k] = v[1];
+    S[2048 + k] = v[2] + kb * v[1];
+  }
+  if (llf) {
+    const int r = li & 15, a = r >> 2, b = r & 3;      // cx == cy: horizontal frequency u = a, vertical v = b (recon_phaseB)
+    float s = 0.0f;
+#pragma unroll
+    for (int iy = 0; iy < 4; iy++) {
+      float rs = 0.0f;
+#pragma unroll
+      for (int ix = 0; ix < 4; ix++) rs += lf[iy * 4 + ix] * LL[a * 4 + ix];
+      s += rs * LL[b * 4 + iy];
+    }
+    s *= (1.0f / 16.0f) * LL[16 + a] * LL[16 + b];
+    S[(li >> 4) * 1024 + a * 32 + b] = s;
+  }
+}
+
 template <int NMIN, int NMAX>
 __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma) {
   __shared__ __attribute__((aligned(16))) ReconLds<NMAX> L;
@@ -122,6 +194,8 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
   if (NMAX == 1024) {
     const float *cc = st_f(stat, ST.cos_off[5]);
     for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
+    if (tid < 16) L.LL[tid] = st_f(stat, ST.cos_off[2])[tid];
+    else if (tid < 20) L.LL[tid] = (st_f(stat, ST.llf_off) + 64)[tid - 16];
   }
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
     const int cell = (int)B.big_list[cls][i];
@@ -129,9 +203,7 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
     if (by < F.band_cy0 || by >= F.band_cy1) continue;       // band decode: the LF groups placed here may reach beyond the band's rows
     if (NMAX == 1024 && B.strategy[cell] == kStrategyDct32) {
       __syncthreads();                               // previous item's pass 2 has finished reading T; CC is in place
-      recon_phaseA(B, stat, ST, L.S, 1024, bx, by, tid, 256);
-      __syncthreads();
-      recon_phaseB(B, stat, ST, L.S, 1024, bx, by, tid, 256);
+      recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
       __syncthreads();
       if (use_mfma) recon_dct32_mfma(B, L.S, L.T, L.CC, bx, by, tid); else recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
     } else {
