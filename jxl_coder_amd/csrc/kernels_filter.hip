@@ -26,11 +26,13 @@ __device__ __forceinline__ int last_filter_stage(const DevFrame &F) { return F.e
 __device__ __forceinline__ int stage_halo_after(const DevFrame &F, int stage) {
   return (stage < 1 && F.epf_iters >= 3 ? 3 : 0) + (stage < 2 && F.epf_iters >= 1 ? 2 : 0) + (stage < 3 && F.epf_iters >= 2 ? 1 : 0);
 }
+__device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F);
 template <int STAGE>
-__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || !stage_runs(F, STAGE) || frame_failed(B)) return;
+  if (sweep_on && frame_uses_sweep(F)) return;                // k_filter_sweep produces this frame's pixels
   const int last = last_filter_stage(F);
   if (STAGE == 4 && last >= 0) return;                       // the writer was fused into stage `last`
   const int halo = stage_halo_after(F, STAGE);
@@ -127,6 +129,142 @@ __global__ void __launch_bounds__(256) k_filter_fused(const DevBuffers *__restri
   }
 }
 
+// ---- Column sweep: Gaborish + EPF iteration 1 (+ iteration 2) + writer in ONE pass over the reconstructed planes, all in registers.
+// A wave owns a strip of 64 - 2 HX columns (lane = column, HX halo lanes on each side) and walks down a segment of rows.  Every stage
+// keeps a rolling window of its input rows in registers; horizontal neighbours come from the adjacent lanes (DPP wave shifts), vertical
+// ones from the window, so each plane sample is loaded once per strip and nothing goes back to HBM but the RGBA pixels.
+// The 5-pixel SADs of EPF iteration 1 are built from two difference maps (per pixel: the channel-weighted absolute difference to the
+// pixel above, E_v, and to the pixel on the left, E_h): SAD_up(x, y) is the plus-shaped sum of E_v around (x, y), SAD_down(x, y) =
+// SAD_up(x, y + 1), SAD_left the plus-shaped sum of E_h, SAD_right(x, y) = SAD_left(x + 1, y) — 20 operations per pixel instead of
+// 120.  Coordinates outside the image are evaluated at their mirror image (virtual rows / columns hold the stage output AT the
+// mirrored position, which is what the per-stage kernels read there); summation order differs from the per-stage kernels in the
+// last bits only.  Frames with three EPF iterations (12-tap first pass) stay on the per-stage kernels.
+__device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }    // lane - 1: x - 1
+__device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // lane + 1: x + 1
+__device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && F.epf_iters <= 2; }
+
+template <bool kGab, int kEpf>
+__device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int strip, int seg, int rows_per_wave, int lane) {
+  constexpr int DG = kGab ? 1 : 0, DE = kEpf >= 1 ? 2 : 0, DF = kEpf >= 2 ? 1 : 0;     // row delay of each stage behind its input
+  constexpr int HX = DG + DE + DF, SW = 64 - 2 * HX;
+  const int w = F.width, h = F.height;
+  const int x0 = strip * SW;
+  const int y0 = F.band_py0 + seg * rows_per_wave;
+  if (x0 >= w || y0 >= F.band_py1) return;
+  const int y1 = y0 + rows_per_wave < F.band_py1 ? y0 + rows_per_wave : F.band_py1;
+  const int x = x0 - HX + lane;                                  // virtual column of this lane
+  const int ex = mirror(x < w + 8 ? x : w + 7, w);               // lanes far beyond the image never produce output
+  const bool lane_out = lane >= HX && lane < 64 - HX && x < w;
+  const bool lane_border = (ex & 7) == 0 || (ex & 7) == 7;
+  const float *src[3] = {B.plane_a[0] + ex, B.plane_a[1] + ex, B.plane_a[2] + ex};
+  const DevStatic &ST = *(const DevStatic *)stat;
+  float gn[3], g1[3], g2[3], cs[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float w1 = F.gab_w[c][0], w2 = F.gab_w[c][1];
+    const float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
+    gn[c] = norm; g1[c] = w1 * norm; g2[c] = w2 * norm; cs[c] = F.epf_chscale[c];
+  }
+  const float sm1 = 1.65f, sm1b = sm1 * F.epf_border_sad, sm2 = 1.65f * F.epf_pass2, sm2b = sm2 * F.epf_border_sad;
+  float in[3][3] = {}, G[4][3] = {}, Ev[3] = {}, Eh[3] = {}, E1[3][3] = {};
+  float sad_up_e = 0.0f, is1 = 0.0f, is2 = 0.0f;
+  int cell1 = -1, cell2 = -1;
+  for (int t = y0 - HX; t < y1 + HX; t++) {
+    const size_t ro = (size_t)mirror(t, h) * (size_t)F.pw;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { in[0][c] = in[1][c]; in[1][c] = in[2][c]; in[2][c] = src[c][ro]; }
+    // Gaborish at row g = t - DG
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      G[0][c] = G[1][c]; G[1][c] = G[2][c]; G[2][c] = G[3][c];
+      if (kGab) {
+        const float U = in[0][c], C = in[1][c], D = in[2][c];
+        const float side = U + D + dpp_left(C) + dpp_right(C);
+        const float diag = dpp_left(U) + dpp_right(U) + dpp_left(D) + dpp_right(D);
+        G[3][c] = C * gn[c] + side * g1[c] + diag * g2[c];
+      } else {
+        G[3][c] = in[2][c];
+      }
+      v[c] = G[3][c];
+    }
+    if (kEpf >= 1) {
+      // difference maps: E_v of row g, E_h of row g - 1
+      const float evn = fabsf(G[3][0] - G[2][0]) * cs[0] + fabsf(G[3][1] - G[2][1]) * cs[1] + fabsf(G[3][2] - G[2][2]) * cs[2];
+      const float ehn = fabsf(G[2][0] - dpp_left(G[2][0])) * cs[0] + fabsf(G[2][1] - dpp_left(G[2][1])) * cs[1] + fabsf(G[2][2] - dpp_left(G[2][2])) * cs[2];
+      Ev[0] = Ev[1]; Ev[1] = Ev[2]; Ev[2] = evn;
+      Eh[0] = Eh[1]; Eh[1] = Eh[2]; Eh[2] = ehn;
+      // EPF iteration 1 at row e = g - 2: window rows G[0] = e - 1, G[1] = e, G[2] = e + 1
+      const int e = t - DG - 2, ey = mirror(e, h);
+      if ((ey >> 3) != cell1) { cell1 = ey >> 3; is1 = epf_inv_sigma(B, F, ex, ey); }
+      const float sad_dn = Ev[0] + Ev[1] + Ev[2] + dpp_left(Ev[1]) + dpp_right(Ev[1]);     // SAD_up(e + 1)
+      const float sad_lf = Eh[0] + Eh[1] + Eh[2] + dpp_left(Eh[1]) + dpp_right(Eh[1]);
+      const float sad_rt = dpp_right(sad_lf);
+      const bool border = (ey & 7) == 0 || (ey & 7) == 7 || lane_border;
+      const float isig = is1 * (border ? sm1b : sm1);
+      float wu = 1.0f + sad_up_e * isig, wl = 1.0f + sad_lf * isig, wr = 1.0f + sad_rt * isig, wd = 1.0f + sad_dn * isig;
+      wu = wu < 0.0f ? 0.0f : wu; wl = wl < 0.0f ? 0.0f : wl; wr = wr < 0.0f ? 0.0f : wr; wd = wd < 0.0f ? 0.0f : wd;
+      const float inv = 1.0f / (1.0f + wu + wl + wr + wd);
+      const bool skip = is1 < -3.90524291751269967465540850526868f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float acc = G[1][c];
+        acc += wu * G[0][c]; acc += wl * dpp_left(G[1][c]); acc += wr * dpp_right(G[1][c]); acc += wd * G[2][c];
+        v[c] = skip ? G[1][c] : acc * inv;
+      }
+      sad_up_e = sad_dn;
+    }
+    if (kEpf >= 2) {
+      // EPF iteration 2 (1-pixel SAD) at row f = e - 1 on the window E1[0] = f - 1, E1[1] = f, E1[2] = f + 1
+#pragma unroll
+      for (int c = 0; c < 3; c++) { E1[0][c] = E1[1][c]; E1[1][c] = E1[2][c]; E1[2][c] = v[c]; }
+      const int f = t - DG - 3, fy = mirror(f, h);
+      if ((fy >> 3) != cell2) { cell2 = fy >> 3; is2 = epf_inv_sigma(B, F, ex, fy); }
+      const bool border = (fy & 7) == 0 || (fy & 7) == 7 || lane_border;
+      const float isig = is2 * (border ? sm2b : sm2);
+      float tl[3], tr[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) { tl[c] = dpp_left(E1[1][c]); tr[c] = dpp_right(E1[1][c]); }
+      float su = 0.0f, sl = 0.0f, sr = 0.0f, sd = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        su += fabsf(E1[1][c] - E1[0][c]) * cs[c]; sl += fabsf(E1[1][c] - tl[c]) * cs[c];
+        sr += fabsf(E1[1][c] - tr[c]) * cs[c]; sd += fabsf(E1[1][c] - E1[2][c]) * cs[c];
+      }
+      float wu = 1.0f + su * isig, wl = 1.0f + sl * isig, wr = 1.0f + sr * isig, wd = 1.0f + sd * isig;
+      wu = wu < 0.0f ? 0.0f : wu; wl = wl < 0.0f ? 0.0f : wl; wr = wr < 0.0f ? 0.0f : wr; wd = wd < 0.0f ? 0.0f : wd;
+      const float inv = 1.0f / (1.0f + wu + wl + wr + wd);
+      const bool skip = is2 < -3.90524291751269967465540850526868f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        float acc = E1[1][c];
+        acc += wu * E1[0][c]; acc += wl * tl[c]; acc += wr * tr[c]; acc += wd * E1[2][c];
+        v[c] = skip ? E1[1][c] : acc * inv;
+      }
+    }
+    const int o = t - HX;                                         // the row that left the last stage
+    if (o >= y0 && lane_out) {
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));      // keep the filter's last multiply and the writer's first add apart (no FMA across the seam)
+      xyb_write_value(B, stat, ST, v[0], v[1], v[2], B.out_bits, x, o);
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave) {
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (!frame_uses_sweep(F) || frame_failed(B)) return;
+  const int lane = (int)(threadIdx.x & 63), seg = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)), strip = (int)blockIdx.x;
+  if (F.gab) {
+    if (F.epf_iters == 0) filter_sweep<true, 0>(B, F, stat, strip, seg, rows_per_wave, lane);
+    else if (F.epf_iters == 1) filter_sweep<true, 1>(B, F, stat, strip, seg, rows_per_wave, lane);
+    else filter_sweep<true, 2>(B, F, stat, strip, seg, rows_per_wave, lane);
+  } else {
+    if (F.epf_iters == 0) filter_sweep<false, 0>(B, F, stat, strip, seg, rows_per_wave, lane);
+    else if (F.epf_iters == 1) filter_sweep<false, 1>(B, F, stat, strip, seg, rows_per_wave, lane);
+    else filter_sweep<false, 2>(B, F, stat, strip, seg, rows_per_wave, lane);
+  }
+}
+
 void launch_filters_fused(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
   const int H = (stage_mask & 1 ? 1 : 0) + (stage_mask & 2 ? 3 : 0) + (stage_mask & 4 ? 2 : 0) + (stage_mask & 8 ? 1 : 0);
   const size_t lds = (size_t)2 * 3 * (kTileW + 2 * H) * (kTileH + 2 * H) * sizeof(float);
@@ -138,12 +276,20 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   // profiles/r02_*): off by default
   static const int fused = getenv("JXLAMD_FUSED_FILTERS") ? atoi(getenv("JXLAMD_FUSED_FILTERS")) : 0;
   if (fused) { launch_filters_fused(Bs, stat, nframes, max_w, max_h, stage_mask, s); return; }
+  // Column sweep (k_filter_sweep) for every frame with at most two EPF iterations; frames with three (stage_mask & 2: the 12-tap first
+  // pass) go through the per-stage kernels, which then skip the frames the sweep has produced.  JXLAMD_FILTER_SWEEP=0: per-stage only.
+  static const int sweep = getenv("JXLAMD_FILTER_SWEEP") ? atoi(getenv("JXLAMD_FILTER_SWEEP")) : 1;
+  if (sweep) {
+    const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
+    hipLaunchKernelGGL(k_filter_sweep, dim3((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes), dim3(256), 0, s, Bs, stat, rows);
+    if (!(stage_mask & 2)) return;
+  }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
-  if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat);
-  if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat);
+  if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat, sweep);
 }
 
 }  // namespace jxlamd
