@@ -20,7 +20,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FRAMES = [os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{i}.jxl") for i in range(8)]
+FRAMES = [os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{i}.jxl") for i in (map(int, os.environ["JXLAMD_BENCH_SEEDS"].split(",")) if os.environ.get("JXLAMD_BENCH_SEEDS") else range(8))]   # JXLAMD_BENCH_SEEDS: experiments on a subset
 FRAMES = [f for f in FRAMES if os.path.exists(f)]
 FRAME = FRAMES[0]
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
@@ -196,6 +196,19 @@ def main():
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
 
+    if os.environ.get("JXLAMD_BENCH_CLOCKS"):
+        # diagnostics: wall time and shader clock of the LF streams of context 0's last flight (decoded next to the other contexts)
+        import ctypes as C
+        import numpy as np
+        L = J.api.lib()
+        L.jxlamd_debug_lf_phases_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        tt = np.zeros((P, 4, 8), np.uint64)
+        for f in range(P):
+            L.jxlamd_debug_lf_phases_frame(decs[0]._h, f, 4, tt[f].ctypes.data)
+        wall = (tt[:, :2, 6].astype(np.int64) - tt[:, :2, 0].astype(np.int64)) / 1e5
+        mhz = tt[:, :2, 7].astype(np.float64) / np.maximum(wall, 1e-9) / 1e3
+        print("[clocks] long LF streams of the last flight of context 0: wall ms min %.1f median %.1f max %.1f; shader clock MHz min %.0f median %.0f max %.0f"
+              % (wall.min(), np.median(wall), wall.max(), mhz.min(), np.median(mhz), mhz.max()), file=sys.stderr)
     if rank == 0:
         frames = total_frames * world
         mp = w * h / 1e6

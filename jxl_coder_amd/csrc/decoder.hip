@@ -3,6 +3,7 @@
 // Host counterpart of the reference's DecodeJpegXlOneShot driver loop (interop/JxlDecoding.cpp:36-176).
 #include <atomic>
 #include <limits>
+#include <chrono>
 #include <thread>
 #include "decoder_ctx.h"
 
@@ -111,20 +112,25 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   // through the slot's own padded buffer: H2D from page-locked staging, or — JXLAMD_IN_DEVICE — a device-to-device copy of the
   // caller's resident bytes (no requirement on the caller's buffer: neither alignment nor padding).
   const bool cs_resident = (flags & JXLAMD_IN_DEVICE) && jxl_dev && plan.cs_owned.empty();
-  HIPCHECK(S.cs.ensure(plan.cs_size + 64));
-  if (cs_resident) HIPCHECK(hipMemcpyAsync(S.cs.p, (const uint8_t *)jxl_dev + (plan.cs - jxl), plan.cs_size, hipMemcpyDeviceToDevice, stream));
-  else {
-    HIPCHECK(S.h_cs.ensure(plan.cs_size));
-    memcpy(S.h_cs.p, plan.cs, plan.cs_size);
-    HIPCHECK(hipMemcpyAsync(S.cs.p, S.h_cs.p, plan.cs_size, hipMemcpyHostToDevice, stream));
+  const bool in_flight = !own_planes;                 // frames of a batched flight: decode_batch uploads tables and streams of all of them at once
+  S.up_cs_dev = cs_resident ? (const uint8_t *)jxl_dev + (plan.cs - jxl) : nullptr;
+  const uint8_t *d_cs = nullptr;
+  if (!in_flight) {
+    HIPCHECK(S.cs.ensure(plan.cs_size + 64));
+    if (cs_resident) HIPCHECK(hipMemcpyAsync(S.cs.p, S.up_cs_dev, plan.cs_size, hipMemcpyDeviceToDevice, stream));
+    else {
+      HIPCHECK(S.h_cs.ensure(plan.cs_size));
+      memcpy(S.h_cs.p, plan.cs, plan.cs_size);
+      HIPCHECK(hipMemcpyAsync(S.cs.p, S.h_cs.p, plan.cs_size, hipMemcpyHostToDevice, stream));
+    }
+    HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
+    d_cs = (const uint8_t *)S.cs.p;
+    // single-section frames: room for the phase-2 (HfGlobal) tables — orders of all 13 order ids x 3 channels x passes + histograms
+    HIPCHECK(S.tables.ensure(plan.tables.size() + (plan.single_section ? (size_t)(12u << 20) : 0u)));
+    HIPCHECK(S.h_tables.ensure(plan.tables.size()));
+    memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
+    HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
   }
-  HIPCHECK(hipMemsetAsync((uint8_t *)S.cs.p + plan.cs_size, 0, 64, stream));
-  const uint8_t *d_cs = (const uint8_t *)S.cs.p;
-  // single-section frames: room for the phase-2 (HfGlobal) tables — orders of all 13 order ids x 3 channels x passes + histograms
-  HIPCHECK(S.tables.ensure(plan.tables.size() + (plan.single_section ? (size_t)(12u << 20) : 0u)));
-  HIPCHECK(S.h_tables.ensure(plan.tables.size()));
-  memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
-  HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
   if (!plan.modular) {
     for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
     for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
@@ -156,7 +162,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   memset(&B, 0, sizeof(B));
   // pointer biases: element [frame coordinate] lands at [frame coordinate - band origin] of the allocation
   const ptrdiff_t cb = (ptrdiff_t)q.scy0 * plan.xb, tb = (ptrdiff_t)q.st0 * ((plan.xb + 7) / 8), pb = (ptrdiff_t)q.prow0 * plan.xb * 8;
-  B.codestream = d_cs; B.tables = (const uint8_t *)S.tables.p;
+  B.codestream = d_cs; B.tables = in_flight ? nullptr : (const uint8_t *)S.tables.p;      // in_flight: decode_batch points both into the flight's buffers
   B.strategy = (uint8_t *)S.cells8[0].p - cb; B.first = (uint8_t *)S.cells8[1].p - cb; B.qfm1 = (uint8_t *)S.cells8[2].p - cb;
   B.sharp = (uint8_t *)S.cells8[3].p - cb; B.lf_idx = (uint8_t *)S.cells8[4].p - cb;
   B.xfromy = (int8_t *)S.tiles[0].p - tb; B.bfromy = (int8_t *)S.tiles[1].p - tb;
@@ -167,11 +173,11 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.local = (LocalTreeScratch *)S.local.p - q.lfg0;
   B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * 3072;
   B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
-  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits;
+  B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits; B.stat = (const uint8_t *)stat.p;
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
-  const bool in_flight = !own_planes;                 // frames of a batched flight: one k_clear_b launch clears these for all of them
+  // frames of a batched flight (in_flight): one k_clear_b launch clears these for all of them
   if (!in_flight) HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
   if (!plan.modular) {
     if (!in_flight) HIPCHECK(hipMemsetAsync(S.cells8[1].p, 0, ncell, stream));
@@ -326,8 +332,12 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   HIPCHECK(hipSetDevice(device));
   std::vector<int> batched, mod_batched;
+  // JXLAMD_TRACE_FLIGHT=1: wall-clock split of every flight on stderr (host parse / per-frame prepare + uploads / launches / wait)
+  static const bool trace = getenv("JXLAMD_TRACE_FLIGHT") && atoi(getenv("JXLAMD_TRACE_FLIGHT"));
+  const auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
   // host parse of all frames in parallel (pure CPU work, independent per frame)
-  for (int i = 0; i < n; i++) { slot((size_t)i).plan = FramePlan(); }
+  for (int i = 0; i < n; i++) { slot((size_t)i).plan.reset(); }
   {
     const int nthr = n < 16 ? n : 16;
     std::vector<std::thread> th;
@@ -335,6 +345,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     for (int t = 0; t < nthr; t++) th.emplace_back([&] { for (;;) { int i = next.fetch_add(1); if (i >= n) return; (void)plan_parse(jxl[i], sizes[i], &slots[(size_t)i]->plan); } });
     for (auto &t : th) t.join();
   }
+  const double t_parsed = now();
+  if (trace) HIPCHECK(hipEventRecord(ev[5], stream));
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
@@ -377,6 +389,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (first_mod_rc) return first_mod_rc;
   }
   if (batched.empty()) return JXLAMD_OK;
+  const double t_prepared = now();
   // ---- the flight.  Two phases with different buffer lifetimes:
   //   LF phase : ONE launch decodes the LfGroup streams of all frames of the flight.  Its outputs are small (per-cell planes,
   //              LF image: ~4 MB per 4K frame), so a flight can be long (hundreds of frames) — which is what the
@@ -412,6 +425,35 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));
   }
   coef_pool_clean = false;                                   // until every frame of this flight has been collected without error
+  // tables and compressed bytes of all frames: one page-locked staging buffer and ONE upload each (a frame used to cost three
+  // stream operations here and one more in collect(); next to seven other busy contexts those ~500 tiny operations per flight
+  // took up to 200 ms of the stream's time)
+  std::vector<GatherDesc> gdesc;
+  uint32_t gather_max = 0;
+  {
+    const auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t tab_total = 0, cs_total = 0;
+    for (int i : batched) { const FramePlan &P = slot((size_t)i).plan; tab_total += al(P.tables.size()); cs_total += al(P.cs_size + 64); }
+    HIPCHECK(flight_tables.ensure(tab_total)); HIPCHECK(h_flight_tables.ensure(tab_total)); HIPCHECK(flight_cs.ensure(cs_total));
+    size_t to = 0, co = 0;
+    bool host_cs = false;
+    for (int i : batched) host_cs = host_cs || !slot((size_t)i).up_cs_dev;
+    if (host_cs) HIPCHECK(h_flight_cs.ensure(cs_total));
+    for (int i : batched) {
+      FrameSlot &S = slot((size_t)i);
+      const FramePlan &P = S.plan;
+      memcpy((uint8_t *)h_flight_tables.p + to, P.tables.data(), P.tables.size());
+      S.B.tables = (const uint8_t *)flight_tables.p + to;
+      S.B.codestream = (const uint8_t *)flight_cs.p + co;
+      if (S.up_cs_dev) { gdesc.push_back({S.up_cs_dev, (uint8_t *)flight_cs.p + co, (uint32_t)P.cs_size, 64u}); gather_max = std::max(gather_max, (uint32_t)P.cs_size); }
+      else {
+        memcpy((uint8_t *)h_flight_cs.p + co, P.cs, P.cs_size); memset((uint8_t *)h_flight_cs.p + co + P.cs_size, 0, 64);
+        HIPCHECK(hipMemcpyAsync((uint8_t *)flight_cs.p + co, (uint8_t *)h_flight_cs.p + co, P.cs_size + 64, hipMemcpyHostToDevice, stream));
+      }
+      to += al(P.tables.size()); co += al(P.cs_size + 64);
+    }
+    HIPCHECK(hipMemcpyAsync(flight_tables.p, h_flight_tables.p, tab_total, hipMemcpyHostToDevice, stream));
+  }
   std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map, w_map;
   std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / workgroup map
   bool all_hf_lds = pass_frame_mode >= 1;
@@ -465,7 +507,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
                o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, o_ec = (o_pg + pg_map.size() * 4 + 255) & ~(size_t)255,
-               o_w = (o_ec + ec_map.size() * 4 + 255) & ~(size_t)255, total = o_w + w_map.size() * 4 + 4;
+               o_w = (o_ec + ec_map.size() * 4 + 255) & ~(size_t)255, o_gd = (o_w + w_map.size() * 4 + 255) & ~(size_t)255,
+               o_fl = (o_gd + gdesc.size() * sizeof(GatherDesc) + 255) & ~(size_t)255, total = o_fl + (size_t)nb * kFlagWords * 4 + 4;
   HIPCHECK(batch_tab.ensure(total));
   HIPCHECK(h_batch.ensure(total));
   uint8_t *bt = (uint8_t *)batch_tab.p, *hbt = (uint8_t *)h_batch.p;
@@ -475,7 +518,9 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   memcpy(hbt + o_pg, pg_map.data(), pg_map.size() * 4);
   if (!ec_map.empty()) memcpy(hbt + o_ec, ec_map.data(), ec_map.size() * 4);
   memcpy(hbt + o_w, w_map.data(), w_map.size() * 4);
-  HIPCHECK(hipMemcpyAsync(bt, hbt, total, hipMemcpyHostToDevice, stream));
+  if (!gdesc.empty()) memcpy(hbt + o_gd, gdesc.data(), gdesc.size() * sizeof(GatherDesc));
+  HIPCHECK(hipMemcpyAsync(bt, hbt, o_fl, hipMemcpyHostToDevice, stream));
+  if (!gdesc.empty()) launch_gather_streams((const GatherDesc *)(bt + o_gd), (int)gdesc.size(), gather_max, stream);
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
   HIPCHECK(hipEventRecord(ev[0], stream));
@@ -502,13 +547,32 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
       launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
+  const double t_launched = now();
   int first_rc = JXLAMD_OK;
   large_blocks_seen = false;
-  for (int i : batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_rc) first_rc = rc; }
+  // flags / counters of all frames in one device-to-host copy and one synchronisation
+  launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
+  HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
+  HIPCHECK(hipMemcpyAsync(h_flags.p, bt + o_fl, (size_t)nb * kFlagWords * 4, hipMemcpyDeviceToHost, stream));
+  for (int i : batched) { FrameSlot &S = slot((size_t)i); if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream)); }
+  HIPCHECK(hipStreamSynchronize(stream));
+  HIPCHECK(hipGetLastError());
+  for (int k = 0; k < nb; k++) {
+    FrameSlot &S = slot((size_t)batched[(size_t)k]);
+    const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
+    if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
+    if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
+    (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
+  }
   coef_pool_clean = first_rc == JXLAMD_OK;
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
+  if (trace) {
+    float to_ev0 = 0; (void)hipEventElapsedTime(&to_ev0, ev[5], ev[0]);       // ev[5]: recorded before the first upload of the flight
+    fprintf(stderr, "[flight %p] begin %.1f end %.1f | n=%d parse %.1f prepare %.1f launch %.1f wait+collect %.1f ms | GPU: uploads %.1f LF %.1f pass0 %.1f rest %.1f\n",
+            (void *)this, t_begin, now(), nb, t_parsed - t_begin, t_prepared - t_parsed, t_launched - t_prepared, now() - t_launched, to_ev0, timing[0], timing[1], timing[2]);
+  }
   return first_rc;
 }
 

@@ -29,7 +29,9 @@ struct DevMem {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
-    size_t want = n + n / 8 + 4096;
+    // growth headroom: a slot sees frames of different sizes flight after flight, and every re-allocation is a hipFree (device-wide
+    // synchronisation that stalls the flights of all contexts); the big pools (GBs) cannot afford more than 1/8
+    size_t want = n < ((size_t)64 << 20) ? n + n / 2 + 65536 : n + n / 8 + 4096;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
     return e;
@@ -83,6 +85,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   jxlamd_info pi;
   size_t out_bytes = 0;
   void *d_out = nullptr; void *host_out = nullptr;
+  const uint8_t *up_cs_dev = nullptr;   // frames of a flight: the caller's resident compressed bytes (null: host bytes), copied by the flight's gather launch
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
   void release() {
@@ -107,7 +110,8 @@ struct jxlamd_decoder {
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
-  PinnedMem h_batch, h_mod_tab;
+  PinnedMem h_batch, h_mod_tab, h_flight_tables, h_flight_cs, h_flags;
+  DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds

@@ -19,7 +19,10 @@ constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
 struct DevChanOut { int32_t *d; int32_t w, h; };
 
-constexpr int kModPoolBytes = 30720;  // LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
+#ifndef JXL_MOD_POOL_BYTES
+#define JXL_MOD_POOL_BYTES 30720
+#endif
+constexpr int kModPoolBytes = JXL_MOD_POOL_BYTES;  // LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
 struct DevTrList { DevTr t[4]; int32_t n; };

@@ -78,7 +78,7 @@ struct DevFrame {
   // LDS image of the pass's code for k_pass_frame (one workgroup per frame, all its lanes share the tables): context map (all presets),
   // hybrid-uint configs, 4-byte alias entries (cutoff | right << 8 | offsets1 << 16) and one frequency table per cluster
   struct HfLds { uint32_t off, bytes, cfg_off, alias_off, d_off; int32_t d_shift; } hf_lds[4];      // bytes == 0: the image does not fit (fallback kernels)
-  uint32_t order_off[4][13][3];    // u16/u32 orders: offset of u32 array in blob
+  uint32_t order_off[4][13][3];    // u32 order arrays: offset in the frame blob, or kOrderInStatic | offset in the static tables (order_ptr)
   // sections
   uint32_t cs_size;                // bytes of the codestream buffer (device copy carries >= 64 B of zero padding)
   uint32_t sec_off;                // DevSection[nsec]: [0]=LfGlobal, 1..=LfGroup, then HfGlobal, then PassGroups
@@ -121,7 +121,9 @@ struct DevStatic {
   uint32_t afv_off;            // float[16*16]
   uint32_t dither_off;         // float[32*32]
   uint32_t llf_off;            // float[6][32]: 1/(cos t cos 2t cos 4t), t = k pi/(16 N), N = 1<<i
+  uint32_t nat_order_off[13];  // u32[covered cells * 64]: the natural coefficient order of each order bucket (frames without a coded permutation)
 };
+constexpr uint32_t kOrderInStatic = 0x80000000u;   // DevFrame::order_off: the order lives in the static tables (natural order), not in the frame blob
 
 // device error flags (bit set by kernels, checked by host after the frame)
 enum : uint32_t {

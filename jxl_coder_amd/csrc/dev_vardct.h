@@ -38,11 +38,17 @@ struct DevBuffers {
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
   int32_t out_bits;             // 8 or 16 (used by the batched writer)
+  const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
 };
 
 constexpr int kLfScratchInts = 6 * 65536 + 2048 + 16;   // LF ints (3 planes) + CfL maps + block info + sharpness + [last] extra_precision
 
 JXL_DEV const DevFrame &frame_of(const DevBuffers &B) { return *(const DevFrame *)B.tables; }
+// coefficient order of (pass, order bucket, channel): coded permutations sit in the frame blob, natural orders in the static tables
+JXL_DEV const uint32_t *order_ptr(const DevBuffers &B, const DevFrame &F, int pass, int o, int c) {
+  const uint32_t off = F.order_off[pass][o][c];
+  return (off & kOrderInStatic) ? (const uint32_t *)(B.stat + (off & ~kOrderInStatic)) : (const uint32_t *)(B.tables + off);
+}
 JXL_DEV int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
 
 // ------------------------------------------------------------------ LfGroup (serial phases run by lane 0)
@@ -263,7 +269,7 @@ JXL_DEV void pass_phase_stage(const DevBuffers &B, DevPassScratch &S, int tid, i
   for (int i = tid; i < 64; i += nthreads) { S.freq_ctx[i] = kCoeffFreqContext[i]; S.nnz_ctx[i] = kCoeffNumNonzeroContext[i]; }
   for (int i = tid; i < 2 * 3 * 64; i += nthreads) {
     const int o = i / 192, c = (i / 64) % 3, k = i & 63;
-    S.order8[o][c][k] = ((const uint32_t *)(B.tables + F.order_off[S.pass][o][c]))[k];
+    S.order8[o][c][k] = order_ptr(B, F, S.pass, o, c)[k];
   }
   { uint8_t *nzflat = &S.nz[0][0]; for (int i = tid; i < 3 * 32 * 32; i += nthreads) nzflat[i] = 0; }
 }
@@ -353,7 +359,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
         for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
         const int histo = F.num_bctx * 37 + 458 * bctx;
-        const uint32_t *order = ord < 2 ? S.order8[ord][c] : (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+        const uint32_t *order = ord < 2 ? S.order8[ord][c] : order_ptr(B, F, pass, ord, c);
         int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
         int prev = nzeros > size / 16 ? 0 : 1;
         for (int k = covered; k < size && nzeros != 0; k++) {
@@ -448,7 +454,7 @@ JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, 
           const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
           for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
           const int histo = F.num_bctx * 37 + 458 * bctx;
-          const uint32_t *order = (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+          const uint32_t *order = order_ptr(B, F, pass, ord, c);
           int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
           int prev = nzeros > size / 16 ? 0 : 1;
           for (int k = covered; k < size && nzeros != 0; k++) {
@@ -576,7 +582,7 @@ JXL_DEV void simt2_stage(const DevBuffers &B, SimtPassLds &L, int pass, int tid,
   for (int i = tid; i < 64; i += nthreads) { L.freq_ctx[i] = kCoeffFreqContext[i]; L.nnz_ctx[i] = kCoeffNumNonzeroContext[i]; }
   for (int i = tid; i < 2 * 3 * 64; i += nthreads) {
     const int o = i / 192, c = (i / 64) % 3, k = i & 63;
-    L.order8[o][c][k] = ((const uint32_t *)(B.tables + F.order_off[pass][o][c]))[k];
+    L.order8[o][c][k] = order_ptr(B, F, pass, o, c)[k];
   }
 }
 JXL_DEV uint32_t pass_group_lane2(const DevBuffers &B, SimtPassLds &L, int pass, uint8_t *nz, int g, int lane) {
@@ -643,7 +649,7 @@ JXL_DEV uint32_t pass_group_lane2(const DevBuffers &B, SimtPassLds &L, int pass,
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
         for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
         const int histo = F.num_bctx * 37 + 458 * bctx;
-        const uint32_t *order = ord < 2 ? L.order8[ord][c] : (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+        const uint32_t *order = ord < 2 ? L.order8[ord][c] : order_ptr(B, F, pass, ord, c);
         int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
         int prev = nzeros > size / 16 ? 0 : 1;
         uint32_t o_cur = order[covered < size ? covered : 0];          // the order entry one symbol ahead of its use
@@ -755,7 +761,7 @@ JXL_DEV uint32_t pass_group_lane_lds(const DevBuffers &B, const uint8_t *lds_img
           const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
           for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
           const int histo = F.num_bctx * 37 + 458 * bctx;
-          const uint32_t *order = (const uint32_t *)(B.tables + F.order_off[pass][ord][c]);
+          const uint32_t *order = order_ptr(B, F, pass, ord, c);
           int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
           int prev = nzeros > size / 16 ? 0 : 1;
           for (int k = covered; k < size && nzeros != 0; k++) {

@@ -152,16 +152,18 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
     uint32_t used = hx_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
     hx_ec oc; int have_oc = 0;
     if (used) { if (hx_ec_read_header(&oc, br, 8)) { plan->error = "bad coefficient-order code"; return -1; } hx_ec_begin(&oc, br, 0); have_oc = 1; }
+    const std::vector<uint8_t> &stat = static_tables();
+    const DevStatic &ST = *(const DevStatic *)stat.data();
     for (int o = 0; o < 13; o++) {
+      // natural orders live in the static tables (1.5 MB for the 13 buckets: not rebuilt and uploaded with every frame)
+      if (!(used & (1u << o))) { for (int c = 0; c < 3; c++) F.order_off[p][o][c] = kOrderInStatic | ST.nat_order_off[o]; continue; }
       int st = kOrderStrategy[o];
       uint32_t size = (uint32_t)kCoveredX[st] * kCoveredY[st] * 64;
-      std::vector<uint32_t> nat(size), ord(size), perm(size);
-      natural_order(st, nat.data());
+      const uint32_t *nat = (const uint32_t *)(stat.data() + ST.nat_order_off[o]);
+      std::vector<uint32_t> ord(size), perm(size);
       for (int c = 0; c < 3; c++) {
-        if (used & (1u << o)) {
-          if (hx_read_permutation(&oc, br, perm.data(), size, size / 64)) { hx_ec_free(&oc); plan->error = "bad coefficient order"; return -1; }
-          for (uint32_t i = 0; i < size; i++) ord[i] = nat[perm[i]];
-        } else ord = nat;
+        if (hx_read_permutation(&oc, br, perm.data(), size, size / 64)) { hx_ec_free(&oc); plan->error = "bad coefficient order"; return -1; }
+        for (uint32_t i = 0; i < size; i++) ord[i] = nat[perm[i]];
         F.order_off[p][o][c] = blob.append(ord.data(), (size_t)size * 4);
       }
     }
@@ -546,6 +548,12 @@ static void build_static_tables(std::vector<uint8_t> &tab) {
   { float l[6 * 32]; memset(l, 0, sizeof(l));
     for (int i = 0; i < 6; i++) { int N = 1 << i; for (int k = 0; k < N; k++) { double t = k * PI / (16.0 * N); l[i * 32 + k] = (float)(1.0 / (cos(t) * cos(2 * t) * cos(4 * t))); } }
     ST.llf_off = blob.append(l, sizeof(l)); }
+  for (int o = 0; o < 13; o++) {
+    const int st = kOrderStrategy[o];
+    std::vector<uint32_t> nat((size_t)kCoveredX[st] * kCoveredY[st] * 64);
+    natural_order(st, nat.data());
+    ST.nat_order_off[o] = blob.append(nat.data(), nat.size() * 4);
+  }
   memcpy(v.data(), &ST, sizeof(ST));
   tab.swap(v);
 }

@@ -40,6 +40,14 @@ struct FramePlan {
   std::string error;
   // internal parse state kept between phase 1 and 2 (single-section frames)
   std::shared_ptr<void> priv;
+  // ready for the next parse; keeps the capacity of the byte vectors (a flight re-parses hundreds of frames per second per context:
+  // fresh megabyte-sized allocations go through mmap / page faults, which serialise the parsing threads of all contexts)
+  void reset() {
+    std::vector<uint8_t> t; t.swap(tables); t.clear();
+    std::vector<uint8_t> c; c.swap(cs_owned); c.clear();
+    *this = FramePlan();
+    tables.swap(t); cs_owned.swap(c);
+  }
 };
 
 // Phase 1: everything up to and including LfGlobal; for multi-section frames also HfGlobal (phase 2 implicit).

@@ -28,6 +28,12 @@ inline void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nfr
   if (parts & 2) launch_filters_batch(Bs, stat, nframes, max_w, max_h, stage_mask, s);
 }
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
+// flight plumbing: the compressed bytes of all (device-resident) frames of a flight into the flight's padded stream buffer in ONE launch,
+// and the flag / counter words of all frames into one array for ONE device-to-host copy (instead of ~5 stream operations per frame)
+struct GatherDesc { const uint8_t *src; uint8_t *dst; uint32_t size, pad; };
+void launch_gather_streams(const GatherDesc *descs, int n, uint32_t max_bytes, hipStream_t s);
+constexpr int kFlagWords = 20;
+void launch_gather_flags(const DevBuffers *Bs, int n, uint32_t *out, hipStream_t s);
 void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);
 void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);

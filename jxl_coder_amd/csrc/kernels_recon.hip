@@ -277,6 +277,29 @@ __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
   if (i + 16 <= ncell) { uint4 z = {0, 0, 0, 0}; *(uint4 *)(first + i) = z; }       // cell arrays are 256-byte aligned allocations
   else for (int k = i; k < ncell; k++) first[k] = 0;
 }
+__global__ void __launch_bounds__(256) k_gather_streams(const GatherDesc *descs) {
+  const GatherDesc g = descs[blockIdx.y];
+  const uint32_t words = (g.size + g.pad + 3) / 4;            // dst is 256-byte aligned; bytes beyond `size` are written as zeros (the bit reader's padding)
+  const bool aligned = ((uintptr_t)g.src & 3) == 0;
+  for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
+    const uint32_t base = w * 4;
+    uint32_t v = 0;
+    if (aligned && base + 4 <= g.size) v = ((const uint32_t *)g.src)[w];
+    else for (uint32_t b = 0; b < 4; b++) if (base + b < g.size) v |= (uint32_t)g.src[base + b] << (8 * b);
+    ((uint32_t *)g.dst)[w] = v;
+  }
+}
+void launch_gather_streams(const GatherDesc *descs, int n, uint32_t max_bytes, hipStream_t s) {
+  const uint32_t words = (max_bytes + 64 + 3) / 4;
+  hipLaunchKernelGGL(k_gather_streams, dim3(std::min<uint32_t>((words + 1023) / 1024, 256u), n), dim3(256), 0, s, descs);
+}
+__global__ void __launch_bounds__(256) k_gather_flags(const DevBuffers *Bs, int n, uint32_t *out) {
+  const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (i < n * kFlagWords) out[i] = Bs[i / kFlagWords].err[i % kFlagWords];
+}
+void launch_gather_flags(const DevBuffers *Bs, int n, uint32_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_flags, dim3((n * kFlagWords + 255) / 256), dim3(256), 0, s, Bs, n, out);
+}
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
   hipLaunchKernelGGL(k_clear_b, dim3((max_cells + 4095) / 4096 + 1, 1, nframes), dim3(256), 0, s, Bs);
 }

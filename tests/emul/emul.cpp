@@ -41,7 +41,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   uint32_t err = 0;
   std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
   DevBuffers B; memset(&B, 0, sizeof(B));
-  B.codestream = cs.data(); B.tables = tables.data();
+  B.codestream = cs.data(); B.tables = tables.data(); B.stat = static_tables().data();
   memset(c8[0].data(), 0xFF, ncell);
   B.strategy = c8[0].data(); B.first = c8[1].data(); B.qfm1 = c8[2].data(); B.sharp = c8[3].data(); B.lf_idx = c8[4].data();
   B.xfromy = tl[0].data(); B.bfromy = tl[1].data();

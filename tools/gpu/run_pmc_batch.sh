@@ -6,7 +6,10 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc_batch; mkdir -p $O
 cd /tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES" "FETCH_SIZE" "WRITE_SIZE")
+# PMC_SETS="a b;c d": other counter sets, one pass each (e.g. the cache-request counters)
+if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; fi
+for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-30)
   rm -rf /tmp/pmcb
   PYTHONPATH=$R timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb -o p -- python $R/bench.py --no-cpu-baseline --steps 1 --batch 128 --inflight 128 --contexts 1 --warmup 0 > /tmp/pmcb.log 2>&1
