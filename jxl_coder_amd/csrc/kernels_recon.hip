@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
   }
 }
 template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
