@@ -526,8 +526,18 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, stream);
-  else launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, stream);
+  // JXLAMD_ENTROPY_STREAM=1: the latency-bound entropy kernels go to a second, high-priority stream of this context (their workgroups
+  // are dispatched ahead of the data-parallel kernels of the other contexts); cross-stream order by events
+  hipStream_t se = stream_e ? stream_e : stream;
+  const auto hop = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after everything queued on `from`
+    if (from == to) return hipSuccess;
+    hipError_t e = hipEventRecord(ev_x, from);
+    return e != hipSuccess ? e : hipStreamWaitEvent(to, ev_x, 0);
+  };
+  HIPCHECK(hop(stream, se));
+  if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, se);
+  else launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, se);
+  HIPCHECK(hop(se, stream));
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
@@ -538,7 +548,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     // the shorter critical path
     if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
     else if (all_simt2 && n_pg >= simt_min_groups) launch_pass_groups_simt2(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
-    else if (n_pg >= simt_min_groups) launch_pass_groups_simt(dB + k0, map, n_pg, stream);
+    else if (n_pg >= simt_min_groups) { HIPCHECK(hop(stream, se)); launch_pass_groups_simt(dB + k0, map, n_pg, se); HIPCHECK(hop(se, stream)); }
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
@@ -589,6 +599,13 @@ jxlamd_decoder *jxlamd_decoder_create(int device) {
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
     g_tls_error = "cannot open HIP device"; delete d; return nullptr;
   }
+  if (getenv("JXLAMD_ENTROPY_STREAM") && atoi(getenv("JXLAMD_ENTROPY_STREAM"))) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
+    const int mode = atoi(getenv("JXLAMD_ENTROPY_STREAM"));    // 1: high priority, 2: same priority (second queue only), 3: low priority
+    if (hipStreamCreateWithPriority(&d->stream_e, hipStreamNonBlocking, mode == 1 ? hi : mode == 3 ? lo : 0) != hipSuccess) d->stream_e = nullptr;
+    (void)hipEventCreateWithFlags(&d->ev_x, hipEventDisableTiming);
+  }
   for (auto &e : d->ev) (void)hipEventCreate(&e);
   return d;
 }
@@ -600,6 +617,8 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->resample_tmp.release(); d->icc_lut.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
   for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
   for (auto &e : d->ev) (void)hipEventDestroy(e);
+  if (d->stream_e) { (void)hipStreamSynchronize(d->stream_e); (void)hipStreamDestroy(d->stream_e); }
+  if (d->ev_x) (void)hipEventDestroy(d->ev_x);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }

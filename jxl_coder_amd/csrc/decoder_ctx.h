@@ -104,6 +104,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_e = nullptr; hipEvent_t ev_x = nullptr;   // optional second stream for the entropy kernels of a flight (JXLAMD_ENTROPY_STREAM)
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch, resample_tmp, icc_lut;

@@ -512,6 +512,105 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
   ring_close(rb, b);
 }
 
+// A channel whose reachable leaves all carry the same cluster, the zero predictor, multiplier 1 and offset 0: no tree walk, no
+// neighbourhood — the rANS chain alone (libjxl's EPF-sharpness channel, 86 % of the samples of an HF-metadata stream: its contexts differ
+// only by N > 3 / W > 3 and share one cluster when the encoder left the map flat).  When that cluster's histogram holds a single
+// symbol (frequency 4096) below the hybrid-uint split, the state never changes and no bit is read: the channel is a constant.
+template <bool kLds>
+__device__ __forceinline__ void wave_decode_channel_uniform(const DevECView &ev, DevBits &b, uint32_t &state, DevModScratch &S, const DevChanOut c, int lane, uint32_t cluster) {
+  const int la = ev.log_alpha, lb = 12 - la;
+  const DevAlias *tab = (kLds ? (const DevAlias *)S.pool : ev.alias) + ((size_t)cluster << la);
+  const uint32_t cfg = kLds ? S.cfg[cluster] : ev.cfg[cluster];
+  const uint32_t split_exp = cfg & 0xff, msb = (cfg >> 8) & 0xff, lsb = (cfg >> 16) & 0xff;
+  const size_t n = (size_t)c.w * (size_t)c.h;
+  {
+    const DevAlias e0 = tab[0];
+    const bool r0 = 0 >= e0.cutoff;
+    const uint32_t sym0 = r0 ? e0.right : 0u, f0 = r0 ? e0.freq1 : e0.freq0;
+    if (f0 == 4096u && sym0 < (1u << split_exp)) {
+      const int32_t v = unpack_signed(sym0);
+      for (size_t i = (size_t)lane; i < n; i += 64) c.d[i] = v;
+      return;
+    }
+  }
+  int32_t keep = 0;
+  for (size_t i0 = 0; i0 < n; i0 += 64) {
+    const int m = n - i0 < 64 ? (int)(n - i0) : 64;
+    #pragma unroll 1
+    for (int i = 0; i < m; i++) {
+      const uint32_t res = state & 0xfff, bi = res >> lb, pos = res & ((1u << lb) - 1);
+      const DevAlias e = tab[bi];
+      const bool right = pos >= e.cutoff;
+      uint32_t u = right ? e.right : bi;
+      state = (right ? e.freq1 : e.freq0) * (state >> 12) + (right ? (uint32_t)e.off1 + pos : pos);
+      if (__ballot(state < (1u << 16))) state = (state << 16) | ubits_read(b, 16);
+      if (__ballot(u >= (1u << split_exp))) {
+        uint32_t nbits = split_exp - (msb + lsb) + ((u - (1u << split_exp)) >> (msb + lsb));
+        if (nbits > 31) nbits = 31;           // corrupt stream; the final-state check flags it
+        const uint32_t low = u & ((1u << lsb) - 1), tok = u >> lsb;
+        const uint32_t bits = ubits_read(b, (int)nbits);
+        u = (((((1u << msb) | (tok & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+      }
+      keep = shift_in_wave1(unpack_signed(u), keep);
+    }
+    if (lane < m) c.d[i0 + (size_t)(m - 1 - lane)] = keep;     // after m steps lane l holds sample i0 + m - 1 - l: one coalesced store
+  }
+}
+
+// "Lean" lock-step loop for the channels of libjxl's HF-metadata streams whose tree only looks at y, x, N, W (properties 2..7) and whose
+// leaves predict with zero, W or N: the general loop's seven-sample neighbourhood window, its sixteen-property sum and the predictor
+// switch shrink to two multiply-adds, the two tree ballots and a select.  Results leave through a lane shift register (one coalesced
+// store per 64 samples); a row buffer in LDS is only kept when N is needed, which also makes channels wider than the LDS rows (the
+// block-info channel: thousands of samples x 2 rows, W and y only) eligible.
+template <bool kLds>
+__device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, DevBits &b, uint32_t &state, DevModScratch &S, DevWaveTree &WT,
+                                                         const DevChanOut c, int lane, bool needs_n) {
+  const int w = c.w, h = c.h;
+  const int ni = WT.ni, nl = WT.nl;
+  const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
+  const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+  const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+  const int my_lctx = lane < nl ? WT.leaf_ctx[lane] : 0, my_lpred = lane < nl ? WT.leaf_pred[lane] : 0;
+  const int my_loff = lane < nl ? WT.leaf_off[lane] : 0, my_lmul = lane < nl ? WT.leaf_mul[lane] : 1;
+  const int my_lclu = (kLds && lane < nl) ? (int)((const uint8_t *)S.pool)[S.ctx_off + my_lctx] : 0;
+  const int cY = my_prop == 2, cX = my_prop == 3, cN = (my_prop == 4 || my_prop == 6), cW = (my_prop == 5 || my_prop == 7);
+  const bool cAbs = my_prop == 4 || my_prop == 5;
+  __syncthreads();
+  for (int y = 0; y < h; y++) {
+    int32_t *out = c.d + (size_t)y * (size_t)w;
+    int32_t *row = S.rows[y & 1];
+    const int32_t *rN = S.rows[(y + 1) & 1];
+    int32_t vW = 0, keep = 0;
+    int32_t vN = y > 0 ? (needs_n ? rN[0] : out[-(ptrdiff_t)w]) : 0;      // the sample above x = 0 stands in for W there (needed even when no property reads N)
+    for (int x0 = 0; x0 < w; x0 += 64) {
+      const int m = w - x0 < 64 ? w - x0 : 64;
+      #pragma unroll 1
+      for (int i = 0; i < m; i++) {
+        const int x = x0 + i;
+        const int32_t W_ = x > 0 ? vW : vN;                       // x == 0: the sample above (0 in the first row)
+        const int32_t N_ = y > 0 ? vN : W_;
+        const int32_t nextN = (needs_n && y > 0 && x + 1 < w) ? rN[x + 1] : 0;
+        int32_t myv = __mul24(cN, N_) + __mul24(cW, W_) + __mul24(cX, x) + __mul24(cY, y);
+        if (cAbs) myv = myv < 0 ? -myv : myv;
+        const uint64_t dec = __ballot(lane < ni && myv > my_split);
+        const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
+        const int leaf = lm ? __builtin_ctzll(lm) : 0;
+        const int l_pred = __builtin_amdgcn_readlane(my_lpred, leaf), l_off = __builtin_amdgcn_readlane(my_loff, leaf);
+        const int l_mul = __builtin_amdgcn_readlane(my_lmul, leaf);
+        const int l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf), l_clu = __builtin_amdgcn_readlane(my_lclu, leaf);
+        const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
+        const int32_t res = unpack_signed(u);
+        const int32_t guess = l_pred == 0 ? 0 : l_pred == 1 ? W_ : N_;
+        const int32_t val = (l_mul == 1 ? res : res * l_mul) + l_off + guess;
+        keep = shift_in_wave1(val, keep);
+        vW = val; vN = nextN;
+      }
+      if (lane < m) { const int32_t v = keep; out[x0 + m - 1 - lane] = v; if (needs_n) row[x0 + m - 1 - lane] = v; }
+    }
+    __syncthreads();        // the row written above is the next row's N
+  }
+}
+
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 template <bool kLds>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
@@ -563,6 +662,28 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       if (!pool_packed) pool_packed = wave_pack_alias(evg.alias, S.st.num_clusters, ev.log_alpha, S, lane);
       if (pool_packed) { wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1); continue; }
       return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
+    }
+    // uniform-leaf channel (see wave_decode_channel_uniform)
+    if (!ev.use_prefix && WT.nl >= 1 && WT.nl <= 64) {
+      const int nl = WT.nl;
+      const int my_clu = lane < nl ? (int)evg.ctx_map[WT.leaf_ctx[lane]] : -1;
+      const int clu0 = __builtin_amdgcn_readfirstlane(my_clu);
+      if (__ballot(lane < nl && (my_clu != clu0 || WT.leaf_pred[lane] != 0 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
+        if (kLds && !pool_packed) wave_decode_channel_uniform<true>(ev, b, state, S, c, lane, (uint32_t)clu0);
+        else wave_decode_channel_uniform<false>(evg, b, state, S, c, lane, (uint32_t)clu0);
+        continue;
+      }
+    }
+    // lean loop (see wave_decode_channel_lean): y / x / N / W properties only, zero / W / N predictors
+    if (m16 && !ev.use_prefix && !uses_wp && WT.ni >= 1 && WT.ni <= 64 && WT.nl <= 64) {
+      const bool props_ok = __ballot(lane < WT.ni && (WT.int_prop[lane] < 2 || WT.int_prop[lane] > 7)) == 0;
+      const bool preds_ok = __ballot(lane < WT.nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 2)) == 0;
+      const bool needs_n = __ballot((lane < WT.ni && (WT.int_prop[lane] == 4 || WT.int_prop[lane] == 6)) || (lane < WT.nl && WT.leaf_pred[lane] == 2)) != 0;
+      if (props_ok && preds_ok && (!needs_n || c.w <= kModMaxW)) {
+        if (kLds && !pool_packed) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n);
+        else wave_decode_channel_lean<false>(evg, b, state, S, WT, c, lane, needs_n);
+        continue;
+      }
     }
     if (pool_packed) {            // the pool no longer holds this stream's 8-byte alias tables / context map
       if (m16) { if (uses_wp) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane); else wave_decode_channel<false, true, false>(evg, b, state, wp, S, WT, c, lane); }

@@ -258,7 +258,32 @@ def test_alternative_kernels_keep_parity():
             assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
         print("alternatives ok")
     """) % (ROOT, ROOT + "/tests")
-    for env in ({"JXLAMD_FUSED_FILTERS": "1"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"},
-                {"JXLAMD_SIMT_LF_MIN": "1"}):
+    # ... and the paths the defaults replaced: per-stage filter kernels instead of the column sweep (JXLAMD_FILTER_SWEEP=0; also what frames
+    # with three EPF iterations use), VALU DCT32 passes (JXLAMD_DCT32_MFMA=0), the entropy kernels on a second stream (JXLAMD_ENTROPY_STREAM=1)
+    for env in ({"JXLAMD_FUSED_FILTERS": "1", "JXLAMD_FILTER_SWEEP": "0"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"},
+                {"JXLAMD_SIMT_LF_MIN": "1"}, {"JXLAMD_FILTER_SWEEP": "0", "JXLAMD_DCT32_MFMA": "0"}, {"JXLAMD_ENTROPY_STREAM": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
+
+
+def test_flight_of_host_buffers_of_mixed_sizes(dec):
+    """A flight whose frames arrive as HOST buffers (one staging upload for all of them) and change from call to call (slots see frames of
+    different sizes): same pixels as the single decodes, and as the same flight with device-resident inputs (gather launch)."""
+    import torch
+    names = ["v264x520_e7", "v64_e3_gab0_epf0", "va300x520_e7", "v267x131_e7", "v256_e7", "v300x300_e7_d3", "v520x264_e7"]
+    names = [n for n in names if os.path.exists(os.path.join(ROOT, "tests", "golden", n + ".jxl"))]
+    datas = [load_case(n)[0] for n in names]
+    singles = [dec.decode_one_shot(d)[0] for d in datas]
+    for order in (list(range(len(datas))), list(reversed(range(len(datas)))), [2, 0, 1]):
+        ds = [datas[i] for i in order]
+        outs = [torch.zeros(singles[i].size, dtype=torch.uint8, device="cuda") for i in order]
+        dec.decode_batch_to_device(ds, [o.data_ptr() for o in outs], [o.numel() for o in outs])          # host-resident inputs
+        torch.cuda.synchronize()
+        for i, o in zip(order, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(singles[i].shape), singles[i])
+        d_in = [torch.frombuffer(bytearray(b"\x00" * 3 + d), dtype=torch.uint8).cuda()[3:] for d in ds]  # resident, deliberately unaligned
+        outs2 = [torch.zeros(singles[i].size, dtype=torch.uint8, device="cuda") for i in order]
+        dec.decode_batch_to_device(ds, [o.data_ptr() for o in outs2], [o.numel() for o in outs2], [t.data_ptr() for t in d_in])
+        torch.cuda.synchronize()
+        for i, o in zip(order, outs2):
+            assert np.array_equal(o.cpu().numpy().reshape(singles[i].shape), singles[i])
