@@ -123,6 +123,22 @@ JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int
   ch[3].d = m_sharp; ch[3].w = q.bw; ch[3].h = q.bh;
   return lf_decode_stream<kWave>(S, ch, 4, 1 + 2 * F.num_lf_groups + g, tid);
 }
+#ifdef __HIPCC__
+// lanes 0 .. n-1 hold list entries (class << 28 | cell): one atomicAdd per class reserves the slots, the lanes store
+__device__ __forceinline__ void place_flush_lists(const DevBuffers &B, int pend, int n, int tid) {
+  const int lane = tid & 63;
+  const bool have = lane < n;
+  const int cls = (int)((uint32_t)pend >> 28);
+  for (int c = 0; c < 3; c++) {
+    const uint64_t mask = __ballot(have && cls == c);
+    if (!mask) continue;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&B.big_count[c], (uint32_t)__builtin_popcountll(mask));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (have && cls == c) B.big_list[c][base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (uint32_t)pend & 0x0fffffffu;
+  }
+}
+#endif
 // phase 3b (all lanes in lock-step): place the varblocks.  The raster scan over the occupancy bitmap is serial by definition
 // (a block goes to the first cell still free) and every lane walks it identically; what the lanes share out is the
 // per-cell bookkeeping of each block (up to 64 covered cells x 3 byte planes).  Lane 0 owns the bitmap and the lists;
@@ -147,6 +163,11 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
   for (int i = tid; i < 256 * 8; i += nthreads) occ[i] = 0;
   sync();
   int num = 0;
+#ifdef __HIPCC__
+  // block records 64 at a time (lane l holds record pf_base + l): the serial loop used to wait for two dependent global loads per block
+  int pf_base = -64, pf_st = 0, pf_q = 0;
+  int pend = 0, npend = 0;
+#endif
   for (int y = 0; y < bh; y++) {
     for (int wx = 0; wx < (bw + 31) / 32; wx++) {
       for (;;) {
@@ -155,7 +176,17 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
         if (!freebits) break;
         const int x = wx * 32 + __builtin_ctz(freebits);
         if (num >= count) return kErrBitstream;
+#ifdef __HIPCC__
+        if (num - pf_base >= 64) {
+          pf_base = num;
+          const int idx = num + (tid & 63);
+          pf_st = idx < count ? m_blk[idx] : 0; pf_q = idx < count ? m_blk[count + idx] : 0;
+        }
+        const int pl = __builtin_amdgcn_readfirstlane(num - pf_base);
+        const int st = __builtin_amdgcn_readlane(pf_st, pl), q = __builtin_amdgcn_readlane(pf_q, pl);
+#else
         const int st = m_blk[num], q = m_blk[count + num];
+#endif
         num++;
         if (st < 0 || st > 26 || q < 0 || q > 255) return kErrBitstream;
         const int cx = kCoveredX[st], cy = kCoveredY[st];
@@ -175,18 +206,27 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
           B.strategy[oo] = (uint8_t)st; B.first[oo] = (uint8_t)(c == 0); B.qfm1[oo] = (uint8_t)q;
         }
         const int ncoef = cx * cy * 64;
+#ifdef __HIPCC__
+        // size-class lists (the reconstruction kernels walk them): entries collect in a lane shift register and reach the lists 64 at a
+        // time with one atomic per class — an atomic with return per block was the serial loop's longest wait (1.2 us per block)
+        if (ncoef <= 4096) {
+          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
+          pend = __builtin_amdgcn_update_dpp((int)(((uint32_t)cls << 28) | (uint32_t)o), pend, 0x138, 0xF, 0xF, false);   // lane l: the entry of l blocks ago
+          if (++npend == 64) { place_flush_lists(B, pend, npend, tid); npend = 0; }
+        }
+#else
         if (tid == 0 && ncoef <= 4096) {         // size-class lists: the reconstruction kernels walk them
           const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
-#ifdef __HIPCC__
-          const uint32_t slot = atomicAdd(&B.big_count[cls], 1u);
-#else
           const uint32_t slot = B.big_count[cls]++;
-#endif
           B.big_list[cls][slot] = (uint32_t)o;
         }
+#endif
       }
     }
   }
+#ifdef __HIPCC__
+  place_flush_lists(B, pend, npend, tid);
+#endif
   return 0;
 }
 

@@ -184,8 +184,7 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
 }
 
 template <int NMIN, int NMAX>
-__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma) {
-  __shared__ __attribute__((aligned(16))) ReconLds<NMAX> L;
+__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma, ReconLds<NMAX> &L) {
   const int tid = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
   const DevFrame &F = frame_of(B);
@@ -243,22 +242,32 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
+// also_large (medium instantiation only): the same workgroups walk the list of 2048 / 4096-coefficient blocks afterwards.  Flights whose
+// previous flight had no such block use this instead of a separate (almost always empty) launch of the large instantiation, whose
+// workgroups waited for 32 KB of LDS behind resident LF waves — 3.6 % of the bench's kernel time for nothing.
 template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma, int also_large) {
+  constexpr size_t kLds = sizeof(ReconLds<1024>) > sizeof(ReconLds<4096>) ? sizeof(ReconLds<1024>) : sizeof(ReconLds<4096>);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NMAX == 1024 ? kLds : sizeof(ReconLds<NMAX>)];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
-  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0);
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0, *(ReconLds<NMAX> *)smem);
+  if (NMAX == 1024 && also_large) {
+    __syncthreads();
+    recon_list_walk<1025, 4096>(B, stat, 1, F.xb, false, *(ReconLds<4096> *)smem);
+  }
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0, use_mfma);
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
+  if (!expect_large) return;
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1, 0);
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(gl, 1, nframes), dim3(256), 0, s, Bs, stat, 1, 0, 0);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {

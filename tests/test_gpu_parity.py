@@ -287,3 +287,19 @@ def test_flight_of_host_buffers_of_mixed_sizes(dec):
         torch.cuda.synchronize()
         for i, o in zip(order, outs2):
             assert np.array_equal(o.cpu().numpy().reshape(singles[i].shape), singles[i])
+
+
+def test_large_varblocks_after_flights_without_any(dec):
+    """A context whose previous flight met no 2048 / 4096-coefficient varblock lets the medium reconstruction kernel walk that list too
+    (no separate launch): a following flight that does contain such blocks must still match the single decodes."""
+    import torch
+    small = [load_case(n)[0] for n in ("v256_e7", "v264x520_e7", "v267x131_e7")]
+    big_names = [n for n in ("v300x300_e7_d3", "vb264x4200_e7_epf3", "vb520x4400_e7", "v520x264_e7") if os.path.exists(os.path.join(ROOT, "tests", "golden", n + ".jxl"))]
+    big = [open(os.path.join(ROOT, "tests", "golden", n + ".jxl"), "rb").read() for n in big_names]     # some of these only carry row sums as fixtures
+    singles = [dec.decode_one_shot(d)[0] for d in small + big]
+    for datas, ref in ((small, singles[:3]), (small, singles[:3]), (small + big, singles), (big + small, singles[3:] + singles[:3])):
+        outs = [torch.zeros(r.size, dtype=torch.uint8, device="cuda") for r in ref]
+        dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for r, o in zip(ref, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(r.shape), r)
