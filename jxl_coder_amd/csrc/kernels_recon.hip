@@ -263,7 +263,9 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
+  // JXLAMD_RECON_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 32 KB — an occupancy experiment knob, no functional effect
+  static const unsigned extra_lds = getenv("JXLAMD_RECON_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_RECON_EXTRA_LDS")) : 0u;
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
   if (!expect_large) return;
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
