@@ -183,6 +183,45 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
   }
 }
 
+// DCT64x64 on the matrix cores, one channel at a time (S and T hold 4096 coefficients each): wave w owns the 32x32 output tile
+// (w >> 1, w & 1) of both 64x64x64 products, 32 v_mfma_f32_32x32x2_f32 each; the 64-point cosine table is read from the static tables
+// (L2-resident).  Same operand maps as recon_dct32_mfma.
+constexpr int kStrategyDct64 = 18;
+__device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const float *cc = st_f(stat, ST.cos_off[6]);
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int t0 = (wave >> 1) * 32, t1 = (wave & 1) * 32;
+  for (int c = 0; c < 3; c++) {
+    recon_phaseA(B, stat, ST, S, 4096, bx, by, tid, 256, c);
+    __syncthreads();
+    recon_phaseB(B, stat, ST, S, 4096, bx, by, tid, 256, c);
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll 8
+    for (int st = 0; st < 32; st++) {
+      const int u = 2 * st + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[u * 64 + t0 + j], cc[u * 64 + t1 + j], acc, 0, 0, 0);      // T[v][x] = sum_u S[u][v] cc[u][x]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) T[(t0 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + t1 + j] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll 8
+    for (int st = 0; st < 32; st++) {
+      const int v = 2 * st + kh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cc[v * 64 + t0 + j], T[v * 64 + t1 + j], acc, 0, 0, 0);      // out[y][x] = sum_v cc[v][y] T[v][x]
+    }
+    float *out = B.plane_a[c] + (size_t)(by * 8 + t0) * (size_t)F.pw + (size_t)(bx * 8 + t1 + j);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[(size_t)((r & 3) + 8 * (r >> 2) + 4 * kh) * (size_t)F.pw] = acc[r];
+    __syncthreads();                                 // T is rewritten by the next channel's first pass
+  }
+}
+
 template <int NMIN, int NMAX>
 __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma, ReconLds<NMAX> &L) {
   const int tid = (int)threadIdx.x;
@@ -205,6 +244,9 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
       recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
       __syncthreads();
       if (use_mfma) recon_dct32_mfma(B, L.S, L.T, L.CC, bx, by, tid); else recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
+    } else if (NMAX > 1024 && use_mfma && B.strategy[cell] == kStrategyDct64 && B.first[cell]) {
+      __syncthreads();
+      recon_dct64_mfma(B, stat, ST, L.S, L.T, bx, by, tid);
     } else {
       __syncthreads();
       recon_block_body<false, (NMAX > 1024)>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
@@ -255,7 +297,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0, *(ReconLds<NMAX> *)smem);
   if (NMAX == 1024 && also_large) {
     __syncthreads();
-    recon_list_walk<1025, 4096>(B, stat, 1, F.xb, false, *(ReconLds<4096> *)smem);
+    recon_list_walk<1025, 4096>(B, stat, 1, F.xb, use_mfma != 0, *(ReconLds<4096> *)smem);
   }
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
@@ -269,7 +311,7 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   if (!expect_large) return;
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(gl, 1, nframes), dim3(256), 0, s, Bs, stat, 1, 0, 0);
+  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(gl, 1, nframes), dim3(256), 0, s, Bs, stat, 1, use_mfma, 0);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
