@@ -151,6 +151,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
+    if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure((size_t)(1 + plan.num_groups) * (size_t)Fh->lz_win_len * 4));
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
@@ -174,6 +175,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * 3072;
   B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits; B.stat = (const uint8_t *)stat.p;
+  B.lz_win = (plan.modular && Fh->lz_win_len) ? (uint32_t *)S.lz_win.p : nullptr;
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);

@@ -78,7 +78,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
   PinnedMem h_tables, h_cs, h_B;
   DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3];
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win;
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -89,7 +89,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
   void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end};
+    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end, &lz_win};
     for (auto *m : all) m->release();
     for (auto &m : cells8) m.release();
     for (auto &m : tiles) m.release();

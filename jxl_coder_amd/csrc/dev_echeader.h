@@ -51,6 +51,7 @@ JXL_DEV DevECView local_view(const LocalEC &e) {
   DevECView v;
   v.ctx_map = e.ctx_map; v.cfg = e.cfg; v.alias = e.alias; v.prefix = e.prefix; v.pool = e.pool;
   v.use_prefix = e.use_prefix; v.log_alpha = e.log_alpha;
+  v.lz77 = 0; v.lz_min_symbol = 0; v.lz_min_length = 0; v.dist_ctx = 0; v.lz_len_cfg = 0;     // codes parsed on the device reject LZ77 (d_ec_read_header_t)
   return v;
 }
 

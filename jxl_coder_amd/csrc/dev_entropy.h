@@ -10,6 +10,7 @@
 #pragma once
 #include <stdint.h>
 #include "dev_types.h"
+#include "dev_tables.h"
 
 #ifdef __HIPCC__
 #define JXL_DEV __device__ __forceinline__
@@ -84,6 +85,7 @@ struct DevECView {            // resolved pointers for one entropy code
   const DevPrefix *prefix;
   const uint16_t *pool;
   int32_t use_prefix, log_alpha;
+  int32_t lz77, lz_min_symbol, lz_min_length, dist_ctx; uint32_t lz_len_cfg;     // LZ77 (serial walker only)
 };
 
 JXL_DEV DevECView ec_view(const uint8_t *tables, const DevEC &e) {
@@ -95,6 +97,7 @@ JXL_DEV DevECView ec_view(const uint8_t *tables, const DevEC &e) {
   v.pool = (const uint16_t *)(tables + e.pool_off);
   v.use_prefix = e.use_prefix;
   v.log_alpha = e.log_alpha;
+  v.lz77 = e.lz77; v.lz_min_symbol = e.lz_min_symbol; v.lz_min_length = e.lz_min_length; v.dist_ctx = e.num_ctx; v.lz_len_cfg = e.lz_len_cfg;
   return v;
 }
 
@@ -142,6 +145,62 @@ JXL_DEV uint32_t ec_read(const DevECView &v, DevBits &b, uint32_t &state, uint32
   uint32_t cluster = v.ctx_map[ctx];
   uint32_t token = ec_token(v, b, state, cluster);
   return ec_hybrid(b, v.cfg[cluster], token);
+}
+
+
+// ---- LZ77 (C.3.3).  Used by the serial Modular walker for codes that enable it (libjxl's low-effort lossless encoders); the window
+// holds the decoded integers of the stream, min(2^20, symbols of the stream) entries in HBM.
+JXL_CONST int8_t kLzSpecialDist[120][2] = {
+    {0, 1},  {1, 0},  {1, 1},  {-1, 1}, {0, 2},  {2, 0},  {1, 2},  {-1, 2}, {2, 1},  {-2, 1}, {2, 2},  {-2, 2},
+    {0, 3},  {3, 0},  {1, 3},  {-1, 3}, {3, 1},  {-3, 1}, {2, 3},  {-2, 3}, {3, 2},  {-3, 2}, {0, 4},  {4, 0},
+    {1, 4},  {-1, 4}, {4, 1},  {-4, 1}, {3, 3},  {-3, 3}, {2, 4},  {-2, 4}, {4, 2},  {-4, 2}, {0, 5},  {3, 4},
+    {-3, 4}, {4, 3},  {-4, 3}, {5, 0},  {1, 5},  {-1, 5}, {5, 1},  {-5, 1}, {2, 5},  {-2, 5}, {5, 2},  {-5, 2},
+    {4, 4},  {-4, 4}, {3, 5},  {-3, 5}, {5, 3},  {-5, 3}, {0, 6},  {6, 0},  {1, 6},  {-1, 6}, {6, 1},  {-6, 1},
+    {2, 6},  {-2, 6}, {6, 2},  {-6, 2}, {4, 5},  {-4, 5}, {5, 4},  {-5, 4}, {3, 6},  {-3, 6}, {6, 3},  {-6, 3},
+    {0, 7},  {7, 0},  {1, 7},  {-1, 7}, {5, 5},  {-5, 5}, {7, 1},  {-7, 1}, {4, 6},  {-4, 6}, {6, 4},  {-6, 4},
+    {2, 7},  {-2, 7}, {7, 2},  {-7, 2}, {3, 7},  {-3, 7}, {7, 3},  {-7, 3}, {5, 6},  {-5, 6}, {6, 5},  {-6, 5},
+    {8, 0},  {4, 7},  {-4, 7}, {7, 4},  {-7, 4}, {8, 1},  {8, 2},  {6, 6},  {-6, 6}, {8, 3},  {5, 7},  {-5, 7},
+    {7, 5},  {-7, 5}, {8, 4},  {6, 7},  {-6, 7}, {7, 6},  {-7, 6}, {8, 5},  {7, 7},  {-7, 7}, {8, 6},  {8, 7}};
+struct DevLz { uint32_t *win; uint32_t win_len, ncopy, pos, ndec, dist_mult, err; };
+JXL_DEV uint32_t ec_read_lz(const DevECView &v, DevBits &b, uint32_t &state, uint32_t ctx, DevLz &z) {
+  const uint32_t mask = (1u << 20) - 1;
+  for (int guard = 0; guard < 2; guard++) {
+    if (z.ncopy) {
+      const uint32_t r = z.win[(z.pos++) & mask];
+      z.ncopy--;
+      z.win[(z.ndec++) & mask] = r;
+      return r;
+    }
+    const uint32_t cluster = v.ctx_map[ctx];
+    const uint32_t token = ec_token(v, b, state, cluster);
+    if (token < (uint32_t)v.lz_min_symbol) {
+      const uint32_t r = ec_hybrid(b, v.cfg[cluster], token);
+      if (z.ndec < z.win_len) z.win[z.ndec & mask] = r;
+      z.ndec++;
+      return r;
+    }
+    uint32_t ncopy = ec_hybrid(b, v.lz_len_cfg, token - (uint32_t)v.lz_min_symbol) + (uint32_t)v.lz_min_length;
+    const uint32_t dc = v.ctx_map[v.dist_ctx];
+    const uint32_t dtok = ec_token(v, b, state, dc);
+    uint32_t distance = ec_hybrid(b, v.cfg[dc], dtok);
+    const uint32_t nspecial = z.dist_mult ? 120u : 0u;
+    if (distance < nspecial) {
+      const int d = (int)z.dist_mult * kLzSpecialDist[distance][1] + kLzSpecialDist[distance][0];
+      distance = d < 1 ? 1u : (uint32_t)d;
+    } else distance = distance + 1 - nspecial;
+    if (distance > z.ndec) distance = z.ndec;
+    if (distance > (1u << 20)) distance = 1u << 20;
+    z.pos = z.ndec - distance;
+    if (distance == 0) {                      // nothing decoded yet: the copy source reads as zeros
+      uint32_t n = ncopy < z.win_len ? ncopy : z.win_len;
+      for (uint32_t i = 0; i < n; i++) z.win[i] = 0;
+    }
+    // a copy can never run past the symbols the stream holds (the window has exactly that many entries when shorter than 2^20)
+    if (ncopy < (uint32_t)v.lz_min_length || (z.win_len < (1u << 20) && (uint64_t)z.ndec + ncopy > z.win_len)) { z.err = 1; return 0; }
+    z.ncopy = ncopy;
+  }
+  z.err = 1;
+  return 0;
 }
 
 }  // namespace jxlamd

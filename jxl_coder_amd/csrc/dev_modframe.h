@@ -55,6 +55,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
     while (skip >= 32) { bits_read(b, 32); skip -= 32; }
     bits_read(b, (int)skip);
     S.st.b = b;
+    S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win : nullptr; S.lz.win_len = F.lz_win_len;      // LZ77 window slot 0
     modular_stream_begin(B.tables, F, B.local[0], S, &S.trs);
   }
   sync();
@@ -84,6 +85,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     if (F.is_modular) bits_init(b, B.codestream, sec.off, F.cs_size);
     else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
+    S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)(1 + g) * (size_t)F.lz_win_len : nullptr; S.lz.win_len = F.lz_win_len;
     modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {
       const DevTr &t = S.trs.t[i];

@@ -67,6 +67,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   DevTrList trs;                      // transforms of the current stream header
   DevWaveTree wt;
   uint32_t fallback_err;
+  DevLz lz;                           // LZ77 state of the current stream (serial walker; window in HBM, set by the stream's caller)
 };
 
 
@@ -250,7 +251,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
           nd = idx < S.tree_ncache ? &S.tree[idx] : &gtree[idx];
         }
         int64_t guess = predict_plain(nd->lchild, W, N, NW, NE, NN, WW, NEE, wp_pred);
-        uint32_t u = ec_read(ev, b, state, (uint32_t)nd->splitval);
+        uint32_t u = ev.lz77 ? ec_read_lz(ev, b, state, (uint32_t)nd->splitval, S.lz) : ec_read(ev, b, state, (uint32_t)nd->splitval);
         int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)nd->rchild + nd->offset + guess;
         row[x] = (int32_t)val;
         if (!wide) out[x] = (int32_t)val;
@@ -312,7 +313,7 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
   if (use_global) {
     if (F.tree_count <= 0) { st.err = kErrBitstream; return; }
     st.tree = (const DevTreeNode *)(tables + F.tree_off); st.count = F.tree_count; st.ev = ec_view(tables, F.tree_ec);
-    st.num_ctx = F.tree_ec.num_ctx; st.num_clusters = F.tree_ec.num_clusters;
+    st.num_ctx = F.tree_ec.num_ctx + (F.tree_ec.lz77 ? 1 : 0); st.num_clusters = F.tree_ec.num_clusters;      // the map carries one more entry (distances) with LZ77
   } else {
     uint32_t e = d_read_local_tree(st.b, L);
     if (e) { st.err = e; return; }
@@ -375,7 +376,13 @@ JXL_DEV uint32_t modular_stream_decode(DevModScratch &S, const DevChanOut *chans
   if (!ev.use_prefix) ev.alias = S.alias;
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
+  if (ev.lz77) {
+    if (!S.lz.win) return kErrLz77;                      // no window behind this stream (LZ77 outside Modular-encoded frames)
+    S.lz.ncopy = 0; S.lz.pos = 0; S.lz.ndec = 0; S.lz.err = 0; S.lz.dist_mult = 0;
+    for (int i = 0; i < nch; i++) if ((uint32_t)chans[i].w > S.lz.dist_mult) S.lz.dist_mult = (uint32_t)chans[i].w;
+  }
   uint32_t err = modular_decode_channels(ev, b, state, st.tree, st.count, st.wp, S, chans, nch, stream_id);
+  if (ev.lz77 && S.lz.err) err |= kErrBitstream;
   if (!err && state != 0x130000u) err |= kErrAnsFinal;
   st.b = b;
   return err;

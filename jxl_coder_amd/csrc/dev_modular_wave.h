@@ -700,6 +700,11 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
 __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
   DevModStream &st = S.st;
   if (st.err) return st.err;
+  if (st.ev.lz77) {                       // LZ77 copies: the serial walker (lane 0) only
+    if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);
+    __syncthreads();
+    return S.fallback_err;
+  }
   DevECView ev = st.ev;
   ev.ctx_map = S.ctx_map;
   if (st.num_clusters <= kLocMaxClusters) ev.cfg = S.cfg;

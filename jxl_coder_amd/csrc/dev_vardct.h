@@ -38,6 +38,7 @@ struct DevBuffers {
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
   int32_t out_bits;             // 8 or 16 (used by the batched writer)
+  uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [1 + num_groups][DevFrame::lz_win_len] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
 };
 
@@ -74,6 +75,7 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   scr[kLfScratchInts - 1] = (int32_t)bits_read(b, 2);      // extra_precision
   S.st.b = b;
+  S.lz.win = nullptr;                                       // LZ77 is confined to Modular-encoded frames (the host rejects it elsewhere)
   modular_stream_begin(B.tables, F, B.local[g], S);
 }
 // one stream's channels: the whole wave on the GPU (dev_modular_wave.h), lane 0 alone in the CPU harness

@@ -44,11 +44,13 @@ struct Blob {
 static int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
 
 // pack a parsed entropy code into the device layout
-static int pack_ec(const hx_ec &ec, Blob &b, DevEC *out, std::string *err) {
-  if (ec.lz77) { *err = "unsupported: LZ77 in a group-level entropy code"; return -1; }
+static int pack_ec(const hx_ec &ec, Blob &b, DevEC *out, std::string *err, bool allow_lz77 = false) {
+  if (ec.lz77 && !allow_lz77) { *err = "unsupported: LZ77 in a group-level entropy code"; return -1; }
   memset(out, 0, sizeof(*out));
   out->num_ctx = ec.num_ctx; out->num_clusters = ec.num_clusters; out->use_prefix = ec.use_prefix; out->log_alpha = ec.log_alpha;
-  out->ctx_map_off = b.append(ec.ctx_map, (size_t)ec.num_ctx);
+  out->lz77 = ec.lz77; out->lz_min_symbol = ec.lz_min_symbol; out->lz_min_length = ec.lz_min_length;
+  out->lz_len_cfg = ec.lz_len_cfg.split_exp | (ec.lz_len_cfg.msb << 8) | (ec.lz_len_cfg.lsb << 16);
+  out->ctx_map_off = b.append(ec.ctx_map, (size_t)ec.num_ctx + (ec.lz77 ? 1u : 0u));      // + the distance context
   std::vector<uint32_t> cfg((size_t)ec.num_clusters);
   for (int i = 0; i < ec.num_clusters; i++) cfg[(size_t)i] = ec.cfg[i].split_exp | (ec.cfg[i].msb << 8) | (ec.cfg[i].lsb << 16);
   out->cfg_off = b.append(cfg.data(), cfg.size() * 4);
@@ -241,6 +243,12 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }
   F.mod_first_group_ch = first_group;
   plan->mod_pool_ints = off;
+  F.lz_win_len = 0;
+  if (F.tree_ec.lz77 && !vardct) {            // a stream never holds more integers than the image has samples; the window is 2^20 at most
+    uint64_t total = 0;
+    for (int i = 0; i < F.mod_nch; i++) total += (uint64_t)F.mod_w[i] * (uint64_t)F.mod_h[i];
+    F.lz_win_len = (uint32_t)std::min<uint64_t>(total + 64, 1u << 20);
+  }
   if (F.mod_nch - first_group > 8) { plan->error = "unsupported: more than 8 group channels"; return -1; }
   // inverse program (last transform first)
   F.mod_nops = 0;
@@ -428,7 +436,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     }
     F.tree_count = tree.count;
     F.tree_off = blob.append(nodes.data(), nodes.size() * sizeof(DevTreeNode));
-    int rc = pack_ec(tree.code, blob, &F.tree_ec, &plan->error);
+    int rc = pack_ec(tree.code, blob, &F.tree_ec, &plan->error, /*allow_lz77=*/f.encoding == 1);      // Modular-encoded frames: the serial walker copies
     hx_tree_free(&tree);
     if (rc) return -1;
   } else F.tree_count = 0;     // streaming-encoded frames: every LfGroup stream carries its own tree (parsed on the device)

@@ -48,6 +48,9 @@ CASES = {
     "l512_e7": (512, 512, dict(seed=1), dict(lossless=True, effort=7)),          # BASELINE config 1
     "l300x260_e5": (300, 260, dict(seed=6), dict(lossless=True, effort=5)),        # single 512-px group (device: rejected, oracle: exact)
     "l700x500_e7": (700, 500, dict(seed=7), dict(lossless=True, effort=7)),        # 3x2 groups with ragged edges
+    "l530x300_e1": (530, 300, dict(seed=31), dict(lossless=True, effort=1)),       # libjxl's fast lossless path: prefix codes + LZ77 in every group stream (3x2 groups)
+    "l300x280_e2": (300, 280, dict(seed=32), dict(lossless=True, effort=2)),
+    "la280x300_e1": (280, 300, dict(seed=33, alpha=True), dict(lossless=True, effort=1)),   # RGBA
 }
 
 

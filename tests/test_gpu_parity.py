@@ -76,9 +76,9 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    fast_lossless, _ = load_case("l64_e1")                                    # effort-1 stream: LZ77 inside group streams
+    big_groups, _ = load_case("l300x260_e5")                                  # effort-5 lossless stream: Modular group size 512
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
-        dec.decode_one_shot(fast_lossless)
+        dec.decode_one_shot(big_groups)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
     assert out.shape == (520, 264, 4)
 

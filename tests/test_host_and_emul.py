@@ -103,7 +103,7 @@ def test_alternate_device_paths_give_identical_pixels(emul, monkeypatch, name):
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
-    data, _ = load_case("l64_e1")
+    data, _ = load_case("l300x260_e5")               # Modular group size 512
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
 
