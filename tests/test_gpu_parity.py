@@ -303,3 +303,37 @@ def test_large_varblocks_after_flights_without_any(dec):
         torch.cuda.synchronize()
         for r, o in zip(ref, outs):
             assert np.array_equal(o.cpu().numpy().reshape(r.shape), r)
+
+
+def test_concurrent_contexts_mixed_flights(dec):
+    """Four decoder contexts on four host threads (own HIP stream and buffers each) decode flights of mixed content — VarDCT, VarDCT + alpha,
+    Modular lossless, LZ77 lossless, 16-bit — at the same time, over and over; every frame of every flight must equal its single decode."""
+    import threading
+    import torch
+    import jxl_coder_amd as J
+    names = ["v264x520_e7", "va300x520_e7", "l200x120_e7", "l530x300_e1", "v267x131_e7", "l700x500_e7", "v300x300_e7_d3", "la280x300_e1", "v256_e7"]
+    datas = [load_case(n)[0] for n in names]
+    refs = [dec.decode_one_shot(d)[0] for d in datas]
+    errors = []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            d = J.JxlDecoder(0)
+            for rep in range(4):
+                order = [(k + rep + i * (k + 1)) % len(datas) for i in range(len(datas) + k)]
+                outs = [torch.zeros(refs[i].size * refs[i].itemsize, dtype=torch.uint8, device="cuda") for i in order]
+                d.decode_batch_to_device([datas[i] for i in order], [o.data_ptr() for o in outs], [o.numel() for o in outs])
+                torch.cuda.synchronize()
+                for i, o in zip(order, outs):
+                    got = o.cpu().numpy().view(refs[i].dtype).reshape(refs[i].shape)
+                    if not np.array_equal(got, refs[i]):
+                        errors.append((k, rep, names[i]))
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:5]
