@@ -301,6 +301,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   }
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
+  // JXLAMD_MERGE_LARGE=1: flights never launch the large-block kernel separately (the medium kernel's workgroups walk that list too)
+  static const int merge_large = getenv("JXLAMD_MERGE_LARGE") ? atoi(getenv("JXLAMD_MERGE_LARGE")) : 0;
+  if (merge_large && nframes > 1) expect_large = false;
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
