@@ -219,8 +219,8 @@ def main():
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
         flights = max(int(kern.get("flights", 1)), 1)
-        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt (first sub-flight of the flight; + k_lf_smooth)" if P > 1 else "k_pass_group (+ k_lf_smooth)"),
-                 "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt, k_recon_*, k_filter_b<*>" if P > 1 else "k_recon_small_b+k_recon_list_b", "filters_write_ms": "k_filter_b<0..4>"}
+        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt2 (first sub-flight of the flight; + k_lf_smooth)" if P > 1 else "k_pass_group (+ k_lf_smooth)"),
+                 "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt2, k_recon_*, k_filter_sweep" if P > 1 else "k_recon_small_b+k_recon_list_b", "filters_write_ms": "k_filter_sweep"}
         stages = {k: kern[k] / flights for k in names if k in kern}
         # the dominant kernel = the one with the largest total duration in rocprofv3 --stats of this command (profiles/): the two serial
         # entropy stages compete for it; both are one launch per flight and both are timed by the HIP events, so the run itself decides

@@ -119,7 +119,7 @@ struct jxlamd_decoder {
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
   int simt_lf_min = getenv("JXLAMD_SIMT_LF_MIN") ? atoi(getenv("JXLAMD_SIMT_LF_MIN")) : 0x7fffffff;     // LfGroup sections in a flight from which the lane-per-stream LF kernel takes over (off by default: measured slower)
   int pass_frame_mode = getenv("JXLAMD_PASS_FRAME") ? atoi(getenv("JXLAMD_PASS_FRAME")) : 0;   // k_pass_frame (HF code in 100-150 KB of LDS per frame): 0 off (default: 30 % faster alone, but next to other decoder contexts its LDS appetite costs more than it saves), 1 flights and bands, 2 single decodes too
-  int simt2 = getenv("JXLAMD_SIMT2") ? atoi(getenv("JXLAMD_SIMT2")) : 0;       // k_pass_group_simt2 (LDS bit rings; 21 % faster alone, measured SLOWER overall next to 7 other contexts: DESIGN.md §7) instead of k_pass_group_simt
+  int simt2 = getenv("JXLAMD_SIMT2") ? atoi(getenv("JXLAMD_SIMT2")) : 1;       // k_pass_group_simt2 (bit supply through LDS rings, hybrid-uint configs in LDS; context maps stay in L2 unless JXLAMD_SIMT2_CTX_LDS=1: with them in LDS — 38 KB per wave — the other kernels lose more than PassGroup gains); 0: k_pass_group_simt
   int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
   void set_error(const std::string &e) { error = e; tls_error() = e; }

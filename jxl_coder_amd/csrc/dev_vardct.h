@@ -529,7 +529,10 @@ JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, 
 //     at once whenever any lane runs below 6 dwords — one memory wait per ~20-60 symbols instead of one per symbol;
 //   * the context map of the frame's presets and the hybrid-uint configs sit in LDS (a wavefront only holds groups of ONE frame);
 //   * the coefficient-order entry of the next position is fetched one symbol ahead.
-constexpr int kSimtRing = 16;                              // dwords per lane
+#ifndef JXL_SIMT_RING
+#define JXL_SIMT_RING 16
+#endif
+constexpr int kSimtRing = JXL_SIMT_RING;                              // dwords per lane
 struct SimtBits {
   uint64_t buf; int32_t n;                                 // valid bits in the low n positions
   uint32_t rd, wr;                                         // ring cursors (dwords, monotonic): slot = cursor & (kSimtRing - 1)

@@ -36,7 +36,9 @@ __global__ void __launch_bounds__(64) k_pass_group_simt(const DevBuffers *Bs, co
 // lane-per-group with the stall-free bit supply (dev_vardct.h pass_group_lane2): one wavefront = up to 64 groups of ONE frame.
 // wmap: {frame, first group, number of groups <= 64} per workgroup
 __global__ void __launch_bounds__(64) k_pass_group_simt2(const DevBuffers *__restrict__ Bs, const int *__restrict__ wmap, int ctx_in_lds) {
-  __shared__ SimtPassLds L;
+  // dynamic LDS: the context-map slices (the struct's last member, 31 KB) are only allocated when they are kept in LDS
+  extern __shared__ __attribute__((aligned(16))) uint8_t simt2_smem[];
+  SimtPassLds &L = *(SimtPassLds *)simt2_smem;
   const int lane = (int)threadIdx.x;
   const int f = wmap[3 * blockIdx.x], g0 = wmap[3 * blockIdx.x + 1], n = wmap[3 * blockIdx.x + 2];
   const DevBuffers &B = Bs[f];
@@ -53,8 +55,9 @@ __global__ void __launch_bounds__(64) k_pass_group_simt2(const DevBuffers *__res
   if (e) atomicOr(B.err, e | kErrStagePass);
 }
 void launch_pass_groups_simt2(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s) {
-  static const int ctx_in_lds = getenv("JXLAMD_SIMT2_CTX_LDS") ? atoi(getenv("JXLAMD_SIMT2_CTX_LDS")) : 1;
-  hipLaunchKernelGGL(k_pass_group_simt2, dim3(nwg), dim3(64), 0, s, Bs, wmap, ctx_in_lds);
+  static const int ctx_in_lds = getenv("JXLAMD_SIMT2_CTX_LDS") ? atoi(getenv("JXLAMD_SIMT2_CTX_LDS")) : 0;
+  const size_t lds = offsetof(SimtPassLds, ctx_map) + (ctx_in_lds ? sizeof(((SimtPassLds *)nullptr)->ctx_map) : 16);
+  hipLaunchKernelGGL(k_pass_group_simt2, dim3(nwg), dim3(64), lds, s, Bs, wmap, ctx_in_lds);
 }
 
 // One workgroup per frame (per 256 groups of a larger frame): the pass's HF code sits in LDS (DevFrame::hf_lds), every lane decodes one
