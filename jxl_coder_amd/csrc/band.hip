@@ -148,6 +148,7 @@ int jxlamd_decoder::band_finish() {
   if (F->epf_iters >= 3) stage_mask |= 2;
   if (F->epf_iters >= 1) stage_mask |= 4;
   if (F->epf_iters >= 2) stage_mask |= 8;
+  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, (q.py1 - q.py0) + 2 * q.halo, stage_mask, true, 2, stream);
   HIPCHECK(hipEventRecord(ev[4], stream));

@@ -228,6 +228,7 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts) {
   if (F->epf_iters >= 3) stage_mask |= 2;
   if (F->epf_iters >= 1) stage_mask |= 4;
   if (F->epf_iters >= 2) stage_mask |= 8;
+  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
   return JXLAMD_OK;
@@ -418,6 +419,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (F->epf_iters >= 3) stage_mask |= 2;
     if (F->epf_iters >= 1) stage_mask |= 4;
     if (F->epf_iters >= 2) stage_mask |= 8;
+  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   }
   HIPCHECK(plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
   const int used_sets = std::min(hf_sets, nb);

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) k_filter_fused(const DevBuffers *__restri
 __device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }    // lane - 1: x - 1
 __device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // lane + 1: x + 1
 __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && F.epf_iters <= 2; }
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 template <bool kGab, int kEpf>
 __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int strip, int seg, int rows_per_wave, int lane) {
@@ -163,9 +164,9 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   for (int c = 0; c < 3; c++) {
     const float w1 = F.gab_w[c][0], w2 = F.gab_w[c][1];
     const float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
-    gn[c] = norm; g1[c] = w1 * norm; g2[c] = w2 * norm; cs[c] = F.epf_chscale[c];
+    gn[c] = sgpr_f(norm); g1[c] = sgpr_f(w1 * norm); g2[c] = sgpr_f(w2 * norm); cs[c] = sgpr_f(F.epf_chscale[c]);      // wave-uniform: scalar registers
   }
-  const float sm1 = 1.65f, sm1b = sm1 * F.epf_border_sad, sm2 = 1.65f * F.epf_pass2, sm2b = sm2 * F.epf_border_sad;
+  const float sm1 = 1.65f, sm1b = sgpr_f(sm1 * F.epf_border_sad), sm2 = sgpr_f(1.65f * F.epf_pass2), sm2b = sgpr_f(sm2 * F.epf_border_sad);
   float in[3][3] = {}, G[4][3] = {}, Ev[3] = {}, Eh[3] = {}, E1[3][3] = {};
   float sad_up_e = 0.0f, is1 = 0.0f, is2 = 0.0f;
   int cell1 = -1, cell2 = -1;
@@ -249,20 +250,16 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
     }
   }
 }
+// one instantiation per stage combination: the register footprint of the longest pipeline (Gaborish + two EPF iterations) must not be
+// charged to the common one (Gaborish + one iteration)
+template <bool kGab, int kEpf>
 __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (!frame_uses_sweep(F) || frame_failed(B)) return;
+  if ((F.gab != 0) != kGab || F.epf_iters != kEpf) return;           // another instantiation's frame
   const int lane = (int)(threadIdx.x & 63), seg = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)), strip = (int)blockIdx.x;
-  if (F.gab) {
-    if (F.epf_iters == 0) filter_sweep<true, 0>(B, F, stat, strip, seg, rows_per_wave, lane);
-    else if (F.epf_iters == 1) filter_sweep<true, 1>(B, F, stat, strip, seg, rows_per_wave, lane);
-    else filter_sweep<true, 2>(B, F, stat, strip, seg, rows_per_wave, lane);
-  } else {
-    if (F.epf_iters == 0) filter_sweep<false, 0>(B, F, stat, strip, seg, rows_per_wave, lane);
-    else if (F.epf_iters == 1) filter_sweep<false, 1>(B, F, stat, strip, seg, rows_per_wave, lane);
-    else filter_sweep<false, 2>(B, F, stat, strip, seg, rows_per_wave, lane);
-  }
+  filter_sweep<kGab, kEpf>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
 
 void launch_filters_fused(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
@@ -281,7 +278,14 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   static const int sweep = getenv("JXLAMD_FILTER_SWEEP") ? atoi(getenv("JXLAMD_FILTER_SWEEP")) : 1;
   if (sweep) {
     const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
-    hipLaunchKernelGGL(k_filter_sweep, dim3((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes), dim3(256), 0, s, Bs, stat, rows);
+    const dim3 g((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes);
+    const int combos = stage_mask >> 8;                        // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use
+    if (combos & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2>), g, dim3(256), 0, s, Bs, stat, rows);
     if (!(stage_mask & 2)) return;
   }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
