@@ -29,7 +29,7 @@ struct ReconLds {                       // medium: S[3][1024] T[3][1024] CC (28 
   float S[NMAX > 1024 ? NMAX : 3 * NMAX];
   float T[NMAX > 1024 ? NMAX : 3 * 1024];
   float CC[NMAX > 1024 ? 4 : 1024];
-  float LL[32];                         // 4-point cosine table (16) + 4-point LLF scales (4): the LLF corner of DCT32x32 blocks
+  float LL[96];                         // 4-point cosine table (16) + 4-point LLF scales (4); [32, 80): the 48 LF samples of the block being reconstructed
 };
 
 __device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
@@ -118,36 +118,37 @@ __device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const floa
 // work-items of the LLF corner, with a barrier in between.  Here every work-item first issues ALL its loads (12 coefficients and
 // their weights; wave 3 also the 16 LF samples of its LLF output), then computes; the LLF corner is skipped by the dequantiser
 // and written by wave 3, so the two need no barrier between them.  Same float operations in the same order as the generic path.
-__device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, const float *LL, int bx, int by, int tid) {
+__device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *LL, int bx, int by, int tid) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
   const int qt = kQuantTableOf[kStrategyDct32];
   const int g = (by / 32) * F.xgroups + (bx / 32);
   uint32_t off = B.coef_off[o];
   if (off + 1024u > 65536u) { if (tid == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
+  // block base addresses are wave-uniform: scalar base + one 32-bit lane offset per access (no 64-bit address registers per plane)
+  const auto uptr = [](const void *p) { const uint64_t v = (uint64_t)p; return (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32))) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
   int32_t *qp[3]; const float *qw[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { qp[c] = &B.coef[c][(size_t)g * 65536 + off + (uint32_t)tid]; qw[c] = st_f(stat, ST.qw_off[qt][c]) + tid; }
+  for (int c = 0; c < 3; c++) { qp[c] = (int32_t *)uptr(&B.coef[c][(size_t)g * 65536 + off]) + tid; qw[c] = (const float *)uptr(st_f(stat, ST.qw_off[qt][c])) + tid; }
   int q[3][4]; float w[3][4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
 #pragma unroll
     for (int c = 0; c < 3; c++) { q[c][j] = qp[c][256 * j]; w[c][j] = qw[c][256 * j]; }
-  // LLF corner: work-item 192 + i, i < 48, produces coefficient (a, b) = (i / 4 % 4, i % 4) of channel i / 16
+  // LLF corner: work-item 192 + i, i < 48 (all in wave 3), produces coefficient (a, b) = (i / 4 % 4, i % 4) of channel i / 16.  Each of the
+  // 48 loads ONE of the 3 x 16 LF samples (same index arithmetic: sample (iy, ix) = (i / 4 % 4, i % 4) of channel i / 16) and the wave
+  // shares them through LDS — sixteen loads per work-item cost sixteen registers in every lane of the workgroup
   const int li = tid - 192;
   const bool llf = li >= 0 && li < 48;
-  float lf[16];
-  if (llf) {
-    const float *src = B.lf_s[li >> 4] + o;
-#pragma unroll
-    for (int iy = 0; iy < 4; iy++)
-#pragma unroll
-      for (int ix = 0; ix < 4; ix++) lf[iy * 4 + ix] = src[(size_t)iy * (size_t)F.xb + (size_t)ix];
-  }
-  const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
+  float lf1 = 0.0f;
+  if (llf) lf1 = B.lf_s[li >> 4][o + (size_t)((li >> 2) & 3) * (size_t)F.xb + (size_t)(li & 3)];
+  const auto sg = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };    // per-block values are wave-uniform: scalar registers
+  const float mul = sg(F.inv_global_scale / (float)((int)B.qfm1[o] + 1));
   const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
-  const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
-  const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+  const float kx = sg(F.base_x + (float)B.xfromy[to] * F.inv_color_factor);
+  const float kb = sg(F.base_b + (float)B.bfromy[to] * F.inv_color_factor);
+  const float qb[4] = {sg(F.quant_bias[0]), sg(F.quant_bias[1]), sg(F.quant_bias[2]), sg(F.quant_bias[3])};
+  const float md[3] = {sg(mul * F.dm[0]), sg(mul * F.dm[1]), sg(mul * F.dm[2])};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int k = tid + 256 * j;
@@ -158,18 +159,23 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
       if (qq != 0) qp[c][256 * j] = 0;                 // consumed exactly once: the reader clears it (see recon_phaseA)
       float a;
       if (qq == 0) a = 0.0f;
-      else if (qq == 1) a = F.quant_bias[c];
-      else if (qq == -1) a = -F.quant_bias[c];
-      else a = (float)qq - F.quant_bias[3] / (float)qq;
-      v[c] = a * (mul * F.dm[c] * w[c][j]);
+      else if (qq == 1) a = qb[c];
+      else if (qq == -1) a = -qb[c];
+      else a = (float)qq - qb[3] / (float)qq;
+      v[c] = a * (md[c] * w[c][j]);
     }
     if ((k >> 5) < 4 && (k & 31) < 4) continue;        // the LLF corner belongs to wave 3
     S[k] = v[0] + kx * v[1];
     S[1024 + k] = v[1];
     S[2048 + k] = v[2] + kb * v[1];
   }
+  if (llf) LL[32 + li] = lf1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");            // wave 3 only: its LDS accesses execute in order, the fences keep the compiler from reordering
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (llf) {
     const int r = li & 15, a = r >> 2, b = r & 3;      // cx == cy: horizontal frequency u = a, vertical v = b (recon_phaseB)
+    const float *lf = LL + 32 + (li >> 4) * 16;
     float s = 0.0f;
 #pragma unroll
     for (int iy = 0; iy < 4; iy++) {
@@ -223,7 +229,7 @@ __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint
 }
 
 template <int NMIN, int NMAX>
-__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma, ReconLds<NMAX> &L) {
+__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma, ReconLds<NMAX> &L, bool skip_dct32 = false) {
   const int tid = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
   const DevFrame &F = frame_of(B);
@@ -240,6 +246,7 @@ __device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8
     const int bx = cell % xb, by = cell / xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;       // band decode: the LF groups placed here may reach beyond the band's rows
     if (NMAX == 1024 && B.strategy[cell] == kStrategyDct32) {
+      if (skip_dct32) continue;                      // k_recon_dct32_b has reconstructed it
       __syncthreads();                               // previous item's pass 2 has finished reading T; CC is in place
       recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
       __syncthreads();
@@ -294,10 +301,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
-  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0, *(ReconLds<NMAX> *)smem);
-  if (NMAX == 1024 && also_large) {
+  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0, *(ReconLds<NMAX> *)smem, (also_large & 2) != 0);
+  if (NMAX == 1024 && (also_large & 1)) {
     __syncthreads();
     recon_list_walk<1025, 4096>(B, stat, 1, F.xb, use_mfma != 0, *(ReconLds<4096> *)smem);
+  }
+}
+// DCT32x32 blocks only (98 % of the area of smooth 4K content): half the LDS of the general medium kernel (the second pass runs in
+// place: wave c reads all of channel c before it writes) and its own, smaller register footprint — what the data-parallel kernels can
+// use next to resident entropy waves is what decides their speed in a flight mix.
+struct ReconDct32Lds { float S[3 * 1024]; float CC[1024]; float LL[96]; };
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_dct32_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) ReconDct32Lds L;
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  const int tid = (int)threadIdx.x, xb = F.xb;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const uint32_t count = B.big_count[0];
+  if (blockIdx.x >= count) return;
+  {
+    const float *cc = st_f(stat, ST.cos_off[5]);
+    for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
+    if (tid < 16) L.LL[tid] = st_f(stat, ST.cos_off[2])[tid];
+    else if (tid < 20) L.LL[tid] = (st_f(stat, ST.llf_off) + 64)[tid - 16];
+  }
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[0][i];
+    const int bx = cell % xb, by = cell / xb;
+    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != kStrategyDct32) continue;
+    __syncthreads();                                 // the previous block's second pass has finished reading S
+    recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
+    __syncthreads();
+    recon_dct32_mfma(B, L.S, L.S, L.CC, bx, by, tid);
   }
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
@@ -310,7 +346,11 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
   // JXLAMD_RECON_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 32 KB — an occupancy experiment knob, no functional effect
   static const unsigned extra_lds = getenv("JXLAMD_RECON_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_RECON_EXTRA_LDS")) : 0u;
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
+  static const int split = getenv("JXLAMD_DCT32_SPLIT") ? atoi(getenv("JXLAMD_DCT32_SPLIT")) : 1;      // 0: the medium kernel handles DCT32x32 too
+  const int dct32_own = use_mfma && split;
+  if (dct32_own) hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(dct32_own && nframes > 1 ? 64 : gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma,
+                     (expect_large ? 0 : 1) | (dct32_own ? 2 : 0));
   if (!expect_large) return;
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
