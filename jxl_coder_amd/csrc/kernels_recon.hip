@@ -336,6 +336,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     recon_dct32_mfma(B, L.S, L.S, L.CC, bx, by, tid);
   }
 }
+// The 512 / 1024-coefficient blocks that are NOT DCT32x32 (DCT16x32, 32x16, 8x32, ... — a few per cent of the blocks), one channel at a
+// time: 8 KB of LDS instead of the general medium kernel's 33 KB, so that this short launch is not kept waiting for LDS by resident LF waves.
+__global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) float S[1024];
+  __shared__ __attribute__((aligned(16))) float T[1024];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  const int tid = (int)threadIdx.x, xb = F.xb;
+  const uint32_t count = B.big_count[0];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[0][i];
+    const int bx = cell % xb, by = cell / xb;
+    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] == kStrategyDct32) continue;
+    __syncthreads();
+    recon_block_body<false, true>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
+  }
+}
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // JXLAMD_MERGE_LARGE=1: flights never launch the large-block kernel separately (the medium kernel's workgroups walk that list too)
   static const int merge_large = getenv("JXLAMD_MERGE_LARGE") ? atoi(getenv("JXLAMD_MERGE_LARGE")) : 0;
@@ -348,9 +366,14 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   static const unsigned extra_lds = getenv("JXLAMD_RECON_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_RECON_EXTRA_LDS")) : 0u;
   static const int split = getenv("JXLAMD_DCT32_SPLIT") ? atoi(getenv("JXLAMD_DCT32_SPLIT")) : 1;      // 0: the medium kernel handles DCT32x32 too
   const int dct32_own = use_mfma && split;
-  if (dct32_own) hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(dct32_own && nframes > 1 ? 64 : gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma,
-                     (expect_large ? 0 : 1) | (dct32_own ? 2 : 0));
+  if (dct32_own) {
+    hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+    hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+    // the 2048 / 4096-coefficient list: its own launch; one workgroup per frame when the previous flight had none
+    hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1, use_mfma, 0);
+    return;
+  }
+  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
   if (!expect_large) return;
   // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
   // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
