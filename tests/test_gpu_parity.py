@@ -234,7 +234,7 @@ def test_config5_full_size_pq16_epf3_tone_map_f16(dec):
 
 def test_alternative_kernels_keep_parity():
     """The measured-and-parked alternatives stay correct: fused LDS-tiled Gaborish + EPF + writer (JXLAMD_FUSED_FILTERS=1), workgroup-per-frame
-    PassGroup decode with the HF code in LDS (JXLAMD_PASS_FRAME=1), LDS-ring PassGroup lanes (JXLAMD_SIMT2=1) and the lane-per-stream LF
+    PassGroup decode with the HF code in LDS (JXLAMD_PASS_FRAME=1), PassGroup lanes without LDS rings (JXLAMD_SIMT2=0) / with the context maps in LDS too, the one-kernel medium reconstruction (JXLAMD_DCT32_SPLIT=0) and the lane-per-stream LF
     kernel (JXLAMD_SIMT_LF_MIN=1): golden vectors within the stated tolerance, flights == single decodes (knobs are read once per process)."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -260,7 +260,8 @@ def test_alternative_kernels_keep_parity():
     """) % (ROOT, ROOT + "/tests")
     # ... and the paths the defaults replaced: per-stage filter kernels instead of the column sweep (JXLAMD_FILTER_SWEEP=0; also what frames
     # with three EPF iterations use), VALU DCT32 passes (JXLAMD_DCT32_MFMA=0), the entropy kernels on a second stream (JXLAMD_ENTROPY_STREAM=1)
-    for env in ({"JXLAMD_FUSED_FILTERS": "1", "JXLAMD_FILTER_SWEEP": "0"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"},
+    for env in ({"JXLAMD_FUSED_FILTERS": "1", "JXLAMD_FILTER_SWEEP": "0"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "0", "JXLAMD_SIMT_MIN_GROUPS": "1"},
+                {"JXLAMD_SIMT2_CTX_LDS": "1", "JXLAMD_SIMT_MIN_GROUPS": "1", "JXLAMD_DCT32_SPLIT": "0"}, {"JXLAMD_SIMT_MIN_GROUPS": "1"},
                 {"JXLAMD_SIMT_LF_MIN": "1"}, {"JXLAMD_FILTER_SWEEP": "0", "JXLAMD_DCT32_MFMA": "0"}, {"JXLAMD_ENTROPY_STREAM": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
