@@ -13,7 +13,7 @@ rnd = random.Random(seed)
 dec = J.JxlDecoder(0)
 dec_ok = rej = 0
 t0 = time.time()
-for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7", "l700x500_e7", "asset_first_jxl"):
+for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7", "l700x500_e7", "asset_first_jxl", "l530x300_e1", "v300x300_e7_d3"):
     d0, _ = load_case(name)
     ref = dec.decode_one_shot(d0)[0]
     for it in range(n):
