@@ -338,3 +338,39 @@ def test_concurrent_contexts_mixed_flights(dec):
     for t in th:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_corrupt_frame_inside_a_flight_is_contained():
+    """A flight with one corrupted frame (bit flips in its PassGroup data) is rejected loudly; the coefficient sets it shares with later
+    frames of the flight (JXLAMD_HF_SETS=2 forces the sharing) and with later flights come back clean: the next flights of the same
+    context give the single-decode pixels again."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from conftest import load_case
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        names = ["v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "va300x520_e7", "v264x520_e7", "v300x300_e7_d3"]
+        datas = [load_case(n)[0] for n in names]
+        singles = [dec.decode_one_shot(d)[0] for d in datas]
+        bad = bytearray(datas[2])
+        for i in range(len(bad) * 2 // 3, len(bad) * 2 // 3 + 48): bad[i] ^= 0xA5
+        rejected = 0
+        for rep in range(3):
+            outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+            try:
+                dec.decode_batch_to_device(datas[:2] + [bytes(bad)] + datas[3:], [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            except (J.InvalidJXLException, J.UnsupportedJXLFeature):
+                rejected += 1
+            outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+            dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            torch.cuda.synchronize()
+            for s, o in zip(singles, outs):
+                assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+        assert rejected == 3, rejected
+        print("contained ok")
+    """) % (ROOT, ROOT + "/tests")
+    env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1", JXLAMD_SIMT_MIN_GROUPS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "contained ok" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
