@@ -274,7 +274,7 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
 // The nested code of an entropy-coded context map has a single context, so it never carries a context map itself:
 // two template instances instead of recursion keep everything inlined (no call stack, no scratch).
 template <bool kNested>
-JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens);
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens, LocalTmp *fast_tmp = nullptr);
 
 JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_clusters, LocalEC *nested, uint8_t *lens) {
   uint32_t err = 0;
@@ -312,7 +312,7 @@ JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_cluste
 }
 
 template <bool kNested>
-JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens) {
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens, LocalTmp *fast_tmp) {
   uint32_t err = 0;
   if (kNested && num_ctx != 1) return kErrBitstream;
   if (num_ctx > kLocMaxCtx) return kErrUnsupportedTransform;
@@ -333,20 +333,23 @@ JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalE
     }
     for (int i = 0; i < ec.num_clusters; i++) { err |= d_read_prefix_code(b, ec, ec.prefix[i], lens, counts[i]); if (err) return err; }
   } else {
+    // histogram + alias-table working arrays: the caller's LDS scratch when it has one (the serial lane's dependent accesses then
+    // cost an LDS round trip instead of an L2 one — the pairing loop of an alias table is ~230 such steps per cluster), else HBM
     const int table = 1 << ec.log_alpha;
-    uint16_t *D = ec.tmp.D;
+    LocalTmp &T = fast_tmp ? *fast_tmp : ec.tmp;
+    uint16_t *D = T.D;
     for (int i = 0; i < ec.num_clusters; i++) {
-      err |= d_read_histogram(b, D, table, ec.tmp);
+      err |= d_read_histogram(b, D, table, T);
       if (err) return err;
-      d_build_alias(D, ec.log_alpha, ec.alias + (size_t)i * (size_t)table, ec.tmp);
+      d_build_alias(D, ec.log_alpha, ec.alias + (size_t)i * (size_t)table, T);
     }
   }
   return err;
 }
 
 // MA tree (H.4.2) + its leaf code
-JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L) {
-  uint32_t err = d_ec_read_header_t<false>(b, 6, L.tree_code, &L.nested, L.lens);
+JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L, LocalTmp *fast_tmp = nullptr) {
+  uint32_t err = d_ec_read_header_t<false>(b, 6, L.tree_code, &L.nested, L.lens, fast_tmp);
   if (err) return err;
   DevECView v = local_view(L.tree_code);
   uint32_t state = ans_init(v, b);
@@ -378,7 +381,7 @@ JXL_DEV uint32_t d_read_local_tree(DevBits &b, LocalTreeScratch &L) {
   }
   if (state != 0x130000u) return kErrAnsFinal;
   L.count = count;
-  return d_ec_read_header_t<false>(b, leaf, L.leaf_code, &L.nested, L.lens);
+  return d_ec_read_header_t<false>(b, leaf, L.leaf_code, &L.nested, L.lens, fast_tmp);
 }
 
 }  // namespace jxlamd

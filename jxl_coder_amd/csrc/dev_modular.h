@@ -315,7 +315,8 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
     st.tree = (const DevTreeNode *)(tables + F.tree_off); st.count = F.tree_count; st.ev = ec_view(tables, F.tree_ec);
     st.num_ctx = F.tree_ec.num_ctx + (F.tree_ec.lz77 ? 1 : 0); st.num_clusters = F.tree_ec.num_clusters;      // the map carries one more entry (distances) with LZ77
   } else {
-    uint32_t e = d_read_local_tree(st.b, L);
+    static_assert(sizeof(LocalTmp) <= (size_t)kModPoolBytes, "the header parser's working arrays fit the table pool");
+    uint32_t e = d_read_local_tree(st.b, L, (LocalTmp *)S.pool);      // the pool is free until modular_stream_stage fills it
     if (e) { st.err = e; return; }
     st.tree = L.nodes; st.count = L.count; st.ev = local_view(L.leaf_code);
     st.num_ctx = L.leaf_code.num_ctx; st.num_clusters = L.leaf_code.num_clusters;
