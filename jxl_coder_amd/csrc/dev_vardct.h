@@ -199,9 +199,20 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
         for (int iy = 0; iy < cy; iy++) {
           if (occ[(y + iy) * 8 + wx] & mask) return kErrBitstream;               // overlapping varblocks (uniform: every lane sees the same word)
         }
-        sync();                                    // all lanes have read the words before lane 0 updates them
-        if (tid == 0) for (int iy = 0; iy < cy; iy++) occ[(y + iy) * 8 + wx] |= mask;
+        // all lanes have read the words before lane 0 updates them.  On the GPU the section is ONE wave whose LDS accesses execute in
+        // program order: a compiler-level fence is enough, and unlike a workgroup barrier it does not wait for the global stores of
+        // the previous block (that wait was most of the serial loop's time)
+#ifdef __HIPCC__
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#else
         sync();
+#endif
+        if (tid == 0) for (int iy = 0; iy < cy; iy++) occ[(y + iy) * 8 + wx] |= mask;
+#ifdef __HIPCC__
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#else
+        sync();
+#endif
         for (int c = tid; c < cx * cy; c += nthreads) {
           const int iy = c / cx, ix = c - iy * cx;
           const size_t oo = o + (size_t)iy * (size_t)F.xb + (size_t)ix;
