@@ -211,6 +211,7 @@ __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint
       const int u = 2 * st + kh;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(S[u * 64 + t0 + j], cc[u * 64 + t1 + j], acc, 0, 0, 0);      // T[v][x] = sum_u S[u][v] cc[u][x]
     }
+    __syncthreads();                                 // T may be S itself (k_recon_large_b): every wave has finished reading S
 #pragma unroll
     for (int r = 0; r < 16; r++) T[(t0 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + t1 + j] = acc[r];
     __syncthreads();
@@ -354,6 +355,25 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs,
     recon_block_body<false, true>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
   }
 }
+// The 2048 / 4096-coefficient blocks with half the LDS of k_recon_list_b<1025, 4096>: DCT64x64 on the matrix cores with the second pass in
+// place (16 KB), the 64x32 / 32x64 blocks one channel at a time in S[2048] + T[2048].
+__global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) float S[4096];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  const int tid = (int)threadIdx.x, xb = F.xb;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const uint32_t count = B.big_count[1];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[1][i];
+    const int bx = cell % xb, by = cell / xb;
+    if (by < F.band_cy0 || by >= F.band_cy1) continue;
+    __syncthreads();
+    if (B.strategy[cell] == kStrategyDct64) recon_dct64_mfma(B, stat, ST, S, S, bx, by, tid);
+    else recon_block_body<false, true>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
+  }
+}
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // JXLAMD_MERGE_LARGE=1: flights never launch the large-block kernel separately (the medium kernel's workgroups walk that list too)
   static const int merge_large = getenv("JXLAMD_MERGE_LARGE") ? atoi(getenv("JXLAMD_MERGE_LARGE")) : 0;
@@ -370,7 +390,7 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
     hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
     hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat);
     // the 2048 / 4096-coefficient list: its own launch; one workgroup per frame when the previous flight had none
-    hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat, 1, use_mfma, 0);
+    hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
     return;
   }
   hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
