@@ -269,7 +269,59 @@ __global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
   if (i >= F.xb * (F.band_cy1 - F.band_cy0)) return;
   lf_smooth_cell(B, i % F.xb, F.band_cy0 + i / F.xb);
 }
-__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat) {
+// DCT8x8 — nearly all of the small varblocks: one lane per coefficient / pixel, the three channels side by side, the 8-point cosine
+// rows a lane needs (its x in the first pass, its y in the second) in registers.  Same operations in the same order as
+// recon_phaseA / recon_phaseB / recon_idct_pass1 / recon_idct_pass2 for this strategy (one tenth of their instructions: no per-element
+// index arithmetic, no table loads inside the sums).
+__device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, int bx, int by, int lane,
+                                                 const float (&cx8)[8], const float (&cy8)[8]) {
+  const DevFrame &F = frame_of(B);
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  const int qt = kQuantTableOf[0];
+  const int g = (by / 32) * F.xgroups + (bx / 32);
+  uint32_t off = B.coef_off[o];
+  if (off + 64u > 65536u) { if (lane == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
+  const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
+  const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
+  const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
+  const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+  float v[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    int32_t *qp = &B.coef[c][(size_t)g * 65536 + off + (uint32_t)lane];
+    const int q = *qp;
+    if (q != 0) *qp = 0;                               // consumed exactly once: the reader clears it
+    float a;
+    if (q == 0) a = 0.0f;
+    else if (q == 1) a = F.quant_bias[c];
+    else if (q == -1) a = -F.quant_bias[c];
+    else a = (float)q - F.quant_bias[3] / (float)q;
+    v[c] = a * (mul * F.dm[c] * st_f(stat, ST.qw_off[qt][c])[lane]);
+  }
+  float s0 = v[0] + kx * v[1], s1 = v[1], s2 = v[2] + kb * v[1];
+  if (lane == 0) { s0 = B.lf_s[0][o]; s1 = B.lf_s[1][o]; s2 = B.lf_s[2][o]; }      // the LLF "corner" of a 1x1 block is the LF sample itself (all scales are 1)
+  S[lane] = s0; S[64 + lane] = s1; S[128 + lane] = s2;
+  __syncthreads();
+  const int hi = lane >> 3, lo = lane & 7;
+  float t[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int u = 0; u < 8; u++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) t[c] += S[c * 64 + u * 8 + hi] * cx8[u];             // T[v][x], lane = v * 8 + x
+#pragma unroll
+  for (int c = 0; c < 3; c++) T[c * 64 + lane] = t[c];
+  __syncthreads();
+  float r[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int vv = 0; vv < 8; vv++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) r[c] += T[c * 64 + vv * 8 + lo] * cy8[vv];            // out[y][x], lane = y * 8 + x
+  const size_t po = (size_t)(by * 8 + hi) * (size_t)F.pw + (size_t)(bx * 8 + lo);
+#pragma unroll
+  for (int c = 0; c < 3; c++) B.plane_a[c][po] = r[c];
+}
+
+__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat, int skip_dct8) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
   const DevBuffers &B = Bs[blockIdx.z];
@@ -288,13 +340,36 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
+    if (skip_dct8 && B.strategy[cell] == 0) continue;            // k_recon_dct8_b has reconstructed it
     __syncthreads();
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
-// also_large (medium instantiation only): the same workgroups walk the list of 2048 / 4096-coefficient blocks afterwards.  Flights whose
-// previous flight had no such block use this instead of a separate (almost always empty) launch of the large instantiation, whose
-// workgroups waited for 32 KB of LDS behind resident LF waves — 3.6 % of the bench's kernel time for nothing.
+__global__ void __launch_bounds__(64) k_recon_dct8_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ float S[3 * 64];
+  __shared__ float T[3 * 64];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  const uint32_t count = B.big_count[2];
+  if (blockIdx.x >= count) return;
+  const int lane = (int)threadIdx.x;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  float cx8[8], cy8[8];                               // 8-point cosine table, row k: this lane's column x = lane & 7 / its row y = lane >> 3
+  { const float *cc = st_f(stat, ST.cos_off[3]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cx8[k] = cc[k * 8 + (lane & 7)]; cy8[k] = cc[k * 8 + (lane >> 3)]; } }
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[2][i];
+    const int by = cell / F.xb;
+    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != 0) continue;
+    __syncthreads();
+    recon_dct8_block(B, stat, ST, S, T, cell % F.xb, by, lane, cx8, cy8);
+  }
+}
+// General medium / large list walker (JXLAMD_DCT32_SPLIT=0 or the VALU DCT32 passes; the default path uses k_recon_dct32_b, k_recon_medium_pc_b
+// and k_recon_large_b below).  also_large bit 0: the same workgroups walk the 2048 / 4096-coefficient list afterwards; bit 1: DCT32x32 blocks
+// belong to k_recon_dct32_b.
 template <int NMIN, int NMAX>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma, int also_large) {
   constexpr size_t kLds = sizeof(ReconLds<1024>) > sizeof(ReconLds<4096>) ? sizeof(ReconLds<1024>) : sizeof(ReconLds<4096>);
@@ -380,7 +455,10 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   if (merge_large && nframes > 1) expect_large = false;
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
-  hipLaunchKernelGGL(k_recon_small_b, dim3(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes), dim3(64), 0, s, Bs, stat);
+  static const int dct8_own = getenv("JXLAMD_DCT8_SPLIT") ? atoi(getenv("JXLAMD_DCT8_SPLIT")) : 1;       // 0: k_recon_small_b handles DCT8x8 too
+  const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes);
+  if (dct8_own) hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
+  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, dct8_own);
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
   // JXLAMD_RECON_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 32 KB — an occupancy experiment knob, no functional effect
   static const unsigned extra_lds = getenv("JXLAMD_RECON_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_RECON_EXTRA_LDS")) : 0u;

@@ -261,7 +261,7 @@ def test_alternative_kernels_keep_parity():
     # ... and the paths the defaults replaced: per-stage filter kernels instead of the column sweep (JXLAMD_FILTER_SWEEP=0; also what frames
     # with three EPF iterations use), VALU DCT32 passes (JXLAMD_DCT32_MFMA=0), the entropy kernels on a second stream (JXLAMD_ENTROPY_STREAM=1)
     for env in ({"JXLAMD_FUSED_FILTERS": "1", "JXLAMD_FILTER_SWEEP": "0"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "0", "JXLAMD_SIMT_MIN_GROUPS": "1"},
-                {"JXLAMD_SIMT2_CTX_LDS": "1", "JXLAMD_SIMT_MIN_GROUPS": "1", "JXLAMD_DCT32_SPLIT": "0"}, {"JXLAMD_SIMT_MIN_GROUPS": "1"},
+                {"JXLAMD_SIMT2_CTX_LDS": "1", "JXLAMD_SIMT_MIN_GROUPS": "1", "JXLAMD_DCT32_SPLIT": "0", "JXLAMD_DCT8_SPLIT": "0"}, {"JXLAMD_SIMT_MIN_GROUPS": "1"},
                 {"JXLAMD_SIMT_LF_MIN": "1"}, {"JXLAMD_FILTER_SWEEP": "0", "JXLAMD_DCT32_MFMA": "0"}, {"JXLAMD_ENTROPY_STREAM": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
