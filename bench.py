@@ -10,7 +10,7 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank de
 units, no data-path collective — weak scaling; value = frames of all ranks / max-over-ranks time.
 """
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # more hardware queues: decoder contexts = HIP streams that must overlap (default is 4)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per decoder context: contexts = HIP streams that must overlap (default is 4; contexts that share a queue serialise)
 import argparse
 import json
 import os
@@ -80,8 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per step (BASELINE configs[2]: 256 x 3840x2160 q90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contexts", type=int, default=8, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
-    ap.add_argument("--inflight", type=int, default=128, help="frames decoded per batched flight (1 = strictly sequential)")
+    ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
+    ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1

@@ -170,6 +170,9 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   float in[3][3] = {}, G[4][3] = {}, Ev[3] = {}, Eh[3] = {}, E1[3][3] = {};
   float sad_up_e = 0.0f, is1 = 0.0f, is2 = 0.0f;
   int cell1 = -1, cell2 = -1;
+#ifdef JXL_SWEEP_UNROLL
+#pragma unroll JXL_SWEEP_UNROLL
+#endif
   for (int t = y0 - HX; t < y1 + HX; t++) {
     const size_t ro = (size_t)mirror(t, h) * (size_t)F.pw;
     float v[3];
