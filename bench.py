@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FRAMES = [os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{i}.jxl") for i in (map(int, os.environ["JXLAMD_BENCH_SEEDS"].split(",")) if os.environ.get("JXLAMD_BENCH_SEEDS") else range(8))]   # JXLAMD_BENCH_SEEDS: experiments on a subset
+if os.environ.get("JXLAMD_BENCH_FILES"):          # experiments on other content (same frame size for all), e.g. bench_data/real4k_summer_nature.jxl
+    FRAMES = [os.path.join(ROOT, f) for f in os.environ["JXLAMD_BENCH_FILES"].split(",")]
 FRAMES = [f for f in FRAMES if os.path.exists(f)]
 FRAME = FRAMES[0]
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
@@ -108,6 +110,11 @@ def main():
     w, h = J.JxlCoder.getSize(data)
     assert all(J.JxlCoder.getSize(d) == (w, h) for d in datas)
     out_bytes = w * h * 4
+    if os.environ.get("JXLAMD_BENCH_FILES"):              # other content may decode to RGBA16
+        import ctypes as _C
+        _n = _C.c_size_t()
+        if J.api.lib().jxlamd_output_size(data, len(data), J.api.JXLAMD_ALLOW_16BIT, _C.byref(_n)) == 0:
+            out_bytes = int(_n.value)
     B = max(1, args.batch)
     total_frames = args.steps * B
     # A step's frames are issued in flights of P frames through jxlamd_decode_batch_resident: every frame is parsed, uploaded,
