@@ -317,20 +317,33 @@ __device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <
 // the two frequencies of an entry are D[i] and D[right], so one table of D per cluster (u16 x 128 symbols) serves both — at the price
 // of a dependent LDS read on the rANS chain, which has slack next to the weighted predictor's.  libjxl's LF streams carry up to one
 // cluster per context (34); 23 fit the pool.  Returns false (pool untouched) when a symbol >= 128 can occur.
-constexpr int kPackedClusterBytes = 1024 + 256;
-__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, int num_clusters, int log_alpha, DevModScratch &S, int lane) {
-  if (log_alpha != 8 || num_clusters * kPackedClusterBytes > kModPoolBytes) return false;
-  const int n = num_clusters << 8;
+// Only the clusters the channel's leaves use are packed (`used`: bit per cluster id; compact index = number of used clusters below it):
+// libjxl's non-streaming encoder writes ONE global tree for all Modular streams of a frame (39 clusters and log_alpha 7 in the
+// reference's 4K demo photographs; the LF channels use 28 of them).  log_alpha 5..8: 4 << log_alpha bytes of entries per cluster.
+// Returns false (pool untouched) when the tables do not fit or a symbol >= 128 can occur.
+__device__ __forceinline__ int wave_packed_bytes(uint64_t used, int log_alpha) { return __builtin_popcountll(used) * ((4 << log_alpha) + 256); }
+__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t used, int log_alpha, DevModScratch &S, int lane) {
+  if (log_alpha < 5 || log_alpha > 8 || wave_packed_bytes(used, log_alpha) > kModPoolBytes) return false;
+  const int table = 1 << log_alpha, nc = __builtin_popcountll(used);
   bool bad = false;
-  for (int i = lane; i < n; i += 64) { const DevAlias e = galias[i]; bad |= ((i & 255) >= 128 && e.freq0 != 0) || e.right >= 128; }
+  if (log_alpha == 8)
+    for (uint64_t m = used; m; m &= m - 1) {
+      const int s = __builtin_ctzll(m);
+      for (int i = lane; i < table; i += 64) { const DevAlias e = galias[(s << 8) + i]; bad |= (i >= 128 && e.freq0 != 0) || e.right >= 128; }
+    }
   if (__ballot(bad)) return false;
   __syncthreads();
   uint32_t *ent = (uint32_t *)S.pool;
-  uint16_t *D = (uint16_t *)((uint8_t *)S.pool + (size_t)num_clusters * 1024);
-  for (int i = lane; i < n; i += 64) {
-    const DevAlias e = galias[i];
-    ent[i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
-    if ((i & 255) < 128) D[((i >> 8) << 7) + (i & 127)] = e.freq0;
+  uint16_t *D = (uint16_t *)((uint8_t *)S.pool + ((size_t)nc << (log_alpha + 2)));
+  int cid = 0;
+  for (uint64_t m = used; m; m &= m - 1, cid++) {
+    const int s = __builtin_ctzll(m);
+    for (int i = lane; i < table; i += 64) {
+      const DevAlias e = galias[(s << log_alpha) + i];
+      ent[(cid << log_alpha) + i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
+      if (i < 128) D[(cid << 7) + i] = e.freq0;
+    }
+    for (int i = table + lane; i < 128; i += 64) D[(cid << 7) + i] = 0;       // symbols beyond the table never occur
   }
   __syncthreads();
   return true;
@@ -630,13 +643,17 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     if (c.w > kModMaxW && uses_wp) return kErrUnsupportedTransform;
     // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
     if (m16 && uses_wp && !ev.use_prefix && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
-        (pool_packed || (S.st.num_clusters <= kLocMaxClusters && S.st.num_clusters * kPackedClusterBytes <= kModPoolBytes && ev.log_alpha == 8)) &&
+        S.st.num_clusters <= kLocMaxClusters && ev.log_alpha >= 5 && ev.log_alpha <= 8 &&
         __ballot(lane < WT.ni && WT.int_prop[lane] != 15) == 0 &&
         __ballot(lane < WT.nl && (WT.leaf_pred[lane] != 6 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
       const int ni = WT.ni, nl = WT.nl;
       const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
       const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
       const int my_lclu = lane < nl ? (int)evg.ctx_map[WT.leaf_ctx[lane]] : 0;
+      uint64_t used = 0;                             // clusters of this channel's leaves
+      for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_lclu, j) & 63);
+      const int la_p = ev.log_alpha;
+      if (wave_packed_bytes(used, la_p) <= kModPoolBytes) {
       // rank the thresholds; lane c then holds a value with exactly c thresholds below it
       int rank = 0;
       for (int j = 0; j < ni; j++) { const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }
@@ -651,17 +668,24 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
-        if (lane == cc) { my_off = clu << 10; my_doff = (S.st.num_clusters << 10) + (clu << 8); my_cfg = (int)S.cfg[clu]; }
+        const int cid = __builtin_popcountll(used & ((1ull << (clu & 63)) - 1ull));      // compact index of the cluster in the packed pool
+        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + (cid << 8); my_cfg = (int)S.cfg[clu]; }
       }
       __syncthreads();
-      // row 0 goes through the generic loop (every neighbour is the late value W there); once the pool holds the packed tables
+      // row 0 goes through the generic loop (every neighbour is the late value W there); once the pool holds packed tables
       // the generic loops of this stream read their tables through L2 instead
       if (pool_packed) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane, /*y_end=*/1);
       else wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
       __syncthreads();
-      if (!pool_packed) pool_packed = wave_pack_alias(evg.alias, S.st.num_clusters, ev.log_alpha, S, lane);
-      if (pool_packed) { wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1); continue; }
+      const bool was_packed = pool_packed;
+      pool_packed = true;                              // whatever happens next, the pool no longer holds the stream's 8-byte tables / context map
+      if (wave_pack_alias(evg.alias, used, la_p, S, lane)) {   // per channel: the set of clusters may differ
+        wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1);
+        continue;
+      }
+      (void)was_packed;
       return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
+      }
     }
     // uniform-leaf channel (see wave_decode_channel_uniform)
     if (!ev.use_prefix && WT.nl >= 1 && WT.nl <= 64) {
