@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
-    if (skip_dct8 && B.strategy[cell] == 0) continue;            // k_recon_dct8_b has reconstructed it
+    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || st == 6 || st == 7) continue; }      // k_recon_dct8_b / k_recon_dct_rc_b have reconstructed it
     __syncthreads();
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
@@ -365,6 +365,109 @@ __global__ void __launch_bounds__(64) k_recon_dct8_b(const DevBuffers *Bs, const
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != 0) continue;
     __syncthreads();
     recon_dct8_block(B, stat, ST, S, T, cell % F.xb, by, lane, cx8, cy8);
+  }
+}
+// DCT16x16, DCT16x8, DCT8x16 — with DCT8x8 the bulk of the varblocks of photographic content (the reference's 4K demo photograph: 9 700
+// DCT16x16, 2 800 16x8 / 8x16, 1 800 DCT8x8, 4 400 DCT32x32).  One wave per block; lane = column x of a group of R C / 64 consecutive rows,
+// so that the 1-D passes are register-blocked (one cosine value / one T value feeds R C / 64 multiply-adds) with both cosine tables in
+// LDS; all coefficient loads of the block are issued up front.  Same operations in the same order as the generic path
+// (recon_phaseA / recon_phaseB / recon_idct_pass1 / recon_idct_pass2, incl. the transposed storage of blocks with R >= C).
+template <int R, int C>
+__device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, const float *ccC, const float *crR,
+                                                   int st, int bx, int by, int lane) {
+  constexpr int N = R * C, NJ = N / 64;
+  const DevFrame &F = frame_of(B);
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  const int qt = kQuantTableOf[st];
+  const int g = (by / 32) * F.xgroups + (bx / 32);
+  uint32_t off = B.coef_off[o];
+  if (off + (uint32_t)N > 65536u) { if (lane == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
+  int q[3][NJ]; float w[3][NJ];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { q[c][j] = B.coef[c][(size_t)g * 65536 + off + (uint32_t)(lane + 64 * j)]; w[c][j] = st_f(stat, ST.qw_off[qt][c])[lane + 64 * j]; }
+  const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
+  const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
+  const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
+  const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int k = lane + 64 * j;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int qq = q[c][j];
+      if (qq != 0) B.coef[c][(size_t)g * 65536 + off + (uint32_t)k] = 0;     // consumed exactly once: the reader clears it
+      float a;
+      if (qq == 0) a = 0.0f;
+      else if (qq == 1) a = F.quant_bias[c];
+      else if (qq == -1) a = -F.quant_bias[c];
+      else a = (float)qq - F.quant_bias[3] / (float)qq;
+      v[c] = a * (mul * F.dm[c] * w[c][j]);
+    }
+    S[k] = v[0] + kx * v[1];
+    S[N + k] = v[1];
+    S[2 * N + k] = v[2] + kb * v[1];
+  }
+  __syncthreads();
+  recon_phaseB(B, stat, ST, S, N, bx, by, lane, 64);          // the LLF corner (C / 8 x R / 8 values per channel) overwrites its positions
+  __syncthreads();
+  const int x = lane % C, r0 = (lane / C) * NJ;                // this lane: column x, rows r0 .. r0 + NJ - 1 of both passes
+  float acc[3][NJ];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[c][j] = 0.0f;
+#pragma unroll 4
+  for (int u = 0; u < C; u++) {
+    const float ccv = ccC[u * C + x];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[c][j] += (R < C ? S[c * N + (r0 + j) * C + u] : S[c * N + u * R + r0 + j]) * ccv;      // T[v][x], v = r0 + j
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { T[c * N + (r0 + j) * C + x] = acc[c][j]; acc[c][j] = 0.0f; }
+  __syncthreads();
+#pragma unroll 4
+  for (int v = 0; v < R; v++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float tv = T[c * N + v * C + x];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[c][j] += tv * crR[v * R + r0 + j];              // out[y][x], y = r0 + j
+    }
+  }
+  const size_t po = (size_t)(by * 8 + r0) * (size_t)F.pw + (size_t)(bx * 8 + x);
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
+}
+template <int R, int C, int STRAT>
+__global__ void __launch_bounds__(64) k_recon_dct_rc_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) float S[3 * R * C];
+  __shared__ __attribute__((aligned(16))) float T[3 * R * C];
+  __shared__ __attribute__((aligned(16))) float ccC[C * C];
+  __shared__ __attribute__((aligned(16))) float crR[R * R];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  const uint32_t count = B.big_count[2];
+  if (blockIdx.x >= count) return;
+  const int lane = (int)threadIdx.x;
+  const DevStatic &ST = *(const DevStatic *)stat;
+  for (int i = lane; i < C * C; i += 64) ccC[i] = st_f(stat, ST.cos_off[C == 8 ? 3 : 4])[i];
+  for (int i = lane; i < R * R; i += 64) crR[i] = st_f(stat, ST.cos_off[R == 8 ? 3 : 4])[i];
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    const int cell = (int)B.big_list[2][i];
+    const int by = cell / F.xb;
+    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != STRAT) continue;
+    __syncthreads();
+    recon_dct_rc_block<R, C>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
   }
 }
 // General medium / large list walker (JXLAMD_DCT32_SPLIT=0 or the VALU DCT32 passes; the default path uses k_recon_dct32_b, k_recon_medium_pc_b
@@ -457,7 +560,12 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   static const int dct8_own = getenv("JXLAMD_DCT8_SPLIT") ? atoi(getenv("JXLAMD_DCT8_SPLIT")) : 1;       // 0: k_recon_small_b handles DCT8x8 too
   const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes);
-  if (dct8_own) hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
+  if (dct8_own) {
+    hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
+    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4>), gs, dim3(64), 0, s, Bs, stat);      // AcStrategy 4: DCT16x16
+    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6>), gs, dim3(64), 0, s, Bs, stat);       // 6: DCT16x8 (16 rows x 8 columns)
+    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7>), gs, dim3(64), 0, s, Bs, stat);       // 7: DCT8x16
+  }
   hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, dct8_own);
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
   // JXLAMD_RECON_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 32 KB — an occupancy experiment knob, no functional effect
