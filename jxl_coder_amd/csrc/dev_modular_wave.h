@@ -624,6 +624,34 @@ __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, De
   }
 }
 
+// Global-tree frames (libjxl's non-streaming encoder: one MA tree and one code for ALL Modular streams of the frame, 39 clusters in the
+// reference's demo photographs) do not fit the LDS table pool whole, but a channel only uses the clusters of its own leaves: stage those
+// 8-byte alias tables compactly, with the context-map entries of the leaves and the hybrid-uint configs renumbered to match, so that the
+// lock-step loops run in their LDS (kLds) form.  Returns false when even the compact set does not fit (pool untouched).
+__device__ __forceinline__ bool wave_restage_compact(const DevECView &g, int num_ctx, DevModScratch &S, const DevWaveTree &WT, int lane, uint64_t *used_out) {
+  const int nl = WT.nl, la = g.log_alpha;
+  const int my_ctx = lane < nl ? WT.leaf_ctx[lane] : 0;
+  const int my_clu = lane < nl ? (int)g.ctx_map[my_ctx] : 0;
+  uint64_t used = 0;
+  for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_clu, j) & 63);
+  const int nc = __builtin_popcountll(used);
+  const int alias_bytes = nc * (8 << la), ctx_bytes = (num_ctx + 7) & ~7;
+  if (g.use_prefix || alias_bytes + ctx_bytes > kModPoolBytes) return false;
+  __syncthreads();
+  DevAlias *dst = (DevAlias *)S.pool;
+  int cid = 0;
+  for (uint64_t m = used; m; m &= m - 1, cid++) {
+    const int s = __builtin_ctzll(m);
+    for (int i = lane; i < (1 << la); i += 64) dst[(cid << la) + i] = g.alias[(s << la) + i];
+    if (lane == 0) S.cfg[cid] = g.cfg[s];
+  }
+  if (lane < nl) ((uint8_t *)S.pool)[alias_bytes + my_ctx] = (uint8_t)__builtin_popcountll(used & ((1ull << (my_clu & 63)) - 1ull));
+  if (lane == 0) S.ctx_off = alias_bytes;
+  __syncthreads();
+  *used_out = used;
+  return true;
+}
+
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 template <bool kLds>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
@@ -669,7 +697,7 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
         const int cid = __builtin_popcountll(used & ((1ull << (clu & 63)) - 1ull));      // compact index of the cluster in the packed pool
-        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + (cid << 8); my_cfg = (int)S.cfg[clu]; }
+        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + (cid << 8); my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
       }
       __syncthreads();
       // row 0 goes through the generic loop (every neighbour is the late value W there); once the pool holds packed tables
@@ -687,13 +715,24 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
       }
     }
+    // the LDS (kLds) form of the remaining loops needs the stream's tables in the pool: there from modular_stream_stage, or staged
+    // compactly for this channel now
+    bool lds_now = kLds && !pool_packed;
+    uint64_t used = 0;
+    bool compact = false;
+    if (!lds_now && !ev.use_prefix && S.st.num_clusters <= kLocMaxClusters && WT.nl >= 1 && WT.nl <= 64 &&
+        wave_restage_compact(S.st.ev, S.st.num_ctx, S, WT, lane, &used)) {
+      lds_now = true; compact = true; pool_packed = true;
+      evg.cfg = S.st.ev.cfg;                        // S.cfg now holds the compact renumbering
+    }
     // uniform-leaf channel (see wave_decode_channel_uniform)
     if (!ev.use_prefix && WT.nl >= 1 && WT.nl <= 64) {
       const int nl = WT.nl;
-      const int my_clu = lane < nl ? (int)evg.ctx_map[WT.leaf_ctx[lane]] : -1;
+      const int my_clu = lane < nl ? (int)S.st.ev.ctx_map[WT.leaf_ctx[lane]] : -1;
       const int clu0 = __builtin_amdgcn_readfirstlane(my_clu);
       if (__ballot(lane < nl && (my_clu != clu0 || WT.leaf_pred[lane] != 0 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
-        if (kLds && !pool_packed) wave_decode_channel_uniform<true>(ev, b, state, S, c, lane, (uint32_t)clu0);
+        const int cl = compact ? __builtin_popcountll(used & ((1ull << (clu0 & 63)) - 1ull)) : clu0;
+        if (lds_now) wave_decode_channel_uniform<true>(ev, b, state, S, c, lane, (uint32_t)cl);
         else wave_decode_channel_uniform<false>(evg, b, state, S, c, lane, (uint32_t)clu0);
         continue;
       }
@@ -704,18 +743,18 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       const bool preds_ok = __ballot(lane < WT.nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 2)) == 0;
       const bool needs_n = __ballot((lane < WT.ni && (WT.int_prop[lane] == 4 || WT.int_prop[lane] == 6)) || (lane < WT.nl && WT.leaf_pred[lane] == 2)) != 0;
       if (props_ok && preds_ok && (!needs_n || c.w <= kModMaxW)) {
-        if (kLds && !pool_packed) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n);
+        if (lds_now) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n);
         else wave_decode_channel_lean<false>(evg, b, state, S, WT, c, lane, needs_n);
         continue;
       }
     }
-    if (pool_packed) {            // the pool no longer holds this stream's 8-byte alias tables / context map
+    if (lds_now) {
+      if (m16) { if (uses_wp) wave_decode_channel<true, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<true, true, false>(ev, b, state, wp, S, WT, c, lane); }
+      else { if (uses_wp) wave_decode_channel<true, false, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<true, false, false>(ev, b, state, wp, S, WT, c, lane); }
+    } else {        // the tables stay in HBM / L2
       if (m16) { if (uses_wp) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane); else wave_decode_channel<false, true, false>(evg, b, state, wp, S, WT, c, lane); }
       else { if (uses_wp) wave_decode_channel<false, false, true>(evg, b, state, wp, S, WT, c, lane); else wave_decode_channel<false, false, false>(evg, b, state, wp, S, WT, c, lane); }
-      continue;
     }
-    if (m16) { if (uses_wp) wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, true, false>(ev, b, state, wp, S, WT, c, lane); }
-    else { if (uses_wp) wave_decode_channel<kLds, false, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<kLds, false, false>(ev, b, state, wp, S, WT, c, lane); }
   }
   return 0;
 }
