@@ -705,13 +705,11 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       if (pool_packed) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane, /*y_end=*/1);
       else wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
       __syncthreads();
-      const bool was_packed = pool_packed;
       pool_packed = true;                              // whatever happens next, the pool no longer holds the stream's 8-byte tables / context map
       if (wave_pack_alias(evg.alias, used, la_p, S, lane)) {   // per channel: the set of clusters may differ
         wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1);
         continue;
       }
-      (void)was_packed;
       return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
       }
     }
