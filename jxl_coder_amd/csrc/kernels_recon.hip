@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
-    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || st == 6 || st == 7) continue; }      // k_recon_dct8_b / k_recon_dct_rc_b have reconstructed it
+    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_dct8_b / k_recon_dct_rc_b have reconstructed it
     __syncthreads();
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
@@ -447,7 +447,7 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
 #pragma unroll
     for (int j = 0; j < NJ; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
 }
-template <int R, int C, int STRAT>
+template <int R, int C, int STRAT, int LIST>      // LIST: the size-class list the strategy's blocks are on (2: <= 256 coefficients, 0: 512 / 1024)
 __global__ void __launch_bounds__(64) k_recon_dct_rc_b(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) float S[3 * R * C];
   __shared__ __attribute__((aligned(16))) float T[3 * R * C];
@@ -456,14 +456,14 @@ __global__ void __launch_bounds__(64) k_recon_dct_rc_b(const DevBuffers *Bs, con
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
-  const uint32_t count = B.big_count[2];
+  const uint32_t count = B.big_count[LIST];
   if (blockIdx.x >= count) return;
   const int lane = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
-  for (int i = lane; i < C * C; i += 64) ccC[i] = st_f(stat, ST.cos_off[C == 8 ? 3 : 4])[i];
-  for (int i = lane; i < R * R; i += 64) crR[i] = st_f(stat, ST.cos_off[R == 8 ? 3 : 4])[i];
+  for (int i = lane; i < C * C; i += 64) ccC[i] = st_f(stat, ST.cos_off[C == 8 ? 3 : C == 16 ? 4 : 5])[i];
+  for (int i = lane; i < R * R; i += 64) crR[i] = st_f(stat, ST.cos_off[R == 8 ? 3 : R == 16 ? 4 : 5])[i];
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[2][i];
+    const int cell = (int)B.big_list[LIST][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != STRAT) continue;
     __syncthreads();
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 }
 // The 512 / 1024-coefficient blocks that are NOT DCT32x32 (DCT16x32, 32x16, 8x32, ... — a few per cent of the blocks), one channel at a
 // time: 8 KB of LDS instead of the general medium kernel's 33 KB, so that this short launch is not kept waiting for LDS by resident LF waves.
-__global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs, const uint8_t *stat, int skip_rc) {
   __shared__ __attribute__((aligned(16))) float S[1024];
   __shared__ __attribute__((aligned(16))) float T[1024];
   const DevBuffers &B = Bs[blockIdx.z];
@@ -528,7 +528,8 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs,
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
     const int cell = (int)B.big_list[0][i];
     const int bx = cell % xb, by = cell / xb;
-    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] == kStrategyDct32) continue;
+    const int st = B.strategy[cell];
+    if (by < F.band_cy0 || by >= F.band_cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_dct_rc_b
     __syncthreads();
     recon_block_body<false, true>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
   }
@@ -562,9 +563,11 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes);
   if (dct8_own) {
     hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
-    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4>), gs, dim3(64), 0, s, Bs, stat);      // AcStrategy 4: DCT16x16
-    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6>), gs, dim3(64), 0, s, Bs, stat);       // 6: DCT16x8 (16 rows x 8 columns)
-    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7>), gs, dim3(64), 0, s, Bs, stat);       // 7: DCT8x16
+    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4, 2>), gs, dim3(64), 0, s, Bs, stat);     // AcStrategy 4: DCT16x16
+    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6, 2>), gs, dim3(64), 0, s, Bs, stat);      // 6: 16 rows x 8 columns
+    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7, 2>), gs, dim3(64), 0, s, Bs, stat);      // 7: 8 x 16
+    hipLaunchKernelGGL((k_recon_dct_rc_b<32, 8, 8, 2>), gs, dim3(64), 0, s, Bs, stat);      // 8: 32 x 8
+    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 32, 9, 2>), gs, dim3(64), 0, s, Bs, stat);      // 9: 8 x 32
   }
   hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, dct8_own);
   static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
@@ -574,7 +577,11 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   const int dct32_own = use_mfma && split;
   if (dct32_own) {
     hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
-    hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+    if (dct8_own) {                                   // the 512-coefficient rectangles of the medium list
+      hipLaunchKernelGGL((k_recon_dct_rc_b<32, 16, 10, 0>), gs, dim3(64), 0, s, Bs, stat);    // 10: 32 x 16
+      hipLaunchKernelGGL((k_recon_dct_rc_b<16, 32, 11, 0>), gs, dim3(64), 0, s, Bs, stat);    // 11: 16 x 32
+    }
+    hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, dct8_own);
     // the 2048 / 4096-coefficient list: its own launch; one workgroup per frame when the previous flight had none
     hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
     return;
