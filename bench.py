@@ -82,8 +82,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per step (BASELINE configs[2]: 256 x 3840x2160 q90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contexts", type=int, default=10, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
-    ap.add_argument("--inflight", type=int, default=128, help="frames decoded per batched flight (1 = strictly sequential)")
+    ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
+    ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
