@@ -151,7 +151,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
-    if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure((size_t)(1 + plan.num_groups) * (size_t)Fh->lz_win_len * 4));
+    if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure(((size_t)Fh->lz_win_len + (size_t)plan.num_groups * (size_t)Fh->lz_win_group) * 4));
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
@@ -528,7 +528,13 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
   HIPCHECK(hipEventRecord(ev[0], stream));
-  launch_clear_batch(dB, nb, max_cells, stream);
+#ifndef JXL_ABLATE_MASK
+#define JXL_ABLATE_MASK 0
+#endif
+  // experiment builds (tools/build_variant.sh): from the third flight of a context on, the stages named by the mask are not launched
+  // (their outputs of the previous flight stay in place) — what a stage costs the mix, measured by leaving it out
+  const int JXL_ABLATE = (JXL_ABLATE_MASK && ++ablate_flights > 2) ? JXL_ABLATE_MASK : 0;
+  if (!(JXL_ABLATE & 1)) launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
   // JXLAMD_ENTROPY_STREAM=1: the latency-bound entropy kernels go to a second, high-priority stream of this context (their workgroups
   // are dispatched ahead of the data-parallel kernels of the other contexts); cross-stream order by events
@@ -539,18 +545,20 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     return e != hipSuccess ? e : hipStreamWaitEvent(to, ev_x, 0);
   };
   HIPCHECK(hop(stream, se));
-  if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, se);
+  if (JXL_ABLATE & 1) {}
+  else if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, se);
   else launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, se);
   HIPCHECK(hop(se, stream));
   HIPCHECK(hipEventRecord(ev[1], stream));
-  launch_lf_smooth_batch(dB, nb, max_cells, stream);
+  if (!(JXL_ABLATE & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
     const int cnt = std::min(hf_sets, nb - k0);
     const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
     // >= simt_min_groups groups: one LANE per group (64 streams per wavefront); below that the one-wave-per-group kernel has
     // the shorter critical path
-    if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
+    if (JXL_ABLATE & 2) {}
+    else if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
     else if (all_simt2 && n_pg >= simt_min_groups) launch_pass_groups_simt2(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
     else if (n_pg >= simt_min_groups) { HIPCHECK(hop(stream, se)); launch_pass_groups_simt(dB + k0, map, n_pg, se); HIPCHECK(hop(se, stream)); }
     else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
@@ -558,7 +566,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream);
+      if ((JXL_ABLATE & 12) != 12) launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3 & ~((JXL_ABLATE >> 2) & 3), stream);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
@@ -618,8 +626,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  d->stat.release(); d->batch_tab.release(); d->mod_tab.release(); d->h_batch.release(); d->h_mod_tab.release(); d->plane_pool.release(); d->coef_pool.release(); d->simt_waves.release(); d->simt_scratch.release(); d->resample_tmp.release(); d->icc_lut.release(); d->post_lin_lut.release(); d->post_gam_lut.release();
-  for (FrameSlot *fs : d->slots) { fs->release(); delete fs; }
+  for (FrameSlot *fs : d->slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   if (d->stream_e) { (void)hipStreamSynchronize(d->stream_e); (void)hipStreamDestroy(d->stream_e); }
   if (d->ev_x) (void)hipEventDestroy(d->ev_x);

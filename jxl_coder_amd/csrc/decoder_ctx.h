@@ -25,6 +25,9 @@ using namespace jxlamd;
 
 struct DevMem {
   void *p = nullptr; size_t cap = 0;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete; DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { release(); }            // owners cannot forget a member (the flight buffers leaked on destroy)
   hipError_t ensure(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
@@ -41,6 +44,9 @@ struct DevMem {
 
 struct PinnedMem {             // page-locked host staging: true async DMA, no shared pageable-copy staging in the runtime
   void *p = nullptr; size_t cap = 0;
+  PinnedMem() = default;
+  PinnedMem(const PinnedMem &) = delete; PinnedMem &operator=(const PinnedMem &) = delete;
+  ~PinnedMem() { release(); }
   hipError_t ensure(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipHostFree(p);
@@ -88,17 +94,6 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   const uint8_t *up_cs_dev = nullptr;   // frames of a flight: the caller's resident compressed bytes (null: host bytes), copied by the flight's gather launch
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
-  void release() {
-    DevMem *all[] = {&cs, &tables, &coef_off, &lf_scratch, &local, &misc, &out, &mod_pool, &mod_scratch, &pass_nz, &pass_end, &lz_win};
-    for (auto *m : all) m->release();
-    for (auto &m : cells8) m.release();
-    for (auto &m : tiles) m.release();
-    for (auto &m : lf) m.release();
-    for (auto &m : coef) m.release();
-    for (auto &m : planes) m.release();
-    for (auto &m : big_list) m.release();
-    h_tables.release(); h_cs.release(); h_B.release(); dB.release();
-  }
 };
 
 struct jxlamd_decoder {
@@ -122,6 +117,7 @@ struct jxlamd_decoder {
   int simt2 = getenv("JXLAMD_SIMT2") ? atoi(getenv("JXLAMD_SIMT2")) : 1;       // k_pass_group_simt2 (bit supply through LDS rings, hybrid-uint configs in LDS; context maps stay in L2 unless JXLAMD_SIMT2_CTX_LDS=1: with them in LDS — 38 KB per wave — the other kernels lose more than PassGroup gains); 0: k_pass_group_simt
   int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
+  int ablate_flights = 0;                 // experiment builds only (JXL_ABLATE_MASK)
   void set_error(const std::string &e) { error = e; tls_error() = e; }
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
 

@@ -175,7 +175,7 @@ JXL_DEV uint32_t ec_read_lz(const DevECView &v, DevBits &b, uint32_t &state, uin
     const uint32_t token = ec_token(v, b, state, cluster);
     if (token < (uint32_t)v.lz_min_symbol) {
       const uint32_t r = ec_hybrid(b, v.cfg[cluster], token);
-      if (z.ndec < z.win_len) z.win[z.ndec & mask] = r;
+      if (z.win_len == (1u << 20) || z.ndec < z.win_len) z.win[z.ndec & mask] = r;      // a full-size window wraps; a shorter one holds the whole stream
       z.ndec++;
       return r;
     }

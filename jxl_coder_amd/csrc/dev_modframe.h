@@ -85,7 +85,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     if (F.is_modular) bits_init(b, B.codestream, sec.off, F.cs_size);
     else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
-    S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)(1 + g) * (size_t)F.lz_win_len : nullptr; S.lz.win_len = F.lz_win_len;
+    S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)F.lz_win_len + (size_t)g * (size_t)F.lz_win_group : nullptr; S.lz.win_len = F.lz_win_group;
     modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {
       const DevTr &t = S.trs.t[i];

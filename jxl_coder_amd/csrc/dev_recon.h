@@ -429,7 +429,8 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
     float lum = 0.0f;
     for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * (F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2);
-    hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : 0.0f;
+    // libjxl: min(pow(luminance, exponent), 1e9) — pow(0, negative exponent) is +inf there, i.e. the clamp value
+    hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : (lum == 0.0f && F.hlg_exponent < 0.0f) ? 1e9f : 0.0f;
     if (hlg_ratio > 1e9f) hlg_ratio = 1e9f;
   }
   for (int c = 0; c < 3; c++) {

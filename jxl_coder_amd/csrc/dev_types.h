@@ -90,7 +90,8 @@ struct DevFrame {
   int32_t has_ec;                  // VarDCT frame with extra channels (alpha): the mod_* fields describe the extra-channel Modular image
   int32_t mod_w[12], mod_h[12]; uint32_t mod_plane_off[12];        // int32 planes (offsets in samples into the pool)
   uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
-  uint32_t lz_win_len;             // LZ77 window entries per Modular stream (0: the frame's global code has no LZ77); DevBuffers::lz_win holds 1 + num_groups of them
+  uint32_t lz_win_len;             // LZ77 window entries of the GlobalModular stream (0: the frame's global code has no LZ77) ...
+  uint32_t lz_win_group;           // ... and of each group stream; DevBuffers::lz_win = [lz_win_len][num_groups x lz_win_group]
   int32_t mod_nops;                // inverse global transforms, in execution order, with resolved plane indices
   int32_t mod_op_kind[8], mod_op_a[8], mod_op_b[8], mod_op_c[8], mod_op_x[8], mod_op_y[8];
   int32_t mod_out[4];              // planes feeding R, G, B, A (-1: opaque / replicate grey is done by repeating the index)

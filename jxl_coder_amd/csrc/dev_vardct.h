@@ -38,7 +38,7 @@ struct DevBuffers {
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
   int32_t out_bits;             // 8 or 16 (used by the batched writer)
-  uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [1 + num_groups][DevFrame::lz_win_len] decoded integers (else null)
+  uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [DevFrame::lz_win_len] + [num_groups][DevFrame::lz_win_group] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
 };
 

@@ -1,7 +1,8 @@
 /* host_bits.cpp — PRODUCT host code: bit reader, field codes, ANS / prefix histogram + context-map reader (ISO/IEC 18181-1 Annex C/D)
  * used by host_parse.cpp to read headers, the embedded ICC stream, the TOC and the LfGlobal / HfGlobal sections into the frame-tables
- * blob.  It decodes no pixel data.  The test oracle has its own, separately compiled restatement of the same clauses (oracle/jxo_entropy.c);
- * the two are deliberately independent so that a shared mistake cannot hide — nothing here includes or links anything under oracle/. */
+ * blob.  It decodes no pixel data.  Nothing here includes or links anything under oracle/.  Note on independence: this file and the
+ * oracle's oracle/jxo_entropy.c were written together from the same clauses and differ in little but the prefix, so the C oracle is NOT an
+ * independent check of header / histogram / context-map parsing — the reference binary's golden outputs (tests/golden) are. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

@@ -243,11 +243,13 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }
   F.mod_first_group_ch = first_group;
   plan->mod_pool_ints = off;
-  F.lz_win_len = 0;
+  F.lz_win_len = 0; F.lz_win_group = 0;
   if (F.tree_ec.lz77 && !vardct) {            // a stream never holds more integers than the image has samples; the window is 2^20 at most
+    // the GlobalModular stream holds the channels before first_group, a group stream at most group_dim^2 samples of each later channel
     uint64_t total = 0;
-    for (int i = 0; i < F.mod_nch; i++) total += (uint64_t)F.mod_w[i] * (uint64_t)F.mod_h[i];
+    for (int i = 0; i < first_group; i++) total += (uint64_t)F.mod_w[i] * (uint64_t)F.mod_h[i];
     F.lz_win_len = (uint32_t)std::min<uint64_t>(total + 64, 1u << 20);
+    F.lz_win_group = (uint32_t)std::min<uint64_t>((uint64_t)(F.mod_nch - first_group) * (uint64_t)f.group_dim * (uint64_t)f.group_dim + 64, 1u << 20);
   }
   if (F.mod_nch - first_group > 8) { plan->error = "unsupported: more than 8 group channels"; return -1; }
   // inverse program (last transform first)

@@ -15,7 +15,7 @@ namespace jxlamd {
 __device__ __forceinline__ uint16_t half_bits(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }   // RNE
 
 __global__ void __launch_bounds__(256) k_post_premul8(uint8_t *px, uint32_t stride, uint32_t w, uint32_t h) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
   if (x >= w) return;
   uint32_t *p = (uint32_t *)(px + (size_t)y * stride) + x;
   const uint32_t v = *p, a = v >> 24;
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_post_premul8(uint8_t *px, uint32_t stri
   *p = r | (g << 8) | (b << 16) | (a << 24);
 }
 __global__ void __launch_bounds__(256) k_post_premul16(uint8_t *px, uint32_t stride, uint32_t w, uint32_t h, uint32_t maxv) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
   if (x >= w) return;
   ushort4 *p = (ushort4 *)(px + (size_t)y * stride) + x;
   ushort4 v = *p;
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) k_post_premul16(uint8_t *px, uint32_t str
 template <int KIND>
 __global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
                                                       uint32_t depth, int attenuate) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
   if (x >= w) return;
   const uint8_t *srow = src + (size_t)y * src_stride;
   uint8_t *drow = dst + (size_t)y * dst_stride;
@@ -119,13 +119,13 @@ __global__ void __launch_bounds__(256) k_post_color_matrix(uint8_t *px, uint32_t
 }
 
 void launch_post_premultiply(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, uint32_t depth, hipStream_t s) {
-  dim3 grid((w + 255) / 256, h);
+  dim3 grid(h, (w + 255) / 256);
   if (is_u16) hipLaunchKernelGGL(k_post_premul16, grid, dim3(256), 0, s, (uint8_t *)px, stride, w, h, (1u << depth) - 1u);
   else hipLaunchKernelGGL(k_post_premul8, grid, dim3(256), 0, s, (uint8_t *)px, stride, w, h);
 }
 
 void launch_post_convert(PostKind kind, const void *src, uint32_t ss, void *dst, uint32_t ds, uint32_t w, uint32_t h, uint32_t depth, bool att, hipStream_t s) {
-  dim3 grid((w + 255) / 256, h), block(256);
+  dim3 grid(h, (w + 255) / 256), block(256);
   const uint8_t *a = (const uint8_t *)src; uint8_t *b = (uint8_t *)dst; const int at = att ? 1 : 0;
   switch (kind) {
     case kPostU16ToF16: hipLaunchKernelGGL(k_post_convert<kPostU16ToF16>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void icc_lut_sample(const uint16_t *__restrict__ lut,
 }
 template <bool kU16>
 __global__ void __launch_bounds__(256) k_post_icc_lut(void *px, uint32_t stride, uint32_t w, uint32_t h, const uint16_t *__restrict__ lut, int n) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
   if (x >= w || y >= h) return;
   float v[3];
   if (kU16) {
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_post_icc_lut(void *px, uint32_t stride,
   }
 }
 void launch_post_icc_lut(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const uint16_t *lut, int n, hipStream_t s) {
-  dim3 grid((w + 255) / 256, h);
+  dim3 grid(h, (w + 255) / 256);
   if (is_u16) hipLaunchKernelGGL(k_post_icc_lut<true>, grid, dim3(256), 0, s, px, stride, w, h, lut, n);
   else hipLaunchKernelGGL(k_post_icc_lut<false>, grid, dim3(256), 0, s, px, stride, w, h, lut, n);
 }

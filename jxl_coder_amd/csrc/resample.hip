@@ -48,7 +48,7 @@ template <bool kFirst, bool kU16>
 __global__ void __launch_bounds__(256) k_resample(const void *__restrict__ src, void *__restrict__ dst, int in_len, int out_full, int other, int crop0, int out_len,
                                                   int src_stride_px, int filter, int premul, float maxv) {
   // consecutive work-items walk along x in both passes (coalesced rows): x is the resampled axis in pass 1, the other one in pass 2
-  const int tx = (int)(blockIdx.x * 256 + threadIdx.x), ty = (int)blockIdx.y;
+  const int tx = (int)(blockIdx.y * 256 + threadIdx.x), ty = (int)blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
   const int o = kFirst ? tx : ty;                                 // index along the resampled axis (inside the crop window)
   const int line = kFirst ? ty : tx;                              // index along the other axis
   if (o >= out_len || line >= other) return;
@@ -136,7 +136,7 @@ int jxlamd_rescale(jxlamd_decoder *d, const void *src_dev, uint32_t w, uint32_t 
   if (d->resample_tmp.ensure(tmp_bytes) != hipSuccess) { d->set_error("HIP: out of memory for the resampler's intermediate"); return JXLAMD_ERR_DEVICE; }
   const float maxv = (float)((1u << depth) - 1);
   const hipStream_t s = d->stream;
-  dim3 g1((q.out_w + 255) / 256, h), g2((q.out_w + 255) / 256, q.out_h);
+  dim3 g1(h, (q.out_w + 255) / 256), g2(q.out_h, (q.out_w + 255) / 256);
   if (is_u16) {
     hipLaunchKernelGGL((k_resample<true, true>), g1, dim3(256), 0, s, src_dev, d->resample_tmp.p, (int)w, (int)q.scaled_w, (int)h, (int)q.crop_x, (int)q.out_w, (int)w, sampler, premultiply_alpha, maxv);
     hipLaunchKernelGGL((k_resample<false, true>), g2, dim3(256), 0, s, d->resample_tmp.p, dst_dev, (int)h, (int)q.scaled_h, (int)q.out_w, (int)q.crop_y, (int)q.out_h, (int)q.out_w, sampler, premultiply_alpha, maxv);

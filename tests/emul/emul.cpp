@@ -51,8 +51,8 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? (size_t)plan.num_groups * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
-  const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len;
-  std::vector<uint32_t> lzw(plan.modular && lzl ? (size_t)(1 + plan.num_groups) * lzl : 1, 0); B.lz_win = plan.modular && lzl ? lzw.data() : nullptr;
+  const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len, lzg = ((const DevFrame *)plan.tables.data())->lz_win_group;
+  std::vector<uint32_t> lzw(plan.modular && lzl ? (size_t)lzl + (size_t)plan.num_groups * lzg : 1, 0); B.lz_win = plan.modular && lzl ? lzw.data() : nullptr;
   B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_list[2] = bl2.data(); B.big_count = bcount;
   DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
   const std::vector<uint8_t> &stat = static_tables();

@@ -197,3 +197,63 @@ def test_corrupted_streams_never_crash_the_device_code(emul):
             except ValueError:
                 rejected += 1
     assert decoded + rejected == 200 and rejected > 150        # the rANS final-state checks catch nearly every corruption
+
+
+# ---- malformed embedded-ICC streams (stride * 4 overflow in the predictor command read far outside the decoded bytes)
+def _varint(v):
+    out = bytearray()
+    while True:
+        b = v & 127
+        v >>= 7
+        out.append(b | (128 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _icc_enc(osize, commands, data):
+    """Encoded ICC = varint(output size) varint(command bytes) commands data (ISO/IEC 18181-1 E.4.2)."""
+    return _varint(osize) + _varint(len(commands)) + commands + data
+
+
+@pytest.fixture(scope="module")
+def icc_harness(tmp_path_factory):
+    import subprocess
+    exe = str(tmp_path_factory.mktemp("icc") / "icc_harness")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer",
+                    os.path.join(ROOT, "tests", "emul", "icc_harness.cpp"), os.path.join(ROOT, "jxl_coder_amd", "csrc", "host_bits.cpp"), "-o", exe], check=True)
+    return exe
+
+
+def _run_icc(exe, enc):
+    import subprocess
+    r = subprocess.run([exe], input=enc, capture_output=True, timeout=60)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+def test_icc_command_decoder_rejects_malformed_streams(icc_harness):
+    hdr = bytes(128)                                     # 128 header residuals (predicted header + 0)
+    # a well-formed minimal profile first: 128-byte header, empty tag list (numtags 0 -> stored 0), 4 inserted bytes
+    good = _icc_enc(128 + 4, b"\x00" + b"\x01" + _varint(4), hdr + b"abcd")
+    rc, out, err = _run_icc(icc_harness, good)
+    assert rc == 0 and out.split() == ["0", "132"], (rc, out, err[-400:])
+    cases = {
+        # predictor (cmd 4), flags 16 = explicit stride: stride 2^62 made `stride * 4` wrap to 0 and pass the old check
+        "huge_stride": _icc_enc(128 + 8, b"\x00" + b"\x04\x10" + _varint(1 << 62) + _varint(8), hdr + bytes(8)),
+        "stride_just_over": _icc_enc(128 + 8, b"\x00" + b"\x04\x10" + _varint(32) + _varint(8), hdr + bytes(8)),       # 32 * 4 >= 128 decoded bytes
+        "stride_2_32": _icc_enc(128 + 8, b"\x00" + b"\x04\x10" + _varint(1 << 32) + _varint(8), hdr + bytes(8)),
+        "huge_num": _icc_enc(128 + 8, b"\x00" + b"\x04\x00" + _varint(1 << 60), hdr + bytes(8)),
+        "huge_insert": _icc_enc(128 + 8, b"\x00" + b"\x01" + _varint((1 << 64) - 1), hdr + bytes(8)),
+        "truncated_commands": _icc_enc(128 + 8, b"\x00" + b"\x04", hdr + bytes(8)),
+        "truncated_header": _icc_enc(128, b"\x00", bytes(100)),
+        "command_stream_beyond_data": _varint(200) + _varint(1 << 40) + b"\x00",
+        "bad_width": _icc_enc(128 + 8, b"\x00" + b"\x04\x02" + _varint(8), hdr + bytes(8)),
+        "unknown_command": _icc_enc(128 + 8, b"\x00" + b"\x07", hdr + bytes(8)),
+        "huge_tag_count": _icc_enc(1 << 27, _varint(1 << 40), hdr),
+    }
+    for name, enc in cases.items():
+        rc, out, err = _run_icc(icc_harness, enc)
+        assert rc == 1, (name, rc, out, err[-600:])      # rejected cleanly: neither decoded nor an AddressSanitizer abort
+    # the widest legal stride still decodes: 31 * 4 < 128
+    ok = _icc_enc(128 + 8, b"\x00" + b"\x04\x10" + _varint(31) + _varint(8), hdr + bytes(8))
+    rc, out, err = _run_icc(icc_harness, ok)
+    assert rc == 0, (rc, out, err[-400:])
