@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — decoded MP/s of the JPEG XL decode hot path on MI355X (BASELINE.json metric).
 
-Workload at N=1: BASELINE.json configs[2] — a batch of 256 x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8
-(8 distinct seeded frames cycled).  A "step" = one such batch; every frame is a full decode: host header/TOC/global-table parse,
-H2D of the frame tables, all HIP kernels (LF/modular + AC entropy decode, dequant + inverse DCT, Gaborish/EPF, XYB->RGBA).  The
-compressed bytes and the RGBA output are resident in HBM (jxlamd_decode_batch_resident + JXLAMD_OUT_DEVICE); nothing is cached
+Workload at N=1: BASELINE.json configs[2] — a batch of 256 x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8,
+256 DISTINCT seeded frames encoded on this box by the reference's own encoder before anything is timed
+(tools/make_bench_frames.py; the 8 committed frames of bench_data/ are cycled only if that encoder is unavailable — the line says which).
+A "step" = one such batch; every frame is a full decode: host header/TOC/global-table parse, H2D of the frame tables, all HIP kernels
+(LF/modular + AC entropy decode, dequant + inverse DCT, Gaborish/EPF, XYB->RGBA).  `value`: the compressed bytes and the RGBA output are
+resident in HBM (jxlamd_decode_batch_resident + JXLAMD_OUT_DEVICE); the same steps with the compressed bytes handed over as HOST buffers
+(their H2D inside the timed region) are timed right after and reported as `config.h2d_included_MPps`.  Nothing is cached
 between frames or steps.  The strictly sequential single-frame latency (configs[1]) is reported in `config`.
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank decodes its own frames — independent
 units, no data-path collective — weak scaling; value = frames of all ranks / max-over-ranks time.
@@ -25,6 +28,22 @@ if os.environ.get("JXLAMD_BENCH_FILES"):          # experiments on other content
     FRAMES = [os.path.join(ROOT, f) for f in os.environ["JXLAMD_BENCH_FILES"].split(",")]
 FRAMES = [f for f in FRAMES if os.path.exists(f)]
 FRAME = FRAMES[0]
+
+
+def distinct_frames(n, budget_s=420):
+    """n distinct seeded frames generated here (untimed input preparation, cached under /tmp); None if the reference encoder is unavailable."""
+    import subprocess
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "jxlamd_bench_frames")
+    try:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_bench_frames.py"), "--out", out, "--count", str(n)],
+                       capture_output=True, text=True, timeout=budget_s, cwd="/tmp")
+    except Exception:  # noqa: BLE001 — whatever was finished in time is used
+        pass
+    files = [os.path.join(out, f"syn4k_q90_seed{i}.jxl") for i in range(n)]
+    files = [f for f in files if os.path.exists(f)]
+    return files if len(files) > len(FRAMES) else None
+
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
 
@@ -84,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
@@ -105,7 +125,14 @@ def main():
     from jxl_coder_amd.shard import max_over_ranks
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
-    datas = [open(f, "rb").read() for f in FRAMES]
+    frames = FRAMES
+    if not os.environ.get("JXLAMD_BENCH_FILES") and not os.environ.get("JXLAMD_BENCH_SEEDS") and args.distinct > len(FRAMES):
+        if world > 1:                       # one rank prepares the inputs, the others wait for the files
+            if rank == 0:
+                distinct_frames(args.distinct)
+            dist.barrier()
+        frames = distinct_frames(args.distinct) or FRAMES
+    datas = [open(f, "rb").read() for f in frames]
     data = datas[0]
     w, h = J.JxlCoder.getSize(data)
     assert all(J.JxlCoder.getSize(d) == (w, h) for d in datas)
@@ -129,7 +156,7 @@ def main():
     d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
     import threading
 
-    def run_frames(n):
+    def run_frames(n, resident=True):
         """n full decodes.  Flights of P frames; NCTX decoder contexts (own HIP stream + HBM buffers each) take flights
         alternately so that one flight's entropy stages overlap another's data-parallel stages."""
         acc = {}
@@ -158,10 +185,10 @@ def main():
                 for attempt in (0, 1):
                     try:
                         if p == 1:
-                            decs[c].decode_to_device(datas[ids[0]], d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[ids[0]].data_ptr())
+                            decs[c].decode_to_device(datas[ids[0]], d_outs[c][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[ids[0]].data_ptr() if resident else None)
                         else:
                             decs[c].decode_batch_to_device([datas[i] for i in ids], [t.data_ptr() for t in d_outs[c][:p]], [out_bytes] * p,
-                                                           [d_ins[i].data_ptr() for i in ids])
+                                                           [d_ins[i].data_ptr() for i in ids] if resident else None)
                         break
                     except J.InvalidJXLException:
                         # Safety net: a flight rejected by the decoder's own rANS final-state checks is decoded again
@@ -202,6 +229,17 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    # the same steps with the compressed bytes arriving as HOST buffers: their H2D (one staging upload per flight) inside the timed region
+    h2d_steps = max(1, min(args.steps, 4))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    run_frames(h2d_steps * B, resident=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed_h2d = max_over_ranks(time.perf_counter() - t1)
 
     if os.environ.get("JXLAMD_BENCH_CLOCKS"):
         # diagnostics: wall time and shader clock of the LF streams of context 0's last flight (decoded next to the other contexts)
@@ -216,6 +254,14 @@ def main():
         mhz = tt[:, :2, 7].astype(np.float64) / np.maximum(wall, 1e-9) / 1e3
         print("[clocks] long LF streams of the last flight of context 0: wall ms min %.1f median %.1f max %.1f; shader clock MHz min %.0f median %.0f max %.0f"
               % (wall.min(), np.median(wall), wall.max(), mhz.min(), np.median(mhz), mhz.max()), file=sys.stderr)
+        # when did each stream START relative to the first one of its launch (workgroups waiting to be placed), and when did the last one end
+        t_start = tt[:, :, 0].astype(np.int64); t_end = tt[:, :, 6].astype(np.int64)
+        ok = t_start > 0
+        if ok.any():
+            t0k = t_start[ok].min()
+            st = (t_start[ok] - t0k) / 1e5
+            print("[clocks] stream start after the launch's first stream (ms): median %.1f p90 %.1f max %.1f; long streams: median %.1f max %.1f; launch span %.1f ms; streams %d"
+                  % (np.median(st), np.percentile(st, 90), st.max(), np.median((t_start[:, :2] - t0k) / 1e5), ((t_start[:, :2] - t0k) / 1e5).max(), (t_end[ok].max() - t0k) / 1e5, int(ok.sum())), file=sys.stderr)
     if rank == 0:
         frames = total_frames * world
         mp = w * h / 1e6
@@ -226,8 +272,8 @@ def main():
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
         flights = max(int(kern.get("flights", 1)), 1)
-        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_group_simt2 (first sub-flight of the flight; + k_lf_smooth)" if P > 1 else "k_pass_group (+ k_lf_smooth)"),
-                 "recon_ms": "rest of the HF phase: later sub-flights' k_pass_group_simt2, k_recon_*, k_filter_sweep" if P > 1 else "k_recon_small_b+k_recon_list_b", "filters_write_ms": "k_filter_sweep"}
+        names = {"lf_groups_ms": "k_lf_group_batch" if P > 1 else "k_lf_group", "pass_groups_ms": ("k_pass_flat (first sub-flight of the flight; + k_lf_smooth, k_pass_prep)" if P > 1 else "k_pass_group (+ k_lf_smooth)"),
+                 "recon_ms": "rest of the HF phase: later sub-flights' k_pass_flat, k_recon_*, k_filter_sweep" if P > 1 else "k_recon_*", "filters_write_ms": "k_filter_sweep"}
         stages = {k: kern[k] / flights for k in names if k in kern}
         # the dominant kernel = the one with the largest total duration in rocprofv3 --stats of this command (profiles/): the two serial
         # entropy stages compete for it; both are one launch per flight and both are timed by the HIP events, so the run itself decides
@@ -249,8 +295,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[2]: one step = a batch of {B} x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8 per GPU "
-                                   f"({len(datas)} distinct seeded frames cycled), every frame a complete decode (host parse, table upload, all kernels); compressed "
-                                   "bytes resident in HBM when the timed region starts (PCIe H2D excluded, DESIGN.md §7), RGBA output stays in HBM",
+                                   f"({len(datas)} distinct seeded frames" + (" generated on this box by the reference's encoder" if len(datas) > len(FRAMES) else " cycled") +
+                                   "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "
+                                   "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
+                       "h2d_included_MPps": round(h2d_steps * B * world * mp / elapsed_h2d, 2), "h2d_included_steps": h2d_steps, "distinct_frames": len(datas),
                        "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,

@@ -35,7 +35,7 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   for (int g = q.g0; g < q.g0 + q.ng; g++) { maps.push_back(0); maps.push_back(g); }
   const size_t n_pairs = maps.size();
   int nwg = 0;
-  for (int g = q.g0; g < q.g0 + q.ng; g += 256) { maps.push_back(0); maps.push_back(g); maps.push_back(std::min(256, q.g0 + q.ng - g)); nwg++; }
+  for (int g = q.g0; g < q.g0 + q.ng; g += 64) { maps.push_back(0); maps.push_back(g); maps.push_back(std::min(64, q.g0 + q.ng - g)); nwg++; }     // k_pass_flat wavefronts
   const size_t o_a = (sizeof(DevBuffers) + 255) & ~(size_t)255, o_m = (o_a + sizeof(DevAux) + 255) & ~(size_t)255, total = o_m + maps.size() * 4;
   HIPCHECK(batch_tab.ensure(total));
   HIPCHECK(h_batch.ensure(total));
@@ -45,7 +45,7 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   bandtab.dB = (const DevBuffers *)db; bandtab.dA = (const DevAux *)(db + o_a);
   bandtab.lf_map = (const int *)(db + o_m); bandtab.pg_map = bandtab.lf_map + 2 * q.nlfg; bandtab.wmap = bandtab.lf_map + n_pairs; bandtab.nwg = nwg; bandtab.flags = flags;
   HIPCHECK(hipEventRecord(ev[0], stream));
-  launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, stream);
+  launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, lf_pool_bytes, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   uint32_t derr = 0;
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
@@ -121,8 +121,8 @@ int jxlamd_decoder::band_reconstruct() {
   if (S.band_stage != 1) { set_error("band: reconstruct needs a band whose LF stage is done"); return JXLAMD_ERR_BUFFER; }
   const BandGeom &q = S.band; const FramePlan &plan = S.plan;
   launch_lf_smooth(S.B, plan.xb, q.cy1 - q.cy0, stream);
-  if (pass_frame_mode >= 1 && frame_has_hf_lds(plan)) launch_pass_frames(bandtab.dB, bandtab.wmap, bandtab.nwg, stream);
-  else if (q.ng >= simt_min_groups) launch_pass_groups_simt(bandtab.dB, bandtab.pg_map, q.ng, stream);
+  // a band of thousands of groups fills the chip with one LANE per group; below that the wave-per-group kernel has the shorter critical path
+  if (q.ng >= flat_min_groups && frame_flat_ok(plan)) { launch_pass_prep(bandtab.dB, bandtab.pg_map, q.ng, stream); launch_pass_flat(bandtab.dB, bandtab.wmap, bandtab.nwg, stream); }
   else launch_pass_groups_batch(bandtab.dB, bandtab.pg_map, q.ng, stream);
   HIPCHECK(hipEventRecord(ev[2], stream));
   launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream);

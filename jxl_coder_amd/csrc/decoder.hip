@@ -140,7 +140,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     if (own_planes) for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));   // flights borrow sets of the decoder's plane pool instead
     HIPCHECK(S.lf_scratch.ensure((size_t)q.nlfg * kLfScratchInts * 4));
     HIPCHECK(S.local.ensure((size_t)q.nlfg * sizeof(LocalTreeScratch)));
-    HIPCHECK(S.pass_nz.ensure((size_t)q.ng * 3072));
+    HIPCHECK(S.pass_nz.ensure((size_t)q.ng * kPassBlkStride));
     HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
     HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
@@ -172,7 +172,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
                                 B.plane_a[c] = (float *)S.planes[c].p - pb; B.plane_b[c] = (float *)S.planes[3 + c].p - pb; }
   B.coef_off = (uint32_t *)S.coef_off.p - cb; B.lf_scratch = (int32_t *)S.lf_scratch.p - (ptrdiff_t)q.lfg0 * kLfScratchInts;
   B.local = (LocalTreeScratch *)S.local.p - q.lfg0;
-  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * 3072;
+  B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * kPassBlkStride;
   B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits; B.stat = (const uint8_t *)stat.p;
   B.lz_win = (plan.modular && Fh->lz_win_len) ? (uint32_t *)S.lz_win.p : nullptr;
@@ -265,6 +265,7 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   HIPCHECK(hipGetLastError());
   (void)flags;
   derr = head[0];
+  if (!S.plan.modular) lf_pool_bytes = lf_pool_clamp(head[1]);
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
@@ -286,19 +287,11 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
     return rc;
   }
   if (S.plan.has_ec) launch_mod_global(S.B, stream);
-  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
+  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
-  if (pass_frame_mode >= 2 && frame_has_hf_lds(S.plan)) {        // workgroup-per-frame PassGroup kernel (LDS-resident code) for a single decode
-    std::vector<int> wm;
-    for (int g = 0; g < S.plan.num_groups; g += 256) { wm.push_back(0); wm.push_back(g); wm.push_back(std::min(256, S.plan.num_groups - g)); }
-    const size_t o_w = (sizeof(DevBuffers) + 255) & ~(size_t)255, total = o_w + wm.size() * 4;
-    HIPCHECK(S.dB.ensure(total)); HIPCHECK(S.h_B.ensure(total));
-    memcpy(S.h_B.p, &S.B, sizeof(DevBuffers)); memcpy((uint8_t *)S.h_B.p + o_w, wm.data(), wm.size() * 4);
-    HIPCHECK(hipMemcpyAsync(S.dB.p, S.h_B.p, total, hipMemcpyHostToDevice, stream));
-    launch_pass_frames((const DevBuffers *)S.dB.p, (const int *)((uint8_t *)S.dB.p + o_w), (int)wm.size() / 3, stream);
-  } else launch_pass_groups(S.B, S.plan.num_groups, stream);
+  launch_pass_groups(S.B, S.plan.num_groups, stream);
   if (S.plan.has_ec) launch_extra_channels(S);
   HIPCHECK(hipEventRecord(ev[2], stream));
   rc = launch_rest(S, 1); if (rc) return rc;
@@ -311,21 +304,29 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
   return rc;
 }
 
-// k_pass_frame applies when every pass of the frame has its LDS image (host_parse.cpp pack_hf_lds_image)
-bool frame_has_hf_lds(const FramePlan &plan) {
+// host-side twin of flat_frame_ok (dev_pass_flat.h)
+bool frame_flat_ok(const FramePlan &plan) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   if (plan.modular || plan.tables.empty()) return false;
-  for (int p = 0; p < F->num_passes; p++) if (!F->hf_lds[p].bytes || (int)F->hf_lds[p].bytes > pass_frame_lds_capacity()) return false;
+  for (int p = 0; p < F->num_passes; p++) if (F->hf_ec[p].use_prefix || F->hf_ec[p].num_clusters > 256) return false;
   return true;
 }
 
-// host-side twin of simt2_frame_ok (dev_vardct.h)
-bool frame_simt2_ok(const FramePlan &plan) {
-  const DevFrame *F = (const DevFrame *)plan.tables.data();
-  if (plan.modular || plan.tables.empty()) return false;
-  for (int p = 0; p < F->num_passes; p++)
-    if (F->hf_ec[p].use_prefix || F->hf_ec[p].num_clusters > 256 || 495 * F->num_bctx * F->num_presets > 495 * 16 * 4) return false;
-  return true;
+std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
+  std::vector<int> per_xcd[8];
+  for (size_t k = 0; k < ngroups.size(); k++)
+    for (int g = 0; g < ngroups[k]; g += 64) { std::vector<int> &v = per_xcd[k & 7]; v.push_back((int)k); v.push_back(g); v.push_back(std::min(64, ngroups[k] - g)); }
+  size_t rows = 0;
+  for (const auto &v : per_xcd) rows = std::max(rows, v.size() / 3);
+  std::vector<int> out;
+  out.reserve(rows * 24);
+  for (size_t r = 0; r < rows; r++)
+    for (int x = 0; x < 8; x++) {
+      const std::vector<int> &v = per_xcd[x];
+      if (3 * r < v.size()) { out.push_back(v[3 * r]); out.push_back(v[3 * r + 1]); out.push_back(v[3 * r + 2]); }
+      else { out.push_back(0); out.push_back(0); out.push_back(0); }       // padding wavefront (exits at once): keeps workgroup index % 8 == frame % 8
+    }
+  return out;
 }
 
 // n independent frames: the entropy stages of ALL frames go into ONE launch each (grid = sum of LF groups / groups
@@ -359,7 +360,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section) {
       if (S.plan.has_ec) launch_mod_global(S.B, stream);
-      launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, stream);
+      launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, stream);
       if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
       launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
       launch_pass_groups(S.B, S.plan.num_groups, stream);
@@ -458,13 +459,11 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     }
     HIPCHECK(hipMemcpyAsync(flight_tables.p, h_flight_tables.p, tab_total, hipMemcpyHostToDevice, stream));
   }
-  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map, w_map;
-  std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / workgroup map
-  bool all_hf_lds = pass_frame_mode >= 1;
-  for (int i : batched) all_hf_lds = all_hf_lds && frame_has_hf_lds(slot((size_t)i).plan);
-  bool all_simt2 = simt2 != 0;
-  for (int i : batched) all_simt2 = all_simt2 && frame_simt2_ok(slot((size_t)i).plan);
-  const int wchunk = all_hf_lds ? 256 : 64;                  // groups per workgroup of the k_pass_frame / k_pass_group_simt2 map
+  std::vector<DevBuffers> hb; std::vector<DevAux> ha; std::vector<int> lf_map, pg_map, ec_map, w_map, sf_groups;
+  std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / wavefront map
+  bool all_flat = true;
+  for (int i : batched) all_flat = all_flat && frame_flat_ok(slot((size_t)i).plan);
+  const auto close_subflight = [&] { const std::vector<int> m = flat_wave_map(sf_groups); w_map.insert(w_map.end(), m.begin(), m.end()); sf_groups.clear(); };
   std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
   bool any_ec = false;
   for (int k = 0; k < nb; k++) {
@@ -473,9 +472,9 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
     for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = cset + (size_t)c * max_coef; }
     hb.push_back(S.B); ha.push_back(S.A);
-    if (k % hf_sets == 0) { pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
+    if (k % hf_sets == 0) { if (k) close_subflight(); pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
+    sf_groups.push_back(S.plan.num_groups);
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
-    for (int g = 0; g < S.plan.num_groups; g += wchunk) { w_map.push_back(k - k / hf_sets * hf_sets); w_map.push_back(g); w_map.push_back(std::min(wchunk, S.plan.num_groups - g)); }
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
       any_ec = true;
@@ -483,30 +482,12 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
       if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { ec_map.push_back(k - k / hf_sets * hf_sets); ec_map.push_back(g); }
     }
   }
+  close_subflight();
   pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); w_off.push_back(w_map.size() / 3);
   // LF map: group-major — the long streams (full 256x256-cell LF groups, 240 ms) are dispatched first and the short edge
   // groups (15 ms) fill the slots they leave, instead of long and short workgroups alternating
-  int max_lfg = 0, n_lf_streams = 0;
-  for (int i : batched) { max_lfg = std::max(max_lfg, slot((size_t)i).plan.num_lf_groups); n_lf_streams += slot((size_t)i).plan.num_lf_groups; }
-  const bool lf_simt = n_lf_streams >= simt_lf_min;
-  if (lf_simt) {
-    // lane-per-stream LF kernel: the 64 sections of a wavefront must share their geometry (lock-step over channel / y / x and
-    // coalesced rows of the lane-interleaved state), so the map is sorted by (cells, width), largest first
-    struct Ent { int key, k, g; };
-    std::vector<Ent> ents;
-    for (int k = 0; k < nb; k++) {
-      const FramePlan &P = slot((size_t)batched[(size_t)k]).plan;
-      const int xlfg = (P.xb + 255) / 256;
-      for (int g = 0; g < P.num_lf_groups; g++) {
-        const int bw = std::min(256, P.xb - (g % xlfg) * 256), bh = std::min(256, P.yb - (g / xlfg) * 256);
-        ents.push_back({(bw * bh) * 512 + bw, k, g});
-      }
-    }
-    std::stable_sort(ents.begin(), ents.end(), [](const Ent &a, const Ent &b) { return a.key > b.key; });
-    for (const Ent &e : ents) { lf_map.push_back(e.k); lf_map.push_back(e.g); }
-    HIPCHECK(simt_waves.ensure((size_t)((n_lf_streams + 63) / 64) * lf_simt_wave_bytes()));
-    HIPCHECK(simt_scratch.ensure((size_t)n_lf_streams * lf_simt_scratch_bytes()));
-  } else
+  int max_lfg = 0;
+  for (int i : batched) max_lfg = std::max(max_lfg, slot((size_t)i).plan.num_lf_groups);
   for (int g = 0; g < max_lfg; g++)
     for (int k = 0; k < nb; k++) if (g < slot((size_t)batched[(size_t)k]).plan.num_lf_groups) { lf_map.push_back(k); lf_map.push_back(g); }
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
@@ -536,32 +517,20 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   const int JXL_ABLATE = (JXL_ABLATE_MASK && ++ablate_flights > 2) ? JXL_ABLATE_MASK : 0;
   if (!(JXL_ABLATE & 1)) launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  // JXLAMD_ENTROPY_STREAM=1: the latency-bound entropy kernels go to a second, high-priority stream of this context (their workgroups
-  // are dispatched ahead of the data-parallel kernels of the other contexts); cross-stream order by events
-  hipStream_t se = stream_e ? stream_e : stream;
-  const auto hop = [&](hipStream_t from, hipStream_t to) -> hipError_t {      // `to` continues after everything queued on `from`
-    if (from == to) return hipSuccess;
-    hipError_t e = hipEventRecord(ev_x, from);
-    return e != hipSuccess ? e : hipStreamWaitEvent(to, ev_x, 0);
-  };
-  HIPCHECK(hop(stream, se));
-  if (JXL_ABLATE & 1) {}
-  else if (lf_simt) launch_lf_groups_simt(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, simt_waves.p, simt_scratch.p, se);
-  else launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, se);
-  HIPCHECK(hop(se, stream));
+  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, lf_pool_bytes, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   if (!(JXL_ABLATE & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
     const int cnt = std::min(hf_sets, nb - k0);
     const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
-    // >= simt_min_groups groups: one LANE per group (64 streams per wavefront); below that the one-wave-per-group kernel has
-    // the shorter critical path
+    // >= flat_min_groups groups: one LANE per group (k_pass_prep + k_pass_flat, 64 streams per wavefront); below that the
+    // one-wave-per-group kernel has the shorter critical path
     if (JXL_ABLATE & 2) {}
-    else if (all_hf_lds) launch_pass_frames(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
-    else if (all_simt2 && n_pg >= simt_min_groups) launch_pass_groups_simt2(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
-    else if (n_pg >= simt_min_groups) { HIPCHECK(hop(stream, se)); launch_pass_groups_simt(dB + k0, map, n_pg, se); HIPCHECK(hop(se, stream)); }
-    else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
+    else if (all_flat && n_pg >= flat_min_groups) {
+      launch_pass_prep(dB + k0, map, n_pg, stream);
+      launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
+    } else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
@@ -572,6 +541,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   const double t_launched = now();
   int first_rc = JXLAMD_OK;
   large_blocks_seen = false;
+  uint32_t pool_want = 0;
   // flags / counters of all frames in one device-to-host copy and one synchronisation
   launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
   HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
@@ -583,10 +553,12 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
+    pool_want = std::max(pool_want, head[1]);
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
   }
   coef_pool_clean = first_rc == JXLAMD_OK;
+  lf_pool_bytes = lf_pool_clamp(pool_want);
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
@@ -611,13 +583,6 @@ jxlamd_decoder *jxlamd_decoder_create(int device) {
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
     g_tls_error = "cannot open HIP device"; delete d; return nullptr;
   }
-  if (getenv("JXLAMD_ENTROPY_STREAM") && atoi(getenv("JXLAMD_ENTROPY_STREAM"))) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // hi = numerically lowest = highest priority
-    const int mode = atoi(getenv("JXLAMD_ENTROPY_STREAM"));    // 1: high priority, 2: same priority (second queue only), 3: low priority
-    if (hipStreamCreateWithPriority(&d->stream_e, hipStreamNonBlocking, mode == 1 ? hi : mode == 3 ? lo : 0) != hipSuccess) d->stream_e = nullptr;
-    (void)hipEventCreateWithFlags(&d->ev_x, hipEventDisableTiming);
-  }
   for (auto &e : d->ev) (void)hipEventCreate(&e);
   return d;
 }
@@ -628,8 +593,6 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   (void)hipStreamSynchronize(d->stream);
   for (FrameSlot *fs : d->slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
   for (auto &e : d->ev) (void)hipEventDestroy(e);
-  if (d->stream_e) { (void)hipStreamSynchronize(d->stream_e); (void)hipStreamDestroy(d->stream_e); }
-  if (d->ev_x) (void)hipEventDestroy(d->ev_x);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }

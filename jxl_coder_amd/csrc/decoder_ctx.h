@@ -77,8 +77,10 @@ struct BandGeom {
 };
 BandGeom band_geometry(const DevFrame &F, int gr0, int gr1);
 int dev_err_class(uint32_t derr);
-bool frame_has_hf_lds(const FramePlan &plan);
-bool frame_simt2_ok(const FramePlan &plan);
+bool frame_flat_ok(const FramePlan &plan);
+// {frame, first group, groups} entries of k_pass_flat for frames [0, n) with ngroups[i] groups each, ordered so that the wavefronts of one frame
+// land on one XCD (workgroup b runs on XCD b % 8): its tables are then read through ONE 4 MB L2 instead of all eight
+std::vector<int> flat_wave_map(const std::vector<int> &ngroups);
 
 struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
@@ -99,10 +101,9 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream_e = nullptr; hipEvent_t ev_x = nullptr;   // optional second stream for the entropy kernels of a flight (JXLAMD_ENTROPY_STREAM)
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, simt_waves, simt_scratch, resample_tmp, icc_lut;
+  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
@@ -112,11 +113,9 @@ struct jxlamd_decoder {
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
-  int simt_lf_min = getenv("JXLAMD_SIMT_LF_MIN") ? atoi(getenv("JXLAMD_SIMT_LF_MIN")) : 0x7fffffff;     // LfGroup sections in a flight from which the lane-per-stream LF kernel takes over (off by default: measured slower)
-  int pass_frame_mode = getenv("JXLAMD_PASS_FRAME") ? atoi(getenv("JXLAMD_PASS_FRAME")) : 0;   // k_pass_frame (HF code in 100-150 KB of LDS per frame): 0 off (default: 30 % faster alone, but next to other decoder contexts its LDS appetite costs more than it saves), 1 flights and bands, 2 single decodes too
-  int simt2 = getenv("JXLAMD_SIMT2") ? atoi(getenv("JXLAMD_SIMT2")) : 1;       // k_pass_group_simt2 (bit supply through LDS rings, hybrid-uint configs in LDS; context maps stay in L2 unless JXLAMD_SIMT2_CTX_LDS=1: with them in LDS — 38 KB per wave — the other kernels lose more than PassGroup gains); 0: k_pass_group_simt
-  int simt_min_groups = getenv("JXLAMD_SIMT_MIN_GROUPS") ? atoi(getenv("JXLAMD_SIMT_MIN_GROUPS")) : 4096;
+  int flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 4096;   // groups in a flight / band from which the lane-per-group kernel takes over from the wave-per-group one (test hook: 1 forces it)
   float timing[5] = {0, 0, 0, 0, 0};
+  int lf_pool_bytes = kModPoolBytes;      // LDS table pool of the next LF launch: what the streams of the previous decode of this context asked for (first decode: the largest)
   int ablate_flights = 0;                 // experiment builds only (JXL_ABLATE_MASK)
   void set_error(const std::string &e) { error = e; tls_error() = e; }
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }

@@ -18,8 +18,9 @@ struct DevAux {
 #define JXL_STAMP(i) do { } while (0)
 #endif
 template <bool kWave = true, class Sync>
-JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
   JXL_STAMP(0);
+  if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = B.err + 1; }      // word 1 of the frame's flag block: LDS table pool the streams would have liked
 #ifdef __HIPCC__
   const uint64_t cyc0 = __builtin_readcyclecounter();      // shader clock (s_memtime): with the 100 MHz wall stamps it gives the effective clock
 #endif

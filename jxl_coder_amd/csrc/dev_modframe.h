@@ -46,6 +46,7 @@ JXL_DEV void inv_rct_planes(int32_t *p0, int32_t *p1, int32_t *p2, size_t n, int
 // ---- GlobalModular: one workgroup; decodes the meta channels and every channel that fits one group
 template <class Sync>
 JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int nthreads, Sync sync) {
+  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
   const DevFrame &F = frame_of(B);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
@@ -73,6 +74,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
 // ---- one 256x256 group of the remaining channels
 template <class Sync>
 JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xgroups, gy = g / F.xgroups;
   const int x0 = gx * 256, y0 = gy * 256;

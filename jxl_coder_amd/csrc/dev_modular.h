@@ -22,7 +22,12 @@ struct DevChanOut { int32_t *d; int32_t w, h; };
 #ifndef JXL_MOD_POOL_BYTES
 #define JXL_MOD_POOL_BYTES 30720
 #endif
-constexpr int kModPoolBytes = JXL_MOD_POOL_BYTES;  // LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
+constexpr int kModPoolBytes = JXL_MOD_POOL_BYTES;  // LARGEST LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
+// The pool is the tail of DevModScratch and the LF kernels allocate it as dynamic LDS: what a stream's tables need decides how many LF
+// streams a CU holds (a stream keeps its LDS for ~100 ms, and LDS-time is what the flights of several decoder contexts run out of first).
+// libjxl's streaming encoder: 9 clusters x 1.25 KB packed for the LF coefficients, <= 7 x 2 KB for the HF metadata; its one-shot encoder
+// (global tree, 39 clusters): 28 x 768 B.  Streams report what they would have liked (DevModScratch::pool_want), the host sizes the next launch.
+constexpr int kModPoolMin = 12288;                 // header parser's working arrays (LocalTmp) and the placement bitmap (8 KB) live there too
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
 struct DevTrList { DevTr t[4]; int32_t n; };
@@ -57,7 +62,6 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   // Table pool, carved per stream by modular_stream_stage: [alias tables | context map | head of the MA tree].  A part
   // that does not fit stays in HBM (the pointers below then address the HBM copy).  libjxl's LF streams need
   // 9 clusters x 256 alias entries = 18 KiB; 20 KiB keeps the workgroup under 40 KiB LDS => 4 streams per CU.
-  uint64_t pool[kModPoolBytes / 8];
   const DevAlias *alias;              // LDS when alias_lds
   const uint8_t *ctx_map;             // LDS when ctx_lds
   const DevTreeNode *tree;            // first tree_ncache nodes of the stream's tree
@@ -68,7 +72,18 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   DevWaveTree wt;
   uint32_t fallback_err;
   DevLz lz;                           // LZ77 state of the current stream (serial walker; window in HBM, set by the stream's caller)
+  int32_t pool_bytes;                 // bytes of `pool` actually backed by LDS in this launch (kModPoolMin .. kModPoolBytes)
+  uint32_t *pool_want;                // where to report (max) the pool bytes this stream's per-channel table sets need; may be null
+  uint64_t pool[kModPoolBytes / 8];   // LAST member: the kernels allocate only pool_bytes of it
 };
+JXL_DEV void mod_pool_want(DevModScratch &S, int bytes, int tid) {
+  if (tid != 0 || !S.pool_want) return;
+#ifdef __HIPCC__
+  atomicMax(S.pool_want, (uint32_t)bytes);
+#else
+  if ((uint32_t)bytes > *S.pool_want) *S.pool_want = (uint32_t)bytes;
+#endif
+}
 
 
 
@@ -315,7 +330,7 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
     st.tree = (const DevTreeNode *)(tables + F.tree_off); st.count = F.tree_count; st.ev = ec_view(tables, F.tree_ec);
     st.num_ctx = F.tree_ec.num_ctx + (F.tree_ec.lz77 ? 1 : 0); st.num_clusters = F.tree_ec.num_clusters;      // the map carries one more entry (distances) with LZ77
   } else {
-    static_assert(sizeof(LocalTmp) <= (size_t)kModPoolBytes, "the header parser's working arrays fit the table pool");
+    static_assert(sizeof(LocalTmp) <= (size_t)kModPoolMin, "the header parser's working arrays fit the table pool");
     uint32_t e = d_read_local_tree(st.b, L, (LocalTmp *)S.pool);      // the pool is free until modular_stream_stage fills it
     if (e) { st.err = e; return; }
     st.tree = L.nodes; st.count = L.count; st.ev = local_view(L.leaf_code);
@@ -345,15 +360,15 @@ JXL_DEV void modular_stream_stage(DevModScratch &S, int tid, int nthreads) {
   uint8_t *pool = (uint8_t *)S.pool;
   int used = 0;
   const int alias_bytes = st.ev.use_prefix ? 0 : (int)((st.num_clusters << st.ev.log_alpha) * sizeof(DevAlias));
-  const bool alias_lds = !st.ev.use_prefix && st.num_clusters <= kLocMaxClusters && alias_bytes <= kModPoolBytes;
+  const bool alias_lds = !st.ev.use_prefix && st.num_clusters <= kLocMaxClusters && alias_bytes <= S.pool_bytes;
   DevAlias *l_alias = (DevAlias *)pool;
   if (alias_lds) used = alias_bytes;
   const int ctx_bytes = (st.num_ctx + 7) & ~7;
-  const bool ctx_lds = used + ctx_bytes <= kModPoolBytes;
+  const bool ctx_lds = used + ctx_bytes <= S.pool_bytes;
   uint8_t *l_ctx = pool + used;
   if (ctx_lds) used += ctx_bytes;
   DevTreeNode *l_tree = (DevTreeNode *)(pool + used);
-  int ncache = (kModPoolBytes - used) / (int)sizeof(DevTreeNode);
+  int ncache = (S.pool_bytes - used) / (int)sizeof(DevTreeNode);
   if (ncache > st.count) ncache = st.count;
   S.alias = alias_lds ? l_alias : st.ev.alias; S.alias_lds = alias_lds;
   S.ctx_map = ctx_lds ? l_ctx : st.ev.ctx_map; S.ctx_lds = ctx_lds; S.ctx_off = (int32_t)(l_ctx - pool);

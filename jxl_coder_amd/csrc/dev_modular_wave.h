@@ -323,7 +323,7 @@ __device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <
 // Returns false (pool untouched) when the tables do not fit or a symbol >= 128 can occur.
 __device__ __forceinline__ int wave_packed_bytes(uint64_t used, int log_alpha) { return __builtin_popcountll(used) * ((4 << log_alpha) + 256); }
 __device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t used, int log_alpha, DevModScratch &S, int lane) {
-  if (log_alpha < 5 || log_alpha > 8 || wave_packed_bytes(used, log_alpha) > kModPoolBytes) return false;
+  if (log_alpha < 5 || log_alpha > 8 || wave_packed_bytes(used, log_alpha) > S.pool_bytes) return false;
   const int table = 1 << log_alpha, nc = __builtin_popcountll(used);
   bool bad = false;
   if (log_alpha == 8)
@@ -636,7 +636,8 @@ __device__ __forceinline__ bool wave_restage_compact(const DevECView &g, int num
   for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_clu, j) & 63);
   const int nc = __builtin_popcountll(used);
   const int alias_bytes = nc * (8 << la), ctx_bytes = (num_ctx + 7) & ~7;
-  if (g.use_prefix || alias_bytes + ctx_bytes > kModPoolBytes) return false;
+  if (!g.use_prefix) mod_pool_want(S, alias_bytes + ctx_bytes, lane);
+  if (g.use_prefix || alias_bytes + ctx_bytes > S.pool_bytes) return false;
   __syncthreads();
   DevAlias *dst = (DevAlias *)S.pool;
   int cid = 0;
@@ -681,7 +682,8 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       uint64_t used = 0;                             // clusters of this channel's leaves
       for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_lclu, j) & 63);
       const int la_p = ev.log_alpha;
-      if (wave_packed_bytes(used, la_p) <= kModPoolBytes) {
+      mod_pool_want(S, wave_packed_bytes(used, la_p), lane);
+      if (wave_packed_bytes(used, la_p) <= S.pool_bytes) {
       // rank the thresholds; lane c then holds a value with exactly c thresholds below it
       int rank = 0;
       for (int j = 0; j < ni; j++) { const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }

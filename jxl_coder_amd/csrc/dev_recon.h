@@ -467,7 +467,9 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
     alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;
   }
   if (out_bits == 8) {
-    const float d = st_f(stat, ST.dither_off)[(oy & 31) * 32 + (ox & 31)];   // libjxl's 8-bit writer dither (oracle/README.md)
+    // libjxl's 8-bit writer dither (oracle/README.md): indexed by the OUTPUT position; for the transposing orientations (5..8) with row
+    // and column swapped (established on the reference's output: tests/golden/vo72x40_e3_o5..8)
+    const float d = st_f(stat, ST.dither_off)[F.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
     uint8_t px[4];
     for (int c = 0; c < 3; c++) px[c] = (uint8_t)(int)rintf(v[c] * 255.0f + d);
     px[3] = (uint8_t)(int)rintf(alpha * 255.0f);

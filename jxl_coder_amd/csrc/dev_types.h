@@ -77,9 +77,6 @@ struct DevFrame {
   uint32_t single_pass_bit;
   // HF
   DevEC hf_ec[4];                  // per pass (up to 4 passes supported on device)
-  // LDS image of the pass's code for k_pass_frame (one workgroup per frame, all its lanes share the tables): context map (all presets),
-  // hybrid-uint configs, 4-byte alias entries (cutoff | right << 8 | offsets1 << 16) and one frequency table per cluster
-  struct HfLds { uint32_t off, bytes, cfg_off, alias_off, d_off; int32_t d_shift; } hf_lds[4];      // bytes == 0: the image does not fit (fallback kernels)
   uint32_t order_off[4][13][3];    // u32 order arrays: offset in the frame blob, or kOrderInStatic | offset in the static tables (order_ptr)
   // sections
   uint32_t cs_size;                // bytes of the codestream buffer (device copy carries >= 64 B of zero padding)

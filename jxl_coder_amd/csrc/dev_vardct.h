@@ -440,106 +440,11 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
   return 0;
 }
 
-// ------------------------------------------------------------------ PassGroup, lane-per-stream (SIMT) form
-// Batch mode: every LANE of a wavefront decodes its own 256x256 group (of any frame of the flight), so one vector
-// instruction advances up to 64 rANS streams.  All per-stream state is per-lane registers; the per-group nonzero map
-// lives in HBM/L2 (3 KiB per group, touched once per block), the code's tables are read through L2.  Same arithmetic
-// as pass_phase_decode; used by k_pass_group_simt and by the CPU harness (one lane at a time).
-JXL_DEV uint32_t pass_group_lane(const DevBuffers &B, const uint16_t *freq_ctx, const uint16_t *nnz_ctx, uint8_t *nz, int g) {
-  const DevFrame &F = frame_of(B);
-  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-  const int gx = g % F.xgroups, gy = g / F.xgroups;
-  const int bx0 = gx * 32, by0 = gy * 32;
-  const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
-  const int nslice = 495 * F.num_bctx;
-  const uint8_t *bctx_map = B.tables + F.bctx_map_off;
-  const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
-  const bool accumulate = F.num_passes > 1;
-  for (int pass = 0; pass < F.num_passes; pass++) {
-    const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
-    DevBits b;
-    bits_init(b, B.codestream, sec.off, F.cs_size);
-    if (F.nsec == 1) {
-      uint32_t skip = F.single_pass_bit;
-      while (skip >= 32) { bits_read(b, 32); skip -= 32; }
-      bits_read(b, (int)skip);
-    }
-    const int sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
-    if (sel >= F.num_presets) return kErrBitstream;
-    DevECView ev = ec_view(B.tables, F.hf_ec[pass]);
-    ev.ctx_map += (size_t)sel * (size_t)nslice;
-    uint32_t state = ans_init(ev, b);
-    const int shift = F.pass_shift[pass];
-    for (int i = 0; i < 3 * 32 * 32; i++) nz[i] = 0;
-    uint32_t pool = 0;
-    for (int y = 0; y < bh; y++)
-      for (int x = 0; x < bw; x++) {
-        const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
-        if (!B.first[o]) continue;
-        const int st = B.strategy[o];
-        const int cx = kCoveredX[st], cy = kCoveredY[st];
-        const int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
-        const int size = covered * 64;
-        const int ord = kStrategyOrder[st];
-        uint32_t off;
-        if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
-        if (off + (uint32_t)size > 65536u) return kErrBitstream;      // a group holds at most 32x32 cells of coefficients (stale / corrupt placement data)
-        const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
-        int qf_idx = 0;
-        for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
-        const int lfi = B.lf_idx[o];
-        for (int ci = 0; ci < 3; ci++) {
-          const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-          uint8_t *nzc = nz + c * 1024;
-          int predicted;
-          if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
-          else if (y == 0) predicted = nzc[x - 1];
-          else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
-          int idx = c < 2 ? c ^ 1 : 2;
-          idx = idx * 13 + ord;
-          idx = idx * (F.nb_qf_thr + 1) + qf_idx;
-          idx = idx * nlf + lfi;
-          const int bctx = bctx_map[idx];
-          const int nzp = predicted >= 64 ? 64 : predicted;
-          const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
-          int nzeros = (int)ec_read(ev, b, state, (uint32_t)nzctx);
-          if (nzeros > size - covered) return kErrBitstream;
-          const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
-          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
-          const int histo = F.num_bctx * 37 + 458 * bctx;
-          const uint32_t *order = order_ptr(B, F, pass, ord, c);
-          int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
-          int prev = nzeros > size / 16 ? 0 : 1;
-          for (int k = covered; k < size && nzeros != 0; k++) {
-            const int nl = (nzeros + covered - 1) >> log2c;
-            const int kk = k >> log2c;
-            const int ctx = histo + (nnz_ctx[nl] + freq_ctx[kk]) * 2 + prev;
-            const uint32_t u = ec_read(ev, b, state, (uint32_t)ctx);
-            if (u) {
-              const int32_t v = unpack_signed(u) * (1 << shift);
-              if (accumulate) blk[order[k]] += v; else blk[order[k]] = v;
-            }
-            prev = u != 0;
-            nzeros -= prev;
-          }
-          if (nzeros != 0) return kErrBitstream;
-        }
-      }
-    if (state != 0x130000u) return kErrAnsFinal;
-    if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
-    if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
-  }
-  return 0;
-}
-
-// ------------------------------------------------------------------ PassGroup, lane-per-group, stall-free bit supply (flights)
-// k_pass_group_simt2.  What held k_pass_group_simt at ~3 us per symbol was not arithmetic: 64 lanes refill their bit buffers at
-// different steps, so nearly every step of the wavefront waited for somebody's global load (and, through the in-order memory counter,
-// for the coefficient stores issued just before).  Here
-//   * every lane reads its stream through a 16-dword ring in LDS (lane-interleaved: bank = lane), topped up for ALL lanes of the wave
-//     at once whenever any lane runs below 6 dwords — one memory wait per ~20-60 symbols instead of one per symbol;
-//   * the context map of the frame's presets and the hybrid-uint configs sit in LDS (a wavefront only holds groups of ONE frame);
-//   * the coefficient-order entry of the next position is fetched one symbol ahead.
+// ------------------------------------------------------------------ bit supply of the lane-per-group PassGroup kernel (dev_pass_flat.h)
+// 64 lanes refill their bit buffers at different steps, so with per-lane global loads nearly every step of the wavefront waits for
+// somebody's refill (and, through the in-order memory counter, for the coefficient stores issued just before).  Every lane reads its
+// stream through a 16-dword ring in LDS instead (lane-interleaved: bank = lane), topped up for ALL lanes of the wave at once whenever
+// any lane runs below 6 dwords — one memory wait per ~20-60 symbols instead of one per symbol.
 #ifndef JXL_SIMT_RING
 #define JXL_SIMT_RING 16
 #endif
@@ -587,260 +492,5 @@ JXL_DEV uint32_t sbits_read(SimtBits &b, uint32_t *ring, int lane, int n) {  // 
 #else
 #define SIMT_ANY(cond) (cond)
 #endif
-struct SimtPassLds {                                       // per wavefront
-  uint32_t ring[kSimtRing * 64];
-  uint32_t cfg[256];
-  uint32_t order8[2][3][64];
-  uint16_t freq_ctx[64], nnz_ctx[64];
-  const uint8_t *ctx_base;                                 // context maps of all presets: ctx_map below, or the frame tables in HBM / L2
-  uint8_t ctx_map[kPassCtxLds * 4];                        // (k_pass_group_simt2<true> only) slices of up to 4 presets x 16 block contexts (31 680 B)
-};
-JXL_DEV uint32_t simt2_ec_read(const SimtPassLds &L, const uint8_t *ctx_map, const DevAlias *alias, int log_alpha, SimtBits &b, uint32_t *ring, int lane,
-                               uint32_t &state, uint32_t ctx) {
-  const uint32_t cluster = ctx_map[ctx];
-  const int lb = 12 - log_alpha;
-  const uint32_t res = state & 0xfff;
-  const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
-  const DevAlias e = alias[(cluster << log_alpha) + i];
-  const uint32_t cfg = L.cfg[cluster & 255];
-  const bool right = pos >= e.cutoff;
-  const uint32_t sym = right ? e.right : i;
-  const uint32_t off = right ? (uint32_t)e.off1 + pos : pos;
-  const uint32_t freq = right ? e.freq1 : e.freq0;
-  state = freq * (state >> 12) + off;
-  if (state < (1u << 16)) state = (state << 16) | sbits_read(b, ring, lane, 16);
-  const uint32_t split_exp = cfg & 0xff, msb = (cfg >> 8) & 0xff, lsb = (cfg >> 16) & 0xff;
-  const uint32_t split = 1u << split_exp;
-  if (sym < split) return sym;
-  uint32_t nbits = split_exp - (msb + lsb) + ((sym - split) >> (msb + lsb));
-  if (nbits > 31) nbits = 31;
-  const uint32_t low = sym & ((1u << lsb) - 1);
-  const uint32_t tok = sym >> lsb;
-  const uint32_t bits = sbits_read(b, ring, lane, (int)nbits);
-  return (((((1u << msb) | (tok & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
-}
-// eligibility (uniform per frame): ANS code with <= 256 clusters whose preset context maps fit the LDS block
-JXL_DEV bool simt2_frame_ok(const DevFrame &F) {
-  for (int p = 0; p < F.num_passes; p++)
-    if (F.hf_ec[p].use_prefix || F.hf_ec[p].num_clusters > 256 || 495 * F.num_bctx * F.num_presets > kPassCtxLds * 4) return false;
-  return true;
-}
-// all lanes of the wave: stage the pass's tables (tid = lane, 64 lanes)
-JXL_DEV void simt2_stage(const DevBuffers &B, SimtPassLds &L, int pass, int tid, int nthreads, bool ctx_in_lds) {
-  const DevFrame &F = frame_of(B);
-  const DevEC &e = F.hf_ec[pass];
-  const int n = 495 * F.num_bctx * F.num_presets;
-  const uint8_t *src = B.tables + e.ctx_map_off;
-  if (ctx_in_lds) for (int i = tid; i < n; i += nthreads) L.ctx_map[i] = src[i];
-  if (tid == 0) L.ctx_base = ctx_in_lds ? L.ctx_map : src;
-  const uint32_t *cfg = (const uint32_t *)(B.tables + e.cfg_off);
-  for (int i = tid; i < e.num_clusters && i < 256; i += nthreads) L.cfg[i] = cfg[i];
-  for (int i = tid; i < 64; i += nthreads) { L.freq_ctx[i] = kCoeffFreqContext[i]; L.nnz_ctx[i] = kCoeffNumNonzeroContext[i]; }
-  for (int i = tid; i < 2 * 3 * 64; i += nthreads) {
-    const int o = i / 192, c = (i / 64) % 3, k = i & 63;
-    L.order8[o][c][k] = order_ptr(B, F, pass, o, c)[k];
-  }
-}
-JXL_DEV uint32_t pass_group_lane2(const DevBuffers &B, SimtPassLds &L, int pass, uint8_t *nz, int g, int lane) {
-  const DevFrame &F = frame_of(B);
-  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-  const int gx = g % F.xgroups, gy = g / F.xgroups;
-  const int bx0 = gx * 32, by0 = gy * 32;
-  const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
-  const int nslice = 495 * F.num_bctx;
-  const uint8_t *bctx_map = B.tables + F.bctx_map_off;
-  const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
-  const bool accumulate = F.num_passes > 1;
-  uint32_t *ring = L.ring;
-  const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
-  SimtBits b;
-  sbits_init(b, ring, lane, B.codestream, sec.off, F.cs_size);
-  if (F.nsec == 1) {
-    uint32_t skip = F.single_pass_bit;
-    while (skip >= 32) { sbits_read(b, ring, lane, 32); skip -= 32; if (SIMT_ANY(b.wr - b.rd < 6u)) sbits_topup(b, ring, lane); }
-    sbits_read(b, ring, lane, (int)skip);
-  }
-  const int sel = (int)sbits_read(b, ring, lane, ceil_log2u((uint32_t)F.num_presets));
-  if (sel >= F.num_presets) return kErrBitstream;
-  const uint8_t *ctx_map = L.ctx_base + (size_t)sel * (size_t)nslice;
-  const DevAlias *alias = (const DevAlias *)(B.tables + F.hf_ec[pass].alias_off);
-  const int la = F.hf_ec[pass].log_alpha;
-  uint32_t state = sbits_read(b, ring, lane, 32);
-  const int shift = F.pass_shift[pass];
-  for (int i = 0; i < 3 * 32 * 32; i++) nz[i] = 0;
-  uint32_t pool = 0;
-  for (int y = 0; y < bh; y++)
-    for (int x = 0; x < bw; x++) {
-      const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
-      if (!B.first[o]) continue;
-      const int st = B.strategy[o];
-      const int cx = kCoveredX[st], cy = kCoveredY[st];
-      const int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
-      const int size = covered * 64;
-      const int ord = kStrategyOrder[st];
-      uint32_t off;
-      if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
-      if (off + (uint32_t)size > 65536u) return kErrBitstream;
-      const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
-      int qf_idx = 0;
-      for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
-      const int lfi = B.lf_idx[o];
-      for (int ci = 0; ci < 3; ci++) {
-        const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-        uint8_t *nzc = nz + c * 1024;
-        int predicted;
-        if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
-        else if (y == 0) predicted = nzc[x - 1];
-        else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
-        int idx = c < 2 ? c ^ 1 : 2;
-        idx = idx * 13 + ord;
-        idx = idx * (F.nb_qf_thr + 1) + qf_idx;
-        idx = idx * nlf + lfi;
-        const int bctx = bctx_map[idx];
-        const int nzp = predicted >= 64 ? 64 : predicted;
-        const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
-        if (SIMT_ANY(b.wr - b.rd < 6u)) sbits_topup(b, ring, lane);
-        int nzeros = (int)simt2_ec_read(L, ctx_map, alias, la, b, ring, lane, state, (uint32_t)nzctx);
-        if (nzeros > size - covered) return kErrBitstream;
-        const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
-        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
-        const int histo = F.num_bctx * 37 + 458 * bctx;
-        const uint32_t *order = ord < 2 ? L.order8[ord][c] : order_ptr(B, F, pass, ord, c);
-        int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
-        int prev = nzeros > size / 16 ? 0 : 1;
-        uint32_t o_cur = order[covered < size ? covered : 0];          // the order entry one symbol ahead of its use
-        for (int k = covered; k < size && nzeros != 0; k++) {
-          const int nl = (nzeros + covered - 1) >> log2c;
-          const int kk = k >> log2c;
-          const int ctx = histo + (L.nnz_ctx[nl] + L.freq_ctx[kk]) * 2 + prev;
-          const uint32_t o_next = order[k + 1 < size ? k + 1 : k];
-          if (SIMT_ANY(b.wr - b.rd < 6u)) sbits_topup(b, ring, lane);
-          const uint32_t u = simt2_ec_read(L, ctx_map, alias, la, b, ring, lane, state, (uint32_t)ctx);
-          if (u) {
-            const int32_t v = unpack_signed(u) * (1 << shift);
-            if (accumulate) blk[o_cur] += v; else blk[o_cur] = v;
-          }
-          o_cur = o_next;
-          prev = u != 0;
-          nzeros -= prev;
-        }
-        if (nzeros != 0) return kErrBitstream;
-      }
-    }
-  if (state != 0x130000u) return kErrAnsFinal;
-  if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
-  if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
-  return 0;
-}
-
-// ------------------------------------------------------------------ PassGroup, lane-per-group with the frame's code in LDS
-// k_pass_frame: one workgroup per frame (or per 256 groups of a large frame); the HF code of the pass — context map, hybrid-uint
-// configs, 4-byte alias entries, per-cluster symbol frequencies (DevFrame::hf_lds, packed on the host) — is copied into LDS once and
-// every lane decodes one 256x256 group with three dependent LDS reads per symbol instead of three dependent L2 / HBM round trips.
-struct HfLdsView { const uint8_t *ctx; const uint32_t *cfg; const uint32_t *alias; const uint16_t *D; int32_t log_alpha, d_shift; };
-JXL_DEV uint32_t lds_ec_read(const HfLdsView &v, DevBits &b, uint32_t &state, uint32_t ctx) {
-  const uint32_t cluster = v.ctx[ctx];
-  const int lb = 12 - v.log_alpha;
-  const uint32_t res = state & 0xfff;
-  const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
-  const uint32_t ent = v.alias[(cluster << v.log_alpha) + i];
-  const uint32_t cfg = v.cfg[cluster];
-  const bool right = pos >= (ent & 0xff);
-  const uint32_t sym = right ? (ent >> 8) & 0xff : i;
-  const uint32_t off = right ? (ent >> 16) + pos : pos;
-  const uint32_t freq = v.D[(cluster << v.d_shift) + sym];
-  state = freq * (state >> 12) + off;
-  if (state < (1u << 16)) state = (state << 16) | bits_read(b, 16);
-  return ec_hybrid(b, cfg, sym);
-}
-JXL_DEV uint32_t pass_group_lane_lds(const DevBuffers &B, const uint8_t *lds_img, int pass, const uint16_t *freq_ctx, const uint16_t *nnz_ctx, uint8_t *nz, int g) {
-  const DevFrame &F = frame_of(B);
-  const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-  const int gx = g % F.xgroups, gy = g / F.xgroups;
-  const int bx0 = gx * 32, by0 = gy * 32;
-  const int bw = F.xb - bx0 < 32 ? F.xb - bx0 : 32, bh = F.yb - by0 < 32 ? F.yb - by0 : 32;
-  const int nslice = 495 * F.num_bctx;
-  const uint8_t *bctx_map = B.tables + F.bctx_map_off;
-  const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
-  const bool accumulate = F.num_passes > 1;
-  {
-    const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
-    DevBits b;
-    bits_init(b, B.codestream, sec.off, F.cs_size);
-    if (F.nsec == 1) {
-      uint32_t skip = F.single_pass_bit;
-      while (skip >= 32) { bits_read(b, 32); skip -= 32; }
-      bits_read(b, (int)skip);
-    }
-    const int sel = (int)bits_read(b, ceil_log2u((uint32_t)F.num_presets));
-    if (sel >= F.num_presets) return kErrBitstream;
-    const DevFrame::HfLds &I = F.hf_lds[pass];
-    HfLdsView ev;
-    ev.ctx = lds_img + (size_t)sel * (size_t)nslice; ev.cfg = (const uint32_t *)(lds_img + I.cfg_off); ev.alias = (const uint32_t *)(lds_img + I.alias_off);
-    ev.D = (const uint16_t *)(lds_img + I.d_off); ev.log_alpha = F.hf_ec[pass].log_alpha; ev.d_shift = I.d_shift;
-    uint32_t state = bits_read(b, 32);
-    const int shift = F.pass_shift[pass];
-    for (int i = 0; i < 3 * 32 * 32; i++) nz[i] = 0;
-    uint32_t pool = 0;
-    for (int y = 0; y < bh; y++)
-      for (int x = 0; x < bw; x++) {
-        const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
-        if (!B.first[o]) continue;
-        const int st = B.strategy[o];
-        const int cx = kCoveredX[st], cy = kCoveredY[st];
-        const int covered = cx * cy, log2c = ceil_log2u((uint32_t)covered);
-        const int size = covered * 64;
-        const int ord = kStrategyOrder[st];
-        uint32_t off;
-        if (pass == 0) { off = pool; B.coef_off[o] = off; pool += (uint32_t)size; } else off = B.coef_off[o];
-        if (off + (uint32_t)size > 65536u) return kErrBitstream;      // a group holds at most 32x32 cells of coefficients (stale / corrupt placement data)
-        const uint32_t qf = (uint32_t)B.qfm1[o] + 1;
-        int qf_idx = 0;
-        for (int t = 0; t < F.nb_qf_thr; t++) if (qf > F.qf_thr[t]) qf_idx++;
-        const int lfi = B.lf_idx[o];
-        for (int ci = 0; ci < 3; ci++) {
-          const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
-          uint8_t *nzc = nz + c * 1024;
-          int predicted;
-          if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
-          else if (y == 0) predicted = nzc[x - 1];
-          else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
-          int idx = c < 2 ? c ^ 1 : 2;
-          idx = idx * 13 + ord;
-          idx = idx * (F.nb_qf_thr + 1) + qf_idx;
-          idx = idx * nlf + lfi;
-          const int bctx = bctx_map[idx];
-          const int nzp = predicted >= 64 ? 64 : predicted;
-          const int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx;
-          int nzeros = (int)lds_ec_read(ev, b, state, (uint32_t)nzctx);
-          if (nzeros > size - covered) return kErrBitstream;
-          const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
-          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
-          const int histo = F.num_bctx * 37 + 458 * bctx;
-          const uint32_t *order = order_ptr(B, F, pass, ord, c);
-          int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;
-          int prev = nzeros > size / 16 ? 0 : 1;
-          for (int k = covered; k < size && nzeros != 0; k++) {
-            const int nl = (nzeros + covered - 1) >> log2c;
-            const int kk = k >> log2c;
-            const int ctx = histo + (nnz_ctx[nl] + freq_ctx[kk]) * 2 + prev;
-            const uint32_t u = lds_ec_read(ev, b, state, (uint32_t)ctx);
-            if (u) {
-              const int32_t v = unpack_signed(u) * (1 << shift);
-              if (accumulate) blk[order[k]] += v; else blk[order[k]] = v;
-            }
-            prev = u != 0;
-            nzeros -= prev;
-          }
-          if (nzeros != 0) return kErrBitstream;
-        }
-      }
-    if (state != 0x130000u) return kErrAnsFinal;
-    if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
-    if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
-  }
-  return 0;
-}
-
 
 }  // namespace jxlamd

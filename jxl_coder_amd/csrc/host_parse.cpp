@@ -87,44 +87,6 @@ static int pack_ec(const hx_ec &ec, Blob &b, DevEC *out, std::string *err, bool 
   return 0;
 }
 
-// The HF code of one pass as the block k_pass_frame copies into LDS (dev_types.h HfLds).  Skipped (bytes = 0) for prefix codes and
-// when it would not leave room for the kernel's other LDS users.
-constexpr size_t kHfLdsMax = 150 * 1024;
-static void pack_hf_lds_image(const hx_ec &ec, Blob &b, DevFrame::HfLds *out) {
-  memset(out, 0, sizeof(*out));
-  if (ec.use_prefix || ec.lz77 || ec.num_clusters > 256) return;
-  const int table = 1 << ec.log_alpha;
-  int maxsym = 0;
-  for (int c = 0; c < ec.num_clusters; c++)
-    for (int i = 0; i < table; i++) { if (ec.cl[c].D[i] && i > maxsym) maxsym = i; }
-  const int d_shift = maxsym < 128 ? 7 : 8;
-  const size_t ctx_bytes = ((size_t)ec.num_ctx + 15) & ~(size_t)15, cfg_bytes = (size_t)ec.num_clusters * 4,
-               alias_bytes = (size_t)ec.num_clusters * (size_t)table * 4, d_bytes = ((size_t)ec.num_clusters << d_shift) * 2;
-  const size_t total = ctx_bytes + ((cfg_bytes + 15) & ~(size_t)15) + alias_bytes + d_bytes;
-  if (total > kHfLdsMax) return;
-  std::vector<uint8_t> img(total, 0);
-  memcpy(img.data(), ec.ctx_map, (size_t)ec.num_ctx);
-  uint32_t *cfg = (uint32_t *)(img.data() + ctx_bytes);
-  uint32_t *al = (uint32_t *)(img.data() + ctx_bytes + ((cfg_bytes + 15) & ~(size_t)15));
-  uint16_t *D = (uint16_t *)((uint8_t *)al + alias_bytes);
-  for (int c = 0; c < ec.num_clusters; c++) {
-    const hx_cluster &cl = ec.cl[c];
-    cfg[c] = ec.cfg[c].split_exp | (ec.cfg[c].msb << 8) | (ec.cfg[c].lsb << 16);
-    // a single-symbol distribution keeps frequency 4096 whatever bucket the state lands in (see pack_ec)
-    int single = -1;
-    for (int i = 0; i < table; i++) if (cl.D[i] == 4096) single = i;
-    for (int i = 0; i < table; i++) {
-      uint32_t right = cl.a_sym[i];
-      if ((int)right > maxsym) right = 0;              // buckets of an unused tail: never selected with a non-zero frequency
-      al[(size_t)c * table + i] = (uint32_t)cl.a_cutoff[i] | (right << 8) | ((uint32_t)cl.a_off[i] << 16);
-    }
-    for (int i = 0; i <= maxsym; i++) D[((size_t)c << d_shift) + i] = single >= 0 ? 4096 : cl.D[i];
-  }
-  out->off = b.append(img.data(), img.size());
-  out->bytes = (uint32_t)total; out->cfg_off = (uint32_t)ctx_bytes; out->alias_off = (uint32_t)(ctx_bytes + ((cfg_bytes + 15) & ~(size_t)15));
-  out->d_off = out->alias_off + (uint32_t)alias_bytes; out->d_shift = d_shift;
-}
-
 struct Priv {                 // state between phase 1 and phase 2
   img_meta m;
   frame_hdr f;
@@ -173,7 +135,6 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
     hx_ec hf;
     if (hx_ec_read_header(&hf, br, 495 * F.num_presets * F.num_bctx)) { plan->error = "bad HF histograms"; return -1; }
     int rc = pack_ec(hf, blob, &F.hf_ec[p], &plan->error);
-    if (!rc) pack_hf_lds_image(hf, blob, &F.hf_lds[p]);
     hx_ec_free(&hf);
     if (rc) return -1;
   }

@@ -3,22 +3,18 @@
 #include <hip/hip_runtime.h>
 #include "dev_bodies.h"
 #include "dev_modframe.h"
+#include "dev_pass_flat.h"
 namespace jxlamd {
-void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, hipStream_t s);
-void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, hipStream_t s);
-// lane-per-stream LfGroup decode (flights): map sorted so that the 64 sections of a wavefront share their geometry; `waves` holds
-// ceil(n / 64) x lf_simt_wave_bytes(), `scratch` n x lf_simt_scratch_bytes() of HBM
-size_t lf_simt_wave_bytes();
-size_t lf_simt_scratch_bytes();
-void launch_lf_groups_simt(const DevBuffers *Bs, const DevAux *As, const int *map, int n, void *waves, void *scratch, hipStream_t s);
-// workgroup-per-frame PassGroup decode with the HF code in LDS; wmap = {frame, first group, groups} per workgroup.  Only for frames whose
-// DevFrame::hf_lds[pass].bytes is non-zero (and <= pass_frame_lds_capacity()) for every pass
-void launch_pass_frames(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
-int pass_frame_lds_capacity();
-// lane-per-group with LDS bit rings / context maps; wmap = {frame, first group, groups <= 64} per wavefront; frames must pass simt2_frame_ok
-void launch_pass_groups_simt2(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
+// pool_bytes: LDS table pool per stream of this launch (kModPoolMin .. kModPoolBytes, dev_modular.h); lf_pool_clamp turns what the streams of
+// a decode reported (word 1 of a frame's flag block) into the value for the next one
+void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, int pool_bytes, hipStream_t s);
+void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, int pool_bytes, hipStream_t s);
+int lf_pool_clamp(uint32_t wanted);
+// flights / large bands: k_pass_prep (group descriptor lists; map = {frame, group} pairs) then k_pass_flat (lane per group; wmap = {frame,
+// first group, groups <= 64} per wavefront, entries with 0 groups allowed); frames must pass flat_frame_ok (dev_pass_flat.h)
+void launch_pass_prep(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
+void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
-void launch_pass_groups_simt(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s);
 // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both

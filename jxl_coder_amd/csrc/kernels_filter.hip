@@ -55,80 +55,6 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
   else for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
 }
 
-// ---- Fused Gaborish + EPF iterations + writer over LDS tiles (one launch per frame set instead of one per stage).
-// A workgroup owns a 64 x 16 output tile.  It loads the tile plus the H-pixel halo the enabled stages need (H = 1 + 3 + 2 + 1 at
-// most) from the reconstructed planes ONCE — coordinates outside the image are mirrored at load time — and runs the stages between two
-// LDS buffers, each over a margin that shrinks by the stage's radius; the last stage feeds the XYB -> RGBA writer directly.  Values
-// the stage-by-stage path would read at mirrored coordinates are computed there too (position p outside the image holds the stage
-// output AT mirror(p)), so the result is what the per-stage kernels produce.  HBM traffic per 4K frame: 3 planes read once (+ halo
-// overlap) and the RGBA written, instead of three plane sets per stage.
-struct LdsTile {
-  const float *base; int stride, plane, ox, oy;             // element (c, y, x) at base[c * plane + (y - oy) * stride + (x - ox)]
-  __device__ __forceinline__ float operator()(int c, int y, int x) const { return base[c * plane + (y - oy) * stride + (x - ox)]; }
-};
-constexpr int kTileW = 64, kTileH = 16;
-__global__ void __launch_bounds__(256) k_filter_fused(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat) {
-  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  const DevBuffers &B = Bs[blockIdx.z];
-  const DevFrame &F = frame_of(B);
-  if (F.is_modular || frame_failed(B)) return;
-  const int tx0 = (int)blockIdx.x * kTileW, ty0 = F.band_py0 + (int)blockIdx.y * kTileH;
-  if (tx0 >= F.width || ty0 >= F.band_py1) return;
-  const int tid = (int)threadIdx.x;
-  const bool run[4] = {F.gab != 0, F.epf_iters >= 3, F.epf_iters >= 1, F.epf_iters >= 2};
-  const int rad[4] = {1, 3, 2, 1};
-  int H = 0, last = -1;
-  for (int s = 0; s < 4; s++) if (run[s]) { H += rad[s]; last = s; }
-  const int RW = kTileW + 2 * H, RH = kTileH + 2 * H, plane = RW * RH;
-  float *bufA = tile_lds, *bufB = tile_lds + 3 * plane;
-  // load: tile + halo, mirrored at the image edges
-  for (int i = tid; i < plane; i += 256) {
-    const int ly = i / RW, lx = i - ly * RW;
-    const size_t so = (size_t)mirror(ty0 - H + ly, F.height) * (size_t)F.pw + (size_t)mirror(tx0 - H + lx, F.width);
-    for (int c = 0; c < 3; c++) bufA[c * plane + i] = B.plane_a[c][so];
-  }
-  __syncthreads();
-  const DevStatic &ST = *(const DevStatic *)stat;
-  if (last < 0) {                                           // no loop filter: writer only
-    for (int i = tid; i < kTileW * kTileH; i += 256) {
-      const int x = tx0 + (i & (kTileW - 1)), y = ty0 + i / kTileW;
-      if (x < F.width && y < F.band_py1) xyb_write_value(B, stat, ST, bufA[i], bufA[plane + i], bufA[2 * plane + i], B.out_bits, x, y);
-    }
-    return;
-  }
-  int m = H;                                                // margin of valid data around the tile in the current source buffer
-  for (int s = 0; s < 4; s++) {
-    if (!run[s]) continue;
-    const int mo = m - rad[s];                              // margin this stage produces
-    const LdsTile src{bufA, RW, plane, tx0 - H, ty0 - H};
-    const int ow = kTileW + 2 * mo, oh = kTileH + 2 * mo;
-    for (int i = tid; i < ow * oh; i += 256) {
-      const int py = i / ow, px = i - py * ow;
-      const int gx = tx0 - mo + px, gy = ty0 - mo + py;     // frame coordinates of the output position (may be outside the image)
-      // outside the image only the `mo` pixels the later stages' taps can reach are ever read (their mirror images lie inside the loaded region)
-      if (gx < -mo || gx > F.width - 1 + mo || gy < -mo || gy > F.height - 1 + mo) continue;
-      const int ex = mirror(gx, F.width), ey = mirror(gy, F.height);   // where the stage-by-stage path evaluates it
-      float v[3];
-      if (s == 0) gab_value_acc(F, src, ex, ey, v);
-      else if (s == 1) epf_value_acc<0>(B, F, src, ex, ey, v);
-      else if (s == 2) epf_value_acc<1>(B, F, src, ex, ey, v);
-      else epf_value_acc<2>(B, F, src, ex, ey, v);
-      if (s == last) {
-        if (gx < F.width && gy < F.band_py1) {
-          asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));      // keep the filter's last multiply and the writer's first add apart (no FMA across the seam)
-          xyb_write_value(B, stat, ST, v[0], v[1], v[2], B.out_bits, gx, gy);
-        }
-      } else {
-        const int o = (gy - (ty0 - H)) * RW + (gx - (tx0 - H));
-        for (int c = 0; c < 3; c++) bufB[c * plane + o] = v[c];
-      }
-    }
-    __syncthreads();
-    float *t = bufA; bufA = bufB; bufB = t;
-    m = mo;
-  }
-}
-
 // ---- Column sweep: Gaborish + EPF iteration 1 (+ iteration 2) + writer in ONE pass over the reconstructed planes, all in registers.
 // A wave owns a strip of 64 - 2 HX columns (lane = column, HX halo lanes on each side) and walks down a segment of rows.  Every stage
 // keeps a rolling window of its input rows in registers; horizontal neighbours come from the adjacent lanes (DPP wave shifts), vertical
@@ -265,21 +191,11 @@ __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, cons
   filter_sweep<kGab, kEpf>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
 
-void launch_filters_fused(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
-  const int H = (stage_mask & 1 ? 1 : 0) + (stage_mask & 2 ? 3 : 0) + (stage_mask & 4 ? 2 : 0) + (stage_mask & 8 ? 1 : 0);
-  const size_t lds = (size_t)2 * 3 * (kTileW + 2 * H) * (kTileH + 2 * H) * sizeof(float);
-  hipLaunchKernelGGL(k_filter_fused, dim3((max_w + kTileW - 1) / kTileW, (max_h + kTileH - 1) / kTileH, nframes), dim3(256), lds, s, Bs, stat);
-}
-
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
-  // k_filter_fused halves the filters' HBM traffic but runs 1.8x longer than the per-stage kernels (LDS-operation bound, 4 waves per SIMD;
-  // profiles/r02_*): off by default
-  static const int fused = getenv("JXLAMD_FUSED_FILTERS") ? atoi(getenv("JXLAMD_FUSED_FILTERS")) : 0;
-  if (fused) { launch_filters_fused(Bs, stat, nframes, max_w, max_h, stage_mask, s); return; }
   // Column sweep (k_filter_sweep) for every frame with at most two EPF iterations; frames with three (stage_mask & 2: the 12-tap first
-  // pass) go through the per-stage kernels, which then skip the frames the sweep has produced.  JXLAMD_FILTER_SWEEP=0: per-stage only.
-  static const int sweep = getenv("JXLAMD_FILTER_SWEEP") ? atoi(getenv("JXLAMD_FILTER_SWEEP")) : 1;
-  if (sweep) {
+  // pass) go through the per-stage kernels, which skip the frames the sweep has produced.
+  const int sweep = 1;
+  {
     const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
     const dim3 g((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes);
     const int combos = stage_mask >> 8;                        // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use

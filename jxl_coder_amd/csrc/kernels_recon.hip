@@ -12,64 +12,9 @@ __global__ void __launch_bounds__(256) k_lf_smooth(DevBuffers B) {
   lf_smooth_cell(B, i % F.xb, F.band_cy0 + i / F.xb);
 }
 
-// Varblock reconstruction in three size classes so that the LDS budget (and with it the occupancy) fits the block:
-//   small  (<= 256 coefficients):  one wave per 8x8 cell, 4 KiB LDS
-//   medium (512, 1024):            256 threads, 28 KiB LDS, walks the list of such blocks recorded at placement
-//   large  (2048, 4096):           256 threads, 32 KiB LDS (one channel at a time), walks its list
-// medium / large varblocks: the placement step recorded their cells; a fixed-size grid walks the list.
-//
-// DCT32x32 (the dominant transform of smooth 4K content) takes a register-blocked path: the 32-point cosine table sits in
-// LDS for the lifetime of the workgroup, the three channels go through each 1-D pass together, and every work-item owns
-// a 4 (frequencies / rows) x 3 (channels) tile of outputs for one column x, so that one b128 LDS broadcast feeds 4 FMAs:
-//   pass 1: T[c][v][x] = sum_u S[c][u][v] * cc[u][x]      pass 2: out[c][y][x] = sum_v T[c][v][x] * cc[v][y]
-// 12 FMAs per 4 LDS reads instead of 1 FMA per (LDS + global) read of the generic path.
+// Varblock reconstruction, one kernel per transform family so that registers and LDS (and with them the occupancy next to resident
+// entropy waves) fit the block; the placement step recorded the varblocks' cells in three size-class lists, fixed-size grids walk them.
 constexpr int kStrategyDct32 = 5;
-template <int NMAX>
-struct ReconLds {                       // medium: S[3][1024] T[3][1024] CC (28 KiB); large: one channel at a time, S[4096] T[4096] (32 KiB)
-  float S[NMAX > 1024 ? NMAX : 3 * NMAX];
-  float T[NMAX > 1024 ? NMAX : 3 * 1024];
-  float CC[NMAX > 1024 ? 4 : 1024];
-  float LL[96];                         // 4-point cosine table (16) + 4-point LLF scales (4); [32, 80): the 48 LF samples of the block being reconstructed
-};
-
-__device__ __forceinline__ void recon_dct32_passes(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
-  const DevFrame &F = frame_of(B);
-  const int x = tid & 31, q0 = (tid >> 5) * 4;
-  float acc[3][4];
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[c][j] = 0.0f;
-#pragma unroll 4
-  for (int u = 0; u < 32; u++) {
-    const float ccv = CC[u * 32 + x];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float4 s4 = *(const float4 *)&S[c * 1024 + u * 32 + q0];
-      acc[c][0] += s4.x * ccv; acc[c][1] += s4.y * ccv; acc[c][2] += s4.z * ccv; acc[c][3] += s4.w * ccv;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) { T[c * 1024 + (q0 + j) * 32 + x] = acc[c][j]; acc[c][j] = 0.0f; }
-  __syncthreads();
-#pragma unroll 4
-  for (int v = 0; v < 32; v++) {
-    const float4 c4 = *(const float4 *)&CC[v * 32 + q0];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-      const float tv = T[c * 1024 + v * 32 + x];
-      acc[c][0] += tv * c4.x; acc[c][1] += tv * c4.y; acc[c][2] += tv * c4.z; acc[c][3] += tv * c4.w;
-    }
-  }
-  const size_t po = (size_t)(by * 8 + q0) * (size_t)F.pw + (size_t)(bx * 8 + x);
-#pragma unroll
-  for (int c = 0; c < 3; c++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
-}
-
 // DCT32x32 on the matrix cores (north_star: "MFMA only for the >= 32x32 matrix-form blocks").  Both 1-D passes are 32x32x32 products
 //   pass 1: T_c = S_c^T x CC          pass 2: out_c = CC^T x T_c
 // issued as 16 v_mfma_f32_32x32x2_f32 each (f32 in, f32 accumulate: exact f32, the only MFMA precision that keeps the +-1 LSB parity);
@@ -229,38 +174,6 @@ __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint
   }
 }
 
-template <int NMIN, int NMAX>
-__device__ __forceinline__ void recon_list_walk(const DevBuffers &B, const uint8_t *stat, int cls, int xb, bool use_mfma, ReconLds<NMAX> &L, bool skip_dct32 = false) {
-  const int tid = (int)threadIdx.x;
-  const DevStatic &ST = *(const DevStatic *)stat;
-  const DevFrame &F = frame_of(B);
-  const uint32_t count = B.big_count[cls];
-  if (blockIdx.x >= count) return;
-  if (NMAX == 1024) {
-    const float *cc = st_f(stat, ST.cos_off[5]);
-    for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
-    if (tid < 16) L.LL[tid] = st_f(stat, ST.cos_off[2])[tid];
-    else if (tid < 20) L.LL[tid] = (st_f(stat, ST.llf_off) + 64)[tid - 16];
-  }
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[cls][i];
-    const int bx = cell % xb, by = cell / xb;
-    if (by < F.band_cy0 || by >= F.band_cy1) continue;       // band decode: the LF groups placed here may reach beyond the band's rows
-    if (NMAX == 1024 && B.strategy[cell] == kStrategyDct32) {
-      if (skip_dct32) continue;                      // k_recon_dct32_b has reconstructed it
-      __syncthreads();                               // previous item's pass 2 has finished reading T; CC is in place
-      recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
-      __syncthreads();
-      if (use_mfma) recon_dct32_mfma(B, L.S, L.T, L.CC, bx, by, tid); else recon_dct32_passes(B, L.S, L.T, L.CC, bx, by, tid);
-    } else if (NMAX > 1024 && use_mfma && B.strategy[cell] == kStrategyDct64 && B.first[cell]) {
-      __syncthreads();
-      recon_dct64_mfma(B, stat, ST, L.S, L.T, bx, by, tid);
-    } else {
-      __syncthreads();
-      recon_block_body<false, (NMAX > 1024)>(B, stat, L.S, L.T, bx, by, NMIN, NMAX, tid, 256, SyncBlock());
-    }
-  }
-}
 __global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
@@ -470,22 +383,6 @@ __global__ void __launch_bounds__(64) k_recon_dct_rc_b(const DevBuffers *Bs, con
     recon_dct_rc_block<R, C>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
   }
 }
-// General medium / large list walker (JXLAMD_DCT32_SPLIT=0 or the VALU DCT32 passes; the default path uses k_recon_dct32_b, k_recon_medium_pc_b
-// and k_recon_large_b below).  also_large bit 0: the same workgroups walk the 2048 / 4096-coefficient list afterwards; bit 1: DCT32x32 blocks
-// belong to k_recon_dct32_b.
-template <int NMIN, int NMAX>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_list_b(const DevBuffers *Bs, const uint8_t *stat, int cls, int use_mfma, int also_large) {
-  constexpr size_t kLds = sizeof(ReconLds<1024>) > sizeof(ReconLds<4096>) ? sizeof(ReconLds<1024>) : sizeof(ReconLds<4096>);
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NMAX == 1024 ? kLds : sizeof(ReconLds<NMAX>)];
-  const DevBuffers &B = Bs[blockIdx.z];
-  const DevFrame &F = frame_of(B);
-  if (F.is_modular || frame_failed(B)) return;
-  recon_list_walk<NMIN, NMAX>(B, stat, cls, F.xb, use_mfma != 0, *(ReconLds<NMAX> *)smem, (also_large & 2) != 0);
-  if (NMAX == 1024 && (also_large & 1)) {
-    __syncthreads();
-    recon_list_walk<1025, 4096>(B, stat, 1, F.xb, use_mfma != 0, *(ReconLds<4096> *)smem);
-  }
-}
 // DCT32x32 blocks only (98 % of the area of smooth 4K content): half the LDS of the general medium kernel (the second pass runs in
 // place: wave c reads all of channel c before it writes) and its own, smaller register footprint — what the data-parallel kernels can
 // use next to resident entropy waves is what decides their speed in a flight mix.
@@ -554,43 +451,23 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, con
   }
 }
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
-  // JXLAMD_MERGE_LARGE=1: flights never launch the large-block kernel separately (the medium kernel's workgroups walk that list too)
-  static const int merge_large = getenv("JXLAMD_MERGE_LARGE") ? atoi(getenv("JXLAMD_MERGE_LARGE")) : 0;
-  if (merge_large && nframes > 1) expect_large = false;
-  // a single decode has the chip to itself: more, shorter workgroups for the list walkers
+  // a single decode has the chip to itself: more, shorter workgroups for the list walkers; in a flight (16 frames per launch) 256 workgroups
+  // per frame fill the chip, and the launches of the families a frame does not use cost 4 096 empty workgroups instead of 16 384
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
-  static const int dct8_own = getenv("JXLAMD_DCT8_SPLIT") ? atoi(getenv("JXLAMD_DCT8_SPLIT")) : 1;       // 0: k_recon_small_b handles DCT8x8 too
-  const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 1024), 1, nframes);
-  if (dct8_own) {
-    hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
-    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4, 2>), gs, dim3(64), 0, s, Bs, stat);     // AcStrategy 4: DCT16x16
-    hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6, 2>), gs, dim3(64), 0, s, Bs, stat);      // 6: 16 rows x 8 columns
-    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7, 2>), gs, dim3(64), 0, s, Bs, stat);      // 7: 8 x 16
-    hipLaunchKernelGGL((k_recon_dct_rc_b<32, 8, 8, 2>), gs, dim3(64), 0, s, Bs, stat);      // 8: 32 x 8
-    hipLaunchKernelGGL((k_recon_dct_rc_b<8, 32, 9, 2>), gs, dim3(64), 0, s, Bs, stat);      // 9: 8 x 32
-  }
-  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, dct8_own);
-  static const int use_mfma = getenv("JXLAMD_DCT32_MFMA") ? atoi(getenv("JXLAMD_DCT32_MFMA")) : 1;     // 0: the register-blocked VALU passes
-  // JXLAMD_RECON_EXTRA_LDS: dynamic LDS bytes added to the kernel's static 32 KB — an occupancy experiment knob, no functional effect
-  static const unsigned extra_lds = getenv("JXLAMD_RECON_EXTRA_LDS") ? (unsigned)atoi(getenv("JXLAMD_RECON_EXTRA_LDS")) : 0u;
-  static const int split = getenv("JXLAMD_DCT32_SPLIT") ? atoi(getenv("JXLAMD_DCT32_SPLIT")) : 1;      // 0: the medium kernel handles DCT32x32 too
-  const int dct32_own = use_mfma && split;
-  if (dct32_own) {
-    hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
-    if (dct8_own) {                                   // the 512-coefficient rectangles of the medium list
-      hipLaunchKernelGGL((k_recon_dct_rc_b<32, 16, 10, 0>), gs, dim3(64), 0, s, Bs, stat);    // 10: 32 x 16
-      hipLaunchKernelGGL((k_recon_dct_rc_b<16, 32, 11, 0>), gs, dim3(64), 0, s, Bs, stat);    // 11: 16 x 32
-    }
-    hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, dct8_own);
-    // the 2048 / 4096-coefficient list: its own launch; one workgroup per frame when the previous flight had none
-    hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
-    return;
-  }
-  hipLaunchKernelGGL((k_recon_list_b<257, 1024>), dim3(gm, 1, nframes), dim3(256), extra_lds, s, Bs, stat, 0, use_mfma, expect_large ? 0 : 1);
-  if (!expect_large) return;
-  // 2048/4096-coefficient blocks: any grid is correct (the workgroups stride over the list); when the previous flight had
-  // none, one workgroup per frame keeps the (then empty) launch from queueing 64 x 32 KB of LDS requests behind resident LF waves
-  hipLaunchKernelGGL((k_recon_list_b<1025, 4096>), dim3(gl, 1, nframes), dim3(256), 0, s, Bs, stat, 1, use_mfma, 0);
+  const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 256), 1, nframes);
+  hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
+  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4, 2>), gs, dim3(64), 0, s, Bs, stat);     // AcStrategy 4: DCT16x16
+  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6, 2>), gs, dim3(64), 0, s, Bs, stat);      // 6: 16 rows x 8 columns
+  hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7, 2>), gs, dim3(64), 0, s, Bs, stat);      // 7: 8 x 16
+  hipLaunchKernelGGL((k_recon_dct_rc_b<32, 8, 8, 2>), gs, dim3(64), 0, s, Bs, stat);      // 8: 32 x 8
+  hipLaunchKernelGGL((k_recon_dct_rc_b<8, 32, 9, 2>), gs, dim3(64), 0, s, Bs, stat);      // 9: 8 x 32
+  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, 1);                   // the other <= 256-coefficient transforms (AFV, DCT4x8, ...)
+  hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+  hipLaunchKernelGGL((k_recon_dct_rc_b<32, 16, 10, 0>), gs, dim3(64), 0, s, Bs, stat);    // 10: 32 x 16
+  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 32, 11, 0>), gs, dim3(64), 0, s, Bs, stat);    // 11: 16 x 32
+  hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  // the 2048 / 4096-coefficient list: one workgroup per frame when the previous flight had none
+  hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {

@@ -67,13 +67,14 @@ def decode(data: bytes, threads=0, allow16=True, mode=0):
     if rc != 0:
         raise ValueError(f"ref_decode failed rc={rc}")
     dt = {8: np.uint8, 16: np.uint16, 32: np.float32}[ri.out_bits]
-    arr = np.frombuffer(C.string_at(out.value, n.value), dtype=dt).reshape(ri.ysize, ri.xsize, 4).copy()
+    # (C.string_at takes a C int: outputs of 2 GiB and more — BASELINE config 4 — need the array view)
+    arr = np.frombuffer((C.c_uint8 * n.value).from_address(out.value), dtype=dt).reshape(ri.ysize, ri.xsize, 4).copy()
     lib().ref_free(out)
     return arr, ri.as_dict(), icc.raw[:ri.icc_size]
 
 
 def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
-           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None):
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1):
     """pixels: [h,w,c] u8 or u16, c in 1,3,4. Same sequence as the reference's EncodeJxlOneshot."""
     pixels = np.ascontiguousarray(pixels)
     h, w, c = pixels.shape
@@ -90,8 +91,10 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
     out = C.c_void_p()
     n = C.c_size_t()
     lib().ref_set_icc(icc or b"", len(icc) if icc else 0)      # JxlEncoderSetICCProfile (interop/JxlEncoding.cpp:125-129) instead of an enum profile
+    lib().ref_set_orientation(int(orientation))                # JxlBasicInfo.orientation of the file (the decoder re-orients by default)
     rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
     lib().ref_set_icc(b"", 0)
+    lib().ref_set_orientation(1)
     if rc != 0:
         raise ValueError(f"ref_encode failed rc={rc}")
     data = C.string_at(out.value, n.value)

@@ -1272,7 +1272,8 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
           float t = v[c];
           t = t < 0 ? 0 : t > 1 ? 1 : t;   /* NaN -> 0 via first compare false... keep simple */
           t = t * maxv;
-          if (out_bits == 8 && m.pub.xyb_encoded) t += kDither32[(oy & 31) * 32 + (ox & 31)];   /* libjxl 8-bit writer dither */
+          /* libjxl 8-bit writer dither: by output position, row / column swapped for the transposing orientations (pinned by the reference's output) */
+          if (out_bits == 8 && m.pub.xyb_encoded) t += kDither32[m.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
           long q = lrintf(t);
           if (out_bits == 16) ((uint16_t *)o)[di + (size_t)c] = (uint16_t)q; else o[di + (size_t)c] = (uint8_t)q;
         }

@@ -178,6 +178,10 @@ void ref_set_icc(const uint8_t *icc, size_t size) {
   if (size) { g_icc = (uint8_t *)malloc(size); memcpy(g_icc, icc, size); g_icc_size = size; }
 }
 
+/* JxlBasicInfo.orientation (1..8) for the NEXT ref_encode call (test fixtures with a non-identity orientation); 0 / 1 = identity. */
+static int g_orientation;
+void ref_set_orientation(int o) { g_orientation = o; }
+
 int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, uint8_t **out, size_t *out_size) {
   if (load_libs()) return -1;
   SYM(h_jxl, JxlEncoderSetICCProfile);
@@ -205,6 +209,7 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   bi.num_color_channels = p->num_channels == 1 ? 1 : 3;
   bi.alpha_premultiplied = JXL_FALSE;
   if (p->intensity_target > 0) bi.intensity_target = p->intensity_target;
+  if (g_orientation >= 1 && g_orientation <= 8) bi.orientation = (JxlOrientation)g_orientation;
   if (p->num_channels == 4) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
   if (p->num_channels == 4) {

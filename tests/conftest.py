@@ -69,11 +69,14 @@ def emul():
 VARDCT_CASES = ["v64_e3_gab0_epf0", "v256_e3_gab0_epf0", "v256_e3_gab1_epf0", "v256_e3_gab0_epf1", "v256_e3_gab0_epf2",
                 "v256_e3_gab0_epf3", "v256_e7", "v264x520_e7", "v267x131_e7", "v300x300_e7_d3", "v64_hard_e7",
                 "va300x520_e7", "va200x150_e7",        # va*: RGBA, VarDCT colour + Modular-coded alpha (alpha must come out bit-exact)
-                "asset_first_jxl", "asset_wide_gamut"]   # real photographs: two of the reference's demo assets (app/src/main/assets)
-LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x260_e5", "l700x500_e7", "l530x300_e1", "l300x280_e2", "la280x300_e1"]
+                "asset_first_jxl", "asset_wide_gamut",   # real photographs: two of the reference's demo assets (app/src/main/assets)
+                "vo72x40_e3_o2", "vo72x40_e3_o3", "vo72x40_e3_o4", "vo72x40_e3_o5", "vo72x40_e3_o6", "vo72x40_e3_o7", "vo72x40_e3_o8",   # ImageMetadata.orientation 2..8:
+                "vo264x300_e7_o6"]                                                                                                        # mirrored / transposed / rotated by the writer
+LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x260_e5", "l700x500_e7", "l530x300_e1", "l300x280_e2", "la280x300_e1",
+                  "lo40x24_e7_o5", "lo200x120_e7_o8"]
 # lossless cases the DEVICE path decodes (the *_e1 files are libjxl's effort-1 fast path: prefix codes + LZ77 in every stream; e2 / e5 use
 # a Modular group size other than 256 -> rejected loudly)
-LOSSLESS_DEVICE_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l700x500_e7", "l530x300_e1", "la280x300_e1"]
+LOSSLESS_DEVICE_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l700x500_e7", "l530x300_e1", "la280x300_e1", "lo40x24_e7_o5", "lo200x120_e7_o8"]
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.1
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).

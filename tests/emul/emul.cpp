@@ -11,7 +11,7 @@
 #include <vector>
 #include "../../jxl_coder_amd/csrc/dev_bodies.h"
 #include "../../jxl_coder_amd/csrc/dev_modframe.h"
-#include "../../jxl_coder_amd/csrc/dev_lf_simt.h"
+#include "../../jxl_coder_amd/csrc/dev_pass_flat.h"
 #include "../../jxl_coder_amd/csrc/host_parse.h"
 
 using namespace jxlamd;
@@ -38,7 +38,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   std::vector<int32_t> scr((size_t)plan.num_lf_groups * kLfScratchInts, 0);
   std::vector<uint64_t> endbits((size_t)plan.num_lf_groups, 0);
   std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16), bl2(ncell + 16); uint32_t bcount[3] = {0, 0, 0};
-  uint32_t err = 0;
+  uint32_t errw[32] = {0}; uint32_t &err = errw[0];       // the frame's flag block (word 1: LF table pool the streams asked for)
   std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
   DevBuffers B; memset(&B, 0, sizeof(B));
   B.codestream = cs.data(); B.tables = tables.data(); B.stat = static_tables().data();
@@ -46,7 +46,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   B.strategy = c8[0].data(); B.first = c8[1].data(); B.qfm1 = c8[2].data(); B.sharp = c8[3].data(); B.lf_idx = c8[4].data();
   B.xfromy = tl[0].data(); B.bfromy = tl[1].data();
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
-  B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = &err; B.out = out;
+  B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = errw; B.out = out;
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? (size_t)plan.num_groups * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
@@ -70,15 +70,6 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   DevModScratch *MS = new DevModScratch();
   uint64_t mod_end = 0; B.mod_end_bit = &mod_end;
   if (plan.has_ec) mod_global_body(B, *MS, 0, 1, NoSync());       // GlobalModular part of the extra channels: before LfGroup 0
-  if (getenv("JXLEMUL_SIMT_LF")) {        // the lane-per-stream LfGroup decoder (k_lf_group_simt), one lane at a time
-    LfSimtWave *Wv = new LfSimtWave(); LfSimtLds *Lds = new LfSimtLds();
-    for (int i = 0; i < 64; i++) Lds->divlut[i] = (1u << 24) / (uint32_t)(i + 1);
-    for (int g = 0; g < plan.num_lf_groups; g++) {
-      const uint32_t e = lf_group_lane(B, A, *MS, *Wv, *Lds, g, (g * 7 + 3) % 64);
-      if (e) err |= e; else lf_group_epilogue(B, g, 0, 1);
-    }
-    delete Wv; delete Lds;
-  } else
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
   delete MS;
   if (err) { g_err = "device flags " + std::to_string(err) + " (LfGroup)"; return -2; }
@@ -88,32 +79,24 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   }
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) lf_smooth_cell(B, x, y);
   DevPassScratch *PS = new DevPassScratch();
-  std::vector<uint8_t> pnz((size_t)plan.num_groups * 3072, 0); B.pass_nz = pnz.data();
+  std::vector<uint8_t> pnz((size_t)plan.num_groups * kPassBlkStride, 0); B.pass_nz = pnz.data();
   if (getenv("JXLEMUL_STATS")) {
     int hist[32] = {0};
     for (size_t o = 0; o < ncell; o++) if (B.first[o]) hist[B.strategy[o] & 31]++;
     for (int i = 0; i < 27; i++) if (hist[i]) fprintf(stderr, "strategy %d (%dx%d cells): %d blocks\n", i, kCoveredX[i], kCoveredY[i], hist[i]);
     fprintf(stderr, "lists: %u medium, %u large, %u small\n", bcount[0], bcount[1], bcount[2]);
   }
-  if (getenv("JXLEMUL_SIMT2_PASS")) {      // k_pass_group_simt2: bit rings / context maps in (emulated) LDS, one lane at a time
+  if (getenv("JXLEMUL_FLAT_PASS")) {       // k_pass_prep + k_pass_flat: group descriptor lists, then the flat lane-per-group state machine, one lane at a time
     const DevFrame &F0 = *(const DevFrame *)tables.data();
-    if (!simt2_frame_ok(F0)) { g_err = "frame not eligible for the SIMT2 PassGroup path"; return -3; }
-    SimtPassLds *L2 = new SimtPassLds();
-    for (int pass = 0; pass < F0.num_passes; pass++) {
-      simt2_stage(B, *L2, pass, 0, 1, getenv("JXLEMUL_SIMT2_GLOBAL_CTX") == nullptr);
-      for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane2(B, *L2, pass, B.pass_nz + (size_t)g * 3072, g, (g * 5 + 1) % 64); if (e) err |= e; }
-    }
+    if (!flat_frame_ok(F0)) { g_err = "frame not eligible for the flat PassGroup path"; return -3; }
+    for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_prep_group_serial(B, g); if (e) err |= e; }
+    FlatPassLds *L2 = new FlatPassLds();
+    for (int pass = 0; pass < F0.num_passes && !err; pass++)
+      for (int g = 0; g < plan.num_groups; g++) {
+        flat_stage(B, *L2, pass, 0, 1);                 // per lane here: the nonzero-count columns start from zero for every group
+        uint32_t e = pass_group_flat(B, *L2, pass, g, (g * 5 + 1) % 64); if (e) err |= e;
+      }
     delete L2;
-  } else
-  if (getenv("JXLEMUL_LDS_PASS")) {        // the workgroup-per-frame PassGroup decoder (k_pass_frame): the packed LDS image of the HF code, one lane at a time
-    const DevFrame &F0 = *(const DevFrame *)tables.data();
-    for (int pass = 0; pass < F0.num_passes; pass++) {
-      if (!F0.hf_lds[pass].bytes) { g_err = "no LDS image for this frame"; return -3; }
-      for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane_lds(B, tables.data() + F0.hf_lds[pass].off, pass, kCoeffFreqContext, kCoeffNumNonzeroContext, B.pass_nz + (size_t)g * 3072, g); if (e) err |= e; }
-    }
-  } else
-  if (getenv("JXLEMUL_SIMT_PASS")) {       // exercise the lane-per-stream PassGroup code (one lane at a time)
-    for (int g = 0; g < plan.num_groups; g++) { uint32_t e = pass_group_lane(B, kCoeffFreqContext, kCoeffNumNonzeroContext, B.pass_nz + (size_t)g * 3072, g); if (e) err |= e; }
   } else
   for (int g = 0; g < plan.num_groups; g++) pass_group_body(B, *PS, g, 0, 1, NoSync());
   delete PS;
@@ -128,7 +111,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   }
   std::vector<float> S(3 * 4096), T(4096);
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
-    if (getenv("JXLEMUL_SIMT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
+    if (getenv("JXLEMUL_FLAT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
       recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
       recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
     } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());

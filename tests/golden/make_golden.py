@@ -51,6 +51,11 @@ CASES = {
     "l530x300_e1": (530, 300, dict(seed=31), dict(lossless=True, effort=1)),       # libjxl's fast lossless path: prefix codes + LZ77 in every group stream (3x2 groups)
     "l300x280_e2": (300, 280, dict(seed=32), dict(lossless=True, effort=2)),
     "la280x300_e1": (280, 300, dict(seed=33, alpha=True), dict(lossless=True, effort=1)),   # RGBA
+    # ImageMetadata.orientation 2..8: the decoder re-orients (interop/JxlDecoding.cpp never switches that off), the writer transposes / mirrors
+    **{f"vo72x40_e3_o{o}": (72, 40, dict(seed=41), dict(effort=3, orientation=o)) for o in range(2, 9)},
+    "vo264x300_e7_o6": (264, 300, dict(seed=42), dict(effort=7, orientation=6)),              # several groups, ragged edges, rotated
+    "lo40x24_e7_o5": (40, 24, dict(seed=43), dict(lossless=True, effort=7, orientation=5)),   # the Modular writer's re-orientation
+    "lo200x120_e7_o8": (200, 120, dict(seed=44), dict(lossless=True, effort=7, orientation=8)),
 }
 
 

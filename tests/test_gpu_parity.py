@@ -232,10 +232,10 @@ def test_config5_full_size_pq16_epf3_tone_map_f16(dec):
         assert np.abs(got.view(np.float16).astype(np.float32) - exp.view(np.float16).astype(np.float32)).max() < 2e-2
 
 
-def test_alternative_kernels_keep_parity():
-    """The measured-and-parked alternatives stay correct: fused LDS-tiled Gaborish + EPF + writer (JXLAMD_FUSED_FILTERS=1), workgroup-per-frame
-    PassGroup decode with the HF code in LDS (JXLAMD_PASS_FRAME=1), PassGroup lanes without LDS rings (JXLAMD_SIMT2=0) / with the context maps in LDS too, the one-kernel medium reconstruction (JXLAMD_DCT32_SPLIT=0) and the lane-per-stream LF
-    kernel (JXLAMD_SIMT_LF_MIN=1): golden vectors within the stated tolerance, flights == single decodes (knobs are read once per process)."""
+def test_flat_passgroup_kernel_on_small_flights():
+    """Flights below 4096 groups take the wave-per-group PassGroup kernel; JXLAMD_FLAT_MIN_GROUPS=1 (read once per process) sends them through
+    k_pass_prep + k_pass_flat, the lane-per-group path of the large flights: golden vectors within the stated tolerance, flights == single
+    decodes (mixed frame sizes, ragged edge groups, extra channels, three EPF iterations)."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np, torch
@@ -258,11 +258,7 @@ def test_alternative_kernels_keep_parity():
             assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
         print("alternatives ok")
     """) % (ROOT, ROOT + "/tests")
-    # ... and the paths the defaults replaced: per-stage filter kernels instead of the column sweep (JXLAMD_FILTER_SWEEP=0; also what frames
-    # with three EPF iterations use), VALU DCT32 passes (JXLAMD_DCT32_MFMA=0), the entropy kernels on a second stream (JXLAMD_ENTROPY_STREAM=1)
-    for env in ({"JXLAMD_FUSED_FILTERS": "1", "JXLAMD_FILTER_SWEEP": "0"}, {"JXLAMD_PASS_FRAME": "2", "JXLAMD_SIMT_MIN_GROUPS": "1"}, {"JXLAMD_SIMT2": "0", "JXLAMD_SIMT_MIN_GROUPS": "1"},
-                {"JXLAMD_SIMT2_CTX_LDS": "1", "JXLAMD_SIMT_MIN_GROUPS": "1", "JXLAMD_DCT32_SPLIT": "0", "JXLAMD_DCT8_SPLIT": "0"}, {"JXLAMD_SIMT_MIN_GROUPS": "1"},
-                {"JXLAMD_SIMT_LF_MIN": "1"}, {"JXLAMD_FILTER_SWEEP": "0", "JXLAMD_DCT32_MFMA": "0"}, {"JXLAMD_ENTROPY_STREAM": "1", "JXLAMD_SIMT_MIN_GROUPS": "1"}):
+    for env in ({"JXLAMD_FLAT_MIN_GROUPS": "1"},):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
 
@@ -371,6 +367,6 @@ def test_corrupt_frame_inside_a_flight_is_contained():
         assert rejected == 3, rejected
         print("contained ok")
     """) % (ROOT, ROOT + "/tests")
-    env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1", JXLAMD_SIMT_MIN_GROUPS="1")
+    env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1", JXLAMD_FLAT_MIN_GROUPS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "contained ok" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]

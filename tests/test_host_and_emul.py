@@ -80,26 +80,16 @@ def test_device_code_on_cpu_harness(emul, oracle, name):
     assert np.array_equal(out[..., 3], exp[..., 3])       # alpha (opaque, or Modular-coded) is integer-exact
 
 
-@pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3"])
-def test_alternate_device_paths_give_identical_pixels(emul, monkeypatch, name):
-    """The lane-per-stream PassGroup decoder (k_pass_group_simt) and the one-channel-at-a-time reconstruction of the
-    large varblocks (k_recon_list<1025,4096>) must reproduce the default paths bit for bit."""
-    data, _ = load_case(name)
+@pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3", "v264x520_e7", "vb520x4400_e7", "asset_first_jxl", "va300x520_e7"])
+def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
+    """The flights' PassGroup path — k_pass_prep's descriptor lists + the flat lane-per-group state machine with its 32-byte-per-channel
+    nonzero-count columns (dev_pass_flat.h) — and the one-channel-at-a-time reconstruction of the large varblocks must reproduce the
+    wave-per-group path bit for bit (mixed varblock sizes, ragged edge groups, several groups, extra channels)."""
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()      # (some of these fixtures only carry row sums)
     base = emul(data)
-    monkeypatch.setenv("JXLEMUL_SIMT_PASS", "1")
+    monkeypatch.setenv("JXLEMUL_FLAT_PASS", "1")
     alt = emul(data)
     assert np.array_equal(base, alt)
-    monkeypatch.setenv("JXLEMUL_SIMT_LF", "1")          # lane-per-stream LfGroup decoder (dev_lf_simt.h, k_lf_group_simt)
-    alt2 = emul(data)
-    assert np.array_equal(base, alt2)
-    monkeypatch.delenv("JXLEMUL_SIMT_PASS")
-    monkeypatch.setenv("JXLEMUL_LDS_PASS", "1")         # workgroup-per-frame PassGroup decoder over the packed LDS image (k_pass_frame)
-    alt3 = emul(data)
-    assert np.array_equal(base, alt3)
-    monkeypatch.delenv("JXLEMUL_LDS_PASS")
-    monkeypatch.setenv("JXLEMUL_SIMT2_PASS", "1")       # lane-per-group PassGroup decoder with LDS bit rings (k_pass_group_simt2)
-    alt4 = emul(data)
-    assert np.array_equal(base, alt4)
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):

@@ -68,6 +68,7 @@ def main():
         stage = np.zeros((n, 3)); bands = {}
         for b in range(n):
             t = time.time(); bands[b] = DeviceBand(decs[b], data, rws[b], w, h, 4, "cuda:0"); stage[b, 0] = time.time() - t
+        halo = (decs[0].band_halo_bytes(HALO_LF), decs[0].band_halo_bytes(HALO_PIXELS))
         for b in range(n - 1):
             bands[b + 1].import_(HALO_LF, 0, bands[b].export(HALO_LF, 1)); bands[b].import_(HALO_LF, 1, bands[b + 1].export(HALO_LF, 0))
         for b in range(n):
@@ -78,7 +79,6 @@ def main():
             t = time.time(); decs[b].band_finish(); stage[b, 2] = time.time() - t
         torch.cuda.synchronize()
         outs = [bands[b].out for b in range(n)]
-        halo = (decs[0].band_halo_bytes(HALO_LF), decs[0].band_halo_bytes(HALO_PIXELS))
         del bands, decs
         return rws, outs, stage, halo
 

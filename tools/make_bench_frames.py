@@ -1,23 +1,56 @@
 #!/usr/bin/env python3
-"""Generate bench_data/syn4k_q90_seed{1..N-1}.jxl (seed 0 comes from tests/golden/make_golden.py): distinct seeded 3840x2160 photo-like
-frames (tools/synth.py) encoded by the reference's own encoder at q90 = distance 1.0, effort 7 (distinct seeds).
-Run in the build container (needs oracle/_ref); the files are data fixtures, committed."""
-import json, os, sys
+"""Bench inputs: distinct seeded 3840x2160 photo-like frames (tools/synth.py) encoded by the reference's own encoder
+(oracle/_ref: the libjxl the reference ships) at q90 = distance 1.0, effort 7.
+  make_bench_frames.py [N]                 bench_data/syn4k_q90_seed{1..N-1}.jxl + their row sums in tests/golden/golden.json (committed
+                                           fixtures; seed 0 comes from tests/golden/make_golden.py) — run in the build container
+  make_bench_frames.py --out DIR --count N  seeds 0..N-1 into DIR (not committed: bench.py generates its 256 distinct frames on the box;
+                                           seeds that exist under bench_data/ are copied, the rest encoded by a process pool)
+Input preparation only: nothing here is part of the decode path."""
+import json, os, shutil, sys
 from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+def encode(seed, threads):
+    import jxl_ref, synth
+    return jxl_ref.encode(synth.photo_like(3840, 2160, seed=seed), effort=7, distance=1.0, threads=threads)
+
+
 def one(seed):
     import numpy as np
-    import jxl_ref, synth
-    data = jxl_ref.encode(synth.photo_like(3840, 2160, seed=seed), effort=7, distance=1.0, threads=2)
+    import jxl_ref
+    data = encode(seed, 2)
     open(os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{seed}.jxl"), "wb").write(data)
     out = jxl_ref.decode(data, threads=2)[0]
     return seed, len(data), [int(x) for x in out[::240].astype(np.int64).sum(axis=(1, 2))]
 
 
+def one_to(args):
+    seed, out = args
+    dst = os.path.join(out, f"syn4k_q90_seed{seed}.jxl")
+    if os.path.exists(dst):
+        return seed
+    src = os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{seed}.jxl")
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+        return seed
+    data = encode(seed, 1)
+    with open(dst + ".tmp", "wb") as f:
+        f.write(data)
+    os.replace(dst + ".tmp", dst)
+    return seed
+
+
 if __name__ == "__main__":
+    if "--out" in sys.argv:
+        out = sys.argv[sys.argv.index("--out") + 1]
+        n = int(sys.argv[sys.argv.index("--count") + 1]) if "--count" in sys.argv else 256
+        os.makedirs(out, exist_ok=True)
+        with ProcessPoolExecutor(max(1, min(96, (os.cpu_count() or 2) // 2))) as ex:
+            done = list(ex.map(one_to, [(s, out) for s in range(n)], chunksize=1))
+        print(json.dumps({"dir": out, "frames": len(done)}))
+        raise SystemExit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     with ProcessPoolExecutor(4) as ex:
         res = list(ex.map(one, range(1, n)))
