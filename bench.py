@@ -30,24 +30,24 @@ FRAMES = [f for f in FRAMES if os.path.exists(f)]
 FRAME = FRAMES[0]
 
 
-def distinct_frames(n, budget_s=420):
+def distinct_frames(n, budget_s=420, kind="c3"):
     """n distinct seeded frames generated here (untimed input preparation, cached under /tmp); None if the reference encoder is unavailable."""
     import subprocess
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "jxlamd_bench_frames")
     try:
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_bench_frames.py"), "--out", out, "--count", str(n)],
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_bench_frames.py"), "--out", out, "--count", str(n), "--kind", kind],
                        capture_output=True, text=True, timeout=budget_s, cwd="/tmp")
     except Exception:  # noqa: BLE001 — whatever was finished in time is used
         pass
-    files = [os.path.join(out, f"syn4k_q90_seed{i}.jxl") for i in range(n)]
+    files = [os.path.join(out, (f"syn4k_q90_seed{i}.jxl" if kind == "c3" else f"syn4k_pq16_epf3_seed{i}.jxl")) for i in range(n)]
     files = [f for f in files if os.path.exists(f)]
-    return files if len(files) > len(FRAMES) else None
+    return files if len(files) > (len(FRAMES) if kind == "c3" else 0) else None
 
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(data, budget_s=12.0):
+def cpu_baseline(data, budget_s=12.0, c5=False):
     """The reference's own libjxl (oracle/_ref: libjxl 0.12.0 Android-x86_64 build, SSE2-only, JXL_HIGH_PRECISION=0,
     under the loader shim) timed on this host with the reference driver's call sequence and thread choice
     (JxlResizableParallelRunnerSuggestThreads, interop/JxlDecoding.cpp:112-114).  Checker/baseline only."""
@@ -64,11 +64,25 @@ def cpu_baseline(data, budget_s=12.0):
         while time.time() - t0 < budget_s and n < 40:
             t = time.time(); jxl_ref.decode(data, threads=0); best = min(best, time.time() - t); n += 1
         t1 = time.time(); jxl_ref.decode(data, threads=1); one = time.time() - t1
+        post_s = 0.0
+        if c5:          # configs[4]: + the reference's own post stages (its sources compiled in place: oracle/_ref/libref_post.so) on the decoded RGBA16
+            import ctypes as C
+            L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_post.so"))
+            hgt, wid = px.shape[:2]
+            buf = np.ascontiguousarray(px); f16 = np.zeros((hgt, wid, 4), np.uint16)
+            xy = (C.c_double * 8)(0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290)
+            tp = time.time()
+            L.refpost_color_matrix(C.c_void_p(buf.ctypes.data), wid * 8, wid, hgt, 1, 16, info["primaries"], info["transfer_function"], xy, C.c_float(info["intensity_target"]), None)
+            L.refpost_u16_to_f16(C.c_void_p(buf.ctypes.data), wid * 8, C.c_void_p(f16.ctypes.data), wid * 8, wid, hgt, 16)
+            post_s = time.time() - tp
+            best += post_s; one += post_s
         threaded = mp / best
         # batches of frames (the bench's workload): a pool of single-threaded reference decoders, one process per host core
         # (SURVEY.md §8d iii), in a fresh process tree (no fork of this CUDA-initialised process)
         pool = None
         try:
+            if c5:
+                raise RuntimeError("c5: the threaded single-frame figure (decode + post stages) is the baseline")
             import subprocess
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_pool_baseline.py"), FRAME, str(ncpu), "4"],
                                capture_output=True, text=True, timeout=180)
@@ -82,7 +96,8 @@ def cpu_baseline(data, budget_s=12.0):
                 "sample": (f"pool: {pool['frames']} decodes of the same 3840x2160 q90 frame by {pool['procs']} single-threaded reference decoder "
                            f"processes in {pool['wall_s']} s (per-worker 4 s windows); " if pool else "") +
                           f"threaded: {n} decodes of one frame, best-of, runner-suggested threads on {ncpu} host cores; "
-                          f"1 thread: {mp / one:.1f} MP/s; libjxl 0.12.0 Android-x86_64 SSE2-only build under bionic shim"}
+                          f"1 thread: {mp / one:.1f} MP/s; libjxl 0.12.0 Android-x86_64 SSE2-only build under bionic shim" +
+                          (f"; + the reference's colour matrix / tone map and u16 -> F16 stages (its own sources, single-threaded as in the reference): {post_s * 1e3:.0f} ms per frame" if c5 else "")}
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": f"CPU baseline unavailable: {e}"}
 
@@ -103,8 +118,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
+    ap.add_argument("--workload", choices=["c3", "c5"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
+                    "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
     args = ap.parse_args()
+    c5 = args.workload == "c5"
+    if c5:                      # 16-bit outputs + F16 destinations: smaller flights / fewer contexts than the RGBA8 batch (HBM), 64 frames per step
+        argv = " ".join(sys.argv[1:])
+        if "--batch" not in argv: args.batch = 64
+        if "--contexts" not in argv: args.contexts = 8
+        if "--inflight" not in argv: args.inflight = 32
+        if "--distinct" not in argv: args.distinct = 64
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -126,18 +150,21 @@ def main():
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
     frames = FRAMES
-    if not os.environ.get("JXLAMD_BENCH_FILES") and not os.environ.get("JXLAMD_BENCH_SEEDS") and args.distinct > len(FRAMES):
+    if c5 or (not os.environ.get("JXLAMD_BENCH_FILES") and not os.environ.get("JXLAMD_BENCH_SEEDS") and args.distinct > len(FRAMES)):
+        kind = "c5" if c5 else "c3"
         if world > 1:                       # one rank prepares the inputs, the others wait for the files
             if rank == 0:
-                distinct_frames(args.distinct)
+                distinct_frames(max(args.distinct, 1), kind=kind)
             dist.barrier()
-        frames = distinct_frames(args.distinct) or FRAMES
+        frames = distinct_frames(max(args.distinct, 1), kind=kind) or (None if c5 else FRAMES)
+        if frames is None:
+            raise SystemExit("--workload c5 needs the reference's encoder (oracle/_ref) to make its 4K PQ 16-bit frames on this box")
     datas = [open(f, "rb").read() for f in frames]
     data = datas[0]
     w, h = J.JxlCoder.getSize(data)
     assert all(J.JxlCoder.getSize(d) == (w, h) for d in datas)
     out_bytes = w * h * 4
-    if os.environ.get("JXLAMD_BENCH_FILES"):              # other content may decode to RGBA16
+    if os.environ.get("JXLAMD_BENCH_FILES") or c5:        # other content may decode to RGBA16
         import ctypes as _C
         _n = _C.c_size_t()
         if J.api.lib().jxlamd_output_size(data, len(data), J.api.JXLAMD_ALLOW_16BIT, _C.byref(_n)) == 0:
@@ -154,6 +181,9 @@ def main():
     decs = [J.JxlDecoder(local) for _ in range(NCTX)]
     d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(f"cuda:{local}") for d in datas]   # compressed bytes resident in HBM
     d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
+    d_f16 = [[torch.empty(w * h * 8, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)] if c5 else None   # the Bitmap buffers (RGBA_F16)
+    info0 = J.api.Info()
+    J.api.lib().jxlamd_basic_info(data, len(data), J.api.C.byref(info0))
     import threading
 
     def run_frames(n, resident=True):
@@ -198,6 +228,10 @@ def main():
                         with lock:
                             acc["retried_flights"] = acc.get("retried_flights", 0) + 1
                 t = decs[c].last_timing()
+                if c5:          # A10 (Rec.2100 PQ -> Rec.2408 tone map -> sRGB) + A11 (u16 -> RGBA_F16) of every frame of the flight, one fused pass each
+                    for j in range(p):
+                        decs[c].post_fused_device(d_outs[c][j].data_ptr(), w, h, True, 16, True, info0.primaries, info0.transfer_function, info0.intensity_target,
+                                                  J.PreferredColorConfig.RGBA_F16, False, False, 33, d_f16[c][j].data_ptr(), d_f16[c][j].numel())
                 with lock:
                     for k, v in t.items():
                         acc[k] = acc.get(k, 0.0) + v
@@ -218,7 +252,11 @@ def main():
     # sequential single-frame latency (one context; BASELINE configs[1]), reported next to the throughput
     lat = []
     for _ in range(3):
-        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[0].data_ptr()); lat.append(time.perf_counter() - t)
+        t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[0].data_ptr())
+        if c5:
+            decs[0].post_fused_device(d_outs[0][0].data_ptr(), w, h, True, 16, True, info0.primaries, info0.transfer_function, info0.intensity_target,
+                                      J.PreferredColorConfig.RGBA_F16, False, False, 33, d_f16[0][0].data_ptr(), d_f16[0][0].numel())
+        lat.append(time.perf_counter() - t)
     seq_stage = decs[0].last_timing()
     if world > 1:
         dist.barrier()
@@ -267,7 +305,7 @@ def main():
         mp = w * h / 1e6
         value = frames * mp / elapsed
         mean_in = sum(len(d) for d in datas) / len(datas)
-        algo_bytes = mean_in + out_bytes                         # compressed read + RGBA written, per frame
+        algo_bytes = mean_in + (w * h * 8 if c5 else out_bytes)     # compressed read + RGBA (c5: RGBA_F16 Bitmap) written, per frame
         # dominant kernel of the TIMED region: the batched LF-group kernel (one launch per flight of P frames), timed
         # live with HIP events on the decoder's own stream (jxlamd_last_timing).  Algorithmic bytes per launch =
         # SURVEY.md §8(d) per-frame figure (compressed read + RGBA written) x frames per launch.
@@ -291,10 +329,12 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         line = {
-            "metric": "decoded MP/s (4K VarDCT q90 -> RGBA8)", "value": round(value, 2), "unit": "MP/s", "n_gpus": world,
+            "metric": "decoded MP/s (4K Rec.2100 PQ 16-bit EPF3 -> tone map -> RGBA_F16)" if c5 else "decoded MP/s (4K VarDCT q90 -> RGBA8)", "value": round(value, 2), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: one step = a batch of {B} x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8 per GPU "
+            "config": {"workload": (f"configs[4] on one GPU: one step = a batch of {B} x 3840x2160 Rec.2100 PQ 16-bit VarDCT (distance 1.0, effort 7, EPF forced to 3 iterations) "
+                                    "frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (A10 + A11 fused into one pass per frame) " if c5 else
+                                    f"configs[2]: one step = a batch of {B} x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8 per GPU ") +
                                    f"({len(datas)} distinct seeded frames" + (" generated on this box by the reference's encoder" if len(datas) > len(FRAMES) else " cycled") +
                                    "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "
                                    "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
@@ -317,7 +357,7 @@ def main():
                                  "bandwidth-bound; achieved = algorithmic bytes / duration of the dominant kernel"},
         }
         line["cpu_baseline"] = ({"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": "skipped"}
-                                if (args.no_cpu_baseline or world > 1) else cpu_baseline(data))
+                                if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, c5=c5))
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

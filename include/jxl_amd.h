@@ -165,6 +165,14 @@ int jxlamd_reformat(jxlamd_decoder *dec, void *src_dev, uint32_t w, uint32_t h, 
                     int alpha_premultiplied, int has_alpha_in_origin, int api_level, void *dst_dev, size_t dst_capacity,
                     jxlamd_reformat_info *out);
 
+/* A10 + A11 in ONE pass: what jxlamd_color_matrix (when apply_color_matrix; same gate and parameters as the
+ * applyColorMatrix block of cpp/JniDecoding.cpp:131-228, cpp/colorspaces/ColorMatrix.cpp:35-219) followed by jxlamd_reformat
+ * (cpp/ReformatBitmap.cpp:46-263) produce, bit for bit, without the two in-place passes over the RGBA buffer in between.  src_dev is
+ * read-only here (the two-call form premultiplies it in place). */
+int jxlamd_post_fused(jxlamd_decoder *dec, const void *src_dev, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int apply_color_matrix,
+                      uint32_t primaries, uint32_t transfer_function, const double *xy8, float intensity_target, int color_config,
+                      int alpha_premultiplied, int has_alpha_in_origin, int api_level, void *dst_dev, size_t dst_capacity, jxlamd_reformat_info *out);
+
 /* applyColorMatrix / applyColorMatrix16Bit (cpp/colorspaces/ColorMatrix.cpp:35-219) with the set-up of the call site
  * (cpp/JniDecoding.cpp:138-228): linearise with the image's transfer function, Rec.2408 tone map for PQ / HLG
  * (colorspaces/Rec2408ToneMapper.cpp:80-100), source primaries -> Rec.709, sRGB OETF; in place, alpha untouched.

@@ -150,6 +150,8 @@ def lib():
         L.jxlamd_reformat_query.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ReformatInfo)]
         L.jxlamd_reformat.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
+        L.jxlamd_post_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.c_float,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(ReformatInfo)]
         L.jxlamd_color_matrix.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_float]
         L.jxlamd_get_icc.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -242,6 +244,18 @@ class JxlDecoder:
         ri = ReformatInfo()
         rc = lib().jxlamd_reformat(self._h, src_ptr, w, h, int(is_u16), depth, int(config), int(alpha_premultiplied), int(has_alpha_in_origin),
                                    int(api_level), dst_ptr, dst_capacity, C.byref(ri))
+        if rc:
+            _raise(rc, self._h)
+        return ri
+
+    def post_fused_device(self, src_ptr: int, w: int, h: int, is_u16: bool, depth: int, apply_color_matrix: bool, primaries: int, transfer_function: int,
+                          intensity_target: float, config, alpha_premultiplied: bool, has_alpha_in_origin: bool, api_level: int, dst_ptr: int, dst_capacity: int,
+                          xy8=None):
+        """A10 + A11 in one pass over a device buffer (jxlamd_post_fused): the values color_matrix_device + reformat_device give, src untouched."""
+        ri = ReformatInfo()
+        xy = (C.c_double * 8)(*xy8) if xy8 is not None else None
+        rc = lib().jxlamd_post_fused(self._h, src_ptr, w, h, int(is_u16), depth, int(apply_color_matrix), primaries, transfer_function, xy, float(intensity_target),
+                                     int(config), int(alpha_premultiplied), int(has_alpha_in_origin), int(api_level), dst_ptr, dst_capacity, C.byref(ri))
         if rc:
             _raise(rc, self._h)
         return ri
@@ -391,7 +405,7 @@ class JxlCoder:
         return cls._decode_pipeline(data, preferredColorConfig, api_level)
 
     @classmethod
-    def _decode_pipeline(cls, data, config, api_level=None, sampling=None):
+    def _decode_pipeline(cls, data, config, api_level=None, sampling=None, fused_post=True):
         import numpy as np
         import torch
         api = cls.api_level if api_level is None else int(api_level)
@@ -416,12 +430,17 @@ class JxlCoder:
             dec.rescale_device(raw.data_ptr(), w, h, is16, depth, sw, sh, mode, sampler, bool(meta["has_alpha_in_origin"]), scaled.data_ptr(), scaled.numel())
             raw, w, h = scaled, q.out_w, q.out_h
         tf = meta["transfer_function"]
-        if meta["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and meta["color_space"] == 0 and api < 34:   # JniDecoding.cpp:131-137
-            dec.color_matrix_device(raw.data_ptr(), w, h, is16, depth, meta["primaries"], tf, meta["intensity_target"])
+        matrix = bool(meta["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and meta["color_space"] == 0 and api < 34)   # JniDecoding.cpp:131-137
         ri = dec.reformat_query(w, h, is16, config, meta["has_alpha_in_origin"], api)
         dst = torch.empty(int(ri.bytes), dtype=torch.uint8, device=dev)
-        ri = dec.reformat_device(raw.data_ptr(), w, h, is16, depth, config, bool(meta["alpha_premultiplied"]), bool(meta["has_alpha_in_origin"]),
-                                 api, dst.data_ptr(), dst.numel())
+        if fused_post:    # A10 + A11 in one pass; fused_post=False: the reference's two stages as two launches (same pixels)
+            ri = dec.post_fused_device(raw.data_ptr(), w, h, is16, depth, matrix, meta["primaries"], tf, meta["intensity_target"], config,
+                                       bool(meta["alpha_premultiplied"]), bool(meta["has_alpha_in_origin"]), api, dst.data_ptr(), dst.numel())
+        else:
+            if matrix:
+                dec.color_matrix_device(raw.data_ptr(), w, h, is16, depth, meta["primaries"], tf, meta["intensity_target"])
+            ri = dec.reformat_device(raw.data_ptr(), w, h, is16, depth, config, bool(meta["alpha_premultiplied"]), bool(meta["has_alpha_in_origin"]),
+                                     api, dst.data_ptr(), dst.numel())
         torch.cuda.synchronize()
         rows = dst.cpu().numpy().reshape(h, ri.stride)
         name = "HARDWARE" if ri.resolved_config == int(PreferredColorConfig.HARDWARE) else FMT_NAMES[ri.format]

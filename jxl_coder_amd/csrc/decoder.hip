@@ -566,6 +566,23 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     float to_ev0 = 0; (void)hipEventElapsedTime(&to_ev0, ev[5], ev[0]);       // ev[5]: recorded before the first upload of the flight
     fprintf(stderr, "[flight %p] begin %.1f end %.1f | n=%d parse %.1f prepare %.1f launch %.1f wait+collect %.1f ms | GPU: uploads %.1f LF %.1f pass0 %.1f rest %.1f\n",
             (void *)this, t_begin, now(), nb, t_parsed - t_begin, t_prepared - t_parsed, t_launched - t_prepared, now() - t_launched, to_ev0, timing[0], timing[1], timing[2]);
+    // the LF streams' own stamps (100 MHz device wall clock): when each started after the launch's first one (workgroups waiting for a
+    // slot) and how long the launch really ran — against the stage time the events bracket
+    std::vector<double> st, dur; uint64_t first = ~0ull, last = 0;
+    for (int k = 0; k < nb; k++) {
+      const FrameSlot &S = slot((size_t)batched[(size_t)k]);
+      const int n = S.plan.num_lf_groups;
+      std::vector<uint64_t> tt((size_t)n * 8);
+      if (hipMemcpy(tt.data(), (uint8_t *)S.misc.p + 4096 + (size_t)n * 8, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) break;
+      for (int g = 0; g < n; g++) if (tt[(size_t)g * 8]) { first = std::min(first, tt[(size_t)g * 8]); last = std::max(last, tt[(size_t)g * 8 + 6]); st.push_back((double)tt[(size_t)g * 8]); dur.push_back((double)(tt[(size_t)g * 8 + 6] - tt[(size_t)g * 8]) / 1e5); }
+    }
+    if (!st.empty()) {
+      for (double &v : st) v = (v - (double)first) / 1e5;
+      std::sort(st.begin(), st.end()); std::sort(dur.begin(), dur.end());
+      fprintf(stderr, "[flight %p]   LF streams %zu: start offsets ms p50 %.1f p75 %.1f p90 %.1f max %.1f | durations ms p50 %.1f p90 %.1f max %.1f | first start -> last end %.1f ms (stage %.1f)\n",
+              (void *)this, st.size(), st[st.size() / 2], st[st.size() * 3 / 4], st[st.size() * 9 / 10], st.back(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(),
+              (double)(last - first) / 1e5, timing[0]);
+    }
   }
   return first_rc;
 }
@@ -698,26 +715,19 @@ int jxlamd_reformat(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int sr
   return JXLAMD_OK;
 }
 
-int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
-                        const double *xy8, float intensity_target) {
-  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  if (!px || (is_u16 ? (depth < 9 || depth > 16) : depth != 8)) { d->set_error("bad pixel buffer / bit depth"); return JXLAMD_ERR_BUFFER; }
+// The colour-matrix parameters of (format, depth, primaries, transfer, intensity target): matrix + the two LUTs on the device, cached per
+// decoder context (the LUTs — 2 x 65 536 powf for u16 — only depend on these).  *runs = 0: the reference's stage is the identity here.
+static int ensure_color_plan(jxlamd_decoder *d, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf, const double *xy8, float intensity_target, bool *runs) {
   static const double zeros[8] = {0.64, 0.33, 0.30, 0.60, 0.15, 0.06, 0.3127, 0.3290};
-  // the LUTs (2 x 65 536 powf for u16) only depend on these parameters: a decoder context keeps the last set on the device
   double key[13] = {(double)(is_u16 != 0), (double)depth, (double)primaries, (double)tf, (double)intensity_target};
   for (int i = 0; i < 8; i++) key[5 + i] = (primaries == 1 || primaries == 9 || primaries == 11 || !xy8) ? 0.0 : xy8[i];
-  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
   const hipStream_t s = d->stream;
-  if (d->post_key_valid && memcmp(key, d->post_key, sizeof(key)) == 0) {
-    if (!d->post_plan_runs) return JXLAMD_OK;
-    launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, d->post_dev, s);
-    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
-    return JXLAMD_OK;
-  }
+  if (d->post_key_valid && memcmp(key, d->post_key, sizeof(key)) == 0) { *runs = d->post_plan_runs; return JXLAMD_OK; }
   d->post_key_valid = false;
   ColorMatrixPlan P;
   if (!plan_color_matrix(is_u16 != 0, depth, primaries, tf, xy8 ? xy8 : zeros, intensity_target, &P)) {
     memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = false;
+    *runs = false;
     return JXLAMD_OK;
   }
   if (d->post_lin_lut.ensure(P.lin_lut.size() * 4) != hipSuccess || d->post_gam_lut.ensure(P.gam_lut.size() * 2) != hipSuccess ||
@@ -731,9 +741,53 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
   D.tone_map = P.tone_map; D.weight_a = P.weight_a; D.weight_b = P.weight_b;
   D.lin_lut = (const float *)d->post_lin_lut.p; D.gam_lut = (const uint16_t *)d->post_gam_lut.p;
   D.index_scale = P.index_scale; D.index_max = P.index_max;
-  launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, D, s);
-  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
   d->post_dev = D; memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = true;
+  *runs = true;
+  return JXLAMD_OK;
+}
+
+int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
+                        const double *xy8, float intensity_target) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  if (!px || (is_u16 ? (depth < 9 || depth > 16) : depth != 8)) { d->set_error("bad pixel buffer / bit depth"); return JXLAMD_ERR_BUFFER; }
+  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
+  bool runs = false;
+  int rc = ensure_color_plan(d, is_u16, depth, primaries, tf, xy8, intensity_target, &runs);
+  if (rc || !runs) return rc;
+  launch_post_color_matrix(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, d->post_dev, d->stream);
+  if (hipStreamSynchronize(d->stream) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: colour matrix stage failed"); return JXLAMD_ERR_DEVICE; }
+  return JXLAMD_OK;
+}
+
+static PostKind reformat_kind(uint32_t resolved_config, int src_is_u16) {
+  switch (resolved_config) {
+    case JXLAMD_CFG_RGBA_8888: return src_is_u16 ? kPostRgba16To8 : kPostCopy8;
+    case JXLAMD_CFG_RGBA_F16: return src_is_u16 ? kPostU16ToF16 : kPostRgba8ToF16;
+    case JXLAMD_CFG_RGB_565: return src_is_u16 ? kPostRgba16To565 : kPostRgba8To565;
+    case JXLAMD_CFG_RGBA_1010102: return src_is_u16 ? kPostRgba16To1010102 : kPostRgba8To1010102;
+    default: return src_is_u16 ? kPostU16ToF16 : kPostCopy8;     // HARDWARE: ReformatBitmap.cpp:231-245
+  }
+}
+
+int jxlamd_post_fused(jxlamd_decoder *d, const void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int apply_color_matrix, uint32_t primaries,
+                      uint32_t tf, const double *xy8, float intensity_target, int cfg, int alpha_premultiplied, int has_alpha, int api_level, void *dst,
+                      size_t dst_cap, jxlamd_reformat_info *out) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  jxlamd_reformat_info info;
+  int rc = jxlamd_reformat_query(w, h, src_is_u16, cfg, has_alpha, api_level, &info);
+  if (rc) { d->error = g_tls_error; return rc; }
+  if (out) *out = info;
+  if (!src || !dst || dst_cap < info.bytes) { d->set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
+  if (src_is_u16 ? (depth < 10 || depth > 16) : depth != 8) { d->set_error("bit depth does not match the source format"); return JXLAMD_ERR_BUFFER; }
+  if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
+  bool runs = false;
+  if (apply_color_matrix) { rc = ensure_color_plan(d, src_is_u16, depth, primaries, tf, xy8, intensity_target, &runs); if (rc) return rc; }
+  const hipStream_t s = d->stream;
+  const uint32_t line = info.format == JXLAMD_FMT_RGB_565 ? w * 2 : info.format == JXLAMD_FMT_RGBA_F16 ? w * 8 : w * 4;
+  if (info.stride != line && hipMemsetAsync(dst, 0, info.bytes, s) != hipSuccess) { d->set_error("HIP: memset failed"); return JXLAMD_ERR_DEVICE; }
+  launch_post_fused(reformat_kind(info.resolved_config, src_is_u16), src, w * (src_is_u16 ? 8u : 4u), dst, info.stride, w, h, runs ? &d->post_dev : nullptr,
+                    !alpha_premultiplied && has_alpha, depth, !alpha_premultiplied, s);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: post stage failed"); return JXLAMD_ERR_DEVICE; }
   return JXLAMD_OK;
 }
 

@@ -15,12 +15,17 @@ __global__ void __launch_bounds__(64) k_lf_group(DevBuffers B, DevAux A, int poo
 }
 
 // batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(128))) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map, int pool_bytes) {
+#ifndef JXL_LF_VGPR_CAP
+#define JXL_LF_VGPR_CAP 128
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(JXL_LF_VGPR_CAP))) k_lf_group_batch(const DevBuffers *__restrict__ Bs, const DevAux *__restrict__ As, const int *__restrict__ map, int pool_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lf_smem[];
   // Issue priority: this wave walks one long dependency chain (one instruction in flight at a time) next to data-parallel
   // waves with many ready instructions; without priority it waits for an issue slot each time it becomes ready, which
   // stretches the time it holds its LDS / register footprint.  It uses < 1/4 of the SIMD's issue slots at full speed.
+#ifndef JXL_LF_NOPRIO
   __builtin_amdgcn_s_setprio(3);
+#endif
   // readfirstlane: the frame index is wave-uniform, so the DevBuffers fields come through scalar loads into SGPRs
   // (as with the by-value kernel argument of k_lf_group) instead of occupying ~60 VGPRs
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
@@ -37,6 +42,9 @@ static size_t lf_lds_bytes(int pool_bytes) {
   return offsetof(DevModScratch, pool) + (size_t)pool_bytes;
 }
 int lf_pool_clamp(uint32_t wanted) {        // the pool the next launch gets for what the streams of the last one reported
+#ifdef JXL_LF_POOL_FORCE
+  wanted = JXL_LF_POOL_FORCE;               // experiment builds (tools/build_variant.sh)
+#endif
   const int w = (int)((wanted + 2047u) & ~2047u);
   return w < kModPoolMin ? kModPoolMin : w > kModPoolBytes ? kModPoolBytes : w;
 }

@@ -21,6 +21,9 @@ struct ColorMatrixDev {
   float index_scale; uint32_t index_max;
 };
 void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const ColorMatrixDev &P, hipStream_t s);
+// A10 (P != null) + premultiply + conversion in one pass: src (read-only) -> dst; equals launch_post_color_matrix, launch_post_premultiply, launch_post_convert in turn
+void launch_post_fused(PostKind kind, const void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, uint32_t w, uint32_t h, const ColorMatrixDev *P, bool premul,
+                       uint32_t depth, bool attenuate, hipStream_t s);
 
 // A8 (cpp/colorspaces/colorspace.cpp:38-86): the profile -> sRGB transform as an n^3 RGB16 lattice (host_icc_lut.cpp), applied in place with
 // trilinear interpolation; alpha is copied (u8) / the colour is un-premultiplied around the transform (u16: the reference passes TYPE_RGBA_16_PREMUL)

@@ -32,21 +32,10 @@ __global__ void __launch_bounds__(256) k_post_premul16(uint8_t *px, uint32_t str
   *p = v;
 }
 
+// one pixel of the conversion stage: (r, g, b, a) as the source holds them -> destination format KIND at column x of drow
 template <int KIND>
-__global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
-                                                      uint32_t depth, int attenuate) {
-  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
-  if (x >= w) return;
-  const uint8_t *srow = src + (size_t)y * src_stride;
-  uint8_t *drow = dst + (size_t)y * dst_stride;
-  constexpr bool kSrc16 = KIND == kPostU16ToF16 || KIND == kPostRgba16To8 || KIND == kPostRgba16To565 || KIND == kPostRgba16To1010102 || KIND == kPostCopy16;
-  uint32_t r, g, b, a;
-  if (kSrc16) { const ushort4 v = ((const ushort4 *)srow)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
-  else {
-    const uint32_t v = ((const uint32_t *)srow)[x];
-    r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24;
-    if (attenuate && (KIND == kPostRgba8ToF16 || KIND == kPostRgba8To565 || KIND == kPostRgba8To1010102)) { r = (r * a) / 255u; g = (g * a) / 255u; b = (b * a) / 255u; }
-  }
+__device__ __forceinline__ void post_convert_store(uint8_t *drow, uint32_t x, uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t depth, int attenuate) {
+  if (attenuate && (KIND == kPostRgba8ToF16 || KIND == kPostRgba8To565 || KIND == kPostRgba8To1010102)) { r = (r * a) / 255u; g = (g * a) / 255u; b = (b * a) / 255u; }
   if (KIND == kPostU16ToF16 || KIND == kPostRgba8ToF16) {
     const float scale = 1.0f / (float)((1u << (KIND == kPostU16ToF16 ? depth : 8u)) - 1u);
     ushort4 o;
@@ -72,15 +61,43 @@ __global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32
     ((ushort4 *)drow)[x] = o;
   }
 }
+template <int KIND> constexpr bool post_src16() { return KIND == kPostU16ToF16 || KIND == kPostRgba16To8 || KIND == kPostRgba16To565 || KIND == kPostRgba16To1010102 || KIND == kPostCopy16; }
+template <int KIND>
+__global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
+                                                      uint32_t depth, int attenuate) {
+  const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
+  if (x >= w) return;
+  const uint8_t *srow = src + (size_t)y * src_stride;
+  uint32_t r, g, b, a;
+  if (post_src16<KIND>()) { const ushort4 v = ((const ushort4 *)srow)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
+  else { const uint32_t v = ((const uint32_t *)srow)[x]; r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24; }
+  post_convert_store<KIND>(dst + (size_t)y * dst_stride, x, r, g, b, a, depth, attenuate);
+}
 
-// One workgroup per row.  Phase 1 (tone map only): the first pixel of the row whose linear luma is exactly 0 — the
-// reference's loop never advances past it, so pixels from there on stay un-mapped.  Phase 2: LUT -> tone map -> matrix -> LUT.
+// A10, one pixel: LUT -> (tone map unless the row is stuck) -> matrix -> LUT.  FMA contraction off: the reference's operation order.
 template <bool kU16>
-__global__ void __launch_bounds__(256) k_post_color_matrix(uint8_t *px, uint32_t stride, uint32_t w, ColorMatrixDev P) {
+__device__ __forceinline__ void post_matrix_px(const ColorMatrixDev &P, bool tone, uint32_t &r, uint32_t &g, uint32_t &b) {
 #pragma clang fp contract(off)
-  __shared__ uint32_t first_zero;
-  uint8_t *row = px + (size_t)blockIdx.x * stride;
-  if (threadIdx.x == 0) first_zero = w;
+  const uint32_t cap = kU16 ? P.index_max : 255u;
+  float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
+  if (tone) {
+    const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
+    const float scale = (1.0f + P.weight_a * y) / (1.0f + P.weight_b * y);
+    fr = fminf(fr * scale, 1.0f); fg = fminf(fg * scale, 1.0f); fb = fminf(fb * scale, 1.0f);
+  }
+  const float nr = fr * P.m[0] + fg * P.m[1] + fb * P.m[2];
+  const float ng = fr * P.m[3] + fg * P.m[4] + fb * P.m[5];
+  const float nb = fr * P.m[6] + fg * P.m[7] + fb * P.m[8];
+  #define IDX(v) ({ float c_ = (v) < 0.0f ? 0.0f : (v) > 1.0f ? 1.0f : (v); if (!((v) == (v))) c_ = 0.0f; uint32_t i_ = (uint32_t)(c_ * P.index_scale) & 0xffffu; i_ < P.index_max ? i_ : P.index_max; })
+  r = P.gam_lut[IDX(nr)]; g = P.gam_lut[IDX(ng)]; b = P.gam_lut[IDX(nb)];
+  #undef IDX
+}
+// the first pixel of the row whose linear luma is exactly 0 — the reference's tone-mapping loop never advances past it, so the pixels
+// from there on stay un-mapped (colorspaces/Rec2408ToneMapper.cpp:80-100).  All work-items of the workgroup (one row) call it.
+template <bool kU16>
+__device__ __forceinline__ uint32_t post_row_first_zero(const uint8_t *row, uint32_t w, const ColorMatrixDev &P, uint32_t *first_zero) {
+#pragma clang fp contract(off)
+  if (threadIdx.x == 0) *first_zero = w;
   __syncthreads();
   const uint32_t cap = kU16 ? P.index_max : 255u;
   if (P.tone_map) {
@@ -93,28 +110,49 @@ __global__ void __launch_bounds__(256) k_post_color_matrix(uint8_t *px, uint32_t
       const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
       if (y == 0.0f) { mine = x; break; }      // x ascends within a work-item: the first hit is its minimum
     }
-    if (mine < w) atomicMin(&first_zero, mine);
+    if (mine < w) atomicMin(first_zero, mine);
   }
   __syncthreads();
-  const uint32_t fz = first_zero;
+  return *first_zero;
+}
+// One workgroup per row, in place.
+template <bool kU16>
+__global__ void __launch_bounds__(256) k_post_color_matrix(uint8_t *px, uint32_t stride, uint32_t w, ColorMatrixDev P) {
+  __shared__ uint32_t first_zero;
+  uint8_t *row = px + (size_t)blockIdx.x * stride;
+  const uint32_t fz = post_row_first_zero<kU16>(row, w, P, &first_zero);
   for (uint32_t x = threadIdx.x; x < w; x += 256) {
     uint32_t r, g, b, a;
     if (kU16) { const ushort4 v = ((const ushort4 *)row)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
     else { const uint32_t v = ((const uint32_t *)row)[x]; r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24; }
-    float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
-    if (P.tone_map && x < fz) {
-      const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
-      const float scale = (1.0f + P.weight_a * y) / (1.0f + P.weight_b * y);
-      fr = fminf(fr * scale, 1.0f); fg = fminf(fg * scale, 1.0f); fb = fminf(fb * scale, 1.0f);
+    post_matrix_px<kU16>(P, P.tone_map && x < fz, r, g, b);
+    if (kU16) { ushort4 o; o.x = (uint16_t)r; o.y = (uint16_t)g; o.z = (uint16_t)b; o.w = (uint16_t)a; ((ushort4 *)row)[x] = o; }
+    else ((uint32_t *)row)[x] = r | (g << 8) | (b << 16) | (a << 24);
+  }
+}
+// A10 + A11 in ONE pass over the decoded buffer: colour matrix / tone map (when `matrix`), premultiply (when `premul`),
+// conversion into the Bitmap's format — the values jxlamd_color_matrix followed by jxlamd_reformat produce, bit for bit, without the two
+// in-place passes over the RGBA buffer in between (a 4K RGBA16 frame: 66 MB read + 66 MB written, each).  src is read-only.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_post_fused(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, ColorMatrixDev P, int matrix,
+                                                    int premul, uint32_t depth, int attenuate) {
+  constexpr bool kU16 = post_src16<KIND>();
+  __shared__ uint32_t first_zero;
+  const uint8_t *row = src + (size_t)blockIdx.x * src_stride;
+  uint8_t *drow = dst + (size_t)blockIdx.x * dst_stride;
+  uint32_t fz = w;
+  if (matrix) fz = post_row_first_zero<kU16>(row, w, P, &first_zero);
+  const uint32_t maxv = (1u << depth) - 1u;
+  for (uint32_t x = threadIdx.x; x < w; x += 256) {
+    uint32_t r, g, b, a;
+    if (kU16) { const ushort4 v = ((const ushort4 *)row)[x]; r = v.x; g = v.y; b = v.z; a = v.w; }
+    else { const uint32_t v = ((const uint32_t *)row)[x]; r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff; a = v >> 24; }
+    if (matrix) post_matrix_px<kU16>(P, P.tone_map && x < fz, r, g, b);
+    if (premul) {                                        // k_post_premul8 / k_post_premul16
+      if (kU16) { r = (uint16_t)((r * a) / maxv); g = (uint16_t)((g * a) / maxv); b = (uint16_t)((b * a) / maxv); }
+      else { r = (r * a) / 255u; g = (g * a) / 255u; b = (b * a) / 255u; }
     }
-    const float nr = fr * P.m[0] + fg * P.m[1] + fb * P.m[2];
-    const float ng = fr * P.m[3] + fg * P.m[4] + fb * P.m[5];
-    const float nb = fr * P.m[6] + fg * P.m[7] + fb * P.m[8];
-    #define IDX(v) ({ float c_ = (v) < 0.0f ? 0.0f : (v) > 1.0f ? 1.0f : (v); if (!((v) == (v))) c_ = 0.0f; uint32_t i_ = (uint32_t)(c_ * P.index_scale) & 0xffffu; i_ < P.index_max ? i_ : P.index_max; })
-    const uint32_t o0 = P.gam_lut[IDX(nr)], o1 = P.gam_lut[IDX(ng)], o2 = P.gam_lut[IDX(nb)];
-    #undef IDX
-    if (kU16) { ushort4 o; o.x = (uint16_t)o0; o.y = (uint16_t)o1; o.z = (uint16_t)o2; o.w = (uint16_t)a; ((ushort4 *)row)[x] = o; }
-    else ((uint32_t *)row)[x] = o0 | (o1 << 8) | (o2 << 16) | (a << 24);
+    post_convert_store<KIND>(drow, x, r, g, b, a, depth, attenuate);
   }
 }
 
@@ -137,6 +175,23 @@ void launch_post_convert(PostKind kind, const void *src, uint32_t ss, void *dst,
     case kPostRgba16To1010102: hipLaunchKernelGGL(k_post_convert<kPostRgba16To1010102>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
     case kPostCopy8: hipLaunchKernelGGL(k_post_convert<kPostCopy8>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
     case kPostCopy16: hipLaunchKernelGGL(k_post_convert<kPostCopy16>, grid, block, 0, s, a, ss, b, ds, w, h, depth, at); break;
+  }
+}
+
+void launch_post_fused(PostKind kind, const void *src, uint32_t ss, void *dst, uint32_t ds, uint32_t w, uint32_t h, const ColorMatrixDev *P, bool premul, uint32_t depth,
+                       bool att, hipStream_t s) {
+  const uint8_t *a = (const uint8_t *)src; uint8_t *b = (uint8_t *)dst;
+  ColorMatrixDev Z = {}; const ColorMatrixDev &M = P ? *P : Z; const int mt = P ? 1 : 0, pm = premul ? 1 : 0, at = att ? 1 : 0;
+  switch (kind) {
+    case kPostU16ToF16: hipLaunchKernelGGL(k_post_fused<kPostU16ToF16>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba8ToF16: hipLaunchKernelGGL(k_post_fused<kPostRgba8ToF16>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba16To8: hipLaunchKernelGGL(k_post_fused<kPostRgba16To8>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba8To565: hipLaunchKernelGGL(k_post_fused<kPostRgba8To565>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba16To565: hipLaunchKernelGGL(k_post_fused<kPostRgba16To565>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba8To1010102: hipLaunchKernelGGL(k_post_fused<kPostRgba8To1010102>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostRgba16To1010102: hipLaunchKernelGGL(k_post_fused<kPostRgba16To1010102>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostCopy8: hipLaunchKernelGGL(k_post_fused<kPostCopy8>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
+    case kPostCopy16: hipLaunchKernelGGL(k_post_fused<kPostCopy16>, dim3(h), dim3(256), 0, s, a, ss, b, ds, w, M, mt, pm, depth, at); break;
   }
 }
 

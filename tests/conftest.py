@@ -78,10 +78,20 @@ LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x
 # a Modular group size other than 256 -> rejected loudly)
 LOSSLESS_DEVICE_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l700x500_e7", "l530x300_e1", "la280x300_e1", "lo40x24_e7_o5", "lo200x120_e7_o8"]
 
-# Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.1
+# Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).
+# Measured means (round 3, device code): 0.004 - 0.007 for every file the reference's encoder writes at its defaults (incl. the demo
+# photographs), 0.024 - 0.028 with one forced EPF iteration on effort-3 (DCT8-only) files.  Two fixtures exceed 0.05: effort 3 with EPF
+# FORCED to 2 / 3 iterations on every pixel — each iteration moves ~2.5 % of the samples by one LSB against the reference (max stays 1;
+# the C oracle shows the same; cause not established, consistent with the reference build's approximate reciprocal in the weight
+# normalisation) — they carry their own measured bound.
 VARDCT_MAX_ABS = 1
-VARDCT_MEAN_ABS = 0.1
+VARDCT_MEAN_ABS = 0.05
+VARDCT_MEAN_ABS_CASE = {"v256_e3_gab0_epf2": 0.06, "v256_e3_gab0_epf3": 0.09}       # measured 0.051 / 0.076
+
+
+def vardct_mean_tol(name):
+    return VARDCT_MEAN_ABS_CASE.get(name, VARDCT_MEAN_ABS)
 
 # 16-bit output (RGBA u16): max |diff| <= 256/65535 and mean <= 16/65535.  PQ-coded frames are checked
 # statistically: the PQ curve's slope near black turns 1e-5 of linear-light float noise into hundreds of code values on a

@@ -105,6 +105,33 @@ def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src)
 
 
+# The other demo assets of the reference that decode on the device: the file (data fixture), per-row sums of the reference's output and
+# its 32x32 block means (compressed npz) — the full pixels are up to 92 MB per file.
+BIG_ASSETS = {"asset_dark_street": "dark_street.jxl", "asset_large_jxl": "large_jxl.jxl", "asset_pexels": "pexels-thibaut-tattevin-18273081.jxl",
+              "asset_second_jxl": "second_jxl.jxl", "asset_summer_nature": "summer_nature.jxl"}
+
+
+def block_means(out, n=32):
+    h, w = out.shape[:2]
+    hh, ww = (h + n - 1) // n, (w + n - 1) // n
+    pad = np.zeros((hh * n, ww * n, 4), np.float64); cnt = np.zeros((hh * n, ww * n, 1), np.float64)
+    pad[:h, :w] = out; cnt[:h, :w] = 1
+    sm = pad.reshape(hh, n, ww, n, 4).sum(axis=(1, 3)); c = cnt.reshape(hh, n, ww, n, 1).sum(axis=(1, 3))
+    return (sm / c).astype(np.float32)
+
+
+def add_big_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
+    for name, src in BIG_ASSETS.items():
+        data = open(os.path.join(asset_dir, src), "rb").read()
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".blocks.npz"), means=block_means(out))
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src,
+                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))])
+        print(name, len(data), out.shape, out.dtype)
+
+
 def main():
     only = set(sys.argv[1:])
     meta = json.load(open(os.path.join(HERE, "golden.json"))) if only else {}
@@ -127,6 +154,8 @@ def main():
     if not only or "assets" in only:
         add_assets(meta)
     add_rowsum_cases(meta, only)
+    if not only or "big_assets" in only:
+        add_big_assets(meta)
     if only:
         json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
         return

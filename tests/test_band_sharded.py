@@ -165,3 +165,20 @@ def test_band_protocol_errors_are_loud():
     whole, _ = dec.decode_one_shot(data)                                  # the context still decodes whole frames afterwards
     assert whole.shape == (4400, 520, 4)
     dec.close()
+
+
+@pytest.mark.gpu
+def test_band_decode_across_the_kernel_switch_at_16384_squared():
+    """BASELINE config 4 at a quarter of its size (16384 x 16384 = 268 MP, 4096 groups, generated and encoded on the box by the reference's
+    encoder): decoded as ONE band of 4096 groups — at and above that count a band takes the lane-per-group PassGroup kernels (k_pass_prep +
+    k_pass_flat) — and as three bands of <= 1408 groups (wave-per-group kernel, LF groups split between bands): both within max 1 / mean 0.05
+    of the reference's libjxl run live, and equal to each other bit for bit (tools/gpu/c4_full.py; the full 32768 x 32768 run of the same
+    tool is kept as profiles/r03_c4_32768.txt)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("the reference encoder (oracle/_ref) did not travel to this box")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu", "c4_full.py"), "16384", "16384", "1"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "1 bands == 3 bands" in r.stdout and "bit for bit" in r.stdout and r.stdout.rstrip().endswith("True"), r.stdout[-800:]

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
+from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
                       LOSSLESS_DEVICE_CASES, load_case)
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +29,7 @@ def test_golden_vectors(dec, oracle, name):
     out, info = dec.decode_one_shot(data)
     assert out.shape == exp.shape and out.dtype == exp.dtype
     d = np.abs(out.astype(int) - exp.astype(int))
-    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS          # vs the reference's libjxl output
+    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= vardct_mean_tol(name), (name, d.max(), d.mean())          # vs the reference's libjxl output
     ora, _ = oracle.decode(data, 8)
     d2 = np.abs(out.astype(int) - ora.astype(int))
     assert d2.max() <= 1 and (d2 > 0).mean() < 2e-3                           # vs the CPU oracle: same algorithm
@@ -370,3 +370,48 @@ def test_corrupt_frame_inside_a_flight_is_contained():
     env = dict(os.environ, JXLAMD_HF_SETS="2", JXLAMD_PLANE_SETS="1", JXLAMD_FLAT_MIN_GROUPS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "contained ok" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
+
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+BIG_ASSETS = {"asset_dark_street": "tests/golden/asset_dark_street.jxl", "asset_large_jxl": "tests/golden/asset_large_jxl.jxl", "asset_pexels": "tests/golden/asset_pexels.jxl",
+              "asset_second_jxl": "tests/golden/asset_second_jxl.jxl", "asset_summer_nature": "bench_data/real4k_summer_nature.jxl"}
+
+
+@pytest.mark.parametrize("name", sorted(BIG_ASSETS))
+def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
+    """The other five demo photographs of the reference that decode on the device (app/src/main/assets: up to 3910 x 5865, two of them
+    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: all nine) against the reference's own output: every row sum and every
+    32x32 block mean (tests/golden/make_golden.py big_assets).  Bounds: a row / block may be off by the VarDCT tolerance in the mean
+    (u8 0.05, u16 16) — measured: u8 <= 0.012, u16 <= 2.6 (gpurun_out of round 3)."""
+    meta = golden_meta[name]
+    data = open(os.path.join(ROOT, BIG_ASSETS[name]), "rb").read()
+    out, info = dec.decode_one_shot(data, allowed_floats=True)
+    assert list(out.shape) == meta["shape"] and str(out.dtype) == meta["dtype"]
+    tol = 16.0 if out.dtype == np.uint16 else 0.05
+    h, w = out.shape[:2]
+    rs = out.astype(np.int64).sum(axis=(1, 2))
+    row_err = np.abs(rs - np.array(meta["row_sums"], np.int64)) / (4.0 * w)
+    blocks = np.load(os.path.join(GOLDEN_DIR, name + ".blocks.npz"))["means"]
+    n = 32
+    hh, ww = blocks.shape[:2]
+    pad = np.zeros((hh * n, ww * n, 4), np.float64); cnt = np.zeros((hh * n, ww * n, 1), np.float64)
+    pad[:h, :w] = out; cnt[:h, :w] = 1
+    mine = pad.reshape(hh, n, ww, n, 4).sum(axis=(1, 3)) / cnt.reshape(hh, n, ww, n, 1).sum(axis=(1, 3))
+    blk_err = np.abs(mine - blocks)
+    print(f"[asset] {name}: row mean error max {row_err.max():.4f}, block mean error max {blk_err.max():.4f} mean {blk_err.mean():.5f} (tolerance {tol})")
+    assert row_err.max() <= tol and blk_err.max() <= 4 * tol and blk_err.mean() <= tol
+
+
+def test_pq16_difference_distribution(dec):
+    """PQ-coded 16-bit output (the arithmetic of BASELINE config 5) has no hard max bound against the reference: the PQ curve's slope at
+    black turns last-bit differences of linear light into hundreds of code values on a few near-black samples.  What IS asserted: the
+    distribution.  Measured on the GPU (round 3): see the printed table; bounds = measured, rounded up."""
+    data, exp = load_case("v160x120_16bit_pq2100_epf3")
+    out, _ = dec.decode_one_shot(data, allowed_floats=True)
+    d = np.abs(out[..., :3].astype(int) - exp[..., :3].astype(int)).ravel()
+    pct = {p: float(np.percentile(d, p)) for p in (50, 90, 99, 99.9, 99.99)}
+    dark = exp[..., :3].ravel() < 2048                                       # below ~0.6 cd/m2 on the PQ scale
+    print("[pq16] |diff| mean %.2f max %d percentiles %s; samples > 256: %d of %d, all of them near black: %s" %
+          (d.mean(), d.max(), pct, int((d > 256).sum()), d.size, bool(dark[d > 256].all())))
+    assert d.mean() <= 16.0 and pct[99] <= 256 and (d > 256).mean() < 2e-3
+    assert dark[d > 256].all()                                               # every outlier sits where the PQ slope explodes

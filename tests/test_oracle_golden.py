@@ -4,7 +4,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
+from conftest import (LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
                       U16_MEAN_ABS, ROOT, load_case)
 
 
@@ -21,7 +21,7 @@ def test_oracle_vardct_within_tolerance(oracle, name):
     data, exp = load_case(name)
     out, info = oracle.decode(data, 8)
     d = np.abs(out.astype(int) - exp.astype(int))
-    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS
+    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= vardct_mean_tol(name)
     assert np.array_equal(out[..., 3], exp[..., 3])
 
 

@@ -189,3 +189,60 @@ def test_gpu_decode_bitmap_premultiplies_real_alpha():
             rows, stride, fl, cfgname = P.reformat(raw, int(cfg), 16 if is16 else 8, is16, False, True, 34)
             assert (bmp.stride, bmp.use_floats, bmp.config) == (stride, fl, cfgname)
             assert np.array_equal(bmp.rows, rows)
+
+
+@pytest.mark.gpu
+def test_fused_post_stage_equals_the_two_stage_form():
+    """jxlamd_post_fused (A10 + A11 in one pass) against jxlamd_color_matrix followed by jxlamd_reformat on the same
+    device buffers: bit for bit, for every colour-matrix case (tone-mapped rows with zero-luma "stuck" pixels included: G["p8"] / G["p16"]
+    carry them), every target format, straight and premultiplied alpha, with and without the matrix stage."""
+    import torch
+    import jxl_coder_amd as J
+    dec = J.JxlDecoder(0)
+    rng = np.random.default_rng(11)
+    h, w = 37, 301
+    imgs = {False: rng.integers(0, 256, (h, w, 4), dtype=np.uint8), True: rng.integers(0, 65536, (h, w, 4), dtype=np.uint16)}
+    for v in imgs.values():
+        v[5, 40:44, :3] = 0; v[9, 0, :3] = 0; v[20, w - 1, :3] = 0      # zero-luma pixels: the tone mapper's loop sticks there for the rest of the row
+    checked = 0
+    for is16, img in imgs.items():
+        depth = 16 if is16 else 8
+        for cfg in (J.PreferredColorConfig.RGBA_8888, J.PreferredColorConfig.RGBA_F16, J.PreferredColorConfig.RGB_565, J.PreferredColorConfig.RGBA_1010102,
+                    J.PreferredColorConfig.HARDWARE, J.PreferredColorConfig.DEFAULT):
+            for prim, tf, target in ((9, 16, 10000.0), (11, 13, 255.0), (1, 13, 255.0), (None, None, None)):
+                for premult, has_alpha in ((False, True), (True, True), (False, False)):
+                    src = torch.from_numpy(img.copy()).cuda()
+                    ri = dec.reformat_query(w, h, is16, cfg, has_alpha, 33)
+                    two = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+                    if prim is not None:
+                        dec.color_matrix_device(src.data_ptr(), w, h, is16, depth, prim, tf, target)
+                    dec.reformat_device(src.data_ptr(), w, h, is16, depth, cfg, premult, has_alpha, 33, two.data_ptr(), two.numel())
+                    src2 = torch.from_numpy(img.copy()).cuda()
+                    one = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+                    ri2 = dec.post_fused_device(src2.data_ptr(), w, h, is16, depth, prim is not None, prim or 1, tf if prim else 13, target if prim else 255.0, cfg,
+                                                premult, has_alpha, 33, one.data_ptr(), one.numel())
+                    torch.cuda.synchronize()
+                    assert (ri2.stride, ri2.format, ri2.resolved_config) == (ri.stride, ri.format, ri.resolved_config)
+                    assert torch.equal(one, two), (is16, int(cfg), prim, tf, premult, has_alpha)
+                    assert np.array_equal(src2.cpu().numpy(), img)                     # the fused form leaves its source alone
+                    checked += 1
+    assert checked == 2 * 6 * 4 * 3
+    dec.close()
+
+
+@pytest.mark.gpu
+def test_decode_pipeline_fused_equals_staged():
+    """JxlCoder.decode's post stages fused (default) vs as the reference's two stages: same Bitmap bytes (PQ 16-bit with tone map -> F16 /
+    1010102, RGBA with alpha -> 565 / F16, plain sRGB -> 8888)."""
+    import jxl_coder_amd as J
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_case
+    for name, cfgs in (("v160x120_16bit_pq2100_epf3", (J.PreferredColorConfig.RGBA_F16, J.PreferredColorConfig.RGBA_1010102, J.PreferredColorConfig.RGBA_8888)),
+                       ("va300x520_e7", (J.PreferredColorConfig.RGB_565, J.PreferredColorConfig.RGBA_F16, J.PreferredColorConfig.DEFAULT)),
+                       ("v256_e7", (J.PreferredColorConfig.RGBA_8888, J.PreferredColorConfig.HARDWARE))):
+        data = load_case(name)[0]
+        for cfg in cfgs:
+            a = J.JxlCoder._decode_pipeline(data, cfg, 33, None, fused_post=True)
+            b = J.JxlCoder._decode_pipeline(data, cfg, 33, None, fused_post=False)
+            assert (a.stride, a.config, a.use_floats) == (b.stride, b.config, b.use_floats)
+            assert np.array_equal(a.rows, b.rows), (name, int(cfg))

@@ -88,13 +88,12 @@ def main():
     for b in range(nb):
         px = outs[b].cpu().numpy().reshape(-1, w, 4)
         r = ref[rws[b][0] * 256: rws[b][0] * 256 + px.shape[0]]
-        rs_ok = bool(np.array_equal(px[..., :3].sum(axis=(1, 2), dtype=np.int64) // (3 * w) // 8, r[..., :3].sum(axis=(1, 2), dtype=np.int64) // (3 * w) // 8))
         mx = 0; sm = 0
         for y0 in range(0, px.shape[0], 256):
             d = np.abs(px[y0:y0 + 256].astype(np.int16) - r[y0:y0 + 256].astype(np.int16)); mx = max(mx, int(d.max())); sm += int(d.sum(dtype=np.int64))
         worst = max(worst, mx); tot += sm
-        print("  band %d group rows %s (%d groups, output byte offset %d): %.0f / %.0f / %.0f ms | vs reference: max |diff| %d mean %.4f, coarse row means equal: %s"
-              % (b, rws[b], (rws[b][1] - rws[b][0]) * ((w + 255) // 256), rws[b][0] * 256 * w * 4, *(stage[b] * 1e3), mx, sm / px.size, rs_ok), flush=True)
+        print("  band %d group rows %s (%d groups, output byte offset %d): %.0f / %.0f / %.0f ms | vs reference: max |diff| %d mean %.4f"
+              % (b, rws[b], (rws[b][1] - rws[b][0]) * ((w + 255) // 256), rws[b][0] * 256 * w * 4, *(stage[b] * 1e3), mx, sm / px.size), flush=True)
     print("all bands vs reference: max |diff| %d, mean %.4f  (tolerance: max <= 1, mean <= 0.05)" % (worst, tot / (w * h * 4)))
     print("one band per GPU: max-over-bands %.0f ms, sum over bands (this GPU, sequential) %.0f ms = %.0f MP/s; reference CPU %.0f ms; halo per border and direction: LF %d B, pixels %d B"
           % (stage.sum(axis=1).max() * 1e3, stage.sum() * 1e3, w * h / 1e6 / stage.sum(), t_ref * 1e3, halo[0], halo[1]))
@@ -103,7 +102,7 @@ def main():
     rws2, outs2, stage2, _ = decode_bands(n2)
     same = bool(torch.equal(torch.cat(outs2), whole_rows))
     print("%d bands == %d bands (other borders, LF groups split) bit for bit over %d bytes: %s" % (nb, n2, whole_rows.numel(), same))
-    if not same or worst > 1:
+    if not same or worst > 1 or tot / (w * h * 4) > 0.05:
         raise SystemExit(1)
 
 

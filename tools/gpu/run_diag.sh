@@ -1,10 +1,11 @@
 ulimit -c 0
 mkdir -p gpurun_out/diag
-for v in "" 14 3; do
-  lib=jxl_coder_amd/libjxlamd${v:+_abl$v}.so
-  echo "== mask ${v:-0}"
-  JXLAMD_BENCH_CLOCKS=1 JXLAMD_LIB=$PWD/$lib timeout 600 python bench.py --no-cpu-baseline --distinct 0 --steps 8 --warmup 2 2>gpurun_out/diag/err_${v:-0}.txt | tail -1 > gpurun_out/diag/b_${v:-0}.json
-  grep clocks gpurun_out/diag/err_${v:-0}.txt
-  python -c "
-import json; d=json.load(open('gpurun_out/diag/b_${v:-0}.json')); print('value', d['value'], d['roofline']['stage_ms_per_flight'])"
-done
+timeout 900 python -m pytest tests/test_post_stages.py -x -q -m gpu 2>&1 | grep -E "^E|passed|failed" | head -12
+for rep in 1 2; do for v in "" pool30 noprio; do
+  lib=jxl_coder_amd/libjxlamd${v:+_$v}.so
+  for m in full lfonly; do
+    if [ $m = lfonly ]; then continue; fi
+    JXLAMD_LIB=$PWD/$lib timeout 600 python bench.py --no-cpu-baseline --distinct 0 --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('${v:-default}', 'value', d['value'], d['roofline']['stage_ms_per_flight'])"
+  done
+done; done

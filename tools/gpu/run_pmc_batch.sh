@@ -12,7 +12,7 @@ if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; fi
 for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-30)
   rm -rf /tmp/pmcb
-  PYTHONPATH=$R timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb -o p -- python $R/bench.py --no-cpu-baseline --steps 1 --batch 128 --inflight 128 --contexts 1 --warmup 0 > /tmp/pmcb.log 2>&1
+  PYTHONPATH=$R timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmcb -o p -- python $R/bench.py --no-cpu-baseline --distinct 0 --steps 1 --batch 128 --inflight 128 --contexts 1 --warmup 0 > /tmp/pmcb.log 2>&1
   f=$(find /tmp/pmcb -name '*counter_collection.csv' | head -1)
   python - "$f" "$O/$tag.json" <<'PY'
 import csv, sys, json, collections

@@ -3,7 +3,7 @@
 (oracle/_ref: the libjxl the reference ships) at q90 = distance 1.0, effort 7.
   make_bench_frames.py [N]                 bench_data/syn4k_q90_seed{1..N-1}.jxl + their row sums in tests/golden/golden.json (committed
                                            fixtures; seed 0 comes from tests/golden/make_golden.py) — run in the build container
-  make_bench_frames.py --out DIR --count N  seeds 0..N-1 into DIR (not committed: bench.py generates its 256 distinct frames on the box;
+  make_bench_frames.py --out DIR --count N [--kind c5]  seeds 0..N-1 into DIR (c5: 4K Rec.2100 PQ 16-bit EPF=3 frames) (not committed: bench.py generates its 256 distinct frames on the box;
                                            seeds that exist under bench_data/ are copied, the rest encoded by a process pool)
 Input preparation only: nothing here is part of the decode path."""
 import json, os, shutil, sys
@@ -12,8 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def encode(seed, threads):
+def encode(seed, threads, kind="c3"):
     import jxl_ref, synth
+    if kind == "c5":     # BASELINE configs[4]: 4K Rec.2100 PQ 16-bit, distance 1.0, EPF forced to 3 iterations
+        return jxl_ref.encode(synth.photo_like(3840, 2160, seed=1000 + seed, bits=16), effort=7, distance=1.0, epf=3, primaries=9, transfer=16,
+                              intensity_target=10000.0, threads=threads)
     return jxl_ref.encode(synth.photo_like(3840, 2160, seed=seed), effort=7, distance=1.0, threads=threads)
 
 
@@ -27,15 +30,15 @@ def one(seed):
 
 
 def one_to(args):
-    seed, out = args
-    dst = os.path.join(out, f"syn4k_q90_seed{seed}.jxl")
+    seed, out, kind = args
+    dst = os.path.join(out, f"syn4k_q90_seed{seed}.jxl" if kind == "c3" else f"syn4k_pq16_epf3_seed{seed}.jxl")
     if os.path.exists(dst):
         return seed
     src = os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{seed}.jxl")
-    if os.path.exists(src):
+    if kind == "c3" and os.path.exists(src):
         shutil.copy(src, dst)
         return seed
-    data = encode(seed, 1)
+    data = encode(seed, 1, kind)
     with open(dst + ".tmp", "wb") as f:
         f.write(data)
     os.replace(dst + ".tmp", dst)
@@ -46,9 +49,10 @@ if __name__ == "__main__":
     if "--out" in sys.argv:
         out = sys.argv[sys.argv.index("--out") + 1]
         n = int(sys.argv[sys.argv.index("--count") + 1]) if "--count" in sys.argv else 256
+        kind = sys.argv[sys.argv.index("--kind") + 1] if "--kind" in sys.argv else "c3"
         os.makedirs(out, exist_ok=True)
         with ProcessPoolExecutor(max(1, min(96, (os.cpu_count() or 2) // 2))) as ex:
-            done = list(ex.map(one_to, [(s, out) for s in range(n)], chunksize=1))
+            done = list(ex.map(one_to, [(s, out, kind) for s in range(n)], chunksize=1))
         print(json.dumps({"dir": out, "frames": len(done)}))
         raise SystemExit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
