@@ -45,7 +45,7 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   bandtab.dB = (const DevBuffers *)db; bandtab.dA = (const DevAux *)(db + o_a);
   bandtab.lf_map = (const int *)(db + o_m); bandtab.pg_map = bandtab.lf_map + 2 * q.nlfg; bandtab.wmap = bandtab.lf_map + n_pairs; bandtab.nwg = nwg; bandtab.flags = flags;
   HIPCHECK(hipEventRecord(ev[0], stream));
-  launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, lf_pool_bytes, stream);
+  launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, lf_pool_bytes, /*general=*/true, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   uint32_t derr = 0;
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));

@@ -58,6 +58,8 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
 }
 
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
+// internal return code: the lean LF kernel met a channel that needs a general lock-step loop (kErrNeedGeneral) — decode again with the general build
+static constexpr int kRetryGeneral = 0x7e7e;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
@@ -203,6 +205,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   HIPCHECK(hipMemcpyAsync(&end_bit, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
+  if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
   HIPCHECK(S.tables.ensure(S.plan.tables.size()));
@@ -267,12 +270,20 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   derr = head[0];
   if (!S.plan.modular) lf_pool_bytes = lf_pool_clamp(head[1]);
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
+  if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
   return JXLAMD_OK;
 }
 
 int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+  int rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
+  if (rc0 != kRetryGeneral) return rc0;
+  lf_general = true;
+  return decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
+}
+
+int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
   HIPCHECK(hipSetDevice(device));
   FrameSlot &S = slot(0);
   int rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
@@ -287,7 +298,7 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
     return rc;
   }
   if (S.plan.has_ec) launch_mod_global(S.B, stream);
-  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, stream);
+  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, lf_general, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
@@ -334,6 +345,14 @@ std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
 // per frame on the same stream.  Frames that need the single-section round trip are decoded one by one.
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
+  int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  if (rc0 != kRetryGeneral) return rc0;
+  lf_general = true;                       // some frame needs a general lock-step loop: this context runs the general LF build from now on
+  return decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+}
+
+int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
+                                      void *const *outs, const size_t *caps, jxlamd_info *infos) {
   HIPCHECK(hipSetDevice(device));
   std::vector<int> batched, mod_batched;
   // JXLAMD_TRACE_FLIGHT=1: wall-clock split of every flight on stderr (host parse / per-frame prepare + uploads / launches / wait)
@@ -360,7 +379,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section) {
       if (S.plan.has_ec) launch_mod_global(S.B, stream);
-      launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, stream);
+      launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, lf_general, stream);
       if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
       launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
       launch_pass_groups(S.B, S.plan.num_groups, stream);
@@ -517,7 +536,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
   const int JXL_ABLATE = (JXL_ABLATE_MASK && ++ablate_flights > 2) ? JXL_ABLATE_MASK : 0;
   if (!(JXL_ABLATE & 1)) launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, lf_pool_bytes, stream);
+  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, lf_pool_bytes, lf_general, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   if (!(JXL_ABLATE & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
@@ -554,6 +573,7 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
     pool_want = std::max(pool_want, head[1]);
+    if ((head[0] & kErrNeedGeneral) && !lf_general) return kRetryGeneral;      // (coef_pool_clean stays false: the second attempt clears the pool)
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
   }

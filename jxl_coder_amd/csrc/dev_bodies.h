@@ -17,7 +17,7 @@ struct DevAux {
 #else
 #define JXL_STAMP(i) do { } while (0)
 #endif
-template <bool kWave = true, class Sync>
+template <bool kWave = true, bool kGeneral = true, class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
   JXL_STAMP(0);
   if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = B.err + 1; }      // word 1 of the frame's flag block: LDS table pool the streams would have liked
@@ -29,7 +29,7 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   modular_stream_stage(S, tid, nthreads);
   sync();
   JXL_STAMP(1);
-  uint32_t e = lf_phase_coeffs<kWave>(B, S, g, tid);          // whole wave on the GPU (kWave), or this lane alone
+  uint32_t e = lf_phase_coeffs<kWave, kGeneral>(B, S, g, tid);          // whole wave on the GPU (kWave), or this lane alone
   JXL_STAMP(2);
   if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e | kErrStageLf; } }
   sync();
@@ -37,7 +37,7 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   modular_stream_stage(S, tid, nthreads);
   sync();
   JXL_STAMP(3);
-  e = lf_phase_meta<kWave>(B, S, g, tid);
+  e = lf_phase_meta<kWave, kGeneral>(B, S, g, tid);
   JXL_STAMP(4);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStageLf | (1u << 20); }
   sync();

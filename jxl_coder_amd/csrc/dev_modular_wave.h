@@ -278,8 +278,9 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
 //     predictions that do not involve W, clamp bounds, the max-error candidate) is computed for 32 samples at a time by 32 lanes
 //     in parallel and handed to the serial loop through LDS records (3 ds_reads per sample);
 //   * the reciprocal table is pre-multiplied by the header weights (S.wdiv), the row is copied to HBM once per row.
-// Same integer arithmetic as wave_decode_channel<true, true, true> (bit-exact); rows [0, 1) still go through the generic loop
-// (in row 0 every neighbour is the late value W).
+// Same integer arithmetic as wave_decode_channel<true, true, true> (bit-exact).  Row 0 runs through the same step with constant records:
+// there every neighbour is the late value W and every previous-row error is 0, so sub-predictor k predicts W8 - ((tW * {0, p1, p2, 0}[k]) >> 5),
+// the clamp interval is [W8, W8] and the max-error property is tW — no generic loop (and none of its ~180 registers) in this path.
 struct DevWpFixedLds {                   // overlays DevWaveTree (dead once the channel's tree sits in registers)
   int32_t U[32][8];                      // per sample of the chunk: q, |q|, tN, tN ^ tNW, max(N8, NE8), min(N8, NE8)
   int32_t K[32][4][4];                   // per sample and sub-predictor k: error-sum base, A_k, B_k
@@ -401,11 +402,22 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
     const int32_t *rN = S.rows[(y + 2) % 3];
     const int32_t *rNN = S.rows[(y + 1) % 3];
     const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
-    int32_t W8 = rN[0] * 8, tW = 0;           // x = 0: W is replaced by N, its error by 0
+    const bool row0 = y == 0;
+    const int cwm = row0 ? -1 : cWmask;       // row 0: every sub-predictor starts from W (N, NE, NW, NN are W there)
+    const bool upw = use_pw && !row0;         // ... and the (NW - W) term vanishes
+    int32_t W8 = row0 ? 0 : rN[0] * 8, tW = 0;           // x = 0: W is replaced by N (0 in row 0), its error by 0
     uint32_t e1 = 0, e2 = 0;                  // this lane's sub-predictor error of the previous / second previous sample
     for (int x0 = 0; x0 < w; x0 += 32) {
       const int n = w - x0 < 32 ? w - x0 : 32;
-      if (lane < n) {                         // ---- parallel part: everything sample x0 + lane takes from the previous rows
+      if (row0) {
+        if (lane < n) {
+          int4 u0; int2 u1; u0.x = 0; u0.y = 0; u0.z = 0; u0.w = 0; u1.x = (int)0x80000000; u1.y = 0x7fffffff;
+          *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.U[lane][4] = u1;
+          int4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) *(int4 *)&R.K[lane][kk][0] = z;
+        }
+      } else if (lane < n) {                  // ---- parallel part: everything sample x0 + lane takes from the previous rows
         const int x = x0 + lane, pos = prev_row + x;
         const bool has_l = x > 0, has_r = x + 1 < w;
         const int32_t N = rN[x], NE = has_r ? rN[x + 1] : N, NW = has_l ? rN[x - 1] : N, NN = y > 1 ? rNN[x] : N;
@@ -460,8 +472,8 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         __builtin_amdgcn_sched_barrier(0);
         // ... prediction of sub-predictor k and the clamp bounds while the tables come in
         int32_t inner = kr.z + __mul24(tW, PT);
-        if (use_pw) inner += __mul24(W8, PW);
-        const int32_t wpk = kr.y + (W8 & cWmask) - (inner >> 5);
+        if (upw) inner += __mul24(W8, PW);
+        const int32_t wpk = kr.y + (W8 & cwm) - (inner >> 5);
         const int32_t mx = u1.x > W8 ? u1.x : W8, mn = u1.y < W8 ? u1.y : W8;
         const bool no_clamp = ((u0.z ^ tW) | u0.w) > 0;
         uint32_t wgt = 4 + (wd >> sh);
@@ -654,7 +666,9 @@ __device__ __forceinline__ bool wave_restage_compact(const DevECView &g, int num
 }
 
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
-template <bool kLds>
+// kGeneral = false: the kernel carries no general lock-step loop (wave_decode_channel: ~180 VGPRs for the lifetime of the wave); a channel
+// that needs one ends the stream with kErrNeedGeneral and the host decodes the frame again with the general kernel.
+template <bool kLds, bool kGeneral>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
                                                         int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
                                                         const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
@@ -702,17 +716,13 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + (cid << 8); my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
       }
       __syncthreads();
-      // row 0 goes through the generic loop (every neighbour is the late value W there); once the pool holds packed tables
-      // the generic loops of this stream read their tables through L2 instead
-      if (pool_packed) wave_decode_channel<false, true, true>(evg, b, state, wp, S, WT, c, lane, /*y_end=*/1);
-      else wave_decode_channel<kLds, true, true>(ev, b, state, wp, S, WT, c, lane, /*y_end=*/1);
-      __syncthreads();
-      pool_packed = true;                              // whatever happens next, the pool no longer holds the stream's 8-byte tables / context map
+      // once the pool holds packed tables the other loops of this stream read their tables through L2 (or restage them compactly)
       if (wave_pack_alias(evg.alias, used, la_p, S, lane)) {   // per channel: the set of clusters may differ
-        wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/1);
+        pool_packed = true;                            // the pool no longer holds the stream's 8-byte tables / context map
+        wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/0);
         continue;
       }
-      return kErrUnsupportedTransform | kErrTreeLocal;      // symbols >= 128 in an LF stream: not produced by libjxl (row 0 is already consumed)
+      // symbols >= 128 in an LF stream (not produced by libjxl): the pool is untouched, the general loops below take the channel
       }
     }
     // the LDS (kLds) form of the remaining loops needs the stream's tables in the pool: there from modular_stream_stage, or staged
@@ -748,6 +758,7 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         continue;
       }
     }
+    if (!kGeneral) return kErrNeedGeneral;
     if (lds_now) {
       if (m16) { if (uses_wp) wave_decode_channel<true, true, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<true, true, false>(ev, b, state, wp, S, WT, c, lane); }
       else { if (uses_wp) wave_decode_channel<true, false, true>(ev, b, state, wp, S, WT, c, lane); else wave_decode_channel<true, false, false>(ev, b, state, wp, S, WT, c, lane); }
@@ -760,6 +771,7 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
 }
 
 // Stream-level wrapper: every lane calls it; falls back to the serial walker when the tree is too large.
+template <bool kGeneral = true>
 __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
   DevModStream &st = S.st;
   if (st.err) return st.err;
@@ -775,8 +787,8 @@ __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S,
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
   const bool lds = S.ctx_lds && S.alias_lds && !ev.use_prefix;
-  uint32_t err = lds ? modular_decode_channels_wave<true>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
-                     : modular_decode_channels_wave<false>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
+  uint32_t err = lds ? modular_decode_channels_wave<true, kGeneral>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
+                     : modular_decode_channels_wave<false, kGeneral>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
   __syncthreads();
   if (err == kErrWaveFallback) {
     if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);

@@ -80,24 +80,24 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
 }
 // one stream's channels: the whole wave on the GPU (dev_modular_wave.h), lane 0 alone in the CPU harness
 // kWave = false: the calling lane decodes the stream alone with the serial walker (lane-per-stream kernels)
-template <bool kWave = true>
+template <bool kWave = true, bool kGeneral = true>
 JXL_DEV uint32_t lf_decode_stream(DevModScratch &S, const DevChanOut *ch, int nch, int stream_id, int tid) {
 #ifdef __HIPCC__
   if (!kWave) return modular_stream_decode(S, ch, nch, stream_id);
-  return modular_stream_decode_wave(S, ch, nch, stream_id, tid);
+  return modular_stream_decode_wave<kGeneral>(S, ch, nch, stream_id, tid);
 #else
   return tid == 0 ? modular_stream_decode(S, ch, nch, stream_id) : 0;
 #endif
 }
 // phase 2a (all lanes): decode LF coefficients (channels Y, X, B)
-template <bool kWave = true>
+template <bool kWave = true, bool kGeneral = true>
 JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g, int tid) {
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   DevChanOut *ch = S.ch;
   for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
-  return lf_decode_stream<kWave>(S, ch, 3, 1 + g, tid);
+  return lf_decode_stream<kWave, kGeneral>(S, ch, 3, 1 + g, tid);
 }
 // phase 2b (lane 0): block count, begin the HF-metadata stream
 JXL_DEV uint32_t lf_phase_meta_open(const DevBuffers &B, DevModScratch &S, int g) {
@@ -111,7 +111,7 @@ JXL_DEV uint32_t lf_phase_meta_open(const DevBuffers &B, DevModScratch &S, int g
   return 0;
 }
 // phase 3a (all lanes): decode HF metadata
-template <bool kWave = true>
+template <bool kWave = true, bool kGeneral = true>
 JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int tid) {
   const DevFrame &F = frame_of(B);
   const LfGeom q = lf_geom(F, g);
@@ -123,7 +123,7 @@ JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int
   ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
   ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;
   ch[3].d = m_sharp; ch[3].w = q.bw; ch[3].h = q.bh;
-  return lf_decode_stream<kWave>(S, ch, 4, 1 + 2 * F.num_lf_groups + g, tid);
+  return lf_decode_stream<kWave, kGeneral>(S, ch, 4, 1 + 2 * F.num_lf_groups + g, tid);
 }
 #ifdef __HIPCC__
 // lanes 0 .. n-1 hold list entries (class << 28 | cell): one atomicAdd per class reserves the slots, the lanes store

@@ -7,8 +7,9 @@
 namespace jxlamd {
 // pool_bytes: LDS table pool per stream of this launch (kModPoolMin .. kModPoolBytes, dev_modular.h); lf_pool_clamp turns what the streams of
 // a decode reported (word 1 of a frame's flag block) into the value for the next one
-void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, int pool_bytes, hipStream_t s);
-void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, int pool_bytes, hipStream_t s);
+// general: the build with the general lock-step loops (a frame the lean build ended with kErrNeedGeneral)
+void launch_lf_groups(const DevBuffers &B, const DevAux &A, int num_lf_groups, int pool_bytes, bool general, hipStream_t s);
+void launch_lf_groups_batch(const DevBuffers *Bs, const DevAux *As, const int *map, int nblocks, int pool_bytes, bool general, hipStream_t s);
 int lf_pool_clamp(uint32_t wanted);
 // flights / large bands: k_pass_prep (group descriptor lists; map = {frame, group} pairs) then k_pass_flat (lane per group; wmap = {frame,
 // first group, groups <= 64} per wavefront, entries with 0 groups allowed); frames must pass flat_frame_ok (dev_pass_flat.h)

@@ -402,16 +402,30 @@ def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
     assert row_err.max() <= tol and blk_err.max() <= 4 * tol and blk_err.mean() <= tol
 
 
+def _pq_eotf(code16):
+    v = code16.astype(np.float64) / 65535
+    m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+    p = np.power(v, 1 / m2)
+    return np.power(np.maximum(p - c1, 0) / (c2 - c3 * p), 1 / m1)
+
+
 def test_pq16_difference_distribution(dec):
-    """PQ-coded 16-bit output (the arithmetic of BASELINE config 5) has no hard max bound against the reference: the PQ curve's slope at
-    black turns last-bit differences of linear light into hundreds of code values on a few near-black samples.  What IS asserted: the
-    distribution.  Measured on the GPU (round 3): see the printed table; bounds = measured, rounded up."""
+    """PQ-coded 16-bit output (the arithmetic of BASELINE config 5) has no hard bound in CODE VALUES against the reference: the PQ curve's
+    slope near zero turns last-bits differences of linear light into hundreds (up to 11 262 here) of code values.  Measured (round 3, GPU
+    == the C oracle): 23 of 57 600 samples differ by more than 256 codes; every one of them is a channel whose LINEAR value is below 0.4 %
+    of full scale in a pixel whose brightest channel is clipped or nearly so (the inverse opsin matrix cancels three terms of order 1 there,
+    so float rounding order decides the fourth digit), and in linear light they differ by at most 3.6e-4 of full scale.  Asserted: the
+    code-value distribution, and the bound in linear light (whole image: 3.6e-3 at the bright end, where one code is 1.6e-4)."""
     data, exp = load_case("v160x120_16bit_pq2100_epf3")
     out, _ = dec.decode_one_shot(data, allowed_floats=True)
-    d = np.abs(out[..., :3].astype(int) - exp[..., :3].astype(int)).ravel()
+    d = np.abs(out[..., :3].astype(int) - exp[..., :3].astype(int))
+    la, lb = _pq_eotf(out[..., :3]), _pq_eotf(exp[..., :3])
+    dl = np.abs(la - lb)
     pct = {p: float(np.percentile(d, p)) for p in (50, 90, 99, 99.9, 99.99)}
-    dark = exp[..., :3].ravel() < 2048                                       # below ~0.6 cd/m2 on the PQ scale
-    print("[pq16] |diff| mean %.2f max %d percentiles %s; samples > 256: %d of %d, all of them near black: %s" %
-          (d.mean(), d.max(), pct, int((d > 256).sum()), d.size, bool(dark[d > 256].all())))
-    assert d.mean() <= 16.0 and pct[99] <= 256 and (d > 256).mean() < 2e-3
-    assert dark[d > 256].all()                                               # every outlier sits where the PQ slope explodes
+    big = d > 256
+    print("[pq16] |diff| mean %.2f max %d percentiles %s; samples > 256 codes: %d of %d; in linear light: max %.2e (whole image), %.2e (those samples), their brightest linear value %.2e" %
+          (d.mean(), d.max(), pct, int(big.sum()), d.size, dl.max(), dl[big].max() if big.any() else 0.0, np.maximum(la, lb)[big].max() if big.any() else 0.0))
+    assert d.mean() <= 16.0 and pct[99] <= 256 and big.mean() < 2e-3
+    assert dl.max() <= 6e-3
+    if big.any():
+        assert dl[big].max() <= 1e-3 and np.maximum(la, lb)[big].max() <= 1e-2      # outliers: dark channels, close in linear light
