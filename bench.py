@@ -186,6 +186,8 @@ def main():
     J.api.lib().jxlamd_basic_info(data, len(data), J.api.C.byref(info0))
     import threading
 
+    stagger_ms = float(os.environ.get("JXLAMD_BENCH_STAGGER_MS", "0"))
+
     def run_frames(n, resident=True):
         """n full decodes.  Flights of P frames; NCTX decoder contexts (own HIP stream + HBM buffers each) take flights
         alternately so that one flight's entropy stages overlap another's data-parallel stages."""
@@ -206,6 +208,8 @@ def main():
 
         def _worker(c):
             torch.cuda.set_device(local)
+            if stagger_ms > 0:      # contexts enter their first flight one after another: their stages stay out of phase
+                time.sleep(c * stagger_ms / 1e3)
             while True:
                 with lock:
                     if not todo:

@@ -253,26 +253,25 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
-    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_dct8_b / k_recon_dct_rc_b have reconstructed it
+    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
     __syncthreads();
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
-__global__ void __launch_bounds__(64) k_recon_dct8_b(const DevBuffers *Bs, const uint8_t *stat) {
-  __shared__ float S[3 * 64];
-  __shared__ float T[3 * 64];
-  const DevBuffers &B = Bs[blockIdx.z];
+// list walkers of the one-wave-per-block families: workgroup `wg` of `nwg` takes every nwg-th entry of the class's size list and
+// reconstructs the blocks of its own strategy.  smem: the workgroup's LDS (k_recon_lists_*: one launch for several families)
+__device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8_t *stat, float *smem, uint32_t wg, uint32_t nwg) {
+  float *S = smem, *T = smem + 3 * 64;
   const DevFrame &F = frame_of(B);
-  if (F.is_modular || frame_failed(B)) return;
   const uint32_t count = B.big_count[2];
-  if (blockIdx.x >= count) return;
+  if (wg >= count) return;
   const int lane = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
   float cx8[8], cy8[8];                               // 8-point cosine table, row k: this lane's column x = lane & 7 / its row y = lane >> 3
   { const float *cc = st_f(stat, ST.cos_off[3]);
 #pragma unroll
     for (int k = 0; k < 8; k++) { cx8[k] = cc[k * 8 + (lane & 7)]; cy8[k] = cc[k * 8 + (lane >> 3)]; } }
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+  for (uint32_t i = wg; i < count; i += nwg) {
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != 0) continue;
@@ -361,26 +360,49 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
     for (int j = 0; j < NJ; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
 }
 template <int R, int C, int STRAT, int LIST>      // LIST: the size-class list the strategy's blocks are on (2: <= 256 coefficients, 0: 512 / 1024)
-__global__ void __launch_bounds__(64) k_recon_dct_rc_b(const DevBuffers *Bs, const uint8_t *stat) {
-  __shared__ __attribute__((aligned(16))) float S[3 * R * C];
-  __shared__ __attribute__((aligned(16))) float T[3 * R * C];
-  __shared__ __attribute__((aligned(16))) float ccC[C * C];
-  __shared__ __attribute__((aligned(16))) float crR[R * R];
-  const DevBuffers &B = Bs[blockIdx.z];
+__device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uint8_t *stat, float *smem, uint32_t wg, uint32_t nwg) {
+  float *S = smem, *T = smem + 3 * R * C, *ccC = smem + 6 * R * C, *crR = smem + 6 * R * C + C * C;
   const DevFrame &F = frame_of(B);
-  if (F.is_modular || frame_failed(B)) return;
   const uint32_t count = B.big_count[LIST];
-  if (blockIdx.x >= count) return;
+  if (wg >= count) return;
   const int lane = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
   for (int i = lane; i < C * C; i += 64) ccC[i] = st_f(stat, ST.cos_off[C == 8 ? 3 : C == 16 ? 4 : 5])[i];
   for (int i = lane; i < R * R; i += 64) crR[i] = st_f(stat, ST.cos_off[R == 8 ? 3 : R == 16 ? 4 : 5])[i];
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+  for (uint32_t i = wg; i < count; i += nwg) {
     const int cell = (int)B.big_list[LIST][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != STRAT) continue;
     __syncthreads();
     recon_dct_rc_block<R, C>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
+  }
+}
+// The one-wave-per-block families in TWO launches instead of nine (blockIdx.y = family): every launch of a flight's stream is a
+// serialisation point — the previous kernel drains, the next one waits for slots among the kernels of 15 other contexts — and these
+// kernels carry a few per cent of the area of smooth content.  _a: DCT8x8, 16x16, 16x8, 8x16 (8 KB of LDS, <= 90 VGPRs: the bulk of
+// photographic content); _b: the 32-wide / 32-tall rectangles (17 KB).
+__global__ void __launch_bounds__(64) k_recon_lists_a(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) float smem[6 * 256 + 2 * 256];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  switch (blockIdx.y) {
+    case 0: recon_dct8_walk(B, stat, smem, blockIdx.x, gridDim.x); break;
+    case 1: recon_dct_rc_walk<16, 16, 4, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;     // AcStrategy 4: DCT16x16
+    case 2: recon_dct_rc_walk<16, 8, 6, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 6: 16 rows x 8 columns
+    default: recon_dct_rc_walk<8, 16, 7, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;     // 7: 8 x 16
+  }
+}
+__global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *Bs, const uint8_t *stat) {
+  __shared__ __attribute__((aligned(16))) float smem[6 * 512 + 256 + 1024];
+  const DevBuffers &B = Bs[blockIdx.z];
+  const DevFrame &F = frame_of(B);
+  if (F.is_modular || frame_failed(B)) return;
+  switch (blockIdx.y) {
+    case 0: recon_dct_rc_walk<32, 8, 8, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 8: 32 x 8
+    case 1: recon_dct_rc_walk<8, 32, 9, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 9: 8 x 32
+    case 2: recon_dct_rc_walk<32, 16, 10, 0>(B, stat, smem, blockIdx.x, gridDim.x); break;    // 10: 32 x 16
+    default: recon_dct_rc_walk<16, 32, 11, 0>(B, stat, smem, blockIdx.x, gridDim.x); break;   // 11: 16 x 32
   }
 }
 // DCT32x32 blocks only (98 % of the area of smooth 4K content): half the LDS of the general medium kernel (the second pass runs in
@@ -426,7 +448,7 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs,
     const int cell = (int)B.big_list[0][i];
     const int bx = cell % xb, by = cell / xb;
     const int st = B.strategy[cell];
-    if (by < F.band_cy0 || by >= F.band_cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_dct_rc_b
+    if (by < F.band_cy0 || by >= F.band_cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_lists_b
     __syncthreads();
     recon_block_body<false, true>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
   }
@@ -455,16 +477,11 @@ void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, 
   // per frame fill the chip, and the launches of the families a frame does not use cost 4 096 empty workgroups instead of 16 384
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 256), 1, nframes);
-  hipLaunchKernelGGL(k_recon_dct8_b, gs, dim3(64), 0, s, Bs, stat);
-  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 16, 4, 2>), gs, dim3(64), 0, s, Bs, stat);     // AcStrategy 4: DCT16x16
-  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 8, 6, 2>), gs, dim3(64), 0, s, Bs, stat);      // 6: 16 rows x 8 columns
-  hipLaunchKernelGGL((k_recon_dct_rc_b<8, 16, 7, 2>), gs, dim3(64), 0, s, Bs, stat);      // 7: 8 x 16
-  hipLaunchKernelGGL((k_recon_dct_rc_b<32, 8, 8, 2>), gs, dim3(64), 0, s, Bs, stat);      // 8: 32 x 8
-  hipLaunchKernelGGL((k_recon_dct_rc_b<8, 32, 9, 2>), gs, dim3(64), 0, s, Bs, stat);      // 9: 8 x 32
-  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, 1);                   // the other <= 256-coefficient transforms (AFV, DCT4x8, ...)
+  const dim3 gs4(gs.x, 4, nframes);
   hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
-  hipLaunchKernelGGL((k_recon_dct_rc_b<32, 16, 10, 0>), gs, dim3(64), 0, s, Bs, stat);    // 10: 32 x 16
-  hipLaunchKernelGGL((k_recon_dct_rc_b<16, 32, 11, 0>), gs, dim3(64), 0, s, Bs, stat);    // 11: 16 x 32
+  hipLaunchKernelGGL(k_recon_lists_a, gs4, dim3(64), 0, s, Bs, stat);                     // DCT8x8, 16x16, 16x8, 8x16
+  hipLaunchKernelGGL(k_recon_lists_b, gs4, dim3(64), 0, s, Bs, stat);                     // 32x8, 8x32, 32x16, 16x32
+  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, 1);                   // the other <= 256-coefficient transforms (AFV, DCT4x8, ...)
   hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
   // the 2048 / 4096-coefficient list: one workgroup per frame when the previous flight had none
   hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);

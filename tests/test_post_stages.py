@@ -214,11 +214,12 @@ def test_fused_post_stage_equals_the_two_stage_form():
                     src = torch.from_numpy(img.copy()).cuda()
                     ri = dec.reformat_query(w, h, is16, cfg, has_alpha, 33)
                     two = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+                    one = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+                    src2 = torch.from_numpy(img.copy()).cuda()
+                    torch.cuda.synchronize()          # torch's fill kernels run on torch's stream, the stages on the decoder's own: order them
                     if prim is not None:
                         dec.color_matrix_device(src.data_ptr(), w, h, is16, depth, prim, tf, target)
                     dec.reformat_device(src.data_ptr(), w, h, is16, depth, cfg, premult, has_alpha, 33, two.data_ptr(), two.numel())
-                    src2 = torch.from_numpy(img.copy()).cuda()
-                    one = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
                     ri2 = dec.post_fused_device(src2.data_ptr(), w, h, is16, depth, prim is not None, prim or 1, tf if prim else 13, target if prim else 255.0, cfg,
                                                 premult, has_alpha, 33, one.data_ptr(), one.numel())
                     torch.cuda.synchronize()
