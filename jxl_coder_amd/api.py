@@ -109,6 +109,7 @@ def build(force=False, verbose=False):
             jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-MMD", "-MF", obj + ".d",
                          "-c", src, "-o", obj])
     if not jobs and os.path.exists(_LIB_PATH) and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        build_compat(verbose=verbose)
         return _LIB_PATH
 
     def run(cmd):
@@ -118,7 +119,30 @@ def build(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as ex:
         list(ex.map(run, jobs))
     run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", _LIB_PATH] + objs)
+    build_compat(verbose=verbose)
     return _LIB_PATH
+
+
+def compat_dir():
+    """Directory of the libjxl-named libraries of the secondary boundary (include/jxl_amd_libjxl.h): libjxl.so, libjxl_threads.so."""
+    return os.path.join(_HERE, "compat")
+
+
+def build_compat(verbose=False):
+    """compat/libjxl.so + compat/libjxl_threads.so: the libjxl C-API subset the reference's decode path calls, over libjxlamd.so
+    (host-only glue, plain g++)."""
+    src = os.path.join(_HERE, "csrc", "libjxl_abi.cpp")
+    os.makedirs(compat_dir(), exist_ok=True)
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(os.path.dirname(_HERE), "include", "jxl_amd_libjxl.h")), os.path.getmtime(_LIB_PATH))
+    for name, macro, extra in (("libjxl.so", "-DJXLC_ONLY_DECODER", [_LIB_PATH, "-Wl,-rpath,$ORIGIN/.."]), ("libjxl_threads.so", "-DJXLC_ONLY_THREADS", [])):
+        out = os.path.join(compat_dir(), name)
+        if os.path.exists(out) and os.path.getmtime(out) >= newest:
+            continue
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", macro, "-Wl,-soname," + name, "-o", out, src] + extra
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return compat_dir()
 
 
 def lib():

@@ -66,29 +66,4 @@ bool DecodeBasicInfo(const uint8_t *jxl, size_t size, size_t *xsize, size_t *ysi
   return true;
 }
 
-// ---- C entry points for tests/test_boundary.py (ctypes cannot pass std::vector)
-extern "C" int boundary_basic_info(const uint8_t *jxl, size_t size, uint64_t *wh) {
-  size_t w = 0, h = 0;
-  if (!DecodeBasicInfo(jxl, size, &w, &h)) return 0;
-  wh[0] = w; wh[1] = h;
-  return 1;
-}
-// returns 1 ok, 0 false, -3 InvalidImageSizeException (message copied to msg)
-extern "C" int boundary_decode(const uint8_t *jxl, size_t size, int allowed_floats, uint8_t *out, size_t cap, uint64_t *meta, double *xy8, char *msg, size_t msg_cap) {
-  std::vector<uint8_t> px, icc;
-  size_t w = 0, h = 0; bool use_floats = false, premul = false, prefer = false, has_alpha = false; uint32_t depth = 0; float it = 0;
-  JxlOrientation orient = JXL_ORIENT_IDENTITY; JxlColorEncoding ce; memset(&ce, 0, sizeof(ce));
-  try {
-    if (!DecodeJpegXlOneShot(jxl, size, &px, &w, &h, &icc, &use_floats, &depth, &premul, allowed_floats != 0, &orient, &prefer, &ce, &has_alpha, &it)) return 0;
-  } catch (InvalidImageSizeException &e) {
-    strncpy(msg, e.what(), msg_cap - 1); msg[msg_cap - 1] = 0;
-    return -3;
-  }
-  if (px.size() > cap) return 0;
-  memcpy(out, px.data(), px.size());
-  meta[0] = w; meta[1] = h; meta[2] = use_floats; meta[3] = depth; meta[4] = premul; meta[5] = (uint64_t)orient; meta[6] = prefer; meta[7] = has_alpha;
-  meta[8] = (uint64_t)ce.primaries; meta[9] = (uint64_t)ce.transfer_function; meta[10] = icc.size(); meta[11] = (uint64_t)(it * 1000.0f);
-  xy8[0] = ce.white_point_xy[0]; xy8[1] = ce.white_point_xy[1]; xy8[2] = ce.primaries_red_xy[0]; xy8[3] = ce.primaries_red_xy[1];
-  xy8[4] = ce.primaries_green_xy[0]; xy8[5] = ce.primaries_green_xy[1]; xy8[6] = ce.primaries_blue_xy[0]; xy8[7] = ce.primaries_blue_xy[1];
-  return 1;
-}
+#include "boundary_entry.inc"
