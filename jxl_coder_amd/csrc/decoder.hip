@@ -62,6 +62,12 @@ static int err_class(const std::string &e) { return e.rfind("unsupported", 0) ==
 static constexpr int kRetryGeneral = 0x7e7e;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
+// host twin of mod_group_scratch_ints (dev_modframe.h)
+static size_t mod_scratch_ints_host(const DevFrame &F) {
+  const size_t gd = (size_t)(F.mod_group_dim > 0 ? F.mod_group_dim : 256);
+  return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
+}
+
 BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
   BandGeom q;
   q.gr0 = gr0; q.gr1 = gr1;
@@ -148,14 +154,14 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
     if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-      HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
+      HIPCHECK(S.mod_scratch.ensure(((size_t)plan.num_groups + 1) * mod_scratch_ints_host(*Fh) * 4 + 256));      // + 1: the GlobalModular stream's slot
       HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
     if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure(((size_t)Fh->lz_win_len + (size_t)plan.num_groups * (size_t)Fh->lz_win_group) * 4));
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-    HIPCHECK(S.mod_scratch.ensure((size_t)plan.num_groups * (size_t)(Fh->mod_nch - Fh->mod_first_group_ch) * 65536 * 4 + 256));
+    HIPCHECK(S.mod_scratch.ensure(((size_t)plan.num_groups + 1) * mod_scratch_ints_host(*Fh) * 4 + 256));      // + 1: the GlobalModular stream's slot
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));

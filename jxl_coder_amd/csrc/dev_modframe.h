@@ -8,7 +8,12 @@
 namespace jxlamd {
 
 constexpr int kModGroupMaxCh = 8;                      // per group: up to 8 channels of 256x256 (host_parse rejects more)
-JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) { return (size_t)(F.mod_nch - F.mod_first_group_ch) * 65536; }   // per group
+// per group: its channels' rectangles (group_dim^2 samples each) + the HBM error rows of the weighted predictor for channels wider than the
+// LDS rows; slot num_groups (same size) belongs to the GlobalModular stream
+JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) {
+  const size_t gd = (size_t)(F.mod_group_dim > 0 ? F.mod_group_dim : 256);
+  return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
+}
 
 JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
 
@@ -57,6 +62,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
     bits_read(b, (int)skip);
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win : nullptr; S.lz.win_len = F.lz_win_len;      // LZ77 window slot 0
+    S.wide_wp = (uint32_t *)(B.mod_scratch + (size_t)F.num_groups * mod_group_scratch_ints(F) + (size_t)(F.mod_nch - F.mod_first_group_ch) * (size_t)F.mod_group_dim * (size_t)F.mod_group_dim);
     modular_stream_begin(B.tables, F, B.local[0], S, &S.trs);
   }
   sync();
@@ -77,7 +83,8 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xgroups, gy = g / F.xgroups;
-  const int x0 = gx * 256, y0 = gy * 256;
+  const int gd = F.mod_group_dim;
+  const int x0 = gx * gd, y0 = gy * gd;
   const int nch = F.mod_nch - F.mod_first_group_ch;
   int32_t *scr = B.mod_scratch + (size_t)g * mod_group_scratch_ints(F);
   if (tid == 0) {
@@ -88,6 +95,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)F.lz_win_len + (size_t)g * (size_t)F.lz_win_group : nullptr; S.lz.win_len = F.lz_win_group;
+    S.wide_wp = (uint32_t *)(scr + (size_t)nch * (size_t)gd * (size_t)gd);
     modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {
       const DevTr &t = S.trs.t[i];
@@ -103,8 +111,8 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   for (int c = tid; c < nch; c += nthreads) {
     const int fc = F.mod_first_group_ch + c;
     int rw = F.mod_w[fc] - x0, rh = F.mod_h[fc] - y0;
-    rw = rw < 0 ? 0 : rw > 256 ? 256 : rw; rh = rh < 0 ? 0 : rh > 256 ? 256 : rh;
-    S.ch[c].d = scr + (size_t)c * 65536; S.ch[c].w = rw; S.ch[c].h = rh;
+    rw = rw < 0 ? 0 : rw > gd ? gd : rw; rh = rh < 0 ? 0 : rh > gd ? gd : rh;
+    S.ch[c].d = scr + (size_t)c * (size_t)gd * (size_t)gd; S.ch[c].w = rw; S.ch[c].h = rh;
   }
   sync();
   const int sid = 1 + 3 * F.num_lf_groups + 17 + g;

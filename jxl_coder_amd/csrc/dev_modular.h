@@ -71,6 +71,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   DevTrList trs;                      // transforms of the current stream header
   DevWaveTree wt;
   uint32_t fallback_err;
+  uint32_t *wide_wp;                  // HBM: the weighted predictor's error rows for channels wider than the LDS rows (kWideWpInts; null: such channels are rejected)
   DevLz lz;                           // LZ77 state of the current stream (serial walker; window in HBM, set by the stream's caller)
   int32_t pool_bytes;                 // bytes of `pool` actually backed by LDS in this launch (kModPoolMin .. kModPoolBytes)
   uint32_t *pool_want;                // where to report (max) the pool bytes this stream's per-channel table sets need; may be null
@@ -101,7 +102,18 @@ JXL_DEV uint32_t wp_error_weight(const uint32_t *divlut, uint32_t x, uint32_t ma
   return 4 + ((maxweight * divlut[x >> shift]) >> shift);
 }
 
-JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x, int y, int xs, int64_t N, int64_t W,
+// where the weighted predictor keeps its two rows of errors: LDS, or — channels wider than kWpMaxW (Modular group sizes 512 / 1024) — HBM
+constexpr int kWideMaxW = 1024;
+constexpr int kWideWpInts = 5 * 2 * (kWideMaxW + 2);
+struct WpRows { uint32_t *pe[4]; int32_t *te; };
+JXL_DEV WpRows wp_rows(DevModScratch &S, bool wide, int w) {
+  WpRows r;
+  if (!wide) { for (int k = 0; k < 4; k++) r.pe[k] = S.wp_pred_err[k]; r.te = S.wp_err; }
+  else { for (int k = 0; k < 4; k++) r.pe[k] = S.wide_wp + (size_t)k * 2 * (size_t)(w + 2); r.te = (int32_t *)(S.wide_wp + (size_t)4 * 2 * (size_t)(w + 2)); }
+  return r;
+}
+
+JXL_DEV int64_t wp_predict(DevModScratch &S, const WpRows &R, WPState &st, const DevWP &h, int x, int y, int xs, int64_t N, int64_t W,
                            int64_t NE, int64_t NW, int64_t NN, int32_t &max_err) {
   int cur_row = (y & 1) ? 0 : (xs + 2);
   int prev_row = (y & 1) ? (xs + 2) : 0;
@@ -110,12 +122,12 @@ JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x,
   int pos_NW = x > 0 ? pos_N - 1 : pos_N;
   uint32_t w[4];
   for (int i = 0; i < 4; i++) {
-    uint32_t e = S.wp_pred_err[i][pos_N] + S.wp_pred_err[i][pos_NE] + S.wp_pred_err[i][pos_NW];
+    uint32_t e = R.pe[i][pos_N] + R.pe[i][pos_NE] + R.pe[i][pos_NW];
     w[i] = wp_error_weight(S.divlut, e, (uint32_t)h.w[i]);
   }
   N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
-  int64_t teW = x == 0 ? 0 : S.wp_err[cur_row + x - 1];
-  int64_t teN = S.wp_err[pos_N], teNW = S.wp_err[pos_NW], teNE = S.wp_err[pos_NE];
+  int64_t teW = x == 0 ? 0 : R.te[cur_row + x - 1];
+  int64_t teN = R.te[pos_N], teNW = R.te[pos_NW], teNE = R.te[pos_NE];
   int64_t sumWN = teN + teW;
   int64_t p = teW;
   if (iabs64(teN) > iabs64(p)) p = teN;
@@ -141,15 +153,15 @@ JXL_DEV int64_t wp_predict(DevModScratch &S, WPState &st, const DevWP &h, int x,
   return (st.pred + 3) >> 3;
 }
 
-JXL_DEV void wp_update(DevModScratch &S, const WPState &st, int64_t val, int x, int y, int xs) {
+JXL_DEV void wp_update(const WpRows &R, const WPState &st, int64_t val, int x, int y, int xs) {
   int cur_row = (y & 1) ? 0 : (xs + 2);
   int prev_row = (y & 1) ? (xs + 2) : 0;
   val *= 8;
-  S.wp_err[cur_row + x] = (int32_t)(st.pred - val);
+  R.te[cur_row + x] = (int32_t)(st.pred - val);
   for (int i = 0; i < 4; i++) {
     uint32_t err = (uint32_t)((iabs64(st.prediction[i] - val) + 3) >> 3);
-    S.wp_pred_err[i][cur_row + x] = err;
-    S.wp_pred_err[i][prev_row + x + 1] += err;
+    R.pe[i][cur_row + x] = err;
+    R.pe[i][prev_row + x + 1] += err;
   }
 }
 
@@ -223,11 +235,12 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
 #endif
     if (tf.max_prop > 15) return kErrUnsupportedTransform;   // previous-channel properties: not on device yet
     const bool wide = w > kModMaxW;
-    if (wide && tf.uses_wp) return kErrUnsupportedTransform;
+    if (wide && tf.uses_wp && (!S.wide_wp || w > kWideMaxW)) return kErrUnsupportedTransform;
     props[0] = ci;
     WPState wst;
+    const WpRows WR = wp_rows(S, wide && tf.uses_wp, w);
     if (tf.uses_wp) {
-      for (int i = 0; i < 2 * (w + 2); i++) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
+      for (int i = 0; i < 2 * (w + 2); i++) { WR.te[i] = 0; for (int k = 0; k < 4; k++) WR.pe[k][i] = 0; }
     }
     for (int y = 0; y < h; y++) {
       int32_t *out = c.d + (size_t)y * (size_t)w;
@@ -258,7 +271,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         props[13] = (int32_t)(N - NN);
         props[14] = (int32_t)(W - WW);
         int64_t wp_pred = 0;
-        if (tf.uses_wp) { int32_t me; wp_pred = wp_predict(S, wst, wp, x, y, w, N, W, NE, NW, NN, me); props[15] = me; }
+        if (tf.uses_wp) { int32_t me; wp_pred = wp_predict(S, WR, wst, wp, x, y, w, N, W, NE, NW, NN, me); props[15] = me; }
         else props[15] = 0;
         const DevTreeNode *nd = S.tree_ncache > 0 ? &S.tree[0] : &gtree[0];
         while (nd->prop >= 0) {
@@ -270,7 +283,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)nd->rchild + nd->offset + guess;
         row[x] = (int32_t)val;
         if (!wide) out[x] = (int32_t)val;
-        if (tf.uses_wp) wp_update(S, wst, val, x, y, w);
+        if (tf.uses_wp) wp_update(WR, wst, val, x, y, w);
       }
     }
   }

@@ -683,7 +683,7 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     __syncthreads();
     if (!WT.ok) return kErrWaveFallback;                    // caller re-runs the stream with the serial walker
     const bool uses_wp = WT.uses_wp != 0;
-    if (c.w > kModMaxW && uses_wp) return kErrUnsupportedTransform;
+    if (c.w > kModMaxW && uses_wp) return kErrWaveFallback;       // the serial walker keeps the predictor's error rows of such channels in HBM
     // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
     if (m16 && uses_wp && !ev.use_prefix && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
         S.st.num_clusters <= kLocMaxClusters && ev.log_alpha >= 5 && ev.log_alpha <= 8 &&

@@ -86,6 +86,7 @@ struct DevFrame {
   int32_t is_modular, mod_nch, mod_nb_meta, mod_first_group_ch;   // channels [mod_first_group_ch, mod_nch) are decoded per group
   int32_t has_ec;                  // VarDCT frame with extra channels (alpha): the mod_* fields describe the extra-channel Modular image
   int32_t mod_w[12], mod_h[12]; uint32_t mod_plane_off[12];        // int32 planes (offsets in samples into the pool)
+  int32_t mod_group_dim;           // group size of a Modular-encoded frame: 128 << group_size_shift (VarDCT frames: 256)
   uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
   uint32_t lz_win_len;             // LZ77 window entries of the GlobalModular stream (0: the frame's global code has no LZ77) ...
   uint32_t lz_win_group;           // ... and of each group stream; DevBuffers::lz_win = [lz_win_len][num_groups x lz_win_group]

@@ -152,6 +152,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   DevFrame &F = pv->F; const frame_hdr &f = pv->f; const img_meta &m = pv->m;
   F.is_modular = vardct ? 0 : 1; F.has_ec = vardct ? 1 : 0;      // vardct: the Modular image holds only the extra channels
   F.mod_global_bit = (uint32_t)sb->pos;
+  F.mod_group_dim = f.group_dim;
   F.mod_bits = (int)m.pub.bits_per_sample;
   if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
   const int ncol = vardct ? 0 : m.pub.num_color_channels == 1 ? 1 : 3;
@@ -307,7 +308,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) { plan->error = "unsupported: cropped frame"; return -1; }
   if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
   if (f.flags & (1 | 2 | 16 | 32)) { plan->error = "unsupported: patches/splines/noise/LF frame"; return -1; }
-  if (f.group_dim != 256 && !(f.encoding == 1 && f.num_groups == 1 && f.width <= 256 && f.height <= 256)) { plan->error = "unsupported: group size"; return -1; }
+  if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
   // ---- TOC
   int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   std::vector<uint32_t> perm;

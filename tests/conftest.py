@@ -73,10 +73,10 @@ VARDCT_CASES = ["v64_e3_gab0_epf0", "v256_e3_gab0_epf0", "v256_e3_gab1_epf0", "v
                 "vo72x40_e3_o2", "vo72x40_e3_o3", "vo72x40_e3_o4", "vo72x40_e3_o5", "vo72x40_e3_o6", "vo72x40_e3_o7", "vo72x40_e3_o8",   # ImageMetadata.orientation 2..8:
                 "vo264x300_e7_o6"]                                                                                                        # mirrored / transposed / rotated by the writer
 LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x260_e5", "l700x500_e7", "l530x300_e1", "l300x280_e2", "la280x300_e1",
-                  "lo40x24_e7_o5", "lo200x120_e7_o8"]
-# lossless cases the DEVICE path decodes (the *_e1 files are libjxl's effort-1 fast path: prefix codes + LZ77 in every stream; e2 / e5 use
-# a Modular group size other than 256 -> rejected loudly)
-LOSSLESS_DEVICE_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l700x500_e7", "l530x300_e1", "la280x300_e1", "lo40x24_e7_o5", "lo200x120_e7_o8"]
+                  "lo40x24_e7_o5", "lo200x120_e7_o8", "l300x200_g128_e7", "la300x200_g128_e5", "l516x300_g512_e5", "l1030x130_g1024_e3"]
+# lossless cases the DEVICE path decodes: all of them (the *_e1 files are libjxl's effort-1 fast path: prefix codes + LZ77 in every stream; e2 / e5
+# and the *_g* files use Modular group sizes 128 / 512 / 1024)
+LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).

@@ -48,7 +48,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = errw; B.out = out;
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
-  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? (size_t)plan.num_groups * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + 64 : 1, 0);
+  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len, lzg = ((const DevFrame *)plan.tables.data())->lz_win_group;

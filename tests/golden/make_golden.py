@@ -46,11 +46,17 @@ CASES = {
     "l64_e7": (64, 64, dict(seed=1), dict(lossless=True, effort=7)),
     "l200x120_e7": (200, 120, dict(seed=5), dict(lossless=True, effort=7)),
     "l512_e7": (512, 512, dict(seed=1), dict(lossless=True, effort=7)),          # BASELINE config 1
-    "l300x260_e5": (300, 260, dict(seed=6), dict(lossless=True, effort=5)),        # single 512-px group (device: rejected, oracle: exact)
+    "l300x260_e5": (300, 260, dict(seed=6), dict(lossless=True, effort=5)),        # single 512-px group
     "l700x500_e7": (700, 500, dict(seed=7), dict(lossless=True, effort=7)),        # 3x2 groups with ragged edges
     "l530x300_e1": (530, 300, dict(seed=31), dict(lossless=True, effort=1)),       # libjxl's fast lossless path: prefix codes + LZ77 in every group stream (3x2 groups)
     "l300x280_e2": (300, 280, dict(seed=32), dict(lossless=True, effort=2)),
     "la280x300_e1": (280, 300, dict(seed=33, alpha=True), dict(lossless=True, effort=1)),   # RGBA
+    # Modular group sizes other than 256 (JXL_ENC_FRAME_SETTING_MODULAR_GROUP_SIZE = 26; libjxl itself picks 512 for images that fit one such group):
+    # 128-px groups (3x2), 512-px groups (2x1, channels wider than the device's LDS rows + weighted predictor), one 1024-px group row
+    "l300x200_g128_e7": (300, 200, dict(seed=61), dict(lossless=True, effort=7, extra=((26, 0),))),
+    "la300x200_g128_e5": (300, 200, dict(seed=65, alpha=True), dict(lossless=True, effort=5, extra=((26, 0),))),
+    "l516x300_g512_e5": (516, 300, dict(seed=62), dict(lossless=True, effort=5, extra=((26, 2),))),
+    "l1030x130_g1024_e3": (1030, 130, dict(seed=63), dict(lossless=True, effort=3, extra=((26, 3),))),
     # ImageMetadata.orientation 2..8: the decoder re-orients (interop/JxlDecoding.cpp never switches that off), the writer transposes / mirrors
     **{f"vo72x40_e3_o{o}": (72, 40, dict(seed=41), dict(effort=3, orientation=o)) for o in range(2, 9)},
     "vo264x300_e7_o6": (264, 300, dict(seed=42), dict(effort=7, orientation=6)),              # several groups, ragged edges, rotated
@@ -108,7 +114,8 @@ def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
 # The other demo assets of the reference that decode on the device: the file (data fixture), per-row sums of the reference's output and
 # its 32x32 block means (compressed npz) — the full pixels are up to 92 MB per file.
 BIG_ASSETS = {"asset_dark_street": "dark_street.jxl", "asset_large_jxl": "large_jxl.jxl", "asset_pexels": "pexels-thibaut-tattevin-18273081.jxl",
-              "asset_second_jxl": "second_jxl.jxl", "asset_summer_nature": "summer_nature.jxl"}
+              "asset_second_jxl": "second_jxl.jxl", "asset_summer_nature": "summer_nature.jxl",
+              "asset_art": "art.jxl"}            # 73 bytes of MA tree: a 1024x1024 Modular frame in one 1024-px group (lossless: the row sums are exact)
 
 
 def block_means(out, n=32):
@@ -128,7 +135,7 @@ def add_big_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
         np.savez_compressed(os.path.join(HERE, name + ".blocks.npz"), means=block_means(out))
         info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src,
-                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))])
+                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))], fnv1a64="%016x" % jxl_ref.fnv1a64(out.tobytes()))
         print(name, len(data), out.shape, out.dtype)
 
 

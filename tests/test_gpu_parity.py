@@ -76,9 +76,9 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    big_groups, _ = load_case("l300x260_e5")                                  # effort-5 lossless stream: Modular group size 512
+    art = open(os.path.join(ROOT, "tests", "golden", "asset_alpha_jxl.jxl"), "rb").read()       # the reference's demo asset with squeeze-coded alpha
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
-        dec.decode_one_shot(big_groups)
+        dec.decode_one_shot(art)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
     assert out.shape == (520, 264, 4)
 
@@ -374,13 +374,14 @@ def test_corrupt_frame_inside_a_flight_is_contained():
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 BIG_ASSETS = {"asset_dark_street": "tests/golden/asset_dark_street.jxl", "asset_large_jxl": "tests/golden/asset_large_jxl.jxl", "asset_pexels": "tests/golden/asset_pexels.jxl",
-              "asset_second_jxl": "tests/golden/asset_second_jxl.jxl", "asset_summer_nature": "bench_data/real4k_summer_nature.jxl"}
+              "asset_second_jxl": "tests/golden/asset_second_jxl.jxl", "asset_summer_nature": "bench_data/real4k_summer_nature.jxl",
+              "asset_art": "tests/golden/asset_art.jxl"}                       # 73 bytes of MA tree -> 1024x1024 in one 1024-px Modular group: bit-exact
 
 
 @pytest.mark.parametrize("name", sorted(BIG_ASSETS))
 def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
-    """The other five demo photographs of the reference that decode on the device (app/src/main/assets: up to 3910 x 5865, two of them
-    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: all nine) against the reference's own output: every row sum and every
+    """The other demo assets of the reference that decode on the device (app/src/main/assets: up to 3910 x 5865, two of them
+    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: ten of the thirteen) against the reference's own output: every row sum and every
     32x32 block mean (tests/golden/make_golden.py big_assets).  Bounds: a row / block may be off by the VarDCT tolerance in the mean
     (u8 0.05, u16 16) — measured: u8 <= 0.012, u16 <= 2.6 (gpurun_out of round 3)."""
     meta = golden_meta[name]
@@ -400,6 +401,8 @@ def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
     blk_err = np.abs(mine - blocks)
     print(f"[asset] {name}: row mean error max {row_err.max():.4f}, block mean error max {blk_err.max():.4f} mean {blk_err.mean():.5f} (tolerance {tol})")
     assert row_err.max() <= tol and blk_err.max() <= 4 * tol and blk_err.mean() <= tol
+    if name == "asset_art":                                                   # Modular (integer) path: exact
+        assert np.array_equal(rs, np.array(meta["row_sums"], np.int64)) and blk_err.max() < 1e-3
 
 
 def _pq_eotf(code16):

@@ -92,8 +92,18 @@ def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
     assert np.array_equal(base, alt)
 
 
+def test_jxl_art_asset_on_cpu_harness(emul):
+    """The reference's 73-byte art.jxl: one MA tree painting a 1024 x 1024 Modular frame (a single 1024-px group, channels four times as wide
+    as the device's LDS rows: the serial walker keeps the weighted predictor's rows in HBM) — row sums equal the reference's, exactly."""
+    import json
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["asset_art"]
+    out = emul(open(os.path.join(ROOT, "tests", "golden", "asset_art.jxl"), "rb").read())
+    assert list(out.shape) == meta["shape"]
+    assert [int(x) for x in out.astype(np.int64).sum(axis=(1, 2))] == meta["row_sums"]
+
+
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
-    data, _ = load_case("l300x260_e5")               # Modular group size 512
+    data = open(os.path.join(ROOT, "tests", "golden", "asset_alpha_jxl.jxl"), "rb").read()      # the reference's demo asset with squeeze-coded alpha
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
 
