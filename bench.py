@@ -109,6 +109,74 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def run_c4(args, rank, local, world):
+    """BASELINE configs[3]: one huge VarDCT frame sharded by bands of 256-pixel group rows (jxl_coder_amd/shard.py).  A step =
+    one decode of the whole frame by all ranks together: every rank parses the (same) bytes, decodes its bands — side by side on their own
+    decoder contexts — and trades the LF / pixel halo rows of its borders with the neighbour ranks (RCCL send/recv in one group); borders
+    between bands of the same GPU are handed over directly.  Outputs stay in HBM, one tensor per band."""
+    import torch
+    import torch.distributed as dist
+    import jxl_coder_amd as J
+    from jxl_coder_amd import shard
+    size = int(os.environ.get("JXLAMD_C4_SIZE", "32768"))
+    path = os.path.join(os.environ.get("JXLAMD_BENCH_DIR", "/tmp/jxlamd_bench_frames"), f"c4_{size}.jxl")
+    if rank == 0 and not os.path.exists(path):
+        import subprocess
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_bench_frames.py"), "--big", str(size), str(size), "--out", path], capture_output=True, text=True)
+        if r.returncode:
+            raise SystemExit("--workload c4 needs the reference's encoder (oracle/_ref) to make its frame on this box: " + r.stderr[-400:])
+    if world > 1:
+        dist.barrier()
+    data = open(path, "rb").read()
+    w, h = J.JxlCoder.getSize(data)
+    ygroups = (h + 255) // 256
+    nbands = int(os.environ.get("JXLAMD_C4_BANDS", str(max(8, world))))
+    rows = shard.band_rows(ygroups, nbands)
+    mine = [b for b in range(nbands) if shard.band_owner(b, nbands, world) == rank]
+    outs = [torch.empty((min(rows[b][1] * 256, h) - rows[b][0] * 256) * w * 4, dtype=torch.uint8, device=f"cuda:{local}") for b in mine]
+
+    def step():
+        shard.decode_sharded(data, nbands=nbands, rank=rank, world=world, device=local, allowed_floats=False, outs=outs)
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
+    ms = elapsed / args.steps * 1e3
+    alg = len(data) + w * h * 4
+    cpu = {"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": "skipped (--no-cpu-baseline)"}
+    if not args.no_cpu_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import jxl_ref        # checker / baseline only
+            t = time.perf_counter(); jxl_ref.decode(data, threads=0); dt = time.perf_counter() - t
+            cpu = {"value": round(w * h / 1e6 / dt, 1), "unit": "MP/s", "cores": os.cpu_count(), "kind": "reference",
+                   "sample": f"one decode of the same {w}x{h} frame by the reference's libjxl 0.12 (oracle/_ref), threads = JxlResizableParallelRunnerSuggestThreads: {dt:.2f} s"}
+        except Exception as e:  # noqa: BLE001
+            cpu["sample"] = f"CPU baseline unavailable: {e}"
+    print(json.dumps({
+        "metric": "decoded MP/s (one 32768x32768-class VarDCT q90 frame, band-sharded)", "value": round(w * h / 1e6 / (ms / 1e3), 2), "unit": "MP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"configs[3]: one {w}x{h} VarDCT q90 (distance 1.0, effort 7) frame, {len(data)} bytes, {ygroups * ((w + 255) // 256)} groups, decoded as {nbands} bands "
+                               f"of group rows over {world} GPU(s) ({len(mine)} bands on rank 0, concurrent decoder contexts), EPF/LF halo rows between ranks by RCCL send/recv; "
+                               "compressed bytes on the host (every rank parses them and uploads its bands' sections), RGBA8 band outputs resident in HBM",
+                   "bands": nbands, "frame_bytes": len(data)},
+        "roofline": {"bound": "hbm", "achieved": round(alg / (ms / 1e3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(alg / (ms / 1e3) / 1e9 / 8000.0, 6), "traffic": None,
+                     "kernel": "whole sharded decode (all kernels of all bands; per-kernel figures: the c3 line)", "algorithmic_bytes_per_launch": alg},
+        "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,8 +186,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
-    ap.add_argument("--workload", choices=["c3", "c5"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
-                    "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused)")
+    ap.add_argument("--workload", choices=["c3", "c5", "c4"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
+                    "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused).  "
+                    "c4: configs[3], ONE 32768x32768 VarDCT q90 frame (JXLAMD_C4_SIZE) as bands of group rows over the ranks (8 bands on one GPU), "
+                    "halo rows by RCCL send/recv; a step = one decode of the frame (strong scaling)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
     args = ap.parse_args()
     c5 = args.workload == "c5"
@@ -147,6 +217,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     import jxl_coder_amd as J
     from jxl_coder_amd.shard import max_over_ranks
+    if args.workload == "c4":
+        return run_c4(args, rank, local, world)
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
     frames = FRAMES

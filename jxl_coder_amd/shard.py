@@ -88,14 +88,22 @@ def exchange_halos(bands, kind: int, nbands: int, rank: int, world: int, group=N
 class DeviceBand:
     """One band of a frame on this rank's GPU: a decoder context + its output rows + halo buffers (all HBM-resident)."""
 
-    def __init__(self, decoder, data: bytes, rows, width: int, height: int, bytes_per_pixel: int, device):
+    def __init__(self, decoder, data: bytes, rows, width: int, height: int, bytes_per_pixel: int, device, out=None, begin=True):
         import torch
-        self.dec, self.rows = decoder, rows
+        self.dec, self.rows, self.data = decoder, rows, data
         self.py0, self.py1 = rows[0] * 256, min(rows[1] * 256, height)
-        self.out = torch.empty((self.py1 - self.py0) * width * bytes_per_pixel, dtype=torch.uint8, device=device)
-        self.info = decoder.band_begin(data, rows[0], rows[1], self.out.data_ptr(), self.out.numel())
+        n = (self.py1 - self.py0) * width * bytes_per_pixel
+        self.out = out if out is not None else torch.empty(n, dtype=torch.uint8, device=device)      # `out`: the caller's (reused) rows
+        assert self.out.numel() >= n
         self._bufs = {}
         self.device = device
+        self.info = None
+        if begin:
+            self.begin()
+
+    def begin(self):
+        """parse + upload + LF stage of the band (returns when done; bands of one GPU call this from one thread each)"""
+        self.info = self.dec.band_begin(self.data, self.rows[0], self.rows[1], self.out.data_ptr(), self.out.numel())
 
     def _buffer(self, kind, slot):
         import torch
@@ -120,10 +128,36 @@ class DeviceBand:
 _contexts = {}
 
 
-def decode_sharded(data: bytes, nbands=None, rank: int = 0, world: int = 1, device: int = 0, group=None, allowed_floats=True):
+def run_concurrently(fn, items):
+    """fn(item) for every item, one host thread each (the C-ABI calls release the GIL): the bands a GPU holds go through each protocol
+    phase side by side on their own decoder contexts / HIP streams, like the flights of a batch — their LF stages are ~150 ms of latency
+    each and leave the chip almost empty when run one after another."""
+    items = list(items)
+    if len(items) <= 1:
+        for it in items:
+            fn(it)
+        return
+    import threading
+    errors = []
+
+    def wrap(it):
+        try:
+            fn(it)
+        except BaseException as e:  # noqa: BLE001 — re-raised below
+            errors.append(e)
+    th = [threading.Thread(target=wrap, args=(it,)) for it in items]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
+def decode_sharded(data: bytes, nbands=None, rank: int = 0, world: int = 1, device: int = 0, group=None, allowed_floats=True, outs=None):
     """Decode ONE frame as `nbands` bands (default: one per rank).  Every rank calls this with the same bytes; returns
     [(pixel_row0, pixel_row1, uint8 CUDA tensor of those rows, tight RGBA8/RGBA16)] for the bands this rank decoded.  The pixels equal
-    the same rows of a whole-frame decode bit for bit."""
+    the same rows of a whole-frame decode bit for bit.  outs: optional list of preallocated uint8 CUDA tensors, one per band of this rank."""
     from . import api
     info = api.Info()
     rc = api.lib().jxlamd_basic_info(data, len(data), api.C.byref(info))
@@ -141,11 +175,13 @@ def decode_sharded(data: bytes, nbands=None, rank: int = 0, world: int = 1, devi
         key = (device, k)
         if key not in _contexts:
             _contexts[key] = api.JxlDecoder(device)
-        bands[b] = DeviceBand(_contexts[key], data, rows[b], w, h, bpp, dev)        # LF stage of the band
+        bands[b] = DeviceBand(_contexts[key], data, rows[b], w, h, bpp, dev, out=outs[k] if outs else None, begin=False)
+    # every phase of the protocol: the bands this GPU holds side by side (one decoder context + host thread each), then the halo step.
+    # (The pixel halo is produced by the reconstruction of the band's border groups, i.e. by the phase it follows: there is no interior
+    # work left to overlap it with — PassGroup decode and inverse DCT of ALL groups precede the filters; the messages are 1.2 MB.)
+    run_concurrently(lambda b: bands[b].begin(), mine)                              # parse + LF stage
     exchange_halos(bands, HALO_LF, nbands, rank, world, group)
-    for b in mine:
-        bands[b].dec.band_reconstruct()
+    run_concurrently(lambda b: bands[b].dec.band_reconstruct(), mine)
     exchange_halos(bands, HALO_PIXELS, nbands, rank, world, group)
-    for b in mine:
-        bands[b].dec.band_finish()
+    run_concurrently(lambda b: bands[b].dec.band_finish(), mine)
     return [(bands[b].py0, bands[b].py1, bands[b].out) for b in mine]

@@ -83,6 +83,57 @@ def test_halo_schedule_two_ranks_gloo(nbands):
     mp.spawn(_halo_worker, args=(2, 29620 + nbands, nbands), nprocs=2, join=True)
 
 
+class _SizedStubBand(_StubBand):
+    """CPU tensors of the true halo sizes of an 8192-pixel-wide frame: LF halo = one cell row x 14 B (14 336 B), pixel halo = H = 3 rows
+    (Gaborish + one EPF iteration) x 8192 px x 3 channels x f32 (294 912 B).  The payload is position dependent, so a truncated or
+    reordered message shows."""
+    SIZES = {0: 8192 // 8 * 14, 1: 3 * 8192 * 3 * 4}
+
+    def _payload(self, kind, index, side):
+        n = self.SIZES[kind]
+        return ((torch.arange(n, dtype=torch.int64) * (7 + 2 * kind) + 31 * index + 5 * side) % 251).to(torch.uint8)
+
+    def export(self, kind, side):
+        return self._payload(kind, self.index, side)
+
+    def recv_buffer(self, kind):
+        return torch.zeros(self.SIZES[kind], dtype=torch.uint8)
+
+    def import_(self, kind, side, buf):
+        src = self.index - 1 if side == 0 else self.index + 1
+        self.got[(kind, side)] = bool(torch.equal(buf, self._payload(kind, src, 1 - side)))
+
+
+def _sized_halo_worker(rank, world, port, nbands):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from jxl_coder_amd.shard import band_owner, exchange_halos
+    bands = {b: _SizedStubBand(b) for b in range(nbands) if band_owner(b, nbands, world) == rank}
+    for kind in (0, 1):
+        exchange_halos(bands, kind, nbands, rank, world)
+    for b, band in bands.items():
+        for kind in (0, 1):
+            assert band.got.get((kind, 0), b == 0) is True and band.got.get((kind, 1), b == nbands - 1) is True, (b, band.got)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nbands", [(2, 8), (4, 8)])
+def test_halo_messages_of_true_size_across_ranks_gloo(world, nbands):
+    """BASELINE config 4's exchange step with the message sizes of an 8192-wide frame, 2 and 4 ranks (the RCCL path uses the same
+    batch_isend_irecv schedule with device tensors)."""
+    mp.spawn(_sized_halo_worker, args=(world, 29650 + world, nbands), nprocs=world, join=True)
+
+
+def test_run_concurrently_runs_all_and_reraises():
+    from jxl_coder_amd.shard import run_concurrently
+    seen = []
+    run_concurrently(lambda i: seen.append(i), range(5))
+    assert sorted(seen) == [0, 1, 2, 3, 4]
+    with pytest.raises(ZeroDivisionError):
+        run_concurrently(lambda i: 1 // (i - 2), range(4))
+
+
 @pytest.mark.parametrize("name", BAND_CASES)
 def test_oracle_matches_reference_row_sums(oracle, golden_meta, name):
     data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()

@@ -45,7 +45,34 @@ def one_to(args):
     return seed
 
 
+def big_frame(w, h, dst, seed=41):
+    """BASELINE configs[3]: ONE w x h VarDCT q90 frame (default use: 32768 x 32768, 16 384 groups, ~157 MB) written to `dst`.  The image is
+    generated in row tiles by a process pool (tools/gpu/c4_full.py: tools/synth.py's recipe per tile) and encoded by the reference's encoder."""
+    import time
+    import numpy as np
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tools", "gpu"))
+    import c4_full
+    import jxl_ref
+    free_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
+    if free_gb < w * h * 48 / 1e9:
+        raise SystemExit("not enough host RAM for a %d x %d encode here" % (w, h))
+    t = time.time()
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
+        tiles = pool.map(c4_full.tile, [(w, h, y0, min(h, y0 + 512), seed) for y0 in range(0, h, 512)])
+    img = np.concatenate(tiles); del tiles
+    data = jxl_ref.encode(img, effort=7, distance=1.0); del img
+    with open(dst + ".tmp", "wb") as f:
+        f.write(data)
+    os.replace(dst + ".tmp", dst)
+    return {"file": dst, "bytes": len(data), "seconds": round(time.time() - t, 1)}
+
+
 if __name__ == "__main__":
+    if "--big" in sys.argv:
+        i = sys.argv.index("--big")
+        print(json.dumps(big_frame(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[sys.argv.index("--out") + 1])))
+        raise SystemExit(0)
     if "--out" in sys.argv:
         out = sys.argv[sys.argv.index("--out") + 1]
         n = int(sys.argv[sys.argv.index("--count") + 1]) if "--count" in sys.argv else 256
