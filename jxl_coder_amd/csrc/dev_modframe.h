@@ -7,7 +7,7 @@
 
 namespace jxlamd {
 
-constexpr int kModGroupMaxCh = 8;                      // per group: up to 8 channels of 256x256 (host_parse rejects more)
+constexpr int kModGroupMaxCh = 24;                     // per group: up to 24 channel rectangles (host_parse rejects more): 3 colour channels x the squeeze levels below shift 3, alpha
 // per group: its channels' rectangles (group_dim^2 samples each) + the HBM error rows of the weighted predictor for channels wider than the
 // LDS rows; slot num_groups (same size) belongs to the GlobalModular stream
 JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) {
@@ -96,27 +96,36 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)F.lz_win_len + (size_t)g * (size_t)F.lz_win_group : nullptr; S.lz.win_len = F.lz_win_group;
     S.wide_wp = (uint32_t *)(scr + (size_t)nch * (size_t)gd * (size_t)gd);
-    modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
+    // the stream's channels: the group's rectangle of every remaining frame channel, scaled by the channel's shifts (squeeze); channels
+    // whose rectangle is empty here are not in the stream, channels with both shifts >= 3 travel in the ModularLfGroup streams
+    int n = 0;
+    for (int c = 0; c < nch; c++) {
+      const int fc = F.mod_first_group_ch + c;
+      const int hs = F.mod_hs[fc], vs = F.mod_vs[fc];
+      if ((hs < vs ? hs : vs) >= 3) continue;
+      int rw = F.mod_w[fc] - (x0 >> hs), rh = F.mod_h[fc] - (y0 >> vs);
+      const int gw = gd >> hs, gh = gd >> vs;
+      rw = rw < 0 ? 0 : rw > gw ? gw : rw; rh = rh < 0 ? 0 : rh > gh ? gh : rh;
+      if (rw == 0 || rh == 0) continue;
+      S.ch[n].d = scr + (size_t)c * (size_t)gd * (size_t)gd; S.ch[n].w = rw; S.ch[n].h = rh; S.grp_src[n] = fc;
+      n++;
+    }
+    S.grp_n = n;
+    if (n > 0) modular_stream_begin(B.tables, F, B.local[g], S, &S.trs); else { S.trs.n = 0; S.st.err = 0; }
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {
       const DevTr &t = S.trs.t[i];
       if (t.id != 0) S.st.err = kErrPalette;                         // group-level palettes: not on the device yet
-      else if (t.begin_c + 3 > nch) S.st.err = kErrBitstream;
+      else if (t.begin_c + 3 > n) S.st.err = kErrBitstream;
     }
     if (S.st.err) *B.err |= S.st.err | kErrStagePass;
   }
   sync();
-  if (S.st.err) return;
+  if (S.st.err || S.grp_n == 0) return;                 // no channel of the frame reaches this group: the stream is empty (not even a header)
   modular_stream_stage(S, tid, nthreads);
   sync();
-  for (int c = tid; c < nch; c += nthreads) {
-    const int fc = F.mod_first_group_ch + c;
-    int rw = F.mod_w[fc] - x0, rh = F.mod_h[fc] - y0;
-    rw = rw < 0 ? 0 : rw > gd ? gd : rw; rh = rh < 0 ? 0 : rh > gd ? gd : rh;
-    S.ch[c].d = scr + (size_t)c * (size_t)gd * (size_t)gd; S.ch[c].w = rw; S.ch[c].h = rh;
-  }
-  sync();
+  const int nst = S.grp_n;
   const int sid = 1 + 3 * F.num_lf_groups + 17 + g;
-  uint32_t e = mod_decode_stream(S, S.ch, nch, sid, tid);
+  uint32_t e = mod_decode_stream(S, S.ch, nst, sid, tid);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
   sync();
   if (S.st.err) return;
@@ -129,15 +138,31 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     else if (tid == 0) *B.err |= kErrBitstream | kErrStagePass;
     sync();
   }
-  for (int c = 0; c < nch; c++) {
-    const int fc = F.mod_first_group_ch + c;
+  for (int c = 0; c < nst; c++) {
+    const int fc = S.grp_src[c];
     const DevChanOut ch = S.ch[c];
     int32_t *dst = mod_plane(B, F, fc);
+    const int cx0 = x0 >> F.mod_hs[fc], cy0 = y0 >> F.mod_vs[fc];
     for (int i = tid; i < ch.w * ch.h; i += nthreads) {
       const int y = i / ch.w, x = i - y * ch.w;
-      dst[(size_t)(y0 + y) * (size_t)F.mod_w[fc] + (size_t)(x0 + x)] = ch.d[i];
+      dst[(size_t)(cy0 + y) * (size_t)F.mod_w[fc] + (size_t)(cx0 + x)] = ch.d[i];
     }
   }
+}
+
+// the smooth tendency term of the squeeze residuals (H.6.2.2): what the neighbours predict for (first - second) of a pair
+JXL_DEV int64_t squeeze_tendency(int64_t Bv, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (Bv >= a && a >= n) {
+    diff = (4 * Bv - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (Bv - a)) diff = 2 * (Bv - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (Bv <= a && a <= n) {
+    diff = (4 * Bv - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (Bv - a)) diff = 2 * (Bv - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
 }
 
 // ---- inverse global transforms (one element per work-item)
@@ -145,6 +170,26 @@ JXL_DEV void mod_op_element(const DevBuffers &B, const DevFrame &F, int op, size
   if (F.mod_op_kind[op] == 0) {            // RCT on planes a, b, c (x = rct_type)
     inv_rct_planes(mod_plane(B, F, F.mod_op_a[op]) + i, mod_plane(B, F, F.mod_op_b[op]) + i, mod_plane(B, F, F.mod_op_c[op]) + i, 1,
                    F.mod_op_x[op], 0, 1);
+  } else if (F.mod_op_kind[op] == 2 || F.mod_op_kind[op] == 3) {      // inverse squeeze (H.6.2.2): one row (horizontal) / one column (vertical) per work item
+    const bool hor = F.mod_op_kind[op] == 2;
+    const int aw = F.mod_op_x[op], ah = F.mod_op_y[op], re = F.mod_op_e[op];
+    const int32_t *avg = mod_plane(B, F, F.mod_op_a[op]), *res = mod_plane(B, F, F.mod_op_b[op]);
+    int32_t *out = mod_plane(B, F, F.mod_op_d[op]);
+    const size_t as = hor ? 1 : (size_t)aw, rs = hor ? 1 : (size_t)aw, os = hor ? 1 : (size_t)aw;      // strides along the squeezed axis
+    const int na = hor ? aw : ah;                                     // averages along the axis; re residuals (na or na - 1)
+    const int32_t *a = avg + (hor ? i * (size_t)aw : i), *r = res + (hor ? i * (size_t)re : i);
+    int32_t *o = out + (hor ? i * (size_t)(aw + re) : i);
+    int64_t left = 0;
+    for (int k = 0; k < re; k++) {
+      const int64_t A0 = a[(size_t)k * as], nx = k + 1 < na ? a[(size_t)(k + 1) * as] : A0;
+      if (k == 0) left = A0;
+      const int64_t diff = (int64_t)r[(size_t)k * rs] + squeeze_tendency(left, A0, nx);
+      const int64_t first = A0 + diff / 2;                          // C division: towards zero
+      const int64_t second = first - diff;
+      o[(size_t)(2 * k) * os] = (int32_t)first; o[(size_t)(2 * k + 1) * os] = (int32_t)second;
+      left = second;
+    }
+    if (na > re) o[(size_t)(2 * re) * os] = a[(size_t)re * as];
   } else {                                  // channel palette: plane a = index/values, plane b = palette (x = nb_colours, y = bit depth)
     int32_t *v = mod_plane(B, F, F.mod_op_a[op]) + i;
     const int32_t *pal = mod_plane(B, F, F.mod_op_b[op]);

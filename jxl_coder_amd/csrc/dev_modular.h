@@ -67,7 +67,8 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   const DevTreeNode *tree;            // first tree_ncache nodes of the stream's tree
   int32_t alias_lds, ctx_lds, tree_ncache, ctx_off;   // ctx_off: byte offset of the context map inside the pool
   DevModStream st;
-  DevChanOut ch[12];                  // channel descriptors of the current stream (LDS: keeps the kernel free of scratch)
+  DevChanOut ch[kModMaxCh];           // channel descriptors of the current stream
+  int32_t grp_src[24], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header
   DevWaveTree wt;
   uint32_t fallback_err;
@@ -307,7 +308,7 @@ JXL_DEV void modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms, int 
 // One modular stream in three phases so that the whole wave can stage the stream's tables in LDS:
 //   begin (lane 0): GroupHeader, (global | local) MA tree + leaf code;  stage (all lanes): tree head, context map,
 //   hybrid-uint configs and alias tables -> LDS;  decode (lane 0): channels + final-state check.
-// Transform list of a stream header (H.6): RCT and palette are parsed, squeeze is flagged.
+// Transform list of a stream header (H.6): RCT and palette are parsed, squeeze parameters skipped (the caller decides what it accepts).
 JXL_DEV uint32_t modular_read_transforms(DevBits &b, int ntr, DevTrList *out) {
   if (ntr > 0 && (!out || ntr > 4)) return kErrUnsupportedTransform;
   if (out) out->n = ntr;
@@ -325,7 +326,14 @@ JXL_DEV uint32_t modular_read_transforms(DevBits &b, int ntr, DevTrList *out) {
       t.nb_colours = (int)bits_u32(b, 8, 0, 10, 256, 12, 1280, 16, 5376);
       t.nb_deltas = (int)bits_u32(b, -1, 0, 8, 1, 10, 257, 16, 1281);
       t.d_pred = (int)bits_read(b, 4);
-    } else if (t.id == 2) return kErrSqueeze;
+    } else if (t.id == 2) {               // squeeze: the steps are resolved on the host (GlobalModular); here they are only skipped
+      const int num_sq = (int)bits_u32(b, -1, 0, 4, 1, 6, 9, 8, 41);
+      for (int q = 0; q < num_sq; q++) {
+        (void)bits_read(b, 2);
+        (void)bits_u32(b, 3, 0, 6, 8, 10, 72, 13, 1096);
+        (void)bits_u32(b, -1, 1, -1, 2, -1, 3, 4, 4);
+      }
+    }
     else return kErrBitstream;
   }
   return 0;

@@ -30,6 +30,10 @@ struct DevEC {
   int32_t lz77, lz_min_symbol, lz_min_length; uint32_t lz_len_cfg;
 };
 
+constexpr int kModMaxCh = 80;        // stream channels of a Modular image (a full default squeeze of RGBA: 4 + ~14 residual levels x channels, capped here)
+constexpr int kModMaxPlanes = 176;   // + one output plane per inverse squeeze step
+constexpr int kModMaxOps = 112;
+
 // ---- MA tree node (Annex H.4), 32 bytes
 struct DevTreeNode {
   int32_t prop;              // -1: leaf
@@ -85,13 +89,18 @@ struct DevFrame {
   // Modular-encoded frames (lossless): stream channels after the GLOBAL transforms' meta-apply, planes in one pool
   int32_t is_modular, mod_nch, mod_nb_meta, mod_first_group_ch;   // channels [mod_first_group_ch, mod_nch) are decoded per group
   int32_t has_ec;                  // VarDCT frame with extra channels (alpha): the mod_* fields describe the extra-channel Modular image
-  int32_t mod_w[12], mod_h[12]; uint32_t mod_plane_off[12];        // int32 planes (offsets in samples into the pool)
+  int32_t mod_w[kModMaxCh], mod_h[kModMaxCh];                      // stream channels (after every meta-apply), in stream order
+  uint8_t mod_hs[kModMaxCh], mod_vs[kModMaxCh];                    // their shifts (squeeze): a group / LF-group rectangle is the frame rectangle >> shift
+  uint32_t mod_plane_off[kModMaxPlanes];                           // int32 planes (offsets in samples into the pool): stream channel i = plane i, then the outputs of the inverse squeeze steps
   int32_t mod_group_dim;           // group size of a Modular-encoded frame: 128 << group_size_shift (VarDCT frames: 256)
   uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
   uint32_t lz_win_len;             // LZ77 window entries of the GlobalModular stream (0: the frame's global code has no LZ77) ...
   uint32_t lz_win_group;           // ... and of each group stream; DevBuffers::lz_win = [lz_win_len][num_groups x lz_win_group]
   int32_t mod_nops;                // inverse global transforms, in execution order, with resolved plane indices
-  int32_t mod_op_kind[8], mod_op_a[8], mod_op_b[8], mod_op_c[8], mod_op_x[8], mod_op_y[8];
+  // kind 0: inverse RCT on planes a, b, c (x = type, y = samples); 1: channel palette (a = index plane, b = palette, x = colours, c = samples);
+  // 2 / 3: inverse horizontal / vertical squeeze (a = average plane, b = residual plane, d = output plane, x, y = average w, h, e = residual extent
+  // along the squeezed axis, c = independent lines: rows for 2, columns for 3).  Work items of op o: kind 0 ? y : c
+  int32_t mod_op_kind[kModMaxOps], mod_op_a[kModMaxOps], mod_op_b[kModMaxOps], mod_op_c[kModMaxOps], mod_op_x[kModMaxOps], mod_op_y[kModMaxOps], mod_op_d[kModMaxOps], mod_op_e[kModMaxOps];
   int32_t mod_out[4];              // planes feeding R, G, B, A (-1: opaque / replicate grey is done by repeating the index)
   int32_t mod_bits, mod_alpha_bits;
   // loop filter

@@ -156,21 +156,21 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   F.mod_bits = (int)m.pub.bits_per_sample;
   if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
   const int ncol = vardct ? 0 : m.pub.num_color_channels == 1 ? 1 : 3;
-  struct Ch { int w, h, plane; };
+  struct Ch { int w, h, hs, vs, plane; };
   std::vector<Ch> L;
-  int nplanes = 0;
   for (int i = 0; i < ncol + m.num_extra; i++) {
     if (i >= ncol && m.ec[i - ncol].dim_shift) { plan->error = "unsupported: extra channel dim_shift"; return -1; }
-    L.push_back({f.width, f.height, nplanes++});
+    L.push_back({f.width, f.height, 0, 0, -1});
   }
   int nb_meta = 0;
   // GroupHeader (H.2): use_global_tree, WP header (skipped here, the device parses it again), transforms
-  if (!hx_bool(sb)) { plan->error = "unsupported: GlobalModular stream with a local MA tree"; return -1; }
-  if (F.tree_count <= 0) { plan->error = "modular frame: missing global MA tree"; return -1; }
+  const bool use_global_tree = hx_bool(sb);        // a local tree + code follow the transforms: the device parses them (as it does for LF groups)
+  if (use_global_tree && F.tree_count <= 0) { plan->error = "modular frame: missing global MA tree"; return -1; }
   if (!hx_bool(sb)) { for (int i = 0; i < 7; i++) (void)hx_bits(sb, 5); for (int i = 0; i < 4; i++) (void)hx_bits(sb, 4); }
   const int ntr = (int)hx_u32(sb, -1, 0, -1, 1, 4, 2, 8, 18);
   if (ntr > 4) { plan->error = "unsupported: more than 4 global transforms"; return -1; }
-  struct Tr { int id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
+  struct Sq { int horizontal, in_place, begin_c, num_c; };
+  struct Tr { int id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; std::vector<Sq> sq; };
   std::vector<Tr> trs;
   for (int i = 0; i < ntr; i++) {
     Tr t{}; t.id = (int)hx_bits(sb, 2);
@@ -187,24 +187,69 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       if (t.num_c != 1 || t.nb_deltas != 0 || t.d_pred != 0) { plan->error = "unsupported: multi-channel / delta palette"; return -1; }
       if (t.begin_c + t.num_c > (int)L.size() || t.nb_colours < 1 || t.nb_colours > 256 || t.begin_c < nb_meta) { plan->error = "unsupported: palette layout"; return -1; }
       // meta-apply: one index channel stays at begin_c, the palette (nb_colours x num_c) becomes meta channel 0
-      L.insert(L.begin(), {t.nb_colours, t.num_c, nplanes++});
+      L.insert(L.begin(), {t.nb_colours, t.num_c, -1, -1, -1});
       nb_meta++;
-    } else { plan->error = "unsupported: squeeze transform"; return -1; }
+    } else if (t.id == 2) {
+      // Squeeze (H.6.2): explicit steps, or — num_sq == 0 — the default sequence derived from the channel list
+      const int num_sq = (int)hx_u32(sb, -1, 0, 4, 1, 6, 9, 8, 41);
+      if (num_sq > 64) { plan->error = "unsupported: more than 64 squeeze steps"; return -1; }
+      for (int q = 0; q < num_sq; q++) {
+        Sq p{};
+        p.horizontal = hx_bool(sb) ? 1 : 0; p.in_place = hx_bool(sb) ? 1 : 0;
+        p.begin_c = (int)hx_u32(sb, 3, 0, 6, 8, 10, 72, 13, 1096);
+        p.num_c = (int)hx_u32(sb, -1, 1, -1, 2, -1, 3, 4, 4);
+        t.sq.push_back(p);
+      }
+      if (num_sq == 0) {
+        const int first = nb_meta, nbc = (int)L.size() - nb_meta;
+        if (nbc < 1) { plan->error = "squeeze without channels"; return -1; }
+        int w = L[(size_t)first].w, h = L[(size_t)first].h;
+        if (nbc > 2 && L[(size_t)first + 1].w == w && L[(size_t)first + 1].h == h) {      // channels 1 and 2 as chroma: squeezed first (4:2:0-like previews)
+          t.sq.push_back({1, 0, first + 1, 2});
+          t.sq.push_back({0, 0, first + 1, 2});
+        }
+        Sq p{0, 1, first, nbc};
+        if (!(w > h) && h > 8) { p.horizontal = 0; t.sq.push_back(p); h = (h + 1) / 2; }     // tall (or square) images start with a vertical step
+        while (w > 8 || h > 8) {
+          if (w > 8) { p.horizontal = 1; t.sq.push_back(p); w = (w + 1) / 2; }
+          if (h > 8) { p.horizontal = 0; t.sq.push_back(p); h = (h + 1) / 2; }
+        }
+      }
+      // meta-apply: each step halves channels [begin_c, begin_c + num_c) along one axis and inserts their residual channels
+      for (const Sq &p : t.sq) {
+        const int b = p.begin_c, e = p.begin_c + p.num_c - 1;
+        if (b < nb_meta || e >= (int)L.size()) { plan->error = "squeeze: channel range"; return -1; }      // (squeezing meta channels: not produced by libjxl)
+        const int offset = p.in_place ? e + 1 : (int)L.size();
+        for (int c = b; c <= e; c++) {
+          Ch &a = L[(size_t)c];
+          if (a.hs < 0 || a.hs > 30 || a.vs > 30) { plan->error = "squeeze: bad channel"; return -1; }
+          Ch r = a;
+          if (p.horizontal) { const int w = a.w; a.w = (w + 1) / 2; a.hs++; r.w = w - a.w; r.hs = a.hs; }
+          else { const int h = a.h; a.h = (h + 1) / 2; a.vs++; r.h = h - a.h; r.vs = a.vs; }
+          L.insert(L.begin() + offset + (c - b), r);
+        }
+      }
+    } else { plan->error = "bad transform id"; return -1; }
     trs.push_back(t);
   }
   if (sb->err) { plan->error = "truncated GlobalModular header"; return -1; }
-  if ((int)L.size() > 12) { plan->error = "unsupported: more than 12 modular channels"; return -1; }
+  if ((int)L.size() > kModMaxCh) { plan->error = "unsupported: more than 80 modular channels"; return -1; }
   F.mod_nch = (int)L.size(); F.mod_nb_meta = nb_meta;
   uint32_t off = 0;
   int first_group = F.mod_nch;
   for (int i = 0; i < F.mod_nch; i++) {
-    F.mod_w[i] = L[(size_t)i].w; F.mod_h[i] = L[(size_t)i].h;
-    if (first_group == F.mod_nch && i >= nb_meta && (L[(size_t)i].w > f.group_dim || L[(size_t)i].h > f.group_dim)) first_group = i;
+    const Ch &c = L[(size_t)i];
+    F.mod_w[i] = c.w; F.mod_h[i] = c.h; F.mod_hs[i] = (uint8_t)(c.hs < 0 ? 0 : c.hs); F.mod_vs[i] = (uint8_t)(c.vs < 0 ? 0 : c.vs);
+    if (first_group == F.mod_nch && i >= nb_meta && (c.w > f.group_dim || c.h > f.group_dim)) first_group = i;
   }
-  // planes are indexed by stream channel position (the device decodes "channel i" into plane i)
+  // channels after the first one that exceeds a group travel in the ModularLfGroup (both shifts >= 3) or ModularGroup streams; the device
+  // decodes the latter (single-pass frames: shifts 0..2)
+  for (int i = first_group; i < F.mod_nch; i++)
+    if (std::min(L[(size_t)i].hs, L[(size_t)i].vs) >= 3 && L[(size_t)i].w > 0 && L[(size_t)i].h > 0) { plan->error = "unsupported: squeeze with ModularLfGroup channels"; return -1; }
+  // planes are indexed by stream channel position (the device decodes "channel i" into plane i); the inverse squeeze steps append theirs
+  int nplanes = F.mod_nch;
   for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }
   F.mod_first_group_ch = first_group;
-  plan->mod_pool_ints = off;
   F.lz_win_len = 0; F.lz_win_group = 0;
   if (F.tree_ec.lz77 && !vardct) {            // a stream never holds more integers than the image has samples; the window is 2^20 at most
     // the GlobalModular stream holds the channels before first_group, a group stream at most group_dim^2 samples of each later channel
@@ -213,11 +258,41 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     F.lz_win_len = (uint32_t)std::min<uint64_t>(total + 64, 1u << 20);
     F.lz_win_group = (uint32_t)std::min<uint64_t>((uint64_t)(F.mod_nch - first_group) * (uint64_t)f.group_dim * (uint64_t)f.group_dim + 64, 1u << 20);
   }
-  if (F.mod_nch - first_group > 8) { plan->error = "unsupported: more than 8 group channels"; return -1; }
+  if (F.mod_nch - first_group > 24) { plan->error = "unsupported: more than 24 group channels"; return -1; }
   // inverse program (last transform first)
   F.mod_nops = 0;
   for (int i = ntr - 1; i >= 0; i--) {
     const Tr &t = trs[(size_t)i];
+    if (t.id == 2) {
+      for (int q = (int)t.sq.size() - 1; q >= 0; q--) {
+        const Sq &p = t.sq[(size_t)q];
+        const int b = p.begin_c, e = p.begin_c + p.num_c - 1;
+        const int offset = p.in_place ? e + 1 : (int)L.size() - p.num_c;          // where this step's residual channels sit now
+        if (e >= (int)L.size() || offset + p.num_c > (int)L.size() || offset <= e) { plan->error = "squeeze: bookkeeping"; return -1; }
+        for (int c = b; c <= e; c++) {
+          if (F.mod_nops >= kModMaxOps || nplanes >= kModMaxPlanes) { plan->error = "unsupported: too many squeeze steps"; return -1; }
+          Ch &a = L[(size_t)c]; const Ch &r = L[(size_t)(offset + c - b)];
+          const int o = F.mod_nops++;
+          F.mod_op_kind[o] = p.horizontal ? 2 : 3;
+          F.mod_op_a[o] = a.plane; F.mod_op_b[o] = r.plane; F.mod_op_d[o] = nplanes;
+          F.mod_op_x[o] = a.w; F.mod_op_y[o] = a.h;
+          if (p.horizontal) {
+            if (r.h != a.h || (r.w != a.w && r.w != a.w - 1)) { plan->error = "squeeze: channel sizes"; return -1; }
+            F.mod_op_e[o] = r.w; F.mod_op_c[o] = a.h;
+            a.w += r.w; a.hs--;
+          } else {
+            if (r.w != a.w || (r.h != a.h && r.h != a.h - 1)) { plan->error = "squeeze: channel sizes"; return -1; }
+            F.mod_op_e[o] = r.h; F.mod_op_c[o] = a.w;
+            a.h += r.h; a.vs--;
+          }
+          a.plane = nplanes;
+          F.mod_plane_off[nplanes++] = off; off += (uint32_t)((size_t)a.w * (size_t)a.h + 64);
+        }
+        L.erase(L.begin() + offset, L.begin() + offset + p.num_c);
+      }
+      continue;
+    }
+    if (F.mod_nops >= kModMaxOps) { plan->error = "unsupported: too many transforms"; return -1; }
     int o = F.mod_nops++;
     if (t.id == 0) {
       F.mod_op_kind[o] = 0;
@@ -235,7 +310,9 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       L.erase(L.begin());
     }
   }
+  plan->mod_pool_ints = off;
   if ((int)L.size() != ncol + m.num_extra) { plan->error = "modular channel bookkeeping"; return -1; }
+  for (const Ch &c : L) if (c.w != f.width || c.h != f.height) { plan->error = "modular channel bookkeeping (sizes)"; return -1; }
   for (int c = 0; c < 3; c++) F.mod_out[c] = vardct ? -1 : L[(size_t)(ncol == 1 ? 0 : c)].plane;
   F.mod_out[3] = -1; F.mod_alpha_bits = 8;
   for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits; break; }

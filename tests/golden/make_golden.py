@@ -53,6 +53,11 @@ CASES = {
     "la280x300_e1": (280, 300, dict(seed=33, alpha=True), dict(lossless=True, effort=1)),   # RGBA
     # Modular group sizes other than 256 (JXL_ENC_FRAME_SETTING_MODULAR_GROUP_SIZE = 26; libjxl itself picks 512 for images that fit one such group):
     # 128-px groups (3x2), 512-px groups (2x1, channels wider than the device's LDS rows + weighted predictor), one 1024-px group row
+    # Squeeze (JXL_ENC_FRAME_SETTING_RESPONSIVE = 16): default squeeze parameters, local-tree GlobalModular, group streams with channels of mixed shifts
+    "lr130x300_e7": (130, 300, dict(seed=74), dict(lossless=True, effort=7, extra=((16, 1),))),            # tall: the sequence starts with a vertical step
+    "lrg300x200_e7": (300, 200, dict(seed=76, grey=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # one colour channel
+    "lra200x150_e5": (200, 150, dict(seed=72, alpha=True), dict(lossless=True, effort=5, extra=((16, 1),))), # RGBA: 60 stream channels
+    "va400x300_e7_d2": (400, 300, dict(seed=75, alpha=True), dict(effort=7, distance=2.0)),                 # VarDCT colour + lossy (squeezed, quantised) alpha over 2x2 groups
     "l300x200_g128_e7": (300, 200, dict(seed=61), dict(lossless=True, effort=7, extra=((26, 0),))),
     "la300x200_g128_e5": (300, 200, dict(seed=65, alpha=True), dict(lossless=True, effort=5, extra=((26, 0),))),
     "l516x300_g512_e5": (516, 300, dict(seed=62), dict(lossless=True, effort=5, extra=((26, 2),))),
@@ -115,7 +120,9 @@ def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
 # its 32x32 block means (compressed npz) — the full pixels are up to 92 MB per file.
 BIG_ASSETS = {"asset_dark_street": "dark_street.jxl", "asset_large_jxl": "large_jxl.jxl", "asset_pexels": "pexels-thibaut-tattevin-18273081.jxl",
               "asset_second_jxl": "second_jxl.jxl", "asset_summer_nature": "summer_nature.jxl",
-              "asset_art": "art.jxl"}            # 73 bytes of MA tree: a 1024x1024 Modular frame in one 1024-px group (lossless: the row sums are exact)
+              "asset_art": "art.jxl",
+              # VarDCT colour + squeeze-coded alpha (the alpha row sums are exact: Modular path)
+              "asset_alpha_jxl": "alpha_jxl.jxl", "asset_alpha_png": "alpha_png_freepik.jxl", "asset_hdr_cosmos": "hdr_cosmos.jxl"}            # 73 bytes of MA tree: a 1024x1024 Modular frame in one 1024-px group (lossless: the row sums are exact)
 
 
 def block_means(out, n=32):
@@ -135,7 +142,7 @@ def add_big_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
         np.savez_compressed(os.path.join(HERE, name + ".blocks.npz"), means=block_means(out))
         info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="reference demo asset app/src/main/assets/" + src,
-                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))], fnv1a64="%016x" % jxl_ref.fnv1a64(out.tobytes()))
+                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))], alpha_row_sums=[int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)], fnv1a64="%016x" % jxl_ref.fnv1a64(out.tobytes()))
         print(name, len(data), out.shape, out.dtype)
 
 
@@ -147,7 +154,11 @@ def main():
             continue
         sk = dict(sk)
         alpha = sk.pop("alpha", False)
+        grey = sk.pop("grey", False)
         img = synth.photo_like(w, h, **sk)
+        if grey:
+            img = np.ascontiguousarray(img[..., :1])
+            sk["grey"] = True
         if alpha:
             img = with_alpha(img)
             sk["alpha"] = True

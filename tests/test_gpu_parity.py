@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
-                      LOSSLESS_DEVICE_CASES, load_case)
+                      LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,16 @@ def test_golden_vectors(dec, oracle, name):
     assert np.array_equal(out[..., 3], exp[..., 3])                          # opaque 255, or the Modular-coded alpha bit for bit
     assert info["out_bits"] == 8 and info["prefer_encoding"] == 1
     assert info["has_alpha_in_origin"] == int(name.startswith("va"))
+
+
+@pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES)
+def test_vardct_with_squeezed_alpha(dec, name):
+    """VarDCT colour + lossy alpha (squeeze + quantised residuals): alpha bit for bit, colour within the VarDCT tolerance of the reference."""
+    data, exp = load_case(name)
+    out, info = dec.decode_one_shot(data)
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert np.array_equal(out[..., 3], exp[..., 3]) and d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS
+    assert info["has_alpha_in_origin"] == 1
 
 
 def test_4k_frame_full_size(dec, golden_meta):
@@ -76,7 +86,7 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    art = open(os.path.join(ROOT, "tests", "golden", "asset_alpha_jxl.jxl"), "rb").read()       # the reference's demo asset with squeeze-coded alpha
+    art = open(os.path.join(ROOT, "tests", "golden", "u64_resampling2.jxl"), "rb").read()       # 2x upsampling (JXL_ENC_FRAME_SETTING_RESAMPLING): not on the device path
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
         dec.decode_one_shot(art)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
@@ -375,13 +385,15 @@ def test_corrupt_frame_inside_a_flight_is_contained():
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 BIG_ASSETS = {"asset_dark_street": "tests/golden/asset_dark_street.jxl", "asset_large_jxl": "tests/golden/asset_large_jxl.jxl", "asset_pexels": "tests/golden/asset_pexels.jxl",
               "asset_second_jxl": "tests/golden/asset_second_jxl.jxl", "asset_summer_nature": "bench_data/real4k_summer_nature.jxl",
-              "asset_art": "tests/golden/asset_art.jxl"}                       # 73 bytes of MA tree -> 1024x1024 in one 1024-px Modular group: bit-exact
+              "asset_art": "tests/golden/asset_art.jxl",                       # 73 bytes of MA tree -> 1024x1024 in one 1024-px Modular group: bit-exact
+              # VarDCT colour + squeeze-coded alpha (alpha bit-exact)
+              "asset_alpha_jxl": "tests/golden/asset_alpha_jxl.jxl", "asset_alpha_png": "tests/golden/asset_alpha_png.jxl", "asset_hdr_cosmos": "tests/golden/asset_hdr_cosmos.jxl"}
 
 
 @pytest.mark.parametrize("name", sorted(BIG_ASSETS))
 def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
     """The other demo assets of the reference that decode on the device (app/src/main/assets: up to 3910 x 5865, two of them
-    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: ten of the thirteen) against the reference's own output: every row sum and every
+    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: twelve of the thirteen — animated_jxl.jxl is the one left) against the reference's own output: every row sum and every
     32x32 block mean (tests/golden/make_golden.py big_assets).  Bounds: a row / block may be off by the VarDCT tolerance in the mean
     (u8 0.05, u16 16) — measured: u8 <= 0.012, u16 <= 2.6 (gpurun_out of round 3)."""
     meta = golden_meta[name]
@@ -401,6 +413,8 @@ def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
     blk_err = np.abs(mine - blocks)
     print(f"[asset] {name}: row mean error max {row_err.max():.4f}, block mean error max {blk_err.max():.4f} mean {blk_err.mean():.5f} (tolerance {tol})")
     assert row_err.max() <= tol and blk_err.max() <= 4 * tol and blk_err.mean() <= tol
+    if "alpha_row_sums" in meta and info["has_alpha_in_origin"]:              # Modular-coded alpha (squeeze): exact
+        assert [int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)] == meta["alpha_row_sums"]
     if name == "asset_art":                                                   # Modular (integer) path: exact
         assert np.array_equal(rs, np.array(meta["row_sums"], np.int64)) and blk_err.max() < 1e-3
 

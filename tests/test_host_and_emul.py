@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, load_case)
+                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, load_case)
 
 import jxl_coder_amd as J
 
@@ -92,6 +92,25 @@ def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
     assert np.array_equal(base, alt)
 
 
+@pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES + ["asset_alpha_jxl"])
+def test_squeezed_alpha_of_vardct_frames_on_cpu_harness(emul, name):
+    """Extra channels coded with the squeeze transform (libjxl's lossy alpha; the reference's alpha_jxl.jxl asset): inverse squeeze steps after the
+    group streams, rectangles scaled by the channels' shifts.  Alpha bit-exact against the reference's output, colour within the VarDCT tolerance."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", name + ".jxl")
+    out = emul(open(path, "rb").read())
+    if name.startswith("asset_"):
+        meta = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))[name]
+        assert list(out.shape) == meta["shape"]
+        assert [int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)] == meta["alpha_row_sums"]
+        rs = np.array([int(x) for x in out.astype(np.int64).sum(axis=(1, 2))]) - np.array(meta["row_sums"])
+        assert np.abs(rs).max() / (4.0 * out.shape[1]) <= VARDCT_MEAN_ABS
+    else:
+        exp = load_case(name)[1]
+        d = np.abs(out.astype(int) - exp.astype(int))
+        assert np.array_equal(out[..., 3], exp[..., 3]) and d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS
+
+
 def test_jxl_art_asset_on_cpu_harness(emul):
     """The reference's 73-byte art.jxl: one MA tree painting a 1024 x 1024 Modular frame (a single 1024-px group, channels four times as wide
     as the device's LDS rows: the serial walker keeps the weighted predictor's rows in HBM) — row sums equal the reference's, exactly."""
@@ -103,7 +122,7 @@ def test_jxl_art_asset_on_cpu_harness(emul):
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
-    data = open(os.path.join(ROOT, "tests", "golden", "asset_alpha_jxl.jxl"), "rb").read()      # the reference's demo asset with squeeze-coded alpha
+    data = open(os.path.join(ROOT, "tests", "golden", "u64_resampling2.jxl"), "rb").read()      # 2x upsampling (JXL_ENC_FRAME_SETTING_RESAMPLING): not on the device path
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
 
