@@ -42,17 +42,6 @@ def build_ref_driver():
     return True
 
 
-def driver():
-    if not build_ref_driver():
-        pytest.skip("the reference's driver is compiled in the build container (needs the reference tree)")
-    from jxl_coder_amd import api
-    api.lib()
-    L = C.CDLL(DRIVER_SO)
-    L.boundary_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64 * 2)]
-    L.boundary_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64 * 12), C.POINTER(C.c_double * 8), C.c_char_p, C.c_size_t]
-    return L
-
-
 def test_every_declared_symbol_is_exported():
     d = _compat()
     hdr = open(os.path.join(ROOT, "include", "jxl_amd_libjxl.h")).read()
@@ -132,35 +121,70 @@ def test_event_order_and_header_calls_on_the_host():
     L.JxlDecoderDestroy(dec)
 
 
-def test_reference_driver_answers_basic_info_on_the_host():
-    """interop/JxlDecoding.cpp:178-225 (DecodeBasicInfo), the reference's own object code, against compat/libjxl.so: no GPU involved."""
-    L = driver()
-    for name, wh in (("v264x520_e7", (264, 520)), ("asset_first_jxl", (768, 768)), ("l512_e7", (512, 512))):
-        data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
-        out = (C.c_uint64 * 2)()
-        assert L.boundary_basic_info(data, len(data), C.byref(out)) == 1 and (out[0], out[1]) == wh
-    assert L.boundary_basic_info(b"not a jxl file at all", 21, C.byref((C.c_uint64 * 2)())) == 0
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,allowed_floats", [("v264x520_e7", 0), ("va300x520_e7", 0), ("l512_e7", 0), ("v160x120_16bit_pq2100_epf3", 1),
-                                                 ("v160x120_16bit_pq2100_epf3", 0), ("asset_wide_gamut", 1)])
-def test_reference_driver_decodes_through_the_libjxl_abi(name, allowed_floats):
-    """DecodeJpegXlOneShot — the reference's own compiled driver loop — over the libjxl-ABI subset: pixels and out-params equal the
-    primary boundary's (jxlamd_decode through the Python mirror)."""
+_CHILD = r"""
+import ctypes as C, os, sys, numpy as np
+ROOT = sys.argv[1]; gpu = sys.argv[2] == "gpu"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_libjxl_abi as T
+L = T.driver_handle()
+maps = open("/proc/self/maps").read()
+assert "jxl_coder_amd/compat/libjxl.so" in maps and "oracle/_ref" not in maps, "the driver must be bound to the compat library, not to the reference's libjxl"
+for name, wh in (("v264x520_e7", (264, 520)), ("asset_first_jxl", (768, 768)), ("l512_e7", (512, 512))):
+    data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
+    out = (C.c_uint64 * 2)()
+    assert L.boundary_basic_info(data, len(data), C.byref(out)) == 1 and (out[0], out[1]) == wh, name
+assert L.boundary_basic_info(b"not a jxl file at all", 21, C.byref((C.c_uint64 * 2)())) == 0
+if gpu:
     import torch
     assert torch.cuda.is_available()
     import jxl_coder_amd as J
-    L = driver()
-    data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
-    dec = J.JxlDecoder(0)
-    exp, info = dec.decode_one_shot(data, allowed_floats=bool(allowed_floats))
-    dec.close()
-    out = np.zeros(exp.nbytes, np.uint8)
-    meta = (C.c_uint64 * 12)(); xy = (C.c_double * 8)(); msg = C.create_string_buffer(256)
-    assert L.boundary_decode(data, len(data), allowed_floats, out.ctypes.data, out.size, C.byref(meta), C.byref(xy), msg, 256) == 1
-    assert (meta[0], meta[1]) == (exp.shape[1], exp.shape[0]) and meta[3] == info["out_bits"] and meta[2] == int(info["out_bits"] == 16)
-    assert np.array_equal(out.view(exp.dtype).reshape(exp.shape), exp)
-    assert meta[6] == info["prefer_encoding"] and meta[7] == info["has_alpha_in_origin"] and meta[4] == info["alpha_premultiplied"]
-    assert (meta[8], meta[9]) == (info["primaries"], 65535 if info["transfer_function"] == 65535 else info["transfer_function"])
-    assert meta[10] == 0                                                       # preferEncoding: the ICC vector is cleared (JxlDecoding.cpp:142-144)
+    from jxl_coder_amd import api
+    for name, allowed_floats in (("v264x520_e7", 0), ("va300x520_e7", 0), ("l512_e7", 0), ("v160x120_16bit_pq2100_epf3", 1), ("v160x120_16bit_pq2100_epf3", 0),
+                                 ("asset_wide_gamut", 1), ("va400x300_e7_d2", 0), ("lra200x150_e5", 0)):
+        data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
+        dec = J.JxlDecoder(0)
+        exp, info = dec.decode_one_shot(data, allowed_floats=bool(allowed_floats))
+        dec.close()
+        out = np.zeros(exp.nbytes, np.uint8)
+        meta = (C.c_uint64 * 12)(); xy = (C.c_double * 8)(); msg = C.create_string_buffer(256)
+        rc = L.boundary_decode(data, len(data), allowed_floats, out.ctypes.data, out.size, C.byref(meta), C.byref(xy), msg, 256)
+        assert rc == 1, (name, rc, api.lib().jxlamd_last_error(None))
+        assert (meta[0], meta[1]) == (exp.shape[1], exp.shape[0]) and meta[3] == info["out_bits"] and meta[2] == int(info["out_bits"] == 16), name
+        assert np.array_equal(out.view(exp.dtype).reshape(exp.shape), exp), name            # same kernels underneath: bit for bit
+        assert meta[6] == info["prefer_encoding"] and meta[7] == info["has_alpha_in_origin"] and meta[4] == info["alpha_premultiplied"], name
+        assert (meta[8], meta[9]) == (info["primaries"], info["transfer_function"]), name
+        assert meta[10] == 0, name                                                          # preferEncoding: the ICC vector is cleared (JxlDecoding.cpp:142-144)
+print("driver ok")
+"""
+
+
+def driver_handle():
+    """(child process) the compiled reference driver, bound to compat/libjxl.so"""
+    from jxl_coder_amd import api
+    api.lib()
+    L = C.CDLL(DRIVER_SO)
+    L.boundary_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64 * 2)]
+    L.boundary_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64 * 12), C.POINTER(C.c_double * 8), C.c_char_p, C.c_size_t]
+    return L
+
+
+def _run_child(mode):
+    """The driver runs in a process of its own: a process that has already loaded the REFERENCE's libjxl.so (oracle/_ref, the live checker of
+    other tests) would hand that library to the driver — the dynamic loader matches sonames — and the test would compare the reference with
+    itself."""
+    if not build_ref_driver():
+        pytest.skip("the reference's driver is compiled in the build container (needs the reference tree)")
+    r = subprocess.run([sys.executable, "-c", _CHILD, ROOT, mode], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "driver ok" in r.stdout, r.stdout[-800:] + r.stderr[-2000:]
+
+
+def test_reference_driver_answers_basic_info_on_the_host():
+    """interop/JxlDecoding.cpp:178-225 (DecodeBasicInfo), the reference's own object code, against compat/libjxl.so: no GPU involved."""
+    _run_child("cpu")
+
+
+@pytest.mark.gpu
+def test_reference_driver_decodes_through_the_libjxl_abi():
+    """DecodeJpegXlOneShot — the reference's own compiled driver loop (JxlDecoding.cpp:46-171) — over the libjxl-ABI subset: pixels and
+    out-params equal the primary boundary's (jxlamd_decode through the Python mirror), incl. squeezed alpha and a responsive lossless file."""
+    _run_child("gpu")
