@@ -68,6 +68,12 @@ static size_t mod_scratch_ints_host(const DevFrame &F) {
   return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
 }
 
+__global__ void __launch_bounds__(256) k_fill_opaque_alpha(void *out, size_t npx, int bits) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= npx) return;
+  if (bits == 16) ((uint16_t *)out)[i * 4 + 3] = 65535; else ((uint8_t *)out)[i * 4 + 3] = 255;
+}
+
 BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
   BandGeom q;
   q.gr0 = gr0; q.gr1 = gr1;
@@ -97,6 +103,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (band_rows) {
     if (plan.modular || plan.has_ec || plan.single_section) { set_error("unsupported: band decode of a Modular / extra-channel / single-group frame"); return JXLAMD_ERR_UNSUPPORTED; }
     if (Fh->orientation != 1) { set_error("unsupported: band decode of a frame with a non-identity orientation"); return JXLAMD_ERR_UNSUPPORTED; }
+    if (plan.cropped) { set_error("unsupported: band decode of a frame that does not cover the image"); return JXLAMD_ERR_UNSUPPORTED; }
     if (band_rows[0] < 0 || band_rows[1] <= band_rows[0] || band_rows[1] > Fh->ygroups) { set_error("band rows outside the frame"); return JXLAMD_ERR_BUFFER; }
   }
   const BandGeom q = band_geometry(*Fh, band_rows ? band_rows[0] : 0, band_rows ? band_rows[1] : Fh->ygroups);
@@ -167,6 +174,15 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
   S.host_out = nullptr; S.d_out = out_ptr;
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(S.out_bytes)); S.d_out = S.out.p; S.host_out = out_ptr; }
+  if (plan.cropped) {
+    // the frame does not cover the image: what it leaves out shows the cleared canvas — transparent black, or opaque black when the image
+    // has no alpha channel
+    HIPCHECK(hipMemsetAsync(S.d_out, 0, S.out_bytes, stream));
+    if (!S.pi.has_alpha_in_origin) {
+      const size_t npx = S.out_bytes / bpp;
+      hipLaunchKernelGGL(k_fill_opaque_alpha, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, S.d_out, npx, (int)S.pi.out_bits);
+    }
+  }
   DevBuffers &B = S.B;
   memset(&B, 0, sizeof(B));
   // pointer biases: element [frame coordinate] lands at [frame coordinate - band origin] of the allocation

@@ -218,15 +218,18 @@ JXL_DEV void mod_write_pixel(const DevBuffers &B, int out_bits, int x, int y) {
     t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
     px[c] = (uint32_t)(int)rintf(t * maxv);
   }
+  x += F.crop_x0; y += F.crop_y0;                      // canvas position (see DevFrame::canvas_w)
+  const int W = F.canvas_w, H = F.canvas_h;
+  if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return;
   int ox = x, oy = y;
   switch (F.orientation) {
-    case 2: ox = w - 1 - x; break;
-    case 3: ox = w - 1 - x; oy = h - 1 - y; break;
-    case 4: oy = h - 1 - y; break;
+    case 2: ox = W - 1 - x; break;
+    case 3: ox = W - 1 - x; oy = H - 1 - y; break;
+    case 4: oy = H - 1 - y; break;
     case 5: ox = y; oy = x; break;
-    case 6: ox = h - 1 - y; oy = x; break;
-    case 7: ox = h - 1 - y; oy = w - 1 - x; break;
-    case 8: ox = y; oy = w - 1 - x; break;
+    case 6: ox = H - 1 - y; oy = x; break;
+    case 7: ox = H - 1 - y; oy = W - 1 - x; break;
+    case 8: ox = y; oy = W - 1 - x; break;
     default: break;
   }
   const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;

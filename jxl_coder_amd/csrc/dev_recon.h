@@ -447,8 +447,11 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
     v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
     if (!(lin == lin)) v[c] = 0.0f;
   }
+  const int fx = x, fy = y;                            // frame position (the alpha plane below is read there)
+  x += F.crop_x0; y += F.crop_y0;                      // canvas position
+  const int w = F.canvas_w, h = F.canvas_h;
+  if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return;
   int ox = x, oy = y;
-  const int w = F.width, h = F.height;
   switch (F.orientation) {
     case 2: ox = w - 1 - x; break;
     case 3: ox = w - 1 - x; oy = h - 1 - y; break;
@@ -462,7 +465,7 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
   float alpha = 1.0f;                                  // extra channel of type alpha (Modular-coded, integer samples)
   if (F.has_ec && F.mod_out[3] >= 0) {
-    const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)y * (size_t)F.width + (size_t)x];
+    const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)fy * (size_t)F.width + (size_t)fx];
     alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
     alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;
   }

@@ -114,6 +114,10 @@ struct DevFrame {
   float gamma, intensity_target;
   int32_t orientation;
   int32_t out_w, out_h;            // oriented
+  // A frame smaller than / offset against the image (have_crop; the last frame of an animation): pixel (x, y) of the frame is pixel
+  // (x + crop_x0, y + crop_y0) of the canvas_w x canvas_h image (unoriented); what falls outside is dropped, what the frame does not cover
+  // keeps the cleared canvas.  Ordinary frames: canvas = frame, offsets 0.
+  int32_t canvas_w, canvas_h, crop_x0, crop_y0;
   // Band decode (BASELINE config 4, one frame sharded over GPUs): this decode covers group rows [band_gr0, band_gr1) only.
   // Every kernel keeps addressing cells / groups / pixels with FRAME coordinates; the host biases the buffer pointers so that
   // only the band's rows (+ halo) are backed by memory.  Whole-frame decode: [0, ygroups), [0, yb), [0, height).

@@ -372,22 +372,46 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
   if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
   uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
-  hx_align(&br);
+  int frame_index = 0;
+  bool slot_saved[4] = {false, false, false, false};
   frame_hdr &f = pv->f;
+  int nsec = 0;
+  std::vector<DevSection> &secs = pv->secs;
+  for (;;) {
+  hx_align(&br);
   if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { plan->error = hx_last_error(); return -1; }
-  if (f.frame_type != 0 || !f.is_last) { plan->error = "unsupported: multi-frame / non-regular frame"; return -1; }
+  if (getenv("JXLAMD_PARSE_TRACE"))
+    fprintf(stderr, "frame %d: type %d encoding %d is_last %d crop %d (%d,%d %dx%d) blend %d (all replace: %d) src %d duration %d save_ref %d before_ct %d flags %llu\n", frame_index, f.frame_type,
+            f.encoding, f.is_last, f.have_crop, f.x0, f.y0, f.width, f.height, f.blend_mode, !f.blend_not_replace, f.blend_source, f.duration, f.save_as_ref, f.save_before_ct, (unsigned long long)f.flags);
+  // Several frames (animation; the reference keeps what the LAST coalesced frame shows, interop/JxlDecoding.cpp:164-166): when the last frame
+  // covers the whole canvas and REPLACES it (no blending, no patches / LF frame taken from earlier frames) the earlier frames cannot show
+  // through — they are skipped by their TOC and only the last one is decoded.  Anything that needs the canvas of earlier frames is rejected.
+  const bool skip_this = !f.is_last;
+  if (!skip_this) {
+    if (f.frame_type != 0) { plan->error = "unsupported: non-regular last frame"; return -1; }
+    if (frame_index > 0 && f.blend_not_replace) { plan->error = "unsupported: multi-frame image whose last frame is blended with earlier frames"; return -1; }
+  }
+  if (!skip_this) {
   if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
   if (f.encoding == 1 && m.pub.xyb_encoded) { plan->error = "unsupported: lossy (XYB) Modular frame"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
   if (f.encoding == 1 && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
   if (f.upsampling != 1) { plan->error = "unsupported: upsampling"; return -1; }
-  if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) { plan->error = "unsupported: cropped frame"; return -1; }
+  if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
+    // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas unless an earlier frame was
+    // saved into that slot
+    if (f.blend_not_replace) { plan->error = "unsupported: cropped frame blended with a reference frame"; return -1; }
+    if (slot_saved[f.blend_source & 3]) { plan->error = "unsupported: cropped frame over a saved reference frame"; return -1; }
+    if (f.width < 1 || f.height < 1) { plan->error = "empty frame"; return -1; }
+    plan->cropped = true;
+  }
   if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
   if (f.flags & (1 | 2 | 16 | 32)) { plan->error = "unsupported: patches/splines/noise/LF frame"; return -1; }
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
+  }
   // ---- TOC
-  int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
+  nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   std::vector<uint32_t> perm;
   if (hx_bool(&br)) {
     hx_ec tc;
@@ -403,17 +427,26 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   std::vector<uint32_t> sz((size_t)nsec);
   for (int i = 0; i < nsec; i++) sz[(size_t)i] = hx_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
   hx_align(&br);
-  std::vector<DevSection> &secs = pv->secs;
   secs.resize((size_t)nsec);
   {
     size_t base = br.pos / 8, acc = 0;
     std::vector<size_t> phys((size_t)nsec);
     for (int i = 0; i < nsec; i++) { phys[(size_t)i] = base + acc; acc += sz[(size_t)i]; }
     if (base + acc > csn || br.err) { plan->error = "truncated file (TOC exceeds input)"; return -1; }
+    if (skip_this) {                       // the next frame header starts right after this frame's sections
+      // FrameHeader::CanBeReferenced: a frame of non-zero duration only stays around when it names a slot other than 0
+      if (f.frame_type != 1 && (f.duration == 0 || f.save_as_ref != 0)) slot_saved[f.save_as_ref & 3] = true;
+      hx_br_init(&br, plan->cs, csn);
+      br.pos = (base + acc) * 8;
+      if (++frame_index > 4096) { plan->error = "too many frames"; return -1; }
+      continue;
+    }
     for (int i = 0; i < nsec; i++) {
       size_t src = perm.empty() ? (size_t)i : perm[(size_t)i];
       secs[(size_t)i].off = (uint32_t)phys[src]; secs[(size_t)i].size = sz[src];
     }
+  }
+  break;
   }
   // ---- DevFrame
   DevFrame &F = pv->F;
@@ -541,6 +574,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     F.gamma = m.pub.gamma; F.intensity_target = m.pub.intensity_target;
   }
   F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;
+  F.canvas_w = (int)raw_w; F.canvas_h = (int)raw_h; F.crop_x0 = f.have_crop ? f.x0 : 0; F.crop_y0 = f.have_crop ? f.y0 : 0;
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;
   F.band_scy0 = 0; F.band_scy1 = F.yb; F.band_g0 = 0; F.band_lfg0 = 0;
   plan->single_section = nsec == 1;

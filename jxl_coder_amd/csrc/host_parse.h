@@ -31,6 +31,7 @@ struct FramePlan {
   std::vector<uint8_t> tables;                           // blob: DevFrame at 0
   bool single_section = false;
   bool modular = false;                                  // Modular-encoded (lossless) frame
+  bool cropped = false;                                  // the decoded frame does not cover the image (have_crop): the output is cleared first
   bool has_ec = false;                                   // VarDCT frame with Modular-coded extra channels (alpha)
   size_t mod_pool_ints = 0;                              // int32 samples in the channel-plane pool
   bool hf_parsed = false;

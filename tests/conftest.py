@@ -80,7 +80,9 @@ LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x
 # oracle has no squeeze: these are checked against the reference's own output only (golden vectors), on the CPU harness and on the GPU.
 SQUEEZE_LOSSLESS_CASES = ["lr130x300_e7", "lrg300x200_e7", "lra200x150_e5"]
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES) + SQUEEZE_LOSSLESS_CASES
-SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2"]          # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact
+# VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
+# 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
+SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).

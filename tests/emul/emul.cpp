@@ -26,6 +26,11 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   const int out_bits = (plan.info.bits_per_sample > 8 && allow16) ? 16 : 8;
   *w = plan.info.xsize; *h = plan.info.ysize; *bits = (uint32_t)out_bits;
   const size_t out_bytes = (size_t)plan.info.xsize * plan.info.ysize * 4 * (out_bits / 8);
+  if (plan.cropped && out_bytes <= out_cap) {             // what jxlamd_decoder::prepare does: the cleared canvas (opaque when the image has no alpha)
+    memset(out, 0, out_bytes);
+    if (!(plan.info.num_extra_channels > 0 && plan.info.alpha_bits > 0))
+      for (size_t i = 0; i < out_bytes / (4 * (size_t)(out_bits / 8)); i++) { if (out_bits == 16) ((uint16_t *)out)[i * 4 + 3] = 65535; else out[i * 4 + 3] = 255; }
+  }
   if (out_cap < out_bytes) { g_err = "buffer"; return -5; }
   const size_t ncell = (size_t)plan.xb * plan.yb, ntile = (size_t)((plan.xb + 7) / 8) * ((plan.yb + 7) / 8), npx = ncell * 64;
   std::vector<uint8_t> cs(plan.cs, plan.cs + plan.cs_size); cs.resize(cs.size() + 64, 0);

@@ -102,7 +102,7 @@ def with_alpha(img):
     return np.dstack([img[..., :3], a.astype(img.dtype)])
 
 
-ASSETS = {"asset_first_jxl": "first_jxl.jxl", "asset_wide_gamut": "wide_gamut.jxl"}     # data files of the reference (app/src/main/assets)
+ASSETS = {"asset_first_jxl": "first_jxl.jxl", "asset_wide_gamut": "wide_gamut.jxl", "asset_animated": "animated_jxl.jxl"}     # data files of the reference (app/src/main/assets)
 
 
 def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):

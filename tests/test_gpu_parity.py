@@ -393,7 +393,7 @@ BIG_ASSETS = {"asset_dark_street": "tests/golden/asset_dark_street.jxl", "asset_
 @pytest.mark.parametrize("name", sorted(BIG_ASSETS))
 def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
     """The other demo assets of the reference that decode on the device (app/src/main/assets: up to 3910 x 5865, two of them
-    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit above: twelve of the thirteen — animated_jxl.jxl is the one left) against the reference's own output: every row sum and every
+    16-bit; with first_jxl / wide_gamut / jxl_icc_12bit / animated_jxl in the other tests: all thirteen) against the reference's own output: every row sum and every
     32x32 block mean (tests/golden/make_golden.py big_assets).  Bounds: a row / block may be off by the VarDCT tolerance in the mean
     (u8 0.05, u16 16) — measured: u8 <= 0.012, u16 <= 2.6 (gpurun_out of round 3)."""
     meta = golden_meta[name]
