@@ -102,6 +102,14 @@ def cpu_baseline(data, budget_s=12.0, c5=False):
         return {"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": f"CPU baseline unavailable: {e}"}
 
 
+def _general_contexts(J, decs):
+    """decoder contexts that had to switch to the LF kernel build with the general lock-step loops (0 for libjxl's own streams)"""
+    import ctypes as C
+    f = J.api.lib().jxlamd_debug_lf_general
+    f.argtypes = [C.c_void_p]; f.restype = C.c_int
+    return sum(int(f(d._h)) for d in decs)
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -415,7 +423,7 @@ def main():
                                    "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "
                                    "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
                        "h2d_included_MPps": round(h2d_steps * B * world * mp / elapsed_h2d, 2), "h2d_included_steps": h2d_steps, "distinct_frames": len(datas),
-                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "retried_flights": int(kern.get("retried_flights", 0)),
+                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective"},

@@ -130,6 +130,9 @@ int jxlamd_last_timing(const jxlamd_decoder *dec, float ms[5]);
  * [5] varblocks placed, [6] epilogue done. */
 int jxlamd_debug_lf_phases(jxlamd_decoder *dec, int num_lf_groups, uint64_t *out);
 int jxlamd_debug_lf_phases_frame(jxlamd_decoder *dec, int frame, int num_lf_groups, uint64_t *out);   /* same, frame `frame` of the last flight */
+/* 1 once a frame of this context needed the LF kernel build with the general lock-step loops (decoded again with it, and every later
+ * decode of the context uses it): the lean build covers libjxl's LF-coefficient and HF-metadata streams. */
+int jxlamd_debug_lf_general(const jxlamd_decoder *dec);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Post-decode stages of the reference's JNI layer, on buffers that stay in HBM.

@@ -60,6 +60,8 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 // internal return code: the lean LF kernel met a channel that needs a general lock-step loop (kErrNeedGeneral) — decode again with the general build
 static constexpr int kRetryGeneral = 0x7e7e;
+// ... or a channel whose packed tables did not fit the LDS table pool this launch was sized with (kErrNeedPool): decode again with the largest
+static constexpr int kRetryPool = 0x7e7f;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host twin of mod_group_scratch_ints (dev_modframe.h)
@@ -227,6 +229,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   HIPCHECK(hipMemcpyAsync(&end_bit, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
+  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
@@ -290,8 +293,9 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   HIPCHECK(hipGetLastError());
   (void)flags;
   derr = head[0];
-  if (!S.plan.modular) lf_pool_bytes = lf_pool_clamp(head[1]);
+  if (!S.plan.modular) lf_pool_bytes = std::max(lf_pool_floor, lf_pool_clamp(head[1]));
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
+  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = std::max(lf_pool_floor, lf_pool_clamp(head[1])); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
@@ -300,7 +304,8 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
 
 int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
   int rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
-  if (rc0 != kRetryGeneral) return rc0;
+  if (rc0 == kRetryPool) rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);       // with the largest table pool
+  if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
   lf_general = true;
   return decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
 }
@@ -368,7 +373,8 @@ std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  if (rc0 != kRetryGeneral) return rc0;
+  if (rc0 == kRetryPool) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);   // with the largest table pool
+  if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
   lf_general = true;                       // some frame needs a general lock-step loop: this context runs the general LF build from now on
   return decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
 }
@@ -583,6 +589,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   int first_rc = JXLAMD_OK;
   large_blocks_seen = false;
   uint32_t pool_want = 0;
+  bool need_pool = false;
   // flags / counters of all frames in one device-to-host copy and one synchronisation
   launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
   HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
@@ -595,12 +602,14 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
     pool_want = std::max(pool_want, head[1]);
-    if ((head[0] & kErrNeedGeneral) && !lf_general) return kRetryGeneral;      // (coef_pool_clean stays false: the second attempt clears the pool)
+    if ((head[0] & kErrNeedPool) && !(head[0] & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) need_pool = true;
+    else if ((head[0] & kErrNeedGeneral) && !lf_general) return kRetryGeneral;      // (coef_pool_clean stays false: the second attempt clears the pool)
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
   }
+  if (need_pool) { lf_pool_floor = std::max(lf_pool_floor, lf_pool_clamp(pool_want)); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   coef_pool_clean = first_rc == JXLAMD_OK;
-  lf_pool_bytes = lf_pool_clamp(pool_want);
+  lf_pool_bytes = std::max(lf_pool_floor, lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
@@ -861,6 +870,7 @@ int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) 
   return hipMemcpy(out, (uint8_t *)d->slots[0]->misc.p + 4096 + (size_t)num_lf_groups * 8, (size_t)num_lf_groups * 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : JXLAMD_ERR_DEVICE;
 }
 
+int jxlamd_debug_lf_general(const jxlamd_decoder *dec) { return dec && dec->lf_general ? 1 : 0; }
 int jxlamd_debug_lf_phases_frame(jxlamd_decoder *d, int frame, int num_lf_groups, uint64_t *out) {     // frame = slot index inside the last flight
   if (!d || frame < 0 || (size_t)frame >= d->slots.size() || !d->slots[(size_t)frame]->misc.p) return JXLAMD_ERR_DEVICE;
   FrameSlot &S = *d->slots[(size_t)frame];

@@ -232,7 +232,14 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     if (w == 0 || h == 0) continue;
     const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id, S.wt.stack_node);
 #ifdef JXL_EMUL_TRACE
-    fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop);
+    {
+      unsigned props_used = 0, preds_used = 0; int leaves = 0, nonunit = 0, sp = 0, st[256]; st[sp++] = 0;
+      while (sp > 0) { const DevTreeNode nd = gtree[st[--sp]];
+        if (nd.prop < 0) { preds_used |= 1u << nd.lchild; leaves++; if (nd.rchild != 1 || nd.offset != 0) nonunit++; continue; }
+        if (nd.prop == 0 || nd.prop == 1) { int v = nd.prop == 0 ? ci : stream_id; st[sp++] = v > nd.splitval ? nd.lchild : nd.rchild; continue; }
+        props_used |= 1u << nd.prop; if (sp + 2 < 256) { st[sp++] = nd.lchild; st[sp++] = nd.rchild; } }
+      fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d props 0x%x predictors 0x%x leaves %d (mul/offset != 1/0: %d)\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop, props_used, preds_used, leaves, nonunit);
+    }
 #endif
     if (tf.max_prop > 15) return kErrUnsupportedTransform;   // previous-channel properties: not on device yet
     const bool wide = w > kModMaxW;

@@ -605,7 +605,7 @@ __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, De
     int32_t *out = c.d + (size_t)y * (size_t)w;
     int32_t *row = S.rows[y & 1];
     const int32_t *rN = S.rows[(y + 1) & 1];
-    int32_t vW = 0, keep = 0;
+    int32_t vW = 0, keep = 0, vNW = 0;
     int32_t vN = y > 0 ? (needs_n ? rN[0] : out[-(ptrdiff_t)w]) : 0;      // the sample above x = 0 stands in for W there (needed even when no property reads N)
     for (int x0 = 0; x0 < w; x0 += 64) {
       const int m = w - x0 < 64 ? w - x0 : 64;
@@ -614,6 +614,7 @@ __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, De
         const int x = x0 + i;
         const int32_t W_ = x > 0 ? vW : vN;                       // x == 0: the sample above (0 in the first row)
         const int32_t N_ = y > 0 ? vN : W_;
+        const int32_t NW_ = (x > 0 && y > 0) ? vNW : W_;
         const int32_t nextN = (needs_n && y > 0 && x + 1 < w) ? rN[x + 1] : 0;
         int32_t myv = __mul24(cN, N_) + __mul24(cW, W_) + __mul24(cX, x) + __mul24(cY, y);
         if (cAbs) myv = myv < 0 ? -myv : myv;
@@ -625,10 +626,11 @@ __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, De
         const int l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf), l_clu = __builtin_amdgcn_readlane(my_lclu, leaf);
         const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
         const int32_t res = unpack_signed(u);
-        const int32_t guess = l_pred == 0 ? 0 : l_pred == 1 ? W_ : N_;
+        // predictors 0 .. 5: zero, W, N, their average, the select and the clamped gradient (libjxl's chroma-from-luma maps: one leaf, gradient)
+        const int32_t guess = l_pred == 0 ? 0 : l_pred == 1 ? W_ : l_pred == 2 ? N_ : predict_plain_t<int32_t>(l_pred, W_, N_, NW_, 0, 0, 0, 0, 0);
         const int32_t val = (l_mul == 1 ? res : res * l_mul) + l_off + guess;
         keep = shift_in_wave1(val, keep);
-        vW = val; vN = nextN;
+        vNW = vN; vW = val; vN = nextN;
       }
       if (lane < m) { const int32_t v = keep; out[x0 + m - 1 - lane] = v; if (needs_n) row[x0 + m - 1 - lane] = v; }
     }
@@ -697,6 +699,8 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_lclu, j) & 63);
       const int la_p = ev.log_alpha;
       mod_pool_want(S, wave_packed_bytes(used, la_p), lane);
+      // the lean build has no general loop to fall back to: a pool sized by the previous flight that is too small for this channel is a retry
+      if (!kGeneral && wave_packed_bytes(used, la_p) > S.pool_bytes && wave_packed_bytes(used, la_p) <= kModPoolBytes) return kErrNeedPool;
       if (wave_packed_bytes(used, la_p) <= S.pool_bytes) {
       // rank the thresholds; lane c then holds a value with exactly c thresholds below it
       int rank = 0;
@@ -748,10 +752,10 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       }
     }
     // lean loop (see wave_decode_channel_lean): y / x / N / W properties only, zero / W / N predictors
-    if (m16 && !ev.use_prefix && !uses_wp && WT.ni >= 1 && WT.ni <= 64 && WT.nl <= 64) {
+    if (m16 && !ev.use_prefix && !uses_wp && WT.ni <= 64 && WT.nl >= 1 && WT.nl <= 64) {
       const bool props_ok = __ballot(lane < WT.ni && (WT.int_prop[lane] < 2 || WT.int_prop[lane] > 7)) == 0;
-      const bool preds_ok = __ballot(lane < WT.nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 2)) == 0;
-      const bool needs_n = __ballot((lane < WT.ni && (WT.int_prop[lane] == 4 || WT.int_prop[lane] == 6)) || (lane < WT.nl && WT.leaf_pred[lane] == 2)) != 0;
+      const bool preds_ok = __ballot(lane < WT.nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 5)) == 0;
+      const bool needs_n = __ballot((lane < WT.ni && (WT.int_prop[lane] == 4 || WT.int_prop[lane] == 6)) || (lane < WT.nl && WT.leaf_pred[lane] >= 2)) != 0;
       if (props_ok && preds_ok && (!needs_n || c.w <= kModMaxW)) {
         if (lds_now) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n);
         else wave_decode_channel_lean<false>(evg, b, state, S, WT, c, lane, needs_n);
