@@ -69,6 +69,10 @@ static size_t mod_scratch_ints_host(const DevFrame &F) {
   const size_t gd = (size_t)(F.mod_group_dim > 0 ? F.mod_group_dim : 256);
   return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
 }
+// ... + the ModularLfGroup rectangles (mod_lfgroup_body): 256 x 256 samples per channel and LF group
+static size_t mod_scratch_total_ints(const DevFrame &F, int num_groups, int num_lf_groups) {
+  return ((size_t)num_groups + 1) * mod_scratch_ints_host(F) + (size_t)num_lf_groups * (size_t)F.mod_lf_nch * 65536;
+}
 
 __global__ void __launch_bounds__(256) k_fill_opaque_alpha(void *out, size_t npx, int bits) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -163,14 +167,14 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
     if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-      HIPCHECK(S.mod_scratch.ensure(((size_t)plan.num_groups + 1) * mod_scratch_ints_host(*Fh) * 4 + 256));      // + 1: the GlobalModular stream's slot
+      HIPCHECK(S.mod_scratch.ensure(mod_scratch_total_ints(*Fh, plan.num_groups, plan.num_lf_groups) * 4 + 256));      // + 1: the GlobalModular stream's slot
       HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
       HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
     }
   } else {
     if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure(((size_t)Fh->lz_win_len + (size_t)plan.num_groups * (size_t)Fh->lz_win_group) * 4));
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
-    HIPCHECK(S.mod_scratch.ensure(((size_t)plan.num_groups + 1) * mod_scratch_ints_host(*Fh) * 4 + 256));      // + 1: the GlobalModular stream's slot
+    HIPCHECK(S.mod_scratch.ensure(mod_scratch_total_ints(*Fh, plan.num_groups, plan.num_lf_groups) * 4 + 256));      // + 1: the GlobalModular stream's slot
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
@@ -278,6 +282,7 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   launch_mod_global(S.B, stream);
+  if (F->mod_lf_nch > 0) launch_mod_lfgroups(S.B, plan.num_lf_groups, stream);
   if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
   launch_mod_write(S.B, plan.width, plan.height, (int)S.pi.out_bits, stream);
@@ -325,7 +330,9 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
     return rc;
   }
   if (S.plan.has_ec) launch_mod_global(S.B, stream);
-  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, lf_general, stream);
+  // a single decode is the latency path and has the chip to itself: the general build (181 VGPRs) runs a lone stream ~5 % faster than the lean
+  // one (125), whose smaller footprint only pays next to the data-parallel kernels of other flights
+  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, /*general=*/true, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
@@ -607,7 +614,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
   }
-  if (need_pool) { lf_pool_floor = std::max(lf_pool_floor, lf_pool_clamp(pool_want)); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  if (need_pool) { lf_pool_floor = std::max(lf_pool_floor, std::min((int)kModPoolBytes, lf_pool_clamp(pool_want) + 3 * 1280)); lf_pool_bytes = kModPoolBytes; return kRetryPool; }      // + three clusters of headroom: the next frames' streams differ by a cluster or two
   coef_pool_clean = first_rc == JXLAMD_OK;
   lf_pool_bytes = std::max(lf_pool_floor, lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one

@@ -3,6 +3,7 @@
 // (tests/emul, test-only) runs each workgroup as one serial "thread" (nthreads = 1, sync = no-op).
 #pragma once
 #include "dev_recon.h"
+#include "dev_modframe.h"
 
 namespace jxlamd {
 
@@ -31,6 +32,17 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
   JXL_STAMP(1);
   uint32_t e = lf_phase_coeffs<kWave, kGeneral>(B, S, g, tid);          // whole wave on the GPU (kWave), or this lane alone
   JXL_STAMP(2);
+  {
+    const DevFrame &Fm = frame_of(B);
+    if (Fm.has_ec && Fm.mod_lf_nch > 0) {                   // ModularLfGroup stream of the extra channels: between the LF coefficients and the HF metadata
+      sync();
+      if (tid == 0) S.st.err = e;
+      sync();
+      if (!S.st.err) { const uint32_t e2 = mod_lfgroup_body<kGeneral>(B, S, g, tid, nthreads, sync); if (e2) e = e2; }
+      if (tid == 0) S.st.err = 0;
+      sync();
+    }
+  }
   if (tid == 0) { if (!e) e = lf_phase_meta_open(B, S, g); if (e) { S.st.err = e; *B.err |= e | kErrStageLf; } }
   sync();
   if (S.st.err) return;                                       // uniform: read from LDS after the barrier

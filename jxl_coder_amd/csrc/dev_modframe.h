@@ -18,9 +18,10 @@ JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) {
 JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
 
 // one stream's channels: whole wave on the GPU, lane 0 alone in the CPU harness
+template <bool kGeneral = true>
 JXL_DEV uint32_t mod_decode_stream(DevModScratch &S, const DevChanOut *ch, int nch, int stream_id, int tid) {
 #ifdef __HIPCC__
-  return modular_stream_decode_wave(S, ch, nch, stream_id, tid);
+  return modular_stream_decode_wave<kGeneral>(S, ch, nch, stream_id, tid);
 #else
   return tid == 0 ? modular_stream_decode(S, ch, nch, stream_id) : 0;
 #endif
@@ -75,6 +76,62 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
   if (tid == 0 && e) *B.err |= e | kErrStageLf;
   if (tid == 0 && F.has_ec) *B.mod_end_bit = S.st.b.consumed;      // absolute: the reader started at the section and skipped mod_global_bit
   sync();
+}
+
+// ---- ModularLfGroup (H.3, stream ModularDC(g)): the rectangle of LF group g (2048 x 2048 pixels) of every remaining frame channel whose shifts
+// are both >= 3 — squeeze residuals of images beyond 2048 pixels — decoded into the frame planes.  The caller has S.st.b at the stream (in a
+// VarDCT frame it follows the LF coefficients of the same section); rectangles are at most 256 x 256 samples (2048 >> 3).
+JXL_DEV size_t mod_lf_scratch_base(const DevFrame &F) { return ((size_t)F.num_groups + 1) * mod_group_scratch_ints(F); }
+template <bool kGeneral = true, class Sync>
+JXL_DEV uint32_t mod_lfgroup_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  const int gx = g % F.xlfg, gy = g / F.xlfg;
+  const int ld = F.mod_group_dim * 8;
+  const int x0 = gx * ld, y0 = gy * ld;
+  int32_t *scr = B.mod_scratch + mod_lf_scratch_base(F) + (size_t)g * (size_t)F.mod_lf_nch * 65536;
+  if (tid == 0) {
+    int n = 0, slot = 0;
+    for (int fc = F.mod_first_group_ch; fc < F.mod_nch; fc++) {
+      const int hs = F.mod_hs[fc], vs = F.mod_vs[fc];
+      if ((hs < vs ? hs : vs) < 3) continue;
+      const int my = slot++;
+      int rw = F.mod_w[fc] - (x0 >> hs), rh = F.mod_h[fc] - (y0 >> vs);
+      const int gw = ld >> hs, gh = ld >> vs;
+      rw = rw < 0 ? 0 : rw > gw ? gw : rw; rh = rh < 0 ? 0 : rh > gh ? gh : rh;
+      if (rw == 0 || rh == 0) continue;
+      S.ch[n].d = scr + (size_t)my * 65536; S.ch[n].w = rw; S.ch[n].h = rh; S.grp_src[n] = fc;
+      n++;
+    }
+    S.grp_n = n;
+    S.st.err = 0; S.trs.n = 0;
+    if (n > 0) {
+      S.lz.win = nullptr;
+      modular_stream_begin(B.tables, F, B.local[g], S, &S.trs);
+      if (!S.st.err && S.trs.n > 0) S.st.err = kErrUnsupportedTransform;      // transforms local to an LF-group stream: not on the device
+      for (int i = 0; i < n && !S.st.err; i++) if (S.ch[i].w > 256 || S.ch[i].h > 256) S.st.err = kErrUnsupportedTransform;
+    }
+  }
+  sync();
+  if (S.st.err) return S.st.err;
+  if (S.grp_n == 0) return 0;                            // no such channel reaches this LF group: the stream is absent
+  modular_stream_stage(S, tid, nthreads);
+  sync();
+  const int nst = S.grp_n;
+  uint32_t e = mod_decode_stream<kGeneral>(S, S.ch, nst, 1 + F.num_lf_groups + g, tid);
+  sync();
+  if (e) return e;
+  for (int c = 0; c < nst; c++) {
+    const int fc = S.grp_src[c];
+    const DevChanOut ch = S.ch[c];
+    int32_t *dst = mod_plane(B, F, fc);
+    const int cx0 = x0 >> F.mod_hs[fc], cy0 = y0 >> F.mod_vs[fc];
+    for (int i = tid; i < ch.w * ch.h; i += nthreads) {
+      const int y = i / ch.w, x = i - y * ch.w;
+      dst[(size_t)(cy0 + y) * (size_t)F.mod_w[fc] + (size_t)(cx0 + x)] = ch.d[i];
+    }
+  }
+  sync();
+  return 0;
 }
 
 // ---- one 256x256 group of the remaining channels

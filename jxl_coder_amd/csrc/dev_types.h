@@ -92,6 +92,7 @@ struct DevFrame {
   int32_t mod_w[kModMaxCh], mod_h[kModMaxCh];                      // stream channels (after every meta-apply), in stream order
   uint8_t mod_hs[kModMaxCh], mod_vs[kModMaxCh];                    // their shifts (squeeze): a group / LF-group rectangle is the frame rectangle >> shift
   uint32_t mod_plane_off[kModMaxPlanes];                           // int32 planes (offsets in samples into the pool): stream channel i = plane i, then the outputs of the inverse squeeze steps
+  int32_t mod_lf_nch;              // frame channels (index >= mod_first_group_ch) with both shifts >= 3: they travel in the ModularLfGroup streams (squeeze residuals of images beyond 2048 px)
   int32_t mod_group_dim;           // group size of a Modular-encoded frame: 128 << group_size_shift (VarDCT frames: 256)
   uint32_t mod_global_bit;         // bit offset inside section 0 of GlobalModular's GroupHeader
   uint32_t lz_win_len;             // LZ77 window entries of the GlobalModular stream (0: the frame's global code has no LZ77) ...

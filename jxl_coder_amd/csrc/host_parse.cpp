@@ -244,8 +244,9 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   }
   // channels after the first one that exceeds a group travel in the ModularLfGroup (both shifts >= 3) or ModularGroup streams; the device
   // decodes the latter (single-pass frames: shifts 0..2)
-  for (int i = first_group; i < F.mod_nch; i++)
-    if (std::min(L[(size_t)i].hs, L[(size_t)i].vs) >= 3 && L[(size_t)i].w > 0 && L[(size_t)i].h > 0) { plan->error = "unsupported: squeeze with ModularLfGroup channels"; return -1; }
+  F.mod_lf_nch = 0;
+  for (int i = first_group; i < F.mod_nch; i++) if (std::min(L[(size_t)i].hs, L[(size_t)i].vs) >= 3) F.mod_lf_nch++;
+  if (F.mod_lf_nch > 8) { plan->error = "unsupported: more than 8 ModularLfGroup channels"; return -1; }
   // planes are indexed by stream channel position (the device decodes "channel i" into plane i); the inverse squeeze steps append theirs
   int nplanes = F.mod_nch;
   for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }

@@ -38,6 +38,7 @@ void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);
 // Modular-encoded (lossless) frames
 void launch_mod_global(const DevBuffers &B, hipStream_t s);
 void launch_mod_groups(const DevBuffers &B, int num_groups, hipStream_t s);
+void launch_mod_lfgroups(const DevBuffers &B, int num_lf_groups, hipStream_t s);      // ModularLfGroup streams of a Modular-encoded frame
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s);
 void launch_mod_write(const DevBuffers &B, int width, int height, int out_bits, hipStream_t s);
 void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s);

@@ -15,6 +15,24 @@ __global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
   __shared__ DevModScratch S;
   mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
 }
+// ModularLfGroup streams of a Modular-encoded frame (section 1 + g holds nothing else there)
+__device__ __forceinline__ void mod_lfgroup_kernel(const DevBuffers &B, DevModScratch &S, int g) {
+  const DevFrame &F = frame_of(B);
+  if (threadIdx.x == 0) {
+    S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.wide_wp = nullptr;
+    const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+    DevBits b;
+    bits_init(b, B.codestream, secs[1 + g].off, F.cs_size);
+    S.st.b = b;
+  }
+  __syncthreads();
+  const uint32_t e = mod_lfgroup_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+  if (threadIdx.x == 0 && e) *B.err |= e | kErrStageLf;
+}
+__global__ void __launch_bounds__(64) k_mod_lfgroup(DevBuffers B) {
+  __shared__ DevModScratch S;
+  mod_lfgroup_kernel(B, S, (int)blockIdx.x);
+}
 __global__ void __launch_bounds__(256) k_mod_op(DevBuffers B, int op, size_t n) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) mod_op_element(B, frame_of(B), op, i);
@@ -26,6 +44,7 @@ __global__ void __launch_bounds__(256) k_mod_write(DevBuffers B, int out_bits, i
 }
 void launch_mod_global(const DevBuffers &B, hipStream_t s) { hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), 0, s, B); }
 void launch_mod_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_group, dim3(n), dim3(64), 0, s, B); }
+void launch_mod_lfgroups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_lfgroup, dim3(n), dim3(64), 0, s, B); }
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_mod_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, op, n); }
 void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream_t s) {
   hipLaunchKernelGGL(k_mod_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, out_bits, w, h);
@@ -45,6 +64,13 @@ __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const 
   const DevFrame &F = frame_of(B);
   if (F.mod_first_group_ch >= F.mod_nch) return;
   mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+}
+__global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *Bs) {      // grid (max LF groups, frames)
+  __shared__ DevModScratch S;
+  const DevBuffers &B = Bs[blockIdx.y];
+  const DevFrame &F = frame_of(B);
+  if (!F.is_modular || F.mod_lf_nch <= 0 || (int)blockIdx.x >= F.num_lf_groups || frame_failed(B)) return;
+  mod_lfgroup_kernel(B, S, (int)blockIdx.x);
 }
 __global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) {
   const DevBuffers &B = Bs[blockIdx.z];
@@ -69,6 +95,8 @@ void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nfra
 }
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s) {
   hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);
+  const int max_lfg = ((max_w + 1023) / 1024) * ((max_h + 1023) / 1024);       // LF groups are 8 x group_dim pixels wide (>= 1024)
+  if (max_w > 1024 || max_h > 1024) hipLaunchKernelGGL(k_mod_lfgroup_b, dim3(max_lfg, nframes), dim3(64), 0, s, Bs);   // only images beyond one LF group can carry such streams
   if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
   for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
   hipLaunchKernelGGL(k_mod_write_b, dim3((max_w + 63) / 64, (max_h + 3) / 4, nframes), dim3(256), 0, s, Bs);

@@ -78,7 +78,7 @@ LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x
 # and the *_g* files use Modular group sizes 128 / 512 / 1024)
 # Squeeze (responsive lossless files: default squeeze parameters, local-tree GlobalModular, group streams with channels of mixed shifts).  The C
 # oracle has no squeeze: these are checked against the reference's own output only (golden vectors), on the CPU harness and on the GPU.
-SQUEEZE_LOSSLESS_CASES = ["lr130x300_e7", "lrg300x200_e7", "lra200x150_e5"]
+SQUEEZE_LOSSLESS_CASES = ["lr130x300_e7", "lrg300x200_e7", "lra200x150_e5", "lr2100x40_e3"]      # the last one: beyond 2048 px, residual channels in the ModularLfGroup streams
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES) + SQUEEZE_LOSSLESS_CASES
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas

@@ -53,7 +53,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = errw; B.out = out;
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
-  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + 64 : 1, 0);
+  std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len, lzg = ((const DevFrame *)plan.tables.data())->lz_win_group;
@@ -65,6 +65,12 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     const DevFrame &F = *(const DevFrame *)tables.data();
     DevModScratch *MS = new DevModScratch();
     mod_global_body(B, *MS, 0, 1, NoSync());
+    for (int g = 0; F.mod_lf_nch > 0 && g < plan.num_lf_groups && !err; g++) {       // ModularLfGroup streams (k_mod_lfgroup)
+      const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
+      DevBits b; bits_init(b, B.codestream, secs[1 + g].off, F.cs_size);
+      MS->st.b = b; MS->wide_wp = nullptr;
+      uint32_t e = mod_lfgroup_body(B, *MS, g, 0, 1, NoSync()); if (e) err |= e;
+    }
     if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS, g, 0, 1, NoSync());
     delete MS;
     if (err) { g_err = "device flags " + std::to_string(err) + " (Modular)"; return -2; }

@@ -57,6 +57,7 @@ CASES = {
     "lr130x300_e7": (130, 300, dict(seed=74), dict(lossless=True, effort=7, extra=((16, 1),))),            # tall: the sequence starts with a vertical step
     "lrg300x200_e7": (300, 200, dict(seed=76, grey=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # one colour channel
     "lra200x150_e5": (200, 150, dict(seed=72, alpha=True), dict(lossless=True, effort=5, extra=((16, 1),))), # RGBA: 60 stream channels
+    "lr2100x40_e3": (2100, 40, dict(seed=92), dict(lossless=True, effort=3, extra=((16, 1),))),              # beyond 2048 px: squeeze residuals in the ModularLfGroup streams
     "va400x300_e7_d2": (400, 300, dict(seed=75, alpha=True), dict(effort=7, distance=2.0)),                 # VarDCT colour + lossy (squeezed, quantised) alpha over 2x2 groups
     "l300x200_g128_e7": (300, 200, dict(seed=61), dict(lossless=True, effort=7, extra=((26, 0),))),
     "la300x200_g128_e5": (300, 200, dict(seed=65, alpha=True), dict(lossless=True, effort=5, extra=((26, 0),))),
@@ -76,6 +77,8 @@ CASES = {
 ROWSUM_CASES = {
     "vb264x4200_e7_epf3": (264, 4200, dict(seed=11), dict(effort=7, epf=3)),      # Gaborish + 3 EPF iterations: halo H = 7 rows
     "vb520x4400_e7": (520, 4400, dict(seed=12), dict(effort=7)),                  # encoder defaults at d = 1: Gaborish + 1 iteration, H = 3
+    # VarDCT + lossy (squeezed) alpha beyond 2048 px: the alpha's shift-3 residuals exceed a group and travel in the ModularLfGroup streams
+    "va2300x700_e7_d3": (2300, 700, dict(seed=91, alpha=True), dict(effort=7, distance=3.0)),
 }
 
 
@@ -83,11 +86,15 @@ def add_rowsum_cases(meta, only):
     for name, (w, h, sk, ek) in ROWSUM_CASES.items():
         if only and name not in only:
             continue
-        data = jxl_ref.encode(synth.photo_like(w, h, **sk), **ek)
+        sk2 = dict(sk); al = sk2.pop("alpha", False)
+        img = synth.photo_like(w, h, **sk2)
+        if al:
+            img = with_alpha(img)
+        data = jxl_ref.encode(img, **ek)
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
         meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), encode=ek, synth=sk,
-                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))])
+                          row_sums=[int(x) for x in out.astype(np.int64).sum(axis=(1, 2))], alpha_row_sums=[int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)])
         print(name, len(data), out.shape)
 
 

@@ -38,6 +38,19 @@ def test_golden_vectors(dec, oracle, name):
     assert info["has_alpha_in_origin"] == int(name.startswith("va"))
 
 
+def test_vardct_with_squeezed_alpha_beyond_2048_pixels(dec, golden_meta):
+    """2300 x 700 VarDCT + lossy alpha: the alpha's shift-3 squeeze residuals exceed a group and travel in the ModularLfGroup streams (decoded by the
+    LF kernel between the LF coefficients and the HF metadata).  Alpha row sums exact, colour row sums within the VarDCT tolerance."""
+    name = "va2300x700_e7_d3"
+    meta = golden_meta[name]
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    out, info = dec.decode_one_shot(data)
+    assert list(out.shape) == meta["shape"]
+    assert [int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)] == meta["alpha_row_sums"]
+    rs = out.astype(np.int64).sum(axis=(1, 2)) - np.array(meta["row_sums"], np.int64)
+    assert np.abs(rs).max() / (4.0 * out.shape[1]) <= VARDCT_MEAN_ABS
+
+
 @pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES)
 def test_vardct_with_squeezed_alpha(dec, name):
     """VarDCT colour + lossy alpha (squeeze + quantised residuals): alpha bit for bit, colour within the VarDCT tolerance of the reference."""

@@ -92,7 +92,7 @@ def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
     assert np.array_equal(base, alt)
 
 
-@pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES + ["asset_alpha_jxl"])
+@pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES + ["asset_alpha_jxl", "va2300x700_e7_d3"])       # the last one: ModularLfGroup stream between LF coefficients and HF metadata
 def test_squeezed_alpha_of_vardct_frames_on_cpu_harness(emul, name):
     """Extra channels coded with the squeeze transform (libjxl's lossy alpha; the reference's alpha_jxl.jxl asset): inverse squeeze steps after the
     group streams, rectangles scaled by the channels' shifts.  Alpha bit-exact against the reference's output, colour within the VarDCT tolerance.
