@@ -20,7 +20,8 @@ static void fill_public_info(const ImageInfo &i, uint32_t flags, jxlamd_info *o)
   o->uses_original_profile = i.uses_original_profile;
   o->intensity_target = i.intensity_target <= 0.f ? 255.f : i.intensity_target;
   o->have_encoded_profile = !i.want_icc;
-  o->color_space = i.color_space; o->white_point = i.white_point; o->primaries = i.primaries;
+  o->color_space = i.color_space; o->white_point = i.white_point;
+  o->primaries = (i.color_space == 0 || i.color_space == 3) ? i.primaries : 0;      // grey / XYB encodings carry no primaries: libjxl leaves the field 0
   o->transfer_function = i.have_gamma ? 65535u : i.transfer_function; o->rendering_intent = i.rendering_intent;
   o->gamma = i.have_gamma ? (double)i.gamma : 0.0;
   o->out_bits = (i.bits_per_sample > 8 && (flags & JXLAMD_ALLOW_16BIT)) ? 16 : 8;

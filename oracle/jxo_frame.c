@@ -138,7 +138,7 @@ static int read_image_header(jxo_br *br, img_meta *m) {
         if (p->color_space != 2 && p->color_space != 1) {
           p->primaries = jxo_enum(br);
           if (p->primaries == 2) for (int k = 0; k < 6; k++) m->prim_xy[k] = read_customxy(br);
-        }
+        } else p->primaries = 0;                 /* grey / XYB encodings carry no primaries: libjxl reports the field as 0 */
         if (p->color_space != 2) {
           p->have_gamma = (uint32_t)jxo_bool(br);
           if (p->have_gamma) p->gamma = (float)jxo_bits(br, 24) * 1e-7f; else p->transfer_function = jxo_enum(br);
@@ -547,7 +547,35 @@ static int read_lf_group(fstate *s, jxo_br *br, int g) {
       }
     jxo_modimg_free(&im);
   }
-  /* ModularLfGroup: channels of the global image with hshift>=3 && vshift>=3: none without squeeze */
+  /* ModularLfGroup (stream ModularDC(g)): the LF group's rectangle of every remaining channel of the global image with hshift >= 3 && vshift >= 3
+     (squeeze residuals of images beyond 2048 pixels) */
+  if (s->gmod_first_undecoded < s->gmod.nch) {
+    int ld = f->group_dim * 8, x0 = gx * ld, y0 = gy * ld;
+    jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = s->gmod.bitdepth;
+    int map[64], nmap = 0;
+    for (int c = s->gmod_first_undecoded; c < s->gmod.nch && nmap < 64; c++) {
+      jxo_chan *fc = &s->gmod.ch[c];
+      int sh = fc->hshift < fc->vshift ? fc->hshift : fc->vshift;
+      if (sh < 3) continue;
+      int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift, rw = ld >> fc->hshift, rh = ld >> fc->vshift;
+      if (rx >= fc->w || ry >= fc->h) continue;
+      if (rx + rw > fc->w) rw = fc->w - rx;
+      if (ry + rh > fc->h) rh = fc->h - ry;
+      if (rw <= 0 || rh <= 0) continue;
+      jxo_modimg_add(&im, rw, rh, fc->hshift, fc->vshift);
+      map[nmap++] = c;
+    }
+    if (nmap) {
+      if (jxo_modular_decode(br, &im, 1 + f->num_lf_groups + g, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
+      for (int i = 0; i < nmap; i++) {
+        jxo_chan *fc = &s->gmod.ch[map[i]];
+        int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift;
+        for (int y = 0; y < im.ch[i].h; y++)
+          memcpy(fc->d + (size_t)(ry + y) * (size_t)fc->w + (size_t)rx, im.ch[i].d + (size_t)y * (size_t)im.ch[i].w, 4 * (size_t)im.ch[i].w);
+      }
+    }
+    jxo_modimg_free(&im);
+  }
   if (f->encoding == 0) {
     int nblocks = bw * bh;
     int count = 1 + (int)jxo_bits(br, ceil_log2u((uint32_t)nblocks));

@@ -32,10 +32,12 @@ typedef struct {
 } jxo_wp_header;
 
 enum { JXO_TR_RCT = 0, JXO_TR_PALETTE = 1, JXO_TR_SQUEEZE = 2 };
+typedef struct { unsigned char horizontal, in_place; int begin_c, num_c; } jxo_squeeze_step;
 typedef struct {
   int id;
   int begin_c, rct_type;
   int num_c, nb_colours, nb_deltas, d_pred;
+  int nsq; jxo_squeeze_step sq[48];      /* squeeze (H.6.2): the explicit steps, or the default sequence resolved at meta-apply time */
 } jxo_transform;
 
 typedef struct {

@@ -292,7 +292,90 @@ static int meta_apply(jxo_modimg *img, const jxo_transform *t) {
     modimg_insert(img, 0, t->nb_colours, t->num_c, -1, -1);
     return 0;
   }
-  JXO_FAIL("unsupported: squeeze transform");
+  /* Squeeze (ISO/IEC 18181-1 H.6.2; what libjxl's MetaSqueeze does under JxlDecoderProcessInput, reference call site
+     jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75): every step halves channels [begin_c, begin_c + num_c) along one axis and inserts
+     their residual channels right behind the range (in_place) or at the end of the list. */
+  for (int q = 0; q < t->nsq; q++) {
+    const jxo_squeeze_step *p = &t->sq[q];
+    int b = p->begin_c, e = p->begin_c + p->num_c - 1;
+    if (b < img->nb_meta || e >= img->nch) JXO_FAIL("squeeze: channel range");
+    int offset = p->in_place ? e + 1 : img->nch;
+    for (int c = b; c <= e; c++) {
+      jxo_chan *a = &img->ch[c];
+      int w = a->w, h = a->h, rw = w, rh = h;
+      if (p->horizontal) { a->w = (w + 1) / 2; a->hshift++; rw = w - a->w; } else { a->h = (h + 1) / 2; a->vshift++; rh = h - a->h; }
+      free(a->d); a->d = (int32_t *)calloc((size_t)a->w * (size_t)a->h + 1, sizeof(int32_t));
+      int hs = a->hshift, vs = a->vshift;
+      modimg_insert(img, offset + (c - b), rw, rh, hs, vs);
+    }
+  }
+  return 0;
+}
+
+/* default squeeze sequence (num_sq == 0): chroma-like channels first, then alternate until both sides are <= 8 */
+static void default_squeeze(const jxo_modimg *img, jxo_transform *t) {
+  int first = img->nb_meta, nbc = img->nch - img->nb_meta;
+  int w = img->ch[first].w, h = img->ch[first].h;
+  t->nsq = 0;
+  if (nbc > 2 && img->ch[first + 1].w == w && img->ch[first + 1].h == h) {
+    jxo_squeeze_step p = {1, 0, first + 1, 2};
+    t->sq[t->nsq++] = p; p.horizontal = 0; t->sq[t->nsq++] = p;
+  }
+  jxo_squeeze_step p = {0, 1, first, nbc};
+  if (!(w > h) && h > 8) { p.horizontal = 0; t->sq[t->nsq++] = p; h = (h + 1) / 2; }
+  while ((w > 8 || h > 8) && t->nsq + 2 <= 48) {
+    if (w > 8) { p.horizontal = 1; t->sq[t->nsq++] = p; w = (w + 1) / 2; }
+    if (h > 8) { p.horizontal = 0; t->sq[t->nsq++] = p; h = (h + 1) / 2; }
+  }
+}
+
+static int64_t smooth_tendency(int64_t B, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (B >= a && a >= n) {
+    diff = (4 * B - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (B <= a && a <= n) {
+    diff = (4 * B - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+
+static int inv_squeeze(jxo_modimg *img, const jxo_transform *t) {
+  for (int q = t->nsq - 1; q >= 0; q--) {
+    const jxo_squeeze_step *p = &t->sq[q];
+    int b = p->begin_c, e = p->begin_c + p->num_c - 1;
+    int offset = p->in_place ? e + 1 : img->nch - p->num_c;
+    if (e >= img->nch || offset <= e || offset + p->num_c > img->nch) JXO_FAIL("squeeze: bookkeeping");
+    for (int c = b; c <= e; c++) {
+      jxo_chan *a = &img->ch[c]; const jxo_chan *r = &img->ch[offset + c - b];
+      int ow = p->horizontal ? a->w + r->w : a->w, oh = p->horizontal ? a->h : a->h + r->h;
+      if (p->horizontal ? (r->h != a->h || (r->w != a->w && r->w != a->w - 1)) : (r->w != a->w || (r->h != a->h && r->h != a->h - 1))) JXO_FAIL("squeeze: channel sizes");
+      int32_t *out = (int32_t *)calloc((size_t)ow * (size_t)oh + 1, sizeof(int32_t));
+      int lines = p->horizontal ? a->h : a->w, na = p->horizontal ? a->w : a->h, nr = p->horizontal ? r->w : r->h;
+      for (int i = 0; i < lines; i++) {
+        size_t as = p->horizontal ? 1 : (size_t)a->w, rs = p->horizontal ? 1 : (size_t)r->w, os = p->horizontal ? 1 : (size_t)ow;
+        const int32_t *av = a->d + (p->horizontal ? (size_t)i * (size_t)a->w : (size_t)i), *rv = r->d + (p->horizontal ? (size_t)i * (size_t)r->w : (size_t)i);
+        int32_t *o = out + (p->horizontal ? (size_t)i * (size_t)ow : (size_t)i);
+        int64_t left = 0;
+        for (int k = 0; k < nr; k++) {
+          int64_t A0 = av[(size_t)k * as], nx = k + 1 < na ? av[(size_t)(k + 1) * as] : A0;
+          if (k == 0) left = A0;
+          int64_t diff = (int64_t)rv[(size_t)k * rs] + smooth_tendency(left, A0, nx);
+          int64_t first = A0 + diff / 2, second = first - diff;
+          o[(size_t)(2 * k) * os] = (int32_t)first; o[(size_t)(2 * k + 1) * os] = (int32_t)second;
+          left = second;
+        }
+        if (na > nr) o[(size_t)(2 * nr) * os] = av[(size_t)nr * as];
+      }
+      free(a->d); a->d = out; a->w = ow; a->h = oh;
+      if (p->horizontal) a->hshift--; else a->vshift--;
+    }
+    modimg_erase(img, offset, p->num_c);
+  }
+  return 0;
 }
 
 static int32_t palette_value(const jxo_chan *pal, int index, int c, int bit_depth) {
@@ -387,7 +470,7 @@ static int inv_rct(jxo_modimg *img, const jxo_transform *t) {
 int jxo_modular_undo_transforms(jxo_modimg *img) {
   for (int i = img->ntr - 1; i >= 0; i--) {
     const jxo_transform *t = &img->tr[i];
-    int rc = t->id == JXO_TR_RCT ? inv_rct(img, t) : t->id == JXO_TR_PALETTE ? inv_palette(img, t) : -1;
+    int rc = t->id == JXO_TR_RCT ? inv_rct(img, t) : t->id == JXO_TR_PALETTE ? inv_palette(img, t) : t->id == JXO_TR_SQUEEZE ? inv_squeeze(img, t) : -1;
     if (rc) return rc;
   }
   img->ntr = 0;
@@ -426,7 +509,15 @@ int jxo_modular_decode(jxo_br *br, jxo_modimg *img, int stream_id, int max_chan_
       t->d_pred = (int)jxo_bits(br, 4);
       if (t->d_pred > 13) JXO_FAIL("bad palette predictor");
     } else if (t->id == JXO_TR_SQUEEZE) {
-      JXO_FAIL("unsupported: squeeze transform");
+      int num_sq = (int)jxo_u32(br, -1, 0, 4, 1, 6, 9, 8, 41);
+      if (num_sq > 48) JXO_FAIL("unsupported: more than 48 squeeze steps");
+      t->nsq = num_sq;
+      for (int q = 0; q < num_sq; q++) {
+        t->sq[q].horizontal = (unsigned char)jxo_bool(br); t->sq[q].in_place = (unsigned char)jxo_bool(br);
+        t->sq[q].begin_c = (int)jxo_u32(br, 3, 0, 6, 8, 10, 72, 13, 1096);
+        t->sq[q].num_c = (int)jxo_u32(br, -1, 1, -1, 2, -1, 3, 4, 4);
+      }
+      if (num_sq == 0) { if (img->nch - img->nb_meta < 1) JXO_FAIL("squeeze without channels"); default_squeeze(img, t); }
     } else JXO_FAIL("bad transform id");
     if (br->err) JXO_FAIL("truncated modular header");
     { extern int jxo_debug; if (jxo_debug > 1) fprintf(stderr, "dbg transforms: stream %d id %d begin_c %d rct %d num_c %d nbcol %d\n", stream_id, t->id, t->begin_c, t->rct_type, t->num_c, t->nb_colours); }

@@ -76,13 +76,15 @@ LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x
                   "lo40x24_e7_o5", "lo200x120_e7_o8", "l300x200_g128_e7", "la300x200_g128_e5", "l516x300_g512_e5", "l1030x130_g1024_e3"]
 # lossless cases the DEVICE path decodes: all of them (the *_e1 files are libjxl's effort-1 fast path: prefix codes + LZ77 in every stream; e2 / e5
 # and the *_g* files use Modular group sizes 128 / 512 / 1024)
-# Squeeze (responsive lossless files: default squeeze parameters, local-tree GlobalModular, group streams with channels of mixed shifts).  The C
-# oracle has no squeeze: these are checked against the reference's own output only (golden vectors), on the CPU harness and on the GPU.
+# Squeeze (responsive lossless files: default squeeze parameters, local-tree GlobalModular, group streams with channels of mixed shifts); the C oracle
+# restates it too (jxo_modular.c: meta_apply / inv_squeeze), so these run through the oracle tests as well
 SQUEEZE_LOSSLESS_CASES = ["lr130x300_e7", "lrg300x200_e7", "lra200x150_e5", "lr2100x40_e3"]      # the last one: beyond 2048 px, residual channels in the ModularLfGroup streams
-LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES) + SQUEEZE_LOSSLESS_CASES
+LOSSLESS_CASES = LOSSLESS_CASES + SQUEEZE_LOSSLESS_CASES
+LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
+VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2"]          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).
