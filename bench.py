@@ -110,6 +110,17 @@ def _general_contexts(J, decs):
     return sum(int(f(d._h)) for d in decs)
 
 
+def _lf_retries(J, decs):
+    """(flights decoded twice because the LF table pool of the launch was too small, table pool sizes the contexts ended with)"""
+    import ctypes as C
+    f = J.api.lib().jxlamd_debug_lf_retries
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 3)]
+    tot, pools = 0, []
+    for d in decs:
+        o = (C.c_uint32 * 3)(); f(d._h, C.byref(o)); tot += int(o[0]); pools.append(int(o[2]))
+    return tot, pools
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -423,7 +434,7 @@ def main():
                                    "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "
                                    "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
                        "h2d_included_MPps": round(h2d_steps * B * world * mp / elapsed_h2d, 2), "h2d_included_steps": h2d_steps, "distinct_frames": len(datas),
-                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "retried_flights": int(kern.get("retried_flights", 0)),
+                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "flights_repeated_for_lf_pool": _lf_retries(J, decs)[0], "lf_pool_bytes": sorted(set(_lf_retries(J, decs)[1])), "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective"},

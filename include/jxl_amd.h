@@ -133,6 +133,9 @@ int jxlamd_debug_lf_phases_frame(jxlamd_decoder *dec, int frame, int num_lf_grou
 /* 1 once a frame of this context needed the LF kernel build with the general lock-step loops (decoded again with it, and every later
  * decode of the context uses it): the lean build covers libjxl's LF-coefficient and HF-metadata streams. */
 int jxlamd_debug_lf_general(const jxlamd_decoder *dec);
+/* out[0]: decodes / flights of this context that ran a second time because the LF table pool was too small (kErrNeedPool), out[1]: ... because
+ * a stream needed the general build, out[2]: the pool (bytes) the next LF launch will get. */
+int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Post-decode stages of the reference's JNI layer, on buffers that stay in HBM.

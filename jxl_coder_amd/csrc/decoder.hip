@@ -60,6 +60,8 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
 
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 // internal return code: the lean LF kernel met a channel that needs a general lock-step loop (kErrNeedGeneral) — decode again with the general build
+// what one decoder context learnt about the frames of this process serves the others (contexts of a service see the same kind of content)
+static std::atomic<int> g_lf_pool_floor{0};
 static constexpr int kRetryGeneral = 0x7e7e;
 // ... or a channel whose packed tables did not fit the LDS table pool this launch was sized with (kErrNeedPool): decode again with the largest
 static constexpr int kRetryPool = 0x7e7f;
@@ -234,7 +236,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   HIPCHECK(hipMemcpyAsync(&end_bit, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
-  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
@@ -299,9 +301,9 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   HIPCHECK(hipGetLastError());
   (void)flags;
   derr = head[0];
-  if (!S.plan.modular) lf_pool_bytes = std::max(lf_pool_floor, lf_pool_clamp(head[1]));
+  if (!S.plan.modular) lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(head[1]));
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
-  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = std::max(lf_pool_floor, lf_pool_clamp(head[1])); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
@@ -310,9 +312,9 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
 
 int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
   int rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
-  if (rc0 == kRetryPool) rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);       // with the largest table pool
+  if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info); }       // with the largest table pool
   if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
-  lf_general = true;
+  lf_general = true; general_retries++;
   return decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
 }
 
@@ -381,9 +383,9 @@ std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  if (rc0 == kRetryPool) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);   // with the largest table pool
+  if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos); }   // with the largest table pool
   if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
-  lf_general = true;                       // some frame needs a general lock-step loop: this context runs the general LF build from now on
+  lf_general = true; general_retries++;     // some frame needs a general lock-step loop: this context runs the general LF build from now on
   return decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
 }
 
@@ -572,7 +574,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const int JXL_ABLATE = (JXL_ABLATE_MASK && ++ablate_flights > 2) ? JXL_ABLATE_MASK : 0;
   if (!(JXL_ABLATE & 1)) launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, lf_pool_bytes, lf_general, stream);
+  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_general, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   if (!(JXL_ABLATE & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
@@ -615,9 +617,11 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
   }
-  if (need_pool) { lf_pool_floor = std::max(lf_pool_floor, std::min((int)kModPoolBytes, lf_pool_clamp(pool_want) + 3 * 1280)); lf_pool_bytes = kModPoolBytes; return kRetryPool; }      // + three clusters of headroom: the next frames' streams differ by a cluster or two
+  // one miss is enough evidence that this context's frames vary: it keeps the largest pool from here on (a repeated flight costs more than a
+  // fourth LF stream per CU gains; measured on 256 distinct frames: wanted pools 12 .. 25 KB, 8 % of the flights repeated with a creeping floor)
+  if (need_pool) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   coef_pool_clean = first_rc == JXLAMD_OK;
-  lf_pool_bytes = std::max(lf_pool_floor, lf_pool_clamp(pool_want));
+  lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
@@ -879,6 +883,11 @@ int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) 
 }
 
 int jxlamd_debug_lf_general(const jxlamd_decoder *dec) { return dec && dec->lf_general ? 1 : 0; }
+int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]) {
+  if (!dec || !out) return JXLAMD_ERR_BUFFER;
+  out[0] = dec->pool_retries; out[1] = dec->general_retries; out[2] = (uint32_t)dec->lf_pool_bytes;
+  return JXLAMD_OK;
+}
 int jxlamd_debug_lf_phases_frame(jxlamd_decoder *d, int frame, int num_lf_groups, uint64_t *out) {     // frame = slot index inside the last flight
   if (!d || frame < 0 || (size_t)frame >= d->slots.size() || !d->slots[(size_t)frame]->misc.p) return JXLAMD_ERR_DEVICE;
   FrameSlot &S = *d->slots[(size_t)frame];

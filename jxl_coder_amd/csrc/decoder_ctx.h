@@ -115,6 +115,7 @@ struct jxlamd_decoder {
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
   int flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 4096;   // groups in a flight / band from which the lane-per-group kernel takes over from the wave-per-group one (test hook: 1 forces it)
   float timing[5] = {0, 0, 0, 0, 0};
+  uint32_t pool_retries = 0, general_retries = 0;   // decodes / flights run a second time (kErrNeedPool / kErrNeedGeneral)
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)
   bool lf_general = false;               // the LF kernel build with the general lock-step loops (set for good the first time a frame of this context needs one)
   int lf_pool_bytes = kModPoolBytes;      // LDS table pool of the next LF launch: what the streams of the previous decode of this context asked for (first decode: the largest)

@@ -9,7 +9,8 @@ except Exception as e: print(sys.argv[2], "failed", e)
 PY
 }
 run 16 16 64
-run 32 32 32
-run 24 24 40
-run 32 16 64
-run 32 32 16
+run 16 12 96
+run 16 10 128
+run 16 16 48
+run 20 20 48
+run 16 16 64
