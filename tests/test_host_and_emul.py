@@ -195,7 +195,7 @@ def test_corrupted_streams_never_crash_the_device_code(emul):
     import random
     rnd = random.Random(20260928)
     decoded = rejected = 0
-    for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7"):
+    for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7", "lra200x150_e5", "va400x300_e7_d2", "asset_animated"):      # the last three: squeeze, squeezed alpha, frame walk + crop (round 3: 1 620 variants of nine such files clean under AddressSanitizer)
         d0 = load_case(name)[0]
         for it in range(40):
             d = bytearray(d0)
