@@ -114,6 +114,23 @@ def test_jxlcoder_surface(dec):
     assert J.JxlCoder.getSize(data) == (256, 256)
 
 
+def test_batch_of_round3_kinds_equals_single_decodes(dec):
+    """Flights with the kinds of files round 3 added: squeezed alpha (VarDCT), responsive lossless RGBA, Modular group sizes 128 / 1024, a
+    Modular frame with ModularLfGroup streams (beyond 2048 px... of an LF group: 2100 px), the 48-frame animation (cropped last frame over the
+    cleared canvas) and jxl-art — each output equals the single decode bit for bit, twice (buffers reused)."""
+    import torch
+    names = ["va400x300_e7_d2", "lra200x150_e5", "l300x200_g128_e7", "asset_animated", "lr2100x40_e3", "v264x520_e7", "l1030x130_g1024_e3", "asset_art", "va2300x700_e7_d3"]
+    datas = [open(os.path.join(ROOT, "tests", "golden", n + ".jxl"), "rb").read() for n in names]
+    singles = [dec.decode_one_shot(d)[0] for d in datas]
+    for rep in range(2):
+        outs = [torch.full((s.size,), 0x5A, dtype=torch.uint8, device="cuda") for s in singles]
+        torch.cuda.synchronize()
+        dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for n, s_, o in zip(names, singles, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
+
+
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
