@@ -172,7 +172,7 @@ def test_entropy_kernels_use_no_scratch():
     J.build()
     checked = 0
     with tempfile.TemporaryDirectory() as tmp:
-        for tu in ("kernels_lf", "kernels_mod", "kernels_pass", "kernels_recon", "kernels_filter", "post", "resample"):
+        for tu in ("kernels_lf", "kernels_lf_general", "kernels_lf_general_b", "kernels_mod", "kernels_pass", "kernels_recon", "kernels_filter", "post", "resample"):
             obj = os.path.join(ROOT, "jxl_coder_amd", "build", tu + ".hip.o")
             fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "co.o")
             subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
