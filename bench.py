@@ -212,10 +212,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
     args = ap.parse_args()
     c5 = args.workload == "c5"
-    if c5:                      # 16-bit outputs + F16 destinations: smaller flights / fewer contexts than the RGBA8 batch (HBM), 64 frames per step
+    if c5:                      # 16-bit outputs + F16 destinations: smaller flights than the RGBA8 batch (HBM), 64 frames per step
         argv = " ".join(sys.argv[1:])
         if "--batch" not in argv: args.batch = 64
-        if "--contexts" not in argv: args.contexts = 8
+        if "--contexts" not in argv: args.contexts = 16         # (8 contexts: 2 680 MP/s, 12 or 16: 3 200; flights below 4 096 groups — 24 frames — take the wave-per-group PassGroup kernel: 1 670)
         if "--inflight" not in argv: args.inflight = 32
         if "--distinct" not in argv: args.distinct = 64
 
