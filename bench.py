@@ -215,7 +215,7 @@ def main():
     if c5:                      # 16-bit outputs + F16 destinations: smaller flights than the RGBA8 batch (HBM), 64 frames per step
         argv = " ".join(sys.argv[1:])
         if "--batch" not in argv: args.batch = 64
-        if "--contexts" not in argv: args.contexts = 16         # (8 contexts: 2 680 MP/s, 12 or 16: 3 200; flights below 4 096 groups — 24 frames — take the wave-per-group PassGroup kernel: 1 670)
+        if "--contexts" not in argv: args.contexts = 16         # (8 contexts: 2 680 MP/s, 12 or 16: 3 200; flights of 16 or 24: 1 670 - 1 790 while the flat PassGroup kernel started at 4 096 groups, 2 770 since it starts at 1 024)
         if "--inflight" not in argv: args.inflight = 32
         if "--distinct" not in argv: args.distinct = 64
 

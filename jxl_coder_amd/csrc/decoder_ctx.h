@@ -113,7 +113,13 @@ struct jxlamd_decoder {
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
-  int flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 4096;   // groups in a flight / band from which the lane-per-group kernel takes over from the wave-per-group one (test hook: 1 forces it)
+  // Groups in a (sub-)flight from which the lane-per-group kernel (k_pass_prep + k_pass_flat: ~100 ms of latency whatever the size, 17 M VALU
+  // per 4K frame) takes over from the wave-per-group one (20 ms alone, 285 M VALU per frame: throughput-bound as soon as several contexts
+  // run it).  Measured with 16 contexts (tools/gpu/run_flatmin.sh): flights of 8 / 16 / 24 4K frames 3 750 -> 4 800, 4 660 -> 8 180,
+  // 4 750 -> 10 360 MP/s with the flat kernel.  JXLAMD_FLAT_MIN_GROUPS: test hook (1 forces it everywhere).
+  int flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 1024;
+  // ... and in a band of one frame (config 4: eight concurrent bands of 2 048 groups reconstruct in 33 - 36 ms each with the wave-per-group kernel)
+  int band_flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
   uint32_t pool_retries = 0, general_retries = 0;   // decodes / flights run a second time (kErrNeedPool / kErrNeedGeneral)
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)
