@@ -58,6 +58,8 @@ enum {
 #define JXLAMD_NO_SIZE_GUARD 4u   /* skip the INT32_MAX guard (BASELINE config 4: 32768^2 below the Bitmap layer) */
 #define JXLAMD_IN_DEVICE 8u       /* `jxl_dev` passed to jxlamd_decode_resident holds the same bytes in HBM (any alignment, no padding needed:
                                      the decoder copies them device-to-device into its own padded stream buffer) */
+#define JXLAMD_BAND_SHARED_GPU 16u /* jxlamd_band_begin: other bands of the frame are decoded on this GPU at the same time (several decoder contexts): the band's
+                                     PassGroup stage takes the lane-per-group kernel from 1 024 groups on (throughput) instead of 4 096 (latency of a lone band) */
 
 jxlamd_decoder *jxlamd_decoder_create(int device);        /* NULL if the HIP device cannot be opened */
 void jxlamd_decoder_destroy(jxlamd_decoder *dec);

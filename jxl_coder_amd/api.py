@@ -73,7 +73,7 @@ class RescaleInfo(C.Structure):                # jxlamd_rescale_info
 
 FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
 
-JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE = 1, 2, 4, 8
+JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE, JXLAMD_BAND_SHARED_GPU = 1, 2, 4, 8, 16
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
 SOURCES = ["kernels_lf.hip", "kernels_lf_general.hip", "kernels_lf_general_b.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp", "host_icc_lut.cpp"]
@@ -323,8 +323,8 @@ class JxlDecoder:
         return ri
 
     # ---- band-sharded decode of one frame (include/jxl_amd.h "Band-sharded decode"; jxl_coder_amd/shard.py drives it)
-    def band_begin(self, data: bytes, group_row0: int, group_row1: int, out_ptr: int, out_capacity: int, allowed_floats=True):
-        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE
+    def band_begin(self, data: bytes, group_row0: int, group_row1: int, out_ptr: int, out_capacity: int, allowed_floats=True, shared_gpu=False):
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE | (JXLAMD_BAND_SHARED_GPU if shared_gpu else 0)
         info = Info()
         rc = lib().jxlamd_band_begin(self._h, data, len(data), flags, group_row0, group_row1, out_ptr, out_capacity, C.byref(info))
         if rc:

@@ -88,7 +88,7 @@ def exchange_halos(bands, kind: int, nbands: int, rank: int, world: int, group=N
 class DeviceBand:
     """One band of a frame on this rank's GPU: a decoder context + its output rows + halo buffers (all HBM-resident)."""
 
-    def __init__(self, decoder, data: bytes, rows, width: int, height: int, bytes_per_pixel: int, device, out=None, begin=True):
+    def __init__(self, decoder, data: bytes, rows, width: int, height: int, bytes_per_pixel: int, device, out=None, begin=True, shared_gpu=False):
         import torch
         self.dec, self.rows, self.data = decoder, rows, data
         self.py0, self.py1 = rows[0] * 256, min(rows[1] * 256, height)
@@ -98,12 +98,13 @@ class DeviceBand:
         self._bufs = {}
         self.device = device
         self.info = None
+        self.shared_gpu = shared_gpu        # other bands of the frame run on this GPU at the same time (JXLAMD_BAND_SHARED_GPU)
         if begin:
             self.begin()
 
     def begin(self):
         """parse + upload + LF stage of the band (returns when done; bands of one GPU call this from one thread each)"""
-        self.info = self.dec.band_begin(self.data, self.rows[0], self.rows[1], self.out.data_ptr(), self.out.numel())
+        self.info = self.dec.band_begin(self.data, self.rows[0], self.rows[1], self.out.data_ptr(), self.out.numel(), shared_gpu=self.shared_gpu)
 
     def _buffer(self, kind, slot):
         import torch
@@ -175,7 +176,7 @@ def decode_sharded(data: bytes, nbands=None, rank: int = 0, world: int = 1, devi
         key = (device, k)
         if key not in _contexts:
             _contexts[key] = api.JxlDecoder(device)
-        bands[b] = DeviceBand(_contexts[key], data, rows[b], w, h, bpp, dev, out=outs[k] if outs else None, begin=False)
+        bands[b] = DeviceBand(_contexts[key], data, rows[b], w, h, bpp, dev, out=outs[k] if outs else None, begin=False, shared_gpu=len(mine) > 1)
     # every phase of the protocol: the bands this GPU holds side by side (one decoder context + host thread each), then the halo step.
     # (The pixel halo is produced by the reconstruction of the band's border groups, i.e. by the phase it follows: there is no interior
     # work left to overlap it with — PassGroup decode and inverse DCT of ALL groups precede the filters; the messages are 1.2 MB.)
