@@ -13,6 +13,7 @@
 // on the same GPU, hands one context's export straight to its neighbour's import.
 // The reference has no counterpart (libjxl decodes a frame in one process); the boundary it sits under is the size guard of
 // DecodeJpegXlOneShot (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:103-109): a band is smaller than a Bitmap.
+#include <chrono>
 #include "decoder_ctx.h"
 
 namespace {
@@ -26,8 +27,12 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   FrameSlot &S = slot(0);
   S.band_stage = 0;
   const int rows[2] = {gr0, gr1};
+  static const bool trace = getenv("JXLAMD_TRACE_BANDS") && atoi(getenv("JXLAMD_TRACE_BANDS"));      // host wall-clock split of band_begin on stderr
+  const auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
   int rc = prepare(S, jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out_ptr, out_cap, info, false, true, rows);
   if (rc) return rc;
+  const double t_prepared = now();
   const BandGeom &q = S.band;
   // the band runs the flight kernels over a one-frame array: DevBuffers, DevAux and the (frame 0, group) maps of its LF groups / groups
   std::vector<int> maps;
@@ -47,10 +52,19 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_lf_groups_batch(bandtab.dB, bandtab.dA, bandtab.lf_map, q.nlfg, lf_pool_bytes, /*general=*/true, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
-  uint32_t derr = 0;
-  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  // (into page-locked memory: a device-to-host copy into pageable memory is synchronous inside the runtime and kept the other bands' host
+  // threads — eight decoder contexts of one process — out of their own enqueue calls for as long as this band's kernels ran)
+  HIPCHECK(h_flags.ensure(256));
+  HIPCHECK(hipMemcpyAsync(h_flags.p, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  const double t_launched = now();
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
+  const uint32_t derr = *(const uint32_t *)h_flags.p;
+  if (trace) {
+    float lf_ms = 0; (void)hipEventElapsedTime(&lf_ms, ev[0], ev[1]);
+    fprintf(stderr, "[band %d-%d] parse + buffers + uploads queued %.1f ms, launch %.1f ms, wait %.1f ms (LF kernel %.1f ms on the device)\n", gr0, gr1, t_prepared - t_begin, t_launched - t_prepared,
+            now() - t_launched, lf_ms);
+  }
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup of a band)"); return dev_err_class(derr); }
   S.band_stage = 1;
   return JXLAMD_OK;
@@ -127,10 +141,11 @@ int jxlamd_decoder::band_reconstruct() {
   HIPCHECK(hipEventRecord(ev[2], stream));
   launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream);
   HIPCHECK(hipEventRecord(ev[3], stream));
-  uint32_t derr = 0;
-  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(h_flags.ensure(256));
+  HIPCHECK(hipMemcpyAsync(h_flags.p, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
+  const uint32_t derr = *(const uint32_t *)h_flags.p;
   if (derr) { S.band_stage = 0; set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", band)"); return dev_err_class(derr); }
   S.band_stage = 2;
   return JXLAMD_OK;

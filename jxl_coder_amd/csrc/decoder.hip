@@ -104,7 +104,11 @@ BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
 int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info,
                             bool parsed, bool own_planes, const int *band_rows) {
   FramePlan &plan = S.plan;
+  static const bool trace_prep = getenv("JXLAMD_TRACE_BANDS") && atoi(getenv("JXLAMD_TRACE_BANDS"));
+  const auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tp0 = now_ms();
   if (!parsed) { plan = FramePlan(); (void)plan_parse(jxl, size, &plan); }
+  const double tp1 = now_ms();
   if (!plan.error.empty() || plan.tables.empty()) { set_error(plan.error); return err_class(plan.error); }
   fill_public_info(plan.info, flags, &S.pi);
   if (info) *info = S.pi;
@@ -142,7 +146,28 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (!in_flight) {
     HIPCHECK(S.cs.ensure(plan.cs_size + 64));
     if (cs_resident) HIPCHECK(hipMemcpyAsync(S.cs.p, S.up_cs_dev, plan.cs_size, hipMemcpyDeviceToDevice, stream));
-    else {
+    else if (band_rows && Fh->nsec > 1) {
+      // A band only reads the sections of its own LF groups and PassGroups: stage and upload those byte ranges (at their codestream offsets:
+      // the kernels keep addressing sections by absolute offset) instead of the whole file — for the 32768 x 32768 frame of config 4 a band of
+      // an eighth of the rows moves ~20 MB instead of 157 MB through page-locked memory and PCIe, and eight bands did that side by side.
+      const DevSection *secs = (const DevSection *)(plan.tables.data() + Fh->sec_off);
+      std::vector<std::pair<size_t, size_t>> need;                      // [begin, end) byte ranges, + 64 bytes the bit reader may look ahead
+      const auto add = [&](int si) { if (si >= 0 && si < Fh->nsec && secs[si].size) need.push_back({secs[si].off, std::min<size_t>(plan.cs_size, (size_t)secs[si].off + secs[si].size + 64)}); };
+      for (int g = q.lfg0; g < q.lfg0 + q.nlfg; g++) add(1 + g);
+      for (int p = 0; p < Fh->num_passes; p++) for (int g = q.g0; g < q.g0 + q.ng; g++) add(2 + Fh->num_lf_groups + p * Fh->num_groups + g);
+      std::sort(need.begin(), need.end());
+      std::vector<std::pair<size_t, size_t>> runs;
+      for (const auto &r : need) { if (!runs.empty() && r.first <= runs.back().second + 4096) runs.back().second = std::max(runs.back().second, r.second); else runs.push_back(r); }
+      size_t total = 0;
+      for (const auto &r : runs) total += r.second - r.first;
+      HIPCHECK(S.h_cs.ensure(total + 64));
+      size_t at = 0;
+      for (const auto &r : runs) {
+        memcpy((uint8_t *)S.h_cs.p + at, plan.cs + r.first, r.second - r.first);
+        HIPCHECK(hipMemcpyAsync((uint8_t *)S.cs.p + r.first, (uint8_t *)S.h_cs.p + at, r.second - r.first, hipMemcpyHostToDevice, stream));
+        at += r.second - r.first;
+      }
+    } else {
       HIPCHECK(S.h_cs.ensure(plan.cs_size));
       memcpy(S.h_cs.p, plan.cs, plan.cs_size);
       HIPCHECK(hipMemcpyAsync(S.cs.p, S.h_cs.p, plan.cs_size, hipMemcpyHostToDevice, stream));
@@ -155,6 +180,8 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     memcpy(S.h_tables.p, plan.tables.data(), plan.tables.size());
     HIPCHECK(hipMemcpyAsync(S.tables.p, S.h_tables.p, plan.tables.size(), hipMemcpyHostToDevice, stream));
   }
+  const double tp2 = now_ms();
+  if (trace_prep && band_rows) fprintf(stderr, "[prepare band %d] parse %.1f ms, codestream + tables staging and upload calls %.1f ms (tables %zu B, cs_owned %zu B)\n", band_rows[0], tp1 - tp0, tp2 - tp1, plan.tables.size(), plan.cs_owned.size());
   if (!plan.modular) {
     for (int i = 0; i < 5; i++) HIPCHECK(S.cells8[i].ensure(ncell));
     for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
@@ -233,9 +260,11 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
 // single-section frames: HfGlobal follows LfGroup 0 in the same section; its bit position is only known after the LF kernel
 int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   uint64_t end_bit = 0; uint32_t derr = 0;
-  HIPCHECK(hipMemcpyAsync(&end_bit, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
-  HIPCHECK(hipMemcpyAsync(&derr, S.B.err, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(h_flags.ensure(256));
+  HIPCHECK(hipMemcpyAsync(h_flags.p, S.A.lf_end_bits, 8, hipMemcpyDeviceToHost, stream));
+  HIPCHECK(hipMemcpyAsync((uint8_t *)h_flags.p + 8, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
+  memcpy(&end_bit, h_flags.p, 8); memcpy(&derr, (uint8_t *)h_flags.p + 8, 4);
   if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
@@ -295,11 +324,13 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
 int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   uint32_t derr = 0;
   uint32_t head[20] = {0};                              // flags word and, at byte 64, the size-class block counters
-  HIPCHECK(hipMemcpyAsync(head, S.B.err, sizeof(head), hipMemcpyDeviceToHost, stream));
+  HIPCHECK(h_flags.ensure(256));                        // page-locked: a copy into pageable memory is synchronous inside the runtime (see band.hip)
+  HIPCHECK(hipMemcpyAsync(h_flags.p, S.B.err, sizeof(head), hipMemcpyDeviceToHost, stream));
   if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
   (void)flags;
+  memcpy(head, h_flags.p, sizeof(head));
   derr = head[0];
   if (!S.plan.modular) lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(head[1]));
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients

@@ -351,7 +351,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   uint8_t *cs; size_t csn; int owned;
   if (extract_codestream(data, size, &cs, &csn, &owned)) { plan->error = hx_last_error(); return -1; }
   if (owned) { plan->cs_owned.assign(cs, cs + csn); free(cs); plan->cs = plan->cs_owned.data(); }
-  else plan->cs = data;
+  else plan->cs = cs;                                   /* the bare codestream, or the one codestream box of a container, in place */
   plan->cs_size = csn;
   std::shared_ptr<Priv> pvs = std::make_shared<Priv>();
   plan->priv = pvs;

@@ -180,9 +180,20 @@ def decode_sharded(data: bytes, nbands=None, rank: int = 0, world: int = 1, devi
     # every phase of the protocol: the bands this GPU holds side by side (one decoder context + host thread each), then the halo step.
     # (The pixel halo is produced by the reconstruction of the band's border groups, i.e. by the phase it follows: there is no interior
     # work left to overlap it with — PassGroup decode and inverse DCT of ALL groups precede the filters; the messages are 1.2 MB.)
+    import os, time
+    trace = os.environ.get("JXLAMD_TRACE_BANDS")
+    t0 = time.perf_counter()
     run_concurrently(lambda b: bands[b].begin(), mine)                              # parse + LF stage
+    t1 = time.perf_counter()
     exchange_halos(bands, HALO_LF, nbands, rank, world, group)
+    t2 = time.perf_counter()
     run_concurrently(lambda b: bands[b].dec.band_reconstruct(), mine)
+    t3 = time.perf_counter()
     exchange_halos(bands, HALO_PIXELS, nbands, rank, world, group)
+    t4 = time.perf_counter()
     run_concurrently(lambda b: bands[b].dec.band_finish(), mine)
+    if trace:
+        t5 = time.perf_counter()
+        print("[bands rank %d] begin %.1f | LF halos %.1f | reconstruct %.1f | pixel halos %.1f | finish %.1f ms" % (
+            rank, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3), flush=True)
     return [(bands[b].py0, bands[b].py1, bands[b].out) for b in mine]
