@@ -89,6 +89,34 @@ def test_device_resident_io_matches_host_io(dec):
     assert np.array_equal(d_out.cpu().numpy().reshape(out.shape), out)
 
 
+def test_device_resident_container_files_are_read_in_place(dec):
+    """A container with one codestream box is parsed in place (host_format.inc: extract_codestream), so with JXLAMD_IN_DEVICE the kernels read
+    the caller's resident bytes at the box's payload offset — here an odd one — in a single decode and in a flight."""
+    import torch
+    names = ["v264x520_e7", "l200x120_e7", "v300x300_e7_d3"]
+    head = b"\x00\x00\x00\x0cJXL \x0d\x0a\x87\x0a" + (20).to_bytes(4, "big") + b"ftypjxl \x00\x00\x00\x00jxl "
+    blobs, singles = [], []
+    for k, n in enumerate(names):
+        data = load_case(n)[0]
+        assert data[:2] == b"\xff\x0a"
+        pad = (8 + 2 * k + 1).to_bytes(4, "big") + b"Exif" + b"\x00" * (2 * k + 1)              # 1, 3, 5 bytes: the codestream starts at an odd offset
+        blobs.append(head + pad + (8 + len(data)).to_bytes(4, "big") + b"jxlc" + data)
+        singles.append(dec.decode_one_shot(data)[0])
+    d_ins = [torch.frombuffer(bytearray(b) + bytearray(64), dtype=torch.uint8).cuda() for b in blobs]
+    outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+    torch.cuda.synchronize()
+    dec.decode_to_device(blobs[0], outs[0].data_ptr(), outs[0].numel(), data_dev_ptr=d_ins[0].data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0].cpu().numpy().reshape(singles[0].shape), singles[0])
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    dec.decode_batch_to_device(blobs, [o.data_ptr() for o in outs], [o.numel() for o in outs], data_dev_ptrs=[d.data_ptr() for d in d_ins])
+    torch.cuda.synchronize()
+    for s, o in zip(singles, outs):
+        assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+
+
 def test_errors_are_loud(dec):
     import jxl_coder_amd as J
     data, _ = load_case("v264x520_e7")

@@ -52,6 +52,45 @@ def test_isjxl_and_invalid_inputs(built):
         J.JxlCoder.getSize(data[:3])
 
 
+def _box(ty, payload, wide=False, to_eof=False):
+    if to_eof:
+        return (0).to_bytes(4, "big") + ty + payload
+    if wide:
+        return (1).to_bytes(4, "big") + ty + (16 + len(payload)).to_bytes(8, "big") + payload
+    return (8 + len(payload)).to_bytes(4, "big") + ty + payload
+
+
+def test_container_layouts_decode_to_the_same_pixels(emul):
+    """ISO 18181-2 boxes around ONE codestream: a single jxlc / jxlp box is parsed in place (host_format.inc: extract_codestream — no copy of
+    the codestream per parse), several jxlp parts are assembled; the reference reads all of them through libjxl (JxlDecoding.cpp:46-171)."""
+    data, _ = load_case("v264x520_e7")
+    assert data[:2] == b"\xff\x0a"                                       # a bare codestream
+    want = emul(data)
+    head = b"\x00\x00\x00\x0cJXL \x0d\x0a\x87\x0a" + _box(b"ftyp", b"jxl \x00\x00\x00\x00jxl ")
+    cut = len(data) // 3
+    layouts = {
+        "jxlc": head + _box(b"jxlc", data),
+        "jxlc, 64-bit box size": head + _box(b"jxlc", data, wide=True),
+        "jxlc to the end of the file": head + _box(b"jxlc", data, to_eof=True),
+        "other boxes around jxlc": head + _box(b"Exif", b"\x00" * 37) + _box(b"jxlc", data) + _box(b"xml ", b"<x/>"),
+        "one jxlp": head + _box(b"jxlp", b"\x80\x00\x00\x00" + data),
+        "two jxlp": head + _box(b"jxlp", b"\x00\x00\x00\x00" + data[:cut]) + _box(b"Exif", b"\x01" * 5)
+                    + _box(b"jxlp", b"\x80\x00\x00\x01" + data[cut:]),
+        "three jxlp, the last to the end of the file": head + _box(b"jxlp", b"\x00\x00\x00\x00" + data[:7]) + _box(b"jxlp", b"\x00\x00\x00\x01" + data[7:cut], wide=True)
+                    + _box(b"jxlp", b"\x80\x00\x00\x02" + data[cut:], to_eof=True),
+    }
+    for what, blob in layouts.items():
+        assert J.JxlCoder.isJXL(blob), what
+        assert J.JxlCoder.getSize(blob) == J.JxlCoder.getSize(data), what
+        assert np.array_equal(emul(blob), want), what
+    for what, blob in {"no codestream box": head + _box(b"Exif", b"\x00" * 9),
+                       "box longer than the file": head + (len(data) + 4000).to_bytes(4, "big") + b"jxlc" + data,
+                       "box shorter than its header": head + (4).to_bytes(4, "big") + b"jxlc" + data,
+                       "jxlp without its index": head + _box(b"jxlp", b"\x80\x00")}.items():
+        with pytest.raises((J.InvalidJXLException, ValueError)):
+            J.JxlCoder.getSize(blob)
+
+
 def test_preconditions_mirror_reference(built):
     data, _ = load_case("v64_e3_gab0_epf0")
     with pytest.raises(ValueError):
