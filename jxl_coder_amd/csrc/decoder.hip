@@ -622,8 +622,18 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
+    hipStream_t rest_stream = stream;
+    if (stream_dp) {                       // the rest of this sub-flight follows its entropy stages on the other stream ...
+      HIPCHECK(hipEventRecord(ev_split[0], stream));
+      HIPCHECK(hipStreamWaitEvent(stream_dp, ev_split[0], 0));
+      rest_stream = stream_dp;
+    }
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      if ((JXL_ABLATE & 12) != 12) launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3 & ~((JXL_ABLATE >> 2) & 3), stream);
+      if ((JXL_ABLATE & 12) != 12) launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3 & ~((JXL_ABLATE >> 2) & 3), rest_stream);
+    if (stream_dp) {                       // ... and the next sub-flight's PassGroups (same coefficient planes), or the end of the flight, follow it
+      HIPCHECK(hipEventRecord(ev_split[1], stream_dp));
+      HIPCHECK(hipStreamWaitEvent(stream, ev_split[1], 0));
+    }
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
@@ -691,7 +701,22 @@ jxlamd_decoder *jxlamd_decoder_create(int device) {
   }
   jxlamd_decoder *d = new jxlamd_decoder();
   d->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess) { g_tls_error = "cannot open HIP device"; delete d; return nullptr; }
+  // JXLAMD_ENTROPY_CUS=N (experiment): a context's entropy stages (serial rANS chains, one wave or lane per stream) on the first
+  // N compute units, the data-parallel stages of its flights (dequantise + IDCT, filters, colour) on the others, each through its own stream
+  const char *split = getenv("JXLAMD_ENTROPY_CUS");
+  const int n_ent = split ? atoi(split) : 0;
+  hipDeviceProp_t prop;
+  if (n_ent > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_ent < prop.multiProcessorCount) {
+    const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+    std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
+    for (int i = 0; i < cus; i++) (i < n_ent ? ma : mb)[(size_t)i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&d->stream, (uint32_t)words, ma.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&d->stream_dp, (uint32_t)words, mb.data()) != hipSuccess) {
+      g_tls_error = "cannot create CU-masked streams"; delete d; return nullptr;
+    }
+    for (auto &e : d->ev_split) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  } else if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
     g_tls_error = "cannot open HIP device"; delete d; return nullptr;
   }
   for (auto &e : d->ev) (void)hipEventCreate(&e);
@@ -705,6 +730,7 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   for (FrameSlot *fs : d->slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
+  if (d->stream_dp) { (void)hipStreamDestroy(d->stream_dp); for (auto &e : d->ev_split) (void)hipEventDestroy(e); }
   delete d;
 }
 

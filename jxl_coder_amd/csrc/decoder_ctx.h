@@ -101,6 +101,8 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_dp = nullptr;      // JXLAMD_ENTROPY_CUS=N: flights run their data-parallel stages here, on the CUs the entropy stages do not use
+  hipEvent_t ev_split[2] = {};
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
