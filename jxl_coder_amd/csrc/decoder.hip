@@ -716,6 +716,16 @@ jxlamd_decoder *jxlamd_decoder_create(int device) {
       g_tls_error = "cannot create CU-masked streams"; delete d; return nullptr;
     }
     for (auto &e : d->ev_split) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  } else if (getenv("JXLAMD_ENTROPY_PRIORITY") && atoi(getenv("JXLAMD_ENTROPY_PRIORITY")) > 0) {
+    // JXLAMD_ENTROPY_PRIORITY=1 (experiment): the same two streams without CU masks — the entropy stages' queue at the highest dispatch
+    // priority, the data-parallel stages' at the lowest: an LF workgroup wants 33 - 52 KB of one CU's LDS in one piece, next to a flood of 8 - 17 KB workgroups
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&d->stream_dp, hipStreamNonBlocking, lo) != hipSuccess) {
+      g_tls_error = "cannot create prioritised streams"; delete d; return nullptr;
+    }
+    for (auto &e : d->ev_split) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
   } else if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
     g_tls_error = "cannot open HIP device"; delete d; return nullptr;
   }

@@ -4,7 +4,10 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmc; mkdir -p $O
 cd /tmp
-for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
+SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE")
+# PMC_SETS="a b;c d": other counter sets, one pass each
+if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; fi
+for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pmc_$tag
   PYTHONPATH=$R timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_$tag -o p -- python $R/tools/prof_decode.py 2 > /tmp/pmc_$tag.log 2>&1
