@@ -178,7 +178,7 @@ extern "C" {
 int jxlamd_band_begin(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t flags, int group_row0, int group_row1, void *out, size_t cap,
                       jxlamd_info *info) {
   if (!d) { tls_error() = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  return d->band_begin(jxl, size, flags, group_row0, group_row1, out, cap, info);
+  return jxlamd_guarded(d, [&]() -> int { return d->band_begin(jxl, size, flags, group_row0, group_row1, out, cap, info); });
 }
 int jxlamd_band_halo_bytes(jxlamd_decoder *d, int kind, size_t *bytes) { return d ? d->band_halo_bytes(kind, bytes) : JXLAMD_ERR_DEVICE; }
 int jxlamd_band_export(jxlamd_decoder *d, int kind, int side, void *dev_buf, size_t cap) { return d ? d->band_export(kind, side, dev_buf, cap) : JXLAMD_ERR_DEVICE; }

@@ -344,7 +344,8 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
 int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
   int rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
   if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info); }       // with the largest table pool
-  if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
+  if (rc0 == kRetryPool) { set_error("LF table pool: the stream asked for a larger pool twice"); return JXLAMD_ERR_DEVICE; }
+  if (rc0 != kRetryGeneral) return rc0;
   lf_general = true; general_retries++;
   return decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
 }
@@ -415,7 +416,8 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
   if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos); }   // with the largest table pool
-  if (rc0 != kRetryGeneral) return rc0 == kRetryPool ? JXLAMD_ERR_DEVICE : rc0;
+  if (rc0 == kRetryPool) { set_error("LF table pool: a stream of the flight asked for a larger pool twice"); return JXLAMD_ERR_DEVICE; }
+  if (rc0 != kRetryGeneral) return rc0;
   lf_general = true; general_retries++;     // some frame needs a general lock-step loop: this context runs the general LF build from now on
   return decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
 }
@@ -597,43 +599,26 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
   HIPCHECK(hipEventRecord(ev[0], stream));
-#ifndef JXL_ABLATE_MASK
-#define JXL_ABLATE_MASK 0
-#endif
-  // experiment builds (tools/build_variant.sh): from the third flight of a context on, the stages named by the mask are not launched
-  // (their outputs of the previous flight stay in place) — what a stage costs the mix, measured by leaving it out
-  const int JXL_ABLATE = (JXL_ABLATE_MASK && ++ablate_flights > 2) ? JXL_ABLATE_MASK : 0;
-  if (!(JXL_ABLATE & 1)) launch_clear_batch(dB, nb, max_cells, stream);
+  launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  if (!(JXL_ABLATE & 1)) launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_general, stream);
+  launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_general, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
-  if (!(JXL_ABLATE & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
+  launch_lf_smooth_batch(dB, nb, max_cells, stream);
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
     const int cnt = std::min(hf_sets, nb - k0);
     const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
     // >= flat_min_groups groups: one LANE per group (k_pass_prep + k_pass_flat, 64 streams per wavefront); below that the
     // one-wave-per-group kernel has the shorter critical path
-    if (JXL_ABLATE & 2) {}
-    else if (all_flat && n_pg >= flat_min_groups) {
+    if (all_flat && n_pg >= flat_min_groups) {
       launch_pass_prep(dB + k0, map, n_pg, stream);
       launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
     } else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
-    hipStream_t rest_stream = stream;
-    if (stream_dp) {                       // the rest of this sub-flight follows its entropy stages on the other stream ...
-      HIPCHECK(hipEventRecord(ev_split[0], stream));
-      HIPCHECK(hipStreamWaitEvent(stream_dp, ev_split[0], 0));
-      rest_stream = stream_dp;
-    }
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      if ((JXL_ABLATE & 12) != 12) launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3 & ~((JXL_ABLATE >> 2) & 3), rest_stream);
-    if (stream_dp) {                       // ... and the next sub-flight's PassGroups (same coefficient planes), or the end of the flight, follow it
-      HIPCHECK(hipEventRecord(ev_split[1], stream_dp));
-      HIPCHECK(hipStreamWaitEvent(stream, ev_split[1], 0));
-    }
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
@@ -702,31 +687,7 @@ jxlamd_decoder *jxlamd_decoder_create(int device) {
   jxlamd_decoder *d = new jxlamd_decoder();
   d->device = device;
   if (hipSetDevice(device) != hipSuccess) { g_tls_error = "cannot open HIP device"; delete d; return nullptr; }
-  // JXLAMD_ENTROPY_CUS=N (experiment): a context's entropy stages (serial rANS chains, one wave or lane per stream) on the first
-  // N compute units, the data-parallel stages of its flights (dequantise + IDCT, filters, colour) on the others, each through its own stream
-  const char *split = getenv("JXLAMD_ENTROPY_CUS");
-  const int n_ent = split ? atoi(split) : 0;
-  hipDeviceProp_t prop;
-  if (n_ent > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_ent < prop.multiProcessorCount) {
-    const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
-    std::vector<uint32_t> ma((size_t)words, 0u), mb((size_t)words, 0u);
-    for (int i = 0; i < cus; i++) (i < n_ent ? ma : mb)[(size_t)i / 32] |= 1u << (i % 32);
-    if (hipExtStreamCreateWithCUMask(&d->stream, (uint32_t)words, ma.data()) != hipSuccess ||
-        hipExtStreamCreateWithCUMask(&d->stream_dp, (uint32_t)words, mb.data()) != hipSuccess) {
-      g_tls_error = "cannot create CU-masked streams"; delete d; return nullptr;
-    }
-    for (auto &e : d->ev_split) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  } else if (getenv("JXLAMD_ENTROPY_PRIORITY") && atoi(getenv("JXLAMD_ENTROPY_PRIORITY")) > 0) {
-    // JXLAMD_ENTROPY_PRIORITY=1 (experiment): the same two streams without CU masks — the entropy stages' queue at the highest dispatch
-    // priority, the data-parallel stages' at the lowest: an LF workgroup wants 33 - 52 KB of one CU's LDS in one piece, next to a flood of 8 - 17 KB workgroups
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&d->stream_dp, hipStreamNonBlocking, lo) != hipSuccess) {
-      g_tls_error = "cannot create prioritised streams"; delete d; return nullptr;
-    }
-    for (auto &e : d->ev_split) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  } else if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
     g_tls_error = "cannot open HIP device"; delete d; return nullptr;
   }
   for (auto &e : d->ev) (void)hipEventCreate(&e);
@@ -740,59 +701,64 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   for (FrameSlot *fs : d->slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
-  if (d->stream_dp) { (void)hipStreamDestroy(d->stream_dp); for (auto &e : d->ev_split) (void)hipEventDestroy(e); }
   delete d;
 }
 
 const char *jxlamd_last_error(const jxlamd_decoder *d) { return d ? d->error.c_str() : g_tls_error.c_str(); }
 
 int jxlamd_basic_info(const uint8_t *jxl, size_t size, jxlamd_info *info) {
-  ImageInfo ii; std::string err;
-  if (parse_basic_info(jxl, size, &ii, &err)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
-  fill_public_info(ii, JXLAMD_ALLOW_16BIT, info);
-  return JXLAMD_OK;
+  return jxlamd_guarded(nullptr, [&]() -> int {
+    ImageInfo ii; std::string err;
+    if (parse_basic_info(jxl, size, &ii, &err)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
+    fill_public_info(ii, JXLAMD_ALLOW_16BIT, info);
+    return JXLAMD_OK;
+  });
 }
 
 int jxlamd_get_icc(const uint8_t *jxl, size_t size, uint8_t *icc, size_t capacity, size_t *icc_size) {
-  ImageInfo ii; std::string err; std::vector<uint8_t> bytes;
-  if (parse_basic_info(jxl, size, &ii, &err, &bytes)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
-  if (icc_size) *icc_size = bytes.size();
-  if (bytes.size() > capacity || (!icc && !bytes.empty())) { g_tls_error = "output buffer too small"; return JXLAMD_ERR_BUFFER; }
-  if (!bytes.empty()) memcpy(icc, bytes.data(), bytes.size());
-  return JXLAMD_OK;
+  return jxlamd_guarded(nullptr, [&]() -> int {
+    ImageInfo ii; std::string err; std::vector<uint8_t> bytes;
+    if (parse_basic_info(jxl, size, &ii, &err, &bytes)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
+    if (icc_size) *icc_size = bytes.size();
+    if (bytes.size() > capacity || (!icc && !bytes.empty())) { g_tls_error = "output buffer too small"; return JXLAMD_ERR_BUFFER; }
+    if (!bytes.empty()) memcpy(icc, bytes.data(), bytes.size());
+    return JXLAMD_OK;
+  });
 }
 
 int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *bytes) {
-  ImageInfo ii; std::string err;
-  if (parse_basic_info(jxl, size, &ii, &err)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
-  jxlamd_info o; fill_public_info(ii, flags, &o);
-  int rc = size_guard(o, flags, &err);
-  if (rc) { g_tls_error = err; return rc; }
-  *bytes = (size_t)o.xsize * o.ysize * 4 * (o.out_bits == 16 ? 2 : 1);
-  return JXLAMD_OK;
+  return jxlamd_guarded(nullptr, [&]() -> int {
+    ImageInfo ii; std::string err;
+    if (parse_basic_info(jxl, size, &ii, &err)) { g_tls_error = err; return JXLAMD_ERR_INVALID; }
+    jxlamd_info o; fill_public_info(ii, flags, &o);
+    int rc = size_guard(o, flags, &err);
+    if (rc) { g_tls_error = err; return rc; }
+    *bytes = (size_t)o.xsize * o.ysize * 4 * (o.out_bits == 16 ? 2 : 1);
+    return JXLAMD_OK;
+  });
 }
 
 int jxlamd_decode(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t cap, jxlamd_info *info) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  return d->decode(jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out, cap, info);
+  return jxlamd_guarded(d, [&]() -> int { return d->decode(jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out, cap, info); });
 }
 
 int jxlamd_decode_resident(jxlamd_decoder *d, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out,
                            size_t cap, jxlamd_info *info) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  return d->decode(jxl, size, jxl_dev, flags | JXLAMD_IN_DEVICE, out, cap, info);
+  return jxlamd_guarded(d, [&]() -> int { return d->decode(jxl, size, jxl_dev, flags | JXLAMD_IN_DEVICE, out, cap, info); });
 }
 
 int jxlamd_decode_batch(jxlamd_decoder *d, int n, const uint8_t *const *jxl, const size_t *sizes, uint32_t flags, void *const *outs,
                         const size_t *caps, jxlamd_info *infos) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  return d->decode_batch(n, jxl, sizes, nullptr, flags & ~JXLAMD_IN_DEVICE, outs, caps, infos);
+  return jxlamd_guarded(d, [&]() -> int { return d->decode_batch(n, jxl, sizes, nullptr, flags & ~JXLAMD_IN_DEVICE, outs, caps, infos); });
 }
 
 int jxlamd_decode_batch_resident(jxlamd_decoder *d, int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev,
                                  uint32_t flags, void *const *outs, const size_t *caps, jxlamd_info *infos) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
-  return d->decode_batch(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  return jxlamd_guarded(d, [&]() -> int { return d->decode_batch(n, jxl, sizes, jxl_dev, flags, outs, caps, infos); });
 }
 
 // ---- post-decode stages (A10, A11)
@@ -816,7 +782,7 @@ int jxlamd_reformat_query(uint32_t w, uint32_t h, int src_is_u16, int cfg, int h
   return JXLAMD_OK;
 }
 
-int jxlamd_reformat(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int cfg, int alpha_premultiplied,
+static int jxlamd_reformat_impl(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int cfg, int alpha_premultiplied,
                     int has_alpha, int api_level, void *dst, size_t dst_cap, jxlamd_reformat_info *out) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   jxlamd_reformat_info info;
@@ -843,6 +809,11 @@ int jxlamd_reformat(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int sr
   launch_post_convert(k, src, ss, dst, info.stride, w, h, depth, att, s);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: post stage failed"); return JXLAMD_ERR_DEVICE; }
   return JXLAMD_OK;
+}
+
+int jxlamd_reformat(jxlamd_decoder *d, void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int cfg, int alpha_premultiplied,
+                    int has_alpha, int api_level, void *dst, size_t dst_cap, jxlamd_reformat_info *out) {
+  return jxlamd_guarded(d, [&]() -> int { return jxlamd_reformat_impl(d, src, w, h, src_is_u16, depth, cfg, alpha_premultiplied, has_alpha, api_level, dst, dst_cap, out); });
 }
 
 // The colour-matrix parameters of (format, depth, primaries, transfer, intensity target): matrix + the two LUTs on the device, cached per
@@ -876,7 +847,7 @@ static int ensure_color_plan(jxlamd_decoder *d, int is_u16, uint32_t depth, uint
   return JXLAMD_OK;
 }
 
-int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
+static int jxlamd_color_matrix_impl(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
                         const double *xy8, float intensity_target) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   if (!px || (is_u16 ? (depth < 9 || depth > 16) : depth != 8)) { d->set_error("bad pixel buffer / bit depth"); return JXLAMD_ERR_BUFFER; }
@@ -889,6 +860,11 @@ int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int
   return JXLAMD_OK;
 }
 
+int jxlamd_color_matrix(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf,
+                        const double *xy8, float intensity_target) {
+  return jxlamd_guarded(d, [&]() -> int { return jxlamd_color_matrix_impl(d, px, w, h, is_u16, depth, primaries, tf, xy8, intensity_target); });
+}
+
 static PostKind reformat_kind(uint32_t resolved_config, int src_is_u16) {
   switch (resolved_config) {
     case JXLAMD_CFG_RGBA_8888: return src_is_u16 ? kPostRgba16To8 : kPostCopy8;
@@ -899,7 +875,7 @@ static PostKind reformat_kind(uint32_t resolved_config, int src_is_u16) {
   }
 }
 
-int jxlamd_post_fused(jxlamd_decoder *d, const void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int apply_color_matrix, uint32_t primaries,
+static int jxlamd_post_fused_impl(jxlamd_decoder *d, const void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int apply_color_matrix, uint32_t primaries,
                       uint32_t tf, const double *xy8, float intensity_target, int cfg, int alpha_premultiplied, int has_alpha, int api_level, void *dst,
                       size_t dst_cap, jxlamd_reformat_info *out) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
@@ -921,7 +897,13 @@ int jxlamd_post_fused(jxlamd_decoder *d, const void *src, uint32_t w, uint32_t h
   return JXLAMD_OK;
 }
 
-int jxlamd_icc_transform(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, const uint8_t *icc, size_t icc_size) {
+int jxlamd_post_fused(jxlamd_decoder *d, const void *src, uint32_t w, uint32_t h, int src_is_u16, uint32_t depth, int apply_color_matrix, uint32_t primaries,
+                      uint32_t tf, const double *xy8, float intensity_target, int cfg, int alpha_premultiplied, int has_alpha, int api_level, void *dst,
+                      size_t dst_cap, jxlamd_reformat_info *out) {
+  return jxlamd_guarded(d, [&]() -> int { return jxlamd_post_fused_impl(d, src, w, h, src_is_u16, depth, apply_color_matrix, primaries, tf, xy8, intensity_target, cfg, alpha_premultiplied, has_alpha, api_level, dst, dst_cap, out); });
+}
+
+static int jxlamd_icc_transform_impl(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, const uint8_t *icc, size_t icc_size) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   if (!px || !icc || !icc_size) { d->set_error("bad pixel buffer / profile"); return JXLAMD_ERR_BUFFER; }
   constexpr int kN = 256;               // every 8-bit level is a lattice point (100 MB of HBM per cached profile)
@@ -941,6 +923,10 @@ int jxlamd_icc_transform(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, in
   launch_post_icc_lut(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, (const uint16_t *)d->icc_lut.p, kN, s);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: ICC stage failed"); return JXLAMD_ERR_DEVICE; }
   return JXLAMD_OK;
+}
+
+int jxlamd_icc_transform(jxlamd_decoder *d, void *px, uint32_t w, uint32_t h, int is_u16, const uint8_t *icc, size_t icc_size) {
+  return jxlamd_guarded(d, [&]() -> int { return jxlamd_icc_transform_impl(d, px, w, h, is_u16, icc, icc_size); });
 }
 
 int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) {

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 #include "../../include/jxl_amd.h"
@@ -19,6 +21,10 @@ std::string &tls_error();
 }
 using namespace jxlamd;
 
+// No C++ exception may cross the C-ABI (a crafted file that makes a std::vector throw must not std::terminate the host process): every
+// extern "C" entry point that parses input or allocates runs its body through this.  Mapping as the reference's JNI layer does
+// (JniDecoding.cpp:81-93): bad_alloc -> "Not enough memory to decode this image", anything else -> an invalid-stream error.
+template <class Fn> static inline int jxlamd_guarded(jxlamd_decoder *d, Fn &&fn);
 #define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); return JXLAMD_ERR_DEVICE; } } while (0)
 
 
@@ -101,8 +107,6 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream_dp = nullptr;      // JXLAMD_ENTROPY_CUS=N: flights run their data-parallel stages here, on the CUs the entropy stages do not use
-  hipEvent_t ev_split[2] = {};
   hipEvent_t ev[6] = {};
   std::string error;
   DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
@@ -127,7 +131,6 @@ struct jxlamd_decoder {
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)
   bool lf_general = false;               // the LF kernel build with the general lock-step loops (set for good the first time a frame of this context needs one)
   int lf_pool_bytes = kModPoolBytes;      // LDS table pool of the next LF launch: what the streams of the previous decode of this context asked for (first decode: the largest)
-  int ablate_flights = 0;                 // experiment builds only (JXL_ABLATE_MASK)
   void set_error(const std::string &e) { error = e; tls_error() = e; }
   FrameSlot &slot(size_t i) { while (slots.size() <= i) slots.push_back(new FrameSlot()); return *slots[i]; }
 
@@ -153,3 +156,9 @@ struct jxlamd_decoder {
                    const size_t *caps, jxlamd_info *infos);
 };
 
+template <class Fn> static inline int jxlamd_guarded(jxlamd_decoder *d, Fn &&fn) {
+  try { return fn(); }
+  catch (const std::bad_alloc &) { const std::string m = "Not enough memory to decode this image"; if (d) d->set_error(m); else jxlamd::tls_error() = m; return JXLAMD_ERR_DEVICE; }
+  catch (const std::exception &e) { const std::string m = std::string("Error: ") + e.what(); if (d) d->set_error(m); else jxlamd::tls_error() = m; return JXLAMD_ERR_INVALID; }
+  catch (...) { const std::string m = "Error: unknown exception"; if (d) d->set_error(m); else jxlamd::tls_error() = m; return JXLAMD_ERR_INVALID; }
+}

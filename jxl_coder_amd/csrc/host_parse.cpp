@@ -235,7 +235,10 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   if (sb->err) { plan->error = "truncated GlobalModular header"; return -1; }
   if ((int)L.size() > kModMaxCh) { plan->error = "unsupported: more than 80 modular channels"; return -1; }
   F.mod_nch = (int)L.size(); F.mod_nb_meta = nb_meta;
-  uint32_t off = 0;
+  // plane offsets (in samples) accumulate in 64 bits: the inverse squeeze steps add one output plane each (~3x the image), and nothing above
+  // bounds a frame's channels by 2^32 samples in total.  The device indexes the pool with 32-bit offsets: beyond that the frame is refused
+  uint64_t off = 0;
+  constexpr uint64_t kPoolLimit = 0xFFFFFFFFull - 4096;
   int first_group = F.mod_nch;
   for (int i = 0; i < F.mod_nch; i++) {
     const Ch &c = L[(size_t)i];
@@ -249,7 +252,10 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   if (F.mod_lf_nch > 8) { plan->error = "unsupported: more than 8 ModularLfGroup channels"; return -1; }
   // planes are indexed by stream channel position (the device decodes "channel i" into plane i); the inverse squeeze steps append theirs
   int nplanes = F.mod_nch;
-  for (int i = 0; i < F.mod_nch; i++) { L[(size_t)i].plane = i; F.mod_plane_off[i] = off; off += (uint32_t)((size_t)F.mod_w[i] * (size_t)F.mod_h[i] + 64); }
+  for (int i = 0; i < F.mod_nch; i++) {
+    L[(size_t)i].plane = i; F.mod_plane_off[i] = (uint32_t)off; off += (uint64_t)F.mod_w[i] * (uint64_t)F.mod_h[i] + 64;
+    if (off > kPoolLimit) { plan->error = "unsupported: Modular image beyond 2^32 samples"; return -1; }
+  }
   F.mod_first_group_ch = first_group;
   F.lz_win_len = 0; F.lz_win_group = 0;
   if (F.tree_ec.lz77 && !vardct) {            // a stream never holds more integers than the image has samples; the window is 2^20 at most
@@ -287,7 +293,8 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
             a.h += r.h; a.vs--;
           }
           a.plane = nplanes;
-          F.mod_plane_off[nplanes++] = off; off += (uint32_t)((size_t)a.w * (size_t)a.h + 64);
+          F.mod_plane_off[nplanes++] = (uint32_t)off; off += (uint64_t)a.w * (uint64_t)a.h + 64;
+          if (off > kPoolLimit) { plan->error = "unsupported: Modular image beyond 2^32 samples"; return -1; }
         }
         L.erase(L.begin() + offset, L.begin() + offset + p.num_c);
       }
@@ -311,7 +318,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       L.erase(L.begin());
     }
   }
-  plan->mod_pool_ints = off;
+  plan->mod_pool_ints = (size_t)off;
   if ((int)L.size() != ncol + m.num_extra) { plan->error = "modular channel bookkeeping"; return -1; }
   for (const Ch &c : L) if (c.w != f.width || c.h != f.height) { plan->error = "modular channel bookkeeping (sizes)"; return -1; }
   for (int c = 0; c < 3; c++) F.mod_out[c] = vardct ? -1 : L[(size_t)(ncol == 1 ? 0 : c)].plane;
