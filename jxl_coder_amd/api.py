@@ -76,7 +76,7 @@ FMT_NAMES = {1: "ARGB_8888", 2: "RGBA_F16", 3: "RGB_565", 4: "RGBA_1010102"}
 JXLAMD_ALLOW_16BIT, JXLAMD_OUT_DEVICE, JXLAMD_NO_SIZE_GUARD, JXLAMD_IN_DEVICE, JXLAMD_BAND_SHARED_GPU = 1, 2, 4, 8, 16
 _ERR = {-1: InvalidJXLException, -2: UnsupportedJXLFeature, -3: InvalidImageSizeException, -4: RuntimeError, -5: ValueError}
 
-SOURCES = ["kernels_lf.hip", "kernels_lf_general.hip", "kernels_lf_general_b.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp", "host_icc_lut.cpp"]
+SOURCES = ["kernels_lf.hip", "kernels_lf_general.hip", "kernels_lf_general_b.hip", "kernels_mod.hip", "kernels_pass.hip", "kernels_recon.hip", "kernels_filter.hip", "kernels_compose.hip", "decoder.hip", "band.hip", "post.hip", "resample.hip", "host_parse.cpp", "host_bits.cpp", "host_post.cpp", "host_icc_lut.cpp"]
 
 
 def library_path():

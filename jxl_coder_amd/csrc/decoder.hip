@@ -70,7 +70,7 @@ int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kE
 // host twin of mod_group_scratch_ints (dev_modframe.h)
 static size_t mod_scratch_ints_host(const DevFrame &F) {
   const size_t gd = (size_t)(F.mod_group_dim > 0 ? F.mod_group_dim : 256);
-  return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
+  return (size_t)(F.mod_nch - F.mod_first_group_ch + 1) * gd * gd + (size_t)kWideWpInts;
 }
 // ... + the ModularLfGroup rectangles (mod_lfgroup_body): 256 x 256 samples per channel and LF group
 static size_t mod_scratch_total_ints(const DevFrame &F, int num_groups, int num_lf_groups) {
@@ -96,6 +96,9 @@ BandGeom band_geometry(const DevFrame &F, int gr0, int gr1) {
   q.prow0 = std::max(0, q.py0 - 8); q.prow1 = std::min((int)F.ph, q.cy1 * 8 + 8);
   q.halo = (F.gab ? 1 : 0) + (F.epf_iters >= 3 ? 3 : 0) + (F.epf_iters >= 1 ? 2 : 0) + (F.epf_iters >= 2 ? 1 : 0);
   q.whole = gr0 == 0 && gr1 == F.ygroups;
+  if (F.is_modular) {               // Modular-encoded frames (group sizes 128 .. 1024) are never banded: every row, whatever the group grid
+    q.cy0 = 0; q.cy1 = F.yb; q.py0 = 0; q.py1 = F.height; q.scy0 = 0; q.scy1 = F.yb; q.st0 = 0; q.st1 = (F.yb + 7) / 8; q.prow0 = 0; q.prow1 = F.ph; q.whole = true;
+  }
   return q;
 }
 
@@ -114,6 +117,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (info) *info = S.pi;
   DevFrame *Fh = (DevFrame *)plan.tables.data();       // host copy of the frame parameters: the band fields are patched in before the upload
   if (band_rows) {
+    if (plan.compose || !plan.refs.empty()) { set_error("unsupported: band decode of a frame with patches / reference frames"); return JXLAMD_ERR_UNSUPPORTED; }
     if (plan.modular || plan.has_ec || plan.single_section) { set_error("unsupported: band decode of a Modular / extra-channel / single-group frame"); return JXLAMD_ERR_UNSUPPORTED; }
     if (Fh->orientation != 1) { set_error("unsupported: band decode of a frame with a non-identity orientation"); return JXLAMD_ERR_UNSUPPORTED; }
     if (plan.cropped) { set_error("unsupported: band decode of a frame that does not cover the image"); return JXLAMD_ERR_UNSUPPORTED; }
@@ -126,6 +130,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   const size_t bpp = S.pi.out_bits == 16 ? 8 : 4;
   if (q.whole) { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }     // a band is below the Bitmap layer (BASELINE config 4)
   S.out_bytes = q.whole ? (size_t)S.pi.xsize * S.pi.ysize * bpp : (size_t)S.pi.xsize * (size_t)(q.py1 - q.py0) * bpp;
+  if (Fh->no_output) S.out_bytes = 0;                   // a reference frame: nothing is written out
   if (out_cap < S.out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
   const size_t ncell = (size_t)plan.xb * (size_t)(q.scy1 - q.scy0);
   const size_t ntile = (size_t)((plan.xb + 7) / 8) * (size_t)(q.st1 - q.st0);
@@ -206,6 +211,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
     HIPCHECK(S.mod_scratch.ensure(mod_scratch_total_ints(*Fh, plan.num_groups, plan.num_lf_groups) * 4 + 256));      // + 1: the GlobalModular stream's slot
     HIPCHECK(S.local.ensure((size_t)(plan.num_groups > 1 ? plan.num_groups : 1) * sizeof(LocalTreeScratch)));
+    if (plan.compose) for (int i = 0; i < (Fh->xyb_modular ? 6 : 3); i++) HIPCHECK(S.planes[i].ensure(npx * 4));      // composed: the image moves into the f32 planes (k_mod_to_planes)
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
   S.host_out = nullptr; S.d_out = out_ptr;
@@ -236,6 +242,12 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits; B.stat = (const uint8_t *)stat.p;
   B.lz_win = (plan.modular && Fh->lz_win_len) ? (uint32_t *)S.lz_win.p : nullptr;
+  for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++)
+    B.ref[k][c] = (ref_store[k].p && Fh->ref_w[k] == ref_w[k] && Fh->ref_h[k] == ref_h[k] && ref_w[k] > 0) ? (float *)ref_store[k].p + (size_t)c * (size_t)ref_w[k] * (size_t)ref_h[k] : nullptr;
+  if (Fh->num_patches > 0) {
+    const DevPatch *P = (const DevPatch *)(plan.tables.data() + Fh->patch_off);
+    for (int i = 0; i < Fh->num_patches; i++) if (!B.ref[P[i].ref][0]) { set_error("patch dictionary: reference frame missing"); return JXLAMD_ERR_INVALID; }
+  }
   B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
@@ -278,10 +290,10 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
 }
 
 // everything after the entropy stages: reconstruction, loop filters, RGBA writer, D2H of the output if asked
-int jxlamd_decoder::launch_rest(FrameSlot &S, int parts) {
+int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  if (parts & 1) {                 // the buffer table goes up once per decode (page-locked staging)
+  if ((parts & 1) || upload_B) {   // the buffer table goes up once per decode (page-locked staging)
     HIPCHECK(S.dB.ensure(sizeof(DevBuffers)));
     HIPCHECK(S.h_B.ensure(sizeof(DevBuffers)));
     memcpy(S.h_B.p, &S.B, sizeof(DevBuffers));
@@ -294,6 +306,7 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts) {
   if (F->epf_iters >= 2) stage_mask |= 8;
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
+  if (F->compose) stage_mask = (stage_mask & 15) | 32;           // stage by stage into the planes; patches, reference copy and writer follow (launch_compose_tail)
   launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
   return JXLAMD_OK;
 }
@@ -317,7 +330,25 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
   if (F->mod_lf_nch > 0) launch_mod_lfgroups(S.B, plan.num_lf_groups, stream);
   if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
-  launch_mod_write(S.B, plan.width, plan.height, (int)S.pi.out_bits, stream);
+  if (!F->compose) { launch_mod_write(S.B, plan.width, plan.height, (int)S.pi.out_bits, stream); return JXLAMD_OK; }
+  launch_mod_to_planes(S.B, plan.width, plan.height, stream);
+  if (F->xyb_modular && (F->gab || F->epf_iters)) { int rc = launch_rest(S, 2, /*upload_B=*/true); if (rc) return rc; }      // loop filters of an XYB frame, stage by stage
+  return launch_compose_tail(S);
+}
+
+// composed frames (dev_compose.h): patches onto the filtered planes, copy into the frame's reference slot, stand-alone writer
+int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
+  const FramePlan &plan = S.plan;
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
+  if (plan.save_slot >= 0) {
+    const int k = plan.save_slot;
+    const size_t n = (size_t)plan.width * (size_t)plan.height;
+    HIPCHECK(ref_store[k].ensure(3 * n * 4));
+    ref_w[k] = plan.width; ref_h[k] = plan.height;
+    launch_save_ref(S.B, plan.width, plan.height, (float *)ref_store[k].p, stream);
+  }
+  if (!F->no_output) launch_compose_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, stream);
   return JXLAMD_OK;
 }
 
@@ -353,11 +384,38 @@ int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev,
 int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
   HIPCHECK(hipSetDevice(device));
   FrameSlot &S = slot(0);
-  int rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
+  S.plan = FramePlan();
+  (void)plan_parse(jxl, size, &S.plan);
+  if (!S.plan.error.empty() || S.plan.tables.empty()) { set_error(S.plan.error); return err_class(S.plan.error); }
+  int rc = decode_refs(S, flags);
   if (rc) return rc;
+  rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info, /*parsed=*/true);
+  if (rc) return rc;
+  return run_frame(S, flags, /*single_latency=*/true);
+}
+
+// The frames a patch dictionary draws on (FramePlan::refs), in file order: each one is decoded like a frame of its own — same kernels — and
+// its image copied into its reference slot instead of being written out.
+int jxlamd_decoder::decode_refs(FrameSlot &main, uint32_t flags) {
+  for (size_t k = 0; k < main.plan.refs.size(); k++) {
+    while (ref_slots.size() <= k) ref_slots.push_back(new FrameSlot());
+    FrameSlot &RS = *ref_slots[k];
+    RS.plan = *main.plan.refs[k];
+    int rc = prepare(RS, nullptr, 0, nullptr, (flags & ~(uint32_t)(JXLAMD_IN_DEVICE | JXLAMD_OUT_DEVICE)) | JXLAMD_NO_SIZE_GUARD, nullptr, ~(size_t)0, nullptr, /*parsed=*/true);
+    if (rc) return rc;
+    rc = run_frame(RS, flags, false);
+    if (rc) return rc;
+  }
+  return JXLAMD_OK;
+}
+
+// one prepared frame through every stage on this context's stream, then the flag readback (and the output copy if the caller's buffer is on the host)
+int jxlamd_decoder::run_frame(FrameSlot &S, uint32_t flags, bool single_latency) {
+  int rc;
+  const DevFrame *F = (const DevFrame *)S.plan.tables.data();
   HIPCHECK(hipEventRecord(ev[0], stream));
   if (S.plan.modular) {
-    launch_modular(S);
+    rc = launch_modular(S); if (rc) return rc;
     for (int i = 1; i <= 4; i++) HIPCHECK(hipEventRecord(ev[i], stream));
     rc = collect(S, flags);
     for (int i = 0; i < 4; i++) timing[i] = 0;
@@ -367,7 +425,7 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
   if (S.plan.has_ec) launch_mod_global(S.B, stream);
   // a single decode is the latency path and has the chip to itself: the general build (181 VGPRs) runs a lone stream ~5 % faster than the lean
   // one (125), whose smaller footprint only pays next to the data-parallel kernels of other flights
-  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, /*general=*/true, stream);
+  launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, /*general=*/single_latency || lf_general, stream);
   if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
@@ -377,6 +435,7 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
   rc = launch_rest(S, 1); if (rc) return rc;
   HIPCHECK(hipEventRecord(ev[3], stream));
   rc = launch_rest(S, 2); if (rc) return rc;
+  if (F->compose) { rc = launch_compose_tail(S); if (rc) return rc; }
   HIPCHECK(hipEventRecord(ev[4], stream));
   rc = collect(S, flags);
   for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);
@@ -443,10 +502,13 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   if (trace) HIPCHECK(hipEventRecord(ev[5], stream));
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
+    const bool composed = S.plan.compose || !S.plan.refs.empty();      // patches / reference frames: one by one, like a single decode
+    if (composed && S.plan.error.empty()) { int rc = decode_refs(S, flags); if (rc) return rc; }
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
-                     /*own_planes=*/S.plan.modular || S.plan.single_section);
+                     /*own_planes=*/S.plan.modular || S.plan.single_section || composed);
     if (rc) return rc;
+    if (composed) { rc = run_frame(S, flags, false); if (rc) return rc; continue; }
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section) {
       if (S.plan.has_ec) launch_mod_global(S.B, stream);
@@ -698,7 +760,8 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   if (!d) return;
   (void)hipSetDevice(d->device);
   (void)hipStreamSynchronize(d->stream);
-  for (FrameSlot *fs : d->slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
+  for (FrameSlot *fs : d->slots) delete fs;
+  for (FrameSlot *fs : d->ref_slots) delete fs;          // DevMem / PinnedMem members release themselves (slots and the decoder's own pools)
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
   delete d;

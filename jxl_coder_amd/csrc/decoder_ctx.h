@@ -116,6 +116,8 @@ struct jxlamd_decoder {
   PinnedMem h_batch, h_mod_tab, h_flight_tables, h_flight_cs, h_flags;
   DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;
+  std::vector<FrameSlot *> ref_slots;     // reference frames of the file being decoded (patch dictionaries), one slot each
+  DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
@@ -144,7 +146,10 @@ struct jxlamd_decoder {
   int band_reconstruct();
   int band_finish();
   int finish_single_section(FrameSlot &S);
-  int launch_rest(FrameSlot &S, int parts = 3);     // parts: 1 = reconstruction, 2 = filters + writer
+  int launch_rest(FrameSlot &S, int parts = 3, bool upload_B = false);     // parts: 1 = reconstruction, 2 = filters + writer
+  int launch_compose_tail(FrameSlot &S);
+  int decode_refs(FrameSlot &main, uint32_t flags);
+  int run_frame(FrameSlot &S, uint32_t flags, bool single_latency);
   int launch_modular(FrameSlot &S);
   int launch_extra_channels(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);

@@ -1,0 +1,96 @@
+// jxl_coder_amd/csrc/dev_compose.h — composition stages between the loop filters and the writer (ISO/IEC 18181-1 Annex K: patches;
+// reference frames): Modular planes -> f32 planes, patch blending, copy into a reference slot, the writer of frames that are not XYB.
+// What libjxl's render pipeline does in its "Patches" stage and when it keeps a frame for later ("save_as_reference", reference call site
+// jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75).  Files the reference's own encoder writes for text / screenshots at its default settings
+// carry a small kReferenceOnly frame with the glyph-like patches and a main frame that adds them back (interop/JxlEncoding.cpp:145-160).
+#pragma once
+#include "dev_recon.h"
+#include "dev_modframe.h"
+
+namespace jxlamd {
+
+// the image planes of a composed frame after its loop filters: the per-stage filter kernels ping-pong between the two sets
+JXL_DEV bool compose_final_is_a(const DevFrame &F) {
+  if (F.is_modular && !F.xyb_modular) return true;
+  int n = (F.gab ? 1 : 0) + F.epf_iters;
+  return (n & 1) == 0;
+}
+
+// Modular-encoded frame -> f32 planes (plane_a): integer samples / (2^bits - 1), or — XYB image — Y, X, B - Y times the LF dequantisation factors
+JXL_DEV void mod_to_planes_pixel(const DevBuffers &B, const DevFrame &F, int x, int y) {
+  const size_t si = (size_t)y * (size_t)F.width + (size_t)x, po = (size_t)y * (size_t)F.pw + (size_t)x;
+  if (F.xyb_modular) {
+    const int32_t vy = mod_plane(B, F, F.mod_out[0])[si], vx = mod_plane(B, F, F.mod_out[1])[si], vb = mod_plane(B, F, F.mod_out[2])[si];
+    B.plane_a[0][po] = (float)vx * F.mod_xyb_fac[0];
+    B.plane_a[1][po] = (float)vy * F.mod_xyb_fac[1];
+    B.plane_a[2][po] = (float)(vb + vy) * F.mod_xyb_fac[2];
+  } else {
+    const float sc = 1.0f / (float)((1u << F.mod_bits) - 1);
+    for (int c = 0; c < 3; c++) B.plane_a[c][po] = (float)mod_plane(B, F, F.mod_out[c])[si] * sc;
+  }
+}
+
+// one sample of one patch placement: item = pixel index inside the patch rectangle
+JXL_DEV void patch_blend_sample(const DevBuffers &B, const DevFrame &F, const DevPatch &P, int item) {
+  const int iy = item / P.w, ix = item - iy * P.w;
+  const int x = P.x + ix, y = P.y + iy;
+  if ((unsigned)x >= (unsigned)F.width || (unsigned)y >= (unsigned)F.height) return;
+  const bool a = compose_final_is_a(F);
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x, ro = (size_t)(P.y0 + iy) * (size_t)F.ref_w[P.ref] + (size_t)(P.x0 + ix);
+  for (int c = 0; c < 3; c++) {
+    float *dst = (a ? B.plane_a[c] : B.plane_b[c]) + po;
+    const float r = B.ref[P.ref][c][ro];
+    if (P.mode == 1) *dst = r;
+    else if (P.mode == 3) *dst = *dst * r;
+    else if (P.mode == 2) {
+#ifdef __HIPCC__
+      atomicAdd(dst, r);          // placements may overlap; without overlap this is the plain sum
+#else
+      *dst += r;
+#endif
+    }
+  }
+}
+
+// copy the composed frame into a reference slot (dense w x h planes)
+JXL_DEV void save_ref_pixel(const DevBuffers &B, const DevFrame &F, float *const dst[3], int x, int y) {
+  const bool a = compose_final_is_a(F);
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x, ro = (size_t)y * (size_t)F.width + (size_t)x;
+  for (int c = 0; c < 3; c++) dst[c][ro] = (a ? B.plane_a[c] : B.plane_b[c])[po];
+}
+
+// writer of a composed frame that is not XYB (Modular-encoded, samples already in the image's own colour space): clamp, scale, round
+JXL_DEV void plain_write_pixel(const DevBuffers &B, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x, si = (size_t)y * (size_t)F.width + (size_t)x;
+  const float maxv = out_bits == 16 ? 65535.0f : 255.0f;
+  uint32_t px[4];
+  for (int c = 0; c < 4; c++) {
+    float t;
+    if (c < 3) t = B.plane_a[c][po];
+    else if (F.mod_out[3] < 0) t = 1.0f;
+    else t = (float)mod_plane(B, F, F.mod_out[3])[si] / (float)((1u << F.mod_alpha_bits) - 1);
+    t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
+    if (!(t == t)) t = 0.0f;
+    px[c] = (uint32_t)(int)rintf(t * maxv);
+  }
+  x += F.crop_x0; y += F.crop_y0;
+  const int W = F.canvas_w, H = F.canvas_h;
+  if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return;
+  int ox = x, oy = y;
+  switch (F.orientation) {
+    case 2: ox = W - 1 - x; break;
+    case 3: ox = W - 1 - x; oy = H - 1 - y; break;
+    case 4: oy = H - 1 - y; break;
+    case 5: ox = y; oy = x; break;
+    case 6: ox = H - 1 - y; oy = x; break;
+    case 7: ox = H - 1 - y; oy = W - 1 - x; break;
+    case 8: ox = y; oy = W - 1 - x; break;
+    default: break;
+  }
+  const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
+  if (out_bits == 8) *(uint32_t *)(B.out + di) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+  else { uint16_t *o = (uint16_t *)B.out + di; for (int c = 0; c < 4; c++) o[c] = (uint16_t)px[c]; }
+}
+
+}  // namespace jxlamd

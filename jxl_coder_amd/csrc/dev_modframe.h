@@ -12,7 +12,7 @@ constexpr int kModGroupMaxCh = 24;                     // per group: up to 24 ch
 // LDS rows; slot num_groups (same size) belongs to the GlobalModular stream
 JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) {
   const size_t gd = (size_t)(F.mod_group_dim > 0 ? F.mod_group_dim : 256);
-  return (size_t)(F.mod_nch - F.mod_first_group_ch) * gd * gd + (size_t)kWideWpInts;
+  return (size_t)(F.mod_nch - F.mod_first_group_ch + 1) * gd * gd + (size_t)kWideWpInts;     // + 1: the palettes of the group's own transforms
 }
 
 JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
@@ -63,7 +63,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
     bits_read(b, (int)skip);
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win : nullptr; S.lz.win_len = F.lz_win_len;      // LZ77 window slot 0
-    S.wide_wp = (uint32_t *)(B.mod_scratch + (size_t)F.num_groups * mod_group_scratch_ints(F) + (size_t)(F.mod_nch - F.mod_first_group_ch) * (size_t)F.mod_group_dim * (size_t)F.mod_group_dim);
+    S.wide_wp = (uint32_t *)(B.mod_scratch + (size_t)F.num_groups * mod_group_scratch_ints(F) + (size_t)(F.mod_nch - F.mod_first_group_ch + 1) * (size_t)F.mod_group_dim * (size_t)F.mod_group_dim);
     modular_stream_begin(B.tables, F, B.local[0], S, &S.trs);
   }
   sync();
@@ -134,6 +134,31 @@ JXL_DEV uint32_t mod_lfgroup_body(const DevBuffers &B, DevModScratch &S, int g, 
   return 0;
 }
 
+// raise a flag of the frame's flag word from any work item
+JXL_DEV void mod_flag(const DevBuffers &B, uint32_t f) {
+#ifdef __HIPCC__
+  atomicOr(B.err, f | kErrStageRecon);
+#else
+  *B.err |= f | kErrStageRecon;
+#endif
+}
+// colour `index` of channel c (H.6.4): an explicit palette entry, or — beyond the palette — the implicit 4x4x4 / 5x5x5 colour cubes
+JXL_DEV int32_t palette_value(const int32_t *pal, int psize, int index, int c, int bit_depth) {
+  if (index >= psize && index < psize + 64) {
+    if (c >= 3) return 0;
+    index -= psize;
+    index >>= c * 2;
+    return (int32_t)(((int64_t)(index % 4) * ((1 << bit_depth) - 1)) / 4) + (1 << (bit_depth - 3 > 0 ? bit_depth - 3 : 0));
+  }
+  if (index >= psize + 64) {
+    if (c >= 3) return 0;
+    index -= psize + 64;
+    if (c == 1) index /= 5; else if (c == 2) index /= 25;
+    return (int32_t)(((int64_t)(index % 5) * ((1 << bit_depth) - 1)) / 4);
+  }
+  return pal[(size_t)c * (size_t)psize + (size_t)index];
+}
+
 // ---- one 256x256 group of the remaining channels
 template <class Sync>
 JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
@@ -152,7 +177,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)F.lz_win_len + (size_t)g * (size_t)F.lz_win_group : nullptr; S.lz.win_len = F.lz_win_group;
-    S.wide_wp = (uint32_t *)(scr + (size_t)nch * (size_t)gd * (size_t)gd);
+    S.wide_wp = (uint32_t *)(scr + (size_t)(nch + 1) * (size_t)gd * (size_t)gd);
     // the stream's channels: the group's rectangle of every remaining frame channel, scaled by the channel's shifts (squeeze); channels
     // whose rectangle is empty here are not in the stream, channels with both shifts >= 3 travel in the ModularLfGroup streams
     int n = 0;
@@ -169,11 +194,31 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     }
     S.grp_n = n;
     if (n > 0) modular_stream_begin(B.tables, F, B.local[g], S, &S.trs); else { S.trs.n = 0; S.st.err = 0; }
+    // the stream's own transforms (H.6): RCTs leave the channel list as it is; a palette folds num_c channels into one index channel and puts
+    // its colours in front as a meta channel (meta-apply, as parse_modular_global does for the global transforms)
+    int cnt = n, nmeta = 0;
+    size_t pal_used = 0;
+    int32_t *pal_scr = scr + (size_t)nch * (size_t)gd * (size_t)gd;
     for (int i = 0; i < S.trs.n && !S.st.err; i++) {
       const DevTr &t = S.trs.t[i];
-      if (t.id != 0) S.st.err = kErrPalette;                         // group-level palettes: not on the device yet
-      else if (t.begin_c + 3 > n) S.st.err = kErrBitstream;
+      if (t.id == 0) { if (t.begin_c + 3 > cnt) S.st.err = kErrBitstream; }
+      else if (t.id == 1) {
+        if (t.num_c < 1 || t.num_c > 4 || t.nb_deltas > 0 || t.begin_c < nmeta) { S.st.err = kErrPalette; break; }      // delta entries / palettes of meta channels: not on the device
+        if (t.begin_c + t.num_c > cnt || cnt + 1 > kModMaxCh) { S.st.err = kErrBitstream; break; }
+        const size_t need = (size_t)t.nb_colours * (size_t)t.num_c;
+        if (pal_used + need > (size_t)gd * (size_t)gd) { S.st.err = kErrPalette; break; }
+        for (int c = 1; c < t.num_c; c++) {
+          if (S.ch[t.begin_c + c].w != S.ch[t.begin_c].w || S.ch[t.begin_c + c].h != S.ch[t.begin_c].h) S.st.err = kErrBitstream;
+          S.pal_saved[i][c - 1] = S.ch[t.begin_c + c];
+        }
+        for (int k = t.begin_c + t.num_c; k < cnt; k++) S.ch[k - (t.num_c - 1)] = S.ch[k];
+        cnt -= t.num_c - 1;
+        for (int k = cnt; k > 0; k--) S.ch[k] = S.ch[k - 1];
+        S.ch[0].d = pal_scr + pal_used; S.ch[0].w = t.nb_colours; S.ch[0].h = t.num_c;
+        pal_used += need; cnt++; nmeta++;
+      } else S.st.err = kErrSqueeze;                                      // group-level squeeze: not on the device
     }
+    S.grp_dec = cnt;
     if (S.st.err) *B.err |= S.st.err | kErrStagePass;
   }
   sync();
@@ -182,17 +227,42 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   sync();
   const int nst = S.grp_n;
   const int sid = 1 + 3 * F.num_lf_groups + 17 + g;
-  uint32_t e = mod_decode_stream(S, S.ch, nst, sid, tid);
+  uint32_t e = mod_decode_stream(S, S.ch, S.grp_dec, sid, tid);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
   sync();
   if (S.st.err) return;
-  // undo this group's own RCTs (last transform first), then copy the rectangles into the full planes
+  // undo this group's own transforms (last one first), then copy the rectangles into the full planes
   for (int i = S.trs.n - 1; i >= 0; i--) {
     const DevTr t = S.trs.t[i];
-    const DevChanOut a = S.ch[t.begin_c], b2 = S.ch[t.begin_c + 1], c2 = S.ch[t.begin_c + 2];
-    if (a.w == b2.w && a.w == c2.w && a.h == b2.h && a.h == c2.h)
-      inv_rct_planes(a.d, b2.d, c2.d, (size_t)a.w * (size_t)a.h, t.rct_type, tid, nthreads);
-    else if (tid == 0) *B.err |= kErrBitstream | kErrStagePass;
+    if (t.id == 0) {
+      const DevChanOut a = S.ch[t.begin_c], b2 = S.ch[t.begin_c + 1], c2 = S.ch[t.begin_c + 2];
+      if (a.w == b2.w && a.w == c2.w && a.h == b2.h && a.h == c2.h)
+        inv_rct_planes(a.d, b2.d, c2.d, (size_t)a.w * (size_t)a.h, t.rct_type, tid, nthreads);
+      else if (tid == 0) *B.err |= kErrBitstream | kErrStagePass;
+      sync();
+      continue;
+    }
+    // palette: S.ch[0] holds the colours, S.ch[begin_c + 1] the indices; colour 0 replaces the indices, colours 1.. go to the folded channels' buffers
+    const DevChanOut pal = S.ch[0], ix = S.ch[t.begin_c + 1];
+    const int bit_depth = F.mod_bits < 24 ? F.mod_bits : 24;
+    bool neg = false;
+    for (int k = tid; k < ix.w * ix.h; k += nthreads) {
+      int index = ix.d[k];
+      if (index < 0) { neg = true; index = 0; }
+      if (t.num_c == 1 && index > pal.w - 1) index = pal.w - 1;
+      ix.d[k] = palette_value(pal.d, pal.w, index, 0, bit_depth);
+      for (int c = 1; c < t.num_c; c++) S.pal_saved[i][c - 1].d[k] = palette_value(pal.d, pal.w, index, c, bit_depth);
+    }
+    if (neg) mod_flag(B, kErrPalette);
+    sync();
+    if (tid == 0) {
+      int cnt = S.grp_dec;
+      for (int k = 1; k < cnt; k++) S.ch[k - 1] = S.ch[k];           // drop the palette channel
+      cnt--;
+      for (int k = cnt - 1; k > t.begin_c; k--) S.ch[k + t.num_c - 1] = S.ch[k];
+      for (int c = 1; c < t.num_c; c++) S.ch[t.begin_c + c] = S.pal_saved[i][c - 1];
+      S.grp_dec = cnt + t.num_c - 1;
+    }
     sync();
   }
   for (int c = 0; c < nst; c++) {
@@ -247,15 +317,42 @@ JXL_DEV void mod_op_element(const DevBuffers &B, const DevFrame &F, int op, size
       left = second;
     }
     if (na > re) o[(size_t)(2 * re) * os] = a[(size_t)re * as];
-  } else {                                  // channel palette: plane a = index/values, plane b = palette (x = nb_colours, y = bit depth)
+  } else if (F.mod_op_kind[op] == 1) {      // palette without delta entries (H.6.4): one pixel per work item, colour 0 replaces the index in place
     int32_t *v = mod_plane(B, F, F.mod_op_a[op]) + i;
     const int32_t *pal = mod_plane(B, F, F.mod_op_b[op]);
+    const int psize = F.mod_op_x[op], bit_depth = F.mod_op_y[op] < 24 ? F.mod_op_y[op] : 24, nc = F.mod_op_e[op];
     int index = *v;
-    const int psize = F.mod_op_x[op], bit_depth = F.mod_op_y[op] < 24 ? F.mod_op_y[op] : 24;
-    if (index < 0) index = 0;               // (delta-palette entries are rejected on the host: nb_deltas must be 0)
-    if (index > psize - 1) index = psize - 1;   // single-channel palette without deltas clamps the index (H.6.4)
-    *v = pal[index];
-    (void)bit_depth;
+    if (index < 0) { mod_flag(B, kErrPalette); index = 0; }           // implicit delta-palette entries (libjxl's lossy palette): not on the device
+    if (nc == 1 && index > psize - 1) index = psize - 1;             // the single-channel form clamps the index
+    *v = palette_value(pal, psize, index, 0, bit_depth);
+    for (int c = 1; c < nc; c++) mod_plane(B, F, F.mod_op_d[op] + c - 1)[i] = palette_value(pal, psize, index, c, bit_depth);
+  } else {                                  // kind 4: palette with delta entries: work item = colour channel, pixels in raster order
+    const int c = (int)i;
+    const int32_t *idx = mod_plane(B, F, F.mod_op_a[op]);
+    const int32_t *pal = mod_plane(B, F, F.mod_op_b[op]);
+    int32_t *out = mod_plane(B, F, F.mod_op_d[op] + c);
+    const int psize = F.mod_op_x[op], bd = F.mod_op_y[op] & 0xff, bit_depth = bd < 24 ? bd : 24;
+    const int nb_deltas = F.mod_op_f[op], d_pred = F.mod_op_g[op], w = F.mod_op_h[op], h = (int)((uint32_t)F.mod_op_y[op] >> 8);
+    for (int y = 0; y < h; y++) {
+      int32_t *row = out + (size_t)y * (size_t)w;
+      const int32_t *rN = y > 0 ? row - w : nullptr, *rNN = y > 1 ? row - 2 * w : nullptr;
+      for (int x = 0; x < w; x++) {
+        int index = idx[(size_t)y * (size_t)w + (size_t)x];
+        if (index < 0) { mod_flag(B, kErrPalette); index = 0; }
+        int64_t v = palette_value(pal, psize, index, c, bit_depth);
+        if (index < nb_deltas) {
+          const int64_t W = x > 0 ? row[x - 1] : (rN ? rN[x] : 0);
+          const int64_t N = rN ? rN[x] : W;
+          const int64_t NW = (x > 0 && rN) ? rN[x - 1] : W;
+          const int64_t NE = (x + 1 < w && rN) ? rN[x + 1] : N;
+          const int64_t NN = rNN ? rNN[x] : N;
+          const int64_t NEE = (x + 2 < w && rN) ? rN[x + 2] : NE;
+          const int64_t WW = x > 1 ? row[x - 2] : W;
+          v += predict_plain(d_pred, W, N, NW, NE, NN, WW, NEE, 0);
+        }
+        row[x] = (int32_t)v;
+      }
+    }
   }
 }
 

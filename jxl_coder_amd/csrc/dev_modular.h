@@ -30,7 +30,8 @@ constexpr int kModPoolBytes = JXL_MOD_POOL_BYTES;  // LARGEST LDS table pool of 
 constexpr int kModPoolMin = 12288;                 // header parser's working arrays (LocalTmp) and the placement bitmap (8 KB) live there too
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };
-struct DevTrList { DevTr t[4]; int32_t n; };
+constexpr int kModMaxLocalTr = 8;      // transforms of one group stream (libjxl: per-channel palettes + one multi-channel palette + an RCT)
+struct DevTrList { DevTr t[kModMaxLocalTr]; int32_t n; };
 
 struct DevModStream {                 // what lane 0 hands to the other lanes / to the next phase of a stream
   DevBits b;
@@ -68,8 +69,10 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t alias_lds, ctx_lds, tree_ncache, ctx_off;   // ctx_off: byte offset of the context map inside the pool
   DevModStream st;
   DevChanOut ch[kModMaxCh];           // channel descriptors of the current stream
+  int32_t grp_dec;                    // channels the current group stream carries after its own transforms' meta-apply (palette channels in front)
   int32_t grp_src[24], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header
+  DevChanOut pal_saved[kModMaxLocalTr][3];   // group-level palettes: the colour channels 1.. each one folded away (their buffers receive the colours again)
   DevWaveTree wt;
   uint32_t fallback_err;
   uint32_t *wide_wp;                  // HBM: the weighted predictor's error rows for channels wider than the LDS rows (kWideWpInts; null: such channels are rejected)
@@ -317,7 +320,7 @@ JXL_DEV void modular_read_header(DevBits &b, DevWP &wp, int &nb_transforms, int 
 //   hybrid-uint configs and alias tables -> LDS;  decode (lane 0): channels + final-state check.
 // Transform list of a stream header (H.6): RCT and palette are parsed, squeeze parameters skipped (the caller decides what it accepts).
 JXL_DEV uint32_t modular_read_transforms(DevBits &b, int ntr, DevTrList *out) {
-  if (ntr > 0 && (!out || ntr > 4)) return kErrUnsupportedTransform;
+  if (ntr > 0 && (!out || ntr > kModMaxLocalTr)) return kErrUnsupportedTransform;
   if (out) out->n = ntr;
   for (int i = 0; i < ntr; i++) {
     DevTr &t = out->t[i];

@@ -253,6 +253,7 @@ JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[
 }
 
 JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y) {
+  if (F.is_modular) return -1.1715728752538099024f / F.epf_sigma_modular;      // Modular-encoded XYB frame: one sigma, no quant field / sharpness map
   const size_t o = (size_t)(y >> 3) * (size_t)F.xb + (size_t)(x >> 3);
   float sigma_quant = F.epf_quant_mul / (F.quant_scale * (float)((int)B.qfm1[o] + 1) * -1.1715728752538099024f);
   float sigma = sigma_quant * F.epf_sharp[B.sharp[o]];
@@ -464,7 +465,7 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   }
   const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
   float alpha = 1.0f;                                  // extra channel of type alpha (Modular-coded, integer samples)
-  if (F.has_ec && F.mod_out[3] >= 0) {
+  if ((F.has_ec || F.is_modular) && F.mod_out[3] >= 0) {
     const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)fy * (size_t)F.width + (size_t)fx];
     alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
     alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;

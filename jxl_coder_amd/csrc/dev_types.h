@@ -44,7 +44,9 @@ struct DevTreeNode {
   int32_t pad[3];
 };
 
-struct DevSection { uint32_t off, size; };   // byte range inside the codestream buffer
+struct DevSection { uint32_t off, size; };
+// One placement of a patch (ISO/IEC 18181-1 K.3): the w x h rectangle at (x0, y0) of reference slot `ref` is blended onto the frame at (x, y)
+struct DevPatch { int32_t ref, x0, y0, w, h, x, y, mode; };       // mode: 0 none, 1 replace, 2 add, 3 multiply (colour channels)   // byte range inside the codestream buffer
 
 // ---- per-frame parameters (host -> device, by value in the tables blob header)
 struct DevFrame {
@@ -98,15 +100,29 @@ struct DevFrame {
   uint32_t lz_win_len;             // LZ77 window entries of the GlobalModular stream (0: the frame's global code has no LZ77) ...
   uint32_t lz_win_group;           // ... and of each group stream; DevBuffers::lz_win = [lz_win_len][num_groups x lz_win_group]
   int32_t mod_nops;                // inverse global transforms, in execution order, with resolved plane indices
-  // kind 0: inverse RCT on planes a, b, c (x = type, y = samples); 1: channel palette (a = index plane, b = palette, x = colours, c = samples);
+  // kind 0: inverse RCT on planes a, b, c (x = type, y = samples); 1: palette without delta entries (a = index plane, which also receives colour 0, b = palette
+  // [num_c][nb_colours], x = nb_colours, y = bit depth, c = samples, e = num_c, d = first of the num_c - 1 consecutive planes of colours 1..); 4: palette
+  // with delta entries — a value is added to the d_pred prediction from the channel's own output, so each colour channel is one serial work item
+  // (c = e = num_c, d = first of num_c consecutive output planes, f = nb_deltas, g = d_pred, h = channel width; the height is in y's upper bits: y = bit depth | h << 8);
   // 2 / 3: inverse horizontal / vertical squeeze (a = average plane, b = residual plane, d = output plane, x, y = average w, h, e = residual extent
   // along the squeezed axis, c = independent lines: rows for 2, columns for 3).  Work items of op o: kind 0 ? y : c
-  int32_t mod_op_kind[kModMaxOps], mod_op_a[kModMaxOps], mod_op_b[kModMaxOps], mod_op_c[kModMaxOps], mod_op_x[kModMaxOps], mod_op_y[kModMaxOps], mod_op_d[kModMaxOps], mod_op_e[kModMaxOps];
+  int32_t mod_op_kind[kModMaxOps], mod_op_a[kModMaxOps], mod_op_b[kModMaxOps], mod_op_c[kModMaxOps], mod_op_x[kModMaxOps], mod_op_y[kModMaxOps], mod_op_d[kModMaxOps], mod_op_e[kModMaxOps],
+          mod_op_f[kModMaxOps], mod_op_g[kModMaxOps], mod_op_h[kModMaxOps];
   int32_t mod_out[4];              // planes feeding R, G, B, A (-1: opaque / replicate grey is done by repeating the index)
   int32_t mod_bits, mod_alpha_bits;
+  // Composition (frames that are not written straight from the last filter stage): reference frames of a patch dictionary, frames with patches.
+  // Such a frame keeps its image in the f32 planes after the filters (Modular-encoded frames are converted into them: k_mod_to_planes), the
+  // patches are blended there, then the frame is copied into a reference slot (host) and / or goes through the stand-alone writer.
+  int32_t compose;                 // 1: no fused writer, no column sweep
+  int32_t no_output;               // 1: a frame that is only stored as a reference (kReferenceOnly / saved, not the one shown): the writer skips it
+  int32_t xyb_modular;             // Modular-encoded frame of an XYB image: channels Y, X, B - Y, scaled by mod_xyb_fac (the LF dequantisation factors)
+  float mod_xyb_fac[3];
+  int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
+  int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter
   int32_t gab; float gab_w[3][2];
   int32_t epf_iters; float epf_sharp[8], epf_chscale[3], epf_quant_mul, epf_pass0, epf_pass2, epf_border_sad;
+  float epf_sigma_modular;         // Modular-encoded XYB frames: one sigma for the whole frame
   // colour
   float opsin_inv[9];              // already scaled by 255/intensity_target and target-primaries matrix
   float opsin_bias[3], opsin_bias_cbrt[3];

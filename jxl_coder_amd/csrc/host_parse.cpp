@@ -92,6 +92,7 @@ struct Priv {                 // state between phase 1 and phase 2
   frame_hdr f;
   DevFrame F;
   std::vector<DevSection> secs;
+  int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // reference slots as they are when this frame is decoded
 };
 
 static void fill_info(const img_meta &m, ImageInfo *i) {
@@ -103,6 +104,62 @@ static void fill_info(const img_meta &m, ImageInfo *i) {
   i->want_icc = p.want_icc; i->color_space = p.color_space; i->white_point = p.white_point; i->primaries = p.primaries;
   i->transfer_function = p.transfer_function; i->rendering_intent = p.rendering_intent; i->have_gamma = p.have_gamma; i->gamma = p.gamma;
   memcpy(i->wp_xy, m.wp_xy, sizeof(i->wp_xy)); memcpy(i->prim_xy, m.prim_xy, sizeof(i->prim_xy));
+}
+
+// Patch dictionary (K.3.1), at the head of LfGlobal when FrameHeader.flags has kPatches: entropy-coded with 10 contexts.  Every placement
+// becomes one DevPatch; the device blends them after the loop filters (dev_compose.h).
+static int parse_patches(FramePlan *plan, Priv *pv, hx_br *sb, Blob &blob) {
+  DevFrame &F = pv->F; const frame_hdr &f = pv->f; const img_meta &m = pv->m;
+  hx_ec ec;
+  if (hx_ec_read_header(&ec, sb, 10)) { plan->error = "patch dictionary: bad entropy header"; return -1; }
+  hx_ec_begin(&ec, sb, 0);
+  std::vector<DevPatch> out;
+  const char *err = nullptr;
+  const uint32_t num_ref = hx_ec_read(&ec, sb, 0);
+  const uint64_t frame_px = (uint64_t)f.coded_width * (uint64_t)f.coded_height;
+  if ((uint64_t)num_ref > frame_px + 1) err = "patch dictionary: too many patches";
+  uint64_t total = 0;
+  for (uint32_t id = 0; id < num_ref && !err; id++) {
+    DevPatch P; memset(&P, 0, sizeof(P));
+    P.ref = (int32_t)hx_ec_read(&ec, sb, 1);
+    P.x0 = (int32_t)hx_ec_read(&ec, sb, 3); P.y0 = (int32_t)hx_ec_read(&ec, sb, 3);
+    const uint32_t pw = hx_ec_read(&ec, sb, 2), ph = hx_ec_read(&ec, sb, 2);
+    if (P.ref < 0 || P.ref > 3 || pv->ref_w[P.ref] <= 0) { err = "patch dictionary: reference to an empty slot"; break; }
+    if (pw >= (1u << 24) || ph >= (1u << 24) || P.x0 < 0 || P.y0 < 0 || (uint64_t)P.x0 + pw + 1 > (uint64_t)pv->ref_w[P.ref] || (uint64_t)P.y0 + ph + 1 > (uint64_t)pv->ref_h[P.ref]) { err = "patch dictionary: patch outside its reference frame"; break; }
+    P.w = (int32_t)pw + 1; P.h = (int32_t)ph + 1;
+    const uint32_t count = hx_ec_read(&ec, sb, 7);
+    if ((uint64_t)count + 1 > frame_px) { err = "patch dictionary: too many placements"; break; }
+    for (uint32_t i = 0; i <= count && !err; i++) {
+      if (i == 0) { P.x = (int32_t)hx_ec_read(&ec, sb, 4); P.y = (int32_t)hx_ec_read(&ec, sb, 4); }
+      else { P.x += hx_unpack_signed(hx_ec_read(&ec, sb, 6)); P.y += hx_unpack_signed(hx_ec_read(&ec, sb, 6)); }
+      if (P.x < 0 || P.y < 0 || (int64_t)P.x + P.w > f.coded_width || (int64_t)P.y + P.h > f.coded_height) { err = "patch dictionary: placement outside the frame"; break; }
+      for (int j = 0; j <= m.num_extra; j++) {
+        const uint32_t mode = hx_ec_read(&ec, sb, 5);
+        if (mode >= 8) { err = "patch dictionary: bad blend mode"; break; }
+        if (mode >= 4 && m.num_extra > 1) (void)hx_ec_read(&ec, sb, 8);      // alpha channel of the alpha-weighted modes
+        if (mode >= 3) (void)hx_ec_read(&ec, sb, 9);                          // clamp flag (kMul and the alpha modes)
+        if (j == 0) {
+          if (mode >= 4) { err = "unsupported: alpha-weighted patch blending"; break; }
+          P.mode = (int32_t)mode;
+        } else if (mode != 0) { err = "unsupported: patches on extra channels"; break; }
+      }
+      if (err) break;
+      total += (uint64_t)P.w * (uint64_t)P.h;
+      if (out.size() >= (1u << 22) || total > ((uint64_t)1 << 33)) { err = "unsupported: patch dictionary beyond 2^22 placements"; break; }
+      if (P.mode != 0) out.push_back(P);
+    }
+    if (sb->err) { err = "truncated patch dictionary"; break; }
+  }
+  const int ok = hx_ec_final_ok(&ec);
+  hx_ec_free(&ec);
+  if (err) { plan->error = err; return -1; }
+  if (!ok || sb->err) { plan->error = "patch dictionary: ANS final state"; return -1; }
+  F.num_patches = (int32_t)out.size();
+  F.patch_off = blob.append(out.data(), out.size() * sizeof(DevPatch));
+  int mw = 1, mh = 1;
+  for (const DevPatch &P : out) { mw = std::max(mw, (int)P.w); mh = std::max(mh, (int)P.h); }
+  plan->patch_max_px = (size_t)mw * (size_t)mh;
+  return 0;
 }
 
 static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
@@ -155,7 +212,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   F.mod_group_dim = f.group_dim;
   F.mod_bits = (int)m.pub.bits_per_sample;
   if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
-  const int ncol = vardct ? 0 : m.pub.num_color_channels == 1 ? 1 : 3;
+  const int ncol = vardct ? 0 : (m.pub.num_color_channels == 1 && !m.pub.xyb_encoded) ? 1 : 3;
   struct Ch { int w, h, hs, vs, plane; };
   std::vector<Ch> L;
   for (int i = 0; i < ncol + m.num_extra; i++) {
@@ -184,9 +241,14 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       t.nb_colours = (int)hx_u32(sb, 8, 0, 10, 256, 12, 1280, 16, 5376);
       t.nb_deltas = (int)hx_u32(sb, -1, 0, 8, 1, 10, 257, 16, 1281);
       t.d_pred = (int)hx_bits(sb, 4);
-      if (t.num_c != 1 || t.nb_deltas != 0 || t.d_pred != 0) { plan->error = "unsupported: multi-channel / delta palette"; return -1; }
-      if (t.begin_c + t.num_c > (int)L.size() || t.nb_colours < 1 || t.nb_colours > 256 || t.begin_c < nb_meta) { plan->error = "unsupported: palette layout"; return -1; }
-      // meta-apply: one index channel stays at begin_c, the palette (nb_colours x num_c) becomes meta channel 0
+      if (t.nb_deltas > 0 && t.d_pred == 6) { plan->error = "unsupported: weighted-predictor delta palette"; return -1; }
+      if (t.d_pred > 13) { plan->error = "bad palette predictor"; return -1; }
+      if (t.num_c < 1 || t.begin_c + t.num_c > (int)L.size() || t.nb_colours < 0 || t.begin_c < nb_meta) { plan->error = "unsupported: palette layout"; return -1; }
+      for (int c = 1; c < t.num_c; c++)
+        if (L[(size_t)t.begin_c + c].w != L[(size_t)t.begin_c].w || L[(size_t)t.begin_c + c].h != L[(size_t)t.begin_c].h || L[(size_t)t.begin_c + c].hs != L[(size_t)t.begin_c].hs ||
+            L[(size_t)t.begin_c + c].vs != L[(size_t)t.begin_c].vs) { plan->error = "palette over channels of different size"; return -1; }
+      // meta-apply: the num_c channels collapse into one index channel at begin_c, the palette (nb_colours x num_c) becomes meta channel 0
+      L.erase(L.begin() + t.begin_c + 1, L.begin() + t.begin_c + t.num_c);
       L.insert(L.begin(), {t.nb_colours, t.num_c, -1, -1, -1});
       nb_meta++;
     } else if (t.id == 2) {
@@ -310,11 +372,30 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       if (a.w != b2.w || a.w != c2.w || a.h != b2.h || a.h != c2.h) { plan->error = "RCT over channels of different size"; return -1; }
       F.mod_op_y[o] = a.w * a.h;
     } else {
-      F.mod_op_kind[o] = 1;
-      F.mod_op_a[o] = L[(size_t)t.begin_c + 1].plane;     // index channel (after the meta channel was inserted at 0)
-      F.mod_op_b[o] = L[0].plane;
-      F.mod_op_x[o] = t.nb_colours; F.mod_op_y[o] = F.mod_bits;
-      F.mod_op_c[o] = L[(size_t)t.begin_c + 1].w * L[(size_t)t.begin_c + 1].h;
+      // inverse palette: the index channel (now at begin_c + 1, behind the palette meta channel) becomes num_c colour channels
+      const Ch ix = L[(size_t)t.begin_c + 1];
+      const bool deltas = t.nb_deltas > 0;
+      F.mod_op_kind[o] = deltas ? 4 : 1;
+      F.mod_op_a[o] = ix.plane; F.mod_op_b[o] = L[0].plane;
+      F.mod_op_x[o] = t.nb_colours; F.mod_op_e[o] = t.num_c;
+      F.mod_op_f[o] = t.nb_deltas; F.mod_op_g[o] = t.d_pred; F.mod_op_h[o] = ix.w;
+      F.mod_op_y[o] = deltas ? (F.mod_bits | (ix.h << 8)) : F.mod_bits;
+      F.mod_op_c[o] = deltas ? t.num_c : ix.w * ix.h;
+      if (deltas && ix.h >= (1 << 23)) { plan->error = "unsupported: palette channel height"; return -1; }
+      const int fresh = deltas ? t.num_c : t.num_c - 1;       // without deltas colour 0 replaces the index in place
+      if (nplanes + fresh > kModMaxPlanes) { plan->error = "unsupported: too many planes"; return -1; }
+      F.mod_op_d[o] = nplanes;
+      std::vector<Ch> outs;
+      for (int c = 0; c < t.num_c; c++) {
+        Ch oc = ix;
+        if (deltas || c > 0) {
+          oc.plane = nplanes; F.mod_plane_off[nplanes++] = (uint32_t)off; off += (uint64_t)ix.w * (uint64_t)ix.h + 64;
+          if (off > kPoolLimit) { plan->error = "unsupported: Modular image beyond 2^32 samples"; return -1; }
+        }
+        outs.push_back(oc);
+      }
+      L.erase(L.begin() + t.begin_c + 1);
+      L.insert(L.begin() + t.begin_c + 1, outs.begin(), outs.end());
       L.erase(L.begin());
     }
   }
@@ -352,9 +433,50 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
   return rc;
 }
 
+// One frame of the walk: its header, where its TOC starts and where the next frame header begins
+struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; };
+
+// TOC of the frame whose header ended at toc_bit: section table (logical order) and the byte where the frame's sections end
+static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t toc_bit, std::vector<DevSection> *secs, size_t *end_byte, std::string *error) {
+  hx_br br; hx_br_init(&br, cs, csn); br.pos = toc_bit;
+  const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
+  std::vector<uint32_t> perm;
+  if (hx_bool(&br)) {
+    hx_ec tc;
+    if (hx_ec_read_header(&tc, &br, 8)) { *error = "bad TOC permutation code"; return -1; }
+    hx_ec_begin(&tc, &br, 0);
+    perm.resize((size_t)nsec);
+    int e = hx_read_permutation(&tc, &br, perm.data(), (uint32_t)nsec, 0);
+    int ok = hx_ec_final_ok(&tc);
+    hx_ec_free(&tc);
+    if (e || !ok) { *error = "bad TOC permutation"; return -1; }
+  }
+  hx_align(&br);
+  std::vector<uint32_t> sz((size_t)nsec);
+  for (int i = 0; i < nsec; i++) sz[(size_t)i] = hx_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
+  hx_align(&br);
+  size_t base = br.pos / 8, acc = 0;
+  std::vector<size_t> phys((size_t)nsec);
+  for (int i = 0; i < nsec; i++) { phys[(size_t)i] = base + acc; acc += sz[(size_t)i]; }
+  if (base + acc > csn || br.err) { *error = "truncated file (TOC exceeds input)"; return -1; }
+  *end_byte = base + acc;
+  if (secs) {
+    secs->resize((size_t)nsec);
+    for (int i = 0; i < nsec; i++) {
+      size_t src = perm.empty() ? (size_t)i : perm[(size_t)i];
+      if (phys[src] > 0xFFFFFFFFull) { *error = "unsupported: codestream beyond 4 GiB"; return -1; }
+      (*secs)[(size_t)i].off = (uint32_t)phys[src]; (*secs)[(size_t)i].size = sz[src];
+    }
+  }
+  return 0;
+}
+
+static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_shown, uint32_t raw_w, uint32_t raw_h);
+
 int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   plan->error.clear();
   plan->tables.clear();
+  plan->refs.clear();
   uint8_t *cs; size_t csn; int owned;
   if (extract_codestream(data, size, &cs, &csn, &owned)) { plan->error = hx_last_error(); return -1; }
   if (owned) { plan->cs_owned.assign(cs, cs + csn); free(cs); plan->cs = plan->cs_owned.data(); }
@@ -379,83 +501,103 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   }
   if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
   if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
-  uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
-  int frame_index = 0;
-  bool slot_saved[4] = {false, false, false, false};
-  frame_hdr &f = pv->f;
-  int nsec = 0;
-  std::vector<DevSection> &secs = pv->secs;
+  const uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
+  // ---- the frame walk: every frame's header and TOC (its sections are skipped by their sizes), up to the frame marked is_last
+  std::vector<FrameRec> recs;
   for (;;) {
-  hx_align(&br);
-  if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { plan->error = hx_last_error(); return -1; }
-  if (getenv("JXLAMD_PARSE_TRACE"))
-    fprintf(stderr, "frame %d: type %d encoding %d is_last %d crop %d (%d,%d %dx%d) blend %d (all replace: %d) src %d duration %d save_ref %d before_ct %d flags %llu\n", frame_index, f.frame_type,
-            f.encoding, f.is_last, f.have_crop, f.x0, f.y0, f.width, f.height, f.blend_mode, !f.blend_not_replace, f.blend_source, f.duration, f.save_as_ref, f.save_before_ct, (unsigned long long)f.flags);
-  // Several frames (animation; the reference keeps what the LAST coalesced frame shows, interop/JxlDecoding.cpp:164-166): when the last frame
-  // covers the whole canvas and REPLACES it (no blending, no patches / LF frame taken from earlier frames) the earlier frames cannot show
-  // through — they are skipped by their TOC and only the last one is decoded.  Anything that needs the canvas of earlier frames is rejected.
-  const bool skip_this = !f.is_last;
-  if (!skip_this) {
-    if (f.frame_type != 0) { plan->error = "unsupported: non-regular last frame"; return -1; }
-    if (frame_index > 0 && f.blend_not_replace) { plan->error = "unsupported: multi-frame image whose last frame is blended with earlier frames"; return -1; }
+    hx_align(&br);
+    FrameRec r;
+    if (read_frame_header(&br, &m, raw_w, raw_h, &r.f)) { plan->error = hx_last_error(); return -1; }
+    const frame_hdr &f = r.f;
+    if (getenv("JXLAMD_PARSE_TRACE"))
+      fprintf(stderr, "frame %zu: type %d encoding %d is_last %d crop %d (%d,%d %dx%d) blend %d (all replace: %d) src %d duration %d save_ref %d before_ct %d flags %llu upsampling %d gab %d epf %d\n", recs.size(), f.frame_type,
+              f.encoding, f.is_last, f.have_crop, f.x0, f.y0, f.width, f.height, f.blend_mode, !f.blend_not_replace, f.blend_source, f.duration, f.save_as_ref, f.save_before_ct, (unsigned long long)f.flags, f.upsampling, f.gab, f.epf_iters);
+    r.toc_bit = br.pos;
+    if (read_toc(plan->cs, csn, f, r.toc_bit, nullptr, &r.end_byte, &plan->error)) return -1;
+    recs.push_back(r);
+    if (f.is_last) break;
+    if (recs.size() > 4096) { plan->error = "too many frames"; return -1; }
+    hx_br_init(&br, plan->cs, csn);
+    br.pos = r.end_byte * 8;
   }
-  if (!skip_this) {
+  // ---- which earlier frames does the shown frame need?  Several frames (animation; the reference keeps what the LAST coalesced frame shows,
+  // interop/JxlDecoding.cpp:164-166): when the last frame covers the whole canvas and REPLACES it, earlier frames show through only as the
+  // reference frames of its patch dictionary.  Those are decoded (in file order, each into its slot); every other frame is skipped.  A last frame
+  // that is blended with / cropped over the canvas of earlier frames is rejected.
+  const size_t last = recs.size() - 1;
+  {
+    const frame_hdr &f = recs[last].f;
+    if (f.frame_type != 0) { plan->error = "unsupported: non-regular last frame"; return -1; }
+    if (last > 0 && f.blend_not_replace) { plan->error = "unsupported: multi-frame image whose last frame is blended with earlier frames"; return -1; }
+  }
+  recs[last].needed = true;
+  std::vector<int> occupant_at((recs.size()) * 4, -1);      // [frame][slot]: which frame sits in the slot when this frame is decoded
+  {
+    int occ[4] = {-1, -1, -1, -1};
+    for (size_t i = 0; i < recs.size(); i++) {
+      for (int k = 0; k < 4; k++) occupant_at[i * 4 + (size_t)k] = occ[k];
+      const frame_hdr &f = recs[i].f;
+      // FrameHeader::CanBeReferenced: a frame of non-zero duration only stays around when it names a slot other than 0
+      if (!f.is_last && f.frame_type != 1 && (f.duration == 0 || f.save_as_ref != 0)) occ[f.save_as_ref & 3] = (int)i;
+    }
+  }
+  for (size_t i = recs.size(); i-- > 0;) {
+    if (!recs[i].needed) continue;
+    const frame_hdr &f = recs[i].f;
+    if (f.flags & 2) for (int k = 0; k < 4; k++) if (occupant_at[i * 4 + (size_t)k] >= 0) recs[(size_t)occupant_at[i * 4 + (size_t)k]].needed = true;    // patches may name any slot
+    if (i == last && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h) && occupant_at[i * 4 + (size_t)(f.blend_source & 3)] >= 0) {
+      plan->error = "unsupported: cropped frame over a saved reference frame"; return -1;
+    }
+  }
+  // ---- reference frames first (each its own FramePlan over the same codestream bytes), then the shown frame
+  int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0};
+  for (size_t i = 0; i < last; i++) {
+    if (!recs[i].needed) continue;
+    const frame_hdr &f = recs[i].f;
+    std::shared_ptr<FramePlan> sub = std::make_shared<FramePlan>();
+    sub->info = plan->info; sub->cs = plan->cs; sub->cs_size = plan->cs_size;
+    std::shared_ptr<Priv> spv = std::make_shared<Priv>();
+    sub->priv = spv;
+    spv->m = m; spv->f = f;
+    memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h));
+    if (f.frame_type != 0 && f.frame_type != 2) { plan->error = "unsupported: reference to an LF / skip-progressive frame"; return -1; }
+    if (f.frame_type == 0 && (f.blend_not_replace || (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)))) { plan->error = "unsupported: blended / cropped regular frame used as a reference"; return -1; }
+    if (!f.save_before_ct && m.pub.xyb_encoded) { plan->error = "unsupported: reference frame saved after the colour transform"; return -1; }
+    if (build_frame(sub.get(), spv.get(), recs[i], /*is_shown=*/false, raw_w, raw_h)) { plan->error = sub->error; return -1; }
+    sub->save_slot = f.save_as_ref & 3;
+    plan->refs.push_back(sub);
+    slot_w[f.save_as_ref & 3] = f.width; slot_h[f.save_as_ref & 3] = f.height;
+  }
+  pv->f = recs[last].f;
+  memcpy(pv->ref_w, slot_w, sizeof(slot_w)); memcpy(pv->ref_h, slot_h, sizeof(slot_h));
+  return build_frame(plan, pv, recs[last], /*is_shown=*/true, raw_w, raw_h);
+}
+
+// Everything a decoded frame needs from the host: checks of what the device path covers, TOC, LfGlobal (patch dictionary, quantiser, block
+// context map, colour correlation, global MA tree, GlobalModular header), HfGlobal, the DevFrame parameter block.
+static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_shown, uint32_t raw_w, uint32_t raw_h) {
+  img_meta &m = pv->m;
+  frame_hdr &f = pv->f;
+  const size_t csn = plan->cs_size;
+  std::vector<DevSection> &secs = pv->secs;
   if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
-  if (f.encoding == 1 && m.pub.xyb_encoded) { plan->error = "unsupported: lossy (XYB) Modular frame"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
-  if (f.encoding == 1 && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
+  if (f.encoding == 1 && !m.pub.xyb_encoded && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
   if (f.upsampling != 1) { plan->error = "unsupported: upsampling"; return -1; }
-  if (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
-    // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas unless an earlier frame was
-    // saved into that slot
+  if (is_shown && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
+    // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas (plan_parse has checked that no
+    // earlier frame was saved into that slot)
     if (f.blend_not_replace) { plan->error = "unsupported: cropped frame blended with a reference frame"; return -1; }
-    if (slot_saved[f.blend_source & 3]) { plan->error = "unsupported: cropped frame over a saved reference frame"; return -1; }
     if (f.width < 1 || f.height < 1) { plan->error = "empty frame"; return -1; }
     plan->cropped = true;
   }
+  if (!is_shown && (f.width < 1 || f.height < 1)) { plan->error = "empty frame"; return -1; }
   if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
-  if (f.flags & (1 | 2 | 16 | 32)) { plan->error = "unsupported: patches/splines/noise/LF frame"; return -1; }
+  if (f.flags & (1 | 16 | 32)) { plan->error = "unsupported: splines/noise/LF frame"; return -1; }
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
-  }
-  // ---- TOC
-  nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
-  std::vector<uint32_t> perm;
-  if (hx_bool(&br)) {
-    hx_ec tc;
-    if (hx_ec_read_header(&tc, &br, 8)) { plan->error = "bad TOC permutation code"; return -1; }
-    hx_ec_begin(&tc, &br, 0);
-    perm.resize((size_t)nsec);
-    int e = hx_read_permutation(&tc, &br, perm.data(), (uint32_t)nsec, 0);
-    int ok = hx_ec_final_ok(&tc);
-    hx_ec_free(&tc);
-    if (e || !ok) { plan->error = "bad TOC permutation"; return -1; }
-  }
-  hx_align(&br);
-  std::vector<uint32_t> sz((size_t)nsec);
-  for (int i = 0; i < nsec; i++) sz[(size_t)i] = hx_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
-  hx_align(&br);
-  secs.resize((size_t)nsec);
-  {
-    size_t base = br.pos / 8, acc = 0;
-    std::vector<size_t> phys((size_t)nsec);
-    for (int i = 0; i < nsec; i++) { phys[(size_t)i] = base + acc; acc += sz[(size_t)i]; }
-    if (base + acc > csn || br.err) { plan->error = "truncated file (TOC exceeds input)"; return -1; }
-    if (skip_this) {                       // the next frame header starts right after this frame's sections
-      // FrameHeader::CanBeReferenced: a frame of non-zero duration only stays around when it names a slot other than 0
-      if (f.frame_type != 1 && (f.duration == 0 || f.save_as_ref != 0)) slot_saved[f.save_as_ref & 3] = true;
-      hx_br_init(&br, plan->cs, csn);
-      br.pos = (base + acc) * 8;
-      if (++frame_index > 4096) { plan->error = "too many frames"; return -1; }
-      continue;
-    }
-    for (int i = 0; i < nsec; i++) {
-      size_t src = perm.empty() ? (size_t)i : perm[(size_t)i];
-      secs[(size_t)i].off = (uint32_t)phys[src]; secs[(size_t)i].size = sz[src];
-    }
-  }
-  break;
-  }
+  const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
+  { size_t end_byte = 0; if (read_toc(plan->cs, csn, f, rec.toc_bit, &secs, &end_byte, &plan->error)) return -1; }
   // ---- DevFrame
   DevFrame &F = pv->F;
   memset(&F, 0, sizeof(F));
@@ -473,6 +615,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   F.sec_off = blob.append(secs.data(), secs.size() * sizeof(DevSection));
   // ---- LfGlobal (section 0)
   hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
+  if ((f.flags & 2) && parse_patches(plan, pv, &sb, blob)) return -1;
   float lf_dequant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   if (!hx_bool(&sb)) for (int c = 0; c < 3; c++) lf_dequant[c] = hx_f16(&sb) * (1.0f / 128);
   uint32_t global_scale = 1, quant_lf = 1;
@@ -544,6 +687,9 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   F.gab = f.gab; memcpy(F.gab_w, f.gab_w, sizeof(F.gab_w));
   F.epf_iters = f.epf_iters; memcpy(F.epf_sharp, f.epf_sharp, sizeof(F.epf_sharp)); memcpy(F.epf_chscale, f.epf_chscale, sizeof(F.epf_chscale));
   F.epf_quant_mul = f.epf_quant_mul; F.epf_pass0 = f.epf_pass0; F.epf_pass2 = f.epf_pass2; F.epf_border_sad = f.epf_border_sad;
+  F.epf_sigma_modular = f.epf_sigma_modular;
+  F.xyb_modular = (f.encoding == 1 && m.pub.xyb_encoded) ? 1 : 0;
+  for (int c = 0; c < 3; c++) F.mod_xyb_fac[c] = lf_dequant[c];
   // colour: opsin inverse scaled to display-relative linear, then to the data profile's primaries
   {
     double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -583,6 +729,13 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
   }
   F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;
   F.canvas_w = (int)raw_w; F.canvas_h = (int)raw_h; F.crop_x0 = f.have_crop ? f.x0 : 0; F.crop_y0 = f.have_crop ? f.y0 : 0;
+  if (!is_shown) { F.canvas_w = f.width; F.canvas_h = f.height; F.crop_x0 = F.crop_y0 = 0; F.orientation = 1; F.out_w = f.width; F.out_h = f.height; }
+  F.no_output = is_shown ? 0 : 1;
+  // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
+  // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
+  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded)) ? 1 : 0;
+  plan->compose = F.compose != 0;
+  memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;
   F.band_scy0 = 0; F.band_scy1 = F.yb; F.band_g0 = 0; F.band_lfg0 = 0;
   plan->single_section = nsec == 1;

@@ -34,6 +34,12 @@ struct FramePlan {
   bool cropped = false;                                  // the decoded frame does not cover the image (have_crop): the output is cleared first
   bool has_ec = false;                                   // VarDCT frame with Modular-coded extra channels (alpha)
   size_t mod_pool_ints = 0;                              // int32 samples in the channel-plane pool
+  // Composition (dev_compose.h).  refs: the earlier frames of the file this frame's patch dictionary draws on, in file order — each a complete
+  // plan of its own over the same codestream bytes, decoded first and copied into reference slot save_slot.
+  std::vector<std::shared_ptr<FramePlan>> refs;
+  int save_slot = -1;                                    // a plan inside `refs`: where its image goes
+  bool compose = false;                                  // the frame keeps its image in the f32 planes after the filters (reference frame / patches / XYB Modular)
+  size_t patch_max_px = 0;                               // largest patch rectangle (launch geometry of the blend kernel)
   bool hf_parsed = false;
   uint32_t lf_global_end_bit = 0;                        // single-section: where LfGroup 0 begins
   // geometry copies for the launcher

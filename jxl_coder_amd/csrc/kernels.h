@@ -4,6 +4,7 @@
 #include "dev_bodies.h"
 #include "dev_modframe.h"
 #include "dev_pass_flat.h"
+#include "dev_compose.h"
 namespace jxlamd {
 // pool_bytes: LDS table pool per stream of this launch (kModPoolMin .. kModPoolBytes, dev_modular.h); lf_pool_clamp turns what the streams of
 // a decode reported (word 1 of a frame's flag block) into the value for the next one
@@ -41,6 +42,11 @@ void launch_mod_groups(const DevBuffers &B, int num_groups, hipStream_t s);
 void launch_mod_lfgroups(const DevBuffers &B, int num_lf_groups, hipStream_t s);      // ModularLfGroup streams of a Modular-encoded frame
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s);
 void launch_mod_write(const DevBuffers &B, int width, int height, int out_bits, hipStream_t s);
+// composition stages (dev_compose.h): frames with a patch dictionary and the reference frames it draws on
+void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s);
+void launch_patch_blend(const DevBuffers &B, int num_patches, size_t max_px, hipStream_t s);
+void launch_save_ref(const DevBuffers &B, int w, int h, float *dst, hipStream_t s);
+void launch_compose_write(const DevBuffers &B, const uint8_t *stat, int w, int h, hipStream_t s);
 void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s);
 void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s);
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s);

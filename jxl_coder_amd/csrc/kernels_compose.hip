@@ -1,0 +1,54 @@
+// jxl_coder_amd/csrc/kernels_compose.hip — HIP kernels (gfx950) of the composition stages (dev_compose.h): Modular planes -> f32 planes,
+// patch blending, copy into a reference slot, the stand-alone writer of composed frames.  All of them are plain streaming kernels over
+// pixels (HBM-bound, a few bytes per pixel); frames that need them are rare next to the flights of ordinary frames and run one by one.
+#include "kernels_common.h"
+#include "dev_compose.h"
+
+namespace jxlamd {
+
+__global__ void __launch_bounds__(256) k_mod_to_planes(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height || frame_failed(B)) return;
+  mod_to_planes_pixel(B, F, x, y);
+}
+// grid (placements, ceil(largest patch / 256)): one placement per blockIdx.x, its pixels over the threads
+__global__ void __launch_bounds__(256) k_patch_blend(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  if (frame_failed(B)) return;
+  const DevPatch P = ((const DevPatch *)(B.tables + F.patch_off))[blockIdx.x];
+  const int n = P.w * P.h;          // <= 2^31: both bounded by the reference frame's size
+  for (int item = (int)(blockIdx.y * 256 + threadIdx.x); item < n; item += (int)(gridDim.y * 256)) patch_blend_sample(B, F, P, item);
+}
+__global__ void __launch_bounds__(256) k_save_ref(DevBuffers B, float *d0, float *d1, float *d2) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height) return;
+  float *dst[3] = {d0, d1, d2};
+  save_ref_pixel(B, F, dst, x, y);
+}
+__global__ void __launch_bounds__(256) k_compose_write(DevBuffers B, const uint8_t *stat) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height || frame_failed(B)) return;
+  if (F.is_modular && !F.xyb_modular) { plain_write_pixel(B, B.out_bits, x, y); return; }
+  float *src[3];
+  for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
+  xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
+}
+
+void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s) { hipLaunchKernelGGL(k_mod_to_planes, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B); }
+void launch_patch_blend(const DevBuffers &B, int num_patches, size_t max_px, hipStream_t s) {
+  if (num_patches <= 0) return;
+  // placements beyond 2^22 are refused by the parser; large patches loop
+  hipLaunchKernelGGL(k_patch_blend, dim3((unsigned)num_patches, (unsigned)std::min<size_t>((max_px + 255) / 256, 4096)), dim3(256), 0, s, B);
+}
+void launch_save_ref(const DevBuffers &B, int w, int h, float *dst, hipStream_t s) {
+  const size_t n = (size_t)w * (size_t)h;
+  hipLaunchKernelGGL(k_save_ref, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, dst, dst + n, dst + 2 * n);
+}
+void launch_compose_write(const DevBuffers &B, const uint8_t *stat, int w, int h, hipStream_t s) {
+  hipLaunchKernelGGL(k_compose_write, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B, stat);
+}
+
+}  // namespace jxlamd

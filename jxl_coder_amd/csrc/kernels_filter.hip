@@ -20,7 +20,7 @@ __device__ __forceinline__ bool stage_src_is_a(const DevFrame &F, int stage) {
 // SIMDs with resident entropy-decode waves, and their occupancy is what is left of the register file.
 // The last filter stage of a frame (EPF iteration 1 or 2, or Gaborish when there is no EPF) is fused with the writer: its
 // XYB value goes straight through the colour transform into the RGBA buffer (no plane store + reload, no writer launch).
-__device__ __forceinline__ int last_filter_stage(const DevFrame &F) { return F.epf_iters >= 2 ? 3 : F.epf_iters == 1 ? 2 : F.gab ? 0 : -1; }
+__device__ __forceinline__ int last_filter_stage(const DevFrame &F) { return F.compose ? -1 : F.epf_iters >= 2 ? 3 : F.epf_iters == 1 ? 2 : F.gab ? 0 : -1; }     // composed frames: every stage stores its planes (dev_compose.h)
 // Band decode: rows of context the stages AFTER `stage` still need around the band (EPF iteration 0 reads +-3 rows, 1: +-2, 2: +-1),
 // i.e. how far beyond the band this stage has to produce output.  0 for the frame's last stage.
 __device__ __forceinline__ int stage_halo_after(const DevFrame &F, int stage) {
@@ -31,7 +31,8 @@ template <int STAGE>
 __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
-  if (F.is_modular || !stage_runs(F, STAGE) || frame_failed(B)) return;
+  if ((F.is_modular && !F.xyb_modular) || !stage_runs(F, STAGE) || frame_failed(B)) return;
+  if (STAGE == 4 && F.compose) return;                       // composed frames have their own writer stage (k_compose_write)
   if (sweep_on && frame_uses_sweep(F)) return;                // k_filter_sweep produces this frame's pixels
   const int last = last_filter_stage(F);
   if (STAGE == 4 && last >= 0) return;                       // the writer was fused into stage `last`
@@ -67,7 +68,7 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
 // last bits only.  Frames with three EPF iterations (12-tap first pass) stay on the per-stage kernels.
 __device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }    // lane - 1: x - 1
 __device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // lane + 1: x + 1
-__device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && F.epf_iters <= 2; }
+__device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && !F.compose && F.epf_iters <= 2; }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 template <bool kGab, int kEpf>
@@ -205,7 +206,7 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
     if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0>), g, dim3(256), 0, s, Bs, stat, rows);
     if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1>), g, dim3(256), 0, s, Bs, stat, rows);
     if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (!(stage_mask & 2)) return;
+    if (!(stage_mask & (2 | 32))) return;                       // 32: a composed frame — stage by stage whatever its filters
   }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
   if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat, sweep);

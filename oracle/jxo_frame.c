@@ -1240,7 +1240,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
     float cb[3];
     for (int c = 0; c < 3; c++) cb[c] = cbrtf(m.opsin_bias[c]);
     double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (m.pub.primaries != 1 || m.pub.white_point != 1) {
+    if ((m.pub.primaries != 1 && m.pub.primaries != 0) || m.pub.white_point != 1) {      /* 0: grey image (no primaries): the XYB data decodes to sRGB-primaries grey */
       static const double srgb[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
       double dst[8];
       if (m.pub.white_point != 1) { jxo_set_error("unsupported: non-D65 white point"); goto done; }

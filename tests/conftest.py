@@ -80,11 +80,21 @@ LOSSLESS_CASES = ["l64_e1", "l64_e3", "l64_e7", "l200x120_e7", "l512_e7", "l300x
 # restates it too (jxo_modular.c: meta_apply / inv_squeeze), so these run through the oracle tests as well
 SQUEEZE_LOSSLESS_CASES = ["lr130x300_e7", "lrg300x200_e7", "lra200x150_e5", "lr2100x40_e3"]      # the last one: beyond 2048 px, residual channels in the ModularLfGroup streams
 LOSSLESS_CASES = LOSSLESS_CASES + SQUEEZE_LOSSLESS_CASES
+# Non-photographic content from the reference's encoder at its defaults (tools/synth.py: screenshot / flat / gradient / two_colour / many_colours):
+# multi-channel palettes (e1 / e3), palettes local to a group stream, > 256 palette entries, RGBA.  Single-frame files: the C oracle decodes them too.
+NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls700x500_e7_nopatch", "lgrad400x300_e7", "lgrad2d200x150_e3", "lflat400x300_e7",
+                           "l2c400x300_e7", "lmany128x96_e3"]
+LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
+# Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
+# encoder writes for text / UI content at effort >= 5, lossless and lossy.  Two frames: pinned on the reference binary's output only (the C oracle does
+# not walk multi-frame files), on the CPU harness and on the GPU.
+PATCH_LOSSLESS_CASES = ["ls400x300_e7", "ls700x500_e5", "lsa400x300_e7"]
+PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1"]      # VarDCT main frame, XYB Modular reference frame
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
-VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2"]          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
+VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7"]      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).

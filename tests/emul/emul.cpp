@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../jxl_coder_amd/csrc/dev_bodies.h"
 #include "../../jxl_coder_amd/csrc/dev_modframe.h"
+#include "../../jxl_coder_amd/csrc/dev_compose.h"
 #include "../../jxl_coder_amd/csrc/dev_pass_flat.h"
 #include "../../jxl_coder_amd/csrc/host_parse.h"
 
@@ -19,6 +20,45 @@ struct NoSync { void operator()() const {} };
 static std::string g_err;
 
 extern "C" const char *emul_last_error() { return g_err.c_str(); }
+
+
+
+// the loop filters, one stage after the other (the per-stage kernels k_filter_b)
+static void filter_stages(const DevBuffers &B, const DevFrame &F) {
+  bool a = true;
+  auto planes = [&](bool isa, float *p[3]) { for (int c = 0; c < 3; c++) p[c] = isa ? B.plane_a[c] : B.plane_b[c]; };
+  float *src[3], *dst[3];
+  if (F.gab) { planes(a, src); planes(!a, dst); for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) gab_pixel(F, src, dst, x, y); a = !a; }
+  for (int pass = 0; pass < 3; pass++) {
+    bool run = pass == 0 ? F.epf_iters >= 3 : pass == 1 ? F.epf_iters >= 1 : F.epf_iters >= 2;
+    if (!run) continue;
+    planes(a, src); planes(!a, dst);
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) epf_pixel(B, F, src, dst, pass, x, y);
+    a = !a;
+  }
+}
+
+struct RefStore { std::vector<float> p[4][3]; };
+
+// composition tail (jxlamd_decoder::launch_compose_tail): patches, copy into the reference slot, stand-alone writer
+static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F, int out_bits, RefStore &refs, const uint8_t *stat) {
+  const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
+  for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
+  if (plan.save_slot >= 0) {
+    float *dst[3];
+    for (int c = 0; c < 3; c++) { refs.p[plan.save_slot][c].assign((size_t)F.width * F.height, 0.f); dst[c] = refs.p[plan.save_slot][c].data(); }
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) save_ref_pixel(B, F, dst, x, y);
+  }
+  if (F.no_output) return;
+  float *src[3];
+  for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
+  for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) {
+    if (F.is_modular && !F.xyb_modular) plain_write_pixel(B, out_bits, x, y);
+    else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, out_bits, x, y);
+  }
+}
+
+static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs);
 
 extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t *out, size_t out_cap, uint32_t *w, uint32_t *h, uint32_t *bits) {
   FramePlan plan;
@@ -32,6 +72,12 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
       for (size_t i = 0; i < out_bytes / (4 * (size_t)(out_bits / 8)); i++) { if (out_bits == 16) ((uint16_t *)out)[i * 4 + 3] = 65535; else out[i * 4 + 3] = 255; }
   }
   if (out_cap < out_bytes) { g_err = "buffer"; return -5; }
+  RefStore refs;
+  for (auto &r : plan.refs) { int rc = run_frame(*r, out_bits, nullptr, refs); if (rc) return rc; }      // the frames the patch dictionary draws on, each into its slot
+  return run_frame(plan, out_bits, out, refs);
+}
+
+static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs) {
   const size_t ncell = (size_t)plan.xb * plan.yb, ntile = (size_t)((plan.xb + 7) / 8) * ((plan.yb + 7) / 8), npx = ncell * 64;
   std::vector<uint8_t> cs(plan.cs, plan.cs + plan.cs_size); cs.resize(cs.size() + 64, 0);
   std::vector<uint8_t> c8[5]; for (auto &v : c8) v.assign(ncell, 0);
@@ -52,6 +98,7 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   B.xfromy = tl[0].data(); B.bfromy = tl[1].data();
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = errw; B.out = out;
+  for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data();
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
@@ -75,7 +122,13 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
     delete MS;
     if (err) { g_err = "device flags " + std::to_string(err) + " (Modular)"; return -2; }
     for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
-    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) mod_write_pixel(B, out_bits, x, y);
+    if (!F.compose) {
+      for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) mod_write_pixel(B, out_bits, x, y);
+      return 0;
+    }
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) mod_to_planes_pixel(B, F, x, y);
+    if (F.xyb_modular) filter_stages(B, F);
+    compose_tail(plan, B, F, out_bits, refs, stat.data());
     return 0;
   }
   DevModScratch *MS = new DevModScratch();
@@ -129,18 +182,10 @@ extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t
   }
   if (err) { g_err = "device flags " + std::to_string(err) + " (recon)"; return -2; }
   const DevFrame &F = *(const DevFrame *)tables.data();
-  bool a = true;
-  auto planes = [&](bool isa, float *p[3]) { for (int c = 0; c < 3; c++) p[c] = isa ? B.plane_a[c] : B.plane_b[c]; };
-  float *src[3], *dst[3];
-  if (F.gab) { planes(a, src); planes(!a, dst); for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) gab_pixel(F, src, dst, x, y); a = !a; }
-  for (int pass = 0; pass < 3; pass++) {
-    bool run = pass == 0 ? F.epf_iters >= 3 : pass == 1 ? F.epf_iters >= 1 : F.epf_iters >= 2;
-    if (!run) continue;
-    planes(a, src); planes(!a, dst);
-    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) epf_pixel(B, F, src, dst, pass, x, y);
-    a = !a;
-  }
-  planes(a, src);
+  filter_stages(B, F);
+  if (F.compose) { compose_tail(plan, B, F, out_bits, refs, stat.data()); return 0; }
+  float *src[3];
+  for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
   for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) xyb_write_pixel(B, stat.data(), *(const DevStatic *)stat.data(), src, out_bits, x, y);
   return 0;
 }

@@ -68,7 +68,56 @@ CASES = {
     "vo264x300_e7_o6": (264, 300, dict(seed=42), dict(effort=7, orientation=6)),              # several groups, ragged edges, rotated
     "lo40x24_e7_o5": (40, 24, dict(seed=43), dict(lossless=True, effort=7, orientation=5)),   # the Modular writer's re-orientation
     "lo200x120_e7_o8": (200, 120, dict(seed=44), dict(lossless=True, effort=7, orientation=8)),
+    # ---- non-photographic content (synth.screenshot / flat / gradient / two_colour), encoder at the reference's defaults (interop/JxlEncoding.cpp:145-160:
+    # distance + effort only).  Lossless: multi-channel palettes (e1 / e3), group-level palettes (700x500 without patches), e7 = a kReferenceOnly
+    # Modular frame with the glyph patches + a main frame that adds them back.  Lossy: VarDCT main frame + patches from an XYB Modular reference frame.
+    "ls400x300_e1": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=1)),
+    "ls400x300_e3": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=3)),
+    "lsa400x300_e3": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(lossless=True, effort=3)),
+    "ls700x500_e7_nopatch": (700, 500, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((8, 0),))),
+    "lgrad400x300_e7": (400, 300, dict(gen="gradient1d"), dict(lossless=True, effort=7)),
+    "lgrad2d200x150_e3": (200, 150, dict(gen="gradient"), dict(lossless=True, effort=3)),
+    "lflat400x300_e7": (400, 300, dict(gen="flat"), dict(lossless=True, effort=7)),
+    "l2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(lossless=True, effort=7)),
+    "lmany128x96_e3": (128, 96, dict(gen="many_colours", seed=5), dict(lossless=True, effort=3)),          # palette of ~1000 colours (beyond 256 entries)
+    "ls400x300_e7": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=7)),              # patches
+    "ls700x500_e5": (700, 500, dict(gen="screenshot", seed=2), dict(lossless=True, effort=5)),              # patches over several groups
+    "lsa400x300_e7": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(lossless=True, effort=7)), # patches + alpha
+    "vs400x300_e7_d1": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=1.0)),
+    "vs400x300_e7_d3": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=3.0)),
+    "vs400x300_e9_d1": (400, 300, dict(gen="screenshot", seed=1), dict(effort=9, distance=1.0)),
+    "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
+    "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
+    "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
 }
+
+
+def make_image(w, h, sk):
+    """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
+    sk = dict(sk)
+    gen = sk.pop("gen", "photo")
+    alpha = sk.pop("alpha", False)
+    grey = sk.pop("grey", False)
+    if gen == "photo":
+        img = synth.photo_like(w, h, **sk)
+        if grey:
+            img = np.ascontiguousarray(img[..., :1])
+        if alpha:
+            img = with_alpha(img)
+        return img
+    if gen == "screenshot":
+        return synth.screenshot(w, h, sk.get("seed", 0), channels=4 if alpha else 3)
+    if gen == "flat":
+        return synth.flat(w, h)
+    if gen == "gradient":
+        return synth.gradient(w, h)
+    if gen == "gradient1d":
+        return np.ascontiguousarray(np.repeat(synth.gradient(w, 1), h, axis=0))
+    if gen == "two_colour":
+        return synth.two_colour(w, h, sk.get("seed", 0))
+    if gen == "many_colours":
+        return synth.many_colours(w, h, sk.get("seed", 0))
+    raise ValueError(gen)
 
 
 # Tall multi-LF-group frames for the band-sharded decode (BASELINE config 4 in miniature): 17 group rows = 3 LF-group rows.
@@ -159,16 +208,7 @@ def main():
     for name, (w, h, sk, ek) in CASES.items():
         if only and name not in only:
             continue
-        sk = dict(sk)
-        alpha = sk.pop("alpha", False)
-        grey = sk.pop("grey", False)
-        img = synth.photo_like(w, h, **sk)
-        if grey:
-            img = np.ascontiguousarray(img[..., :1])
-            sk["grey"] = True
-        if alpha:
-            img = with_alpha(img)
-            sk["alpha"] = True
+        img = make_image(w, h, sk)
         data = jxl_ref.encode(img, **ek)
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)

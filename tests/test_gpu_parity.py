@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
-                      LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, load_case)
+                      LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -197,6 +197,29 @@ def test_lossless_bit_exact(dec, name):
     out, info = dec.decode_one_shot(data)
     assert out.dtype == exp.dtype and np.array_equal(out, exp)
     assert info["uses_original_profile"] == 1
+
+
+@pytest.mark.parametrize("name", PATCH_LOSSLESS_CASES + PATCH_VARDCT_CASES)
+def test_patch_frames(dec, name):
+    """Patch dictionaries (what the reference's encoder writes for text / UI content at effort >= 5): the kReferenceOnly frame goes into its reference
+    slot, the main frame gets the patches blended after its loop filters (kernels_compose.hip).  Lossless bit-exact, lossy within the VarDCT
+    tolerance; through the batch entry point (next to an ordinary frame) the pixels are the same."""
+    import torch
+    data, exp = load_case(name)
+    out, info = dec.decode_one_shot(data)
+    if name in PATCH_LOSSLESS_CASES:
+        assert np.array_equal(out, exp)
+    else:
+        d = np.abs(out.astype(int) - exp.astype(int))
+        assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (d.max(), d.mean())
+    other, _ = load_case("v264x520_e7")
+    single_other, _ = dec.decode_one_shot(other)
+    bufs = [torch.empty(out.size, dtype=torch.uint8, device="cuda:0"), torch.empty(single_other.size, dtype=torch.uint8, device="cuda:0"),
+            torch.empty(out.size, dtype=torch.uint8, device="cuda:0")]
+    dec.decode_batch_to_device([data, other, data], [b.data_ptr() for b in bufs], [b.numel() for b in bufs])
+    torch.cuda.synchronize()
+    assert np.array_equal(bufs[0].cpu().numpy().reshape(out.shape), out) and np.array_equal(bufs[2].cpu().numpy().reshape(out.shape), out)
+    assert np.array_equal(bufs[1].cpu().numpy().reshape(single_other.shape), single_other)
 
 
 def test_flight_subflights_and_pools_in_a_small_configuration():

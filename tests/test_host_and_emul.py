@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, load_case)
+                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, load_case)
 
 import jxl_coder_amd as J
 
@@ -198,6 +198,19 @@ def test_device_code_lossless_bit_exact_on_cpu_harness(emul, name):
     data, exp = load_case(name)
     out = emul(data)
     assert out.dtype == exp.dtype and np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("name", PATCH_LOSSLESS_CASES + PATCH_VARDCT_CASES)
+def test_patch_frames_on_cpu_harness(emul, name):
+    """Files with a patch dictionary: the kReferenceOnly frame is decoded into its slot, the main frame (Modular or VarDCT) gets the patches added
+    after its loop filters (dev_compose.h).  Lossless bit-exact, lossy within the VarDCT tolerance — against the reference binary's output."""
+    data, exp = load_case(name)
+    out = emul(data)
+    if name in PATCH_LOSSLESS_CASES:
+        assert np.array_equal(out, exp)
+    else:
+        d = np.abs(out.astype(int) - exp.astype(int))
+        assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (d.max(), d.mean())
 
 
 def test_entropy_kernels_use_no_scratch():
