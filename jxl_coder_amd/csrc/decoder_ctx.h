@@ -92,7 +92,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
   PinnedMem h_tables, h_cs, h_B;
   DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win;
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win, up_planes;
   FramePlan plan;
   DevBuffers B;
   DevAux A;

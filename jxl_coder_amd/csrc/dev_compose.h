@@ -52,6 +52,41 @@ JXL_DEV void patch_blend_sample(const DevBuffers &B, const DevFrame &F, const De
   }
 }
 
+// Upsampling (factor 2 / 4 / 8): output pixel (X, Y) = the 5 x 5 neighbourhood of coded pixel (X / N, Y / N) weighted by the kernel of its phase
+// (X % N, Y % N), clamped to the neighbourhood's range; the frame edges are mirrored.  Multiply and add stay separate (the reference's libjxl is an
+// SSE2 build: no fused multiply-add), rows outer, columns inner.
+JXL_DEV void upsample_pixel(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int X, int Y) {
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const int N = F.upsampling, sh = N == 2 ? 1 : N == 4 ? 2 : 3;
+  const int x = X >> sh, y = Y >> sh, ox = X & (N - 1), oy = Y & (N - 1);
+  const float *k = (const float *)(stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
+  const bool a = compose_final_is_a(F);
+  int xs[5], ys[5];
+  for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.width); ys[i] = mirror(y + i - 2, F.height); }
+  for (int c = 0; c < 3; c++) {
+    const float *src = a ? B.plane_a[c] : B.plane_b[c];
+    float acc = 0.0f, mn = src[(size_t)ys[2] * (size_t)F.pw + (size_t)xs[2]], mx = mn;
+    for (int iy = 0; iy < 5; iy++)
+      for (int ix = 0; ix < 5; ix++) {
+        const float v = src[(size_t)ys[iy] * (size_t)F.pw + (size_t)xs[ix]];
+#ifdef __HIPCC__
+        acc = __fadd_rn(__fmul_rn(k[iy * 5 + ix], v), acc);
+#else
+        acc = k[iy * 5 + ix] * v + acc;
+#endif
+        mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+      }
+    acc = acc < mn ? mn : acc > mx ? mx : acc;
+    B.up[c][(size_t)Y * (size_t)F.full_w + (size_t)X] = acc;
+  }
+}
+// writer of an upsampled XYB frame: full-resolution planes -> colour transform -> RGBA
+JXL_DEV void upsampled_write_pixel(const DevBuffers &B, const uint8_t *stat, int out_bits, int X, int Y) {
+  const DevFrame &F = frame_of(B);
+  const size_t o = (size_t)Y * (size_t)F.full_w + (size_t)X;
+  xyb_write_value(B, stat, *(const DevStatic *)stat, B.up[0][o], B.up[1][o], B.up[2][o], out_bits, X, Y);
+}
+
 // copy the composed frame into a reference slot (dense w x h planes)
 JXL_DEV void save_ref_pixel(const DevBuffers &B, const DevFrame &F, float *const dst[3], int x, int y) {
   const bool a = compose_final_is_a(F);

@@ -795,6 +795,10 @@ __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S,
                      : modular_decode_channels_wave<false, kGeneral>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
   __syncthreads();
   if (err == kErrWaveFallback) {
+    // An earlier channel of the stream may have re-used the table pool (packed alias tables of the weighted-predictor loop, compact restaging):
+    // the serial walker starts the stream over and needs the tables as modular_stream_stage laid them out
+    modular_stream_stage(S, lane, 64);
+    __syncthreads();
     if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);
     __syncthreads();
     return S.fallback_err;

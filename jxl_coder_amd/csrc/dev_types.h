@@ -117,6 +117,8 @@ struct DevFrame {
   int32_t no_output;               // 1: a frame that is only stored as a reference (kReferenceOnly / saved, not the one shown): the writer skips it
   int32_t xyb_modular;             // Modular-encoded frame of an XYB image: channels Y, X, B - Y, scaled by mod_xyb_fac (the LF dequantisation factors)
   float mod_xyb_fac[3];
+  int32_t upsampling;              // 1, or 2 / 4 / 8: width / height above are the CODED size, the frame shows full_w x full_h pixels (K.? Upsampling, after the patches)
+  int32_t full_w, full_h;
   int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter
@@ -153,6 +155,7 @@ struct DevStatic {
   uint32_t afv_off;            // float[16*16]
   uint32_t dither_off;         // float[32*32]
   uint32_t llf_off;            // float[6][32]: 1/(cos t cos 2t cos 4t), t = k pi/(16 N), N = 1<<i
+  uint32_t ups_off[3];         // float[N][N][5][5], N = 2 / 4 / 8: the default upsampling kernels of every output phase (mirrored phases expanded)
   uint32_t nat_order_off[13];  // u32[covered cells * 64]: the natural coefficient order of each order bucket (frames without a coded permutation)
 };
 constexpr uint32_t kOrderInStatic = 0x80000000u;   // DevFrame::order_off: the order lives in the static tables (natural order), not in the frame blob

@@ -24,6 +24,7 @@ typedef struct { int nbands; float b[3][8]; } hx_dctparams;
 #include "host_format.inc"
 #include "host_icc.inc"
 #include "dither_lut.h"
+#include "upsampling_weights.h"
 }  // namespace
 
 namespace jxlamd {
@@ -584,7 +585,13 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
   if (f.encoding == 1 && !m.pub.xyb_encoded && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
-  if (f.upsampling != 1) { plan->error = "unsupported: upsampling"; return -1; }
+  if (f.upsampling != 1) {
+    // an upsampled frame (what the reference's encoder writes from distance 10 up, i.e. its quality <= 12: interop/JxlEncoding.cpp:38-46) is coded at
+    // ceil(size / upsampling) and enlarged after the patches (dev_compose.h)
+    if (m.num_extra) { plan->error = "unsupported: upsampling of a frame with extra channels"; return -1; }
+    if (!m.pub.xyb_encoded) { plan->error = "unsupported: upsampling of a frame that is not XYB"; return -1; }
+    if (!is_shown) { plan->error = "unsupported: upsampled reference frame"; return -1; }
+  }
   if (is_shown && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
     // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas (plan_parse has checked that no
     // earlier frame was saved into that slot)
@@ -601,8 +608,9 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // ---- DevFrame
   DevFrame &F = pv->F;
   memset(&F, 0, sizeof(F));
-  F.width = f.width; F.height = f.height;
-  F.xb = (f.width + 7) / 8; F.yb = (f.height + 7) / 8; F.pw = F.xb * 8; F.ph = F.yb * 8;
+  F.width = f.coded_width; F.height = f.coded_height;          // (an upsampled frame: the coded size; its pixels are full_w x full_h)
+  F.upsampling = f.upsampling; F.full_w = f.width; F.full_h = f.height;
+  F.xb = (F.width + 7) / 8; F.yb = (F.height + 7) / 8; F.pw = F.xb * 8; F.ph = F.yb * 8;
   F.tiles_x = (F.xb + 7) / 8; F.tiles_y = (F.yb + 7) / 8;
   F.xgroups = f.xgroups; F.ygroups = f.ygroups; F.num_groups = f.num_groups;
   F.xlfg = f.xlfg; F.ylfg = f.ylfg; F.num_lf_groups = f.num_lf_groups;
@@ -733,7 +741,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   F.no_output = is_shown ? 0 : 1;
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
-  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded)) ? 1 : 0;
+  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;
@@ -789,6 +797,21 @@ static void build_static_tables(std::vector<uint8_t> &tab) {
   }
   { float a[256]; for (int j = 0; j < 16; j++) for (int i = 0; i < 16; i++) a[j * 16 + i] = (float)kAFVBasis[j][i]; ST.afv_off = blob.append(a, sizeof(a)); }
   ST.dither_off = blob.append(kDither32, sizeof(kDither32));
+  {
+    // default upsampling kernels: the symmetric 5n x 5n matrix of each factor N = 2n, expanded to one 5 x 5 kernel per output phase (the phases
+    // of the right / lower half are the mirror images of the left / upper half)
+    const float *w[3] = {kUpsampling2, kUpsampling4, kUpsampling8};
+    for (int t = 0; t < 3; t++) {
+      const int N = 2 << t, n = N / 2;
+      std::vector<float> sym((size_t)(5 * n) * (size_t)(5 * n)), k((size_t)N * N * 25);
+      for (int i = 0; i < 5 * n; i++) for (int j = 0; j < 5 * n; j++) { const int y = std::min(i, j), x = std::max(i, j); sym[(size_t)j * (size_t)(5 * n) + (size_t)i] = w[t][5 * n * y - y * (y - 1) / 2 + x - y]; }
+      for (int oy = 0; oy < N; oy++) for (int ox = 0; ox < N; ox++) for (int iy = 0; iy < 5; iy++) for (int ix = 0; ix < 5; ix++) {
+        const int py = oy < n ? oy : N - 1 - oy, px = ox < n ? ox : N - 1 - ox, ty = oy < n ? iy : 4 - iy, tx = ox < n ? ix : 4 - ix;
+        k[(size_t)((oy * N + ox) * 25 + iy * 5 + ix)] = sym[(size_t)(py * 5 + ty) * (size_t)(5 * n) + (size_t)(px * 5 + tx)];      // kernel[py][px][ty][tx] = sym[5 py + ty][5 px + tx]
+      }
+      ST.ups_off[t] = blob.append(k.data(), k.size() * 4);
+    }
+  }
   { float l[6 * 32]; memset(l, 0, sizeof(l));
     for (int i = 0; i < 6; i++) { int N = 1 << i; for (int k = 0; k < N; k++) { double t = k * PI / (16.0 * N); l[i * 32 + k] = (float)(1.0 / (cos(t) * cos(2 * t) * cos(4 * t))); } }
     ST.llf_off = blob.append(l, sizeof(l)); }

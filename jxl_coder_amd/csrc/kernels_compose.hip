@@ -37,6 +37,24 @@ __global__ void __launch_bounds__(256) k_compose_write(DevBuffers B, const uint8
   xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y);
 }
 
+__global__ void __launch_bounds__(256) k_upsample(DevBuffers B, const uint8_t *stat) {
+  const DevFrame &F = frame_of(B);
+  const int X = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), Y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (X >= F.full_w || Y >= F.full_h || frame_failed(B)) return;
+  upsample_pixel(B, F, stat, X, Y);
+}
+__global__ void __launch_bounds__(256) k_upsampled_write(DevBuffers B, const uint8_t *stat) {
+  const DevFrame &F = frame_of(B);
+  const int X = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), Y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (X >= F.full_w || Y >= F.full_h || frame_failed(B)) return;
+  upsampled_write_pixel(B, stat, B.out_bits, X, Y);
+}
+void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
+  const dim3 g((full_w + 63) / 64, (full_h + 3) / 4);
+  hipLaunchKernelGGL(k_upsample, g, dim3(256), 0, s, B, stat);
+  hipLaunchKernelGGL(k_upsampled_write, g, dim3(256), 0, s, B, stat);
+}
+
 void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s) { hipLaunchKernelGGL(k_mod_to_planes, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B); }
 void launch_patch_blend(const DevBuffers &B, int num_patches, size_t max_px, hipStream_t s) {
   if (num_patches <= 0) return;

@@ -86,6 +86,12 @@ CASES = {
     "vs400x300_e7_d1": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=1.0)),
     "vs400x300_e7_d3": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=3.0)),
     "vs400x300_e9_d1": (400, 300, dict(gen="screenshot", seed=1), dict(effort=9, distance=1.0)),
+    # upsampled frames: the reference's quality <= 12 is distance >= 10 (interop/JxlEncoding.cpp:38-46), where libjxl codes the frame at half size;
+    # 4x / 8x through JXL_ENC_FRAME_SETTING_RESAMPLING = 2
+    "vu400x300_e7_d10": (400, 300, dict(seed=3), dict(effort=7, distance=10.0)),
+    "vu523x267_e7_up4": (523, 267, dict(seed=4), dict(effort=7, distance=2.0, extra=((2, 4),))),
+    "vu523x267_e7_up8": (523, 267, dict(seed=4), dict(effort=7, distance=1.0, extra=((2, 8),))),
+    "vus400x300_e7_d12": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=12.0)),       # upsampling + patches
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
