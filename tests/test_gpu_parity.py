@@ -127,7 +127,7 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    art = open(os.path.join(ROOT, "tests", "golden", "u64_resampling2.jxl"), "rb").read()       # 2x upsampling (JXL_ENC_FRAME_SETTING_RESAMPLING): not on the device path
+    art = open(os.path.join(ROOT, "tests", "golden", "u96x64_lf_frame.jxl"), "rb").read()       # progressive DC (JXL_ENC_FRAME_SETTING_PROGRESSIVE_DC: the LF image travels as a frame of its own): not on the device path — and a VALID file: unsupported, not corrupt
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
         dec.decode_one_shot(art)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
