@@ -419,7 +419,6 @@ int jxlamd_decoder::decode_refs(FrameSlot &main, uint32_t flags) {
 // one prepared frame through every stage on this context's stream, then the flag readback (and the output copy if the caller's buffer is on the host)
 int jxlamd_decoder::run_frame(FrameSlot &S, uint32_t flags, bool single_latency) {
   int rc;
-  const DevFrame *F = (const DevFrame *)S.plan.tables.data();
   HIPCHECK(hipEventRecord(ev[0], stream));
   if (S.plan.modular) {
     rc = launch_modular(S); if (rc) return rc;
@@ -442,7 +441,7 @@ int jxlamd_decoder::run_frame(FrameSlot &S, uint32_t flags, bool single_latency)
   rc = launch_rest(S, 1); if (rc) return rc;
   HIPCHECK(hipEventRecord(ev[3], stream));
   rc = launch_rest(S, 2); if (rc) return rc;
-  if (F->compose) { rc = launch_compose_tail(S); if (rc) return rc; }
+  if (S.plan.compose) { rc = launch_compose_tail(S); if (rc) return rc; }      // (plan flag: finish_single_section re-packs the tables blob, a DevFrame pointer taken earlier would dangle)
   HIPCHECK(hipEventRecord(ev[4], stream));
   rc = collect(S, flags);
   for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&timing[i], ev[i], ev[i + 1]);

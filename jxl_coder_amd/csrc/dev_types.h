@@ -7,7 +7,7 @@
 namespace jxlamd {
 
 // ---- entropy code (ISO/IEC 18181-1 Annex C) as the kernels see it
-struct DevAlias {            // 8 bytes per alias-table entry: ONE 64-bit load yields everything an rANS step needs
+struct alignas(8) DevAlias {  // 8 bytes per alias-table entry: ONE 64-bit load yields everything an rANS step needs (alignas: without it the compiler splits the load in three)
   uint8_t cutoff;            // position within the bucket at which the "right" symbol starts (< bucket <= 128)
   uint8_t right;             // right_value symbol
   uint16_t off1;             // offsets1 added to pos for the right symbol
