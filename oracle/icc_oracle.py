@@ -1,8 +1,10 @@
-"""convertUseDefinedColorSpace (cpp/colorspaces/colorspace.cpp:38-86) restated over the system's Little CMS through ctypes —
-TEST INFRASTRUCTURE ONLY.  Same calls and parameters as the reference: cmsOpenProfileFromMem, cmsCreate_sRGBProfile,
-cmsCreateTransform(src, TYPE_RGBA_8 | TYPE_RGBA_16_PREMUL, sRGB, same, INTENT_PERCEPTUAL, BLACKPOINTCOMPENSATION | NOWHITEONWHITEFIXUP |
-COPY_ALPHA), one cmsDoTransform per row.  (The reference's file itself cannot be compiled here without a stand-in for android/log.h;
-the library is the one the reference vendors under cpp/icc, here the distribution's liblcms2 2.12.)"""
+"""convertUseDefinedColorSpace (cpp/colorspaces/colorspace.cpp:38-86) restated over Little CMS through ctypes — TEST INFRASTRUCTURE ONLY.
+Same calls and parameters as the reference: cmsOpenProfileFromMem, cmsCreate_sRGBProfile, cmsCreateTransform(src, TYPE_RGBA_8 |
+TYPE_RGBA_16_PREMUL, sRGB, same, INTENT_PERCEPTUAL, BLACKPOINTCOMPENSATION | NOWHITEONWHITEFIXUP | COPY_ALPHA), one cmsDoTransform per row.
+The library: oracle/_ref/liblcms2_ref.so = the Little CMS 2.16 the reference vendors under cpp/icc, compiled from those sources where they
+lie (oracle/ref_lcms/Makefile) — the reference's own CMM; the distribution's liblcms2 (2.12) only when that build is absent.  (The reference's
+colorspace.cpp itself cannot be compiled here without a stand-in for android/log.h.)"""
+import os
 import ctypes as C
 import numpy as np
 
@@ -15,7 +17,8 @@ _L = None
 def _lib():
     global _L
     if _L is None:
-        L = C.CDLL("liblcms2.so.2")
+        ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "liblcms2_ref.so")
+        L = C.CDLL(ref if os.path.exists(ref) and not os.environ.get("JXO_SYSTEM_LCMS") else "liblcms2.so.2")
         L.cmsOpenProfileFromMem.restype = C.c_void_p; L.cmsOpenProfileFromMem.argtypes = [C.c_char_p, C.c_uint32]
         L.cmsCreate_sRGBProfile.restype = C.c_void_p
         L.cmsCreateTransform.restype = C.c_void_p; L.cmsCreateTransform.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -24,6 +27,10 @@ def _lib():
         L.cmsGetEncodedCMMversion.restype = C.c_int
         _L = L
     return _L
+
+
+def cmm_version():
+    return int(_lib().cmsGetEncodedCMMversion())
 
 
 def available():

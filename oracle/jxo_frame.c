@@ -953,7 +953,11 @@ static void gaborish(fstate *s, int w, int h) {
   }
 }
 
+#include <xmmintrin.h>
+static int jxo_epf_rcpps = -1;
+static float rcpps1(float v) { return _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(v))); }
 static void epf_pass(fstate *s, int w, int h, int pass, const float *inv_sigma) {
+  if (jxo_epf_rcpps < 0) jxo_epf_rcpps = getenv("JXO_EPF_RCPPS") && atoi(getenv("JXO_EPF_RCPPS")) ? 1 : 0;
   const frame_hdr *f = &s->f;
   float sm = 1.65f * (pass == 0 ? f->epf_pass0 : pass == 2 ? f->epf_pass2 : 1.0f);
   float bsm = sm * f->epf_border_sad;
@@ -990,6 +994,10 @@ static void epf_pass(fstate *s, int w, int h, int pass, const float *inv_sigma) 
         wsum += wgt;
         for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, y + ty, x + tx);
       }
+      if (jxo_epf_rcpps) {                /* experiment (JXO_EPF_RCPPS=1): the reference build's ApproximateReciprocal = the host CPU's 12-bit rcpps */
+        float inv = rcpps1(wsum);
+        for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)s->pw + (size_t)x] = acc[c] * inv;
+      } else
       for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)s->pw + (size_t)x] = acc[c] / wsum;
     }
   #undef PX

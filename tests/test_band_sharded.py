@@ -233,3 +233,22 @@ def test_band_decode_across_the_kernel_switch_at_16384_squared():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu", "c4_full.py"), "16384", "16384", "1"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "1 bands == 3 bands" in r.stdout and "bit for bit" in r.stdout and r.stdout.rstrip().endswith("True"), r.stdout[-800:]
+
+
+@pytest.mark.gpu
+def test_config4_at_its_true_size_last_band():
+    """BASELINE configs[3] at its true size — one 32768 x 32768 VarDCT frame (16 384 groups, 4 GiB of RGBA8), generated and encoded on the box by
+    the reference's encoder: the LAST of the eight bands (group rows 112 - 128, byte offset 3.76 GB of the frame's output: beyond 2^31 and 2^32 / 1.14)
+    decoded next to its upper neighbour, once as one band and once as three (borders inside LF groups): within max 1 / mean 0.05 of the reference's
+    libjxl run live on the same file, and bit-identical between the two partitions (tools/gpu/c4_full.py ... tail)."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("the reference encoder (oracle/_ref) did not travel to this box")
+    free_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
+    if free_gb < 60:
+        pytest.skip("needs ~52 GB of host RAM for the 1 GP encode")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu", "c4_full.py"), "32768", "32768", "8", "tail"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "bit for bit" in r.stdout and r.stdout.rstrip().endswith("True") and "frame output byte offset 3758096384" in r.stdout, r.stdout[-800:]

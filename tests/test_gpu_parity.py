@@ -331,14 +331,14 @@ def test_flat_passgroup_kernel_on_small_flights():
     code = textwrap.dedent("""
         import sys, numpy as np, torch
         sys.path.insert(0, %r); sys.path.insert(0, %r)
-        from conftest import load_case, VARDCT_CASES
+        from conftest import load_case, VARDCT_CASES, vardct_mean_tol
         import jxl_coder_amd as J
         dec = J.JxlDecoder(0)
         for name in VARDCT_CASES:
             data, exp = load_case(name)
             out, _ = dec.decode_one_shot(data)
             d = np.abs(out.astype(int) - exp.astype(int))
-            assert d.max() <= 1 and d.mean() <= 0.1, (name, d.max(), d.mean())
+            assert d.max() <= 1 and d.mean() <= vardct_mean_tol(name), (name, d.max(), d.mean())
         names = ["v264x520_e7", "asset_first_jxl", "va300x520_e7", "v267x131_e7", "v256_e3_gab0_epf3", "v300x300_e7_d3"]
         datas = [load_case(n)[0] for n in names]
         singles = [dec.decode_one_shot(d)[0] for d in datas]

@@ -247,3 +247,45 @@ def test_decode_pipeline_fused_equals_staged():
             b = J.JxlCoder._decode_pipeline(data, cfg, 33, None, fused_post=False)
             assert (a.stride, a.config, a.use_floats) == (b.stride, b.config, b.use_floats)
             assert np.array_equal(a.rows, b.rows), (name, int(cfg))
+
+
+def test_reference_cmm_and_system_cmm_agree_on_a8():
+    """Stage A8's checker (oracle/icc_oracle.py) runs the Little CMS 2.16 the reference vendors (cpp/icc/*.c compiled where they lie: oracle/_ref/
+    liblcms2_ref.so); the product's lattice builder (host_icc_lut.cpp) samples the distribution's liblcms2 (2.12 in this image).  On the embedded
+    profile of the ICC fixture the two libraries give the same 8-bit pixels and 16-bit values within 1 code — so the product's lattice needs no
+    second source, and the A8 GPU test (tests/test_boundary.py) is a check against the reference's own CMM."""
+    import ctypes as C
+    import subprocess, sys, textwrap
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import icc_oracle
+    if not icc_oracle.available() or not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "liblcms2_ref.so")):
+        pytest.skip("needs both Little CMS builds")
+    assert icc_oracle.cmm_version() == 2160                          # the reference's: cpp/icc/lcms2.h LCMS_VERSION
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        import icc_oracle
+        icc = open(sys.argv[1], "rb").read()
+        rng = np.random.default_rng(11)
+        px8 = rng.integers(0, 256, (64, 257, 4)).astype(np.uint8)
+        px16 = rng.integers(0, 65536, (64, 257, 4)).astype(np.uint16); px16[..., 3] = 65535
+        np.save(sys.argv[2], icc_oracle.convert(px8, icc)); np.save(sys.argv[3], icc_oracle.convert(px16, icc))
+        print(icc_oracle.cmm_version())
+    """) % os.path.join(ROOT, "oracle")
+    import tempfile
+    import jxl_coder_amd as J
+    from jxl_coder_amd import api
+    data = open(os.path.join(ROOT, "tests", "golden", "licc96x64_e3.jxl"), "rb").read()
+    n = C.c_size_t(); buf = np.zeros(1 << 16, np.uint8)
+    assert api.lib().jxlamd_get_icc(data, len(data), buf.ctypes.data, buf.size, C.byref(n)) == 0 and n.value > 0
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "p.icc"), "wb").write(buf[: n.value].tobytes())
+        outs = {}
+        for tag, env in (("ref", {}), ("sys", {"JXO_SYSTEM_LCMS": "1"})):
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "p.icc"), os.path.join(td, tag + "8.npy"), os.path.join(td, tag + "16.npy")],
+                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr[-800:]
+            outs[tag] = (int(r.stdout.strip()), np.load(os.path.join(td, tag + "8.npy")), np.load(os.path.join(td, tag + "16.npy")))
+    assert outs["ref"][0] == 2160 and outs["sys"][0] != 2160
+    d8 = np.abs(outs["ref"][1].astype(int) - outs["sys"][1].astype(int)); d16 = np.abs(outs["ref"][2].astype(int) - outs["sys"][2].astype(int))
+    assert d8.max() <= 1 and d16.max() <= 2, (d8.max(), d16.max())

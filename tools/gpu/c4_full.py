@@ -4,7 +4,10 @@
 exchange going through device buffers, compared per band with the reference's libjxl run live below its size guard (row sums and
 max / mean |diff|), and — the bit-exact check — with the same frame decoded as 2 * NB + 1 bands (different band borders, incl. bands
 that split LF groups).  The synthetic image is generated in row tiles by a process pool (tools/synth.py's recipe per tile).
-usage: c4_full.py [W H NB]"""
+usage: c4_full.py [W H NB [tail]]
+tail: only the LAST band of the NB (for 32768 x 32768 and NB = 8: group rows 112 - 128, output byte offset 3.76 GB of the 4 GiB frame) is checked — decoded
+next to its upper neighbour (which supplies the halo), once as one band and once as three, compared bit for bit and with the reference's rows: the
+driver-run form of the full-size check (tests/test_band_sharded.py), ~2 minutes of which 1.5 are the reference's encoder."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -40,6 +43,7 @@ def tile(args):
 def main():
     w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32768, 32768)
     nb = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    tail = len(sys.argv) > 4 and sys.argv[4] == "tail"
     free_gb = int(open("/proc/meminfo").read().split("MemAvailable:")[1].split()[0]) / 1e6
     need_gb = w * h * 48 / 1e9            # image + encoder working set (f32 planes) + reference output, with margin
     print("host RAM available %.0f GB, estimated need %.0f GB, cores %d" % (free_gb, need_gb, os.cpu_count()), flush=True)
@@ -62,8 +66,8 @@ def main():
     from jxl_coder_amd.shard import DeviceBand, band_rows, HALO_LF, HALO_PIXELS
     ygroups = (h + 255) // 256
 
-    def decode_bands(n):
-        rws = band_rows(ygroups, n)
+    def decode_bands(n, rws=None):
+        rws = rws if rws is not None else band_rows(ygroups, n)
         decs = [J.JxlDecoder(0) for _ in range(n)]
         stage = np.zeros((n, 3)); bands = {}
         for b in range(n):
@@ -82,6 +86,27 @@ def main():
         del bands, decs
         return rws, outs, stage, halo
 
+    if tail:
+        # the last band and the one above it (whose lower edge is the last band's halo; its own upper rows go unchecked: nothing is imported there)
+        allr = band_rows(ygroups, nb)
+        up, last = allr[-2], allr[-1]
+        rws, outs, stage, halo = decode_bands(2, [up, last])
+        px = outs[1].cpu().numpy().reshape(-1, w, 4)
+        r = ref[last[0] * 256: last[0] * 256 + px.shape[0]]
+        mx = 0; sm = 0
+        for y0 in range(0, px.shape[0], 256):
+            d = np.abs(px[y0:y0 + 256].astype(np.int16) - r[y0:y0 + 256].astype(np.int16)); mx = max(mx, int(d.max())); sm += int(d.sum(dtype=np.int64))
+        print("last band group rows %s (%d groups, frame output byte offset %d): begin / reconstruct / finish %.0f / %.0f / %.0f ms | vs reference: max |diff| %d mean %.4f"
+              % (last, (last[1] - last[0]) * ((w + 255) // 256), last[0] * 256 * w * 4, *(stage[1] * 1e3), mx, sm / px.size), flush=True)
+        third = max(1, (last[1] - last[0]) // 3)
+        parts = [(last[0], last[0] + third), (last[0] + third, last[0] + 2 * third), (last[0] + 2 * third, last[1])]
+        parts = [p for p in parts if p[1] > p[0]]
+        rws2, outs2, _, _ = decode_bands(1 + len(parts), [up] + parts)
+        same = bool(torch.equal(torch.cat(outs2[1:]), outs[1]))
+        print("last band as 1 band == as %d bands (borders inside LF groups) bit for bit over %d bytes: %s" % (len(parts), outs[1].numel(), same))
+        if not same or mx > 1 or sm / px.size > 0.05:
+            raise SystemExit(1)
+        return
     rws, outs, stage, halo = decode_bands(nb)
     print("%d bands, per band (ms) begin[parse + LF stage] / reconstruct[smoothing + PassGroup + IDCT] / finish[filters + writer]:" % nb)
     worst, tot = 0, 0.0
