@@ -13,7 +13,19 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank de
 units, no data-path collective — weak scaling; value = frames of all ranks / max-over-ranks time.
 """
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per decoder context: contexts = HIP streams that must overlap (default is 4; contexts that share a queue serialise)
+import sys
+
+
+def _argv_int(name, default):
+    for i, a in enumerate(sys.argv):
+        if a == name and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith(name + "="):
+            return int(a.split("=", 1)[1])
+    return default
+
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, min(64, _argv_int("--contexts", 16)))))   # one hardware queue per decoder context: contexts = HIP streams that must overlap (default is 4; contexts that share a queue serialise)
 import argparse
 import json
 import os
@@ -204,6 +216,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step (BASELINE configs[2]: 256 x 3840x2160 q90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
+    ap.add_argument("--share", type=int, default=1, help="contexts per set of HF-phase pools (jxlamd_decoder_share_pools): with 2, --contexts 32 keeps 16 pool sets busy — a context's LF stage "
+                    "overlaps its partner's PassGroup / reconstruction / filter stages")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
     ap.add_argument("--workload", choices=["c3", "c5", "c4"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
                     "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused).  "
@@ -270,6 +284,10 @@ def main():
     P = max(1, min(args.inflight, B))
     NCTX = max(1, min(args.contexts, (total_frames + P - 1) // P))
     decs = [J.JxlDecoder(local) for _ in range(NCTX)]
+    SHARE = max(1, args.share)
+    for c in range(NCTX):
+        if c % SHARE:
+            decs[c].share_pools(decs[c - c % SHARE])
     d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(f"cuda:{local}") for d in datas]   # compressed bytes resident in HBM
     d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
     d_f16 = [[torch.empty(w * h * 8, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)] if c5 else None   # the Bitmap buffers (RGBA_F16)
@@ -434,7 +452,7 @@ def main():
                                    "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "
                                    "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
                        "h2d_included_MPps": round(h2d_steps * B * world * mp / elapsed_h2d, 2), "h2d_included_steps": h2d_steps, "distinct_frames": len(datas),
-                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "flights_repeated_for_lf_pool": _lf_retries(J, decs)[0], "lf_pool_bytes": sorted(set(_lf_retries(J, decs)[1])), "retried_flights": int(kern.get("retried_flights", 0)),
+                       "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_per_pool_set": SHARE, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "flights_repeated_for_lf_pool": _lf_retries(J, decs)[0], "lf_pool_bytes": sorted(set(_lf_retries(J, decs)[1])), "retried_flights": int(kern.get("retried_flights", 0)),
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective"},

@@ -93,6 +93,13 @@ int jxlamd_decode_resident(jxlamd_decoder *dec, const uint8_t *jxl, size_t size,
 int jxlamd_decode_batch(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes, uint32_t flags,
                         void *const *outs, const size_t *out_capacities, jxlamd_info *infos);
 
+/* Flights of several contexts on ONE set of HF-phase buffers: after this call `peer` runs the PassGroup / reconstruction / filter stages of its
+ * batches in `owner`'s coefficient and pixel-plane pools (106 MB + 12 MB per 4K frame in flight) instead of its own, taking turns with the other
+ * contexts that share them.  A flight needs those pools for about two thirds of its time; during its LF stage (a few MB per frame) they serve a
+ * sharing context, so 2 contexts per pool set keep the pools busy without doubling the memory.  Both decoders must be on the same device; call
+ * before the first batch of `peer`.  Single decodes are not affected.  (Extension; the reference decodes one file per call.) */
+int jxlamd_decoder_share_pools(jxlamd_decoder *owner, jxlamd_decoder *peer);
+
 /* Batch with the compressed bytes of frame i also resident in HBM at jxl_dev[i] (may be NULL per frame). */
 int jxlamd_decode_batch_resident(jxlamd_decoder *dec, int n, const uint8_t *const *jxl, const size_t *sizes,
                                  const void *const *jxl_dev, uint32_t flags, void *const *outs, const size_t *out_capacities,

@@ -183,6 +183,7 @@ def lib():
         L.jxlamd_rescale_query.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(RescaleInfo)]
         L.jxlamd_rescale.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_size_t, C.POINTER(RescaleInfo)]
+        L.jxlamd_decoder_share_pools.argtypes = [C.c_void_p, C.c_void_p]
         L.jxlamd_band_begin.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_band_halo_bytes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.jxlamd_band_export.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
@@ -207,6 +208,12 @@ class JxlDecoder:
         if not self._h:
             raise RuntimeError(lib().jxlamd_last_error(None).decode())
         self.device = device
+
+    def share_pools(self, owner):
+        """run the HF phase of this context's batches in `owner`'s coefficient / pixel-plane pools, taking turns (include/jxl_amd.h: jxlamd_decoder_share_pools)"""
+        rc = lib().jxlamd_decoder_share_pools(owner._h, self._h)
+        if rc:
+            _raise(rc, None)
 
     def close(self):
         if self._h:

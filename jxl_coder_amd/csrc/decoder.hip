@@ -65,6 +65,8 @@ static std::atomic<int> g_lf_pool_floor{0};
 static constexpr int kRetryGeneral = 0x7e7e;
 // ... or a channel whose packed tables did not fit the LDS table pool this launch was sized with (kErrNeedPool): decode again with the largest
 static constexpr int kRetryPool = 0x7e7f;
+// ... or the shared HF pools moved while this flight's LF stage ran (decode_batch_once): start the flight over
+static constexpr int kRetryMoved = 0x7e80;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host twin of mod_group_scratch_ints (dev_modframe.h)
@@ -480,11 +482,15 @@ std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
   int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
   if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos); }   // with the largest table pool
-  if (rc0 == kRetryPool) { set_error("LF table pool: a stream of the flight asked for a larger pool twice"); return JXLAMD_ERR_DEVICE; }
+  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  if (rc0 == kRetryPool || rc0 == kRetryMoved) { set_error("LF table pool / shared HF pools: the flight was restarted too often"); return JXLAMD_ERR_DEVICE; }
   if (rc0 != kRetryGeneral) return rc0;
   lf_general = true; general_retries++;     // some frame needs a general lock-step loop: this context runs the general LF build from now on
-  return decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+  return (rc0 == kRetryPool || rc0 == kRetryMoved || rc0 == kRetryGeneral) ? JXLAMD_ERR_DEVICE : rc0;
 }
 
 int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
@@ -580,14 +586,20 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (F->epf_iters >= 2) stage_mask |= 8;
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   }
-  HIPCHECK(plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
+  // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
+  // contexts sharing it overlap one's LF stage with the other's HF phase
   const int used_sets = std::min(hf_sets, nb);
   const size_t coef_need = (size_t)used_sets * 3 * max_coef * 4;
-  if (coef_need > coef_pool.cap || !coef_pool_clean) {      // (re)allocated or left dirty by a failed flight: clear once
-    HIPCHECK(coef_pool.ensure(coef_need));
-    HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));
+  uint64_t pool_gen;
+  {
+    std::lock_guard<std::mutex> lk(pools->mu);
+    const void *p0 = pools->plane_pool.p, *c0 = pools->coef_pool.p;
+    HIPCHECK(pools->plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
+    HIPCHECK(pools->coef_pool.ensure(coef_need));
+    if (pools->plane_pool.p != p0 || pools->coef_pool.p != c0) { pools->generation++; pools->coef_pool_clean = false; }
+    pool_gen = pools->generation;
   }
-  coef_pool_clean = false;                                   // until every frame of this flight has been collected without error
+  DevMem &plane_pool = pools->plane_pool, &coef_pool = pools->coef_pool;
   // tables and compressed bytes of all frames: one page-locked staging buffer and ONE upload each (a frame used to cost three
   // stream operations here and one more in collect(); next to seven other busy contexts those ~500 tiny operations per flight
   // took up to 200 ms of the stream's time)
@@ -672,6 +684,11 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_general, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth_batch(dB, nb, max_cells, stream);
+  // ---- HF phase: this context's turn on the pools (uncontended unless shared).  The wait is host-side and overlaps the LF stage launched above
+  std::unique_lock<std::mutex> pool_lock(pools->mu);
+  if (pools->generation != pool_gen) return kRetryMoved;      // a sharing context re-allocated the pools meanwhile (first flights only): the tables above hold stale addresses
+  if (!pools->coef_pool_clean) HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));      // fresh, or left dirty by a failed flight: clear once
+  pools->coef_pool_clean = false;                            // until every frame of this flight has been collected without error
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
     const int cnt = std::min(hf_sets, nb - k0);
     const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
@@ -714,7 +731,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // one miss is enough evidence that this context's frames vary: it keeps the largest pool from here on (a repeated flight costs more than a
   // fourth LF stream per CU gains; measured on 256 distinct frames: wanted pools 12 .. 25 KB, 8 % of the flights repeated with a creeping floor)
   if (need_pool) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
-  coef_pool_clean = first_rc == JXLAMD_OK;
+  pools->coef_pool_clean = first_rc == JXLAMD_OK;
   lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
@@ -771,6 +788,12 @@ void jxlamd_decoder_destroy(jxlamd_decoder *d) {
   for (auto &e : d->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(d->stream);
   delete d;
+}
+
+int jxlamd_decoder_share_pools(jxlamd_decoder *owner, jxlamd_decoder *peer) {
+  if (!owner || !peer || owner == peer || owner->device != peer->device) { g_tls_error = "share_pools: two decoders of one device"; return JXLAMD_ERR_BUFFER; }
+  peer->pools = owner->pools;           // the peer's own pools (if any were allocated) are released with its last reference
+  return JXLAMD_OK;
 }
 
 const char *jxlamd_last_error(const jxlamd_decoder *d) { return d ? d->error.c_str() : g_tls_error.c_str(); }

@@ -7,6 +7,8 @@
 #include <string.h>
 #include <algorithm>
 #include <exception>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -104,15 +106,25 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
 };
 
+// HF-phase memory of a flight: hf_sets coefficient sets (3 x groups x 65536 i32, 106 MB per 4K frame) shared by its sub-flights and plane_sets x 6
+// f32 planes shared by the frames of a sub-batch.  A flight only needs it from its PassGroup stage on; while its LF stage runs (a third of
+// the flight's time, a few MB per frame) the memory can serve another context's HF phase: contexts that share one HfPools take turns (mu).
+struct HfPools {
+  DevMem plane_pool, coef_pool;
+  bool coef_pool_clean = false;     // the reconstruction kernels clear every coefficient they consume: after a flight without errors the pool is all-zero
+  uint64_t generation = 0;          // bumped whenever a buffer is (re)allocated: a flight that baked the old addresses into its tables starts over
+  std::mutex mu;
+};
+
 struct jxlamd_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   std::string error;
-  DevMem stat, batch_tab, mod_tab, plane_pool, coef_pool, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
+  DevMem stat, batch_tab, mod_tab, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
-  bool coef_pool_clean = false;           // coef_pool: hf_sets coefficient sets shared by the sub-flights of a flight   // post_*: LUTs of the colour-matrix stage     // plane_pool: kPlaneSets x 6 f32 planes shared by the frames of a flight (sub-batches)
+  std::shared_ptr<HfPools> pools = std::make_shared<HfPools>();     // HF-phase memory of this context's flights (own, or shared: jxlamd_decoder_share_pools)
   PinnedMem h_batch, h_mod_tab, h_flight_tables, h_flight_cs, h_flags;
   DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;

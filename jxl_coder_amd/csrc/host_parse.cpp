@@ -25,6 +25,7 @@ typedef struct { int nbands; float b[3][8]; } hx_dctparams;
 #include "host_icc.inc"
 #include "dither_lut.h"
 #include "upsampling_weights.h"
+#include "host_icc_synth.inc"
 }  // namespace
 
 namespace jxlamd {
@@ -428,6 +429,11 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
       else { rc = -1; if (error) *error = hx_last_error(); }
     } else if (m.pub.want_icc) {
       info->want_icc = 0; info->color_space = 0; info->white_point = 1; info->primaries = 1; info->transfer_function = 13; info->have_gamma = 0; info->rendering_intent = 1;
+    } else if (!m.pub.have_gamma && m.pub.transfer_function == 8) {
+      // an enum encoding with a transfer function the reference does not handle itself (linear light): it asks libjxl for the data profile — which
+      // libjxl synthesises — and hands it to Little CMS (interop/JxlDecoding.cpp:126-141, JniDecoding.cpp:103-114).  Same here (host_icc_synth.inc)
+      std::vector<uint8_t> tmp;
+      if (icc_synth::synthesize(m.pub, m.wp_xy, m.prim_xy, &tmp)) { info->icc_size = (uint32_t)tmp.size(); if (icc) icc->swap(tmp); }
     }
   }
   if (owned) free(cs);
@@ -499,6 +505,9 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     if (m.pub.xyb_encoded) { m.pub.want_icc = 0; m.pub.color_space = 0; m.pub.white_point = 1; m.pub.primaries = 1; m.pub.transfer_function = 13; m.pub.have_gamma = 0; m.pub.rendering_intent = 1; }
     fill_info(m, &plan->info);
     plan->info.icc_size = (uint32_t)icc.size();
+  } else if (!m.pub.have_gamma && m.pub.transfer_function == 8) {
+    std::vector<uint8_t> tmp;                                  // linear-light enum encoding: the synthesised data profile (parse_basic_info)
+    if (icc_synth::synthesize(m.pub, m.wp_xy, m.prim_xy, &tmp)) plan->info.icc_size = (uint32_t)tmp.size();
   }
   if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
   if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }

@@ -134,9 +134,9 @@ static bool load_icc(D *d) {
   d->icc.resize(got);
   return !d->icc.empty();
 }
-// The embedded profile of an ICC-coded image.  For enum-coded images libjxl synthesises a profile here; this library does not (size 0):
-// the reference reads the bytes only when it does not 'prefer' the enum encoding (JxlDecoding.cpp:135-144) — for such a file
-// (linear / unknown transfer function) JxlDecoderGetColorAsICCProfile fails and with it the decode, loudly.
+// The embedded profile of an ICC-coded image, or — enum-coded image with the LINEAR transfer function, the one case in which the reference reads
+// the bytes of an enum encoding (it does not 'prefer' it: JxlDecoding.cpp:126-144) — the profile libjxl synthesises, byte for byte
+// (host_icc_synth.inc; jxlamd_info::icc_size carries its size).  Other enum encodings: size 0, as before; the reference never asks for them.
 int JxlDecoderGetICCProfileSize(const D *d, int, size_t *size) {
   if (!d || d->stage < 1) return JXLC_DEC_NEED_MORE_INPUT;
   if (size) *size = d->info.icc_size;

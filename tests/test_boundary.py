@@ -203,3 +203,50 @@ def test_icc_stage_matches_little_cms(golden_meta):
     d = np.abs(px.astype(int) - ref.astype(int))
     assert d.max() <= 2 and d.mean() <= 0.25
     dec.close()
+
+
+LINEAR_CASES = ["vlin96x64_e3", "vlin2100_96x64_e3", "vlinp3_96x64_e3", "llin96x64_e3", "vlingrey96x64_e3"]
+
+
+@pytest.mark.parametrize("name", LINEAR_CASES)
+def test_synthesised_profile_of_linear_enum_encodings_equals_libjxls(name, golden_meta):
+    """The reference does not treat the LINEAR transfer function as a preferred encoding: DecodeJpegXlOneShot asks libjxl for the data profile
+    (which libjxl synthesises for an enum encoding) and fails the decode without it (interop/JxlDecoding.cpp:126-141); the JNI layer then converts
+    through Little CMS.  jxlamd_get_icc returns that profile (host_icc_synth.inc) — byte for byte what the reference's libjxl returned for the
+    same file (ICC v4.4, 'para' curves, Bradford chad, cicp, MD5 profile ID) — and jxlamd_basic_info reports its size with prefer_encoding 0."""
+    from jxl_coder_amd import api
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    want = open(os.path.join(GOLDEN, name + ".icc"), "rb").read()
+    info = api.Info()
+    assert api.lib().jxlamd_basic_info(data, len(data), C.byref(info)) == 0
+    assert info.prefer_encoding == 0 and info.have_encoded_profile == 1 and info.transfer_function == 8
+    assert info.icc_size == len(want) == golden_meta[name]["icc_size"]
+    buf = np.zeros(info.icc_size, np.uint8); n = C.c_size_t()
+    assert api.lib().jxlamd_get_icc(data, len(data), buf.ctypes.data, buf.size, C.byref(n)) == 0
+    assert buf[: n.value].tobytes() == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["vlin96x64_e3", "llin96x64_e3"])
+def test_linear_enum_image_goes_through_a8_like_the_reference(name):
+    """End to end for a linear-light enum encoding: the decoder proper returns the data (linear) pixels the reference's libjxl returns, and
+    JxlCoder.decode then runs stage A8 with the synthesised profile — linear -> sRGB through the Little CMS lattice — as the reference's JNI layer
+    does with libjxl's profile (JniDecoding.cpp:103-114); checked against Little CMS run per pixel on the reference's pixels and profile."""
+    import jxl_coder_amd as J
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import icc_oracle
+    if not icc_oracle.available():
+        pytest.skip("Little CMS not present on this box")
+    data, exp = load_case(name)
+    icc = open(os.path.join(GOLDEN, name + ".icc"), "rb").read()
+    dec = J.JxlDecoder(0)
+    raw, info = dec.decode_one_shot(data)
+    d = np.abs(raw.astype(int) - exp.astype(int))
+    assert (d.max() == 0) if name.startswith("l") else (d.max() <= 1 and d.mean() <= 0.05)
+    assert info["prefer_encoding"] == 0 and info["icc_size"] == len(icc)
+    px = J.JxlCoder.decode(data, J.PreferredColorConfig.RGBA_8888)
+    want = icc_oracle.convert(exp, icc)
+    assert (want != exp).any()                                     # linear -> sRGB really changes the pixels
+    d = np.abs(px.astype(int) - want.astype(int))
+    assert d.max() <= 3 and d.mean() <= 0.35, (d.max(), d.mean())   # A8's lattice tolerance (max 2) on top of the decoder's +-1 in linear light
+    dec.close()

@@ -154,6 +154,17 @@ if gpu:
         assert meta[6] == info["prefer_encoding"] and meta[7] == info["has_alpha_in_origin"] and meta[4] == info["alpha_premultiplied"], name
         assert (meta[8], meta[9]) == (info["primaries"], info["transfer_function"]), name
         assert meta[10] == 0, name                                                          # preferEncoding: the ICC vector is cleared (JxlDecoding.cpp:142-144)
+    # linear-light enum encodings: not 'preferred' -> the driver fetches the (synthesised) data profile and fails the decode without it (:135-141)
+    for name in ("vlin96x64_e3", "llin96x64_e3", "vlingrey96x64_e3"):
+        data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
+        want = np.load(os.path.join(ROOT, "tests/golden", name + ".npz"))["rgba"]
+        out = np.zeros(want.nbytes, np.uint8)
+        meta = (C.c_uint64 * 12)(); xy = (C.c_double * 8)(); msg = C.create_string_buffer(256)
+        rc = L.boundary_decode(data, len(data), 0, out.ctypes.data, out.size, C.byref(meta), C.byref(xy), msg, 256)
+        assert rc == 1, (name, rc, api.lib().jxlamd_last_error(None))
+        assert meta[6] == 0 and meta[10] == os.path.getsize(os.path.join(ROOT, "tests/golden", name + ".icc")), (name, list(meta))      # preferEncoding false, ICC vector filled
+        d = np.abs(out.view(want.dtype).reshape(want.shape).astype(int) - want.astype(int))
+        assert (d.max() == 0) if name.startswith("l") else (d.max() <= 1 and d.mean() <= 0.05), (name, d.max(), d.mean())
 print("driver ok")
 """
 
