@@ -245,8 +245,10 @@ def test_linear_enum_image_goes_through_a8_like_the_reference(name):
     assert (d.max() == 0) if name.startswith("l") else (d.max() <= 1 and d.mean() <= 0.08), (d.max(), d.mean())      # effort-3 file with one EPF iteration, linear-light codes: the rcpps offset of conftest.py (measured 0.051)
     assert info["prefer_encoding"] == 0 and info["icc_size"] == len(icc)
     px = J.JxlCoder.decode(data, J.PreferredColorConfig.RGBA_8888)
-    want = icc_oracle.convert(exp, icc)
-    assert (want != exp).any()                                     # linear -> sRGB really changes the pixels
+    # Little CMS on the DECODED linear pixels: one 8-bit linear code near black spans up to 13 sRGB codes, so the decoder's +-1 must not enter
+    # this comparison — it is the A8 stage (lattice vs the library per pixel) that is checked here, with its own tolerance
+    want = icc_oracle.convert(raw, icc)
+    assert (want != raw).any()                                     # linear -> sRGB really changes the pixels
     d = np.abs(px.astype(int) - want.astype(int))
-    assert d.max() <= 3 and d.mean() <= 0.35, (d.max(), d.mean())   # A8's lattice tolerance (max 2) on top of the decoder's +-1 in linear light
+    assert d.max() <= 2 and d.mean() <= 0.25, (d.max(), d.mean())
     dec.close()
