@@ -1001,16 +1001,16 @@ static int jxlamd_icc_transform_impl(jxlamd_decoder *d, void *px, uint32_t w, ui
   constexpr int kN = 256;               // every 8-bit level is a lattice point (100 MB of HBM per cached profile)
   if (hipSetDevice(d->device) != hipSuccess) { d->set_error("cannot select device"); return JXLAMD_ERR_DEVICE; }
   const hipStream_t s = d->stream;
-  if (d->icc_lut_key.size() != icc_size || memcmp(d->icc_lut_key.data(), icc, icc_size) != 0 || !d->icc_lut.p) {
+  if (d->icc_lut_key.size() != icc_size || memcmp(d->icc_lut_key.data(), icc, icc_size) != 0 || !d->icc_lut.p || d->icc_lut_u16 != (is_u16 != 0)) {
     std::vector<uint16_t> lut; std::string err;
-    if (!build_icc_lut(icc, icc_size, kN, &lut, &err)) {
+    if (!build_icc_lut(icc, icc_size, kN, &lut, &err, /*eight_bit=*/!is_u16)) {
       if (err.rfind("unsupported", 0) == 0) { d->set_error(err); return JXLAMD_ERR_UNSUPPORTED; }
       return JXLAMD_OK;              // colorspace.cpp:47-51, :70-74: "better proceed with invalid photo than crash"
     }
     if (d->icc_lut.ensure(lut.size() * 2) != hipSuccess || hipMemcpy(d->icc_lut.p, lut.data(), lut.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
       d->set_error("HIP: ICC lattice upload failed"); return JXLAMD_ERR_DEVICE;
     }
-    d->icc_lut_key.assign(icc, icc + icc_size);
+    d->icc_lut_key.assign(icc, icc + icc_size); d->icc_lut_u16 = is_u16 != 0;
   }
   launch_post_icc_lut(px, w * (is_u16 ? 8u : 4u), w, h, is_u16 != 0, (const uint16_t *)d->icc_lut.p, kN, s);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { d->set_error("HIP: ICC stage failed"); return JXLAMD_ERR_DEVICE; }

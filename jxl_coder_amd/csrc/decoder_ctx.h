@@ -132,6 +132,7 @@ struct jxlamd_decoder {
   DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
+  bool icc_lut_u16 = false;                // ... sampled through Little CMS's 16-bit transform (RGBA16 images) or its 8-bit one (RGBA8: host_icc_lut.cpp)
   struct { const DevBuffers *dB = nullptr; const DevAux *dA = nullptr; const int *lf_map = nullptr, *pg_map = nullptr, *wmap = nullptr; int nwg = 0; uint32_t flags = 0; } bandtab;   // band decode: device tables of the one-frame 'flight'
   // Groups in a (sub-)flight from which the lane-per-group kernel (k_pass_prep + k_pass_flat: ~100 ms of latency whatever the size, 17 M VALU
   // per 4K frame) takes over from the wave-per-group one (20 ms alone, 285 M VALU per frame: throughput-bound as soon as several contexts

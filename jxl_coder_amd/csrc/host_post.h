@@ -24,6 +24,6 @@ bool plan_color_matrix(bool is_u16, uint32_t depth, uint32_t primaries, uint32_t
 
 // A8: the embedded profile -> sRGB transform of convertUseDefinedColorSpace (cpp/colorspaces/colorspace.cpp:38-86) sampled from Little CMS
 // on an n^3 RGB16 lattice (host_icc_lut.cpp)
-bool build_icc_lut(const uint8_t *icc, size_t icc_size, int n, std::vector<uint16_t> *lut, std::string *err);
+bool build_icc_lut(const uint8_t *icc, size_t icc_size, int n, std::vector<uint16_t> *lut, std::string *err, bool eight_bit = false);
 
 }  // namespace jxlamd
