@@ -171,6 +171,7 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
   if (!hx_bool(br)) { plan->error = "unsupported: custom dequant matrices"; return -1; }
   F.num_presets = 1 + (int)hx_bits(br, ceil_log2u((uint32_t)f.num_groups));
   if (f.num_passes > 4) { plan->error = "unsupported: more than 4 passes"; return -1; }
+  if (getenv("JXLAMD_PARSE_TRACE")) fprintf(stderr, "HfGlobal: %d presets, %d block contexts, %d groups\n", F.num_presets, F.num_bctx, f.num_groups);
   for (int p = 0; p < f.num_passes; p++) {
     uint32_t used = hx_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
     hx_ec oc; int have_oc = 0;
