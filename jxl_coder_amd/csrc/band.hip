@@ -14,6 +14,7 @@
 // The reference has no counterpart (libjxl decodes a frame in one process); the boundary it sits under is the size guard of
 // DecodeJpegXlOneShot (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:103-109): a band is smaller than a Bitmap.
 #include <chrono>
+#include <mutex>
 #include "decoder_ctx.h"
 
 namespace {
@@ -30,7 +31,20 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   static const bool trace = getenv("JXLAMD_TRACE_BANDS") && atoi(getenv("JXLAMD_TRACE_BANDS"));      // host wall-clock split of band_begin on stderr
   const auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
-  int rc = prepare(S, jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out_ptr, out_cap, info, false, true, rows);
+  // The bands of one frame parse the SAME file (header, 16 642 TOC entries and the global tables of a 32768 x 32768 frame: 14 - 17 ms each): the
+  // first band of a process to see a file parses it, the others copy the plan (one entry, keyed by the caller's buffer and a sample of its bytes)
+  {
+    static std::mutex mu; static const uint8_t *k_data = nullptr; static size_t k_size = 0; static uint64_t k_sig = 0; static std::shared_ptr<FramePlan> cached;
+    uint64_t sig = 1469598103934665603ull;
+    for (size_t i = 0; i < size; i += (size <= 8192 ? 1 : (i < 4096 || i + 8192 >= size ? 1 : size / 4096))) sig = (sig ^ jxl[i]) * 1099511628211ull;
+    std::lock_guard<std::mutex> lk(mu);
+    if (cached && k_data == jxl && k_size == size && k_sig == sig) S.plan = *cached;
+    else {
+      S.plan = FramePlan(); (void)plan_parse(jxl, size, &S.plan);
+      if (S.plan.error.empty() && !S.plan.tables.empty()) { cached = std::make_shared<FramePlan>(S.plan); k_data = jxl; k_size = size; k_sig = sig; }
+    }
+  }
+  int rc = prepare(S, jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out_ptr, out_cap, info, /*parsed=*/true, true, rows);
   if (rc) return rc;
   const double t_prepared = now();
   const BandGeom &q = S.band;
