@@ -244,10 +244,10 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   B.pass_end_bits = (uint64_t *)S.pass_end.p; B.mod_end_bit = (uint64_t *)((uint8_t *)S.misc.p + 256);
   B.err = (uint32_t *)S.misc.p; B.out = (uint8_t *)S.d_out - (ptrdiff_t)q.py0 * (ptrdiff_t)S.pi.xsize * (ptrdiff_t)bpp; B.out_bits = (int32_t)S.pi.out_bits; B.stat = (const uint8_t *)stat.p;
   B.lz_win = (plan.modular && Fh->lz_win_len) ? (uint32_t *)S.lz_win.p : nullptr;
-  if (Fh->upsampling > 1) {
+  if (Fh->upsampling > 1 || Fh->alpha_up > 1) {
     const size_t n = (size_t)Fh->full_w * (size_t)Fh->full_h;
-    HIPCHECK(S.up_planes.ensure(3 * n * 4));
-    for (int c = 0; c < 3; c++) B.up[c] = (float *)S.up_planes.p + (size_t)c * n;
+    HIPCHECK(S.up_planes.ensure(4 * n * 4));
+    for (int c = 0; c < 4; c++) B.up[c] = (float *)S.up_planes.p + (size_t)c * n;
   }
   for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++)
     B.ref[k][c] = (ref_store[k].p && Fh->ref_w[k] == ref_w[k] && Fh->ref_h[k] == ref_h[k] && ref_w[k] > 0) ? (float *)ref_store[k].p + (size_t)c * (size_t)ref_w[k] * (size_t)ref_h[k] : nullptr;
@@ -356,6 +356,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
     launch_save_ref(S.B, plan.width, plan.height, (float *)ref_store[k].p, stream);
   }
   if (F->no_output) return JXLAMD_OK;
+  if (F->alpha_up > 1 && F->mod_out[3] >= 0) launch_upsample_alpha(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);
   if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);
   else launch_compose_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, stream);
   return JXLAMD_OK;

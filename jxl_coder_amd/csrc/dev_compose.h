@@ -80,6 +80,31 @@ JXL_DEV void upsample_pixel(const DevBuffers &B, const DevFrame &F, const uint8_
     B.up[c][(size_t)Y * (size_t)F.full_w + (size_t)X] = acc;
   }
 }
+// the alpha channel of a frame whose alpha is coded coarser than the image (extra-channel upsampling alpha_up = 2 / 4 / 8): same kernels, same
+// clamp, on the Modular plane's samples as fractions of full scale
+JXL_DEV void upsample_alpha_pixel(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int X, int Y) {
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const int N = F.alpha_up, sh = N == 2 ? 1 : N == 4 ? 2 : 3;
+  const int x = X >> sh, y = Y >> sh, ox = X & (N - 1), oy = Y & (N - 1);
+  const float *k = (const float *)(stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
+  const int32_t *src = mod_plane(B, F, F.mod_out[3]);
+  const float sc = 1.0f / (float)((1u << F.mod_alpha_bits) - 1);
+  int xs[5], ys[5];
+  for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.alpha_w); ys[i] = mirror(y + i - 2, F.alpha_h); }
+  float acc = 0.0f, mn = (float)src[(size_t)ys[2] * (size_t)F.alpha_w + (size_t)xs[2]] * sc, mx = mn;
+  for (int iy = 0; iy < 5; iy++)
+    for (int ix = 0; ix < 5; ix++) {
+      const float v = (float)src[(size_t)ys[iy] * (size_t)F.alpha_w + (size_t)xs[ix]] * sc;
+#ifdef __HIPCC__
+      acc = __fadd_rn(__fmul_rn(k[iy * 5 + ix], v), acc);
+#else
+      acc = k[iy * 5 + ix] * v + acc;
+#endif
+      mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+    }
+  acc = acc < mn ? mn : acc > mx ? mx : acc;
+  B.up[3][(size_t)Y * (size_t)F.full_w + (size_t)X] = acc;
+}
 // writer of an upsampled XYB frame: full-resolution planes -> colour transform -> RGBA
 JXL_DEV void upsampled_write_pixel(const DevBuffers &B, const uint8_t *stat, int out_bits, int X, int Y) {
   const DevFrame &F = frame_of(B);

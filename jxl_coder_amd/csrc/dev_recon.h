@@ -466,8 +466,11 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
   float alpha = 1.0f;                                  // extra channel of type alpha (Modular-coded, integer samples)
   if ((F.has_ec || F.is_modular) && F.mod_out[3] >= 0) {
-    const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)fy * (size_t)F.width + (size_t)fx];
-    alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
+    if (F.alpha_up > 1) alpha = B.up[3][(size_t)fy * (size_t)F.full_w + (size_t)fx];       // enlarged beforehand (upsample_alpha_pixel); fx, fy are full-resolution here
+    else {
+      const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)fy * (size_t)F.width + (size_t)fx];
+      alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
+    }
     alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;
   }
   if (out_bits == 8) {
@@ -476,7 +479,7 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
     const float d = st_f(stat, ST.dither_off)[F.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
     uint8_t px[4];
     for (int c = 0; c < 3; c++) px[c] = (uint8_t)(int)rintf(v[c] * 255.0f + d);
-    px[3] = (uint8_t)(int)rintf(alpha * 255.0f);
+    px[3] = (uint8_t)(int)rintf(alpha * 255.0f + d);        // the dither goes on every channel; it only shows on a fractional (upsampled) alpha: |d| < 0.5
     *(uint32_t *)(B.out + di) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
   } else {
     uint16_t *o16 = (uint16_t *)B.out + di;

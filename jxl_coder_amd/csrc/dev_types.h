@@ -119,6 +119,7 @@ struct DevFrame {
   float mod_xyb_fac[3];
   int32_t upsampling;              // 1, or 2 / 4 / 8: width / height above are the CODED size, the frame shows full_w x full_h pixels (K.? Upsampling, after the patches)
   int32_t full_w, full_h;
+  int32_t alpha_up, alpha_w, alpha_h;   // the alpha channel is coded at alpha_w x alpha_h = ceil(full size / alpha_up); alpha_up > 1: enlarged like the colour (DevBuffers::up[3])
   int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter

@@ -40,7 +40,7 @@ struct DevBuffers {
   int32_t out_bits;             // 8 or 16 (used by the batched writer)
   uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [DevFrame::lz_win_len] + [num_groups][DevFrame::lz_win_group] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
-  float *up[3];                 // upsampled frames: dense full_w x full_h f32 planes between the upsampling stage and the writer
+  float *up[4];                 // upsampled frames: dense full_w x full_h f32 planes between the upsampling stage and the writer ([3]: an upsampled alpha channel)
   float *ref[4][3];             // reference slots (patch dictionaries): 3 f32 planes of DevFrame::ref_w x ref_h samples each, XYB or RGB as the image is coded
 };
 

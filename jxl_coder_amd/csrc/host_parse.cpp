@@ -220,8 +220,15 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   std::vector<Ch> L;
   for (int i = 0; i < ncol + m.num_extra; i++) {
     if (i >= ncol && m.ec[i - ncol].dim_shift) { plan->error = "unsupported: extra channel dim_shift"; return -1; }
-    L.push_back({f.width, f.height, 0, 0, -1});
+    // colour channels: the coded size of the frame; an extra channel: ceil(full size / its own upsampling factor) (>= the frame's)
+    if (i < ncol) L.push_back({f.coded_width, f.coded_height, 0, 0, -1});
+    else {
+      const int u = f.ec_upsampling[i - ncol];
+      int sh = 0; while ((f.upsampling << sh) < u) sh++;            // coarser than the colour channels by this shift: its group rectangles shrink with it
+      L.push_back({(f.width + u - 1) / u, (f.height + u - 1) / u, sh, sh, -1});
+    }
   }
+  const std::vector<Ch> L0 = L;                 // what the inverse transforms must arrive at again
   int nb_meta = 0;
   // GroupHeader (H.2): use_global_tree, WP header (skipped here, the device parses it again), transforms
   const bool use_global_tree = hx_bool(sb);        // a local tree + code follow the transforms: the device parses them (as it does for LF groups)
@@ -404,10 +411,15 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   }
   plan->mod_pool_ints = (size_t)off;
   if ((int)L.size() != ncol + m.num_extra) { plan->error = "modular channel bookkeeping"; return -1; }
-  for (const Ch &c : L) if (c.w != f.width || c.h != f.height) { plan->error = "modular channel bookkeeping (sizes)"; return -1; }
+  for (size_t i = 0; i < L.size(); i++) if (L[i].w != L0[i].w || L[i].h != L0[i].h) { plan->error = "modular channel bookkeeping (sizes)"; return -1; }
   for (int c = 0; c < 3; c++) F.mod_out[c] = vardct ? -1 : L[(size_t)(ncol == 1 ? 0 : c)].plane;
   F.mod_out[3] = -1; F.mod_alpha_bits = 8;
-  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits; break; }
+  F.alpha_up = 1; F.alpha_w = f.width; F.alpha_h = f.height;
+  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) {
+    F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits;
+    F.alpha_up = f.ec_upsampling[i]; F.alpha_w = L[(size_t)(ncol + i)].w; F.alpha_h = L[(size_t)(ncol + i)].h;
+    break;
+  }
   return 0;
 }
 
@@ -595,10 +607,14 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
   if (f.encoding == 1 && !m.pub.xyb_encoded && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
+  for (int i = 0; i < m.num_extra; i++) {
+    // an extra channel is coded at 1 / ec_upsampling of the full size, never finer than the colour channels
+    if (f.ec_upsampling[i] < f.upsampling) { plan->error = "extra channel upsampling below the frame's"; return -1; }
+    if (f.ec_upsampling[i] != 1 && (f.encoding == 1 && !m.pub.xyb_encoded)) { plan->error = "unsupported: extra channel upsampling in a Modular frame that is not XYB"; return -1; }
+  }
   if (f.upsampling != 1) {
     // an upsampled frame (what the reference's encoder writes from distance 10 up, i.e. its quality <= 12: interop/JxlEncoding.cpp:38-46) is coded at
     // ceil(size / upsampling) and enlarged after the patches (dev_compose.h)
-    if (m.num_extra) { plan->error = "unsupported: upsampling of a frame with extra channels"; return -1; }
     if (!m.pub.xyb_encoded) { plan->error = "unsupported: upsampling of a frame that is not XYB"; return -1; }
     if (!is_shown) { plan->error = "unsupported: upsampled reference frame"; return -1; }
   }
@@ -751,7 +767,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   F.no_output = is_shown ? 0 : 1;
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
-  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1) ? 1 : 0;
+  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;

@@ -49,6 +49,15 @@ __global__ void __launch_bounds__(256) k_upsampled_write(DevBuffers B, const uin
   if (X >= F.full_w || Y >= F.full_h || frame_failed(B)) return;
   upsampled_write_pixel(B, stat, B.out_bits, X, Y);
 }
+__global__ void __launch_bounds__(256) k_upsample_alpha(DevBuffers B, const uint8_t *stat) {
+  const DevFrame &F = frame_of(B);
+  const int X = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), Y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (X >= F.full_w || Y >= F.full_h || frame_failed(B)) return;
+  upsample_alpha_pixel(B, F, stat, X, Y);
+}
+void launch_upsample_alpha(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
+  hipLaunchKernelGGL(k_upsample_alpha, dim3((full_w + 63) / 64, (full_h + 3) / 4), dim3(256), 0, s, B, stat);
+}
 void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
   const dim3 g((full_w + 63) / 64, (full_h + 3) / 4);
   hipLaunchKernelGGL(k_upsample, g, dim3(256), 0, s, B, stat);

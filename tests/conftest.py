@@ -92,7 +92,9 @@ LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 PATCH_LOSSLESS_CASES = ["ls400x300_e7", "ls700x500_e5", "lsa400x300_e7"]
 PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",      # VarDCT main frame, XYB Modular reference frame
                       # Upsampling 2x / 4x / 8x (K: frames coded at a fraction of their size; the reference's quality <= 12), the last one with patches too
-                      "vu400x300_e7_d10", "vu523x267_e7_up4", "vu523x267_e7_up8", "vus400x300_e7_d12"]
+                      "vu400x300_e7_d10", "vu523x267_e7_up4", "vu523x267_e7_up8", "vus400x300_e7_d12",
+                      # RGBA at low quality: alpha coded at half size (extra-channel upsampling; its values get the writer's dither like the colour), with patches, and alpha alone at half size
+                      "vua400x300_e7_d12", "vusa400x300_e7_d12", "va400x300_e7_ecup2"]
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]

@@ -50,6 +50,7 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
     for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) save_ref_pixel(B, F, dst, x, y);
   }
   if (F.no_output) return;
+  if (F.alpha_up > 1 && F.mod_out[3] >= 0) for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_alpha_pixel(B, F, stat, X, Y);
   if (F.upsampling > 1) {                                  // k_upsample, then the writer at full resolution
     for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_pixel(B, F, stat, X, Y);
     for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsampled_write_pixel(B, stat, out_bits, X, Y);
@@ -104,8 +105,9 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   for (int c = 0; c < 3; c++) { B.lf[c] = lf[c].data(); B.lf_s[c] = lf[3 + c].data(); B.coef[c] = coef[c].data(); B.plane_a[c] = pl[c].data(); B.plane_b[c] = pl[3 + c].data(); }
   B.coef_off = coef_off.data(); B.lf_scratch = scr.data(); B.err = errw; B.out = out;
   const DevFrame &F0 = *(const DevFrame *)plan.tables.data();
-  std::vector<float> upv[3];
+  std::vector<float> upv[4];
   if (F0.upsampling > 1) for (int c = 0; c < 3; c++) { upv[c].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[c] = upv[c].data(); }
+  if (F0.alpha_up > 1) { upv[3].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[3] = upv[3].data(); }
   for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data();
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);

@@ -92,6 +92,10 @@ CASES = {
     "vu523x267_e7_up4": (523, 267, dict(seed=4), dict(effort=7, distance=2.0, extra=((2, 4),))),
     "vu523x267_e7_up8": (523, 267, dict(seed=4), dict(effort=7, distance=1.0, extra=((2, 8),))),
     "vus400x300_e7_d12": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=12.0)),       # upsampling + patches
+    # ... and RGBA at low quality: the alpha channel is coded at half size too (extra-channel upsampling), or alone (RESAMPLING of the extra channels = 3)
+    "vua400x300_e7_d12": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=12.0)),
+    "vusa400x300_e7_d12": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(effort=7, distance=12.0)),
+    "va400x300_e7_ecup2": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=1.0, extra=((3, 2),))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
