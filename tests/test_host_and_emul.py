@@ -329,3 +329,32 @@ def test_icc_command_decoder_rejects_malformed_streams(icc_harness):
     ok = _icc_enc(128 + 8, b"\x00" + b"\x04\x10" + _varint(31) + _varint(8), hdr + bytes(8))
     rc, out, err = _run_icc(icc_harness, ok)
     assert rc == 0, (rc, out, err[-400:])
+
+
+def test_reference_encoder_probe_table_on_cpu_harness(emul):
+    """VERDICT r3's probe, kept alive: images encoded by the reference's encoder HERE (oracle/_ref; its defaults — distance + effort only, interop/
+    JxlEncoding.cpp:145-160 — plus a few explicit settings) and decoded by the product's host parser + device functions: non-photographic content
+    (palettes, patches), low quality (upsampled frames, with alpha too), odd sizes, progressive / responsive, lossy Modular.  Lossless bit-exact,
+    lossy max 1 / mean <= 0.05 against the reference's own decode of the same bytes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("the reference encoder (oracle/_ref) is not here")
+    import synth
+    shot, photo = synth.screenshot(200, 150, 1), synth.photo_like(200, 150, 3)
+    a = np.full((150, 200, 1), 255, np.uint8); a[:40, :50] = 0; a[75:, 100:] = 128
+    photo_a = np.concatenate([photo, a], axis=2)
+    cases = [(shot, dict(lossless=True, effort=1)), (shot, dict(lossless=True, effort=3)), (shot, dict(lossless=True, effort=7)), (shot, dict(distance=1.0, effort=7)),
+             (shot, dict(distance=3.0, effort=9)), (synth.gradient(200, 1).repeat(150, axis=0).copy(), dict(lossless=True, effort=7)), (synth.two_colour(200, 150, 1), dict(lossless=True, effort=7)),
+             (photo, dict(distance=10.0, effort=7)), (photo, dict(distance=25.0, effort=7)), (photo_a, dict(distance=12.0, effort=7)), (synth.photo_like(33, 17, 2), dict(distance=12.0, effort=7)),
+             (photo, dict(distance=1.0, effort=7, extra=((17, 1),))), (photo, dict(distance=1.0, effort=7, modular=1)), (synth.photo_like(7, 5, 4), dict(lossless=True, effort=3))]
+    for img, ek in cases:
+        data = jxl_ref.encode(img, **ek)
+        want, _, _ = jxl_ref.decode(data)
+        out = emul(data)
+        d = np.abs(out.astype(int) - want.astype(int))
+        if ek.get("lossless"):
+            assert d.max() == 0, (img.shape, ek)
+        else:
+            assert d.max() <= 1 and d.mean() <= 0.05, (img.shape, ek, d.max(), d.mean())
