@@ -603,6 +603,9 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   frame_hdr &f = pv->f;
   const size_t csn = plan->cs_size;
   std::vector<DevSection> &secs = pv->secs;
+  // a frame may exceed the canvas (cropped frames, reference frames of a patch dictionary), but one that is orders of magnitude larger than the
+  // image it belongs to only sizes allocations: refused
+  if ((int64_t)f.coded_width * (int64_t)f.coded_height > 64 * (int64_t)raw_w * (int64_t)raw_h + ((int64_t)1 << 24)) { plan->error = "unsupported: frame far larger than the image"; return -1; }
   if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
   if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
