@@ -102,6 +102,17 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
     return data
 
 
+def encode_jpeg(jpeg: bytes, effort=7):
+    """JPEG -> JPEG XL with the reference's JxlConstruction call sequence (interop/JxlConstruction.hpp:46-90)."""
+    out = C.c_void_p(); n = C.c_size_t()
+    rc = lib().ref_encode_jpeg(jpeg, len(jpeg), int(effort), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"ref_encode_jpeg failed rc={rc}")
+    data = C.string_at(out.value, n.value)
+    lib().ref_free(out)
+    return data
+
+
 def fnv1a64(b: bytes) -> int:
     h = 0xcbf29ce484222325
     # vectorised FNV is awkward; fall back to a C-speed-ish loop via int.from_bytes chunks

@@ -259,3 +259,41 @@ done:
   p_JxlThreadParallelRunnerDestroy(runner);
   return rc;
 }
+
+/* JPEG -> JPEG XL as the reference's JxlConstruction does (interop/JxlConstruction.hpp:46-90): StoreJPEGMetadata, lossless frame settings,
+ * effort, decoding speed 3, JxlEncoderAddJPEGFrame.  The result is a VarDCT frame in YCbCr with the JPEG's quantisation tables. */
+int ref_encode_jpeg(const uint8_t *jpeg, size_t jpeg_size, int effort, uint8_t **out, size_t *out_size) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlEncoderCreate); SYM(h_jxl, JxlEncoderDestroy); SYM(h_jxl, JxlEncoderSetParallelRunner);
+  SYM(h_jxl, JxlEncoderStoreJPEGMetadata); SYM(h_jxl, JxlEncoderFrameSettingsCreate); SYM(h_jxl, JxlEncoderSetFrameLossless);
+  SYM(h_jxl, JxlEncoderFrameSettingsSetOption); SYM(h_jxl, JxlEncoderAddJPEGFrame); SYM(h_jxl, JxlEncoderCloseInput); SYM(h_jxl, JxlEncoderProcessOutput);
+  SYM(h_thr, JxlThreadParallelRunner); SYM(h_thr, JxlThreadParallelRunnerCreate);
+  SYM(h_thr, JxlThreadParallelRunnerDestroy); SYM(h_thr, JxlThreadParallelRunnerDefaultNumWorkerThreads);
+  int rc = -2;
+  *out = NULL; *out_size = 0;
+  JxlEncoder *enc = p_JxlEncoderCreate(NULL);
+  void *runner = p_JxlThreadParallelRunnerCreate(NULL, p_JxlThreadParallelRunnerDefaultNumWorkerThreads());
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetParallelRunner(enc, p_JxlThreadParallelRunner, runner)) goto done;
+  if (JXL_ENC_SUCCESS != p_JxlEncoderStoreJPEGMetadata(enc, JXL_TRUE)) { rc = -3; goto done; }
+  JxlEncoderFrameSettings *fs = p_JxlEncoderFrameSettingsCreate(enc, NULL);
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetFrameLossless(fs, JXL_TRUE)) { rc = -4; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_EFFORT, effort)) { rc = -5; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_DECODING_SPEED, 3)) { rc = -6; goto done; }
+  if (JXL_ENC_SUCCESS != p_JxlEncoderAddJPEGFrame(fs, jpeg, jpeg_size)) { rc = -7; goto done; }
+  p_JxlEncoderCloseInput(enc);
+  size_t cap = 1 << 16;
+  uint8_t *buf = (uint8_t *)malloc(cap), *next = buf;
+  size_t avail = cap;
+  JxlEncoderStatus st = JXL_ENC_NEED_MORE_OUTPUT;
+  while (st == JXL_ENC_NEED_MORE_OUTPUT) {
+    st = p_JxlEncoderProcessOutput(enc, &next, &avail);
+    if (st == JXL_ENC_NEED_MORE_OUTPUT) { size_t off = (size_t)(next - buf); cap *= 2; buf = (uint8_t *)realloc(buf, cap); next = buf + off; avail = cap - off; }
+  }
+  if (st != JXL_ENC_SUCCESS) { free(buf); rc = -11; goto done; }
+  *out = buf; *out_size = (size_t)(next - buf);
+  rc = 0;
+done:
+  p_JxlEncoderDestroy(enc);
+  p_JxlThreadParallelRunnerDestroy(runner);
+  return rc;
+}
