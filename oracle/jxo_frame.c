@@ -29,6 +29,7 @@ typedef struct {
 typedef struct {
   int frame_type, encoding; uint64_t flags;
   int do_ycbcr, upsampling, group_size_shift, x_qm, b_qm;
+  int hshift[3], vshift[3], subsampled;   /* YCbCr chroma subsampling: channel c (0 Cb, 1 Y, 2 Cr) is coded at 1 / 2^shift of the frame */
   int num_passes, pass_shift[12], num_ds, ds[4], ds_last[4];
   int have_crop, x0, y0, width, height;
   int blend_mode, blend_source, duration, is_last, save_as_ref, save_before_ct;
@@ -193,13 +194,20 @@ static int read_frame_header(jxo_br *br, const img_meta *m, uint32_t img_w, uint
     f->flags = jxo_u64(br);
     if (!m->pub.xyb_encoded) f->do_ycbcr = jxo_bool(br);
     int use_lf_frame = (f->flags & 32) != 0;
-    if (f->do_ycbcr && !use_lf_frame) { for (int i = 0; i < 3; i++) if (jxo_bits(br, 2)) JXO_FAIL("unsupported: chroma subsampling"); }
+    if (f->do_ycbcr && !use_lf_frame) {
+      /* YCbCrChromaSubsampling: a 2-bit sampling-factor mode per channel (0: 1x1, 1: 2x2, 2: 2x1, 3: 1x2); a channel's shift is the largest factor minus its own */
+      static const int kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+      int mode[3], maxh = 0, maxv = 0;
+      for (int i = 0; i < 3; i++) { mode[i] = (int)jxo_bits(br, 2); if (kH[mode[i]] > maxh) maxh = kH[mode[i]]; if (kV[mode[i]] > maxv) maxv = kV[mode[i]]; }
+      for (int i = 0; i < 3; i++) { f->hshift[i] = maxh - kH[mode[i]]; f->vshift[i] = maxv - kV[mode[i]]; if (f->hshift[i] || f->vshift[i]) f->subsampled = 1; }
+    }
     if (!use_lf_frame) {
       f->upsampling = (int)jxo_u32(br, -1, 1, -1, 2, -1, 4, -1, 8);
       for (int i = 0; i < m->num_extra; i++) if (jxo_u32(br, -1, 1, -1, 2, -1, 4, -1, 8) != 1) JXO_FAIL("unsupported: extra channel upsampling");
     }
     if (f->encoding == 1) f->group_size_shift = (int)jxo_bits(br, 2);
     if (f->encoding == 0 && m->pub.xyb_encoded) { f->x_qm = (int)jxo_bits(br, 3); f->b_qm = (int)jxo_bits(br, 3); }
+    else if (f->encoding == 0) f->x_qm = f->b_qm = 2;          /* not coded for an image that is not XYB: both multipliers are 1 */
     if (f->frame_type != 2) {
       f->num_passes = (int)jxo_u32(br, -1, 1, -1, 2, -1, 3, 3, 4);
       if (f->num_passes != 1) {
@@ -450,6 +458,7 @@ typedef struct {
   float *lf[3];
   uint32_t *coef_off; int32_t *coef[3];
   /* HfGlobal */
+  float *qt_frame[17][3];           /* dequant weights coded in the frame (DequantMatrices other than the library's); NULL: library table */
   int num_presets;
   uint32_t *orders[12][13][3];      /* [pass][order][c] */
   jxo_ec hf_code[12];
@@ -522,14 +531,35 @@ static int read_lf_group(fstate *s, jxo_br *br, int g) {
     if (f->flags & 32) JXO_FAIL("unsupported: LF frame");
     int extra = (int)jxo_bits(br, 2);
     jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = 16;
-    for (int c = 0; c < 3; c++) jxo_modimg_add(&im, bw, bh, 0, 0);
+    /* stream channels are Y, X (Cb), B (Cr); a subsampled channel carries the group's rectangle >> its shifts */
+    static const int chan_of[3] = {1, 0, 2};
+    for (int i = 0; i < 3; i++) jxo_modimg_add(&im, bw >> f->hshift[chan_of[i]], bh >> f->vshift[chan_of[i]], 0, 0);
     if (jxo_modular_decode(br, &im, 1 + g, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
     float inv_quant_dc = 65536.0f / ((float)s->global_scale * (float)s->quant_lf);
     float mul = 1.0f / (float)(1 << extra);
     float fac[3];
     for (int c = 0; c < 3; c++) fac[c] = s->lf_dequant[c] * inv_quant_dc * mul;
+    if (jxo_debug) fprintf(stderr, "lfgroup %d: extra %d fac %g %g %g  first ints Y %d %d X %d B %d\n", g, extra, fac[0], fac[1], fac[2], im.ch[0].d[0], im.ch[0].d[1], im.ch[1].d[0], im.ch[2].d[0]);
     float cfl_x = s->base_x + (float)s->ytox_dc / (float)s->color_factor;
     float cfl_b = s->base_b + (float)s->ytob_dc / (float)s->color_factor;
+    if (f->subsampled) {
+      /* no chroma from luma on LF; every channel on its own grid (stride xb), the block-context bucket at full resolution from the shifted samples */
+      for (int i = 0; i < 3; i++) {
+        int c = chan_of[i], cw = bw >> f->hshift[c], chh = bh >> f->vshift[c];
+        for (int y = 0; y < chh; y++) for (int x = 0; x < cw; x++)
+          s->lf[c][(size_t)((by0 >> f->vshift[c]) + y) * (size_t)s->xb + (size_t)((bx0 >> f->hshift[c]) + x)] = (float)im.ch[i].d[y * cw + x] * fac[c];
+      }
+      for (int y = 0; y < bh; y++) for (int x = 0; x < bw; x++) {
+        int32_t q[3];
+        for (int i = 0; i < 3; i++) { int c = chan_of[i]; q[c] = im.ch[i].d[(y >> f->vshift[c]) * (bw >> f->hshift[c]) + (x >> f->hshift[c])]; }
+        int ix = 0, iy = 0, ib = 0;
+        for (int t = 0; t < s->nb_lf_thr[0]; t++) if (q[0] > s->lf_thr[0][t]) ix++;
+        for (int t = 0; t < s->nb_lf_thr[1]; t++) if (q[1] > s->lf_thr[1][t]) iy++;
+        for (int t = 0; t < s->nb_lf_thr[2]; t++) if (q[2] > s->lf_thr[2][t]) ib++;
+        int bucket = ix; bucket = bucket * (s->nb_lf_thr[2] + 1) + ib; bucket = bucket * (s->nb_lf_thr[1] + 1) + iy;
+        s->lf_idx[(size_t)(by0 + y) * (size_t)s->xb + (size_t)(bx0 + x)] = (uint8_t)bucket;
+      }
+    } else
     for (int y = 0; y < bh; y++)
       for (int x = 0; x < bw; x++) {
         int32_t qy = im.ch[0].d[y * bw + x], qx = im.ch[1].d[y * bw + x], qb = im.ch[2].d[y * bw + x];
@@ -622,7 +652,43 @@ static int read_lf_group(fstate *s, jxo_br *br, int g) {
 
 static int read_hf_global(fstate *s, jxo_br *br) {
   const frame_hdr *f = &s->f;
-  if (!jxo_bool(br)) JXO_FAIL("unsupported: custom dequant matrices");
+  if (!jxo_bool(br)) {
+    /* DequantMatrices (ISO/IEC 18181-1 I.2.4): one encoding per quant table.  Mode 0 library, 6 DCT band parameters, 7 RAW (a Modular image of
+       3 channels: what libjxl writes for the 8x8 table of a recompressed JPEG); the parametrised 8x8 special tables (modes 1-5) are not restated */
+    for (int t = 0; t < 17; t++) {
+      int mode = (int)jxo_bits(br, 3);
+      int rows = kQTRows[t] * 8, cols = kQTCols[t] * 8, n = rows * cols;
+      if (mode == 0) continue;
+      float *w[3];
+      for (int c = 0; c < 3; c++) w[c] = s->qt_frame[t][c] = (float *)calloc((size_t)n, 4);
+      if (mode == 6) {
+        int nb = (int)jxo_bits(br, 4) + 1;
+        double b[3][17];
+        for (int c = 0; c < 3; c++) { for (int i = 0; i < nb; i++) b[c][i] = jxo_f16(br); if (b[c][0] < 1e-8) JXO_FAIL("bad DCT quant parameters"); b[c][0] *= 64.0; }
+        for (int c = 0; c < 3; c++) {
+          double bands[17];
+          bands[0] = b[c][0];
+          for (int i = 1; i < nb; i++) { bands[i] = bands[i - 1] * band_mult(b[c][i]); if (bands[i] < 1e-8) JXO_FAIL("bad DCT quant parameters"); }
+          for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) {
+            double dx = (double)x / (cols - 1), dy = (double)y / (rows - 1);
+            w[c][y * cols + x] = (float)interp_bands(sqrt(dx * dx + dy * dy), sqrt(2.0) + 1e-6, bands, nb);
+          }
+        }
+      } else if (mode == 7) {
+        float den = jxo_f16(br);
+        if (den < 1e-8f) JXO_FAIL("bad RAW quant table denominator");
+        jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = 8;
+        for (int c = 0; c < 3; c++) jxo_modimg_add(&im, cols, rows, 0, 0);
+        if (jxo_modular_decode(br, &im, 1 + 3 * f->num_lf_groups + t, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
+        for (int c = 0; c < 3; c++) for (int i = 0; i < n; i++) {
+          int q = im.ch[c].d[i];
+          if (q <= 0) { jxo_modimg_free(&im); JXO_FAIL("RAW quant table entry <= 0"); }
+          w[c][i] = 1.0f / (den * (float)q);          /* the "weight" as the library tables hold it; the dequant multiplier is its reciprocal, ~ den * q */
+        }
+        jxo_modimg_free(&im);
+      } else JXO_FAIL("unsupported: parametrised 8x8 quant tables (mode %d)", mode);
+    }
+  }
   s->num_presets = 1 + (int)jxo_bits(br, ceil_log2u((uint32_t)f->num_groups));
   for (int p = 0; p < f->num_passes; p++) {
     uint32_t used = jxo_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
@@ -679,10 +745,13 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
         for (int ci = 0; ci < 3; ci++) {
           int c = corder[ci];
           int *nzc = nz + (size_t)c * (size_t)bw * (size_t)bh;
+          int hs = f->hshift[c], vs = f->vshift[c];
+          if (((x >> hs) << hs) != x || ((y >> vs) << vs) != y) continue;        /* this channel has no block here */
+          int sx = x >> hs, sy = y >> vs;
           int predicted;
-          if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * bw];
-          else if (y == 0) predicted = nzc[x - 1];
-          else predicted = (nzc[(y - 1) * bw + x] + nzc[y * bw + x - 1] + 1) / 2;
+          if (sx == 0) predicted = sy == 0 ? 32 : nzc[(sy - 1) * bw];
+          else if (sy == 0) predicted = nzc[sx - 1];
+          else predicted = (nzc[(sy - 1) * bw + sx] + nzc[sy * bw + sx - 1] + 1) / 2;
           /* block context */
           int qf_idx = 0;
           for (int t = 0; t < s->nb_qf_thr; t++) if ((uint32_t)s->qf[o] > s->qf_thr[t]) qf_idx++;
@@ -696,7 +765,7 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
           int nzctx = (nzp < 8 ? nzp : 4 + nzp / 2) * s->num_bctx + bctx + ctx_offset;
           int nzeros = (int)jxo_ec_read(ec, br, nzctx);
           if (nzeros > size - covered) { free(nz); JXO_FAIL("too many nonzeros (group %d)", g); }
-          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * bw + x + ix] = (nzeros + covered - 1) >> log2c;
+          for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(sy + iy) * bw + sx + ix] = (nzeros + covered - 1) >> log2c;
           int histo = ctx_offset + s->num_bctx * 37 + 458 * bctx;
           const uint32_t *order = s->orders[pass][ord][c];
           int32_t *blk = s->coef[c] + s->coef_off[o];
@@ -893,7 +962,7 @@ static void reconstruct_vardct(fstate *s) {
       float mul = inv_gs / (float)s->qf[o];
       for (int c = 0; c < 3; c++) {
         const int32_t *q = s->coef[c] + s->coef_off[o];
-        const float *w = qt_weights[qt][c];
+        const float *w = s->qt_frame[qt][c] ? s->qt_frame[qt][c] : qt_weights[qt][c];
         for (int k = 0; k < n; k++) {
           int v = q[k];
           float a;
@@ -912,17 +981,70 @@ static void reconstruct_vardct(fstate *s) {
       int srows = cy < cx ? cy : cx, scols = cy < cx ? cx : cy;   /* storage dims in cells */
       for (int c = 0; c < 3; c++) {
         float lfb[32 * 32], ss[32 * 32];
-        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) lfb[iy * cx + ix] = s->lf[c][o + (size_t)iy * (size_t)s->xb + (size_t)ix];
+        int hs = f->hshift[c], vs = f->vshift[c];
+        if (((bx >> hs) << hs) != bx || ((by >> vs) << vs) != by) continue;      /* subsampled channel: no block at this position */
+        const int cbx = bx >> hs, cby = by >> vs;                                  /* the channel's own block grid */
+        const size_t co = (size_t)cby * (size_t)s->xb + (size_t)cbx;
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) lfb[iy * cx + ix] = s->lf[c][co + (size_t)iy * (size_t)s->xb + (size_t)ix];
         dct2d(lfb, cx, cy, cx, ss);
         for (int a = 0; a < srows; a++) for (int b = 0; b < scols; b++) {
           float sa, sb;
           if (cy >= cx) { sa = llf_scale(cx, a); sb = llf_scale(cy, b); } else { sa = llf_scale(cy, a); sb = llf_scale(cx, b); }
           S[c][a * scols * 8 + b] = ss[a * scols + b] * sa * sb;
         }
-        transform_block(st, S[c], s->plane[c] + (size_t)by * 8 * (size_t)s->pw + (size_t)bx * 8, s->pw);
+        transform_block(st, S[c], s->plane[c] + (size_t)cby * 8 * (size_t)s->pw + (size_t)cbx * 8, s->pw);
       }
     }
   for (int c = 0; c < 3; c++) free(S[c]);
+}
+
+/* Chroma upsampling of a YCbCr frame (libjxl's render stages HChromaUps, then VChromaUps, before the loop filters): a subsampled channel of
+   cw = ceil(w / 2) samples per row becomes out[2x] = 0.25 in[x - 1] + 0.75 in[x], out[2x + 1] = 0.25 in[x + 1] + 0.75 in[x] (the product 0.75 in[x]
+   first, then one fused multiply-add), mirrored at the channel's edges. */
+static inline int mirror1(int x, int n) { return x < 0 ? -x - 1 : x >= n ? 2 * n - 1 - x : x; }
+static void chroma_upsample(fstate *s, int w, int h) {
+  const frame_hdr *f = &s->f;
+  for (int c = 0; c < 3; c++) {
+    if (!f->hshift[c] && !f->vshift[c]) continue;
+    int cw = f->hshift[c] ? (w + 1) / 2 : w, chh = f->vshift[c] ? (h + 1) / 2 : h;
+    float *p = s->plane[c];
+    size_t pw = (size_t)s->pw;
+    if (f->hshift[c]) {
+      float *row = (float *)malloc(4 * (size_t)cw);
+      for (int y = 0; y < chh; y++) {
+        memcpy(row, p + (size_t)y * pw, 4 * (size_t)cw);
+        for (int x = 0; x < cw; x++) {
+          float cur = row[x] * 0.75f, prev = row[mirror1(x - 1, cw)], next = row[mirror1(x + 1, cw)];
+          if (2 * x < s->pw) p[(size_t)y * pw + (size_t)(2 * x)] = fmaf(0.25f, prev, cur);
+          if (2 * x + 1 < s->pw) p[(size_t)y * pw + (size_t)(2 * x + 1)] = fmaf(0.25f, next, cur);
+        }
+      }
+      free(row);
+    }
+    if (f->vshift[c]) {
+      float *col = (float *)malloc(4 * (size_t)chh);
+      for (int x = 0; x < w; x++) {
+        for (int y = 0; y < chh; y++) col[y] = p[(size_t)y * pw + (size_t)x];
+        for (int y = 0; y < chh; y++) {
+          float cur = col[y] * 0.75f, top = col[mirror1(y - 1, chh)], bot = col[mirror1(y + 1, chh)];
+          if (2 * y < s->ph) p[(size_t)(2 * y) * pw + (size_t)x] = fmaf(top, 0.25f, cur);
+          if (2 * y + 1 < s->ph) p[(size_t)(2 * y + 1) * pw + (size_t)x] = fmaf(bot, 0.25f, cur);
+        }
+      }
+      free(col);
+    }
+  }
+}
+/* YCbCr -> RGB: full-range BT.601 as JFIF defines it, on samples centred on zero (Y + 128 / 255); channels Cb, Y, Cr -> R, G, B in place */
+static void ycbcr_to_rgb(fstate *s, int w, int h) {
+  const float c128 = 128.0f / 255, crcr = 1.402f, cgcb = -0.114f * 1.772f / 0.587f, cgcr = -0.299f * 1.402f / 0.587f, cbcb = 1.772f;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    size_t i = (size_t)y * (size_t)s->pw + (size_t)x;
+    float yv = s->plane[1][i] + c128, cb = s->plane[0][i], cr = s->plane[2][i];
+    s->plane[0][i] = fmaf(crcr, cr, yv);
+    s->plane[1][i] = fmaf(cgcr, cr, fmaf(cgcb, cb, yv));
+    s->plane[2][i] = fmaf(cbcb, cb, yv);
+  }
 }
 
 static inline int mirror(int x, int n) {
@@ -1105,6 +1227,7 @@ static void free_state(fstate *s) {
   free(s->bctx_map); jxo_tree_free(&s->gtree); jxo_modimg_free(&s->gmod);
   free(s->strategy); free(s->first); free(s->qf); free(s->sharp); free(s->lf_idx); free(s->xfromy); free(s->bfromy); free(s->coef_off);
   for (int c = 0; c < 3; c++) { free(s->lf[c]); free(s->coef[c]); free(s->plane[c]); }
+  for (int t = 0; t < 17; t++) for (int c = 0; c < 3; c++) free(s->qt_frame[t][c]);
   for (int p = 0; p < 12; p++) {
     for (int o = 0; o < 13; o++) for (int c = 0; c < 3; c++) free(s->orders[p][o][c]);
     if (s->hf_code[p].cl) jxo_ec_free(&s->hf_code[p]);
@@ -1132,7 +1255,6 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
   if (f->frame_type != 0 || !f->is_last) { jxo_set_error("unsupported: multi-frame / non-regular frame"); goto done; }
   if (f->upsampling != 1) { jxo_set_error("unsupported: upsampling"); goto done; }
   if (f->have_crop && (f->x0 || f->y0 || f->width != (int)raw_w || f->height != (int)raw_h)) { jxo_set_error("unsupported: cropped frame"); goto done; }
-  if (f->do_ycbcr) { jxo_set_error("unsupported: YCbCr"); goto done; }
   if (f->num_passes > 11) { jxo_set_error("too many passes"); goto done; }
   /* TOC */
   int nsec = (f->num_groups == 1 && f->num_passes == 1) ? 1 : 1 + f->num_lf_groups + 1 + f->num_groups * f->num_passes;
@@ -1169,6 +1291,11 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
     for (int i = 0; i < nsec && i < 12; i++) fprintf(stderr, "  sec %d off %zu size %u\n", i, sec_off[i], sec_size[i]); }
   /* state */
   s->xb = (f->width + 7) / 8; s->yb = (f->height + 7) / 8;
+  if (f->subsampled) {          /* the block grid is padded to whole MCUs: ceil(size / (8 << max shift)) << max shift */
+    int mh = 0, mv = 0;
+    for (int c = 0; c < 3; c++) { if (f->hshift[c] > mh) mh = f->hshift[c]; if (f->vshift[c] > mv) mv = f->vshift[c]; }
+    s->xb = ((f->width + (8 << mh) - 1) / (8 << mh)) << mh; s->yb = ((f->height + (8 << mv) - 1) / (8 << mv)) << mv;
+  }
   s->pw = s->xb * 8; s->ph = s->yb * 8;
   s->tiles_x = (s->xb + 7) / 8; s->tiles_y = (s->yb + 7) / 8;
   size_t ncell = (size_t)s->xb * (size_t)s->yb;
@@ -1210,8 +1337,10 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
   size_t npx = (size_t)w * (size_t)h;
   if (f->encoding == 0) {
     if (m.num_extra && jxo_modular_undo_transforms(&s->gmod)) goto done;   /* extra channels (alpha): global palette etc. */
-    if (!(f->flags & 128)) adaptive_lf_smoothing(s);
+    if (!(f->flags & 128)) { if (f->subsampled) { jxo_set_error("unsupported: adaptive LF smoothing of a chroma-subsampled frame"); goto done; } adaptive_lf_smoothing(s); }
     reconstruct_vardct(s);
+    if (f->subsampled) chroma_upsample(s, w, h);
+    if (f->do_ycbcr) ycbcr_to_rgb(s, w, h);
     if (jxo_debug) { FILE *fp = fopen("/tmp/jxo_xyb.bin", "wb"); for (int c = 0; c < 3; c++) fwrite(s->plane[c], 4, (size_t)s->pw * (size_t)s->ph, fp); fclose(fp); }
     if (f->gab) gaborish(s, w, h);
     if (f->epf_iters) epf(s, w, h);
@@ -1309,7 +1438,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
           t = t < 0 ? 0 : t > 1 ? 1 : t;   /* NaN -> 0 via first compare false... keep simple */
           t = t * maxv;
           /* libjxl 8-bit writer dither: by output position, row / column swapped for the transposing orientations (pinned by the reference's output) */
-          if (out_bits == 8 && m.pub.xyb_encoded) t += kDither32[m.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
+          if (out_bits == 8 && (m.pub.xyb_encoded || f->encoding == 0)) t += kDither32[m.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
           long q = lrintf(t);
           if (out_bits == 16) ((uint16_t *)o)[di + (size_t)c] = (uint16_t)q; else o[di + (size_t)c] = (uint8_t)q;
         }
