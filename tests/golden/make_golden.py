@@ -102,6 +102,39 @@ CASES = {
 }
 
 
+# JPEG transcodes: what the reference's JxlCoder.construct / JXLJpegInterop (cpp/JXLJpegInterop.cpp:40 -> interop/JxlConstruction.hpp:46-90,
+# JxlEncoderAddJPEGFrame) writes and its decode() reads back: a VarDCT frame that is not XYB — YCbCr, the JPEG's quant tables as RAW dequant
+# matrices, DCT8 only, chroma coded at the JPEG's subsampling.  The JPEG itself is made here by Pillow (libjpeg) from a seeded synthetic image.
+JPEG_CASES = {
+    # name: (w, h, synth kwargs, Pillow save kwargs)
+    "j444_200x136": (200, 136, dict(seed=3), dict(quality=85, subsampling=0)),
+    "j420_200x136": (200, 136, dict(seed=3), dict(quality=85, subsampling=2)),          # ragged in both directions: 12.5 x 8.5 MCUs
+    "j422_200x136": (200, 136, dict(seed=3), dict(quality=85, subsampling=1)),
+    "j420_600x410": (600, 410, dict(seed=5), dict(quality=75, subsampling=2)),          # 3 x 2 groups, multi-section
+    "j420_prog_333x277": (333, 277, dict(seed=6), dict(quality=90, subsampling=2, progressive=True)),
+    "jgrey_160x120": (160, 120, dict(seed=7, grey=True), dict(quality=85)),
+    "j420s_400x300": (400, 300, dict(gen="screenshot", seed=2), dict(quality=92, subsampling=2)),
+}
+
+
+def add_jpeg_cases(meta, only):
+    import io
+    from PIL import Image
+    for name, (w, h, sk, jk) in JPEG_CASES.items():
+        if only and name not in only:
+            continue
+        img = make_image(w, h, sk)
+        buf = io.BytesIO()
+        (Image.fromarray(img[..., 0], "L") if img.shape[2] == 1 else Image.fromarray(img[..., :3])).save(buf, "JPEG", **jk)
+        data = jxl_ref.encode_jpeg(buf.getvalue())
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), jpeg_bytes=len(buf.getvalue()), shape=list(out.shape), dtype=str(out.dtype), info=info, jpeg=jk, synth=sk)
+        print(name, len(buf.getvalue()), len(data), out.shape)
+
+
 def make_image(w, h, sk):
     """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
     sk = dict(sk)
@@ -229,6 +262,7 @@ def main():
     if not only or "assets" in only:
         add_assets(meta)
     add_rowsum_cases(meta, only)
+    add_jpeg_cases(meta, only)
     if not only or "big_assets" in only:
         add_big_assets(meta)
     if only:

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import (LOSSLESS_CASES, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, ROOT, load_case)
+                      U16_MEAN_ABS, ROOT, JPEG_CASES, load_case)
 
 
 @pytest.mark.parametrize("name", LOSSLESS_CASES)
@@ -23,6 +23,15 @@ def test_oracle_vardct_within_tolerance(oracle, name):
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.max() <= VARDCT_MAX_ABS and d.mean() <= vardct_mean_tol(name)
     assert np.array_equal(out[..., 3], exp[..., 3])
+
+
+@pytest.mark.parametrize("name", JPEG_CASES)
+def test_oracle_jpeg_transcodes(oracle, name):
+    """YCbCr frames with chroma subsampling and RAW dequant matrices (recompressed JPEGs) against the reference binary's pixels."""
+    data, exp = load_case(name)
+    out, info = oracle.decode(data, 8)
+    d = np.abs(out.astype(int) - exp.astype(int))
+    assert d.max() <= VARDCT_MAX_ABS and d.mean() <= 1e-3, (d.max(), d.mean())          # measured: 1 - 27 samples of a file differ, by one
 
 
 def test_oracle_basic_info_matches_reference(oracle, golden_meta):
