@@ -347,6 +347,7 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
 int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
+  if (F->subsampled) launch_chroma_upsample(S.B, plan.width, plan.height, stream);      // recompressed JPEG: chroma to full resolution (no loop filters in between)
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
   if (plan.save_slot >= 0) {
     const int k = plan.save_slot;

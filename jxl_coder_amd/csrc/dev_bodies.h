@@ -81,6 +81,31 @@ JXL_DEV void pass_group_body(const DevBuffers &B, DevPassScratch &S, int g, int 
   }
 }
 
+// ---- a DCT8x8 varblock of a chroma-subsampled YCbCr frame (recompressed JPEG): channel c has a block at cell (bx, by) only when the cell is aligned to its
+// sampling, and that block lives at (bx >> hshift, by >> vshift) of the channel's own grid — LF sample, pixels.  Other strategies do not occur there.
+template <class Sync>
+JXL_DEV void recon_block_subsampled(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int st, int tid, int nthreads, Sync sync) {
+  const DevFrame &F = frame_of(B);
+  const DevStatic &ST = *(const DevStatic *)stat;
+  if (st != 0) { if (tid == 0) *B.err |= kErrUnsupportedBlock | kErrStageRecon; return; }
+  recon_phaseA(B, stat, ST, S, 64, bx, by, tid, nthreads);      // a channel without a block here reads zeros: its coefficients were never written
+  sync();
+  bool present[3]; int cbx[3], cby[3];
+  for (int c = 0; c < 3; c++) {
+    cbx[c] = bx >> F.hshift[c]; cby[c] = by >> F.vshift[c];
+    present[c] = (cbx[c] << F.hshift[c]) == bx && (cby[c] << F.vshift[c]) == by;
+  }
+  if (tid == 0) for (int c = 0; c < 3; c++) if (present[c]) S[c * 64] = B.lf_s[c][(size_t)cby[c] * (size_t)F.xb + (size_t)cbx[c]];      // LLF of a 1 x 1 block: the LF sample (all scales are 1)
+  sync();
+  for (int c = 0; c < 3; c++) {
+    if (!present[c]) continue;
+    recon_idct_pass1(stat, ST, S + c * 64, T, 8, 8, tid, nthreads);
+    sync();
+    recon_idct_pass2(stat, ST, T, B.plane_a[c] + (size_t)cby[c] * 8 * (size_t)F.pw + (size_t)cbx[c] * 8, F.pw, 8, 8, tid, nthreads);
+    sync();
+  }
+}
+
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]
 // kSpecial: the 8x8 special transforms can occur (small-block launch only); kPerChannel: S holds ONE channel (LDS: S[n] + T[n])
 template <bool kSpecial, bool kPerChannel = false, class Sync>
@@ -95,6 +120,7 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   const int n = cx * cy * 64;
   if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock | kErrStageRecon; return; }   // DCT128+/256
   if (n < nmin || n > nmax) return;                 // another size class' launch handles it
+  if (F.subsampled) { recon_block_subsampled(B, stat, S, T, bx, by, st, tid, nthreads, sync); return; }
   float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};
   const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
   if (kPerChannel) {

@@ -12,6 +12,7 @@ namespace jxlamd {
 // the image planes of a composed frame after its loop filters: the per-stage filter kernels ping-pong between the two sets
 JXL_DEV bool compose_final_is_a(const DevFrame &F) {
   if (F.is_modular && !F.xyb_modular) return true;
+  if (F.subsampled) return false;                       // chroma_upsample_pixel moved the image into the second set
   int n = (F.gab ? 1 : 0) + F.epf_iters;
   return (n & 1) == 0;
 }
@@ -110,6 +111,29 @@ JXL_DEV void upsampled_write_pixel(const DevBuffers &B, const uint8_t *stat, int
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)Y * (size_t)F.full_w + (size_t)X;
   xyb_write_value(B, stat, *(const DevStatic *)stat, B.up[0][o], B.up[1][o], B.up[2][o], out_bits, X, Y);
+}
+
+// Chroma upsampling of a YCbCr frame whose chroma is coded at half resolution (libjxl's render stages HChromaUps, then VChromaUps, in front of the
+// loop filters — which such a frame, a recompressed JPEG, does not have): out[2x] = 0.25 in[x - 1] + 0.75 in[x], out[2x + 1] = 0.25 in[x + 1] + 0.75 in[x],
+// first along the rows, then along the columns of the result; the channel's edges (ceil(size / 2) samples) are mirrored; every product and sum rounded on
+// its own.  One output sample of channel c, plane_a -> plane_b; channels at full resolution are copied.
+JXL_DEV int mirror1(int x, int n) { return x < 0 ? -x - 1 : x >= n ? 2 * n - 1 - x : x; }
+JXL_DEV void chroma_upsample_pixel(const DevBuffers &B, const DevFrame &F, int c, int X, int Y) {
+  const int hs = F.hshift[c], vs = F.vshift[c];
+  const int cw = hs ? (F.width + 1) / 2 : F.width, chh = vs ? (F.height + 1) / 2 : F.height;
+  const float *in = B.plane_a[c];
+  const size_t pw = (size_t)F.pw;
+  const int x = hs ? X >> 1 : X, xn = hs ? mirror1((X & 1) ? x + 1 : x - 1, cw) : 0;
+  const int y = vs ? Y >> 1 : Y, yn = vs ? mirror1((Y & 1) ? y + 1 : y - 1, chh) : 0;
+  float cur, nb = 0.0f;
+  if (hs) {
+    cur = mul_add_rn(0.25f, in[(size_t)y * pw + (size_t)xn], in[(size_t)y * pw + (size_t)x] * 0.75f);
+    if (vs) nb = mul_add_rn(0.25f, in[(size_t)yn * pw + (size_t)xn], in[(size_t)yn * pw + (size_t)x] * 0.75f);
+  } else {
+    cur = in[(size_t)y * pw + (size_t)x];
+    if (vs) nb = in[(size_t)yn * pw + (size_t)x];
+  }
+  B.plane_b[c][(size_t)Y * pw + (size_t)X] = vs ? mul_add_rn(nb, 0.25f, cur * 0.75f) : cur;
 }
 
 // copy the composed frame into a reference slot (dense w x h planes)

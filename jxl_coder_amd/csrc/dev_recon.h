@@ -14,6 +14,12 @@ namespace jxlamd {
 
 JXL_DEV const float *st_f(const uint8_t *st, uint32_t off) { return (const float *)(st + off); }
 JXL_DEV int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+// dequant multipliers of quant table qt, channel c: the library's (static tables) unless the frame codes its own (DevFrame::qw_frame_off: RAW tables of a
+// recompressed JPEG, DCT band parameters)
+JXL_DEV const float *quant_mul(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, const DevStatic &ST, int qt, int c) {
+  const uint32_t off = F.qw_frame_off[qt][c];
+  return off ? (const float *)(B.tables + off) : st_f(stat, ST.qw_off[qt][c]);
+}
 
 // ------------------------------------------------------------------ adaptive LF smoothing (one cell)
 JXL_DEV void lf_smooth_cell(const DevBuffers &B, int x, int y) {
@@ -59,6 +65,7 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
   const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
   const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
   const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+  const float *qw[3] = {quant_mul(B, F, stat, ST, qt, 0), quant_mul(B, F, stat, ST, qt, 1), quant_mul(B, F, stat, ST, qt, 2)};
   for (int k = tid; k < n; k += nthreads) {
     float v[3];
     for (int c = 0; c < 3; c++) {
@@ -74,7 +81,7 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
       else if (q == 1) a = F.quant_bias[c];
       else if (q == -1) a = -F.quant_bias[c];
       else a = (float)q - F.quant_bias[3] / (float)q;
-      v[c] = a * (mul * F.dm[c] * st_f(stat, ST.qw_off[qt][c])[k]);
+      v[c] = a * (mul * F.dm[c] * qw[c][k]);
     }
     if (only_c >= 0) { S[k] = only_c == 0 ? v[0] + kx * v[1] : only_c == 1 ? v[1] : v[2] + kb * v[1]; continue; }
     S[k] = v[0] + kx * v[1];
@@ -416,38 +423,9 @@ JXL_DEV float tf_709(float v) {
   return v < 0 ? -r : r;
 }
 
-JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y);
-JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *const src[3], int out_bits, int x, int y) {
-  const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
-  xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
-}
-JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y) {
+// the writer's last step: three colour values in [0, 1] of frame pixel (x, y) -> canvas position, orientation, alpha, dither, RGBA8 / RGBA16
+JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, const float (&v)[3], int out_bits, int x, int y) {
   const DevFrame &F = frame_of(B);
-  const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
-  const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
-  float v[3];
-  float hlg_ratio = 1.0f;
-  if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
-    float lum = 0.0f;
-    for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * (F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2);
-    // libjxl: min(pow(luminance, exponent), 1e9) — pow(0, negative exponent) is +inf there, i.e. the clamp value
-    hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : (lum == 0.0f && F.hlg_exponent < 0.0f) ? 1e9f : 0.0f;
-    if (hlg_ratio > 1e9f) hlg_ratio = 1e9f;
-  }
-  for (int c = 0; c < 3; c++) {
-    float lin = F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2;
-    switch (F.transfer) {
-      case 18: lin = tf_hlg(lin * hlg_ratio); break;
-      case 17: { float a = pow_pos(fabsf(lin), 1.0f / 2.6f); lin = lin < 0 ? -a : a; } break;
-      case 13: lin = tf_srgb(lin); break;
-      case 16: lin = tf_pq(lin, F.intensity_target); break;
-      case 1: lin = tf_709(lin); break;
-      case -1: { float a = pow_pos(fabsf(lin), F.gamma); lin = lin < 0 ? -a : a; } break;
-      default: break;   // 8 = linear
-    }
-    v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
-    if (!(lin == lin)) v[c] = 0.0f;
-  }
   const int fx = x, fy = y;                            // frame position (the alpha plane below is read there)
   x += F.crop_x0; y += F.crop_y0;                      // canvas position
   const int w = F.canvas_w, h = F.canvas_h;
@@ -486,6 +464,64 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
     for (int c = 0; c < 3; c++) o16[c] = (uint16_t)(int)rintf(v[c] * 65535.0f);
     o16[3] = (uint16_t)(int)rintf(alpha * 65535.0f);
   }
+}
+JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y);
+JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *const src[3], int out_bits, int x, int y) {
+  const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
+  xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
+}
+JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
+  const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
+  float v[3];
+  float hlg_ratio = 1.0f;
+  if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
+    float lum = 0.0f;
+    for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * (F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2);
+    // libjxl: min(pow(luminance, exponent), 1e9) — pow(0, negative exponent) is +inf there, i.e. the clamp value
+    hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : (lum == 0.0f && F.hlg_exponent < 0.0f) ? 1e9f : 0.0f;
+    if (hlg_ratio > 1e9f) hlg_ratio = 1e9f;
+  }
+  for (int c = 0; c < 3; c++) {
+    float lin = F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2;
+    switch (F.transfer) {
+      case 18: lin = tf_hlg(lin * hlg_ratio); break;
+      case 17: { float a = pow_pos(fabsf(lin), 1.0f / 2.6f); lin = lin < 0 ? -a : a; } break;
+      case 13: lin = tf_srgb(lin); break;
+      case 16: lin = tf_pq(lin, F.intensity_target); break;
+      case 1: lin = tf_709(lin); break;
+      case -1: { float a = pow_pos(fabsf(lin), F.gamma); lin = lin < 0 ? -a : a; } break;
+      default: break;   // 8 = linear
+    }
+    v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
+    if (!(lin == lin)) v[c] = 0.0f;
+  }
+  rgba_store(B, stat, ST, v, out_bits, x, y);
+}
+
+// Writer of a VarDCT frame that is not XYB (a recompressed JPEG): the planes hold the image's own samples — R, G, B, or Cb, Y, Cr centred on zero, which
+// libjxl's YCbCr stage turns into RGB with the full-range BT.601 matrix of JFIF (multiply and add rounded separately: the reference is an SSE2 build).
+// No transfer function (the samples are already in the image's colour space); clamp, the 8-bit writer's dither, orientation as for every frame.
+JXL_DEV float mul_add_rn(float a, float b, float c) {
+#ifdef __HIPCC__
+  return __fadd_rn(__fmul_rn(a, b), c);
+#else
+  volatile float p = a * b;      // (the CPU harness may be built with contraction enabled)
+  return p + c;
+#endif
+}
+JXL_DEV void plain_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float c0, float c1, float c2, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  float v[3] = {c0, c1, c2};
+  if (F.not_xyb == 2) {
+    const float yv = c1 + 128.0f / 255;
+    v[0] = mul_add_rn(1.402f, c2, yv);
+    v[1] = mul_add_rn(-0.299f * 1.402f / 0.587f, c2, mul_add_rn(-0.114f * 1.772f / 0.587f, c0, yv));
+    v[2] = mul_add_rn(1.772f, c0, yv);
+  }
+  for (int c = 0; c < 3; c++) { const float t = v[c]; v[c] = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t; if (!(t == t)) v[c] = 0.0f; }
+  rgba_store(B, stat, ST, v, out_bits, x, y);
 }
 
 }  // namespace jxlamd

@@ -129,6 +129,15 @@ struct DevFrame {
   // colour
   float opsin_inv[9];              // already scaled by 255/intensity_target and target-primaries matrix
   float opsin_bias[3], opsin_bias_cbrt[3];
+  // VarDCT frames of an image that is not XYB (recompressed JPEGs): no opsin inverse, no transfer function — the planes hold the image's own
+  // samples, R, G, B (not_xyb = 1) or Cb, Y, Cr centred on zero (not_xyb = 2: full-range BT.601 to RGB in the writer)
+  int32_t not_xyb;
+  // chroma subsampling of such a frame: channel c (0 Cb, 1 Y, 2 Cr) is coded at 1 / 2^shift — LF samples, varblocks and pixels of the channel live on
+  // its own grid in the top-left corner of the full-size arrays (same strides); enlarged after reconstruction (dev_compose.h: chroma_upsample_*)
+  int32_t subsampled, hshift[3], vshift[3];
+  // dequant matrices coded in the frame (I.2.4: RAW tables of a recompressed JPEG, DCT band parameters): float[rows * cols] multipliers per
+  // quant table and channel in the frame blob; 0 = the library table of the static tables
+  uint32_t qw_frame_off[17][3];
   int32_t transfer;                // 13 sRGB, 8 linear, 16 PQ, 1 bt709, 17 DCI, 18 HLG, -1 gamma
   float hlg_lum[3], hlg_exponent;  // HLG target: luminance weights of the target primaries and (gamma - 1) of the inverse OOTF (0: not applied)
   float gamma, intensity_target;

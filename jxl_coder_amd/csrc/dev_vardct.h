@@ -99,6 +99,9 @@ JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g, i
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   DevChanOut *ch = S.ch;
   for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
+  if (F.subsampled) {       // YCbCr frame with subsampled chroma: stream channels Y, Cb, Cr carry the group's rectangle >> the channel's shifts (the block grid is whole MCUs)
+    for (int i = 0; i < 3; i++) { const int c = i == 0 ? 1 : i == 1 ? 0 : 2; ch[i].w = q.bw >> F.hshift[c]; ch[i].h = q.bh >> F.vshift[c]; }
+  }
   return lf_decode_stream<kWave, kGeneral>(S, ch, 3, 1 + g, tid);
 }
 // phase 2b (lane 0): block count, begin the HF-metadata stream
@@ -255,6 +258,34 @@ JXL_DEV void lf_group_epilogue(const DevBuffers &B, int g, int lane, int nlanes)
   const float mul = 1.0f / (float)(1 << scr[kLfScratchInts - 1]);
   const float fx = F.lf_fac[0] * mul, fy = F.lf_fac[1] * mul, fb = F.lf_fac[2] * mul;
   const int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_sharp = m_b + 1024 + 2 * 65536;
+  if (F.subsampled) {
+    // every channel on its own grid in the top-left corner of its LF plane (stride xb), no chroma from luma on LF; the block-context bucket of a
+    // full-resolution cell comes from the samples that cover it
+    const int cof[3] = {1, 0, 2};                       // stream channel i holds channel cof[i]
+    const float fac[3] = {fx, fy, fb};
+    for (int i = 0; i < 3; i++) {
+      const int c = cof[i], cw = bw >> F.hshift[c], chh = bh >> F.vshift[c];
+      for (int k = lane; k < cw * chh; k += nlanes) {
+        const int y = k / cw, x = k - y * cw;
+        B.lf[c][(size_t)((by0 >> F.vshift[c]) + y) * (size_t)F.xb + (size_t)((bx0 >> F.hshift[c]) + x)] = (float)scr[(size_t)i * 65536 + (size_t)k] * fac[c];
+      }
+    }
+    for (int i = lane; i < bw * bh; i += nlanes) {
+      const int y = i / bw, x = i - y * bw;
+      const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+      const int32_t qy = scr[(y >> F.vshift[1]) * (bw >> F.hshift[1]) + (x >> F.hshift[1])];
+      const int32_t qx = scr[65536 + (y >> F.vshift[0]) * (bw >> F.hshift[0]) + (x >> F.hshift[0])];
+      const int32_t qb = scr[2 * 65536 + (y >> F.vshift[2]) * (bw >> F.hshift[2]) + (x >> F.hshift[2])];
+      int ix = 0, iy = 0, ib = 0;
+      for (int t = 0; t < F.nb_lf_thr[0]; t++) if (qx > F.lf_thr[0][t]) ix++;
+      for (int t = 0; t < F.nb_lf_thr[1]; t++) if (qy > F.lf_thr[1][t]) iy++;
+      for (int t = 0; t < F.nb_lf_thr[2]; t++) if (qb > F.lf_thr[2][t]) ib++;
+      int bucket = ix; bucket = bucket * (F.nb_lf_thr[2] + 1) + ib; bucket = bucket * (F.nb_lf_thr[1] + 1) + iy;
+      B.lf_idx[o] = (uint8_t)bucket;
+      const int sh = m_sharp[i];
+      B.sharp[o] = (uint8_t)(sh < 0 ? 0 : sh > 7 ? 7 : sh);
+    }
+  } else
   for (int i = lane; i < bw * bh; i += nlanes) {
     int y = i / bw, x = i - y * bw;
     size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
@@ -397,10 +428,14 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : ci == 1 ? 0 : 2;
         uint8_t *nzc = S.nz[c];
+        // chroma-subsampled frames: a channel only has the blocks aligned to its sampling, and predicts its nonzero counts on its own grid
+        const int hs = F.subsampled ? F.hshift[c] : 0, vs = F.subsampled ? F.vshift[c] : 0;
+        if (((x >> hs) << hs) != x || ((y >> vs) << vs) != y) continue;
+        const int sx = x >> hs, sy = y >> vs;
         int predicted;
-        if (x == 0) predicted = y == 0 ? 32 : nzc[(y - 1) * 32];
-        else if (y == 0) predicted = nzc[x - 1];
-        else predicted = (nzc[(y - 1) * 32 + x] + nzc[y * 32 + x - 1] + 1) / 2;
+        if (sx == 0) predicted = sy == 0 ? 32 : nzc[(sy - 1) * 32];
+        else if (sy == 0) predicted = nzc[sx - 1];
+        else predicted = (nzc[(sy - 1) * 32 + sx] + nzc[sy * 32 + sx - 1] + 1) / 2;
         int idx = c < 2 ? c ^ 1 : 2;
         idx = idx * 13 + ord;
         idx = idx * (F.nb_qf_thr + 1) + qf_idx;
@@ -412,7 +447,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
         int nzeros = (int)(fast ? pass_ec_read(S, ev.alias, ev.log_alpha, lds_ctx, gctx, b, state, (uint32_t)nzctx) : ec_read(ev, b, state, (uint32_t)nzctx));
         if (nzeros > size - covered) return kErrBitstream;
         const uint8_t nzv = (uint8_t)((nzeros + covered - 1) >> log2c);
-        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(y + iy) * 32 + x + ix] = nzv;
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) nzc[(sy + iy) * 32 + sx + ix] = nzv;
         const int histo = F.num_bctx * 37 + 458 * bctx;
         const uint32_t *order = ord < 2 ? S.order8[ord][c] : order_ptr(B, F, pass, ord, c);
         int32_t *blk = B.coef[c] + (size_t)g * 65536 + off;

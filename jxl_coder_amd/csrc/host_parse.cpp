@@ -26,6 +26,7 @@ typedef struct { int nbands; float b[3][8]; } hx_dctparams;
 #include "dither_lut.h"
 #include "upsampling_weights.h"
 #include "host_icc_synth.inc"
+#include "host_modular_small.inc"
 }  // namespace
 
 namespace jxlamd {
@@ -95,6 +96,7 @@ struct Priv {                 // state between phase 1 and phase 2
   DevFrame F;
   std::vector<DevSection> secs;
   int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // reference slots as they are when this frame is decoded
+  int64_t tree_bit = -1;        // where the global MA tree starts inside LfGlobal (-1: none): a RAW dequant matrix of HfGlobal may be coded with it
 };
 
 static void fill_info(const img_meta &m, ImageInfo *i) {
@@ -168,7 +170,51 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
   DevFrame &F = pv->F;
   const frame_hdr &f = pv->f;
   Blob blob(plan->tables);
-  if (!hx_bool(br)) { plan->error = "unsupported: custom dequant matrices"; return -1; }
+  if (!hx_bool(br)) {
+    // DequantMatrices (ISO/IEC 18181-1 I.2.4), one encoding per quant table: 0 library, 6 DCT band parameters, 7 RAW (a Modular image of three
+    // channels — libjxl's 8x8 table of a recompressed JPEG).  The multipliers go into the frame blob (DevFrame::qw_frame_off); the parametrised
+    // special 8x8 tables (modes 1 - 5), which no encoder writes, are reported unsupported.
+    for (int t = 0; t < 17; t++) {
+      const int mode = (int)hx_bits(br, 3);
+      const int rows = kQTRows[t] * 8, cols = kQTCols[t] * 8, n = rows * cols;
+      if (mode == 0) continue;
+      std::vector<float> mul[3];
+      for (int c = 0; c < 3; c++) mul[c].assign((size_t)n, 0.0f);
+      if (mode == 6) {
+        const int nb = (int)hx_bits(br, 4) + 1;
+        double b[3][17];
+        for (int c = 0; c < 3; c++) {
+          for (int i = 0; i < nb; i++) b[c][i] = hx_f16(br);
+          if (b[c][0] < 1e-8) { plan->error = "bad DCT quant parameters"; return -1; }
+          b[c][0] *= 64.0;
+        }
+        for (int c = 0; c < 3; c++) {
+          double bands[17];
+          bands[0] = b[c][0];
+          for (int i = 1; i < nb; i++) { bands[i] = bands[i - 1] * band_mult(b[c][i]); if (bands[i] < 1e-8) { plan->error = "bad DCT quant parameters"; return -1; } }
+          for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) {
+            const double dx = (double)x / (cols - 1), dy = (double)y / (rows - 1);
+            mul[c][(size_t)(y * cols + x)] = 1.0f / (float)interp_bands(sqrt(dx * dx + dy * dy), sqrt(2.0) + 1e-6, bands, nb);
+          }
+        }
+      } else if (mode == 7) {
+        const float den = hx_f16(br);
+        if (den < 1e-8f) { plan->error = "bad RAW quant table denominator"; return -1; }
+        std::vector<int32_t> q;
+        if (modsmall::decode(br, cols, rows, 3, 1 + 3 * f.num_lf_groups + t, plan->cs + pv->secs[0].off,
+                             plan->single_section ? plan->cs_size - pv->secs[0].off : pv->secs[0].size, pv->tree_bit, &q, &plan->error)) return -1;
+        for (int c = 0; c < 3; c++) for (int i = 0; i < n; i++) {
+          const int32_t v = q[(size_t)c * (size_t)n + (size_t)i];
+          if (v <= 0) { plan->error = "RAW quant table entry <= 0"; return -1; }
+          const float wgt = 1.0f / (den * (float)v);           // libjxl keeps this "weight" and multiplies by its reciprocal (~ den * q)
+          if (wgt >= 1e8f || wgt < 1e-8f) { plan->error = "RAW quant table entry out of range"; return -1; }
+          mul[c][(size_t)i] = 1.0f / wgt;
+        }
+      } else { plan->error = "unsupported: parametrised 8x8 dequant matrices (encoding mode " + std::to_string(mode) + ")"; return -1; }
+      if (br->err) { plan->error = "truncated HfGlobal"; return -1; }
+      for (int c = 0; c < 3; c++) F.qw_frame_off[t][c] = blob.append(mul[c].data(), (size_t)n * 4);
+    }
+  }
   F.num_presets = 1 + (int)hx_bits(br, ceil_log2u((uint32_t)f.num_groups));
   if (f.num_passes > 4) { plan->error = "unsupported: more than 4 passes"; return -1; }
   if (getenv("JXLAMD_PARSE_TRACE")) fprintf(stderr, "HfGlobal: %d presets, %d block contexts, %d groups\n", F.num_presets, F.num_bctx, f.num_groups);
@@ -607,7 +653,16 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // image it belongs to only sizes allocations: refused
   if ((int64_t)f.coded_width * (int64_t)f.coded_height > 64 * (int64_t)raw_w * (int64_t)raw_h + ((int64_t)1 << 24)) { plan->error = "unsupported: frame far larger than the image"; return -1; }
   if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
-  if (f.encoding == 0 && !m.pub.xyb_encoded) { plan->error = "unsupported: VarDCT frame without XYB"; return -1; }
+  if (f.encoding == 0 && !m.pub.xyb_encoded) {
+    // a VarDCT frame of an image that is not XYB: a recompressed JPEG (YCbCr, chroma possibly subsampled, RAW dequant matrices).  Decoded like any
+    // VarDCT frame up to the planes, which then hold the image's own samples (dev_compose.h: chroma upsampling, YCbCr -> RGB in the writer)
+    if (m.num_extra) { plan->error = "unsupported: extra channels on a VarDCT frame that is not XYB"; return -1; }
+    if (m.pub.num_color_channels != 3 && !f.do_ycbcr) { plan->error = "unsupported: grey VarDCT frame without XYB / YCbCr"; return -1; }
+    if (f.upsampling != 1 || (f.flags & 2) || !is_shown) { plan->error = "unsupported: upsampling / patches / reference use of a VarDCT frame that is not XYB"; return -1; }
+    if (f.subsampled && (f.gab || f.epf_iters)) { plan->error = "unsupported: loop filters on a chroma-subsampled frame"; return -1; }
+    if (f.subsampled && !(f.flags & 128)) { plan->error = "unsupported: adaptive LF smoothing of a chroma-subsampled frame"; return -1; }
+    if (f.subsampled && f.num_passes != 1) { plan->error = "unsupported: multi-pass chroma-subsampled frame"; return -1; }
+  }
   if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
   if (f.encoding == 1 && !m.pub.xyb_encoded && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
   for (int i = 0; i < m.num_extra; i++) {
@@ -629,7 +684,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     plan->cropped = true;
   }
   if (!is_shown && (f.width < 1 || f.height < 1)) { plan->error = "empty frame"; return -1; }
-  if (f.do_ycbcr) { plan->error = "unsupported: YCbCr"; return -1; }
+  if (f.do_ycbcr && f.encoding == 1) { plan->error = "unsupported: YCbCr Modular frame"; return -1; }
   if (f.flags & (1 | 16 | 32)) { plan->error = "unsupported: splines/noise/LF frame"; return -1; }
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
   const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
@@ -639,7 +694,16 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   memset(&F, 0, sizeof(F));
   F.width = f.coded_width; F.height = f.coded_height;          // (an upsampled frame: the coded size; its pixels are full_w x full_h)
   F.upsampling = f.upsampling; F.full_w = f.width; F.full_h = f.height;
-  F.xb = (F.width + 7) / 8; F.yb = (F.height + 7) / 8; F.pw = F.xb * 8; F.ph = F.yb * 8;
+  F.xb = (F.width + 7) / 8; F.yb = (F.height + 7) / 8;
+  if (f.encoding == 0 && f.subsampled) {          // the block grid is padded to whole MCUs: ceil(size / (8 << max shift)) << max shift
+    int mh = 0, mv = 0;
+    for (int c = 0; c < 3; c++) { mh = std::max(mh, f.hshift[c]); mv = std::max(mv, f.vshift[c]); }
+    F.xb = ((F.width + (8 << mh) - 1) / (8 << mh)) << mh; F.yb = ((F.height + (8 << mv) - 1) / (8 << mv)) << mv;
+    F.subsampled = 1;
+    for (int c = 0; c < 3; c++) { F.hshift[c] = f.hshift[c]; F.vshift[c] = f.vshift[c]; }
+  }
+  F.pw = F.xb * 8; F.ph = F.yb * 8;
+  F.not_xyb = (f.encoding == 0 && !m.pub.xyb_encoded) ? (f.do_ycbcr ? 2 : 1) : 0;
   F.tiles_x = (F.xb + 7) / 8; F.tiles_y = (F.yb + 7) / 8;
   F.xgroups = f.xgroups; F.ygroups = f.ygroups; F.num_groups = f.num_groups;
   F.xlfg = f.xlfg; F.ylfg = f.ylfg; F.num_lf_groups = f.num_lf_groups;
@@ -686,6 +750,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
   hx_tree tree; memset(&tree, 0, sizeof(tree));
   const bool have_tree = hx_bool(&sb);
+  pv->tree_bit = have_tree ? (int64_t)sb.pos : -1;
   if (have_tree && hx_tree_read(&tree, &sb)) { hx_tree_free(&tree); plan->error = std::string("global MA tree: ") + hx_last_error(); return -1; }
   if (sb.err) { hx_tree_free(&tree); plan->error = "truncated LfGlobal"; return -1; }
   if (have_tree) {
@@ -770,7 +835,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   F.no_output = is_shown ? 0 : 1;
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
-  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1) ? 1 : 0;
+  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;

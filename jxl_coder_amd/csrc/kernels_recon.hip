@@ -74,7 +74,7 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
   const auto uptr = [](const void *p) { const uint64_t v = (uint64_t)p; return (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32))) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); };
   int32_t *qp[3]; const float *qw[3];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { qp[c] = (int32_t *)uptr(&B.coef[c][(size_t)g * 65536 + off]) + tid; qw[c] = (const float *)uptr(st_f(stat, ST.qw_off[qt][c])) + tid; }
+  for (int c = 0; c < 3; c++) { qp[c] = (int32_t *)uptr(&B.coef[c][(size_t)g * 65536 + off]) + tid; qw[c] = (const float *)uptr(quant_mul(B, F, stat, ST, qt, c)) + tid; }
   int q[3][4]; float w[3][4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
@@ -209,7 +209,7 @@ __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint
     else if (q == 1) a = F.quant_bias[c];
     else if (q == -1) a = -F.quant_bias[c];
     else a = (float)q - F.quant_bias[3] / (float)q;
-    v[c] = a * (mul * F.dm[c] * st_f(stat, ST.qw_off[qt][c])[lane]);
+    v[c] = a * (mul * F.dm[c] * quant_mul(B, F, stat, ST, qt, c)[lane]);
   }
   float s0 = v[0] + kx * v[1], s1 = v[1], s2 = v[2] + kb * v[1];
   if (lane == 0) { s0 = B.lf_s[0][o]; s1 = B.lf_s[1][o]; s2 = B.lf_s[2][o]; }      // the LLF "corner" of a 1x1 block is the LF sample itself (all scales are 1)
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     const int cell = (int)B.big_list[2][i];
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
-    if (skip_dct8) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
+    if (skip_dct8 && !F.subsampled) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
     __syncthreads();
     recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
@@ -264,7 +264,7 @@ __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8
   float *S = smem, *T = smem + 3 * 64;
   const DevFrame &F = frame_of(B);
   const uint32_t count = B.big_count[2];
-  if (wg >= count) return;
+  if (wg >= count || F.subsampled) return;           // chroma-subsampled frames (recompressed JPEGs): the generic small-block kernel places each channel on its own grid
   const int lane = (int)threadIdx.x;
   const DevStatic &ST = *(const DevStatic *)stat;
   float cx8[8], cy8[8];                               // 8-point cosine table, row k: this lane's column x = lane & 7 / its row y = lane >> 3
@@ -298,7 +298,7 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { q[c][j] = B.coef[c][(size_t)g * 65536 + off + (uint32_t)(lane + 64 * j)]; w[c][j] = st_f(stat, ST.qw_off[qt][c])[lane + 64 * j]; }
+    for (int j = 0; j < NJ; j++) { q[c][j] = B.coef[c][(size_t)g * 65536 + off + (uint32_t)(lane + 64 * j)]; w[c][j] = quant_mul(B, F, stat, ST, qt, c)[lane + 64 * j]; }
   const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
   const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
   const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;

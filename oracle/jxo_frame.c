@@ -1000,7 +1000,7 @@ static void reconstruct_vardct(fstate *s) {
 
 /* Chroma upsampling of a YCbCr frame (libjxl's render stages HChromaUps, then VChromaUps, before the loop filters): a subsampled channel of
    cw = ceil(w / 2) samples per row becomes out[2x] = 0.25 in[x - 1] + 0.75 in[x], out[2x + 1] = 0.25 in[x + 1] + 0.75 in[x] (the product 0.75 in[x]
-   first, then one fused multiply-add), mirrored at the channel's edges. */
+   first, then multiply and add, each rounded: the reference's libjxl is an SSE2 build without fused multiply-add), mirrored at the channel's edges. */
 static inline int mirror1(int x, int n) { return x < 0 ? -x - 1 : x >= n ? 2 * n - 1 - x : x; }
 static void chroma_upsample(fstate *s, int w, int h) {
   const frame_hdr *f = &s->f;
@@ -1015,8 +1015,8 @@ static void chroma_upsample(fstate *s, int w, int h) {
         memcpy(row, p + (size_t)y * pw, 4 * (size_t)cw);
         for (int x = 0; x < cw; x++) {
           float cur = row[x] * 0.75f, prev = row[mirror1(x - 1, cw)], next = row[mirror1(x + 1, cw)];
-          if (2 * x < s->pw) p[(size_t)y * pw + (size_t)(2 * x)] = fmaf(0.25f, prev, cur);
-          if (2 * x + 1 < s->pw) p[(size_t)y * pw + (size_t)(2 * x + 1)] = fmaf(0.25f, next, cur);
+          if (2 * x < s->pw) p[(size_t)y * pw + (size_t)(2 * x)] = 0.25f * prev + cur;
+          if (2 * x + 1 < s->pw) p[(size_t)y * pw + (size_t)(2 * x + 1)] = 0.25f * next + cur;
         }
       }
       free(row);
@@ -1027,8 +1027,8 @@ static void chroma_upsample(fstate *s, int w, int h) {
         for (int y = 0; y < chh; y++) col[y] = p[(size_t)y * pw + (size_t)x];
         for (int y = 0; y < chh; y++) {
           float cur = col[y] * 0.75f, top = col[mirror1(y - 1, chh)], bot = col[mirror1(y + 1, chh)];
-          if (2 * y < s->ph) p[(size_t)(2 * y) * pw + (size_t)x] = fmaf(top, 0.25f, cur);
-          if (2 * y + 1 < s->ph) p[(size_t)(2 * y + 1) * pw + (size_t)x] = fmaf(bot, 0.25f, cur);
+          if (2 * y < s->ph) p[(size_t)(2 * y) * pw + (size_t)x] = top * 0.25f + cur;
+          if (2 * y + 1 < s->ph) p[(size_t)(2 * y + 1) * pw + (size_t)x] = bot * 0.25f + cur;
         }
       }
       free(col);
@@ -1041,9 +1041,9 @@ static void ycbcr_to_rgb(fstate *s, int w, int h) {
   for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
     size_t i = (size_t)y * (size_t)s->pw + (size_t)x;
     float yv = s->plane[1][i] + c128, cb = s->plane[0][i], cr = s->plane[2][i];
-    s->plane[0][i] = fmaf(crcr, cr, yv);
-    s->plane[1][i] = fmaf(cgcr, cr, fmaf(cgcb, cb, yv));
-    s->plane[2][i] = fmaf(cbcb, cb, yv);
+    s->plane[0][i] = crcr * cr + yv;
+    s->plane[1][i] = cgcr * cr + (cgcb * cb + yv);
+    s->plane[2][i] = cbcb * cb + yv;
   }
 }
 

@@ -42,6 +42,7 @@ struct RefStore { std::vector<float> p[4][3]; };
 
 // composition tail (jxlamd_decoder::launch_compose_tail): patches, copy into the reference slot, stand-alone writer
 static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F, int out_bits, RefStore &refs, const uint8_t *stat) {
+  if (F.subsampled) for (int c = 0; c < 3; c++) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) chroma_upsample_pixel(B, F, c, x, y);      // k_chroma_upsample
   const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
   for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
   if (plan.save_slot >= 0) {
@@ -60,6 +61,7 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
   for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) {
     if (F.is_modular && !F.xyb_modular) plain_write_pixel(B, out_bits, x, y);
+    else if (F.not_xyb) { const size_t po = (size_t)y * (size_t)F.pw + (size_t)x; plain_write_value(B, stat, *(const DevStatic *)stat, src[0][po], src[1][po], src[2][po], out_bits, x, y); }
     else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, out_bits, x, y);
   }
 }
