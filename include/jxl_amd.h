@@ -82,6 +82,16 @@ int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *
 int jxlamd_decode(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t out_capacity,
                   jxlamd_info *info);
 
+/* Animations (the reference's JxlAnimatedDecoder, interop/JxlAnimatedDecoder.hpp:68-185 and .cpp:28-144).
+ * jxlamd_anim_info  = what its constructor collects: *num_frames regular frames, their durations in ms (round(1000 * ticks * tps_den / tps_num); the first
+ *                     min(capacity, *num_frames) are stored), *loops = animation.num_loops (-1: not an animation).  Host only.
+ * jxlamd_decode_frame = getFrame(frame): coalesced frame `frame` (frames of non-zero duration and the last one count), i.e. the frame laid over the canvas its
+ *                     BlendingInfo names — kReplace / kAdd / kBlend / kMulAdd / kMul on colour and alpha, cropped layers, reference slots — decoded and
+ *                     blended on the GPU.  jxlamd_decode is jxlamd_decode_frame of the last frame (interop/JxlDecoding.cpp:164-166). */
+int jxlamd_anim_info(const uint8_t *jxl, size_t size, int32_t *durations_ms, int capacity, int32_t *num_frames, int32_t *loops);
+int jxlamd_decode_frame(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, int frame, uint32_t flags, void *out, size_t out_capacity,
+                        jxlamd_info *info);
+
 /* Same, with the compressed bytes ALSO resident in device memory at `jxl_dev` (skips the H2D of the codestream;
  * the host copy is still needed for header/TOC parsing). */
 int jxlamd_decode_resident(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags,

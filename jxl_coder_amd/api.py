@@ -168,6 +168,8 @@ def lib():
         L.jxlamd_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_output_size.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
         L.jxlamd_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_anim_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float * 5)]
         L.jxlamd_decode_batch_resident.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -253,6 +255,26 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return info.as_dict()
+
+    def decode_frame_to_device(self, data: bytes, frame: int, out_ptr: int, out_capacity: int, allowed_floats=False):
+        """Coalesced frame `frame` of an animation into device memory (jxlamd_decode_frame; the reference's JxlAnimatedDecoder::getFrame)."""
+        flags = (JXLAMD_ALLOW_16BIT if allowed_floats else 0) | JXLAMD_OUT_DEVICE
+        info = Info()
+        rc = lib().jxlamd_decode_frame(self._h, data, len(data), int(frame), flags, out_ptr, out_capacity, C.byref(info))
+        if rc:
+            _raise(rc, self._h)
+        return info.as_dict()
+
+    def decode_frame(self, data: bytes, frame: int):
+        """-> (h, w, 4) u8: coalesced frame `frame` (always 8-bit, as the reference's animated decoder: JxlAnimatedDecoder.cpp:60)."""
+        import numpy as np
+        w, h = JxlCoder.getSize(data)
+        out = np.empty((h, w, 4), np.uint8)
+        info = Info()
+        rc = lib().jxlamd_decode_frame(self._h, data, len(data), int(frame), 0, out.ctypes.data, out.nbytes, C.byref(info))
+        if rc:
+            _raise(rc, self._h)
+        return out, info.as_dict()
 
     def color_matrix_device(self, ptr: int, w: int, h: int, is_u16: bool, depth: int, primaries: int, transfer_function: int,
                             intensity_target: float, xy8=None):
@@ -476,6 +498,100 @@ class JxlCoder:
         rows = dst.cpu().numpy().reshape(h, ri.stride)
         name = "HARDWARE" if ri.resolved_config == int(PreferredColorConfig.HARDWARE) else FMT_NAMES[ri.format]
         return Bitmap(rows, w, h, int(ri.stride), name, bool(ri.use_floats), meta)
+
+
+def anim_info(data: bytes):
+    """-> (durations_ms, loops): the frame list the reference's JxlAnimatedDecoder constructor collects (interop/JxlAnimatedDecoder.hpp:68-185)."""
+    n, loops = C.c_int32(), C.c_int32()
+    rc = lib().jxlamd_anim_info(data, len(data), None, 0, C.byref(n), C.byref(loops))
+    if rc:
+        raise InvalidJXLException(lib().jxlamd_last_error(None).decode())
+    d = (C.c_int32 * max(1, n.value))()
+    lib().jxlamd_anim_info(data, len(data), d, n.value, C.byref(n), C.byref(loops))
+    return [int(d[i]) for i in range(n.value)], int(loops.value)
+
+
+class JxlAnimatedImage:
+    """class JxlAnimatedImage (kt/JxlAnimatedImage.kt:41-199) over jxlamd_anim_info / jxlamd_decode_frame: numberOfFrames, loopsCount, getFrameDuration,
+    getFrame(frame, scaleWidth, scaleHeight), getWidth / getHeight, close.  getFrame follows getFrameImpl (cpp/JxlAnimatedDecoderCoordinator.cpp:161-412):
+    always 8-bit; colour matrix / tone map (API < 34) -> ICC -> rescale -> reformat — the animated path's order, which differs from the still path's
+     — every stage on the HBM-resident frame."""
+
+    def __init__(self, data: bytes, preferredColorConfig=PreferredColorConfig.DEFAULT, scaleMode=ScaleMode.FIT, jxlResizeFilter=3, api_level=None):
+        _check_preconditions(preferredColorConfig, scaleMode, jxlResizeFilter, JxlCoder.api_level if api_level is None else api_level)
+        if not JxlCoder.isJXL(data):
+            raise InvalidJXLException("Not an JXL image")                          # JxlAnimatedDecoder.hpp:71-74
+        self._data, self._config, self.scaleMode, self._sampler = bytes(data), preferredColorConfig, scaleMode, jxlResizeFilter
+        self._api = JxlCoder.api_level if api_level is None else int(api_level)
+        self._durations, self._loops = anim_info(self._data)
+        self._w, self._h = JxlCoder.getSize(self._data)
+        self._open = True
+
+    def _assert_open(self):
+        if not self._open:
+            raise RuntimeError("Animated image is already closed, call of it is impossible")     # kt/JxlAnimatedImage.kt:159-165
+
+    @property
+    def numberOfFrames(self):
+        self._assert_open(); return len(self._durations)
+
+    @property
+    def loopsCount(self):
+        self._assert_open(); return self._loops
+
+    def getFrameDuration(self, frame: int) -> int:
+        self._assert_open()
+        if frame < 0 or frame >= len(self._durations):
+            raise ValueError("Requested frame index more than frames in the container")          # JxlAnimatedDecoder.cpp:35-38
+        return self._durations[frame]
+
+    def getWidth(self):
+        self._assert_open(); return self._w
+
+    def getHeight(self):
+        self._assert_open(); return self._h
+
+    def getFrame(self, frame: int, scaleWidth: int = 0, scaleHeight: int = 0):
+        import torch
+        self._assert_open()
+        if frame < 0:
+            raise ValueError("Frame position must be positive")                                    # JxlAnimatedDecoder.cpp:30-33
+        if frame >= len(self._durations):
+            raise ValueError("Requested frame index more than frames in the container")
+        dec = JxlCoder._decoder()
+        dev = f"cuda:{dec.device}"
+        w, h = self._w, self._h
+        raw = torch.empty(w * h * 4, dtype=torch.uint8, device=dev)
+        meta = dec.decode_frame_to_device(self._data, frame, raw.data_ptr(), raw.numel(), allowed_floats=False)
+        tf = meta["transfer_function"]
+        matrix = bool(meta["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and meta["color_space"] == 0 and self._api < 34)      # Coordinator.cpp:184-190
+        if matrix:
+            dec.color_matrix_device(raw.data_ptr(), w, h, False, 8, meta["primaries"], tf, meta["intensity_target"])
+        if meta["icc_size"] and not meta["prefer_encoding"]:                                       # Coordinator.cpp:267-274
+            buf = (C.c_uint8 * meta["icc_size"])(); n = C.c_size_t()
+            if lib().jxlamd_get_icc(self._data, len(self._data), buf, meta["icc_size"], C.byref(n)) == 0 and n.value:
+                dec.icc_transform_device(raw.data_ptr(), w, h, False, bytes(buf[:n.value]))
+        if (scaleWidth > 0 or scaleHeight > 0) and scaleWidth != 0 and scaleHeight != 0 and scaleWidth > 0 and scaleHeight > 0:      # Coordinator.cpp:275-294
+            q = dec.rescale_query(w, h, scaleWidth, scaleHeight, self.scaleMode)
+            scaled = torch.empty(q.out_w * q.out_h * 4, dtype=torch.uint8, device=dev)
+            dec.rescale_device(raw.data_ptr(), w, h, False, 8, scaleWidth, scaleHeight, self.scaleMode, self._sampler, bool(meta["has_alpha_in_origin"]), scaled.data_ptr(), scaled.numel())
+            raw, w, h = scaled, q.out_w, q.out_h
+        ri = dec.reformat_query(w, h, False, self._config, meta["has_alpha_in_origin"], self._api)
+        dst = torch.empty(int(ri.bytes), dtype=torch.uint8, device=dev)
+        ri = dec.reformat_device(raw.data_ptr(), w, h, False, 8, self._config, bool(meta["alpha_premultiplied"]), bool(meta["has_alpha_in_origin"]), self._api, dst.data_ptr(), dst.numel())
+        torch.cuda.synchronize()
+        rows = dst.cpu().numpy().reshape(h, ri.stride)
+        name = "HARDWARE" if ri.resolved_config == int(PreferredColorConfig.HARDWARE) else FMT_NAMES[ri.format]
+        return Bitmap(rows, w, h, int(ri.stride), name, bool(ri.use_floats), meta)
+
+    def close(self):
+        self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Bitmap:

@@ -249,8 +249,14 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.up_planes.ensure(4 * n * 4));
     for (int c = 0; c < 4; c++) B.up[c] = (float *)S.up_planes.p + (size_t)c * n;
   }
-  for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++)
-    B.ref[k][c] = (ref_store[k].p && Fh->ref_w[k] == ref_w[k] && Fh->ref_h[k] == ref_h[k] && ref_w[k] > 0) ? (float *)ref_store[k].p + (size_t)c * (size_t)ref_w[k] * (size_t)ref_h[k] : nullptr;
+  for (int k = 0; k < 4; k++) {
+    const bool have = ref_store[k].p && Fh->ref_w[k] == ref_w[k] && Fh->ref_h[k] == ref_h[k] && ref_w[k] > 0;
+    const size_t n = (size_t)ref_w[k] * (size_t)ref_h[k];
+    for (int c = 0; c < 3; c++) B.ref[k][c] = have ? (float *)ref_store[k].p + (size_t)c * n : nullptr;
+    B.ref_a[k] = (have && ref_alpha[k]) ? (float *)ref_store[k].p + 3 * n : nullptr;      // a blended canvas kept with its alpha plane
+  }
+  for (int c = 0; c < 4; c++) B.canvas_save[c] = nullptr;
+  if (Fh->blend && Fh->bl_src >= 0 && !B.ref[Fh->bl_src][0]) { set_error("blending: the source canvas is missing"); return JXLAMD_ERR_INVALID; }
   if (Fh->num_patches > 0) {
     const DevPatch *P = (const DevPatch *)(plan.tables.data() + Fh->patch_off);
     for (int i = 0; i < Fh->num_patches; i++) if (!B.ref[P[i].ref][0]) { set_error("patch dictionary: reference frame missing"); return JXLAMD_ERR_INVALID; }
@@ -349,11 +355,31 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   if (F->subsampled) launch_chroma_upsample(S.B, plan.width, plan.height, stream);      // recompressed JPEG: chroma to full resolution (no loop filters in between)
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
+  if (F->blend) {
+    // a frame of an animation over its canvas (dev_compose.h: blend_canvas_pixel): the background is a reference slot's canvas, the result goes out and / or
+    // becomes the new canvas of the frame's slot — in place when it is the slot it was read from (every pixel reads before it writes)
+    DevBuffers Bb = S.B;
+    if (plan.save_slot >= 0 && plan.save_canvas) {
+      const int k = plan.save_slot;
+      const size_t n = (size_t)F->canvas_w * (size_t)F->canvas_h;
+      const bool has_alpha = (F->has_ec || F->is_modular) && F->mod_out[3] >= 0;
+      const bool in_place = F->bl_src == k && ref_w[k] == F->canvas_w && ref_h[k] == F->canvas_h && ref_store[k].p;
+      if (!in_place) {
+        if (F->bl_src == k) { set_error("blending: canvas geometry changed"); return JXLAMD_ERR_INVALID; }
+        HIPCHECK(ref_store[k].ensure(4 * n * 4));
+      }
+      ref_w[k] = F->canvas_w; ref_h[k] = F->canvas_h; ref_alpha[k] = has_alpha;
+      for (int c = 0; c < 4; c++) Bb.canvas_save[c] = (c < 3 || has_alpha) ? (float *)ref_store[k].p + (size_t)c * n : nullptr;
+      if (in_place) for (int c = 0; c < 3; c++) Bb.ref[k][c] = Bb.canvas_save[c];
+    }
+    launch_blend_canvas(Bb, (const uint8_t *)stat.p, F->canvas_w, F->canvas_h, stream);
+    return JXLAMD_OK;
+  }
   if (plan.save_slot >= 0) {
     const int k = plan.save_slot;
     const size_t n = (size_t)plan.width * (size_t)plan.height;
     HIPCHECK(ref_store[k].ensure(3 * n * 4));
-    ref_w[k] = plan.width; ref_h[k] = plan.height;
+    ref_w[k] = plan.width; ref_h[k] = plan.height; ref_alpha[k] = false;
     launch_save_ref(S.B, plan.width, plan.height, (float *)ref_store[k].p, stream);
   }
   if (F->no_output) return JXLAMD_OK;
@@ -383,7 +409,8 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   return JXLAMD_OK;
 }
 
-int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info) {
+int jxlamd_decoder::decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info, int frame) {
+  target_frame = frame;
   int rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info);
   if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_once(jxl, size, jxl_dev, flags, out_ptr, out_cap, info); }       // with the largest table pool
   if (rc0 == kRetryPool) { set_error("LF table pool: the stream asked for a larger pool twice"); return JXLAMD_ERR_DEVICE; }
@@ -396,7 +423,7 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
   HIPCHECK(hipSetDevice(device));
   FrameSlot &S = slot(0);
   S.plan = FramePlan();
-  (void)plan_parse(jxl, size, &S.plan);
+  (void)plan_parse(jxl, size, &S.plan, target_frame);
   if (!S.plan.error.empty() || S.plan.tables.empty()) { set_error(S.plan.error); return err_class(S.plan.error); }
   int rc = decode_refs(S, flags);
   if (rc) return rc;
@@ -835,6 +862,26 @@ int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *
 int jxlamd_decode(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t cap, jxlamd_info *info) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   return jxlamd_guarded(d, [&]() -> int { return d->decode(jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out, cap, info); });
+}
+
+// Coalesced frame `frame` of an animation (what the reference's JxlAnimatedDecoder::getFrame returns, interop/JxlAnimatedDecoder.cpp:28-144): the frames it
+// is blended over are decoded into their reference slots first, all on the device.
+int jxlamd_decode_frame(jxlamd_decoder *d, const uint8_t *jxl, size_t size, int frame, uint32_t flags, void *out, size_t cap, jxlamd_info *info) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  if (frame < 0) { d->set_error("Frame position must be positive"); return JXLAMD_ERR_INVALID; }
+  return jxlamd_guarded(d, [&]() -> int { return d->decode(jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out, cap, info, frame); });
+}
+// The frame list of an animation as the reference's JxlAnimatedDecoder constructor collects it (interop/JxlAnimatedDecoder.hpp:68-185): *num_frames
+// entries (the first min(cap, *num_frames) durations, in milliseconds, are stored) and the loop count (-1: the file is not an animation).  Host only.
+int jxlamd_anim_info(const uint8_t *jxl, size_t size, int32_t *durations_ms, int cap, int32_t *num_frames, int32_t *loops) {
+  return jxlamd_guarded(nullptr, [&]() -> int {
+    std::vector<int32_t> d; int32_t l = -1; std::string err;
+    if (parse_anim_info(jxl, size, &d, &l, &err)) { g_tls_error = err; return err_class(err); }
+    if (num_frames) *num_frames = (int32_t)d.size();
+    if (loops) *loops = l;
+    for (int i = 0; i < cap && i < (int)d.size() && durations_ms; i++) durations_ms[i] = d[(size_t)i];
+    return JXLAMD_OK;
+  });
 }
 
 int jxlamd_decode_resident(jxlamd_decoder *d, const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out,

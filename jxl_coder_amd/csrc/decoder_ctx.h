@@ -129,7 +129,7 @@ struct jxlamd_decoder {
   DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;
   std::vector<FrameSlot *> ref_slots;     // reference frames of the file being decoded (patch dictionaries), one slot each
-  DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // the four reference slots: 3 dense f32 planes each
+  DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0}; bool ref_alpha[4] = {false, false, false, false}; int target_frame = -1;     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   bool icc_lut_u16 = false;                // ... sampled through Little CMS's 16-bit transform (RGBA16 images) or its 8-bit one (RGBA8: host_icc_lut.cpp)
@@ -166,7 +166,7 @@ struct jxlamd_decoder {
   int launch_modular(FrameSlot &S);
   int launch_extra_channels(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
-  int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
+  int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info, int frame = -1);
   int decode_once(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
   int decode_batch_once(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
                         const size_t *caps, jxlamd_info *infos);

@@ -136,6 +136,104 @@ JXL_DEV void chroma_upsample_pixel(const DevBuffers &B, const DevFrame &F, int c
   B.plane_b[c][(size_t)Y * pw + (size_t)X] = vs ? mul_add_rn(nb, 0.25f, cur * 0.75f) : cur;
 }
 
+// ---- Blending (libjxl's "Blending" stage, after the colour transform): one pixel (x, y) of the CANVAS.  Background = the blend source's canvas (reference
+// slot bl_src; transparent black when the slot is empty); inside the frame's rectangle the frame's colour (in the image's colour encoding, not clamped) and
+// alpha are combined with it by the frame's BlendingInfo, outside the background shows.  The result is kept (canvas_save: a later frame's background)
+// and / or written out with the writer's clamp, dither and orientation.  Alpha blending as libjxl's PerformAlphaBlending / PerformAlphaWeightedAdd /
+// PerformMulBlending (not premultiplied: out = (fg fa + bg ba (1 - fa)) / (1 - (1 - fa)(1 - ba)); premultiplied: fg + bg (1 - fa)).
+JXL_DEV void blend_canvas_pixel(const DevBuffers &B, const uint8_t *stat, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const int W = F.canvas_w, H = F.canvas_h;
+  const size_t ci = (size_t)y * (size_t)W + (size_t)x;
+  const bool has_alpha = (F.has_ec || F.is_modular) && F.mod_out[3] >= 0;
+  float bg[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int s = F.bl_src;
+  if (s >= 0 && B.ref[s][0]) {
+    for (int c = 0; c < 3; c++) bg[c] = B.ref[s][c][ci];
+    bg[3] = B.ref_a[s] ? B.ref_a[s][ci] : 1.0f;
+  } else if (!has_alpha) bg[3] = 1.0f;
+  float out[4] = {bg[0], bg[1], bg[2], bg[3]};
+  const int fx = x - F.crop_x0, fy = y - F.crop_y0;
+  if (fx >= 0 && fy >= 0 && fx < F.width && fy < F.height) {
+    const size_t po = (size_t)fy * (size_t)F.pw + (size_t)fx;
+    const bool a = compose_final_is_a(F);
+    const float p0 = (a ? B.plane_a[0] : B.plane_b[0])[po], p1 = (a ? B.plane_a[1] : B.plane_b[1])[po], p2 = (a ? B.plane_a[2] : B.plane_b[2])[po];
+    float fg[3];
+    if ((F.is_modular && !F.xyb_modular) || F.not_xyb) plain_to_rgb(F, p0, p1, p2, fg); else xyb_to_rgb(F, p0, p1, p2, fg);
+    float fa = 1.0f;
+    if (has_alpha) fa = (float)mod_plane(B, F, F.mod_out[3])[(size_t)fy * (size_t)F.width + (size_t)fx] * (1.0f / (float)((1u << F.mod_alpha_bits) - 1));
+    // colour channels
+    {
+      float wa = fa;
+      if (F.bl_clamp_c) wa = wa < 0.0f ? 0.0f : wa > 1.0f ? 1.0f : wa;
+      switch (F.bl_mode_c) {
+        case 1: for (int c = 0; c < 3; c++) out[c] = bg[c] + fg[c]; break;
+        case 2:
+          if (F.bl_premultiplied) { for (int c = 0; c < 3; c++) out[c] = fg[c] + bg[c] * (1.0f - wa); }
+          else {
+            const float na = 1.0f - (1.0f - wa) * (1.0f - bg[3]);
+            const float rna = na > 0.0f ? 1.0f / na : 0.0f;
+            for (int c = 0; c < 3; c++) out[c] = (fg[c] * wa + bg[c] * bg[3] * (1.0f - wa)) * rna;
+          }
+          break;
+        case 3: for (int c = 0; c < 3; c++) out[c] = bg[c] + fg[c] * wa; break;
+        case 4: for (int c = 0; c < 3; c++) { float m = fg[c]; if (F.bl_clamp_c) m = m < 0.0f ? 0.0f : m > 1.0f ? 1.0f : m; out[c] = bg[c] * m; } break;
+        default: for (int c = 0; c < 3; c++) out[c] = fg[c]; break;
+      }
+    }
+    // the alpha channel, by its own BlendingInfo
+    if (has_alpha) {
+      float wa = fa;
+      if (F.bl_clamp_a) wa = wa < 0.0f ? 0.0f : wa > 1.0f ? 1.0f : wa;
+      switch (F.bl_mode_a) {
+        case 1: out[3] = bg[3] + fa; break;
+        case 2: out[3] = 1.0f - (1.0f - wa) * (1.0f - bg[3]); break;
+        case 3: out[3] = bg[3]; break;
+        case 4: { float m = fa; if (F.bl_clamp_a) m = m < 0.0f ? 0.0f : m > 1.0f ? 1.0f : m; out[3] = bg[3] * m; } break;
+        default: out[3] = fa; break;
+      }
+    }
+  }
+  if (B.canvas_save[0]) { for (int c = 0; c < 3; c++) B.canvas_save[c][ci] = out[c]; if (B.canvas_save[3]) B.canvas_save[3][ci] = out[3]; }
+  if (F.no_output) return;
+  int ox = x, oy = y;
+  switch (F.orientation) {
+    case 2: ox = W - 1 - x; break;
+    case 3: ox = W - 1 - x; oy = H - 1 - y; break;
+    case 4: oy = H - 1 - y; break;
+    case 5: ox = y; oy = x; break;
+    case 6: ox = H - 1 - y; oy = x; break;
+    case 7: ox = H - 1 - y; oy = W - 1 - x; break;
+    case 8: ox = y; oy = W - 1 - x; break;
+    default: break;
+  }
+  const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
+  if (!has_alpha) out[3] = 1.0f;
+  for (int c = 0; c < 4; c++) { const float t = out[c]; out[c] = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t; if (!(t == t)) out[c] = 0.0f; }
+  if (out_bits == 8) {
+    // The 8-bit writer's dither.  The reference's libjxl (an SSE2 build) loads FOUR consecutive entries of the flat 32 x 32 table at
+    // (row & 31) * 32 + (first column of the vector & 31): a vector that straddles a multiple of 32 takes its upper lanes from the NEXT row of the table.
+    // Vectors start at the left edge of the row segment the writer is handed — column 0 for whole rows, the frame's left edge in the frame's columns, its
+    // right edge behind them (in every row of the canvas) — so the straddle only shows next to layers whose edges are not multiples of four (established on the reference binary's output of
+    // blended animations; tests/golden/an*).  Unoriented images only: with an orientation the writer is handed transposed / mirrored rows.
+    int di32 = (oy & 31) * 32 + (ox & 31);
+    if (F.orientation == 1) {
+      const int rx0 = F.crop_x0 > 0 ? F.crop_x0 : 0, rx1 = F.crop_x0 + F.width;
+      const int seg = x >= rx1 ? rx1 : x >= rx0 ? rx0 : 0;          // the canvas left of the frame, the frame's columns, the canvas right of it: three strips, every row
+      const int vs = seg + ((x - seg) & ~3);
+      di32 = ((y & 31) * 32 + (vs & 31) + (x - vs)) & 1023;
+    }
+    const float d = st_f(stat, ST.dither_off)[F.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : di32];
+    uint32_t px = 0;
+    for (int c = 0; c < 4; c++) px |= (uint32_t)(uint8_t)(int)rintf(out[c] * 255.0f + d) << (8 * c);
+    *(uint32_t *)(B.out + di) = px;
+  } else {
+    uint16_t *o16 = (uint16_t *)B.out + di;
+    for (int c = 0; c < 4; c++) o16[c] = (uint16_t)(int)rintf(out[c] * 65535.0f);
+  }
+}
+
 // copy the composed frame into a reference slot (dense w x h planes)
 JXL_DEV void save_ref_pixel(const DevBuffers &B, const DevFrame &F, float *const dst[3], int x, int y) {
   const bool a = compose_final_is_a(F);

@@ -397,9 +397,11 @@ JXL_DEV float pow_pos(float a, float e) {
 #endif
 }
 JXL_DEV float tf_srgb(float v) {
-  float a = fabsf(v);
-  float r = a <= 0.0031308f ? 12.92f * a : 1.055f * pow_pos(a, 1.0f / 2.4f) - 0.055f;
-  return v < 0 ? -r : r;
+  // negative (out-of-gamut) input: libjxl 0.12's sRGB curve has no sign handling — everything at or below the threshold takes the linear segment, so a
+  // negative value is 12.92 v (established on the reference binary's float output of a blended animation; it only shows where values are not clamped
+  // straight away, i.e. in the background a later frame is blended over)
+  if (v <= 0.0031308f) return 12.92f * v;
+  return 1.055f * pow_pos(v, 1.0f / 2.4f) - 0.055f;
 }
 JXL_DEV float tf_pq(float v, float intensity_target) {
   float a = fabsf(v) * (intensity_target * 1e-4f);
@@ -470,11 +472,11 @@ JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const Dev
   const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
   xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
 }
-JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y) {
-  const DevFrame &F = frame_of(B);
+// XYB -> the image's colour encoding (opsin inverse, target primaries, transfer function), NOT clamped: what libjxl's "XYB" + "FromLinear" stages hand to
+// the blending stage / the writer
+JXL_DEV void xyb_to_rgb(const DevFrame &F, float X, float Y, float Bc, float (&v)[3]) {
   const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
   const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
-  float v[3];
   float hlg_ratio = 1.0f;
   if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
     float lum = 0.0f;
@@ -494,9 +496,13 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
       case -1: { float a = pow_pos(fabsf(lin), F.gamma); lin = lin < 0 ? -a : a; } break;
       default: break;   // 8 = linear
     }
-    v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
-    if (!(lin == lin)) v[c] = 0.0f;
+    v[c] = lin;
   }
+}
+JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y) {
+  float v[3];
+  xyb_to_rgb(frame_of(B), X, Y, Bc, v);
+  for (int c = 0; c < 3; c++) { const float lin = v[c]; v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin; if (!(lin == lin)) v[c] = 0.0f; }
   rgba_store(B, stat, ST, v, out_bits, x, y);
 }
 
@@ -511,15 +517,19 @@ JXL_DEV float mul_add_rn(float a, float b, float c) {
   return p + c;
 #endif
 }
-JXL_DEV void plain_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float c0, float c1, float c2, int out_bits, int x, int y) {
-  const DevFrame &F = frame_of(B);
-  float v[3] = {c0, c1, c2};
+JXL_DEV void plain_to_rgb(const DevFrame &F, float c0, float c1, float c2, float (&v)[3]) {
+  v[0] = c0; v[1] = c1; v[2] = c2;
   if (F.not_xyb == 2) {
     const float yv = c1 + 128.0f / 255;
     v[0] = mul_add_rn(1.402f, c2, yv);
     v[1] = mul_add_rn(-0.299f * 1.402f / 0.587f, c2, mul_add_rn(-0.114f * 1.772f / 0.587f, c0, yv));
     v[2] = mul_add_rn(1.772f, c0, yv);
   }
+}
+JXL_DEV void plain_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float c0, float c1, float c2, int out_bits, int x, int y) {
+  const DevFrame &F = frame_of(B);
+  float v[3];
+  plain_to_rgb(F, c0, c1, c2, v);
   for (int c = 0; c < 3; c++) { const float t = v[c]; v[c] = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t; if (!(t == t)) v[c] = 0.0f; }
   rgba_store(B, stat, ST, v, out_bits, x, y);
 }

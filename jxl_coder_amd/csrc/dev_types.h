@@ -120,6 +120,10 @@ struct DevFrame {
   int32_t upsampling;              // 1, or 2 / 4 / 8: width / height above are the CODED size, the frame shows full_w x full_h pixels (K.? Upsampling, after the patches)
   int32_t full_w, full_h;
   int32_t alpha_up, alpha_w, alpha_h;   // the alpha channel is coded at alpha_w x alpha_h = ceil(full size / alpha_up); alpha_up > 1: enlarged like the colour (DevBuffers::up[3])
+  // Blending (ISO/IEC 18181-1 F.? BlendingInfo, after the colour transform): the frame is laid at (crop_x0, crop_y0) over a canvas of canvas_w x canvas_h
+  // samples — reference slot bl_src (-1: transparent black) — and the result is written out and / or kept as a slot's new canvas.  Modes: 0 replace, 1 add,
+  // 2 blend (alpha), 3 alpha-weighted add, 4 multiply; colour channels and the alpha channel each have theirs (dev_compose.h: blend_canvas_pixel)
+  int32_t blend, bl_src, bl_mode_c, bl_mode_a, bl_clamp_c, bl_clamp_a, bl_premultiplied;
   int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter

@@ -96,6 +96,7 @@ struct Priv {                 // state between phase 1 and phase 2
   DevFrame F;
   std::vector<DevSection> secs;
   int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // reference slots as they are when this frame is decoded
+  bool blend = false, save_canvas = false, has_src = false; int alpha_ec = -1;      // composition over a canvas (plan_parse: the frame walk)
   int64_t tree_bit = -1;        // where the global MA tree starts inside LfGlobal (-1: none): a RAW dequant matrix of HfGlobal may be coded with it
 };
 
@@ -500,7 +501,7 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
 }
 
 // One frame of the walk: its header, where its TOC starts and where the next frame header begins
-struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; };
+struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; bool blend = false; bool canvas_needed = false; int src_frame = -1; };
 
 // TOC of the frame whose header ended at toc_bit: section table (logical order) and the byte where the frame's sections end
 static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t toc_bit, std::vector<DevSection> *secs, size_t *end_byte, std::string *error) {
@@ -539,7 +540,40 @@ static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t to
 
 static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_shown, uint32_t raw_w, uint32_t raw_h);
 
-int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
+int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *durations_ms, int32_t *loops, std::string *error) {
+  uint8_t *cs0; size_t csn; int owned_flag;
+  if (extract_codestream(data, size, &cs0, &csn, &owned_flag)) { *error = hx_last_error(); return -1; }
+  std::vector<uint8_t> owned;
+  if (owned_flag) { owned.assign(cs0, cs0 + csn); free(cs0); }
+  const uint8_t *cs = owned_flag ? owned.data() : cs0;
+  hx_br br; hx_br_init(&br, cs, csn);
+  img_meta m;
+  if (read_image_header(&br, &m)) { *error = hx_last_error(); return -1; }
+  if (m.pub.want_icc && read_icc_stream(&br, nullptr)) { *error = hx_last_error(); return -1; }
+  if (m.have_preview) { *error = "unsupported: preview frame"; return -1; }
+  const uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
+  *loops = m.have_animation ? (int32_t)m.num_loops : -1;
+  durations_ms->clear();
+  for (size_t n = 0;; n++) {
+    hx_align(&br);
+    frame_hdr f;
+    if (read_frame_header(&br, &m, raw_w, raw_h, &f)) { *error = hx_last_error(); return -1; }
+    size_t end_byte = 0;
+    if (read_toc(cs, csn, f, br.pos, nullptr, &end_byte, error)) return -1;
+    if (f.frame_type == 0 || f.frame_type == 3) {
+      int ms = 0;
+      if (m.have_animation && m.tps_num) ms = (int)roundf(1000.0f * (float)f.duration * (float)m.tps_den / (float)m.tps_num);
+      durations_ms->push_back(ms);
+    }
+    if (f.is_last) break;
+    if (n > 4096) { *error = "too many frames"; return -1; }
+    hx_br_init(&br, cs, csn);
+    br.pos = end_byte * 8;
+  }
+  return 0;
+}
+
+int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_frame) {
   plan->error.clear();
   plan->tables.clear();
   plan->refs.clear();
@@ -589,16 +623,30 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     hx_br_init(&br, plan->cs, csn);
     br.pos = r.end_byte * 8;
   }
-  // ---- which earlier frames does the shown frame need?  Several frames (animation; the reference keeps what the LAST coalesced frame shows,
-  // interop/JxlDecoding.cpp:164-166): when the last frame covers the whole canvas and REPLACES it, earlier frames show through only as the
-  // reference frames of its patch dictionary.  Those are decoded (in file order, each into its slot); every other frame is skipped.  A last frame
-  // that is blended with / cropped over the canvas of earlier frames is rejected.
-  const size_t last = recs.size() - 1;
+  // ---- which frame is shown, and which earlier frames does it need?  The reference keeps what the LAST coalesced frame shows (interop/JxlDecoding.cpp:
+  // 164-166); its animated decoder asks for coalesced frame i (JxlAnimatedDecoder.cpp:28-144).  A coalesced frame is a regular frame of non-zero duration
+  // (or the last one) laid over the canvas its BlendingInfo names: the content of a reference slot, i.e. an earlier frame's blended canvas.  Needed are
+  // therefore, recursively: the occupants of the slots a needed frame's patches may draw on, and the occupant of the slot a needed frame is blended over.
+  size_t last = recs.size() - 1;
+  if (target_frame >= 0) {
+    int seen = 0; bool found = false;
+    for (size_t i = 0; i < recs.size(); i++) {
+      const frame_hdr &f = recs[i].f;
+      if ((f.frame_type == 0 || f.frame_type == 3) && (f.is_last || f.duration > 0)) { if (seen == target_frame) { last = i; found = true; break; } seen++; }
+    }
+    if (!found) { plan->error = "frame index beyond the frames of the file"; return -1; }
+  }
   {
     const frame_hdr &f = recs[last].f;
-    if (f.frame_type != 0) { plan->error = "unsupported: non-regular last frame"; return -1; }
-    if (last > 0 && f.blend_not_replace) { plan->error = "unsupported: multi-frame image whose last frame is blended with earlier frames"; return -1; }
+    if (f.frame_type != 0 && f.frame_type != 3) { plan->error = "unsupported: non-regular last frame"; return -1; }
   }
+  const int alpha_ec = [&] { for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) return i; return -1; }();
+  // does a regular frame look at its blend source?  (colour and the alpha channel count: the other extra channels are not part of the output)
+  const auto full_frame = [&](const frame_hdr &f) { return !f.have_crop || (f.x0 == 0 && f.y0 == 0 && f.width == (int)raw_w && f.height == (int)raw_h); };
+  const auto uses_canvas = [&](const frame_hdr &f) {
+    if (f.frame_type != 0 && f.frame_type != 3) return false;
+    return !full_frame(f) || f.bl_mode[0] != 0 || (alpha_ec >= 0 && f.bl_mode[1 + alpha_ec] != 0);
+  };
   recs[last].needed = true;
   std::vector<int> occupant_at((recs.size()) * 4, -1);      // [frame][slot]: which frame sits in the slot when this frame is decoded
   {
@@ -610,16 +658,37 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
       if (!f.is_last && f.frame_type != 1 && (f.duration == 0 || f.save_as_ref != 0)) occ[f.save_as_ref & 3] = (int)i;
     }
   }
-  for (size_t i = recs.size(); i-- > 0;) {
+  for (size_t i = last + 1; i-- > 0;) {
     if (!recs[i].needed) continue;
     const frame_hdr &f = recs[i].f;
     if (f.flags & 2) for (int k = 0; k < 4; k++) if (occupant_at[i * 4 + (size_t)k] >= 0) recs[(size_t)occupant_at[i * 4 + (size_t)k]].needed = true;    // patches may name any slot
-    if (i == last && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h) && occupant_at[i * 4 + (size_t)(f.blend_source & 3)] >= 0) {
-      plan->error = "unsupported: cropped frame over a saved reference frame"; return -1;
+    if (uses_canvas(f)) {
+      const int src = f.bl_source[0] & 3;
+      if (alpha_ec >= 0 && (f.bl_source[1 + alpha_ec] & 3) != src && (f.bl_mode[1 + alpha_ec] != 0 || !full_frame(f))) { plan->error = "unsupported: colour and alpha blended over different reference slots"; return -1; }
+      const int occ = occupant_at[i * 4 + (size_t)src];
+      recs[i].src_frame = occ;
+      // over an empty slot a replacing frame shows the cleared canvas: the writer's cropped-frame path; everything else is laid over a canvas
+      if (occ >= 0 || f.bl_mode[0] != 0 || (alpha_ec >= 0 && f.bl_mode[1 + alpha_ec] != 0)) recs[i].blend = true;
+      if (occ >= 0) {
+        FrameRec &o = recs[(size_t)occ];
+        if (o.f.frame_type != 0 && o.f.frame_type != 3) { plan->error = "unsupported: blending over a reference-only frame"; return -1; }
+        if (o.f.save_before_ct && (m.pub.xyb_encoded || !full_frame(o.f))) { plan->error = "unsupported: blending over a frame saved before the colour transform"; return -1; }
+        o.needed = true; o.canvas_needed = true; o.blend = true;
+      }
     }
   }
-  // ---- reference frames first (each its own FramePlan over the same codestream bytes), then the shown frame
+  // ---- the needed earlier frames first, in file order (each its own FramePlan over the same codestream bytes), then the shown frame
   int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0};
+  const auto blend_checks = [&](const FrameRec &r) -> bool {
+    const frame_hdr &f = r.f;
+    if (!r.blend) return true;
+    if (f.upsampling != 1) { plan->error = "unsupported: blending of an upsampled frame"; return false; }
+    for (int ch : {0, alpha_ec >= 0 ? 1 + alpha_ec : 0}) {
+      if ((f.bl_mode[ch] == 2 || f.bl_mode[ch] == 3) && m.num_extra > 0 && f.bl_alpha[ch] != alpha_ec) { plan->error = "unsupported: blending weighted by an extra channel that is not the alpha channel"; return false; }
+    }
+    if (m.orientation != 1 && false) return false;
+    return true;
+  };
   for (size_t i = 0; i < last; i++) {
     if (!recs[i].needed) continue;
     const frame_hdr &f = recs[i].f;
@@ -629,14 +698,23 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan) {
     sub->priv = spv;
     spv->m = m; spv->f = f;
     memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h));
-    if (f.frame_type != 0 && f.frame_type != 2) { plan->error = "unsupported: reference to an LF / skip-progressive frame"; return -1; }
-    if (f.frame_type == 0 && (f.blend_not_replace || (f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)))) { plan->error = "unsupported: blended / cropped regular frame used as a reference"; return -1; }
-    if (!f.save_before_ct && m.pub.xyb_encoded) { plan->error = "unsupported: reference frame saved after the colour transform"; return -1; }
+    if (f.frame_type != 0 && f.frame_type != 2 && f.frame_type != 3) { plan->error = "unsupported: reference to an LF frame"; return -1; }
+    if (!recs[i].canvas_needed) {
+      // a frame kept for a patch dictionary: stored as it is, before the colour transform
+      if (f.frame_type != 2 && (recs[i].blend || !full_frame(f))) { plan->error = "unsupported: blended / cropped regular frame used as a patch source"; return -1; }
+      if (!f.save_before_ct && m.pub.xyb_encoded) { plan->error = "unsupported: reference frame saved after the colour transform"; return -1; }
+    }
+    if (!blend_checks(recs[i])) return -1;
+    spv->blend = recs[i].blend; spv->save_canvas = recs[i].canvas_needed; spv->has_src = recs[i].src_frame >= 0; spv->alpha_ec = alpha_ec;
     if (build_frame(sub.get(), spv.get(), recs[i], /*is_shown=*/false, raw_w, raw_h)) { plan->error = sub->error; return -1; }
     sub->save_slot = f.save_as_ref & 3;
+    sub->save_canvas = recs[i].canvas_needed;
     plan->refs.push_back(sub);
-    slot_w[f.save_as_ref & 3] = f.width; slot_h[f.save_as_ref & 3] = f.height;
+    if (recs[i].canvas_needed) { slot_w[f.save_as_ref & 3] = (int)raw_w; slot_h[f.save_as_ref & 3] = (int)raw_h; }
+    else { slot_w[f.save_as_ref & 3] = f.width; slot_h[f.save_as_ref & 3] = f.height; }
   }
+  if (!blend_checks(recs[last])) return -1;
+  pv->blend = recs[last].blend; pv->save_canvas = false; pv->has_src = recs[last].src_frame >= 0; pv->alpha_ec = alpha_ec;
   pv->f = recs[last].f;
   memcpy(pv->ref_w, slot_w, sizeof(slot_w)); memcpy(pv->ref_h, slot_h, sizeof(slot_h));
   return build_frame(plan, pv, recs[last], /*is_shown=*/true, raw_w, raw_h);
@@ -676,7 +754,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     if (!m.pub.xyb_encoded) { plan->error = "unsupported: upsampling of a frame that is not XYB"; return -1; }
     if (!is_shown) { plan->error = "unsupported: upsampled reference frame"; return -1; }
   }
-  if (is_shown && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
+  if (is_shown && !pv->blend && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
     // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas (plan_parse has checked that no
     // earlier frame was saved into that slot)
     if (f.blend_not_replace) { plan->error = "unsupported: cropped frame blended with a reference frame"; return -1; }
@@ -831,11 +909,21 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   }
   F.orientation = m.orientation; F.out_w = (int)m.pub.xsize; F.out_h = (int)m.pub.ysize;
   F.canvas_w = (int)raw_w; F.canvas_h = (int)raw_h; F.crop_x0 = f.have_crop ? f.x0 : 0; F.crop_y0 = f.have_crop ? f.y0 : 0;
-  if (!is_shown) { F.canvas_w = f.width; F.canvas_h = f.height; F.crop_x0 = F.crop_y0 = 0; F.orientation = 1; F.out_w = f.width; F.out_h = f.height; }
+  if (!is_shown && !pv->blend) { F.canvas_w = f.width; F.canvas_h = f.height; F.crop_x0 = F.crop_y0 = 0; F.orientation = 1; F.out_w = f.width; F.out_h = f.height; }
   F.no_output = is_shown ? 0 : 1;
+  if (pv->blend) {
+    // the frame is laid over a canvas of the image's size (dev_compose.h: blend_canvas_pixel): BlendingInfo of the colour channels and of the alpha channel
+    const int a = pv->alpha_ec;
+    F.blend = 1; F.bl_src = pv->has_src ? (f.bl_source[0] & 3) : -1;
+    F.bl_mode_c = f.bl_mode[0]; F.bl_clamp_c = f.bl_clamp[0];
+    F.bl_mode_a = a >= 0 ? f.bl_mode[1 + a] : 0; F.bl_clamp_a = a >= 0 ? f.bl_clamp[1 + a] : 0;
+    if (a < 0) { if (F.bl_mode_c == 2) F.bl_mode_c = 0; else if (F.bl_mode_c == 3) F.bl_mode_c = 1; }      // without an alpha channel "blend" replaces and the weighted sum is a plain one
+    F.bl_premultiplied = (a >= 0 && m.ec[a].alpha_assoc) ? 1 : 0;
+    plan->blend = true;
+  }
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
-  F.compose = (!is_shown || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
+  F.compose = (!is_shown || pv->blend || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;

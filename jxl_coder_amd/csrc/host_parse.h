@@ -38,6 +38,8 @@ struct FramePlan {
   // plan of its own over the same codestream bytes, decoded first and copied into reference slot save_slot.
   std::vector<std::shared_ptr<FramePlan>> refs;
   int save_slot = -1;                                    // a plan inside `refs`: where its image goes
+  bool save_canvas = false;                              // ... as the blended canvas after the colour transform (4 planes of the IMAGE's size: a blend source), not as the frame itself
+  bool blend = false;                                    // the frame is laid over a canvas (dev_compose.h: blend_canvas_pixel) instead of being written straight out
   bool compose = false;                                  // the frame keeps its image in the f32 planes after the filters (reference frame / patches / XYB Modular)
   size_t patch_max_px = 0;                               // largest patch rectangle (launch geometry of the blend kernel)
   bool hf_parsed = false;
@@ -59,7 +61,12 @@ struct FramePlan {
 
 // Phase 1: everything up to and including LfGlobal; for multi-section frames also HfGlobal (phase 2 implicit).
 // Returns 0 on success; on failure plan->error says why (unsupported feature or corrupt stream).
-int plan_parse(const uint8_t *data, size_t size, FramePlan *plan);
+// target_frame: which coalesced frame of an animation to decode (what libjxl emits with coalescing on: every frame of non-zero duration, and the last
+// one), -1 = the last — the reference's decode() keeps that one (interop/JxlDecoding.cpp:164-166), its JxlAnimatedDecoder::getFrame(i) frame i.
+int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_frame = -1);
+// The frame list of an animation as the reference's JxlAnimatedDecoder constructor collects it (interop/JxlAnimatedDecoder.hpp:68-185): one entry per
+// regular frame, durations in milliseconds (round(1000 * ticks * tps_denominator / tps_numerator)), the loop count (-1: not an animation).  Returns 0.
+int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *durations_ms, int32_t *loops, std::string *error);
 // Phase 2 for single-section frames: HfGlobal starts at `lf_end_bit` (reported by the LF kernel).
 int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit);
 // Header-only parse (DecodeBasicInfo).

@@ -44,6 +44,16 @@ __global__ void __launch_bounds__(256) k_chroma_upsample(DevBuffers B) {
   if (x >= F.width || y >= F.height || frame_failed(B)) return;
   chroma_upsample_pixel(B, F, (int)blockIdx.z, x, y);
 }
+// frames laid over a canvas (animations): one work-item per canvas pixel
+__global__ void __launch_bounds__(256) k_blend_canvas(DevBuffers B, const uint8_t *stat) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.canvas_w || y >= F.canvas_h || frame_failed(B)) return;
+  blend_canvas_pixel(B, stat, B.out_bits, x, y);
+}
+void launch_blend_canvas(const DevBuffers &B, const uint8_t *stat, int canvas_w, int canvas_h, hipStream_t s) {
+  hipLaunchKernelGGL(k_blend_canvas, dim3((canvas_w + 63) / 64, (canvas_h + 3) / 4), dim3(256), 0, s, B, stat);
+}
 void launch_chroma_upsample(const DevBuffers &B, int w, int h, hipStream_t s) { hipLaunchKernelGGL(k_chroma_upsample, dim3((w + 63) / 64, (h + 3) / 4, 3), dim3(256), 0, s, B); }
 
 __global__ void __launch_bounds__(256) k_upsample(DevBuffers B, const uint8_t *stat) {

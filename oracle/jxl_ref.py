@@ -119,3 +119,47 @@ def fnv1a64(b: bytes) -> int:
     for x in b:
         h = ((h ^ x) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
     return h
+
+
+class RefAnimFrame(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("x0", C.c_int32), ("y0", C.c_int32),
+                ("blend_mode", C.c_int32), ("source", C.c_int32), ("save_as_reference", C.c_int32), ("duration", C.c_uint32)]
+
+
+def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1), loops=0):
+    """frames: list of dicts {rgba: [h,w,4] u8, x0, y0, blend (0 replace, 1 add, 2 blend, 3 muladd, 4 mul), source, save, duration (ticks)} -> an
+    animated JPEG XL over a W x H RGBA canvas (libjxl's encoder API, JxlEncoderSetFrameHeader with layer_info)."""
+    arr = (RefAnimFrame * len(frames))()
+    keep = []
+    for i, f in enumerate(frames):
+        px = np.ascontiguousarray(f["rgba"], dtype=np.uint8); keep.append(px)
+        arr[i].rgba = px.ctypes.data; arr[i].h, arr[i].w = px.shape[:2]
+        arr[i].x0, arr[i].y0 = f.get("x0", 0), f.get("y0", 0)
+        arr[i].blend_mode, arr[i].source, arr[i].save_as_reference, arr[i].duration = f.get("blend", 0), f.get("source", 0), f.get("save", 0), f.get("duration", 1)
+    out = C.c_void_p(); n = C.c_size_t()
+    rc = lib().ref_encode_anim(arr, len(frames), W, H, int(lossless), C.c_float(distance), effort, tps[0], tps[1], loops, C.byref(out), C.byref(n))
+    if rc != 0:
+        raise ValueError(f"ref_encode_anim failed rc={rc}")
+    data = C.string_at(out.value, n.value)
+    lib().ref_free(out)
+    return data
+
+
+def anim_info(data: bytes):
+    """-> (durations_ms list, loops): the frame list of the reference's JxlAnimatedDecoder constructor (coalescing off)"""
+    d = (C.c_int32 * 4096)(); loops = C.c_int32()
+    n = lib().ref_anim_info(data, len(data), d, 4096, C.byref(loops))
+    if n < 0:
+        raise ValueError(f"ref_anim_info failed rc={n}")
+    return [int(d[i]) for i in range(n)], int(loops.value)
+
+
+def decode_frame(data: bytes, index: int):
+    """coalesced frame `index` as RGBA8 [h,w,4]: the reference's JxlAnimatedDecoder::getFrame sequence"""
+    out = C.c_void_p(); n = C.c_size_t(); w = C.c_uint32(); h = C.c_uint32()
+    rc = lib().ref_decode_frame(data, len(data), int(index), C.byref(out), C.byref(n), C.byref(w), C.byref(h))
+    if rc != 0:
+        raise ValueError(f"ref_decode_frame failed rc={rc}")
+    arr = np.frombuffer((C.c_uint8 * n.value).from_address(out.value), dtype=np.uint8).reshape(h.value, w.value, 4).copy()
+    lib().ref_free(out)
+    return arr

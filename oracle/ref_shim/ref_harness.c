@@ -297,3 +297,159 @@ done:
   p_JxlThreadParallelRunnerDestroy(runner);
   return rc;
 }
+
+/* ---- animations: an encoder entry for building fixtures with cropped / blended layers, and the reference's frame-indexed decode.
+ * Encode: libjxl's public API as the reference's animated encoder drives it (interop/JxlAnimatedEncoder: JxlEncoderSetFrameHeader with duration),
+ *         plus layer_info (crop, blend mode, source, save_as_reference) so that the fixtures cover what files from other encoders (cjxl from GIF / APNG) hold.
+ * Decode: jxlcoder/src/main/cpp/interop/JxlAnimatedDecoder.cpp:28-144 (getFrame: rewind, JxlDecoderSkipFrames(position), coalescing on, first full image)
+ *         and JxlAnimatedDecoder.hpp:68-185 (the constructor's frame walk with coalescing off: frame count and durations). */
+typedef struct {
+  const uint8_t *rgba; uint32_t w, h; int32_t x0, y0;
+  int32_t blend_mode, source, save_as_reference; uint32_t duration;
+} RefAnimFrame;
+
+int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_t H, int lossless, float distance, int effort,
+                    uint32_t tps_num, uint32_t tps_den, uint32_t loops, uint8_t **out, size_t *out_size) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlEncoderCreate); SYM(h_jxl, JxlEncoderDestroy); SYM(h_jxl, JxlEncoderSetParallelRunner); SYM(h_jxl, JxlEncoderInitBasicInfo);
+  SYM(h_jxl, JxlEncoderSetBasicInfo); SYM(h_jxl, JxlEncoderInitExtraChannelInfo); SYM(h_jxl, JxlEncoderSetExtraChannelInfo);
+  SYM(h_jxl, JxlColorEncodingSetToSRGB); SYM(h_jxl, JxlEncoderSetColorEncoding); SYM(h_jxl, JxlEncoderFrameSettingsCreate);
+  SYM(h_jxl, JxlEncoderSetFrameDistance); SYM(h_jxl, JxlEncoderFrameSettingsSetOption); SYM(h_jxl, JxlEncoderSetFrameLossless);
+  SYM(h_jxl, JxlEncoderAddImageFrame); SYM(h_jxl, JxlEncoderCloseInput); SYM(h_jxl, JxlEncoderProcessOutput);
+  SYM(h_jxl, JxlEncoderInitFrameHeader); SYM(h_jxl, JxlEncoderSetFrameHeader);
+  SYM(h_thr, JxlThreadParallelRunner); SYM(h_thr, JxlThreadParallelRunnerCreate); SYM(h_thr, JxlThreadParallelRunnerDestroy);
+  SYM(h_thr, JxlThreadParallelRunnerDefaultNumWorkerThreads);
+  int rc = -2;
+  *out = NULL; *out_size = 0;
+  JxlEncoder *enc = p_JxlEncoderCreate(NULL);
+  void *runner = p_JxlThreadParallelRunnerCreate(NULL, p_JxlThreadParallelRunnerDefaultNumWorkerThreads());
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetParallelRunner(enc, p_JxlThreadParallelRunner, runner)) goto done;
+  JxlBasicInfo bi;
+  p_JxlEncoderInitBasicInfo(&bi);
+  bi.xsize = W; bi.ysize = H; bi.bits_per_sample = 8; bi.num_color_channels = 3; bi.num_extra_channels = 1; bi.alpha_bits = 8;
+  bi.uses_original_profile = lossless ? JXL_TRUE : JXL_FALSE;
+  bi.have_animation = JXL_TRUE; bi.animation.tps_numerator = tps_num; bi.animation.tps_denominator = tps_den; bi.animation.num_loops = loops;
+  bi.animation.have_timecodes = JXL_FALSE;
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
+  JxlExtraChannelInfo ci;
+  p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
+  ci.bits_per_sample = 8;
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
+  JxlColorEncoding ce;
+  p_JxlColorEncodingSetToSRGB(&ce, JXL_FALSE);
+  if (JXL_ENC_SUCCESS != p_JxlEncoderSetColorEncoding(enc, &ce)) { rc = -5; goto done; }
+  JxlPixelFormat pf = {4, JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+  for (int i = 0; i < nframes; i++) {
+    const RefAnimFrame *fr = &frames[i];
+    JxlEncoderFrameSettings *fs = p_JxlEncoderFrameSettingsCreate(enc, NULL);
+    if (!lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameDistance(fs, distance)) { rc = -6; goto done; }
+    if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, JXL_ENC_FRAME_SETTING_EFFORT, effort)) { rc = -7; goto done; }
+    if (lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameLossless(fs, JXL_TRUE)) { rc = -8; goto done; }
+    JxlFrameHeader fh;
+    p_JxlEncoderInitFrameHeader(&fh);
+    fh.duration = fr->duration;
+    fh.layer_info.have_crop = (fr->x0 || fr->y0 || fr->w != W || fr->h != H) ? JXL_TRUE : JXL_FALSE;
+    fh.layer_info.crop_x0 = fr->x0; fh.layer_info.crop_y0 = fr->y0; fh.layer_info.xsize = fr->w; fh.layer_info.ysize = fr->h;
+    fh.layer_info.blend_info.blendmode = (JxlBlendMode)fr->blend_mode; fh.layer_info.blend_info.source = (uint32_t)fr->source;
+    fh.layer_info.blend_info.alpha = 0; fh.layer_info.blend_info.clamp = JXL_FALSE;
+    fh.layer_info.save_as_reference = (uint32_t)fr->save_as_reference;
+    if (JXL_ENC_SUCCESS != p_JxlEncoderSetFrameHeader(fs, &fh)) { rc = -9; goto done; }
+    if (JXL_ENC_SUCCESS != p_JxlEncoderAddImageFrame(fs, &pf, fr->rgba, (size_t)fr->w * fr->h * 4)) { rc = -10; goto done; }
+  }
+  p_JxlEncoderCloseInput(enc);
+  {
+    size_t cap = 1 << 16, used = 0;
+    uint8_t *buf = (uint8_t *)malloc(cap);
+    JxlEncoderStatus st;
+    do {
+      uint8_t *next = buf + used; size_t avail = cap - used;
+      st = p_JxlEncoderProcessOutput(enc, &next, &avail);
+      used = (size_t)(next - buf);
+      if (st == JXL_ENC_NEED_MORE_OUTPUT) { cap *= 2; buf = (uint8_t *)realloc(buf, cap); }
+    } while (st == JXL_ENC_NEED_MORE_OUTPUT);
+    if (st != JXL_ENC_SUCCESS) { free(buf); rc = -11; goto done; }
+    *out = buf; *out_size = used; rc = 0;
+  }
+done:
+  p_JxlEncoderDestroy(enc);
+  p_JxlThreadParallelRunnerDestroy(runner);
+  return rc;
+}
+
+/* frame count and durations (ms) as the reference's JxlAnimatedDecoder constructor collects them (coalescing OFF); returns the count or < 0 */
+int ref_anim_info(const uint8_t *jxl, size_t size, int32_t *durations_ms, int cap, int32_t *loops) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlDecoderCreate); SYM(h_jxl, JxlDecoderDestroy); SYM(h_jxl, JxlDecoderSubscribeEvents); SYM(h_jxl, JxlDecoderSetInput);
+  SYM(h_jxl, JxlDecoderCloseInput); SYM(h_jxl, JxlDecoderProcessInput); SYM(h_jxl, JxlDecoderGetBasicInfo); SYM(h_jxl, JxlDecoderSetCoalescing);
+  SYM(h_jxl, JxlDecoderGetFrameHeader); SYM(h_jxl, JxlDecoderSkipCurrentFrame);
+  JxlDecoder *dec = p_JxlDecoderCreate(NULL);
+  int n = -2;
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSubscribeEvents(dec, JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE | JXL_DEC_FRAME)) goto done;
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSetCoalescing(dec, JXL_FALSE)) goto done;
+  p_JxlDecoderSetInput(dec, jxl, size);
+  p_JxlDecoderCloseInput(dec);
+  JxlBasicInfo info; memset(&info, 0, sizeof(info));
+  n = 0;
+  for (;;) {
+    JxlDecoderStatus st = p_JxlDecoderProcessInput(dec);
+    if (st == JXL_DEC_ERROR || st == JXL_DEC_NEED_MORE_INPUT) { n = -3; break; }
+    else if (st == JXL_DEC_BASIC_INFO) { if (JXL_DEC_SUCCESS != p_JxlDecoderGetBasicInfo(dec, &info)) { n = -4; break; } *loops = info.have_animation ? (int32_t)info.animation.num_loops : -1; }
+    else if (st == JXL_DEC_FRAME) {
+      JxlFrameHeader fh;
+      if (JXL_DEC_SUCCESS != p_JxlDecoderGetFrameHeader(dec, &fh)) { n = -5; break; }
+      int ms = 0;
+      if (info.animation.tps_numerator) ms = (int)__builtin_roundf(1000.0f * (float)fh.duration * (float)info.animation.tps_denominator / (float)info.animation.tps_numerator);
+      if (n < cap) durations_ms[n] = ms;
+      n++;
+    }
+    else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) { if (JXL_DEC_SUCCESS != p_JxlDecoderSkipCurrentFrame(dec)) { n = -6; break; } }
+    else if (st == JXL_DEC_FULL_IMAGE) continue;       /* (the reference stops at the first one and rewinds: a quirk that truncates its list to one entry when a frame is not skipped) */
+    else if (st == JXL_DEC_SUCCESS) break;
+  }
+done:
+  p_JxlDecoderDestroy(dec);
+  return n;
+}
+
+/* coalesced frame `index` as RGBA8: getFrame's call sequence (JxlAnimatedDecoder.cpp:28-144) */
+int ref_decode_frame(const uint8_t *jxl, size_t size, int index, uint8_t **out, size_t *out_size, uint32_t *w, uint32_t *h) {
+  if (load_libs()) return -1;
+  SYM(h_jxl, JxlDecoderCreate); SYM(h_jxl, JxlDecoderDestroy); SYM(h_jxl, JxlDecoderSubscribeEvents); SYM(h_jxl, JxlDecoderSetInput);
+  SYM(h_jxl, JxlDecoderCloseInput); SYM(h_jxl, JxlDecoderProcessInput); SYM(h_jxl, JxlDecoderGetBasicInfo); SYM(h_jxl, JxlDecoderSetCoalescing);
+  SYM(h_jxl, JxlDecoderSkipFrames); SYM(h_jxl, JxlDecoderImageOutBufferSize); SYM(h_jxl, JxlDecoderSetImageOutBuffer);
+  SYM(h_jxl, JxlDecoderSetParallelRunner);
+  SYM(h_thr, JxlResizableParallelRunner); SYM(h_thr, JxlResizableParallelRunnerCreate); SYM(h_thr, JxlResizableParallelRunnerDestroy);
+  int rc = -2;
+  *out = NULL; *out_size = 0;
+  void *runner = p_JxlResizableParallelRunnerCreate(NULL);
+  JxlDecoder *dec = p_JxlDecoderCreate(NULL);
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSubscribeEvents(dec, JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE | JXL_DEC_FRAME)) goto done;
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSetParallelRunner(dec, p_JxlResizableParallelRunner, runner)) goto done;
+  p_JxlDecoderSetInput(dec, jxl, size);
+  p_JxlDecoderCloseInput(dec);
+  p_JxlDecoderSkipFrames(dec, (size_t)index);
+  if (JXL_DEC_SUCCESS != p_JxlDecoderSetCoalescing(dec, JXL_TRUE)) goto done;
+  JxlPixelFormat format = {4, JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+  JxlBasicInfo info; memset(&info, 0, sizeof(info));
+  int got = 0;
+  for (;;) {
+    JxlDecoderStatus st = p_JxlDecoderProcessInput(dec);
+    if (st == JXL_DEC_ERROR || st == JXL_DEC_NEED_MORE_INPUT) { rc = -3; goto done; }
+    else if (st == JXL_DEC_BASIC_INFO) { if (JXL_DEC_SUCCESS != p_JxlDecoderGetBasicInfo(dec, &info)) { rc = -4; goto done; } *w = info.xsize; *h = info.ysize; }
+    else if (st == JXL_DEC_FRAME) continue;
+    else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) {
+      size_t need = 0;
+      if (JXL_DEC_SUCCESS != p_JxlDecoderImageOutBufferSize(dec, &format, &need)) { rc = -5; goto done; }
+      free(*out);
+      *out = (uint8_t *)malloc(need); *out_size = need;
+      if (JXL_DEC_SUCCESS != p_JxlDecoderSetImageOutBuffer(dec, &format, *out, need)) { rc = -6; goto done; }
+      got = 1;
+    }
+    else if (st == JXL_DEC_FULL_IMAGE || st == JXL_DEC_SUCCESS) { rc = got ? 0 : -7; goto done; }
+  }
+done:
+  p_JxlDecoderDestroy(dec);
+  p_JxlResizableParallelRunnerDestroy(runner);
+  if (rc) { free(*out); *out = NULL; *out_size = 0; }
+  return rc;
+}

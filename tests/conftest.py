@@ -52,13 +52,15 @@ def emul():
                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.emul_last_error.restype = C.c_char_p
 
-    def decode(data, allow16=True):
+    def decode(data, allow16=True, frame=-1):
         cap = 1 << 20
         import jxl_coder_amd as J
         w, h = J.JxlCoder.getSize(data)
         buf = np.zeros(w * h * 8, np.uint8)
         cw, ch, cb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.emul_set_target_frame(int(frame))                  # coalesced frame of an animation (-1: the last, what decode() keeps)
         rc = lib.emul_decode(data, len(data), int(allow16), buf.ctypes.data, buf.nbytes, C.byref(cw), C.byref(ch), C.byref(cb))
+        lib.emul_set_target_frame(-1)
         if rc:
             raise ValueError(lib.emul_last_error().decode())
         n = cw.value * ch.value * 4 * (cb.value // 8)
@@ -98,6 +100,10 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW
 # dequant matrices, 4:4:4 / 4:2:0 / 4:2:2 chroma, progressive source, grey, several groups.  Same tolerance as every VarDCT file (measured 1e-5 - 5e-5).
 JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j420_prog_333x277", "jgrey_160x120", "j420s_400x300"]
+# Animations with layers (cropped frames blended over reference slots: kBlend, kAdd, kMulAdd, kMul on colour and alpha, zero-duration layers, two slots):
+# every coalesced frame against what the reference's JxlAnimatedDecoder::getFrame returns.  Lossless bit-exact, lossy within the VarDCT tolerance.
+ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless"]
+ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5"]
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
@@ -116,6 +122,12 @@ VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x1
 VARDCT_MAX_ABS = 1
 VARDCT_MEAN_ABS = 0.05
 VARDCT_MEAN_ABS_CASE = {"v256_e3_gab0_epf2": 0.06, "v256_e3_gab0_epf3": 0.09}       # measured 0.051 / 0.076
+
+
+def load_anim_case(name):
+    """-> (jxl bytes, frames [n, h, w, 4] u8): the coalesced frames of an animation fixture"""
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    return data, np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["frames"]
 
 
 def vardct_mean_tol(name):

@@ -38,13 +38,24 @@ static void filter_stages(const DevBuffers &B, const DevFrame &F) {
   }
 }
 
-struct RefStore { std::vector<float> p[4][3]; };
+struct RefStore { std::vector<float> p[4][4]; int w[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}; };      // [slot][R, G, B, alpha (blended canvases only)]
 
 // composition tail (jxlamd_decoder::launch_compose_tail): patches, copy into the reference slot, stand-alone writer
 static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F, int out_bits, RefStore &refs, const uint8_t *stat) {
   if (F.subsampled) for (int c = 0; c < 3; c++) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) chroma_upsample_pixel(B, F, c, x, y);      // k_chroma_upsample
   const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
   for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
+  if (F.blend) {                                           // jxlamd_decoder::launch_compose_tail: the frame over its canvas (k_blend_canvas)
+    DevBuffers Bb = B;
+    std::vector<float> keep[4];
+    const bool has_alpha = (F.has_ec || F.is_modular) && F.mod_out[3] >= 0;
+    if (plan.save_slot >= 0 && plan.save_canvas) for (int c = 0; c < 4; c++) { if (c == 3 && !has_alpha) continue; keep[c].assign((size_t)F.canvas_w * F.canvas_h, 0.f); Bb.canvas_save[c] = keep[c].data(); }
+    for (int y = 0; y < F.canvas_h; y++) for (int x = 0; x < F.canvas_w; x++) blend_canvas_pixel(Bb, stat, out_bits, x, y);
+    if (getenv("JXLEMUL_TRACE_PX") && plan.save_slot >= 0 && plan.save_canvas) { int px, py; sscanf(getenv("JXLEMUL_TRACE_PX"), "%d,%d", &px, &py); size_t i = (size_t)py * F.canvas_w + px; fprintf(stderr, "canvas px (%d,%d): %g %g %g a %g | planes %g %g %g\n", px, py, keep[0][i], keep[1][i], keep[2][i], keep[3].empty() ? -1.f : keep[3][i], (compose_final_is_a(F) ? B.plane_a[0] : B.plane_b[0])[(size_t)(py - F.crop_y0) * F.pw + (px - F.crop_x0)], (compose_final_is_a(F) ? B.plane_a[1] : B.plane_b[1])[(size_t)(py - F.crop_y0) * F.pw + (px - F.crop_x0)], (compose_final_is_a(F) ? B.plane_a[2] : B.plane_b[2])[(size_t)(py - F.crop_y0) * F.pw + (px - F.crop_x0)]); }
+    if (getenv("JXLEMUL_TRACE_CANVAS") && plan.save_slot >= 0 && plan.save_canvas) for (int c = 0; c < 3; c++) { float mn = 1e9f, mx = -1e9f; for (float v : keep[c]) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; } fprintf(stderr, "canvas slot %d ch %d min %g max %g (blend mode %d src %d)\n", plan.save_slot, c, mn, mx, F.bl_mode_c, F.bl_src); }
+    if (plan.save_slot >= 0 && plan.save_canvas) { for (int c = 0; c < 4; c++) refs.p[plan.save_slot][c].swap(keep[c]); refs.w[plan.save_slot] = F.canvas_w; refs.h[plan.save_slot] = F.canvas_h; }
+    return;
+  }
   if (plan.save_slot >= 0) {
     float *dst[3];
     for (int c = 0; c < 3; c++) { refs.p[plan.save_slot][c].assign((size_t)F.width * F.height, 0.f); dst[c] = refs.p[plan.save_slot][c].data(); }
@@ -68,9 +79,11 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
 
 static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs);
 
+static int g_target_frame = -1;
+extern "C" void emul_set_target_frame(int i) { g_target_frame = i; }
 extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t *out, size_t out_cap, uint32_t *w, uint32_t *h, uint32_t *bits) {
   FramePlan plan;
-  if (plan_parse(jxl, size, &plan)) { g_err = plan.error; return -1; }
+  if (plan_parse(jxl, size, &plan, g_target_frame)) { g_err = plan.error; return -1; }
   const int out_bits = (plan.info.bits_per_sample > 8 && allow16) ? 16 : 8;
   *w = plan.info.xsize; *h = plan.info.ysize; *bits = (uint32_t)out_bits;
   const size_t out_bytes = (size_t)plan.info.xsize * plan.info.ysize * 4 * (out_bits / 8);
@@ -110,7 +123,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   std::vector<float> upv[4];
   if (F0.upsampling > 1) for (int c = 0; c < 3; c++) { upv[c].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[c] = upv[c].data(); }
   if (F0.alpha_up > 1) { upv[3].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[3] = upv[3].data(); }
-  for (int k = 0; k < 4; k++) for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data();
+  for (int k = 0; k < 4; k++) { for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data(); B.ref_a[k] = refs.p[k][3].empty() ? nullptr : refs.p[k][3].data(); }
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();

@@ -135,6 +135,58 @@ def add_jpeg_cases(meta, only):
         print(name, len(buf.getvalue()), len(data), out.shape)
 
 
+# Animations with layers: cropped frames blended over reference slots (what cjxl writes from GIF / APNG sources; the reference's JxlAnimatedEncoder
+# itself writes full replacing frames).  Built through libjxl's encoder API (oracle/ref_shim: ref_encode_anim = JxlEncoderSetFrameHeader with layer_info);
+# expected = every coalesced frame as the reference's JxlAnimatedDecoder::getFrame returns it (interop/JxlAnimatedDecoder.cpp:28-144) + its frame list.
+def anim_scene(kind):
+    W, H = 160, 120
+    def rgba(img, a):
+        return np.dstack([img[..., :3], np.full(img.shape[:2], a, np.uint8) if np.isscalar(a) else a.astype(np.uint8)])
+    bg = synth.photo_like(W, H, seed=1)
+    yy, xx = np.mgrid[0:40, 0:60]
+    al = 255 * np.clip(1 - np.hypot(xx - 30, yy - 20) / 25, 0, 1)
+    spr = rgba(synth.photo_like(60, 40, seed=2), al)
+    if kind == "blend":            # alpha-blended sprite moving over a kept background; edges not multiples of four, one layer partly outside the canvas
+        return W, H, [dict(rgba=rgba(bg, 255), duration=5, save=1), dict(rgba=spr, x0=20, y0=30, blend=2, source=1, duration=5, save=1),
+                      dict(rgba=spr, x0=70, y0=50, blend=2, source=1, duration=5, save=1), dict(rgba=spr[:, ::-1].copy(), x0=-10, y0=90, blend=2, source=1, duration=7)]
+    if kind == "modes":            # kAdd / kMulAdd / kMul layers, zero-duration layers (merged into the next shown frame), two slots, a translucent background
+        soft = rgba(synth.photo_like(W, H, seed=3), 200)
+        dim = rgba(np.full((30, 50, 3), 40, np.uint8), 128)
+        mul = rgba(np.full((50, 70, 3), 200, np.uint8), 255)
+        return W, H, [dict(rgba=soft, duration=0, save=2), dict(rgba=dim, x0=12, y0=8, blend=1, source=2, duration=3, save=2),
+                      dict(rgba=spr, x0=64, y0=40, blend=3, source=2, duration=0, save=1), dict(rgba=mul, x0=30, y0=60, blend=4, source=1, duration=4, save=1),
+                      dict(rgba=spr, x0=100, y0=10, blend=2, source=2, duration=2, save=0), dict(rgba=spr, x0=0, y0=0, blend=0, source=1, duration=6)]
+    raise ValueError(kind)
+
+
+ANIM_CASES = {
+    # name: (scene, encode kwargs)
+    "an_blend_lossless": ("blend", dict(lossless=True, effort=3)),
+    "an_blend_d1_e7": ("blend", dict(lossless=False, distance=1.0, effort=7)),
+    "an_modes_lossless": ("modes", dict(lossless=True, effort=3)),
+    "an_modes_d2_e5": ("modes", dict(lossless=False, distance=2.0, effort=5)),
+}
+
+
+def add_anim_cases(meta, only):
+    for name, (scene, ek) in ANIM_CASES.items():
+        if only and name not in only:
+            continue
+        W, H, frames = anim_scene(scene)
+        data = jxl_ref.encode_anim(frames, W, H, tps=(100, 1), loops=3, **ek)
+        durations, loops = jxl_ref.anim_info(data)
+        coalesced = sum(1 for i, f in enumerate(frames) if f.get("duration", 1) > 0 or i == len(frames) - 1)
+        out = np.stack([jxl_ref.decode_frame(data, i) for i in range(coalesced)])
+        last, info, _ = jxl_ref.decode(data)
+        assert np.array_equal(last, out[-1])
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=last, frames=out)
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), shape=list(last.shape), dtype=str(last.dtype), info=info, encode=ek, scene=scene, durations_ms=durations, loops=loops,
+                          coalesced_frames=coalesced)
+        print(name, len(data), out.shape, durations, loops)
+
+
 def make_image(w, h, sk):
     """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
     sk = dict(sk)
@@ -263,6 +315,7 @@ def main():
         add_assets(meta)
     add_rowsum_cases(meta, only)
     add_jpeg_cases(meta, only)
+    add_anim_cases(meta, only)
     if not only or "big_assets" in only:
         add_big_assets(meta)
     if only:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
-                      LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, load_case)
+                      LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, ANIM_LOSSLESS_CASES, ANIM_VARDCT_CASES, load_anim_case, load_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -240,6 +240,57 @@ def test_jpeg_transcodes(dec, name):
     torch.cuda.synchronize()
     assert np.array_equal(bufs[0].cpu().numpy().reshape(out.shape), out)
     assert np.array_equal(bufs[1].cpu().numpy().reshape(single_other.shape), single_other)
+
+
+@pytest.mark.parametrize("name", ANIM_LOSSLESS_CASES + ANIM_VARDCT_CASES)
+def test_animation_frames(dec, name):
+    """jxlamd_decode_frame: coalesced frame i of an animation with cropped, blended layers (kBlend / kAdd / kMulAdd / kMul, zero-duration layers, two reference
+    slots) — the frames it is laid over are decoded into their slots and blended on the GPU (k_blend_canvas) — against the reference's
+    JxlAnimatedDecoder::getFrame(i) (interop/JxlAnimatedDecoder.cpp:28-144).  Lossless bit-exact, lossy within the VarDCT tolerance; the plain decode is the
+    last frame; an ordinary frame decoded in between is not disturbed."""
+    data, frames = load_anim_case(name)
+    other, other_exp = load_case("l64_e7")
+    for i in range(len(frames)):
+        out, info = dec.decode_frame(data, i)
+        if name in ANIM_LOSSLESS_CASES:
+            assert np.array_equal(out, frames[i]), i
+        else:
+            d = np.abs(out.astype(int) - frames[i].astype(int))
+            assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (i, d.max(), d.mean())
+            assert np.array_equal(out[..., 3], frames[i][..., 3])
+        assert info["have_animation"] == 1
+        if i == 1:
+            o2, _ = dec.decode_one_shot(other)
+            assert np.array_equal(o2, other_exp)
+    last, _ = dec.decode_one_shot(data)
+    assert np.array_equal(last, dec.decode_frame(data, len(frames) - 1)[0])
+    with pytest.raises(J.InvalidJXLException, match="frame index beyond"):
+        dec.decode_frame(data, len(frames))
+
+
+def test_animated_image_surface(dec, golden_meta):
+    """JxlAnimatedImage (kt/JxlAnimatedImage.kt:41-199): numberOfFrames / loopsCount / getFrameDuration as the reference's constructor collects them,
+    getFrame(i) = the coalesced frame through the animated path's post stages (8-bit, ARGB_8888 by default), getFrame with a target size, close()."""
+    import jxl_coder_amd as J
+    name = "an_blend_lossless"
+    data, frames = load_anim_case(name)
+    with J.JxlAnimatedImage(data) as img:
+        assert img.numberOfFrames == len(golden_meta[name]["durations_ms"]) and img.loopsCount == golden_meta[name]["loops"]
+        assert [img.getFrameDuration(i) for i in range(img.numberOfFrames)] == golden_meta[name]["durations_ms"]
+        assert (img.getWidth(), img.getHeight()) == (frames.shape[2], frames.shape[1])
+        for i in range(len(frames)):
+            bmp = img.getFrame(i)
+            assert bmp.config == "ARGB_8888" and np.array_equal(bmp.pixels_view(), frames[i])
+        half = img.getFrame(1, 80, 60)
+        assert (half.width, half.height) == (80, 60)
+        with pytest.raises(ValueError, match="Frame position must be positive"):
+            img.getFrame(-1)
+        with pytest.raises(ValueError, match="more than frames in the container"):
+            img.getFrame(99)
+    with pytest.raises(RuntimeError):
+        img.getFrame(0)
+    with pytest.raises(J.InvalidJXLException, match="Not an JXL image"):
+        J.JxlAnimatedImage(b"GIF89a")
 
 
 def test_flight_subflights_and_pools_in_a_small_configuration():

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import (ROOT, VARDCT_CASES, LOSSLESS_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS,
-                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, load_case)
+                      U16_MEAN_ABS, LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, ANIM_LOSSLESS_CASES, ANIM_VARDCT_CASES, load_anim_case, load_case)
 
 import jxl_coder_amd as J
 
@@ -223,6 +223,42 @@ def test_jpeg_transcodes_on_cpu_harness(emul, name):
     d = np.abs(out.astype(int) - exp.astype(int))
     assert out.shape == exp.shape and d.max() <= VARDCT_MAX_ABS and d.mean() <= 1e-3, (d.max(), d.mean())
     assert np.array_equal(out[..., 3], exp[..., 3])
+
+
+@pytest.mark.parametrize("name", ANIM_LOSSLESS_CASES + ANIM_VARDCT_CASES)
+def test_animation_frames_on_cpu_harness(emul, name):
+    """Coalesced frame i of an animation with layers = the frame laid over the canvas its BlendingInfo names (dev_compose.h: blend_canvas_pixel; the frames
+    it is blended over are decoded into their reference slots first) — against the reference's JxlAnimatedDecoder::getFrame(i)
+    (interop/JxlAnimatedDecoder.cpp:28-144).  Lossless: bit-exact, which includes the reference writer's dither next to layer edges that are not multiples
+    of four; the plain decode is the last frame (interop/JxlDecoding.cpp:164-166)."""
+    data, frames = load_anim_case(name)
+    for i in range(len(frames)):
+        out = emul(data, frame=i)
+        if name in ANIM_LOSSLESS_CASES:
+            assert np.array_equal(out, frames[i]), i
+        else:
+            d = np.abs(out.astype(int) - frames[i].astype(int))
+            assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (i, d.max(), d.mean())
+            assert np.array_equal(out[..., 3], frames[i][..., 3])
+    assert np.array_equal(emul(data), emul(data, frame=len(frames) - 1))
+    with pytest.raises(ValueError, match="frame index beyond"):
+        emul(data, frame=len(frames))
+
+
+def test_animation_info_matches_the_reference_frame_list(built, golden_meta):
+    """jxlamd_anim_info (host only) = the frame list of the reference's JxlAnimatedDecoder constructor (interop/JxlAnimatedDecoder.hpp:68-185):
+    one entry per regular frame — zero-duration layers included —, durations in ms, the loop count; -1 loops for a still image."""
+    for name in ANIM_LOSSLESS_CASES + ANIM_VARDCT_CASES + ["asset_animated"]:
+        data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+        durations, loops = J.api.anim_info(data)
+        if "durations_ms" in golden_meta[name]:
+            assert durations == golden_meta[name]["durations_ms"] and loops == golden_meta[name]["loops"]
+        else:
+            assert len(durations) == 48 and loops == 0                          # the reference's animated_jxl.jxl (SURVEY.md appendix C)
+    data, _ = load_case("v256_e7")
+    assert J.api.anim_info(data) == ([0], -1)
+    with pytest.raises(J.InvalidJXLException):
+        J.api.anim_info(b"\xff\x0a\x00")
 
 
 def test_entropy_kernels_use_no_scratch():
