@@ -244,6 +244,7 @@ def test_jpeg_transcodes(dec, name):
 
 @pytest.mark.parametrize("name", ANIM_LOSSLESS_CASES + ANIM_VARDCT_CASES)
 def test_animation_frames(dec, name):
+    import jxl_coder_amd as J
     """jxlamd_decode_frame: coalesced frame i of an animation with cropped, blended layers (kBlend / kAdd / kMulAdd / kMul, zero-duration layers, two reference
     slots) — the frames it is laid over are decoded into their slots and blended on the GPU (k_blend_canvas) — against the reference's
     JxlAnimatedDecoder::getFrame(i) (interop/JxlAnimatedDecoder.cpp:28-144).  Lossless bit-exact, lossy within the VarDCT tolerance; the plain decode is the
@@ -269,6 +270,7 @@ def test_animation_frames(dec, name):
 
 
 def test_animated_image_surface(dec, golden_meta):
+    import jxl_coder_amd as J
     """JxlAnimatedImage (kt/JxlAnimatedImage.kt:41-199): numberOfFrames / loopsCount / getFrameDuration as the reference's constructor collects them,
     getFrame(i) = the coalesced frame through the animated path's post stages (8-bit, ARGB_8888 by default), getFrame with a target size, close()."""
     import jxl_coder_amd as J
