@@ -89,6 +89,10 @@ int jxlamd_decode(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t
  *                     BlendingInfo names — kReplace / kAdd / kBlend / kMulAdd / kMul on colour and alpha, cropped layers, reference slots — decoded and
  *                     blended on the GPU.  jxlamd_decode is jxlamd_decode_frame of the last frame (interop/JxlDecoding.cpp:164-166). */
 int jxlamd_anim_info(const uint8_t *jxl, size_t size, int32_t *durations_ms, int capacity, int32_t *num_frames, int32_t *loops);
+/* the same walk with what libjxl's frame events carry (JxlFrameHeader, JxlAnimationHeader: jxl/codestream_header.h:77-90, 391-425) */
+typedef struct { uint32_t duration_ticks; int32_t duration_ms; int32_t is_last; int32_t coalesced_index; /* -1: a zero-duration layer, shown as part of the next frame */ } jxlamd_anim_frame;
+typedef struct { uint32_t have_animation, tps_numerator, tps_denominator, num_loops, have_timecodes; } jxlamd_anim_header;
+int jxlamd_anim_frames(const uint8_t *jxl, size_t size, jxlamd_anim_frame *frames, int capacity, int32_t *num_frames, jxlamd_anim_header *header);
 int jxlamd_decode_frame(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, int frame, uint32_t flags, void *out, size_t out_capacity,
                         jxlamd_info *info);
 

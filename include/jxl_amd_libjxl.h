@@ -42,6 +42,10 @@ enum { JXLC_SIG_NOT_ENOUGH_BYTES = 0, JXLC_SIG_INVALID = 1, JXLC_SIG_CODESTREAM 
 typedef struct { uint32_t num_channels; int data_type; int endianness; size_t align; } JxlcPixelFormat;
 typedef struct { uint32_t xsize, ysize; } JxlcPreviewHeader;
 typedef struct { uint32_t tps_numerator, tps_denominator, num_loops; int have_timecodes; } JxlcAnimationHeader;
+/* jxl/codestream_header.h:325-425 (JxlBlendInfo, JxlLayerInfo, JxlFrameHeader) */
+typedef struct { int blendmode; uint32_t source, alpha; int clamp; } JxlcBlendInfo;
+typedef struct { int have_crop; int32_t crop_x0, crop_y0; uint32_t xsize, ysize; JxlcBlendInfo blend_info; uint32_t save_as_reference; } JxlcLayerInfo;
+typedef struct { uint32_t duration, timecode, name_length; int is_last; JxlcLayerInfo layer_info; } JxlcFrameHeader;
 typedef struct {
   int have_container;
   uint32_t xsize, ysize, bits_per_sample, exponent_bits_per_sample;
@@ -86,6 +90,12 @@ int JxlDecoderGetICCProfileSize(const JxlAmdCompatDecoder *dec, int target, size
 int JxlDecoderGetColorAsICCProfile(const JxlAmdCompatDecoder *dec, int target, uint8_t *icc_profile, size_t size);
 int JxlDecoderImageOutBufferSize(const JxlAmdCompatDecoder *dec, const JxlcPixelFormat *format, size_t *size);
 int JxlDecoderSetImageOutBuffer(JxlAmdCompatDecoder *dec, const JxlcPixelFormat *format, void *buffer, size_t size);
+/* the calls of the reference's animated decoder (interop/JxlAnimatedDecoder.hpp:68-185, .cpp:28-222; jxl/decode.h): frame events, frame-indexed decode */
+void JxlDecoderRewind(JxlAmdCompatDecoder *dec);
+void JxlDecoderSkipFrames(JxlAmdCompatDecoder *dec, size_t amount);
+int JxlDecoderSkipCurrentFrame(JxlAmdCompatDecoder *dec);
+int JxlDecoderSetCoalescing(JxlAmdCompatDecoder *dec, int coalescing);
+int JxlDecoderGetFrameHeader(const JxlAmdCompatDecoder *dec, JxlcFrameHeader *header);
 /* libjxl_threads */
 int JxlResizableParallelRunner(void *runner_opaque, void *jpegxl_opaque, JxlcParallelRunInit init, JxlcParallelRunFunction func,
                                uint32_t start_range, uint32_t end_range);

@@ -875,11 +875,23 @@ int jxlamd_decode_frame(jxlamd_decoder *d, const uint8_t *jxl, size_t size, int 
 // entries (the first min(cap, *num_frames) durations, in milliseconds, are stored) and the loop count (-1: the file is not an animation).  Host only.
 int jxlamd_anim_info(const uint8_t *jxl, size_t size, int32_t *durations_ms, int cap, int32_t *num_frames, int32_t *loops) {
   return jxlamd_guarded(nullptr, [&]() -> int {
-    std::vector<int32_t> d; int32_t l = -1; std::string err;
-    if (parse_anim_info(jxl, size, &d, &l, &err)) { g_tls_error = err; return err_class(err); }
+    std::vector<AnimFrame> d; AnimHeader h; std::string err;
+    if (parse_anim_info(jxl, size, &d, &h, &err)) { g_tls_error = err; return err_class(err); }
     if (num_frames) *num_frames = (int32_t)d.size();
-    if (loops) *loops = l;
-    for (int i = 0; i < cap && i < (int)d.size() && durations_ms; i++) durations_ms[i] = d[(size_t)i];
+    if (loops) *loops = h.have_animation ? (int32_t)h.num_loops : -1;
+    for (int i = 0; i < cap && i < (int)d.size() && durations_ms; i++) durations_ms[i] = d[(size_t)i].ms;
+    return JXLAMD_OK;
+  });
+}
+// The same walk with everything libjxl's frame events carry (JxlFrameHeader::duration in ticks, is_last; JxlAnimationHeader): what the libjxl-named
+// compat library needs to answer JxlDecoderGetFrameHeader / JxlDecoderGetBasicInfo of an animation (csrc/libjxl_abi.cpp).
+int jxlamd_anim_frames(const uint8_t *jxl, size_t size, jxlamd_anim_frame *frames, int cap, int32_t *num_frames, jxlamd_anim_header *header) {
+  return jxlamd_guarded(nullptr, [&]() -> int {
+    std::vector<AnimFrame> d; AnimHeader h; std::string err;
+    if (parse_anim_info(jxl, size, &d, &h, &err)) { g_tls_error = err; return err_class(err); }
+    if (num_frames) *num_frames = (int32_t)d.size();
+    if (header) { header->have_animation = h.have_animation; header->tps_numerator = h.tps_numerator; header->tps_denominator = h.tps_denominator; header->num_loops = h.num_loops; header->have_timecodes = h.have_timecodes; }
+    for (int i = 0; i < cap && i < (int)d.size() && frames; i++) { frames[i].duration_ticks = d[(size_t)i].ticks; frames[i].duration_ms = d[(size_t)i].ms; frames[i].is_last = d[(size_t)i].is_last; frames[i].coalesced_index = d[(size_t)i].coalesced; }
     return JXLAMD_OK;
   });
 }

@@ -540,7 +540,7 @@ static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t to
 
 static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_shown, uint32_t raw_w, uint32_t raw_h);
 
-int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *durations_ms, int32_t *loops, std::string *error) {
+int parse_anim_info(const uint8_t *data, size_t size, std::vector<AnimFrame> *frames, AnimHeader *hdr, std::string *error) {
   uint8_t *cs0; size_t csn; int owned_flag;
   if (extract_codestream(data, size, &cs0, &csn, &owned_flag)) { *error = hx_last_error(); return -1; }
   std::vector<uint8_t> owned;
@@ -552,8 +552,10 @@ int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *dura
   if (m.pub.want_icc && read_icc_stream(&br, nullptr)) { *error = hx_last_error(); return -1; }
   if (m.have_preview) { *error = "unsupported: preview frame"; return -1; }
   const uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
-  *loops = m.have_animation ? (int32_t)m.num_loops : -1;
-  durations_ms->clear();
+  hdr->have_animation = (uint32_t)m.have_animation; hdr->tps_numerator = m.have_animation ? m.tps_num : 0; hdr->tps_denominator = m.have_animation ? m.tps_den : 0;
+  hdr->num_loops = m.have_animation ? m.num_loops : 0; hdr->have_timecodes = m.have_animation ? (uint32_t)m.have_timecodes : 0;
+  frames->clear();
+  int shown = 0;
   for (size_t n = 0;; n++) {
     hx_align(&br);
     frame_hdr f;
@@ -561,9 +563,11 @@ int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *dura
     size_t end_byte = 0;
     if (read_toc(cs, csn, f, br.pos, nullptr, &end_byte, error)) return -1;
     if (f.frame_type == 0 || f.frame_type == 3) {
-      int ms = 0;
-      if (m.have_animation && m.tps_num) ms = (int)roundf(1000.0f * (float)f.duration * (float)m.tps_den / (float)m.tps_num);
-      durations_ms->push_back(ms);
+      AnimFrame a;
+      a.ticks = (uint32_t)f.duration; a.ms = 0; a.is_last = f.is_last;
+      if (m.have_animation && m.tps_num) a.ms = (int)roundf(1000.0f * (float)f.duration * (float)m.tps_den / (float)m.tps_num);
+      a.coalesced = (f.is_last || f.duration > 0) ? shown++ : -1;
+      frames->push_back(a);
     }
     if (f.is_last) break;
     if (n > 4096) { *error = "too many frames"; return -1; }

@@ -66,7 +66,9 @@ struct FramePlan {
 int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_frame = -1);
 // The frame list of an animation as the reference's JxlAnimatedDecoder constructor collects it (interop/JxlAnimatedDecoder.hpp:68-185): one entry per
 // regular frame, durations in milliseconds (round(1000 * ticks * tps_denominator / tps_numerator)), the loop count (-1: not an animation).  Returns 0.
-int parse_anim_info(const uint8_t *data, size_t size, std::vector<int32_t> *durations_ms, int32_t *loops, std::string *error);
+struct AnimFrame { uint32_t ticks; int32_t ms; int32_t is_last; int32_t coalesced; };      // coalesced: index among the frames libjxl emits with coalescing on (-1: a zero-duration layer, merged into the next one)
+struct AnimHeader { uint32_t have_animation, tps_numerator, tps_denominator, num_loops, have_timecodes; };
+int parse_anim_info(const uint8_t *data, size_t size, std::vector<AnimFrame> *frames, AnimHeader *hdr, std::string *error);
 // Phase 2 for single-section frames: HfGlobal starts at `lf_end_bit` (reported by the LF kernel).
 int plan_parse_hf_single(FramePlan *plan, uint64_t lf_end_bit);
 // Header-only parse (DecodeBasicInfo).

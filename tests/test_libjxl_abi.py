@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF_CPP = "/root/reference/jxlcoder/src/main/cpp"
 DRIVER_SO = os.path.join(ROOT, "tests", "boundary", "libref_driver_on_compat.so")
+ANIM_SO = os.path.join(ROOT, "tests", "boundary", "libref_anim_on_compat.so")
 
 
 def _compat():
@@ -42,11 +43,25 @@ def build_ref_driver():
     return True
 
 
+def build_ref_anim():
+    """The reference's interop/JxlAnimatedDecoder.cpp + tests/boundary/ref_anim_entry.cpp -> tests/boundary/libref_anim_on_compat.so (build container only)."""
+    d = _compat()
+    if not os.path.isdir(REF_CPP):
+        return os.path.exists(ANIM_SO)
+    srcs = [os.path.join(ROOT, "tests", "boundary", "ref_anim_entry.cpp"), os.path.join(REF_CPP, "interop", "JxlAnimatedDecoder.cpp")]
+    deps = srcs + [os.path.join(d, "libjxl.so"), os.path.join(d, "libjxl_threads.so")]
+    if not os.path.exists(ANIM_SO) or os.path.getmtime(ANIM_SO) < max(os.path.getmtime(f) for f in deps):
+        subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-include", "cstring", "-include", "cstdint", "-include", "mutex", "-I", REF_CPP, "-I", os.path.join(REF_CPP, "jxl"),
+                        "-I", os.path.join(REF_CPP, "interop"), "-o", ANIM_SO] + srcs +
+                       ["-L" + d, "-ljxl", "-ljxl_threads", "-Wl,-rpath,$ORIGIN/../../jxl_coder_amd/compat"], check=True)
+    return True
+
+
 def test_every_declared_symbol_is_exported():
     d = _compat()
     hdr = open(os.path.join(ROOT, "include", "jxl_amd_libjxl.h")).read()
     names = set(re.findall(r"\b(Jxl(?:Decoder|Signature|ResizableParallelRunner)\w*)\s*\(", hdr.split("JXL_AMD_LIBJXL_NO_PROTOTYPES", 1)[1]))
-    assert len(names) == 22, sorted(names)
+    assert len(names) == 27, sorted(names)            # 17 + 5 of the still decode path, 5 more of the animated decoder's
     exported = set()
     for lib in ("libjxl.so", "libjxl_threads.so"):
         out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(d, lib)], capture_output=True, text=True, check=True).stdout
@@ -64,8 +79,13 @@ def test_abi_layout_equals_the_reference_headers(tmp_path):
                                "intrinsic_xsize", "intrinsic_ysize", "padding"],
               "JxlColorEncoding": ["color_space", "white_point", "white_point_xy", "primaries", "primaries_red_xy", "primaries_green_xy", "primaries_blue_xy",
                                    "transfer_function", "gamma", "rendering_intent"],
-              "JxlPixelFormat": ["num_channels", "data_type", "endianness", "align"]}
-    mine = {"JxlBasicInfo": "JxlcBasicInfo", "JxlColorEncoding": "JxlcColorEncoding", "JxlPixelFormat": "JxlcPixelFormat"}
+              "JxlPixelFormat": ["num_channels", "data_type", "endianness", "align"],
+              "JxlAnimationHeader": ["tps_numerator", "tps_denominator", "num_loops", "have_timecodes"],
+              "JxlBlendInfo": ["blendmode", "source", "alpha", "clamp"],
+              "JxlLayerInfo": ["have_crop", "crop_x0", "crop_y0", "xsize", "ysize", "blend_info", "save_as_reference"],
+              "JxlFrameHeader": ["duration", "timecode", "name_length", "is_last", "layer_info"]}
+    mine = {"JxlBasicInfo": "JxlcBasicInfo", "JxlColorEncoding": "JxlcColorEncoding", "JxlPixelFormat": "JxlcPixelFormat", "JxlAnimationHeader": "JxlcAnimationHeader",
+            "JxlBlendInfo": "JxlcBlendInfo", "JxlLayerInfo": "JxlcLayerInfo", "JxlFrameHeader": "JxlcFrameHeader"}
     lines = ['#include <cstddef>', '#include "jxl/decode.h"', '#include "jxl/resizable_parallel_runner.h"', '#define JXL_AMD_LIBJXL_NO_PROTOTYPES', '#include "jxl_amd_libjxl.h"']
     for ref, flds in fields.items():
         lines.append(f"static_assert(sizeof({ref}) == sizeof({mine[ref]}), \"size of {ref}\");")
@@ -167,6 +187,78 @@ if gpu:
         assert (d.max() == 0) if name.startswith("l") else (d.max() <= 1 and d.mean() <= 0.08), (d.max(), d.mean())      # effort-3 file with one EPF iteration, linear-light codes: the rcpps offset of conftest.py (measured 0.051), (name, d.max(), d.mean())
 print("driver ok")
 """
+
+
+_ANIM_CHILD = r"""
+import ctypes as C, json, os, sys, numpy as np
+ROOT = sys.argv[1]; gpu = sys.argv[2] == "gpu"
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_libjxl_abi as T
+from jxl_coder_amd import api
+api.lib()
+L = C.CDLL(T.ANIM_SO)
+maps = open("/proc/self/maps").read()
+assert "jxl_coder_amd/compat/libjxl.so" in maps and "oracle/_ref" not in maps, "the animated decoder must be bound to the compat library, not to the reference's libjxl"
+L.refanim_open.restype = C.c_void_p; L.refanim_open.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+for f in ("refanim_close", "refanim_frames", "refanim_loops"): getattr(L, f).argtypes = [C.c_void_p]
+L.refanim_duration.argtypes = [C.c_void_p, C.c_int]; L.refanim_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 2)]
+L.refanim_get_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+meta = json.load(open(os.path.join(ROOT, "tests/golden/golden.json")))
+msg = C.create_string_buffer(256)
+assert not L.refanim_open(b"GIF89a....", 10, msg, 256) and msg.value == b"Not an JXL image"
+for name in ("an_blend_lossless", "an_modes_d2_e5", "asset_animated", "v256_e7"):
+    data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
+    h = L.refanim_open(data, len(data), msg, 256)
+    assert h, (name, msg.value)
+    n = L.refanim_frames(h)
+    durations = [L.refanim_duration(h, i) for i in range(n)]
+    wh = (C.c_uint32 * 2)(); L.refanim_size(h, C.byref(wh))
+    if name.startswith("an_"):
+        # the reference's own constructor (coalescing off, every frame skipped) over the compat library = what it collects over its libjxl
+        assert durations == meta[name]["durations_ms"] and L.refanim_loops(h) == meta[name]["loops"], (name, durations)
+        assert (wh[0], wh[1]) == (160, 120)
+    elif name == "asset_animated":
+        assert n == 48 and (wh[0], wh[1]) == (128, 128)
+    else:
+        assert n == 1 and durations == [0] and L.refanim_loops(h) == -1
+    if gpu and name.startswith("an_"):
+        frames = np.load(os.path.join(ROOT, "tests/golden", name + ".npz"))["frames"]
+        for i in range(len(frames)):
+            out = np.zeros(frames[i].nbytes, np.uint8); dur = C.c_int(); pref = C.c_int()
+            assert L.refanim_get_frame(h, i, out.ctypes.data, out.size, C.byref(dur), C.byref(pref), msg, 256) == 1, (name, i, msg.value, api.lib().jxlamd_last_error(None))
+            got = out.reshape(frames[i].shape)
+            d = np.abs(got.astype(int) - frames[i].astype(int))
+            assert (d.max() == 0) if "lossless" in name else (d.max() <= 1 and d.mean() <= 0.05), (name, i, d.max(), d.mean())
+            assert pref.value == 1                                                  # sRGB enum encoding: the reference uses it and ignores the ICC bytes
+        assert L.refanim_get_frame(h, len(frames) + 3, None, 0, C.byref(dur), C.byref(pref), msg, 256) == 0      # beyond the coalesced frames: an AnimatedDecoderError
+    if gpu and name == "v256_e7":
+        import jxl_coder_amd as J
+        exp, _ = J.JxlDecoder(0).decode_one_shot(data, allowed_floats=False)
+        out = np.zeros(exp.nbytes, np.uint8); dur = C.c_int(); pref = C.c_int()
+        assert L.refanim_get_frame(h, 0, out.ctypes.data, out.size, C.byref(dur), C.byref(pref), msg, 256) == 1 and np.array_equal(out.reshape(exp.shape), exp)
+    L.refanim_close(h)
+print("anim ok")
+"""
+
+
+def _run_anim_child(mode):
+    if not build_ref_anim():
+        pytest.skip("the reference's animated decoder is compiled in the build container (needs the reference tree)")
+    r = subprocess.run([sys.executable, "-c", _ANIM_CHILD, ROOT, mode], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "anim ok" in r.stdout, r.stdout[-800:] + r.stderr[-2000:]
+
+
+def test_reference_animated_decoder_walks_frames_on_the_host():
+    """interop/JxlAnimatedDecoder.hpp:68-185 — the reference's own constructor (frame events with coalescing off, JxlDecoderSkipCurrentFrame, durations,
+    loop count) compiled unchanged against compat/libjxl.so: no GPU involved."""
+    _run_anim_child("cpu")
+
+
+@pytest.mark.gpu
+def test_reference_animated_decoder_gets_frames_through_the_libjxl_abi():
+    """JxlAnimatedDecoder::getFrame (interop/JxlAnimatedDecoder.cpp:28-144: JxlDecoderRewind, JxlDecoderSkipFrames, coalescing on) — the reference's own
+    object code — over the libjxl-ABI subset: every coalesced frame of the layered fixtures equals the golden frames the reference's libjxl produced."""
+    _run_anim_child("gpu")
 
 
 def driver_handle():
