@@ -82,6 +82,14 @@ int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *
 int jxlamd_decode(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t out_capacity,
                   jxlamd_info *info);
 
+/* A10 + A11 with the decode ("fuse the colour matrix / tone map and the reformat into the writer").  Once set, every decode of this
+ * context (single, batch, resident) delivers the Bitmap format of jxlamd_reformat_query(xsize, ysize, out_bits == 16, cfg, has_alpha_in_origin, api_level)
+ * into `out` — rows of that stride — instead of RGBA8 / RGBA16: the colour matrix / Rec.2408 tone map where the reference's JNI layer applies it
+ * (cpp/JniDecoding.cpp:131-228: 'preferred' RGB enum encoding, API level < 34), premultiply and conversion (cpp/ReformatBitmap.cpp:46-263).  Frames whose
+ * last filter stage is a per-stage kernel (three EPF iterations: BASELINE config 5) emit it from that stage — the RGBA image is never stored —, the others
+ * take one pass over their RGBA behind the writer; the pixels equal jxlamd_decode + jxlamd_post_fused bit for bit.  enabled = 0 restores RGBA output. */
+int jxlamd_decoder_set_writer_post(jxlamd_decoder *dec, int enabled, int cfg, int api_level);
+
 /* Animations (the reference's JxlAnimatedDecoder, interop/JxlAnimatedDecoder.hpp:68-185 and .cpp:28-144).
  * jxlamd_anim_info  = what its constructor collects: *num_frames regular frames, their durations in ms (round(1000 * ticks * tps_den / tps_num); the first
  *                     min(capacity, *num_frames) are stored), *loops = animation.num_loops (-1: not an animation).  Host only.

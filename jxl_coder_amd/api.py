@@ -168,6 +168,7 @@ def lib():
         L.jxlamd_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_output_size.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
         L.jxlamd_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
+        L.jxlamd_decoder_set_writer_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.jxlamd_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_anim_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
@@ -255,6 +256,13 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return info.as_dict()
+
+    def set_writer_post(self, enabled: bool, config=PreferredColorConfig.DEFAULT, api_level=34):
+        """A10 + A11 with the decode (jxlamd_decoder_set_writer_post): decodes of this context deliver the Bitmap format of
+        reformat_query(w, h, 16-bit?, config, has alpha, api_level) — from the writer itself where the frame's last filter stage allows it."""
+        rc = lib().jxlamd_decoder_set_writer_post(self._h, int(bool(enabled)), int(config), int(api_level))
+        if rc:
+            _raise(rc, self._h)
 
     def decode_frame_to_device(self, data: bytes, frame: int, out_ptr: int, out_capacity: int, allowed_floats=False):
         """Coalesced frame `frame` of an animation into device memory (jxlamd_decode_frame; the reference's JxlAnimatedDecoder::getFrame)."""

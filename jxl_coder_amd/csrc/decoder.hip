@@ -58,6 +58,8 @@ static int size_guard(const jxlamd_info &o, uint32_t flags, std::string *err) {
   return 0;
 }
 
+static int ensure_color_plan(jxlamd_decoder *d, int is_u16, uint32_t depth, uint32_t primaries, uint32_t tf, const double *xy8, float intensity_target, bool *runs);
+static PostKind reformat_kind(uint32_t resolved_config, int src_is_u16);
 static int err_class(const std::string &e) { return e.rfind("unsupported", 0) == 0 ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 // internal return code: the lean LF kernel met a channel that needs a general lock-step loop (kErrNeedGeneral) — decode again with the general build
 // what one decoder context learnt about the frames of this process serves the others (contexts of a service see the same kind of content)
@@ -133,7 +135,8 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   if (q.whole) { std::string e; int rc = size_guard(S.pi, flags, &e); if (rc) { set_error(e); return rc; } }     // a band is below the Bitmap layer (BASELINE config 4)
   S.out_bytes = q.whole ? (size_t)S.pi.xsize * S.pi.ysize * bpp : (size_t)S.pi.xsize * (size_t)(q.py1 - q.py0) * bpp;
   if (Fh->no_output) S.out_bytes = 0;                   // a reference frame: nothing is written out
-  if (out_cap < S.out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
+  const bool post_wanted = wpost_enabled && q.whole && !Fh->no_output;      // the buffer then receives the Bitmap format (checked against its size below)
+  if (!post_wanted && out_cap < S.out_bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
   const size_t ncell = (size_t)plan.xb * (size_t)(q.scy1 - q.scy0);
   const size_t ntile = (size_t)((plan.xb + 7) / 8) * (size_t)(q.st1 - q.st0);
   const size_t npx = (size_t)plan.xb * 8 * (size_t)(q.prow1 - q.prow0);
@@ -217,6 +220,53 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   }
   HIPCHECK(S.misc.ensure(4096 + (size_t)plan.num_lf_groups * 72));
   S.host_out = nullptr; S.d_out = out_ptr;
+  // A10 + A11 with the decode (jxlamd_decoder_set_writer_post): the caller's buffer receives the Bitmap format.  Decided per frame as the
+  // reference's JNI layer does (cpp/JniDecoding.cpp:131-137: colour matrix when the enum encoding is 'preferred', RGB, and the API level is below 34)
+  S.post_active = false; S.post_fused = false;
+  if (post_wanted) {
+    const bool is16 = S.pi.out_bits == 16;
+    jxlamd_reformat_info ri;
+    int rc = jxlamd_reformat_query(S.pi.xsize, S.pi.ysize, is16, wpost_cfg, (int)S.pi.has_alpha_in_origin, wpost_api, &ri);
+    if (rc) { set_error(g_tls_error); return rc; }
+    if (out_cap < ri.bytes) { set_error("output buffer too small"); return JXLAMD_ERR_BUFFER; }
+    const uint32_t tf = S.pi.transfer_function;
+    const bool matrix = S.pi.prefer_encoding && (tf == 16 || tf == 18 || tf == 17 || tf == 1 || tf == 65535u || tf == 13) && S.pi.color_space == 0 && wpost_api < 34;
+    S.post_depth = is16 ? 16u : 8u;                       // bitDepth as DecodeJpegXlOneShot reports it (JxlDecoding.cpp:92-101)
+    S.post_runs = false;
+    if (matrix) {
+      const double xy8[8] = {S.pi.primaries_red_xy[0], S.pi.primaries_red_xy[1], S.pi.primaries_green_xy[0], S.pi.primaries_green_xy[1], S.pi.primaries_blue_xy[0], S.pi.primaries_blue_xy[1],
+                             S.pi.white_point_xy[0], S.pi.white_point_xy[1]};
+      rc = ensure_color_plan(this, is16, S.post_depth, S.pi.primaries, tf, xy8, S.pi.intensity_target, &S.post_runs);
+      if (rc) return rc;
+    }
+    S.post_active = true; S.post_gen = post_lut_gen;
+    S.post_kind = (int)reformat_kind(ri.resolved_config, is16);
+    S.post_premul = !S.pi.alpha_premultiplied && S.pi.has_alpha_in_origin; S.post_att = !S.pi.alpha_premultiplied;
+    S.post_stride = ri.stride; S.post_bytes = ri.bytes;
+    // inside the writer where the frame's last stage is a per-stage kernel (three EPF iterations: BASELINE config 5); elsewhere one pass behind it
+    S.post_fused = !plan.modular && !plan.compose && !plan.cropped && plan.refs.empty() && Fh->epf_iters == 3 && Fh->orientation >= 1;
+    S.post_final = out_ptr;
+    if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(ri.bytes)); S.post_final = S.out.p; S.host_out = out_ptr; }
+    const uint32_t line = ri.format == JXLAMD_FMT_RGB_565 ? S.pi.xsize * 2 : ri.format == JXLAMD_FMT_RGBA_F16 ? S.pi.xsize * 8 : S.pi.xsize * 4;
+    if (ri.stride != line) HIPCHECK(hipMemsetAsync(S.post_final, 0, ri.bytes, stream));
+    if (S.post_fused) {
+      HIPCHECK(S.post_fz.ensure((size_t)(1 + S.pi.ysize) * 4));
+      HIPCHECK(hipMemsetAsync(S.post_fz.p, 0xFF, (size_t)(1 + S.pi.ysize) * 4, stream));
+      HIPCHECK(hipMemsetAsync(S.post_fz.p, 0, 4, stream));
+      DevPost Q; memset(&Q, 0, sizeof(Q));
+      if (S.post_runs) Q.P = post_dev;
+      Q.matrix = S.post_runs ? 1 : 0; Q.premul = S.post_premul ? 1 : 0; Q.kind = S.post_kind; Q.depth = (int32_t)S.post_depth; Q.attenuate = S.post_att ? 1 : 0;
+      Q.dst_stride = ri.stride; Q.dst = (uint8_t *)S.post_final; Q.row_fz = (uint32_t *)S.post_fz.p;
+      HIPCHECK(S.post_dev.ensure(sizeof(DevPost)));
+      HIPCHECK(S.h_post.ensure(sizeof(DevPost)));
+      memcpy(S.h_post.p, &Q, sizeof(Q));
+      HIPCHECK(hipMemcpyAsync(S.post_dev.p, S.h_post.p, sizeof(DevPost), hipMemcpyHostToDevice, stream));
+      S.d_out = S.post_final;                             // (the RGBA writer is not used: B.out only has to be a valid address)
+    } else {
+      HIPCHECK(S.post_tmp.ensure(S.out_bytes));
+      S.d_out = S.post_tmp.p;
+    }
+  } else
   if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(S.out_bytes)); S.d_out = S.out.p; S.host_out = out_ptr; }
   if (plan.cropped) {
     // the frame does not cover the image: what it leaves out shows the cleared canvas — transparent black, or opaque black when the image
@@ -256,6 +306,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     B.ref_a[k] = (have && ref_alpha[k]) ? (float *)ref_store[k].p + 3 * n : nullptr;      // a blended canvas kept with its alpha plane
   }
   for (int c = 0; c < 4; c++) B.canvas_save[c] = nullptr;
+  B.post = (S.post_active && S.post_fused) ? (const DevPost *)S.post_dev.p : nullptr;
   if (Fh->blend && Fh->bl_src >= 0 && !B.ref[Fh->bl_src][0]) { set_error("blending: the source canvas is missing"); return JXLAMD_ERR_INVALID; }
   if (Fh->num_patches > 0) {
     const DevPatch *P = (const DevPatch *)(plan.tables.data() + Fh->patch_off);
@@ -320,6 +371,7 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   if (F->compose) stage_mask = (stage_mask & 15) | 32;           // stage by stage into the planes; patches, reference copy and writer follow (launch_compose_tail)
+  if (S.post_active && S.post_fused) stage_mask |= 64;           // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
   launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
   return JXLAMD_OK;
 }
@@ -389,12 +441,22 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   return JXLAMD_OK;
 }
 
+// A10 + A11 behind the writer for a frame whose last filter stage could not take them (column-sweep frames, Modular and composed frames): one pass over
+// the RGBA the writer stored (k_post_fused), into the caller's buffer
+void jxlamd_decoder::launch_post_pass(FrameSlot &S) {
+  if (!S.post_active || S.post_fused) return;
+  const bool is16 = S.pi.out_bits == 16;
+  launch_post_fused((PostKind)S.post_kind, S.post_tmp.p, S.pi.xsize * (is16 ? 8u : 4u), S.post_final, S.post_stride, S.pi.xsize, S.pi.ysize, S.post_runs ? &post_dev : nullptr,
+                    S.post_premul, S.post_depth, S.post_att, stream);
+}
+
 int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   uint32_t derr = 0;
   uint32_t head[20] = {0};                              // flags word and, at byte 64, the size-class block counters
   HIPCHECK(h_flags.ensure(256));                        // page-locked: a copy into pageable memory is synchronous inside the runtime (see band.hip)
+  launch_post_pass(S);
   HIPCHECK(hipMemcpyAsync(h_flags.p, S.B.err, sizeof(head), hipMemcpyDeviceToHost, stream));
-  if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream));
+  if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.post_active ? S.post_final : S.d_out, S.post_active ? S.post_bytes : S.out_bytes, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
   (void)flags;
@@ -614,6 +676,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (F->epf_iters >= 1) stage_mask |= 4;
     if (F->epf_iters >= 2) stage_mask |= 8;
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
+    if (S.post_active && S.post_fused) stage_mask |= 64;      // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
   }
   // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
   // contexts sharing it overlap one's LF stage with the other's HF phase
@@ -744,7 +807,12 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
   HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
   HIPCHECK(hipMemcpyAsync(h_flags.p, bt + o_fl, (size_t)nb * kFlagWords * 4, hipMemcpyDeviceToHost, stream));
-  for (int i : batched) { FrameSlot &S = slot((size_t)i); if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.d_out, S.out_bytes, hipMemcpyDeviceToHost, stream)); }
+  for (int i : batched) if (slot((size_t)i).post_active && slot((size_t)i).post_runs && slot((size_t)i).post_gen != post_lut_gen) {
+    // the context holds ONE set of tone-map LUTs: frames of a flight that need different ones (other primaries / transfer function / bit depth) cannot share it
+    set_error("unsupported: frames of one batch with different colour-matrix plans under jxlamd_decoder_set_writer_post"); return JXLAMD_ERR_UNSUPPORTED;
+  }
+  for (int i : batched) launch_post_pass(slot((size_t)i));      // frames whose writer could not take A10 + A11 itself: one pass over their RGBA each
+  for (int i : batched) { FrameSlot &S = slot((size_t)i); if (S.host_out) HIPCHECK(hipMemcpyAsync(S.host_out, S.post_active ? S.post_final : S.d_out, S.post_active ? S.post_bytes : S.out_bytes, hipMemcpyDeviceToHost, stream)); }
   HIPCHECK(hipStreamSynchronize(stream));
   HIPCHECK(hipGetLastError());
   for (int k = 0; k < nb; k++) {
@@ -862,6 +930,16 @@ int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *
 int jxlamd_decode(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t cap, jxlamd_info *info) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   return jxlamd_guarded(d, [&]() -> int { return d->decode(jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out, cap, info); });
+}
+
+// A10 + A11 with the decode: from now on this context's decodes deliver the Bitmap format of jxlamd_reformat_query(w, h, 16-bit?, cfg,
+// has alpha, api_level) — colour matrix / tone map when the reference's JNI layer would apply it (cpp/JniDecoding.cpp:131-137), premultiply, conversion —
+// INSIDE the writer for frames whose last filter stage is a per-stage kernel (three EPF iterations: BASELINE config 5), one pass behind it otherwise.
+int jxlamd_decoder_set_writer_post(jxlamd_decoder *d, int enabled, int cfg, int api_level) {
+  if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  if (enabled && (cfg < 1 || cfg > 6)) { d->set_error("Invalid Color Config: " + std::to_string(cfg) + " was passed"); return JXLAMD_ERR_BUFFER; }
+  d->wpost_enabled = enabled != 0; d->wpost_cfg = cfg; d->wpost_api = api_level;
+  return JXLAMD_OK;
 }
 
 // Coalesced frame `frame` of an animation (what the reference's JxlAnimatedDecoder::getFrame returns, interop/JxlAnimatedDecoder.cpp:28-144): the frames it
@@ -995,7 +1073,7 @@ static int ensure_color_plan(jxlamd_decoder *d, int is_u16, uint32_t depth, uint
   D.tone_map = P.tone_map; D.weight_a = P.weight_a; D.weight_b = P.weight_b;
   D.lin_lut = (const float *)d->post_lin_lut.p; D.gam_lut = (const uint16_t *)d->post_gam_lut.p;
   D.index_scale = P.index_scale; D.index_max = P.index_max;
-  d->post_dev = D; memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = true;
+  d->post_dev = D; memcpy(d->post_key, key, sizeof(key)); d->post_key_valid = true; d->post_plan_runs = true; d->post_lut_gen++;
   *runs = true;
   return JXLAMD_OK;
 }

@@ -102,6 +102,12 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   size_t out_bytes = 0;
   void *d_out = nullptr; void *host_out = nullptr;
   const uint8_t *up_cs_dev = nullptr;   // frames of a flight: the caller's resident compressed bytes (null: host bytes), copied by the flight's gather launch
+  // A10 + A11 behind / inside the writer (jxlamd_decoder_set_writer_post): `out` receives the Bitmap format.  fused: the frame's last filter stage emits it
+  // (DevBuffers::post); otherwise the writer fills post_tmp (RGBA8 / RGBA16) and one k_post_fused pass over it follows the frame's kernels
+  bool post_active = false, post_fused = false, post_runs = false, post_premul = false, post_att = false;
+  int post_kind = 0; uint32_t post_depth = 8, post_stride = 0; size_t post_bytes = 0; uint64_t post_gen = 0;      // post_gen: which upload of the context's tone-map LUTs the frame was prepared against
+  void *post_final = nullptr;
+  DevMem post_dev, post_fz, post_tmp; PinnedMem h_post;
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
 };
@@ -129,7 +135,8 @@ struct jxlamd_decoder {
   DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;
   std::vector<FrameSlot *> ref_slots;     // reference frames of the file being decoded (patch dictionaries), one slot each
-  DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0}; bool ref_alpha[4] = {false, false, false, false}; int target_frame = -1;     // the four reference slots: 3 dense f32 planes each
+  DevMem ref_store[4]; int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0}; bool ref_alpha[4] = {false, false, false, false}; int target_frame = -1;
+  bool wpost_enabled = false; int wpost_cfg = 0, wpost_api = 34; uint64_t post_lut_gen = 0;      // jxlamd_decoder_set_writer_post     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds
   bool icc_lut_u16 = false;                // ... sampled through Little CMS's 16-bit transform (RGBA16 images) or its 8-bit one (RGBA8: host_icc_lut.cpp)
@@ -167,6 +174,7 @@ struct jxlamd_decoder {
   int launch_extra_channels(FrameSlot &S);
   int collect(FrameSlot &S, uint32_t flags);
   int decode(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info, int frame = -1);
+  void launch_post_pass(FrameSlot &S);
   int decode_once(const uint8_t *jxl, size_t size, const void *jxl_dev, uint32_t flags, void *out_ptr, size_t out_cap, jxlamd_info *info);
   int decode_batch_once(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags, void *const *outs,
                         const size_t *caps, jxlamd_info *infos);

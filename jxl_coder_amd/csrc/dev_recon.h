@@ -426,13 +426,14 @@ JXL_DEV float tf_709(float v) {
 }
 
 // the writer's last step: three colour values in [0, 1] of frame pixel (x, y) -> canvas position, orientation, alpha, dither, RGBA8 / RGBA16
-JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, const float (&v)[3], int out_bits, int x, int y) {
+// ... as integer codes: px[4] (8- or 16-bit) and the output position; false when the pixel falls outside the canvas
+JXL_DEV bool rgba_codes(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, const float (&v)[3], int out_bits, int x, int y, uint32_t (&px)[4], int &ox, int &oy) {
   const DevFrame &F = frame_of(B);
   const int fx = x, fy = y;                            // frame position (the alpha plane below is read there)
   x += F.crop_x0; y += F.crop_y0;                      // canvas position
   const int w = F.canvas_w, h = F.canvas_h;
-  if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return;
-  int ox = x, oy = y;
+  if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return false;
+  ox = x; oy = y;
   switch (F.orientation) {
     case 2: ox = w - 1 - x; break;
     case 3: ox = w - 1 - x; oy = h - 1 - y; break;
@@ -443,7 +444,6 @@ JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStati
     case 8: ox = y; oy = w - 1 - x; break;
     default: break;
   }
-  const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
   float alpha = 1.0f;                                  // extra channel of type alpha (Modular-coded, integer samples)
   if ((F.has_ec || F.is_modular) && F.mod_out[3] >= 0) {
     if (F.alpha_up > 1) alpha = B.up[3][(size_t)fy * (size_t)F.full_w + (size_t)fx];       // enlarged beforehand (upsample_alpha_pixel); fx, fy are full-resolution here
@@ -457,21 +457,22 @@ JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStati
     // libjxl's 8-bit writer dither (oracle/README.md): indexed by the OUTPUT position; for the transposing orientations (5..8) with row
     // and column swapped (established on the reference's output: tests/golden/vo72x40_e3_o5..8)
     const float d = st_f(stat, ST.dither_off)[F.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
-    uint8_t px[4];
-    for (int c = 0; c < 3; c++) px[c] = (uint8_t)(int)rintf(v[c] * 255.0f + d);
-    px[3] = (uint8_t)(int)rintf(alpha * 255.0f + d);        // the dither goes on every channel; it only shows on a fractional (upsampled) alpha: |d| < 0.5
-    *(uint32_t *)(B.out + di) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | ((uint32_t)px[3] << 24);
+    for (int c = 0; c < 3; c++) px[c] = (uint32_t)(uint8_t)(int)rintf(v[c] * 255.0f + d);
+    px[3] = (uint32_t)(uint8_t)(int)rintf(alpha * 255.0f + d);        // the dither goes on every channel; it only shows on a fractional (upsampled) alpha: |d| < 0.5
   } else {
-    uint16_t *o16 = (uint16_t *)B.out + di;
-    for (int c = 0; c < 3; c++) o16[c] = (uint16_t)(int)rintf(v[c] * 65535.0f);
-    o16[3] = (uint16_t)(int)rintf(alpha * 65535.0f);
+    for (int c = 0; c < 3; c++) px[c] = (uint32_t)(uint16_t)(int)rintf(v[c] * 65535.0f);
+    px[3] = (uint32_t)(uint16_t)(int)rintf(alpha * 65535.0f);
   }
+  return true;
 }
-JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float X, float Y, float Bc, int out_bits, int x, int y);
-JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *const src[3], int out_bits, int x, int y) {
-  const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
-  xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
+JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, const float (&v)[3], int out_bits, int x, int y) {
+  uint32_t px[4]; int ox, oy;
+  if (!rgba_codes(B, stat, ST, v, out_bits, x, y, px, ox, oy)) return;
+  const size_t di = ((size_t)oy * (size_t)frame_of(B).out_w + (size_t)ox) * 4;
+  if (out_bits == 8) *(uint32_t *)(B.out + di) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+  else { uint16_t *o16 = (uint16_t *)B.out + di; for (int c = 0; c < 4; c++) o16[c] = (uint16_t)px[c]; }
 }
+
 // XYB -> the image's colour encoding (opsin inverse, target primaries, transfer function), NOT clamped: what libjxl's "XYB" + "FromLinear" stages hand to
 // the blending stage / the writer
 JXL_DEV void xyb_to_rgb(const DevFrame &F, float X, float Y, float Bc, float (&v)[3]) {
@@ -504,6 +505,10 @@ JXL_DEV void xyb_write_value(const DevBuffers &B, const uint8_t *stat, const Dev
   xyb_to_rgb(frame_of(B), X, Y, Bc, v);
   for (int c = 0; c < 3; c++) { const float lin = v[c]; v[c] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin; if (!(lin == lin)) v[c] = 0.0f; }
   rgba_store(B, stat, ST, v, out_bits, x, y);
+}
+JXL_DEV void xyb_write_pixel(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *const src[3], int out_bits, int x, int y) {
+  const size_t po = (size_t)y * (size_t)frame_of(B).pw + (size_t)x;
+  xyb_write_value(B, stat, ST, src[0][po], src[1][po], src[2][po], out_bits, x, y);
 }
 
 // Writer of a VarDCT frame that is not XYB (a recompressed JPEG): the planes hold the image's own samples — R, G, B, or Cb, Y, Cr centred on zero, which

@@ -12,6 +12,7 @@
 
 namespace jxlamd {
 
+struct DevPost;                  // post.h: A10 + A11 inside the writer (HIP builds only)
 struct DevBuffers {
   const uint8_t *codestream;
   const uint8_t *tables;        // blob; DevFrame at offset 0
@@ -41,6 +42,7 @@ struct DevBuffers {
   uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [DevFrame::lz_win_len] + [num_groups][DevFrame::lz_win_group] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
   float *up[4];                 // upsampled frames: dense full_w x full_h f32 planes between the upsampling stage and the writer ([3]: an upsampled alpha channel)
+  const DevPost *post;          // non-null: the frame's last filter stage hands its pixels to the post stages instead of storing RGBA (kernels_filter.hip: k_filter_b<3, 1>)
   float *ref_a[4];              // ... and, for a slot that holds a blended canvas (frames of an animation), its alpha plane (null: the image has none)
   float *canvas_save[4];        // where blend_canvas_pixel keeps the blended canvas (R, G, B, A planes of canvas_w x canvas_h; null: not kept)
   float *ref[4][3];             // reference slots (patch dictionaries): 3 f32 planes of DevFrame::ref_w x ref_h samples each, XYB or RGB as the image is coded

@@ -1,6 +1,7 @@
 // jxl_coder_amd/csrc/kernels_filter.hip — HIP kernels (gfx950): Gaborish / EPF iterations, the last one fused with the XYB -> RGB -> RGBA8/16 writer.
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
 #include "kernels_common.h"
+#include "dev_post.h"
 
 namespace jxlamd {
 
@@ -27,11 +28,18 @@ __device__ __forceinline__ int stage_halo_after(const DevFrame &F, int stage) {
   return (stage < 1 && F.epf_iters >= 3 ? 3 : 0) + (stage < 2 && F.epf_iters >= 1 ? 2 : 0) + (stage < 3 && F.epf_iters >= 2 ? 1 : 0);
 }
 __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F);
-template <int STAGE>
+// POST (EPF iteration 2 as the last stage only — frames with three iterations, BASELINE config 5): 0 = frames whose writer stores RGBA;
+// 1 = frames with DevBuffers::post: the stage's pixel goes through the colour transform into RGBA codes and from there straight through A10 (colour matrix /
+// tone map) and A11 (premultiply, Bitmap format) — nothing but the Bitmap is written; 2 = the pass behind it that re-writes, un-mapped, the pixels at or
+// behind their row's first zero-luma pixel (dev_post.h: post_emit).  Separate instantiations: the LUT lookups and the format switch stay out of the
+// ordinary writer's registers.
+template <int STAGE, int POST = 0>
 __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if ((F.is_modular && !F.xyb_modular) || !stage_runs(F, STAGE) || frame_failed(B)) return;
+  if ((POST != 0) != (B.post != nullptr && STAGE == 3)) return;        // the other instantiation's frame
+  if (POST == 2 && B.post->row_fz[0] == 0) return;                     // no pixel of zero luma anywhere in the frame: the first pass was final
   if (STAGE == 4 && F.compose) return;                       // composed frames have their own writer stage (k_compose_write)
   if (sweep_on && frame_uses_sweep(F)) return;                // k_filter_sweep produces this frame's pixels
   const int last = last_filter_stage(F);
@@ -51,6 +59,13 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
     // keep the filter's last multiply and the writer's first add apart (no FMA contraction across the fusion seam): the fused
     // path must give the very pixels of the stage-by-stage path (single decodes, tests/test_gpu_parity.py batch == single)
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    if (POST != 0) {
+      float c[3];
+      xyb_to_rgb(F, v[0], v[1], v[2], c);
+      for (int k = 0; k < 3; k++) { const float lin = c[k]; c[k] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin; if (!(lin == lin)) c[k] = 0.0f; }
+      uint32_t px[4]; int ox, oy;
+      if (rgba_codes(B, stat, *(const DevStatic *)stat, c, B.out_bits, x, y, px, ox, oy)) post_emit<POST == 2 ? 2 : 1>(*B.post, px[0], px[1], px[2], px[3], ox, oy, B.out_bits == 16);
+    } else
     xyb_write_value(B, stat, *(const DevStatic *)stat, v[0], v[1], v[2], B.out_bits, x, y);
   }
   else for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
@@ -193,6 +208,7 @@ __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, cons
 }
 
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
+  const bool post = (stage_mask & 64) != 0;                      // some frame of the launch hands its pixels to the post stages (DevBuffers::post)
   // Column sweep (k_filter_sweep) for every frame with at most two EPF iterations; frames with three (stage_mask & 2: the 12-tap first
   // pass) go through the per-stage kernels, which skip the frames the sweep has produced.
   const int sweep = 1;
@@ -213,6 +229,10 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat, sweep);
   if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat, sweep);
   if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if ((stage_mask & 8) && post) {
+    hipLaunchKernelGGL((k_filter_b<3, 1>), grid, dim3(256), 0, s, Bs, stat, sweep);
+    hipLaunchKernelGGL((k_filter_b<3, 2>), grid, dim3(256), 0, s, Bs, stat, sweep);
+  }
   if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat, sweep);
 }
 

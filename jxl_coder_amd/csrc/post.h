@@ -21,6 +21,16 @@ struct ColorMatrixDev {
   float index_scale; uint32_t index_max;
 };
 void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h, bool is_u16, const ColorMatrixDev &P, hipStream_t s);
+// A10 + A11 INSIDE the decoder's writer: the last filter stage hands its RGBA codes straight to the colour matrix / tone map, the
+// premultiply and the conversion into the Bitmap's format (kernels_filter.hip: k_filter_b<3, 1>); nothing but the Bitmap is written.  DevBuffers::post
+// points at one of these (device memory) for a frame decoded that way.
+struct DevPost {
+  ColorMatrixDev P;
+  int32_t matrix, premul, kind, depth, attenuate;     // kind: PostKind
+  uint32_t dst_stride;
+  uint8_t *dst;                                       // the Bitmap (rows of dst_stride bytes)
+  uint32_t *row_fz;                                   // [1 + output rows]: word 0 = some row has a pixel of zero linear luma; word 1 + y = the first such pixel of row y (0xFFFFFFFF: none) — see k_filter_b<3, 2>
+};
 // A10 (P != null) + premultiply + conversion in one pass: src (read-only) -> dst; equals launch_post_color_matrix, launch_post_premultiply, launch_post_convert in turn
 void launch_post_fused(PostKind kind, const void *src, uint32_t src_stride, void *dst, uint32_t dst_stride, uint32_t w, uint32_t h, const ColorMatrixDev *P, bool premul,
                        uint32_t depth, bool attenuate, hipStream_t s);

@@ -8,11 +8,9 @@
 // All of them are streaming kernels (HBM-bound): one work-item per pixel, 4-16 bytes in, 2-8 bytes out.
 // Integer stages are bit-exact with the reference; the float stage keeps the reference's operation order with FMA
 // contraction disabled, so that it differs from the reference only through the host-built LUTs / matrix.
-#include "post.h"
+#include "dev_post.h"
 
 namespace jxlamd {
-
-__device__ __forceinline__ uint16_t half_bits(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(uint16_t, h); }   // RNE
 
 __global__ void __launch_bounds__(256) k_post_premul8(uint8_t *px, uint32_t stride, uint32_t w, uint32_t h) {
   const uint32_t x = blockIdx.y * 256 + threadIdx.x, y = blockIdx.x;      // rows in grid.x (grid.y is capped at 65 535)
@@ -32,36 +30,6 @@ __global__ void __launch_bounds__(256) k_post_premul16(uint8_t *px, uint32_t str
   *p = v;
 }
 
-// one pixel of the conversion stage: (r, g, b, a) as the source holds them -> destination format KIND at column x of drow
-template <int KIND>
-__device__ __forceinline__ void post_convert_store(uint8_t *drow, uint32_t x, uint32_t r, uint32_t g, uint32_t b, uint32_t a, uint32_t depth, int attenuate) {
-  if (attenuate && (KIND == kPostRgba8ToF16 || KIND == kPostRgba8To565 || KIND == kPostRgba8To1010102)) { r = (r * a) / 255u; g = (g * a) / 255u; b = (b * a) / 255u; }
-  if (KIND == kPostU16ToF16 || KIND == kPostRgba8ToF16) {
-    const float scale = 1.0f / (float)((1u << (KIND == kPostU16ToF16 ? depth : 8u)) - 1u);
-    ushort4 o;
-    o.x = half_bits((float)r * scale); o.y = half_bits((float)g * scale); o.z = half_bits((float)b * scale); o.w = half_bits((float)a * scale);
-    ((ushort4 *)drow)[x] = o;
-  } else if (KIND == kPostRgba16To8) {
-    const uint32_t d = depth - 8;
-    ((uint32_t *)drow)[x] = ((r >> d) & 0xff) | (((g >> d) & 0xff) << 8) | (((b >> d) & 0xff) << 16) | (((a >> d) & 0xff) << 24);
-  } else if (KIND == kPostRgba8To565) {
-    ((uint16_t *)drow)[x] = (uint16_t)(((r >> 3) << 11) | ((g >> 2) << 5) | (b >> 3));
-  } else if (KIND == kPostRgba16To565) {
-    const uint32_t rb = depth - 8 + 3, gd = depth - 8 + 2;
-    ((uint16_t *)drow)[x] = (uint16_t)((((r >> rb) << 11) & 0xffffu) | (((g >> gd) << 5) & 0xffffu) | (b >> rb));
-  } else if (KIND == kPostRgba8To1010102) {
-    ((uint32_t *)drow)[x] = ((a >> 6) << 30) | ((b << 2) << 20) | ((g << 2) << 10) | (r << 2);
-  } else if (KIND == kPostRgba16To1010102) {
-    const uint32_t d = depth - 10, ad = depth - 2;
-    ((uint32_t *)drow)[x] = (((a >> ad) & 3u) << 30) | (((b >> d) & 0x3ffu) << 20) | (((g >> d) & 0x3ffu) << 10) | ((r >> d) & 0x3ffu);
-  } else if (KIND == kPostCopy8) {
-    ((uint32_t *)drow)[x] = r | (g << 8) | (b << 16) | (a << 24);
-  } else {
-    ushort4 o; o.x = (uint16_t)r; o.y = (uint16_t)g; o.z = (uint16_t)b; o.w = (uint16_t)a;
-    ((ushort4 *)drow)[x] = o;
-  }
-}
-template <int KIND> constexpr bool post_src16() { return KIND == kPostU16ToF16 || KIND == kPostRgba16To8 || KIND == kPostRgba16To565 || KIND == kPostRgba16To1010102 || KIND == kPostCopy16; }
 template <int KIND>
 __global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32_t src_stride, uint8_t *dst, uint32_t dst_stride, uint32_t w, uint32_t h,
                                                       uint32_t depth, int attenuate) {
@@ -74,24 +42,6 @@ __global__ void __launch_bounds__(256) k_post_convert(const uint8_t *src, uint32
   post_convert_store<KIND>(dst + (size_t)y * dst_stride, x, r, g, b, a, depth, attenuate);
 }
 
-// A10, one pixel: LUT -> (tone map unless the row is stuck) -> matrix -> LUT.  FMA contraction off: the reference's operation order.
-template <bool kU16>
-__device__ __forceinline__ void post_matrix_px(const ColorMatrixDev &P, bool tone, uint32_t &r, uint32_t &g, uint32_t &b) {
-#pragma clang fp contract(off)
-  const uint32_t cap = kU16 ? P.index_max : 255u;
-  float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
-  if (tone) {
-    const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
-    const float scale = (1.0f + P.weight_a * y) / (1.0f + P.weight_b * y);
-    fr = fminf(fr * scale, 1.0f); fg = fminf(fg * scale, 1.0f); fb = fminf(fb * scale, 1.0f);
-  }
-  const float nr = fr * P.m[0] + fg * P.m[1] + fb * P.m[2];
-  const float ng = fr * P.m[3] + fg * P.m[4] + fb * P.m[5];
-  const float nb = fr * P.m[6] + fg * P.m[7] + fb * P.m[8];
-  #define IDX(v) ({ float c_ = (v) < 0.0f ? 0.0f : (v) > 1.0f ? 1.0f : (v); if (!((v) == (v))) c_ = 0.0f; uint32_t i_ = (uint32_t)(c_ * P.index_scale) & 0xffffu; i_ < P.index_max ? i_ : P.index_max; })
-  r = P.gam_lut[IDX(nr)]; g = P.gam_lut[IDX(ng)]; b = P.gam_lut[IDX(nb)];
-  #undef IDX
-}
 // the first pixel of the row whose linear luma is exactly 0 — the reference's tone-mapping loop never advances past it, so the pixels
 // from there on stay un-mapped (colorspaces/Rec2408ToneMapper.cpp:80-100).  All work-items of the workgroup (one row) call it.
 template <bool kU16>

@@ -289,3 +289,70 @@ def test_reference_cmm_and_system_cmm_agree_on_a8():
     assert outs["ref"][0] == 2160 and outs["sys"][0] != 2160
     d8 = np.abs(outs["ref"][1].astype(int) - outs["sys"][1].astype(int)); d16 = np.abs(outs["ref"][2].astype(int) - outs["sys"][2].astype(int))
     assert d8.max() <= 1 and d16.max() <= 2, (d8.max(), d16.max())
+
+
+@pytest.mark.gpu
+def test_writer_post_equals_decode_then_fused_post_stage():
+    """jxlamd_decoder_set_writer_post (A10 + A11 WITH the decode): the Bitmap bytes equal jxlamd_decode followed by jxlamd_post_fused, bit for
+    bit — for frames whose last filter stage emits them itself (three EPF iterations: the PQ 16-bit fixture, and a 16-bit PQ frame with black bars, whose
+    zero-luma pixels stop the reference's tone mapper for the rest of their rows: the second pass of the fused writer), for column-sweep, alpha and Modular
+    frames (one pass behind the writer), single decodes and a mixed batch."""
+    import torch
+    import jxl_coder_amd as J
+    from conftest import load_case
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    files = {name: load_case(name)[0] for name in ("v160x120_16bit_pq2100_epf3", "v264x520_e7", "va300x520_e7", "l512_e7", "va530x270_16bit_e7")}
+    try:
+        import jxl_ref, synth
+        if jxl_ref.available():
+            img = synth.photo_like(520, 300, seed=5, bits=16)
+            img[:40] = 0; img[120:180, 100:400] = 0; img[:, 500:] = 0                      # letterbox bars and a black rectangle: rows with pixels of zero luma
+            files["live_pq16_epf3_black_bars"] = jxl_ref.encode(img, effort=7, distance=1.0, epf=3, primaries=9, transfer=16, intensity_target=4000.0)
+    except Exception:
+        pass
+    dec = J.JxlDecoder(0)
+    plain = J.JxlDecoder(0)
+    combos = ((29, J.PreferredColorConfig.RGBA_F16), (29, J.PreferredColorConfig.RGBA_8888), (33, J.PreferredColorConfig.RGBA_1010102), (29, J.PreferredColorConfig.RGB_565),
+              (34, J.PreferredColorConfig.DEFAULT))
+    def expected(data, cfg, api):
+        raw, info = plain.decode_one_shot(data, allowed_floats=True)
+        h, w = raw.shape[:2]; is16 = raw.dtype == np.uint16
+        src = torch.from_numpy(raw.view(np.uint8).reshape(-1).copy()).cuda()
+        tf = info["transfer_function"]
+        matrix = bool(info["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and info["color_space"] == 0 and api < 34)
+        ri = plain.reformat_query(w, h, is16, cfg, info["has_alpha_in_origin"], api)
+        dst = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+        plain.post_fused_device(src.data_ptr(), w, h, is16, 16 if is16 else 8, matrix, info["primaries"], tf, info["intensity_target"], cfg,
+                                bool(info["alpha_premultiplied"]), bool(info["has_alpha_in_origin"]), api, dst.data_ptr(), dst.numel())
+        torch.cuda.synchronize()
+        return dst.cpu().numpy(), raw
+    zero_rows_seen = False
+    for name, data in files.items():
+        for api, cfg in combos:
+            want, raw = expected(data, cfg, api)
+            if "black" in name:
+                zero_rows_seen = zero_rows_seen or bool(((raw[..., :3] == 0).all(axis=2)).any())
+            dec.set_writer_post(True, cfg, api)
+            out = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+            dec.decode_to_device(data, out.data_ptr(), out.numel(), allowed_floats=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), (name, api, int(cfg))
+    if "live_pq16_epf3_black_bars" in files:
+        assert zero_rows_seen                                                               # the stuck-row behaviour was exercised
+    # a batch: frames that emit the Bitmap from their last stage next to frames that take the pass behind the writer
+    api, cfg = 29, J.PreferredColorConfig.RGBA_F16
+    names = ["v160x120_16bit_pq2100_epf3", "v160x120_16bit_pq2100_epf3", "v160x120_16bit_pq2100_epf3"]
+    wants = [expected(files[n], cfg, api)[0] for n in names]
+    dec.set_writer_post(True, cfg, api)
+    outs = [torch.zeros(wv.size, dtype=torch.uint8, device="cuda") for wv in wants]
+    dec.decode_batch_to_device([files[n] for n in names], [o.data_ptr() for o in outs], [o.numel() for o in outs])
+    torch.cuda.synchronize()
+    for o, wv, n in zip(outs, wants, names):
+        assert np.array_equal(o.cpu().numpy(), wv), n
+    # and back: RGBA output again
+    dec.set_writer_post(False)
+    raw2, _ = dec.decode_one_shot(files["v264x520_e7"])
+    assert np.array_equal(raw2, plain.decode_one_shot(files["v264x520_e7"])[0])
+    with pytest.raises(ValueError):
+        dec.set_writer_post(True, 9, 29)
+    dec.close(); plain.close()
