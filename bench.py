@@ -223,6 +223,8 @@ def main():
                     "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused).  "
                     "c4: configs[3], ONE 32768x32768 VarDCT q90 frame (JXLAMD_C4_SIZE) as bands of group rows over the ranks (8 bands on one GPU), "
                     "halo rows by RCCL send/recv; a step = one decode of the frame (strong scaling)")
+    ap.add_argument("--c5-post", choices=["writer", "pass"], default="writer", help="--workload c5: A10 + A11 inside the decoder's writer (jxlamd_decoder_set_writer_post: the last "
+                    "EPF stage emits RGBA_F16, the RGBA16 image is never stored) or as one fused pass over the stored RGBA16 (jxlamd_post_fused, rounds 2-3)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
     args = ap.parse_args()
     c5 = args.workload == "c5"
@@ -289,8 +291,13 @@ def main():
         if c % SHARE:
             decs[c].share_pools(decs[c - c % SHARE])
     d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(f"cuda:{local}") for d in datas]   # compressed bytes resident in HBM
+    c5_writer = c5 and args.c5_post == "writer"
+    if c5_writer:                   # the decoder's writer emits the Bitmap format (RGBA_F16, API level 33: colour matrix + tone map apply): the decode's output IS the F16 buffer
+        for dctx in decs:
+            dctx.set_writer_post(True, J.PreferredColorConfig.RGBA_F16, 33)
+        out_bytes = w * h * 8
     d_outs = [[torch.empty(out_bytes, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
-    d_f16 = [[torch.empty(w * h * 8, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)] if c5 else None   # the Bitmap buffers (RGBA_F16)
+    d_f16 = [[torch.empty(w * h * 8, dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)] if (c5 and not c5_writer) else None   # the Bitmap buffers (RGBA_F16) of the separate post pass
     info0 = J.api.Info()
     J.api.lib().jxlamd_basic_info(data, len(data), J.api.C.byref(info0))
     import threading
@@ -341,7 +348,7 @@ def main():
                         with lock:
                             acc["retried_flights"] = acc.get("retried_flights", 0) + 1
                 t = decs[c].last_timing()
-                if c5:          # A10 (Rec.2100 PQ -> Rec.2408 tone map -> sRGB) + A11 (u16 -> RGBA_F16) of every frame of the flight, one fused pass each
+                if c5 and not c5_writer:          # A10 (Rec.2100 PQ -> Rec.2408 tone map -> sRGB) + A11 (u16 -> RGBA_F16) of every frame of the flight, one fused pass each
                     for j in range(p):
                         decs[c].post_fused_device(d_outs[c][j].data_ptr(), w, h, True, 16, True, info0.primaries, info0.transfer_function, info0.intensity_target,
                                                   J.PreferredColorConfig.RGBA_F16, False, False, 33, d_f16[c][j].data_ptr(), d_f16[c][j].numel())
@@ -366,7 +373,7 @@ def main():
     lat = []
     for _ in range(3):
         t = time.perf_counter(); decs[0].decode_to_device(data, d_outs[0][0].data_ptr(), out_bytes, data_dev_ptr=d_ins[0].data_ptr())
-        if c5:
+        if c5 and not c5_writer:
             decs[0].post_fused_device(d_outs[0][0].data_ptr(), w, h, True, 16, True, info0.primaries, info0.transfer_function, info0.intensity_target,
                                       J.PreferredColorConfig.RGBA_F16, False, False, 33, d_f16[0][0].data_ptr(), d_f16[0][0].numel())
         lat.append(time.perf_counter() - t)
@@ -446,7 +453,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"configs[4] on one GPU: one step = a batch of {B} x 3840x2160 Rec.2100 PQ 16-bit VarDCT (distance 1.0, effort 7, EPF forced to 3 iterations) "
-                                    "frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (A10 + A11 fused into one pass per frame) " if c5 else
+                                    + ("frames -> colour matrix + Rec.2408 tone map -> RGBA_F16 INSIDE the decoder's writer (the last EPF stage emits the Bitmap format; the RGBA16 image is never stored) " if c5_writer else
+                                       "frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (A10 + A11 fused into one pass per frame) ") if c5 else
                                     f"configs[2]: one step = a batch of {B} x 3840x2160 VarDCT q90 (distance 1.0, effort 7) RGB frames -> RGBA8 per GPU ") +
                                    f"({len(datas)} distinct seeded frames" + (" generated on this box by the reference's encoder" if len(datas) > len(FRAMES) else " cycled") +
                                    "), every frame a complete decode (host parse, table upload, all kernels); value: compressed bytes resident in HBM when the "

@@ -39,11 +39,9 @@ __device__ __forceinline__ void post_convert_store(uint8_t *drow, uint32_t x, ui
 }
 template <int KIND> constexpr bool post_src16() { return KIND == kPostU16ToF16 || KIND == kPostRgba16To8 || KIND == kPostRgba16To565 || KIND == kPostRgba16To1010102 || KIND == kPostCopy16; }
 // A10, one pixel: LUT -> (tone map unless the row is stuck) -> matrix -> LUT.  FMA contraction off: the reference's operation order.
-template <bool kU16>
-__device__ __forceinline__ void post_matrix_px(const ColorMatrixDev &P, bool tone, uint32_t &r, uint32_t &g, uint32_t &b) {
+// ... from the linearised values on (the writer's pass has looked them up already for its zero-luma test)
+__device__ __forceinline__ void post_matrix_lin(const ColorMatrixDev &P, bool tone, float fr, float fg, float fb, uint32_t &r, uint32_t &g, uint32_t &b) {
 #pragma clang fp contract(off)
-  const uint32_t cap = kU16 ? P.index_max : 255u;
-  float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
   if (tone) {
     const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
     const float scale = (1.0f + P.weight_a * y) / (1.0f + P.weight_b * y);
@@ -56,7 +54,12 @@ __device__ __forceinline__ void post_matrix_px(const ColorMatrixDev &P, bool ton
   r = P.gam_lut[IDX(nr)]; g = P.gam_lut[IDX(ng)]; b = P.gam_lut[IDX(nb)];
   #undef IDX
 }
-
+template <bool kU16>
+__device__ __forceinline__ void post_matrix_px(const ColorMatrixDev &P, bool tone, uint32_t &r, uint32_t &g, uint32_t &b) {
+  const uint32_t cap = kU16 ? P.index_max : 255u;
+  const float fr = P.lin_lut[r < cap ? r : cap], fg = P.lin_lut[g < cap ? g : cap], fb = P.lin_lut[b < cap ? b : cap];
+  post_matrix_lin(P, tone, fr, fg, fb, r, g, b);
+}
 // A10 + A11 of ONE pixel whose RGBA codes (8- or 16-bit, as the writer would have stored them) are r, g, b, a: output position (ox, oy) of the Bitmap.
 // MODE 1: the writer's pass — tone-mapped as if the row held no pixel of zero linear luma; such a pixel records its column in row_fz (the reference's tone
 // mapper never advances past the first one: the rest of the row stays un-mapped, Rec2408ToneMapper.cpp:91-93).  MODE 2: the pass after it — pixels at
@@ -68,13 +71,16 @@ __device__ __forceinline__ void post_emit(const DevPost &Q, uint32_t r, uint32_t
   if (MODE == 2) {
     if (!tone || (uint32_t)ox < Q.row_fz[1 + oy]) return;
     tone = false;
-  } else if (tone) {
+  }
+  if (Q.matrix) {
     const uint32_t cap = src16 ? Q.P.index_max : 255u;
     const float fr = Q.P.lin_lut[r < cap ? r : cap], fg = Q.P.lin_lut[g < cap ? g : cap], fb = Q.P.lin_lut[b < cap ? b : cap];
-    const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
-    if (y == 0.0f) { atomicMin(&Q.row_fz[1 + oy], (uint32_t)ox); Q.row_fz[0] = 1u; }      // word 0: some row of the frame has one (the second pass has work)
+    if (MODE == 1 && tone) {
+      const float y = 0.2627f * fr + 0.6780f * fg + 0.0593f * fb;
+      if (y == 0.0f) { atomicMin(&Q.row_fz[1 + oy], (uint32_t)ox); Q.row_fz[0] = 1u; }      // word 0: some row of the frame has one (the second pass has work)
+    }
+    post_matrix_lin(Q.P, tone, fr, fg, fb, r, g, b);
   }
-  if (Q.matrix) { if (src16) post_matrix_px<true>(Q.P, tone, r, g, b); else post_matrix_px<false>(Q.P, tone, r, g, b); }
   if (Q.premul) {
     const uint32_t maxv = (1u << Q.depth) - 1u;
     if (src16) { r = (uint16_t)((r * a) / maxv); g = (uint16_t)((g * a) / maxv); b = (uint16_t)((b * a) / maxv); }

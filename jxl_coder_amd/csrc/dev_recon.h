@@ -426,6 +426,24 @@ JXL_DEV float tf_709(float v) {
 }
 
 // the writer's last step: three colour values in [0, 1] of frame pixel (x, y) -> canvas position, orientation, alpha, dither, RGBA8 / RGBA16
+// output position of frame pixel (x, y): canvas offset, then the image's orientation; false when it falls outside the canvas
+JXL_DEV bool out_position(const DevFrame &F, int x, int y, int &ox, int &oy) {
+  x += F.crop_x0; y += F.crop_y0;
+  const int w = F.canvas_w, h = F.canvas_h;
+  if ((unsigned)x >= (unsigned)w || (unsigned)y >= (unsigned)h) return false;
+  ox = x; oy = y;
+  switch (F.orientation) {
+    case 2: ox = w - 1 - x; break;
+    case 3: ox = w - 1 - x; oy = h - 1 - y; break;
+    case 4: oy = h - 1 - y; break;
+    case 5: ox = y; oy = x; break;
+    case 6: ox = h - 1 - y; oy = x; break;
+    case 7: ox = h - 1 - y; oy = w - 1 - x; break;
+    case 8: ox = y; oy = w - 1 - x; break;
+    default: break;
+  }
+  return true;
+}
 // ... as integer codes: px[4] (8- or 16-bit) and the output position; false when the pixel falls outside the canvas
 JXL_DEV bool rgba_codes(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, const float (&v)[3], int out_bits, int x, int y, uint32_t (&px)[4], int &ox, int &oy) {
   const DevFrame &F = frame_of(B);

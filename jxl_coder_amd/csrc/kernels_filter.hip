@@ -48,6 +48,10 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
   const int y_begin = F.band_py0 - halo > 0 ? F.band_py0 - halo : 0, y_end = F.band_py1 + halo < F.height ? F.band_py1 + halo : F.height;
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = y_begin + (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   if (x >= F.width || y >= y_end) return;
+  if (POST == 2) {                                            // only the pixels at or behind their row's first zero-luma pixel are computed again
+    int ox, oy;
+    if (!out_position(F, x, y, ox, oy) || (uint32_t)ox < B.post->row_fz[1 + oy]) return;
+  }
   const bool a = stage_src_is_a(F, STAGE);
   float *src[3], *dst[3];
   for (int c = 0; c < 3; c++) { src[c] = a ? B.plane_a[c] : B.plane_b[c]; dst[c] = a ? B.plane_b[c] : B.plane_a[c]; }

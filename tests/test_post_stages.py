@@ -322,6 +322,7 @@ def test_writer_post_equals_decode_then_fused_post_stage():
         matrix = bool(info["prefer_encoding"] and tf in (16, 18, 17, 1, 65535, 13) and info["color_space"] == 0 and api < 34)
         ri = plain.reformat_query(w, h, is16, cfg, info["has_alpha_in_origin"], api)
         dst = torch.zeros(int(ri.bytes), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         plain.post_fused_device(src.data_ptr(), w, h, is16, 16 if is16 else 8, matrix, info["primaries"], tf, info["intensity_target"], cfg,
                                 bool(info["alpha_premultiplied"]), bool(info["has_alpha_in_origin"]), api, dst.data_ptr(), dst.numel())
         torch.cuda.synchronize()
@@ -334,6 +335,7 @@ def test_writer_post_equals_decode_then_fused_post_stage():
                 zero_rows_seen = zero_rows_seen or bool(((raw[..., :3] == 0).all(axis=2)).any())
             dec.set_writer_post(True, cfg, api)
             out = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()                                                        # (the decoder writes on its own stream: torch's fill must be done)
             dec.decode_to_device(data, out.data_ptr(), out.numel(), allowed_floats=True)
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), want), (name, api, int(cfg))
@@ -345,6 +347,7 @@ def test_writer_post_equals_decode_then_fused_post_stage():
     wants = [expected(files[n], cfg, api)[0] for n in names]
     dec.set_writer_post(True, cfg, api)
     outs = [torch.zeros(wv.size, dtype=torch.uint8, device="cuda") for wv in wants]
+    torch.cuda.synchronize()
     dec.decode_batch_to_device([files[n] for n in names], [o.data_ptr() for o in outs], [o.numel() for o in outs])
     torch.cuda.synchronize()
     for o, wv, n in zip(outs, wants, names):
