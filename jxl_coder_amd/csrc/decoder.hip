@@ -251,16 +251,26 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     if (ri.stride != line) HIPCHECK(hipMemsetAsync(S.post_final, 0, ri.bytes, stream));
     if (S.post_fused) {
       HIPCHECK(S.post_fz.ensure((size_t)(1 + S.pi.ysize) * 4));
-      HIPCHECK(hipMemsetAsync(S.post_fz.p, 0xFF, (size_t)(1 + S.pi.ysize) * 4, stream));
-      HIPCHECK(hipMemsetAsync(S.post_fz.p, 0, 4, stream));
+      if (!in_flight) {
+        HIPCHECK(hipMemsetAsync(S.post_fz.p, 0xFF, (size_t)(1 + S.pi.ysize) * 4, stream));
+        HIPCHECK(hipMemsetAsync(S.post_fz.p, 0, 4, stream));
+      }                                                   // (frames of a flight: k_clear_b initialises it, and the DevPost block travels inside the frame's tables — no extra dispatch per frame: every one of them waits its turn among the kernels of the other contexts)
       DevPost Q; memset(&Q, 0, sizeof(Q));
       if (S.post_runs) Q.P = post_dev;
       Q.matrix = S.post_runs ? 1 : 0; Q.premul = S.post_premul ? 1 : 0; Q.kind = S.post_kind; Q.depth = (int32_t)S.post_depth; Q.attenuate = S.post_att ? 1 : 0;
       Q.dst_stride = ri.stride; Q.dst = (uint8_t *)S.post_final; Q.row_fz = (uint32_t *)S.post_fz.p;
-      HIPCHECK(S.post_dev.ensure(sizeof(DevPost)));
-      HIPCHECK(S.h_post.ensure(sizeof(DevPost)));
-      memcpy(S.h_post.p, &Q, sizeof(Q));
-      HIPCHECK(hipMemcpyAsync(S.post_dev.p, S.h_post.p, sizeof(DevPost), hipMemcpyHostToDevice, stream));
+      Q.rows = (int32_t)S.pi.ysize;
+      if (in_flight) {
+        plan.tables.resize((plan.tables.size() + 15) & ~(size_t)15);
+        S.post_off = plan.tables.size();
+        plan.tables.insert(plan.tables.end(), (const uint8_t *)&Q, (const uint8_t *)&Q + sizeof(Q));
+        Fh = (DevFrame *)plan.tables.data();              // (the vector may have moved)
+      } else {
+        HIPCHECK(S.post_dev.ensure(sizeof(DevPost)));
+        HIPCHECK(S.h_post.ensure(sizeof(DevPost)));
+        memcpy(S.h_post.p, &Q, sizeof(Q));
+        HIPCHECK(hipMemcpyAsync(S.post_dev.p, S.h_post.p, sizeof(DevPost), hipMemcpyHostToDevice, stream));
+      }
       S.d_out = S.post_final;                             // (the RGBA writer is not used: B.out only has to be a valid address)
     } else {
       HIPCHECK(S.post_tmp.ensure(S.out_bytes));
@@ -306,7 +316,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     B.ref_a[k] = (have && ref_alpha[k]) ? (float *)ref_store[k].p + 3 * n : nullptr;      // a blended canvas kept with its alpha plane
   }
   for (int c = 0; c < 4; c++) B.canvas_save[c] = nullptr;
-  B.post = (S.post_active && S.post_fused) ? (const DevPost *)S.post_dev.p : nullptr;
+  B.post = (S.post_active && S.post_fused && !in_flight) ? (const DevPost *)S.post_dev.p : nullptr;      // in a flight: inside the flight's tables (decode_batch)
   if (Fh->blend && Fh->bl_src >= 0 && !B.ref[Fh->bl_src][0]) { set_error("blending: the source canvas is missing"); return JXLAMD_ERR_INVALID; }
   if (Fh->num_patches > 0) {
     const DevPatch *P = (const DevPatch *)(plan.tables.data() + Fh->patch_off);
@@ -371,7 +381,7 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   if (F->compose) stage_mask = (stage_mask & 15) | 32;           // stage by stage into the planes; patches, reference copy and writer follow (launch_compose_tail)
-  if (S.post_active && S.post_fused) stage_mask |= 64;           // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
+  if (S.post_active && S.post_fused) stage_mask |= 64 | 128;     // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>); 128: no other frame in this launch
   launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
   return JXLAMD_OK;
 }
@@ -664,6 +674,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const int nb = (int)batched.size();
   size_t max_npx = 0, max_coef = 0;
   int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 0;
+  bool all_post = true;
   for (int i : batched) {
     const FrameSlot &S = slot((size_t)i);
     const DevFrame *F = (const DevFrame *)S.plan.tables.data();
@@ -677,7 +688,9 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (F->epf_iters >= 2) stage_mask |= 8;
   if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
     if (S.post_active && S.post_fused) stage_mask |= 64;      // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
+    else all_post = false;
   }
+  if (all_post && (stage_mask & 64)) stage_mask |= 128;       // every frame of the flight: the plain instantiation of the last stage is not launched
   // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
   // contexts sharing it overlap one's LF stage with the other's HF phase
   const int used_sets = std::min(hf_sets, nb);
@@ -711,6 +724,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
       const FramePlan &P = S.plan;
       memcpy((uint8_t *)h_flight_tables.p + to, P.tables.data(), P.tables.size());
       S.B.tables = (const uint8_t *)flight_tables.p + to;
+      if (S.post_active && S.post_fused) S.B.post = (const DevPost *)(S.B.tables + S.post_off);
       S.B.codestream = (const uint8_t *)flight_cs.p + co;
       if (S.up_cs_dev) { gdesc.push_back({S.up_cs_dev, (uint8_t *)flight_cs.p + co, (uint32_t)P.cs_size, 64u}); gather_max = std::max(gather_max, (uint32_t)P.cs_size); }
       else {

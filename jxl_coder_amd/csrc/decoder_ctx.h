@@ -105,7 +105,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   // A10 + A11 behind / inside the writer (jxlamd_decoder_set_writer_post): `out` receives the Bitmap format.  fused: the frame's last filter stage emits it
   // (DevBuffers::post); otherwise the writer fills post_tmp (RGBA8 / RGBA16) and one k_post_fused pass over it follows the frame's kernels
   bool post_active = false, post_fused = false, post_runs = false, post_premul = false, post_att = false;
-  int post_kind = 0; uint32_t post_depth = 8, post_stride = 0; size_t post_bytes = 0; uint64_t post_gen = 0;      // post_gen: which upload of the context's tone-map LUTs the frame was prepared against
+  int post_kind = 0; uint32_t post_depth = 8, post_stride = 0; size_t post_bytes = 0; uint64_t post_gen = 0; size_t post_off = 0;      // post_off: where the frame's DevPost sits inside its tables (flights); post_gen: which upload of the context's tone-map LUTs the frame was prepared against
   void *post_final = nullptr;
   DevMem post_dev, post_fz, post_tmp; PinnedMem h_post;
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them

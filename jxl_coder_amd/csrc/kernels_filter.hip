@@ -46,16 +46,19 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
   if (STAGE == 4 && last >= 0) return;                       // the writer was fused into stage `last`
   const int halo = stage_halo_after(F, STAGE);
   const int y_begin = F.band_py0 - halo > 0 ? F.band_py0 - halo : 0, y_end = F.band_py1 + halo < F.height ? F.band_py1 + halo : F.height;
-  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = y_begin + (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (x >= F.width || y >= y_end) return;
+  const int y = y_begin + (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (y >= y_end) return;
+  // POST == 2 is launched one workgroup wide and walks its rows (a frame with a zero-luma pixel somewhere has them in few rows); the others cover the width
+  if (POST == 2 && F.orientation == 1 && B.post->row_fz[1 + y + F.crop_y0] == 0xFFFFFFFFu) return;
+  for (int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)); x < F.width; x += (int)gridDim.x * 64) {
   if (POST == 2) {                                            // only the pixels at or behind their row's first zero-luma pixel are computed again
     int ox, oy;
-    if (!out_position(F, x, y, ox, oy) || (uint32_t)ox < B.post->row_fz[1 + oy]) return;
+    if (!out_position(F, x, y, ox, oy) || (uint32_t)ox < B.post->row_fz[1 + oy]) continue;
   }
   const bool a = stage_src_is_a(F, STAGE);
   float *src[3], *dst[3];
   for (int c = 0; c < 3; c++) { src[c] = a ? B.plane_a[c] : B.plane_b[c]; dst[c] = a ? B.plane_b[c] : B.plane_a[c]; }
-  if (STAGE == 4) { xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y); return; }
+  if (STAGE == 4) { xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, B.out_bits, x, y); continue; }
   float v[3];
   if (STAGE == 0) gab_value(F, src, x, y, v);
   else epf_value_p<(STAGE >= 1 && STAGE <= 3 ? STAGE - 1 : 0)>(B, F, src, x, y, v);
@@ -73,6 +76,7 @@ __global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const ui
     xyb_write_value(B, stat, *(const DevStatic *)stat, v[0], v[1], v[2], B.out_bits, x, y);
   }
   else for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
+  }
 }
 
 // ---- Column sweep: Gaborish + EPF iteration 1 (+ iteration 2) + writer in ONE pass over the reconstructed planes, all in registers.
@@ -232,10 +236,10 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   if (stage_mask & 1) hipLaunchKernelGGL(k_filter_b<0>, grid, dim3(256), 0, s, Bs, stat, sweep);
   if (stage_mask & 2) hipLaunchKernelGGL(k_filter_b<1>, grid, dim3(256), 0, s, Bs, stat, sweep);
   if (stage_mask & 4) hipLaunchKernelGGL(k_filter_b<2>, grid, dim3(256), 0, s, Bs, stat, sweep);
-  if (stage_mask & 8) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat, sweep);
+  if ((stage_mask & 8) && !(stage_mask & 128)) hipLaunchKernelGGL(k_filter_b<3>, grid, dim3(256), 0, s, Bs, stat, sweep);      // 128: every frame of the launch goes through the post instantiations
   if ((stage_mask & 8) && post) {
     hipLaunchKernelGGL((k_filter_b<3, 1>), grid, dim3(256), 0, s, Bs, stat, sweep);
-    hipLaunchKernelGGL((k_filter_b<3, 2>), grid, dim3(256), 0, s, Bs, stat, sweep);
+    hipLaunchKernelGGL((k_filter_b<3, 2>), dim3(1, grid.y, grid.z), dim3(256), 0, s, Bs, stat, sweep);
   }
   if (stage_mask & 16) hipLaunchKernelGGL(k_filter_b<4>, grid, dim3(256), 0, s, Bs, stat, sweep);
 }

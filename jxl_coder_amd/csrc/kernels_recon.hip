@@ -2,6 +2,7 @@
 // per-flight clears.
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
 #include "kernels_common.h"
+#include "post.h"
 
 namespace jxlamd {
 
@@ -495,6 +496,10 @@ __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
     uint32_t *m = B.err;                                   // misc block: 4096 bytes of flags + 72 bytes per LF group
     const int words = (4096 + F.num_lf_groups * 72) / 4;
     for (int i = (int)threadIdx.x; i < words; i += 256) m[i] = 0;
+    if (B.post) {                                          // the writer hands this frame's pixels to the post stages: "no zero-luma pixel seen" (dev_post.h: post_emit)
+      uint32_t *fz = B.post->row_fz;
+      for (int i = (int)threadIdx.x; i <= B.post->rows; i += 256) fz[i] = i ? 0xFFFFFFFFu : 0u;
+    }
     return;
   }
   const int ncell = F.xb * (F.band_scy1 - F.band_scy0);        // the rows backed by storage (whole frame unless this is a band decode)

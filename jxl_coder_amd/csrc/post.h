@@ -27,7 +27,7 @@ void launch_post_color_matrix(void *px, uint32_t stride, uint32_t w, uint32_t h,
 struct DevPost {
   ColorMatrixDev P;
   int32_t matrix, premul, kind, depth, attenuate;     // kind: PostKind
-  uint32_t dst_stride;
+  uint32_t dst_stride; int32_t rows;                  // rows: output rows (size of row_fz - 1)
   uint8_t *dst;                                       // the Bitmap (rows of dst_stride bytes)
   uint32_t *row_fz;                                   // [1 + output rows]: word 0 = some row has a pixel of zero linear luma; word 1 + y = the first such pixel of row y (0xFFFFFFFF: none) — see k_filter_b<3, 2>
 };
