@@ -133,15 +133,20 @@ def build_compat(verbose=False):
     (host-only glue, plain g++)."""
     src = os.path.join(_HERE, "csrc", "libjxl_abi.cpp")
     os.makedirs(compat_dir(), exist_ok=True)
-    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(os.path.dirname(_HERE), "include", "jxl_amd_libjxl.h")), os.path.getmtime(_LIB_PATH))
+    # (libjxlamd.so is linked dynamically: the compat libraries only follow their own source and the two headers — a fresh copy of the tree, whose file times
+    # are in no particular order, must not relink them under the feet of a process that is loading them)
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(os.path.dirname(_HERE), "include", "jxl_amd_libjxl.h")),
+                 os.path.getmtime(os.path.join(os.path.dirname(_HERE), "include", "jxl_amd.h")))
     for name, macro, extra in (("libjxl.so", "-DJXLC_ONLY_DECODER", [_LIB_PATH, "-Wl,-rpath,$ORIGIN/.."]), ("libjxl_threads.so", "-DJXLC_ONLY_THREADS", [])):
         out = os.path.join(compat_dir(), name)
         if os.path.exists(out) and os.path.getmtime(out) >= newest:
             continue
-        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", macro, "-Wl,-soname," + name, "-o", out, src] + extra
+        tmp = out + ".%d.tmp" % os.getpid()
+        cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", macro, "-Wl,-soname," + name, "-o", tmp, src] + extra
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        os.replace(tmp, out)                      # atomic: another process may be loading the library right now
     return compat_dir()
 
 

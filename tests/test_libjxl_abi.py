@@ -196,6 +196,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_libjxl_abi as T
 from jxl_coder_amd import api
 api.lib()
+for so in ("libjxl_threads.so", "libjxl.so"):           # by path, before the driver asks for them by soname
+    C.CDLL(os.path.join(api.compat_dir(), so), mode=C.RTLD_GLOBAL)
 L = C.CDLL(T.ANIM_SO)
 maps = open("/proc/self/maps").read()
 assert "jxl_coder_amd/compat/libjxl.so" in maps and "oracle/_ref" not in maps, "the animated decoder must be bound to the compat library, not to the reference's libjxl"
@@ -265,6 +267,8 @@ def driver_handle():
     """(child process) the compiled reference driver, bound to compat/libjxl.so"""
     from jxl_coder_amd import api
     api.lib()
+    for so in ("libjxl_threads.so", "libjxl.so"):       # by path, before the driver asks for them by soname
+        C.CDLL(os.path.join(api.compat_dir(), so), mode=C.RTLD_GLOBAL)
     L = C.CDLL(DRIVER_SO)
     L.boundary_basic_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64 * 2)]
     L.boundary_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64 * 12), C.POINTER(C.c_double * 8), C.c_char_p, C.c_size_t]
