@@ -315,6 +315,11 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int c = 0; c < 3; c++) B.ref[k][c] = have ? (float *)ref_store[k].p + (size_t)c * n : nullptr;
     B.ref_a[k] = (have && ref_alpha[k]) ? (float *)ref_store[k].p + 3 * n : nullptr;      // a blended canvas kept with its alpha plane
   }
+  for (int c = 0; c < 3; c++) B.lf_frame[c] = nullptr;
+  if (Fh->use_lf_frame) {
+    if (!ref_store[4].p || ref_w[4] != Fh->lf_frame_w || ref_h[4] != Fh->lf_frame_h) { set_error("LF frame missing"); return JXLAMD_ERR_INVALID; }
+    for (int c = 0; c < 3; c++) B.lf_frame[c] = (const float *)ref_store[4].p + (size_t)c * (size_t)ref_w[4] * (size_t)ref_h[4];
+  }
   for (int c = 0; c < 4; c++) B.canvas_save[c] = nullptr;
   B.post = (S.post_active && S.post_fused && !in_flight) ? (const DevPost *)S.post_dev.p : nullptr;      // in a flight: inside the flight's tables (decode_batch)
   if (Fh->blend && Fh->bl_src >= 0 && !B.ref[Fh->bl_src][0]) { set_error("blending: the source canvas is missing"); return JXLAMD_ERR_INVALID; }

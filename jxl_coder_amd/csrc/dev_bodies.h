@@ -27,10 +27,13 @@ JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &
 #endif
   if (tid == 0) lf_phase_open(B, S, g);
   sync();
-  modular_stream_stage(S, tid, nthreads);
-  sync();
-  JXL_STAMP(1);
-  uint32_t e = lf_phase_coeffs<kWave, kGeneral>(B, S, g, tid);          // whole wave on the GPU (kWave), or this lane alone
+  uint32_t e = 0;
+  if (!frame_of(B).use_lf_frame) {                          // (uniform) progressive_dc frames have no LF-coefficient stream
+    modular_stream_stage(S, tid, nthreads);
+    sync();
+    JXL_STAMP(1);
+    e = lf_phase_coeffs<kWave, kGeneral>(B, S, g, tid);     // whole wave on the GPU (kWave), or this lane alone
+  }
   JXL_STAMP(2);
   {
     const DevFrame &Fm = frame_of(B);

@@ -42,6 +42,7 @@ struct DevBuffers {
   uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [DevFrame::lz_win_len] + [num_groups][DevFrame::lz_win_group] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
   float *up[4];                 // upsampled frames: dense full_w x full_h f32 planes between the upsampling stage and the writer ([3]: an upsampled alpha channel)
+  const float *lf_frame[3];     // DevFrame::use_lf_frame: the LF frame's X, Y, B planes (dense lf_frame_w x lf_frame_h)
   const DevPost *post;          // non-null: the frame's last filter stage hands its pixels to the post stages instead of storing RGBA (kernels_filter.hip: k_filter_b<3, 1>)
   float *ref_a[4];              // ... and, for a slot that holds a blended canvas (frames of an animation), its alpha plane (null: the image has none)
   float *canvas_save[4];        // where blend_canvas_pixel keeps the blended canvas (R, G, B, A planes of canvas_w x canvas_h; null: not kept)
@@ -79,6 +80,7 @@ JXL_DEV void lf_phase_open(const DevBuffers &B, DevModScratch &S, int g) {
     bits_init_at_bit(b, B.codestream, sec.off, F.has_ec ? *B.mod_end_bit : (uint64_t)F.single_lf_bit, F.cs_size);
   } else bits_init(b, B.codestream, sec.off, F.cs_size);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
+  if (F.use_lf_frame) { scr[kLfScratchInts - 1] = 0; S.st.b = b; S.lz.win = nullptr; return; }      // no LF coefficients in the section: the LF image is an LF frame's pixels
   scr[kLfScratchInts - 1] = (int32_t)bits_read(b, 2);      // extra_precision
   S.st.b = b;
   S.lz.win = nullptr;                                       // LZ77 is confined to Modular-encoded frames (the host rejects it elsewhere)
@@ -262,6 +264,18 @@ JXL_DEV void lf_group_epilogue(const DevBuffers &B, int g, int lane, int nlanes)
   const float mul = 1.0f / (float)(1 << scr[kLfScratchInts - 1]);
   const float fx = F.lf_fac[0] * mul, fy = F.lf_fac[1] * mul, fb = F.lf_fac[2] * mul;
   const int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_sharp = m_b + 1024 + 2 * 65536;
+  if (F.use_lf_frame) {
+    // progressive_dc: one pixel of the LF frame per cell, already dequantised XYB; the block context sees LF bucket 0 (libjxl zero-fills quant_dc)
+    for (int i = lane; i < bw * bh; i += nlanes) {
+      const int y = i / bw, x = i - y * bw;
+      const size_t o = (size_t)(by0 + y) * (size_t)F.xb + (size_t)(bx0 + x);
+      const size_t so = (size_t)(by0 + y) * (size_t)F.lf_frame_w + (size_t)(bx0 + x);
+      for (int c = 0; c < 3; c++) B.lf[c][o] = B.lf_frame[c][so];
+      B.lf_idx[o] = 0;
+      const int sh = m_sharp[i];
+      B.sharp[o] = (uint8_t)(sh < 0 ? 0 : sh > 7 ? 7 : sh);
+    }
+  } else
   if (F.subsampled) {
     // every channel on its own grid in the top-left corner of its LF plane (stride xb), no chroma from luma on LF; the block-context bucket of a
     // full-resolution cell comes from the samples that cover it

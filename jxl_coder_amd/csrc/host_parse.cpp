@@ -96,7 +96,7 @@ struct Priv {                 // state between phase 1 and phase 2
   DevFrame F;
   std::vector<DevSection> secs;
   int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // reference slots as they are when this frame is decoded
-  bool blend = false, save_canvas = false, has_src = false; int alpha_ec = -1;      // composition over a canvas (plan_parse: the frame walk)
+  bool blend = false, save_canvas = false, has_src = false; int alpha_ec = -1, lf_w = 0, lf_h = 0;      // composition over a canvas (plan_parse: the frame walk)
   int64_t tree_bit = -1;        // where the global MA tree starts inside LfGlobal (-1: none): a RAW dequant matrix of HfGlobal may be coded with it
 };
 
@@ -501,7 +501,7 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
 }
 
 // One frame of the walk: its header, where its TOC starts and where the next frame header begins
-struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; bool blend = false; bool canvas_needed = false; int src_frame = -1; };
+struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; bool blend = false; bool canvas_needed = false; int src_frame = -1; bool lf_needed = false; };
 
 // TOC of the frame whose header ended at toc_bit: section table (logical order) and the byte where the frame's sections end
 static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t toc_bit, std::vector<DevSection> *secs, size_t *end_byte, std::string *error) {
@@ -666,6 +666,14 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     if (!recs[i].needed) continue;
     const frame_hdr &f = recs[i].f;
     if (f.flags & 2) for (int k = 0; k < 4; k++) if (occupant_at[i * 4 + (size_t)k] >= 0) recs[(size_t)occupant_at[i * 4 + (size_t)k]].needed = true;    // patches may name any slot
+    if (f.flags & 32) {
+      // kUseDcFrame (progressive_dc): the frame's LF image is the latest LF frame of level 1 before it (libjxl's dc_frames[0]) instead of LF coefficients
+      if (f.frame_type == 1) { plan->error = "unsupported: LF frame of level 2 and beyond"; return -1; }
+      int lf = -1;
+      for (size_t j = i; j-- > 0;) if (recs[j].f.frame_type == 1 && recs[j].f.lf_level == 1) { lf = (int)j; break; }
+      if (lf < 0) { plan->error = "frame refers to an LF frame the file does not have"; return -1; }
+      recs[(size_t)lf].needed = true; recs[(size_t)lf].lf_needed = true;
+    }
     if (uses_canvas(f)) {
       const int src = f.bl_source[0] & 3;
       if (alpha_ec >= 0 && (f.bl_source[1 + alpha_ec] & 3) != src && (f.bl_mode[1 + alpha_ec] != 0 || !full_frame(f))) { plan->error = "unsupported: colour and alpha blended over different reference slots"; return -1; }
@@ -682,7 +690,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     }
   }
   // ---- the needed earlier frames first, in file order (each its own FramePlan over the same codestream bytes), then the shown frame
-  int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0};
+  int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0}, lf_w = 0, lf_h = 0;
   const auto blend_checks = [&](const FrameRec &r) -> bool {
     const frame_hdr &f = r.f;
     if (!r.blend) return true;
@@ -701,9 +709,9 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     std::shared_ptr<Priv> spv = std::make_shared<Priv>();
     sub->priv = spv;
     spv->m = m; spv->f = f;
-    memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h));
-    if (f.frame_type != 0 && f.frame_type != 2 && f.frame_type != 3) { plan->error = "unsupported: reference to an LF frame"; return -1; }
-    if (!recs[i].canvas_needed) {
+    memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h)); spv->lf_w = lf_w; spv->lf_h = lf_h;
+    if (f.frame_type == 1 && (!recs[i].lf_needed || (f.flags & 32))) { plan->error = "unsupported: LF frame of level 2 and beyond"; return -1; }
+    if (!recs[i].canvas_needed && f.frame_type != 1) {
       // a frame kept for a patch dictionary: stored as it is, before the colour transform
       if (f.frame_type != 2 && (recs[i].blend || !full_frame(f))) { plan->error = "unsupported: blended / cropped regular frame used as a patch source"; return -1; }
       if (!f.save_before_ct && m.pub.xyb_encoded) { plan->error = "unsupported: reference frame saved after the colour transform"; return -1; }
@@ -711,13 +719,15 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     if (!blend_checks(recs[i])) return -1;
     spv->blend = recs[i].blend; spv->save_canvas = recs[i].canvas_needed; spv->has_src = recs[i].src_frame >= 0; spv->alpha_ec = alpha_ec;
     if (build_frame(sub.get(), spv.get(), recs[i], /*is_shown=*/false, raw_w, raw_h)) { plan->error = sub->error; return -1; }
-    sub->save_slot = f.save_as_ref & 3;
+    sub->save_slot = f.frame_type == 1 ? 4 : (f.save_as_ref & 3);          // slot 4: the LF image of the next frame that asks for one
     sub->save_canvas = recs[i].canvas_needed;
     plan->refs.push_back(sub);
+    if (f.frame_type == 1) { lf_w = f.coded_width; lf_h = f.coded_height; continue; }
     if (recs[i].canvas_needed) { slot_w[f.save_as_ref & 3] = (int)raw_w; slot_h[f.save_as_ref & 3] = (int)raw_h; }
     else { slot_w[f.save_as_ref & 3] = f.width; slot_h[f.save_as_ref & 3] = f.height; }
   }
   if (!blend_checks(recs[last])) return -1;
+  pv->lf_w = lf_w; pv->lf_h = lf_h;
   pv->blend = recs[last].blend; pv->save_canvas = false; pv->has_src = recs[last].src_frame >= 0; pv->alpha_ec = alpha_ec;
   pv->f = recs[last].f;
   memcpy(pv->ref_w, slot_w, sizeof(slot_w)); memcpy(pv->ref_h, slot_h, sizeof(slot_h));
@@ -767,7 +777,13 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   }
   if (!is_shown && (f.width < 1 || f.height < 1)) { plan->error = "empty frame"; return -1; }
   if (f.do_ycbcr && f.encoding == 1) { plan->error = "unsupported: YCbCr Modular frame"; return -1; }
-  if (f.flags & (1 | 16 | 32)) { plan->error = "unsupported: splines/noise/LF frame"; return -1; }
+  if (f.flags & (1 | 16)) { plan->error = "unsupported: splines / noise"; return -1; }
+  if (f.flags & 32) {
+    if (f.encoding != 0) { plan->error = "unsupported: Modular frame with an LF frame"; return -1; }
+    if (f.subsampled) { plan->error = "unsupported: chroma-subsampled frame with an LF frame"; return -1; }
+    if (pv->lf_w != (f.coded_width + 7) / 8 || pv->lf_h != (f.coded_height + 7) / 8) { plan->error = "LF frame does not match the frame it serves"; return -1; }
+  }
+  if (f.frame_type == 1 && (f.encoding != 1 || !m.pub.xyb_encoded || m.num_extra)) { plan->error = "unsupported: LF frame that is not a Modular XYB frame without extra channels"; return -1; }
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
   const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   { size_t end_byte = 0; if (read_toc(plan->cs, csn, f, rec.toc_bit, &secs, &end_byte, &plan->error)) return -1; }
@@ -866,7 +882,8 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   F.dm[0] = powf(1.0f / 1.25f, (float)f.x_qm - 2.0f); F.dm[1] = 1.0f; F.dm[2] = powf(1.0f / 1.25f, (float)f.b_qm - 2.0f);
   F.base_x = base_x; F.base_b = base_b; F.inv_color_factor = 1.0f / (float)color_factor;
   memcpy(F.quant_bias, m.quant_bias, sizeof(F.quant_bias));
-  F.skip_lf_smoothing = (f.flags & 128) ? 1 : 0;
+  F.skip_lf_smoothing = (f.flags & (128 | 32)) ? 1 : 0;      // (a frame that takes its LF image from an LF frame is not smoothed either)
+  F.use_lf_frame = (f.flags & 32) ? 1 : 0; F.lf_frame_w = pv->lf_w; F.lf_frame_h = pv->lf_h;
   F.modular_16bit = m.modular_16;
   F.gab = f.gab; memcpy(F.gab_w, f.gab_w, sizeof(F.gab_w));
   F.epf_iters = f.epf_iters; memcpy(F.epf_sharp, f.epf_sharp, sizeof(F.epf_sharp)); memcpy(F.epf_chscale, f.epf_chscale, sizeof(F.epf_chscale));

@@ -38,7 +38,7 @@ static void filter_stages(const DevBuffers &B, const DevFrame &F) {
   }
 }
 
-struct RefStore { std::vector<float> p[4][4]; int w[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0}; };      // [slot][R, G, B, alpha (blended canvases only)]
+struct RefStore { std::vector<float> p[5][4]; int w[5] = {0, 0, 0, 0, 0}, h[5] = {0, 0, 0, 0, 0}; };      // [slot][R, G, B, alpha (blended canvases only)]
 
 // composition tail (jxlamd_decoder::launch_compose_tail): patches, copy into the reference slot, stand-alone writer
 static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F, int out_bits, RefStore &refs, const uint8_t *stat) {
@@ -124,6 +124,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (F0.upsampling > 1) for (int c = 0; c < 3; c++) { upv[c].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[c] = upv[c].data(); }
   if (F0.alpha_up > 1) { upv[3].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[3] = upv[3].data(); }
   for (int k = 0; k < 4; k++) { for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data(); B.ref_a[k] = refs.p[k][3].empty() ? nullptr : refs.p[k][3].data(); }
+  for (int c = 0; c < 3; c++) B.lf_frame[c] = refs.p[4][c].empty() ? nullptr : refs.p[4][c].data();      // slot 4: the LF frame of a progressive_dc file
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();

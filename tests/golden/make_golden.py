@@ -96,6 +96,10 @@ CASES = {
     "vua400x300_e7_d12": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=12.0)),
     "vusa400x300_e7_d12": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(effort=7, distance=12.0)),
     "va400x300_e7_ecup2": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=1.0, extra=((3, 2),))),
+    # progressive DC (JXL_ENC_FRAME_SETTING_PROGRESSIVE_DC = 19): the LF image travels as an LF frame of its own (a Modular XYB frame at an eighth of the size),
+    # the main frame's LfGroup sections carry no LF coefficients; one and two LF groups
+    "vlf600x410_e7": (600, 410, dict(seed=11), dict(effort=7, distance=1.0, extra=((19, 1),))),
+    "vlf2100x100_e7_d2": (2100, 100, dict(seed=11), dict(effort=7, distance=2.0, extra=((19, 1),))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
