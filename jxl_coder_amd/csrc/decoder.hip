@@ -315,6 +315,11 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int c = 0; c < 3; c++) B.ref[k][c] = have ? (float *)ref_store[k].p + (size_t)c * n : nullptr;
     B.ref_a[k] = (have && ref_alpha[k]) ? (float *)ref_store[k].p + 3 * n : nullptr;      // a blended canvas kept with its alpha plane
   }
+  for (int c = 0; c < 3; c++) B.noise[c] = nullptr;
+  if (Fh->noise) {
+    HIPCHECK(S.noise_planes.ensure(3 * npx * 4));
+    for (int c = 0; c < 3; c++) B.noise[c] = (float *)S.noise_planes.p + (size_t)c * npx;
+  }
   for (int c = 0; c < 3; c++) B.lf_frame[c] = nullptr;
   if (Fh->use_lf_frame) {
     if (!ref_store[4].p || ref_w[4] != Fh->lf_frame_w || ref_h[4] != Fh->lf_frame_h) { set_error("LF frame missing"); return JXLAMD_ERR_INVALID; }
@@ -422,6 +427,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   if (F->subsampled) launch_chroma_upsample(S.B, plan.width, plan.height, stream);      // recompressed JPEG: chroma to full resolution (no loop filters in between)
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
+  if (F->noise) launch_noise(S.B, plan.num_groups, plan.width, plan.height, stream);      // after the patches, before the colour transform (libjxl's stage order)
   if (F->blend) {
     // a frame of an animation over its canvas (dev_compose.h: blend_canvas_pixel): the background is a reference slot's canvas, the result goes out and / or
     // becomes the new canvas of the frame's slot — in place when it is the slot it was read from (every pixel reads before it writes)

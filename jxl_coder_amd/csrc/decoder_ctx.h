@@ -108,6 +108,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   int post_kind = 0; uint32_t post_depth = 8, post_stride = 0; size_t post_bytes = 0; uint64_t post_gen = 0; size_t post_off = 0;      // post_off: where the frame's DevPost sits inside its tables (flights); post_gen: which upload of the context's tone-map LUTs the frame was prepared against
   void *post_final = nullptr;
   DevMem post_dev, post_fz, post_tmp; PinnedMem h_post;
+  DevMem noise_planes;           // frames with noise synthesis: three random planes
   BandGeom band;                 // rows this decode covers (whole frame unless jxlamd_band_begin set it up) and the storage behind them
   int band_stage = 0;            // band decode protocol: 0 idle, 1 LF stage done, 2 reconstructed, (finish returns to 0)
 };

@@ -136,6 +136,86 @@ JXL_DEV void chroma_upsample_pixel(const DevBuffers &B, const DevFrame &F, int c
   B.plane_b[c][(size_t)Y * pw + (size_t)X] = vs ? mul_add_rn(nb, 0.25f, cur * 0.75f) : cur;
 }
 
+// ---- Noise synthesis (libjxl: PrepareNoiseInput / RandomImage, the "ConvolveNoise" and "AddNoise" render stages).
+// The random planes: every 256 x 256 group runs its own Xorshift128+ — eight generators side by side, seeded through SplitMix64 with (frame counters, group
+// origin) — over plane 0, 1, 2 in turn, row by row; a call yields eight 64-bit words = sixteen floats in [1, 2) (the upper 23 bits of each half as a
+// mantissa); a row takes one call per whole sixteen-float batch that ends BEFORE its last sample, plus one more for the rest.  Work item = one generator.
+JXL_DEV uint64_t noise_splitmix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+JXL_DEV void noise_gen_lane(const DevBuffers &B, const DevFrame &F, int g, int lane) {
+  const int gx = g % F.xgroups, gy = g / F.xgroups;
+  const int x0 = gx * 256, y0 = gy * 256;
+  const int xs = F.width - x0 < 256 ? F.width - x0 : 256, ys = F.height - y0 < 256 ? F.height - y0 : 256;
+  uint64_t s0 = noise_splitmix((((uint64_t)F.noise_seed[0]) << 32) + F.noise_seed[1] + 0x9E3779B97F4A7C15ull);
+  uint64_t s1 = noise_splitmix((((uint64_t)(uint32_t)x0) << 32) + (uint32_t)y0 + 0x9E3779B97F4A7C15ull);
+  for (int i = 0; i < lane; i++) { s0 = noise_splitmix(s0); s1 = noise_splitmix(s1); }
+  int nfull = 0;
+  while ((nfull + 1) * 16 < xs) nfull++;                      // batches with x + 16 < xsize
+  for (int c = 0; c < 3; c++)
+    for (int y = 0; y < ys; y++) {
+      float *row = B.noise[c] + (size_t)(y0 + y) * (size_t)F.pw + (size_t)x0;
+      for (int f = 0; f <= nfull; f++) {
+        uint64_t a = s0; const uint64_t b = s1;
+        const uint64_t bits = a + b;
+        s0 = b;
+        a ^= a << 23;
+        s1 = a ^ b ^ (a >> 18) ^ (b >> 5);
+        for (int k = 0; k < 2; k++) {
+          const int x = f * 16 + 2 * lane + k;
+          if (x >= xs) continue;
+          const uint32_t w = (uint32_t)(k ? bits >> 32 : bits);
+          const uint32_t fb = (w >> 9) | 0x3F800000u;
+#ifdef __HIPCC__
+          row[x] = __uint_as_float(fb);
+#else
+          float fv; memcpy(&fv, &fb, 4); row[x] = fv;
+#endif
+        }
+      }
+    }
+}
+// one pixel: the three planes through the 5 x 5 high-pass (0.16 everywhere, -3.84 in the middle; the frame's edges mirrored), scaled by 0.22 and by the
+// strength the 8-point curve gives for the local red / green intensities ((Y + X) / 2, (Y - X) / 2), added to X, Y, B with libjxl's correlations
+JXL_DEV float noise_strength(const DevFrame &F, float x) {
+  float sx = x * 6.0f; sx = sx > 0.0f ? sx : 0.0f;
+  float fl = floorf(sx), fr = sx - fl;
+  if (sx >= 7.0f) { fl = 6.0f; fr = 1.0f; }
+  const int i = (int)fl;
+  const float lo = F.noise_lut[i], hi = F.noise_lut[i + 1];
+  const float v = mul_add_rn(hi - lo, fr, lo);
+  return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
+}
+JXL_DEV void noise_add_pixel(const DevBuffers &B, const DevFrame &F, int x, int y) {
+  float rnd[3];
+  int xs[5], ys[5];
+  for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.width); ys[i] = mirror(y + i - 2, F.height); }
+  for (int c = 0; c < 3; c++) {
+    const float *p = B.noise[c];
+    float others = 0.0f;
+    for (int i = 0; i < 5; i++) {
+      others += p[(size_t)ys[0] * (size_t)F.pw + (size_t)xs[i]]; others += p[(size_t)ys[1] * (size_t)F.pw + (size_t)xs[i]];
+      others += p[(size_t)ys[3] * (size_t)F.pw + (size_t)xs[i]]; others += p[(size_t)ys[4] * (size_t)F.pw + (size_t)xs[i]];
+    }
+    const float *mid = p + (size_t)ys[2] * (size_t)F.pw;
+    others += mid[xs[0]]; others += mid[xs[1]]; others += mid[xs[3]]; others += mid[xs[4]];
+    rnd[c] = mul_add_rn(others, 0.16f, mid[xs[2]] * -3.84f) * 0.22f;
+  }
+  const bool a = compose_final_is_a(F);
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x;
+  float *px = (a ? B.plane_a[0] : B.plane_b[0]) + po, *py = (a ? B.plane_a[1] : B.plane_b[1]) + po, *pb = (a ? B.plane_a[2] : B.plane_b[2]) + po;
+  const float vx = *px, vy = *py;
+  const float sg = noise_strength(F, (vy - vx) * 0.5f), sr = noise_strength(F, (vy + vx) * 0.5f);
+  const float red = sr * mul_add_rn(0.0078125f, rnd[0], 0.9921875f * rnd[2]);
+  const float green = sg * mul_add_rn(0.0078125f, rnd[1], 0.9921875f * rnd[2]);
+  const float rg = red + green;
+  *px = mul_add_rn(F.base_x, rg, red - green) + vx;
+  *py = vy + rg;
+  *pb = mul_add_rn(F.base_b, rg, *pb);
+}
+
 // ---- Blending (libjxl's "Blending" stage, after the colour transform): one pixel (x, y) of the CANVAS.  Background = the blend source's canvas (reference
 // slot bl_src; transparent black when the slot is empty); inside the frame's rectangle the frame's colour (in the image's colour encoding, not clamped) and
 // alpha are combined with it by the frame's BlendingInfo, outside the background shows.  The result is kept (canvas_save: a later frame's background)

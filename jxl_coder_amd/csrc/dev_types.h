@@ -125,6 +125,9 @@ struct DevFrame {
   // samples — reference slot bl_src (-1: transparent black) — and the result is written out and / or kept as a slot's new canvas.  Modes: 0 replace, 1 add,
   // 2 blend (alpha), 3 alpha-weighted add, 4 multiply; colour channels and the alpha channel each have theirs (dev_compose.h: blend_canvas_pixel)
   int32_t blend, bl_src, bl_mode_c, bl_mode_a, bl_clamp_c, bl_clamp_a, bl_premultiplied;
+  // Noise synthesis (flag kNoise): three planes of pseudo-random numbers per 256 x 256 group (Xorshift128+ seeded with libjxl's frame counters and the
+  // group's origin), high-pass filtered and added to X, Y, B with a strength read off an 8-point curve of the local intensity (dev_compose.h)
+  int32_t noise; float noise_lut[8]; uint32_t noise_seed[2];
   int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter

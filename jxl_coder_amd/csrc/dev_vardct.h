@@ -42,6 +42,7 @@ struct DevBuffers {
   uint32_t *lz_win;             // Modular-encoded frames whose code uses LZ77: [DevFrame::lz_win_len] + [num_groups][DevFrame::lz_win_group] decoded integers (else null)
   const uint8_t *stat;          // the decoder's static tables (DevStatic at 0): natural coefficient orders for the PassGroup kernels
   float *up[4];                 // upsampled frames: dense full_w x full_h f32 planes between the upsampling stage and the writer ([3]: an upsampled alpha channel)
+  float *noise[3];              // DevFrame::noise: the three random planes (pw x ph f32 each)
   const float *lf_frame[3];     // DevFrame::use_lf_frame: the LF frame's X, Y, B planes (dense lf_frame_w x lf_frame_h)
   const DevPost *post;          // non-null: the frame's last filter stage hands its pixels to the post stages instead of storing RGBA (kernels_filter.hip: k_filter_b<3, 1>)
   float *ref_a[4];              // ... and, for a slot that holds a blended canvas (frames of an animation), its alpha plane (null: the image has none)

@@ -501,7 +501,7 @@ int parse_basic_info(const uint8_t *data, size_t size, ImageInfo *info, std::str
 }
 
 // One frame of the walk: its header, where its TOC starts and where the next frame header begins
-struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; bool blend = false; bool canvas_needed = false; int src_frame = -1; bool lf_needed = false; };
+struct FrameRec { frame_hdr f; size_t toc_bit = 0; size_t end_byte = 0; bool needed = false; bool blend = false; bool canvas_needed = false; int src_frame = -1; bool lf_needed = false; int visible_index = 0, nonvisible_index = 0; };
 
 // TOC of the frame whose header ended at toc_bit: section table (logical order) and the byte where the frame's sections end
 static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t toc_bit, std::vector<DevSection> *secs, size_t *end_byte, std::string *error) {
@@ -626,6 +626,15 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     if (recs.size() > 4096) { plan->error = "too many frames"; return -1; }
     hx_br_init(&br, plan->cs, csn);
     br.pos = r.end_byte * 8;
+  }
+  {   // libjxl's frame counters (they seed the noise generator), advanced BEFORE a frame is decoded: shown frames up to and including this one / frames
+      // since the last shown one (established on the reference binary: the first frame of a still image is seeded with (1, 0))
+    int vis = 0, nonvis = 0;
+    for (auto &r : recs) {
+      const bool shown = (r.f.frame_type == 0 || r.f.frame_type == 3) && (r.f.is_last || r.f.duration > 0);
+      if (shown) { vis++; nonvis = 0; } else nonvis++;
+      r.visible_index = vis; r.nonvisible_index = nonvis;
+    }
   }
   // ---- which frame is shown, and which earlier frames does it need?  The reference keeps what the LAST coalesced frame shows (interop/JxlDecoding.cpp:
   // 164-166); its animated decoder asks for coalesced frame i (JxlAnimatedDecoder.cpp:28-144).  A coalesced frame is a regular frame of non-zero duration
@@ -777,7 +786,12 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   }
   if (!is_shown && (f.width < 1 || f.height < 1)) { plan->error = "empty frame"; return -1; }
   if (f.do_ycbcr && f.encoding == 1) { plan->error = "unsupported: YCbCr Modular frame"; return -1; }
-  if (f.flags & (1 | 16)) { plan->error = "unsupported: splines / noise"; return -1; }
+  if (f.flags & 16) { plan->error = "unsupported: splines"; return -1; }
+  if (f.flags & 1) {
+    if (f.encoding != 0 || !m.pub.xyb_encoded) { plan->error = "unsupported: noise on a frame that is not a VarDCT XYB frame"; return -1; }
+    if (f.upsampling != 1) { plan->error = "unsupported: noise on an upsampled frame"; return -1; }
+    if (!is_shown) { plan->error = "unsupported: noise on a reference frame"; return -1; }
+  }
   if (f.flags & 32) {
     if (f.encoding != 0) { plan->error = "unsupported: Modular frame with an LF frame"; return -1; }
     if (f.subsampled) { plan->error = "unsupported: chroma-subsampled frame with an LF frame"; return -1; }
@@ -815,6 +829,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // ---- LfGlobal (section 0)
   hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
   if ((f.flags & 2) && parse_patches(plan, pv, &sb, blob)) return -1;
+  if (f.flags & 1) for (int i = 0; i < 8; i++) F.noise_lut[i] = (float)hx_bits(&sb, 10) * (1.0f / 1024);      // NoiseParameters: eight points of the strength curve
   float lf_dequant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   if (!hx_bool(&sb)) for (int c = 0; c < 3; c++) lf_dequant[c] = hx_f16(&sb) * (1.0f / 128);
   uint32_t global_scale = 1, quant_lf = 1;
@@ -944,7 +959,8 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   }
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
-  F.compose = (!is_shown || pv->blend || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
+  F.noise = (f.flags & 1) ? 1 : 0; F.noise_seed[0] = (uint32_t)rec.visible_index; F.noise_seed[1] = (uint32_t)rec.nonvisible_index;
+  F.compose = (!is_shown || pv->blend || F.noise || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;

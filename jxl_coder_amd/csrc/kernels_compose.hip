@@ -44,6 +44,23 @@ __global__ void __launch_bounds__(256) k_chroma_upsample(DevBuffers B) {
   if (x >= F.width || y >= F.height || frame_failed(B)) return;
   chroma_upsample_pixel(B, F, (int)blockIdx.z, x, y);
 }
+// noise synthesis: the random planes (one work-item per generator: 8 per group), then one work-item per pixel
+__global__ void __launch_bounds__(64) k_noise_gen(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  const int item = (int)(blockIdx.x * 64 + threadIdx.x);
+  if (item >= F.num_groups * 8 || frame_failed(B)) return;
+  noise_gen_lane(B, F, item >> 3, item & 7);
+}
+__global__ void __launch_bounds__(256) k_noise_add(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height || frame_failed(B)) return;
+  noise_add_pixel(B, F, x, y);
+}
+void launch_noise(const DevBuffers &B, int num_groups, int w, int h, hipStream_t s) {
+  hipLaunchKernelGGL(k_noise_gen, dim3((unsigned)(num_groups * 8 + 63) / 64), dim3(64), 0, s, B);
+  hipLaunchKernelGGL(k_noise_add, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B);
+}
 // frames laid over a canvas (animations): one work-item per canvas pixel
 __global__ void __launch_bounds__(256) k_blend_canvas(DevBuffers B, const uint8_t *stat) {
   const DevFrame &F = frame_of(B);

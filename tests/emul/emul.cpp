@@ -45,6 +45,10 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   if (F.subsampled) for (int c = 0; c < 3; c++) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) chroma_upsample_pixel(B, F, c, x, y);      // k_chroma_upsample
   const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
   for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
+  if (F.noise && !getenv("JXLEMUL_NO_NOISE")) {                                           // k_noise_gen, k_noise_add
+    for (int g = 0; g < F.num_groups; g++) for (int lane = 0; lane < 8; lane++) noise_gen_lane(B, F, g, lane);
+    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) noise_add_pixel(B, F, x, y);
+  }
   if (F.blend) {                                           // jxlamd_decoder::launch_compose_tail: the frame over its canvas (k_blend_canvas)
     DevBuffers Bb = B;
     std::vector<float> keep[4];
@@ -124,6 +128,8 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (F0.upsampling > 1) for (int c = 0; c < 3; c++) { upv[c].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[c] = upv[c].data(); }
   if (F0.alpha_up > 1) { upv[3].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[3] = upv[3].data(); }
   for (int k = 0; k < 4; k++) { for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data(); B.ref_a[k] = refs.p[k][3].empty() ? nullptr : refs.p[k][3].data(); }
+  std::vector<float> noisev[3];
+  if (F0.noise) for (int c = 0; c < 3; c++) { noisev[c].assign(npx, 0.f); B.noise[c] = noisev[c].data(); }
   for (int c = 0; c < 3; c++) B.lf_frame[c] = refs.p[4][c].empty() ? nullptr : refs.p[4][c].data();      // slot 4: the LF frame of a progressive_dc file
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);

@@ -100,6 +100,10 @@ CASES = {
     # the main frame's LfGroup sections carry no LF coefficients; one and two LF groups
     "vlf600x410_e7": (600, 410, dict(seed=11), dict(effort=7, distance=1.0, extra=((19, 1),))),
     "vlf2100x100_e7_d2": (2100, 100, dict(seed=11), dict(effort=7, distance=2.0, extra=((19, 1),))),
+    # noise synthesis (JXL_ENC_FRAME_SETTING_NOISE = 6: the encoder models the image's grain as 8 points of a strength curve, the decoder regenerates it)
+    "vn300x200_e7": (300, 200, dict(seed=4, grain=6), dict(effort=7, distance=1.0, extra=((6, 1),))),
+    "vn600x410_e7_d15": (600, 410, dict(seed=4, grain=5), dict(effort=7, distance=1.5, extra=((6, 1),))),        # 3 x 2 groups with ragged edges: each group seeds its own generator
+    "vna333x277_e7_d15": (333, 277, dict(seed=4, grain=5, alpha=True), dict(effort=7, distance=1.5, extra=((6, 1),))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
@@ -197,8 +201,11 @@ def make_image(w, h, sk):
     gen = sk.pop("gen", "photo")
     alpha = sk.pop("alpha", False)
     grey = sk.pop("grey", False)
+    grain = sk.pop("grain", 0)
     if gen == "photo":
         img = synth.photo_like(w, h, **sk)
+        if grain:               # sensor-like grain (seeded): what makes the encoder's noise estimation find something to model
+            img = np.clip(img.astype(int) + np.random.default_rng(1000 + sk.get("seed", 0)).normal(0, grain, img.shape), 0, 255).astype(np.uint8)
         if grey:
             img = np.ascontiguousarray(img[..., :1])
         if alpha:
