@@ -272,7 +272,9 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     else {
       const int u = f.ec_upsampling[i - ncol];
       int sh = 0; while ((f.upsampling << sh) < u) sh++;            // coarser than the colour channels by this shift: its group rectangles shrink with it
-      L.push_back({(f.width + u - 1) / u, (f.height + u - 1) / u, sh, sh, -1});
+      // (an LF frame is the image at an eighth: its extra channels shrink with it)
+      const int fw = f.frame_type == 1 ? f.coded_width : f.width, fh = f.frame_type == 1 ? f.coded_height : f.height;
+      L.push_back({(fw + u - 1) / u, (fh + u - 1) / u, sh, sh, -1});
     }
   }
   const std::vector<Ch> L0 = L;                 // what the inverse transforms must arrive at again
@@ -797,7 +799,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     if (f.subsampled) { plan->error = "unsupported: chroma-subsampled frame with an LF frame"; return -1; }
     if (pv->lf_w != (f.coded_width + 7) / 8 || pv->lf_h != (f.coded_height + 7) / 8) { plan->error = "LF frame does not match the frame it serves"; return -1; }
   }
-  if (f.frame_type == 1 && (f.encoding != 1 || !m.pub.xyb_encoded || m.num_extra)) { plan->error = "unsupported: LF frame that is not a Modular XYB frame without extra channels"; return -1; }
+  if (f.frame_type == 1 && (f.encoding != 1 || !m.pub.xyb_encoded)) { plan->error = "unsupported: LF frame that is not a Modular XYB frame"; return -1; }      // (its extra channels, coded at an eighth too, are decoded and not used: the main frame carries its own)
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
   const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   { size_t end_byte = 0; if (read_toc(plan->cs, csn, f, rec.toc_bit, &secs, &end_byte, &plan->error)) return -1; }

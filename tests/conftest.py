@@ -98,7 +98,7 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       # RGBA at low quality: alpha coded at half size (extra-channel upsampling; its values get the writer's dither like the colour), with patches, and alpha alone at half size
                       "vua400x300_e7_d12", "vusa400x300_e7_d12", "va400x300_e7_ecup2",
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
-                      "vlf600x410_e7", "vlf2100x100_e7_d2", "u96x64_lf_frame",
+                      "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame",
                       # noise synthesis: Xorshift128+ planes per group (seeded with libjxl's frame counters and the group origin), high-passed, added to XYB by an 8-point strength curve
                       "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW

@@ -100,6 +100,7 @@ CASES = {
     # the main frame's LfGroup sections carry no LF coefficients; one and two LF groups
     "vlf600x410_e7": (600, 410, dict(seed=11), dict(effort=7, distance=1.0, extra=((19, 1),))),
     "vlf2100x100_e7_d2": (2100, 100, dict(seed=11), dict(effort=7, distance=2.0, extra=((19, 1),))),
+    "vlfa520x300_e7_d15": (520, 300, dict(seed=11, alpha=True), dict(effort=7, distance=1.5, extra=((19, 1),))),      # RGBA: the LF frame carries an alpha channel at an eighth too (decoded, not used)
     # noise synthesis (JXL_ENC_FRAME_SETTING_NOISE = 6: the encoder models the image's grain as 8 points of a strength curve, the decoder regenerates it)
     "vn300x200_e7": (300, 200, dict(seed=4, grain=6), dict(effort=7, distance=1.0, extra=((6, 1),))),
     "vn600x410_e7_d15": (600, 410, dict(seed=4, grain=5), dict(effort=7, distance=1.5, extra=((6, 1),))),        # 3 x 2 groups with ragged edges: each group seeds its own generator
