@@ -911,15 +911,43 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // colour: opsin inverse scaled to display-relative linear, then to the data profile's primaries
   {
     double T[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    if (m.pub.white_point != 1) { plan->error = "unsupported: non-D65 white point"; return -1; }
-    if (m.pub.primaries != 1) {
-      static const double srgb[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
-      double dst[8];
-      if (m.pub.primaries == 9) { double t[8] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
-      else if (m.pub.primaries == 11) { double t[8] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.3127, 0.3290}; memcpy(dst, t, sizeof(t)); }
-      else { plan->error = "unsupported: custom primaries"; return -1; }
+    static const double srgb[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
+    double dst[8]; memcpy(dst, srgb, sizeof(dst));      // r, g, b, white
+    bool custom = false;
+    if (m.pub.primaries == 9) { const double t[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046}; memcpy(dst, t, sizeof(t)); }
+    else if (m.pub.primaries == 11) { const double t[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060}; memcpy(dst, t, sizeof(t)); }
+    else if (m.pub.primaries == 2) { for (int k = 0; k < 6; k++) dst[k] = (double)m.prim_xy[k]; custom = true; }
+    else if (m.pub.primaries != 1) { plan->error = "unsupported: primaries"; return -1; }
+    if (m.pub.white_point == 2) { dst[6] = (double)m.wp_xy[0]; dst[7] = (double)m.wp_xy[1]; custom = true; }
+    else if (m.pub.white_point == 10) { dst[6] = dst[7] = 1.0 / 3; custom = true; }
+    else if (m.pub.white_point == 11) { dst[6] = 0.314; dst[7] = 0.351; custom = true; }
+    else if (m.pub.white_point != 1) { plan->error = "unsupported: white point"; return -1; }
+    for (int k = 0; k < 4; k++) if (!(dst[2 * k + 1] > 1e-6)) { plan->error = "bad chromaticities"; return -1; }
+    if (m.pub.primaries != 1 || custom) {
+      // linear sRGB -> the target's linear RGB.  Same white point on both sides: the two RGB -> XYZ matrices.  Another white point (custom, E, DCI): both
+      // sides go to XYZ-D50 through the Bradford adaptation of their white point, as libjxl's output stage does (PrimariesToXYZD50 on the image's encoding and
+      // on sRGB); for a D65 target the two adaptations cancel, and the enum cases keep the arithmetic they had
       double A[9], Bm[9], Bi[9];
-      primaries_to_xyz(srgb, A); primaries_to_xyz(dst, Bm); inv3(Bm, Bi);
+      primaries_to_xyz(srgb, A); primaries_to_xyz(dst, Bm);
+      if (dst[6] != srgb[6] || dst[7] != srgb[7]) {
+        const auto bradford_to_d50 = [](double wx, double wy, double out[9]) {
+          static const double kB[9] = {0.8951, 0.2664, -0.1614, -0.7502, 1.7135, 0.0367, 0.0389, -0.0685, 1.0296};
+          static const double kBi[9] = {0.9869929, -0.1470543, 0.1599627, 0.4323053, 0.5183603, 0.0492912, -0.0085287, 0.0400428, 0.9684867};
+          const double w[3] = {wx / wy, 1.0, (1.0 - wx - wy) / wy}, w50[3] = {0.96422, 1.0, 0.82521};
+          double lms[3], lms50[3];
+          for (int i = 0; i < 3; i++) { lms[i] = kB[i * 3] * w[0] + kB[i * 3 + 1] * w[1] + kB[i * 3 + 2] * w[2]; lms50[i] = kB[i * 3] * w50[0] + kB[i * 3 + 1] * w50[1] + kB[i * 3 + 2] * w50[2]; }
+          double t[9];
+          for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) t[r * 3 + c] = (lms50[r] / lms[r]) * kB[r * 3 + c];
+          for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { out[r * 3 + c] = 0; for (int k = 0; k < 3; k++) out[r * 3 + c] += kBi[r * 3 + k] * t[k * 3 + c]; }
+        };
+        double As[9], Ad[9], t[9];
+        bradford_to_d50(srgb[6], srgb[7], As); bradford_to_d50(dst[6], dst[7], Ad);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { t[r * 3 + c] = 0; for (int k = 0; k < 3; k++) t[r * 3 + c] += As[r * 3 + k] * A[k * 3 + c]; }
+        memcpy(A, t, sizeof(A));
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { t[r * 3 + c] = 0; for (int k = 0; k < 3; k++) t[r * 3 + c] += Ad[r * 3 + k] * Bm[k * 3 + c]; }
+        memcpy(Bm, t, sizeof(Bm));
+      }
+      inv3(Bm, Bi);
       for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { T[r * 3 + c] = 0; for (int k = 0; k < 3; k++) T[r * 3 + c] += Bi[r * 3 + k] * A[k * 3 + c]; }
     }
     float itscale = 255.0f / m.pub.intensity_target;
@@ -933,11 +961,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     if (F.transfer == 18) {
       // HLG encodes scene light: the display-referred linear values go through the inverse OOTF first — every channel is scaled by
       // Y^(gamma - 1), gamma = (1 / 1.2) * 1.111^(-log2(intensity_target / 1000)), Y from the target primaries' luminance weights
-      static const double srgb8[8] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204, 0.3127, 0.3290};
-      double prim[8]; memcpy(prim, srgb8, sizeof(prim));
-      if (m.pub.primaries == 9) { const double t[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046}; memcpy(prim, t, sizeof(t)); }
-      else if (m.pub.primaries == 11) { const double t[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060}; memcpy(prim, t, sizeof(t)); }
-      double M[9]; primaries_to_xyz(prim, M);
+      double M[9]; primaries_to_xyz(dst, M);
       for (int c = 0; c < 3; c++) F.hlg_lum[c] = (float)M[3 + c];
       const float gamma = (1.0f / 1.2f) * powf(1.111f, -log2f(m.pub.intensity_target / 1000.0f));
       F.hlg_exponent = gamma - 1.0f;

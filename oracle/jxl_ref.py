@@ -50,6 +50,7 @@ def lib():
         _lib.ref_free.argtypes = [C.c_void_p]
         _lib.ref_set_icc.argtypes = [C.c_char_p, C.c_size_t]
         _lib.ref_version.restype = C.c_int
+        _lib.ref_set_custom_xy.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -74,7 +75,7 @@ def decode(data: bytes, threads=0, allow16=True, mode=0):
 
 
 def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
-           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1):
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1, custom_xy=None):
     """pixels: [h,w,c] u8 or u16, c in 1,3,4. Same sequence as the reference's EncodeJxlOneshot."""
     pixels = np.ascontiguousarray(pixels)
     h, w, c = pixels.shape
@@ -92,9 +93,12 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
     n = C.c_size_t()
     lib().ref_set_icc(icc or b"", len(icc) if icc else 0)      # JxlEncoderSetICCProfile (interop/JxlEncoding.cpp:125-129) instead of an enum profile
     lib().ref_set_orientation(int(orientation))                # JxlBasicInfo.orientation of the file (the decoder re-orients by default)
+    _xy = (C.c_double * 8)(*custom_xy) if custom_xy else None
+    lib().ref_set_custom_xy(C.cast(_xy, C.c_void_p) if custom_xy else None)      # custom white point + primaries (white xy, red, green, blue xy) instead of the enum values
     rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
     lib().ref_set_icc(b"", 0)
     lib().ref_set_orientation(1)
+    lib().ref_set_custom_xy(None)
     if rc != 0:
         raise ValueError(f"ref_encode failed rc={rc}")
     data = C.string_at(out.value, n.value)

@@ -179,6 +179,8 @@ void ref_set_icc(const uint8_t *icc, size_t size) {
 }
 
 /* JxlBasicInfo.orientation (1..8) for the NEXT ref_encode call (test fixtures with a non-identity orientation); 0 / 1 = identity. */
+static double g_custom_xy[8]; static int g_custom_xy_set;     /* white point xy, red, green, blue xy: custom colour encoding of the next ref_encode (0 entries: enum) */
+void ref_set_custom_xy(const double *xy8) { g_custom_xy_set = xy8 != NULL; if (xy8) memcpy(g_custom_xy, xy8, sizeof(g_custom_xy)); }
 static int g_orientation;
 void ref_set_orientation(int o) { g_orientation = o; }
 
@@ -222,6 +224,12 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   p_JxlColorEncodingSetToSRGB(&ce, p->num_channels == 1);
   if (p->primaries) ce.primaries = (JxlPrimaries)p->primaries;
   if (p->transfer) ce.transfer_function = (JxlTransferFunction)p->transfer;
+  if (g_custom_xy_set) {
+    ce.white_point = JXL_WHITE_POINT_CUSTOM; ce.primaries = JXL_PRIMARIES_CUSTOM;
+    ce.white_point_xy[0] = g_custom_xy[0]; ce.white_point_xy[1] = g_custom_xy[1];
+    ce.primaries_red_xy[0] = g_custom_xy[2]; ce.primaries_red_xy[1] = g_custom_xy[3]; ce.primaries_green_xy[0] = g_custom_xy[4]; ce.primaries_green_xy[1] = g_custom_xy[5];
+    ce.primaries_blue_xy[0] = g_custom_xy[6]; ce.primaries_blue_xy[1] = g_custom_xy[7];
+  }
   if (g_icc_size) { if (JXL_ENC_SUCCESS != p_JxlEncoderSetICCProfile(enc, g_icc, g_icc_size)) { rc = -5; goto done; } }
   else if (JXL_ENC_SUCCESS != p_JxlEncoderSetColorEncoding(enc, &ce)) { rc = -5; goto done; }
   JxlEncoderFrameSettings *fs = p_JxlEncoderFrameSettingsCreate(enc, NULL);

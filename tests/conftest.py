@@ -100,7 +100,9 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
                       "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame",
                       # noise synthesis: Xorshift128+ planes per group (seeded with libjxl's frame counters and the group origin), high-passed, added to XYB by an 8-point strength curve
-                      "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]
+                      "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15",
+                      # custom primaries (Adobe RGB) and a custom white point with custom primaries (ProPhoto, D50: Bradford on both sides as in libjxl's output stage)
+                      "vcadobe200x136_e7", "vcprophoto200x136_e7"]
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW
 # dequant matrices, 4:4:4 / 4:2:0 / 4:2:2 chroma, progressive source, grey, several groups.  Same tolerance as every VarDCT file (measured 1e-5 - 5e-5).
 JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j420_prog_333x277", "jgrey_160x120", "j420s_400x300"]

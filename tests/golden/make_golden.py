@@ -105,6 +105,10 @@ CASES = {
     "vn300x200_e7": (300, 200, dict(seed=4, grain=6), dict(effort=7, distance=1.0, extra=((6, 1),))),
     "vn600x410_e7_d15": (600, 410, dict(seed=4, grain=5), dict(effort=7, distance=1.5, extra=((6, 1),))),        # 3 x 2 groups with ragged edges: each group seeds its own generator
     "vna333x277_e7_d15": (333, 277, dict(seed=4, grain=5, alpha=True), dict(effort=7, distance=1.5, extra=((6, 1),))),
+    # custom chromaticities in an enum colour encoding (what encoders write for Adobe RGB / ProPhoto sources): primaries by xy, and a D50 white point that
+    # libjxl's output stage adapts with Bradford (white xy, red, green, blue xy)
+    "vcadobe200x136_e7": (200, 136, dict(seed=9), dict(effort=7, custom_xy=(0.3127, 0.3290, 0.64, 0.33, 0.21, 0.71, 0.15, 0.06))),
+    "vcprophoto200x136_e7": (200, 136, dict(seed=9), dict(effort=7, custom_xy=(0.3457, 0.3585, 0.7347, 0.2653, 0.1596, 0.8404, 0.0366, 0.0001))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
