@@ -171,7 +171,10 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   int32_t *scr = B.mod_scratch + (size_t)g * mod_group_scratch_ints(F);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-    const DevSection sec = secs[2 + F.num_lf_groups + g];
+    // the ModularGroup stream of a VarDCT frame's extra channels follows the group's AC stream of the LAST pass (a channel of shift 0 always belongs to the last pass:
+    // Passes::GetDownsamplingBracket; the host rejects squeezed extra channels on multi-pass frames); Modular frames are single-pass
+    const int last_pass = F.is_modular ? 0 : F.num_passes - 1;
+    const DevSection sec = secs[2 + F.num_lf_groups + last_pass * F.num_groups + g];
     DevBits b;
     if (F.is_modular) bits_init(b, B.codestream, sec.off, F.cs_size);
     else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
@@ -226,7 +229,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   modular_stream_stage(S, tid, nthreads);
   sync();
   const int nst = S.grp_n;
-  const int sid = 1 + 3 * F.num_lf_groups + 17 + g;
+  const int sid = 1 + 3 * F.num_lf_groups + 17 + (F.is_modular ? 0 : F.num_passes - 1) * F.num_groups + g;      // ModularAC(group, pass)
   uint32_t e = mod_decode_stream(S, S.ch, S.grp_dec, sid, tid);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
   sync();

@@ -755,7 +755,6 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // a frame may exceed the canvas (cropped frames, reference frames of a patch dictionary), but one that is orders of magnitude larger than the
   // image it belongs to only sizes allocations: refused
   if ((int64_t)f.coded_width * (int64_t)f.coded_height > 64 * (int64_t)raw_w * (int64_t)raw_h + ((int64_t)1 << 24)) { plan->error = "unsupported: frame far larger than the image"; return -1; }
-  if (f.encoding == 0 && m.num_extra && f.num_passes != 1) { plan->error = "unsupported: extra channels on a multi-pass VarDCT frame"; return -1; }
   if (f.encoding == 0 && !m.pub.xyb_encoded) {
     // a VarDCT frame of an image that is not XYB: a recompressed JPEG (YCbCr, chroma possibly subsampled, RAW dequant matrices).  Decoded like any
     // VarDCT frame up to the planes, which then hold the image's own samples (dev_compose.h: chroma upsampling, YCbCr -> RGB in the writer)
@@ -888,6 +887,9 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   if (f.encoding == 0 && m.num_extra) {
     if (parse_modular_global(plan, pv, &sb, /*vardct=*/true)) return -1;
     plan->has_ec = true;
+    // several passes: a channel of shift 0 always travels with the LAST pass (every earlier pass's bracket starts at shift 1 or above, the last one's at 0:
+    // Passes::GetDownsamplingBracket), which is where the device looks; squeezed channels would be spread over the passes
+    if (f.num_passes != 1) for (int c = 0; c < F.mod_nch; c++) if (F.mod_hs[c] || F.mod_vs[c]) { plan->error = "unsupported: squeezed extra channels on a multi-pass VarDCT frame"; return -1; }
   }
   // quantiser-derived constants
   float inv_quant_dc = 65536.0f / ((float)global_scale * (float)quant_lf);

@@ -795,6 +795,7 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
       jxo_chan *fc = &s->gmod.ch[c];
       int sh = fc->hshift < fc->vshift ? fc->hshift : fc->vshift;
       if (sh > 2 || sh < 0) continue;      /* single-pass bracket: minShift 0, maxShift 2 */
+      if (f->num_passes > 1 && sh != 0) { jxo_modimg_free(&im); JXO_FAIL("unsupported: squeezed channels over several passes"); }      /* several passes: a channel of shift 0 always travels with the LAST pass (Passes::GetDownsamplingBracket) */
       int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift;
       int rw = f->group_dim >> fc->hshift, rh = f->group_dim >> fc->vshift;
       if (rx >= fc->w || ry >= fc->h) continue;
@@ -804,7 +805,7 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
       jxo_modimg_add(&im, rw, rh, fc->hshift, fc->vshift);
       map[nmap++] = c;
     }
-    if (pass == 0 && nmap) {
+    if (pass == f->num_passes - 1 && nmap) {
       int sid = 1 + 3 * f->num_lf_groups + 17 + f->num_groups * pass + g;
       if (jxo_modular_decode(br, &im, sid, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
       for (int i = 0; i < nmap; i++) {

@@ -113,7 +113,7 @@ ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5"]
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
-VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7"]      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
+VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7"]      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05
 # (the reference build is JXL_HIGH_PRECISION=0 + SSE2 fast paths, so last-ulp float equality is not meaningful).
