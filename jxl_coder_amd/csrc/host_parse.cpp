@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include "host_bits.h"
 
 namespace {
@@ -730,6 +731,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     if (!blend_checks(recs[i])) return -1;
     spv->blend = recs[i].blend; spv->save_canvas = recs[i].canvas_needed; spv->has_src = recs[i].src_frame >= 0; spv->alpha_ec = alpha_ec;
     if (build_frame(sub.get(), spv.get(), recs[i], /*is_shown=*/false, raw_w, raw_h)) { plan->error = sub->error; return -1; }
+    if (plan->refs.size() >= 2048) { plan->error = "unsupported: more than 2048 frames to decode for one shown frame"; return -1; }      // (a blend chain through every frame of a long animation)
     sub->save_slot = f.frame_type == 1 ? 4 : (f.save_as_ref & 3);          // slot 4: the LF image of the next frame that asks for one
     sub->save_canvas = recs[i].canvas_needed;
     plan->refs.push_back(sub);
@@ -951,6 +953,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
       }
       inv3(Bm, Bi);
       for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { T[r * 3 + c] = 0; for (int k = 0; k < 3; k++) T[r * 3 + c] += Bi[r * 3 + k] * A[k * 3 + c]; }
+      for (int k = 0; k < 9; k++) if (!std::isfinite(T[k]) || fabs(T[k]) > 1e6) { plan->error = "bad chromaticities"; return -1; }      // collinear primaries, a white point on the axis
     }
     float itscale = 255.0f / m.pub.intensity_target;
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
