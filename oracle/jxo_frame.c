@@ -443,6 +443,7 @@ typedef struct {
   const img_meta *m; frame_hdr f;
   int xb, yb;                       /* 8x8 cells */
   /* LfGlobal */
+  float noise_lut[8];
   float lf_dequant[3];
   uint32_t global_scale, quant_lf;
   int nb_lf_thr[3]; int32_t lf_thr[3][16]; int nb_qf_thr; uint32_t qf_thr[16];
@@ -470,7 +471,8 @@ static int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return
 
 static int read_lf_global(fstate *s, jxo_br *br) {
   const frame_hdr *f = &s->f;
-  if (f->flags & (1 | 2 | 16)) JXO_FAIL("unsupported: patches/splines/noise");
+  if (f->flags & (2 | 16)) JXO_FAIL("unsupported: patches/splines");
+  if (f->flags & 1) for (int i = 0; i < 8; i++) s->noise_lut[i] = (float)jxo_bits(br, 10) * (1.0f / 1024);      /* NoiseParameters: eight points of the strength curve */
   s->lf_dequant[0] = 1.0f / 4096; s->lf_dequant[1] = 1.0f / 512; s->lf_dequant[2] = 1.0f / 256;
   if (!jxo_bool(br)) for (int c = 0; c < 3; c++) s->lf_dequant[c] = jxo_f16(br) * (1.0f / 128);
   if (f->encoding == 0) {
@@ -999,6 +1001,80 @@ static void reconstruct_vardct(fstate *s) {
   for (int c = 0; c < 3; c++) free(S[c]);
 }
 
+/* Noise synthesis (libjxl: PrepareNoiseInput / RandomImage, the ConvolveNoise and AddNoise render stages; ISO/IEC 18181-1 K.5).  Three planes of pseudo-random
+   numbers: every 256 x 256 group runs its own Xorshift128+ — eight generators side by side, SplitMix64-seeded with libjxl's frame counters (advanced before the
+   frame is decoded: a still image's only frame sees (1, 0) — established on the reference binary) and the group's origin — over plane 0, 1, 2 in turn, row by
+   row; one call yields sixteen floats in [1, 2); a row takes one call per whole batch that ends BEFORE its last sample and one more for the rest.  Then per pixel
+   the 5 x 5 high-pass (0.16, centre -3.84; frame edges mirrored), x 0.22, x the strength the 8-point curve gives for (Y -/+ X) / 2, added to X, Y, B with the
+   1/128 : 127/128 correlation and the base colour correlation.  Single-frame files only (the oracle does not walk frames). */
+static inline int mirror(int x, int n);
+static uint64_t splitmix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static float noise_strength(const float *lut, float x) {
+  float sx = x * 6.0f; if (!(sx > 0.0f)) sx = 0.0f;
+  float fl = floorf(sx), fr = sx - fl;
+  if (sx >= 7.0f) { fl = 6.0f; fr = 1.0f; }
+  int i = (int)fl;
+  float v = (lut[i + 1] - lut[i]) * fr + lut[i];
+  return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
+}
+static void add_noise(fstate *s, int w, int h) {
+  const frame_hdr *f = &s->f;
+  float *nz[3];
+  for (int c = 0; c < 3; c++) nz[c] = (float *)calloc((size_t)w * (size_t)h, 4);
+  for (int gy = 0; gy < f->ygroups; gy++) for (int gx = 0; gx < f->xgroups; gx++) {
+    int x0 = gx * 256, y0 = gy * 256, xs = w - x0 < 256 ? w - x0 : 256, ys = h - y0 < 256 ? h - y0 : 256;
+    uint64_t s0[8], s1[8];
+    s0[0] = splitmix64((((uint64_t)1) << 32) + 0 + 0x9E3779B97F4A7C15ull);
+    s1[0] = splitmix64((((uint64_t)(uint32_t)x0) << 32) + (uint32_t)y0 + 0x9E3779B97F4A7C15ull);
+    for (int i = 1; i < 8; i++) { s0[i] = splitmix64(s0[i - 1]); s1[i] = splitmix64(s1[i - 1]); }
+    for (int c = 0; c < 3; c++) for (int y = 0; y < ys; y++) {
+      float *row = nz[c] + (size_t)(y0 + y) * (size_t)w + (size_t)x0;
+      int x = 0;
+      for (;;) {
+        int last = !(x + 16 < xs);
+        uint32_t batch[16];
+        for (int i = 0; i < 8; i++) {
+          uint64_t a = s0[i], b = s1[i], bits = a + b;
+          s0[i] = b; a ^= a << 23; s1[i] = a ^ b ^ (a >> 18) ^ (b >> 5);
+          batch[2 * i] = (uint32_t)bits; batch[2 * i + 1] = (uint32_t)(bits >> 32);
+        }
+        for (int k = 0; k < 16 && x + k < xs; k++) { uint32_t fb = (batch[k] >> 9) | 0x3F800000u; memcpy(&row[x + k], &fb, 4); }
+        x += 16;
+        if (last) break;
+      }
+    }
+  }
+  float ytox = s->base_x, ytob = s->base_b;
+  for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) {
+    float rnd[3];
+    for (int c = 0; c < 3; c++) {
+      float others = 0.0f;
+      for (int i = -2; i <= 2; i++) {
+        int xx = mirror(x + i, w);
+        others += nz[c][(size_t)mirror(y - 2, h) * w + xx]; others += nz[c][(size_t)mirror(y - 1, h) * w + xx];
+        others += nz[c][(size_t)mirror(y + 1, h) * w + xx]; others += nz[c][(size_t)mirror(y + 2, h) * w + xx];
+      }
+      const float *mid = nz[c] + (size_t)y * w;
+      others += mid[mirror(x - 2, w)]; others += mid[mirror(x - 1, w)]; others += mid[mirror(x + 1, w)]; others += mid[mirror(x + 2, w)];
+      rnd[c] = (others * 0.16f + mid[x] * -3.84f) * 0.22f;
+    }
+    size_t po = (size_t)y * (size_t)s->pw + (size_t)x;
+    float vx = s->plane[0][po], vy = s->plane[1][po];
+    float sg = noise_strength(s->noise_lut, (vy - vx) * 0.5f), sr = noise_strength(s->noise_lut, (vy + vx) * 0.5f);
+    float red = sr * (0.0078125f * rnd[0] + 0.9921875f * rnd[2]);
+    float green = sg * (0.0078125f * rnd[1] + 0.9921875f * rnd[2]);
+    float rg = red + green;
+    s->plane[0][po] = (ytox * rg + (red - green)) + vx;
+    s->plane[1][po] = vy + rg;
+    s->plane[2][po] = ytob * rg + s->plane[2][po];
+  }
+  for (int c = 0; c < 3; c++) free(nz[c]);
+}
+
 /* Chroma upsampling of a YCbCr frame (libjxl's render stages HChromaUps, then VChromaUps, before the loop filters): a subsampled channel of
    cw = ceil(w / 2) samples per row becomes out[2x] = 0.25 in[x - 1] + 0.75 in[x], out[2x + 1] = 0.25 in[x + 1] + 0.75 in[x] (the product 0.75 in[x]
    first, then multiply and add, each rounded: the reference's libjxl is an SSE2 build without fused multiply-add), mirrored at the channel's edges. */
@@ -1345,6 +1421,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
     if (jxo_debug) { FILE *fp = fopen("/tmp/jxo_xyb.bin", "wb"); for (int c = 0; c < 3; c++) fwrite(s->plane[c], 4, (size_t)s->pw * (size_t)s->ph, fp); fclose(fp); }
     if (f->gab) gaborish(s, w, h);
     if (f->epf_iters) epf(s, w, h);
+    if (f->flags & 1) add_noise(s, w, h);
     for (int c = 0; c < 3; c++) rgb[c] = (float *)malloc(4 * npx);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int c = 0; c < 3; c++) rgb[c][(size_t)y * (size_t)w + (size_t)x] = s->plane[c][(size_t)y * (size_t)s->pw + (size_t)x];
   } else {
