@@ -11,7 +11,8 @@
 
 namespace jxlamd {
 
-constexpr int kLocMaxClusters = 64;
+constexpr int kLocMaxClusters = 64;       // clusters whose configurations (and alias tables) the streams stage in LDS; codes with more read them from HBM
+constexpr int kLeafMaxClusters = 256;     // a context map's entries are bytes: no code has more
 constexpr int kLocMaxCtx = 4096;
 constexpr int kLocMaxNodes = 2 * kLocMaxCtx;
 constexpr int kLocPool = 1 << 16;
@@ -23,31 +24,36 @@ struct LocalTmp {
   uint8_t logc[258]; uint16_t same[258]; int16_t cnt[258];
   uint16_t cut[256], under[512], over[512]; uint8_t right[256]; uint16_t off[256];
   uint32_t offs[17], cloffs[17]; int32_t sym[4]; uint8_t cll[18]; uint16_t clsorted[18];
-  uint8_t mtf[256]; uint16_t counts[kLocMaxClusters]; uint16_t D[256];
+  uint8_t mtf[256]; uint16_t counts[kLeafMaxClusters]; uint16_t D[256];
   DevPrefix clp;
 };
 
-struct LocalEC {
+template <int NC>
+struct LocalECT {
+  static constexpr int kMaxClusters = NC;
   LocalTmp tmp;
   uint8_t ctx_map[kLocMaxCtx + 8];
-  uint32_t cfg[kLocMaxClusters];
-  DevAlias alias[kLocMaxClusters * 256];
-  DevPrefix prefix[kLocMaxClusters];
+  uint32_t cfg[NC];
+  DevAlias alias[NC * 256];
+  DevPrefix prefix[NC];
   uint16_t pool[kLocPool];
   uint32_t pool_used;
   int32_t num_ctx, num_clusters, use_prefix, log_alpha;
 };
+using LocalEC = LocalECT<kLeafMaxClusters>;      // a leaf code: up to 256 clusters (libjxl's encoder goes past 64 with squeezed channels at effort 7)
+using LocalECSmall = LocalECT<8>;                // the tree's own code (6 contexts) and the nested code of a context map (1)
 
 struct LocalTreeScratch {       // per LF group, reused by its two streams
-  LocalEC tree_code;            // 6 contexts
+  LocalECSmall tree_code;       // 6 contexts
   LocalEC leaf_code;
-  LocalEC nested;               // for entropy-coded context maps
+  LocalECSmall nested;          // for entropy-coded context maps
   DevTreeNode nodes[kLocMaxNodes];
   uint8_t lens[1 << 15];        // prefix-code lengths scratch
   int32_t count;
 };
 
-JXL_DEV DevECView local_view(const LocalEC &e) {
+template <class EC>
+JXL_DEV DevECView local_view(const EC &e) {
   DevECView v;
   v.ctx_map = e.ctx_map; v.cfg = e.cfg; v.alias = e.alias; v.prefix = e.prefix; v.pool = e.pool;
   v.use_prefix = e.use_prefix; v.log_alpha = e.log_alpha;
@@ -180,7 +186,8 @@ JXL_DEV void d_build_alias(const uint16_t *D, int log_alpha, DevAlias *a, LocalT
 }
 
 // canonical code from lengths -> DevPrefix (+ symbols appended to the pool)
-JXL_DEV uint32_t d_build_canonical(LocalEC &ec, DevPrefix &p, const uint8_t *lens, int n) {
+template <class EC>
+JXL_DEV uint32_t d_build_canonical(EC &ec, DevPrefix &p, const uint8_t *lens, int n) {
   for (int l = 0; l < 16; l++) p.cnt[l] = 0;
   int nz = 0, last = -1;
   for (int i = 0; i < n; i++) if (lens[i]) { p.cnt[lens[i]]++; nz++; last = i; }
@@ -206,7 +213,8 @@ JXL_DEV int d_prefix_decode_raw(const DevPrefix &p, const uint16_t *pool, DevBit
   return 0;
 }
 
-JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8_t *lens, int alphabet) {
+template <class EC>
+JXL_DEV uint32_t d_read_prefix_code(DevBits &b, EC &ec, DevPrefix &p, uint8_t *lens, int alphabet) {
   for (int i = 0; i < alphabet; i++) lens[i] = 0;
   if (alphabet == 1) { uint32_t e = d_build_canonical(ec, p, lens, 1); p.single = 0; return e; }
   int hskip = (int)bits_read(b, 2);
@@ -273,10 +281,10 @@ JXL_DEV uint32_t d_read_prefix_code(DevBits &b, LocalEC &ec, DevPrefix &p, uint8
 
 // The nested code of an entropy-coded context map has a single context, so it never carries a context map itself:
 // two template instances instead of recursion keep everything inlined (no call stack, no scratch).
-template <bool kNested>
-JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens, LocalTmp *fast_tmp = nullptr);
+template <bool kNested, class EC>
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, EC &ec, LocalECSmall *nested, uint8_t *lens, LocalTmp *fast_tmp = nullptr);
 
-JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_clusters, LocalEC *nested, uint8_t *lens) {
+JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_clusters, LocalECSmall *nested, uint8_t *lens) {
   uint32_t err = 0;
   if (bits_read(b, 1)) {
     int nb = (int)bits_read(b, 2);
@@ -311,8 +319,8 @@ JXL_DEV uint32_t d_read_ctx_map(DevBits &b, uint8_t *map, int n, int &num_cluste
   return err;
 }
 
-template <bool kNested>
-JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalEC *nested, uint8_t *lens, LocalTmp *fast_tmp) {
+template <bool kNested, class EC>
+JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, EC &ec, LocalECSmall *nested, uint8_t *lens, LocalTmp *fast_tmp) {
   uint32_t err = 0;
   if (kNested && num_ctx != 1) return kErrBitstream;
   if (num_ctx > kLocMaxCtx) return kErrUnsupportedTransform;
@@ -321,7 +329,7 @@ JXL_DEV uint32_t d_ec_read_header_t(DevBits &b, int num_ctx, LocalEC &ec, LocalE
   ec.num_clusters = 1;
   for (int i = 0; i < num_ctx; i++) ec.ctx_map[i] = 0;
   if (!kNested && num_ctx > 1) { err |= d_read_ctx_map(b, ec.ctx_map, num_ctx, ec.num_clusters, nested, lens); if (err) return err; }
-  if (ec.num_clusters > kLocMaxClusters) return kErrUnsupportedTransform;
+  if (ec.num_clusters > num_ctx || ec.num_clusters > EC::kMaxClusters) return kErrBitstream;      // more clusters than contexts: libjxl refuses that
   ec.use_prefix = (int)bits_read(b, 1);
   ec.log_alpha = ec.use_prefix ? 15 : 5 + (int)bits_read(b, 2);
   for (int i = 0; i < ec.num_clusters; i++) ec.cfg[i] = d_read_huc(b, ec.log_alpha, err);

@@ -142,8 +142,16 @@ JXL_DEV void mod_flag(const DevBuffers &B, uint32_t f) {
   *B.err |= f | kErrStageRecon;
 #endif
 }
-// colour `index` of channel c (H.6.4): an explicit palette entry, or — beyond the palette — the implicit 4x4x4 / 5x5x5 colour cubes
+#include "delta_palette.h"
+// colour `index` of channel c (H.6.4): an explicit palette entry, beyond the palette the implicit 4x4x4 / 5x5x5 colour cubes, below zero one of 143 implicit
+// delta entries (always added to the prediction: a negative index is below any nb_deltas)
 JXL_DEV int32_t palette_value(const int32_t *pal, int psize, int index, int c, int bit_depth) {
+  if (index < 0) {
+    if (c >= 3) return 0;
+    const int k = (int)((uint32_t)(-(index + 1)) % 143u);
+    const int32_t v = (k & 1) ? (int32_t)kDeltaPalette[(k + 1) >> 1][c] : -(int32_t)kDeltaPalette[(k + 1) >> 1][c];
+    return bit_depth > 8 ? v * (1 << (bit_depth - 8)) : v;
+  }
   if (index >= psize && index < psize + 64) {
     if (c >= 3) return 0;
     index -= psize;
@@ -206,7 +214,7 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
       const DevTr &t = S.trs.t[i];
       if (t.id == 0) { if (t.begin_c + 3 > cnt) S.st.err = kErrBitstream; }
       else if (t.id == 1) {
-        if (t.num_c < 1 || t.num_c > 4 || t.nb_deltas > 0 || t.begin_c < nmeta) { S.st.err = kErrPalette; break; }      // delta entries / palettes of meta channels: not on the device
+        if (t.num_c < 1 || t.num_c > 4 || t.nb_deltas > 0 || t.d_pred != 0 || t.begin_c < nmeta) { S.st.err = kErrPalette; break; }      // predicted (delta) entries in a group's own palette / palettes of meta channels: not on the device
         if (t.begin_c + t.num_c > cnt || cnt + 1 > kModMaxCh) { S.st.err = kErrBitstream; break; }
         const size_t need = (size_t)t.nb_colours * (size_t)t.num_c;
         if (pal_used + need > (size_t)gd * (size_t)gd) { S.st.err = kErrPalette; break; }
@@ -248,15 +256,12 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     // palette: S.ch[0] holds the colours, S.ch[begin_c + 1] the indices; colour 0 replaces the indices, colours 1.. go to the folded channels' buffers
     const DevChanOut pal = S.ch[0], ix = S.ch[t.begin_c + 1];
     const int bit_depth = F.mod_bits < 24 ? F.mod_bits : 24;
-    bool neg = false;
     for (int k = tid; k < ix.w * ix.h; k += nthreads) {
       int index = ix.d[k];
-      if (index < 0) { neg = true; index = 0; }
-      if (t.num_c == 1 && index > pal.w - 1) index = pal.w - 1;
+      if (t.num_c == 1) index = index < 0 ? 0 : index > pal.w - 1 ? pal.w - 1 : index;      // (several channels: an index below zero is an implicit delta entry over a prediction of zero)
       ix.d[k] = palette_value(pal.d, pal.w, index, 0, bit_depth);
       for (int c = 1; c < t.num_c; c++) S.pal_saved[i][c - 1].d[k] = palette_value(pal.d, pal.w, index, c, bit_depth);
     }
-    if (neg) mod_flag(B, kErrPalette);
     sync();
     if (tid == 0) {
       int cnt = S.grp_dec;
@@ -325,8 +330,7 @@ JXL_DEV void mod_op_element(const DevBuffers &B, const DevFrame &F, int op, size
     const int32_t *pal = mod_plane(B, F, F.mod_op_b[op]);
     const int psize = F.mod_op_x[op], bit_depth = F.mod_op_y[op] < 24 ? F.mod_op_y[op] : 24, nc = F.mod_op_e[op];
     int index = *v;
-    if (index < 0) { mod_flag(B, kErrPalette); index = 0; }           // implicit delta-palette entries (libjxl's lossy palette): not on the device
-    if (nc == 1 && index > psize - 1) index = psize - 1;             // the single-channel form clamps the index
+    if (nc == 1) index = index < 0 ? 0 : index > psize - 1 ? psize - 1 : index;      // the single-channel form clamps the index; otherwise an index below zero is an implicit delta entry, added to a prediction of zero (this form: no deltas, predictor Zero)
     *v = palette_value(pal, psize, index, 0, bit_depth);
     for (int c = 1; c < nc; c++) mod_plane(B, F, F.mod_op_d[op] + c - 1)[i] = palette_value(pal, psize, index, c, bit_depth);
   } else {                                  // kind 4: palette with delta entries: work item = colour channel, pixels in raster order
@@ -340,8 +344,7 @@ JXL_DEV void mod_op_element(const DevBuffers &B, const DevFrame &F, int op, size
       int32_t *row = out + (size_t)y * (size_t)w;
       const int32_t *rN = y > 0 ? row - w : nullptr, *rNN = y > 1 ? row - 2 * w : nullptr;
       for (int x = 0; x < w; x++) {
-        int index = idx[(size_t)y * (size_t)w + (size_t)x];
-        if (index < 0) { mod_flag(B, kErrPalette); index = 0; }
+        const int index = idx[(size_t)y * (size_t)w + (size_t)x];
         int64_t v = palette_value(pal, psize, index, c, bit_depth);
         if (index < nb_deltas) {
           const int64_t W = x > 0 ? row[x - 1] : (rN ? rN[x] : 0);

@@ -307,9 +307,9 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
       for (int c = 1; c < t.num_c; c++)
         if (L[(size_t)t.begin_c + c].w != L[(size_t)t.begin_c].w || L[(size_t)t.begin_c + c].h != L[(size_t)t.begin_c].h || L[(size_t)t.begin_c + c].hs != L[(size_t)t.begin_c].hs ||
             L[(size_t)t.begin_c + c].vs != L[(size_t)t.begin_c].vs) { plan->error = "palette over channels of different size"; return -1; }
-      // meta-apply: the num_c channels collapse into one index channel at begin_c, the palette (nb_colours x num_c) becomes meta channel 0
+      // meta-apply: the num_c channels collapse into one index channel at begin_c, the palette ((nb_colours + nb_deltas) x num_c: the delta entries first) becomes meta channel 0
       L.erase(L.begin() + t.begin_c + 1, L.begin() + t.begin_c + t.num_c);
-      L.insert(L.begin(), {t.nb_colours, t.num_c, -1, -1, -1});
+      L.insert(L.begin(), {t.nb_colours + t.nb_deltas, t.num_c, -1, -1, -1});
       nb_meta++;
     } else if (t.id == 2) {
       // Squeeze (H.6.2): explicit steps, or — num_sq == 0 — the default sequence derived from the channel list
@@ -434,10 +434,10 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     } else {
       // inverse palette: the index channel (now at begin_c + 1, behind the palette meta channel) becomes num_c colour channels
       const Ch ix = L[(size_t)t.begin_c + 1];
-      const bool deltas = t.nb_deltas > 0;
+      const bool deltas = t.nb_deltas > 0 || t.d_pred != 0;      // entries added to a prediction of the pixel (explicit ones, or implicit ones = indices below zero): raster order per channel
       F.mod_op_kind[o] = deltas ? 4 : 1;
       F.mod_op_a[o] = ix.plane; F.mod_op_b[o] = L[0].plane;
-      F.mod_op_x[o] = t.nb_colours; F.mod_op_e[o] = t.num_c;
+      F.mod_op_x[o] = t.nb_colours + t.nb_deltas; F.mod_op_e[o] = t.num_c;
       F.mod_op_f[o] = t.nb_deltas; F.mod_op_g[o] = t.d_pred; F.mod_op_h[o] = ix.w;
       F.mod_op_y[o] = deltas ? (F.mod_bits | (ix.h << 8)) : F.mod_bits;
       F.mod_op_c[o] = deltas ? t.num_c : ix.w * ix.h;

@@ -289,7 +289,7 @@ static int meta_apply(jxo_modimg *img, const jxo_transform *t) {
     int hs = img->ch[b].hshift, vs = img->ch[b].vshift;
     (void)hs; (void)vs;
     modimg_erase(img, b + 1, t->num_c - 1);
-    modimg_insert(img, 0, t->nb_colours, t->num_c, -1, -1);
+    modimg_insert(img, 0, t->nb_colours + t->nb_deltas, t->num_c, -1, -1);
     return 0;
   }
   /* Squeeze (ISO/IEC 18181-1 H.6.2; what libjxl's MetaSqueeze does under JxlDecoderProcessInput, reference call site
@@ -378,9 +378,15 @@ static int inv_squeeze(jxo_modimg *img, const jxo_transform *t) {
   return 0;
 }
 
+#include "jxo_delta_palette.h"
 static int32_t palette_value(const jxo_chan *pal, int index, int c, int bit_depth) {
   int psize = pal->w;
-  if (index < 0) return 0;   /* delta palette: unsupported, caller rejects */
+  if (index < 0) {           /* implicit delta entries: 143 of them, +/- the rows of the table */
+    if (c >= 3) return 0;
+    int k = (int)((uint32_t)(-(index + 1)) % 143u);
+    int32_t v = (k & 1) ? kJxoDeltaPalette[(k + 1) >> 1][c] : -kJxoDeltaPalette[(k + 1) >> 1][c];
+    return bit_depth > 8 ? v * (1 << (bit_depth - 8)) : v;
+  }
   if (psize <= index && index < psize + 64) {
     if (c >= 3) return 0;
     index -= psize;
@@ -412,8 +418,7 @@ static int inv_palette(jxo_modimg *img, const jxo_transform *t) {
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
         int index = idx[(size_t)y * (size_t)w + (size_t)x];
-        if (index < 0) { free(idx); JXO_FAIL("unsupported: implicit delta palette entries"); }
-        if (t->nb_deltas == 0 && t->d_pred == 0 && nb == 1) { if (index > pal->w - 1) index = pal->w - 1; }
+        if (t->nb_deltas == 0 && t->d_pred == 0 && nb == 1) index = index < 0 ? 0 : index > pal->w - 1 ? pal->w - 1 : index;
         int64_t v = palette_value(pal, index, c, bit_depth);
         if (index < t->nb_deltas) {
           int32_t *row = out + (size_t)y * (size_t)w;
@@ -520,7 +525,7 @@ int jxo_modular_decode(jxo_br *br, jxo_modimg *img, int stream_id, int max_chan_
       if (num_sq == 0) { if (img->nch - img->nb_meta < 1) JXO_FAIL("squeeze without channels"); default_squeeze(img, t); }
     } else JXO_FAIL("bad transform id");
     if (br->err) JXO_FAIL("truncated modular header");
-    { extern int jxo_debug; if (jxo_debug > 1) fprintf(stderr, "dbg transforms: stream %d id %d begin_c %d rct %d num_c %d nbcol %d\n", stream_id, t->id, t->begin_c, t->rct_type, t->num_c, t->nb_colours); }
+    { extern int jxo_debug; if (jxo_debug > 1) fprintf(stderr, "dbg transforms: stream %d id %d begin_c %d rct %d num_c %d nbcol %d nbdeltas %d pred %d\n", stream_id, t->id, t->begin_c, t->rct_type, t->num_c, t->nb_colours, t->nb_deltas, t->d_pred); }
     if (meta_apply(img, t)) return -1;
     img->ntr++;
   }

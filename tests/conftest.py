@@ -85,13 +85,15 @@ LOSSLESS_CASES = LOSSLESS_CASES + SQUEEZE_LOSSLESS_CASES
 # Non-photographic content from the reference's encoder at its defaults (tools/synth.py: screenshot / flat / gradient / two_colour / many_colours):
 # multi-channel palettes (e1 / e3), palettes local to a group stream, > 256 palette entries, RGBA.  Single-frame files: the C oracle decodes them too.
 NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls700x500_e7_nopatch", "lgrad400x300_e7", "lgrad2d200x150_e3", "lflat400x300_e7",
-                           "l2c400x300_e7", "lmany128x96_e3"]
+                           "l2c400x300_e7", "lmany128x96_e3",
+                           "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
+                           "lra400x300_e7"]                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
 # encoder writes for text / UI content at effort >= 5, lossless and lossy.  Two frames: pinned on the reference binary's output only (the C oracle does
 # not walk multi-frame files), on the CPU harness and on the GPU.
-PATCH_LOSSLESS_CASES = ["ls400x300_e7", "ls700x500_e5", "lsa400x300_e7"]
+PATCH_LOSSLESS_CASES = ["ls400x300_e7", "ls700x500_e5", "lsa400x300_e7", "lpl400x300_e7"]
 PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",      # VarDCT main frame, XYB Modular reference frame
                       # Upsampling 2x / 4x / 8x (K: frames coded at a fraction of their size; the reference's quality <= 12), the last one with patches too
                       "vu400x300_e7_d10", "vu523x267_e7_up4", "vu523x267_e7_up8", "vus400x300_e7_d12",

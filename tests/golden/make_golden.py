@@ -80,7 +80,13 @@ CASES = {
     "lflat400x300_e7": (400, 300, dict(gen="flat"), dict(lossless=True, effort=7)),
     "l2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(lossless=True, effort=7)),
     "lmany128x96_e3": (128, 96, dict(gen="many_colours", seed=5), dict(lossless=True, effort=3)),          # palette of ~1000 colours (beyond 256 entries)
+    # lossy palette (JXL_ENC_FRAME_SETTING_LOSSY_PALETTE = 23): delta palettes — explicit delta entries in front of the colours (the palette channel is
+    # nb_colours + nb_deltas wide), indices below zero = the 143 implicit deltas, every delta added to the Average4 prediction of the pixel (raster order)
+    "lpl400x300_e7_nopatch": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1), (8, 0)))),   # 7 colours + 12 explicit deltas
+    "lpl200x136_e7_photo": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((23, 1), (8, 0)))),                        # 1024 colours, implicit deltas only
+    "lra400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # squeezed RGBA at effort 7: group streams whose own leaf codes have more than 64 clusters
     "ls400x300_e7": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=7)),              # patches
+    "lpl400x300_e7": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1),))),                   # lossy palette in the patch frame and in the main frame
     "ls700x500_e5": (700, 500, dict(gen="screenshot", seed=2), dict(lossless=True, effort=5)),              # patches over several groups
     "lsa400x300_e7": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(lossless=True, effort=7)), # patches + alpha
     "vs400x300_e7_d1": (400, 300, dict(gen="screenshot", seed=1), dict(effort=7, distance=1.0)),

@@ -1,0 +1,127 @@
+"""Which files of the reference's encoder does the product's host parser + device code (CPU harness, tests/emul) decode, and how far from the
+reference's decoder?  A sweep over encoder settings: prints one line per case.  Needs /root/reference (oracle/_ref): a development tool.
+
+    python tools/probe_features.py [substring]
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import jxl_ref        # noqa: E402
+import synth          # noqa: E402
+import jxl_coder_amd as J        # noqa: E402
+
+# libjxl frame-setting ids (encode.h)
+RESAMPLING, EC_RESAMPLING, PHOTON, NOISE, DOTS, PATCHES, EPF, GAB, MODULAR, KEEP_INVIS, GROUP_ORDER = 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13
+RESPONSIVE, PROG_AC, QPROG_AC, PROG_DC, PALETTE_COLORS, LOSSY_PALETTE, COLOR_TRANSFORM, MOD_COLORSPACE, MOD_GROUP, MOD_PRED, NB_PREV = 16, 17, 18, 19, 22, 23, 24, 25, 26, 27, 29
+
+
+def emul_lib():
+    so = os.path.join(ROOT, "tests", "emul", "libjxlemul.so")
+    lib = C.CDLL(so)
+    lib.emul_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.emul_last_error.restype = C.c_char_p
+    return lib
+
+
+def emul_decode(lib, data):
+    w, h = J.JxlCoder.getSize(data)
+    buf = np.zeros(w * h * 8, np.uint8)
+    cw, ch, cb = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = lib.emul_decode(data, len(data), 1, buf.ctypes.data, buf.nbytes, C.byref(cw), C.byref(ch), C.byref(cb))
+    if rc:
+        return None, lib.emul_last_error().decode()
+    n = cw.value * ch.value * 4 * (cb.value // 8)
+    return buf[:n].view(np.uint16 if cb.value == 16 else np.uint8).reshape(ch.value, cw.value, 4), ""
+
+
+def cases():
+    ph = synth.photo_like(400, 300, seed=5)
+    pha = synth.photo_like(400, 300, seed=6, channels=4)
+    big = synth.photo_like(700, 520, seed=7)
+    biga = synth.photo_like(700, 520, seed=8, channels=4)
+    shot = synth.screenshot(400, 300, seed=2)
+    grey = synth.photo_like(300, 200, seed=9, channels=1)
+    ph16 = synth.photo_like(300, 200, seed=10, bits=16)
+    yield "rgba d1 qprog_ac + responsive", pha, dict(distance=1.0, extra=((QPROG_AC, 1), (RESPONSIVE, 1)))
+    yield "rgba d1 prog_ac + responsive", pha, dict(distance=1.0, extra=((PROG_AC, 1), (RESPONSIVE, 1)))
+    yield "rgb d1 prog_ac + qprog_ac", ph, dict(distance=1.0, extra=((PROG_AC, 1), (QPROG_AC, 1)))
+    yield "rgb d1 prog_ac", ph, dict(distance=1.0, extra=((PROG_AC, 1),))
+    yield "rgb d2 prog_dc 2", big, dict(distance=2.0, extra=((PROG_DC, 2),))
+    yield "rgb d1 prog_dc 1 + qprog_ac", big, dict(distance=1.0, extra=((PROG_DC, 1), (QPROG_AC, 1)))
+    yield "rgba d12 (auto resampling?)", pha, dict(distance=12.0)
+    yield "rgba d20", pha, dict(distance=20.0)
+    yield "rgb d25", ph, dict(distance=25.0)
+    yield "rgba d2 resampling 2", pha, dict(distance=2.0, extra=((RESAMPLING, 2),))
+    yield "rgba d2 ec_resampling 2", pha, dict(distance=2.0, extra=((EC_RESAMPLING, 2),))
+    yield "rgb d2 noise + resampling 2", ph, dict(distance=2.0, extra=((NOISE, 1), (RESAMPLING, 2)))
+    yield "rgb d5 (auto prog_dc)", big, dict(distance=5.0)
+    yield "rgba d5", biga, dict(distance=5.0)
+    yield "rgb lossy modular d1", ph, dict(distance=1.0, modular=1)
+    yield "rgba lossy modular d1", pha, dict(distance=1.0, modular=1)
+    yield "rgb lossy modular d3 responsive 0", ph, dict(distance=3.0, modular=1, extra=((RESPONSIVE, 0),))
+    yield "shot lossy palette", shot, dict(lossless=True, extra=((LOSSY_PALETTE, 1),))
+    yield "rgb group order centre", big, dict(distance=1.0, extra=((GROUP_ORDER, 1),))
+    yield "rgb lossless group order centre", big, dict(lossless=True, effort=3, extra=((GROUP_ORDER, 1),))
+    yield "rgb d1 dots", ph, dict(distance=1.0, extra=((DOTS, 1),))
+    yield "grey d1", grey, dict(distance=1.0)
+    yield "grey lossless", grey, dict(lossless=True)
+    yield "rgb16 d1", ph16, dict(distance=1.0)
+    yield "rgb16 lossless e7", ph16, dict(lossless=True)
+    yield "rgb lossless e9 shot", shot, dict(lossless=True, effort=9)
+    yield "rgba lossless responsive", pha, dict(lossless=True, extra=((RESPONSIVE, 1),))
+    yield "rgb lossless nb_prev 3", ph, dict(lossless=True, effort=7, extra=((NB_PREV, 3),))
+    yield "rgb lossless e9 nb_prev", ph, dict(lossless=True, effort=9)
+    for ds in (1, 2, 3, 4):
+        yield f"rgb d1 decoding_speed {ds}", ph, dict(distance=1.0, decoding_speed=ds)
+    for e in (1, 2, 4, 5, 6, 8, 9):
+        yield f"rgb d1 effort {e}", ph, dict(distance=1.0, effort=e)
+    for e in (1, 2, 4, 5, 6, 8):
+        yield f"rgba lossless effort {e}", pha, dict(lossless=True, effort=e)
+    for wh in ((1, 1), (1, 17), (17, 1), (8, 8), (9, 7), (257, 3)):
+        im = synth.photo_like(wh[0], wh[1], seed=11)
+        yield f"rgb d1 {wh[0]}x{wh[1]}", im, dict(distance=1.0)
+        yield f"rgb lossless {wh[0]}x{wh[1]}", im, dict(lossless=True)
+    yield "rgb d0.1", ph, dict(distance=0.1)
+    yield "rgb d0.05 e3", ph, dict(distance=0.05, effort=3)
+    yield "rgb hard d0.1", synth.photo_like(256, 256, seed=3, hard=True), dict(distance=0.1)
+    yield "rgb keep invisible lossless", pha, dict(lossless=True, extra=((KEEP_INVIS, 1),))
+    yield "rgb lossless colour transform none", ph, dict(lossless=True, extra=((COLOR_TRANSFORM, 1),))
+    yield "rgb d1 colour transform none (non-XYB VarDCT)", ph, dict(distance=1.0, extra=((COLOR_TRANSFORM, 1),))
+    yield "rgb d1 colour transform ycbcr", ph, dict(distance=1.0, extra=((COLOR_TRANSFORM, 2),))
+    yield "rgb lossless modular group 0 (128)", big, dict(lossless=True, effort=3, extra=((MOD_GROUP, 0),))
+    yield "rgb lossless modular group 3 (1024)", big, dict(lossless=True, effort=3, extra=((MOD_GROUP, 3),))
+    for p in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+        yield f"rgb lossless predictor {p}", ph[:120, :160], dict(lossless=True, effort=4, extra=((MOD_PRED, p),))
+
+
+def main():
+    sub = sys.argv[1] if len(sys.argv) > 1 else ""
+    lib = emul_lib()
+    for name, img, kw in cases():
+        if sub not in name:
+            continue
+        try:
+            data = jxl_ref.encode(img, **kw)
+        except Exception as e:      # noqa: BLE001
+            print(f"{name:48s} ENCODE FAILED {e}")
+            continue
+        ref = jxl_ref.decode(data)
+        got, err = emul_decode(lib, data)
+        if got is None:
+            print(f"{name:48s} {len(data):8d} B  REJECT {err}")
+            continue
+        r = np.asarray(ref[0])
+        if r.shape != got.shape or r.dtype != got.dtype:
+            print(f"{name:48s} {len(data):8d} B  SHAPE {r.shape} {r.dtype} vs {got.shape} {got.dtype}")
+            continue
+        d = np.abs(r.astype(np.int64) - got.astype(np.int64))
+        print(f"{name:48s} {len(data):8d} B  ok max {int(d.max())} mean {float(d.mean()):.4f}")
+
+
+if __name__ == "__main__":
+    main()
