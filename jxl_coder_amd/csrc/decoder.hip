@@ -209,7 +209,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
       HIPCHECK(S.mod_scratch.ensure(mod_scratch_total_ints(*Fh, plan.num_groups, plan.num_lf_groups) * 4 + 256));      // + 1: the GlobalModular stream's slot
       HIPCHECK(S.local.ensure((size_t)std::max(plan.num_groups, plan.num_lf_groups) * sizeof(LocalTreeScratch)));
-      HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * 8));
+      HIPCHECK(S.pass_end.ensure((size_t)plan.num_groups * (size_t)plan.num_passes * 8));
     }
   } else {
     if (Fh->lz_win_len) HIPCHECK(S.lz_win.ensure(((size_t)Fh->lz_win_len + (size_t)plan.num_groups * (size_t)Fh->lz_win_group) * 4));

@@ -167,9 +167,11 @@ JXL_DEV int32_t palette_value(const int32_t *pal, int psize, int index, int c, i
   return pal[(size_t)c * (size_t)psize + (size_t)index];
 }
 
-// ---- one 256x256 group of the remaining channels
+// ---- one 256x256 group of the remaining channels: the ModularGroup stream of one pass.  A pass carries the channels whose shift (the smaller of the two: squeeze)
+// lies in the pass's bracket (Passes::GetDownsamplingBracket; DevFrame::pass_min_shift / pass_max_shift — a single pass takes 0..2, shifts of 3 and more travel in the
+// ModularLfGroup streams); a pass without such a channel in this group has no stream.  Returns false when the group's decode must stop (flagged).
 template <class Sync>
-JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, int pass, int tid, int nthreads, Sync sync) {
   if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xgroups, gy = g / F.xgroups;
@@ -179,13 +181,11 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
   int32_t *scr = B.mod_scratch + (size_t)g * mod_group_scratch_ints(F);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-    // the ModularGroup stream of a VarDCT frame's extra channels follows the group's AC stream of the LAST pass (a channel of shift 0 always belongs to the last pass:
-    // Passes::GetDownsamplingBracket; the host rejects squeezed extra channels on multi-pass frames); Modular frames are single-pass
-    const int last_pass = F.is_modular ? 0 : F.num_passes - 1;
-    const DevSection sec = secs[2 + F.num_lf_groups + last_pass * F.num_groups + g];
+    // the ModularGroup stream of a VarDCT frame's extra channels follows the group's AC stream of the same pass
+    const DevSection sec = secs[F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g];
     DevBits b;
     if (F.is_modular) bits_init(b, B.codestream, sec.off, F.cs_size);
-    else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
+    else bits_init_at_bit(b, B.codestream, sec.off, B.pass_end_bits[(size_t)pass * (size_t)F.num_groups + (size_t)g], F.cs_size);   // VarDCT + extra channels: after the group's AC stream
     S.st.b = b;
     S.lz.win = (B.lz_win && F.lz_win_len) ? B.lz_win + (size_t)F.lz_win_len + (size_t)g * (size_t)F.lz_win_group : nullptr; S.lz.win_len = F.lz_win_group;
     S.wide_wp = (uint32_t *)(scr + (size_t)(nch + 1) * (size_t)gd * (size_t)gd);
@@ -195,7 +195,8 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     for (int c = 0; c < nch; c++) {
       const int fc = F.mod_first_group_ch + c;
       const int hs = F.mod_hs[fc], vs = F.mod_vs[fc];
-      if ((hs < vs ? hs : vs) >= 3) continue;
+      const int sh = hs < vs ? hs : vs;
+      if (sh < F.pass_min_shift[pass] || sh > F.pass_max_shift[pass]) continue;
       int rw = F.mod_w[fc] - (x0 >> hs), rh = F.mod_h[fc] - (y0 >> vs);
       const int gw = gd >> hs, gh = gd >> vs;
       rw = rw < 0 ? 0 : rw > gw ? gw : rw; rh = rh < 0 ? 0 : rh > gh ? gh : rh;
@@ -233,15 +234,16 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
     if (S.st.err) *B.err |= S.st.err | kErrStagePass;
   }
   sync();
-  if (S.st.err || S.grp_n == 0) return;                 // no channel of the frame reaches this group: the stream is empty (not even a header)
+  if (S.st.err) return false;
+  if (S.grp_n == 0) return true;                        // no channel of the frame reaches this group in this pass: the stream is empty (not even a header)
   modular_stream_stage(S, tid, nthreads);
   sync();
   const int nst = S.grp_n;
-  const int sid = 1 + 3 * F.num_lf_groups + 17 + (F.is_modular ? 0 : F.num_passes - 1) * F.num_groups + g;      // ModularAC(group, pass)
+  const int sid = 1 + 3 * F.num_lf_groups + 17 + pass * F.num_groups + g;      // ModularAC(group, pass)
   uint32_t e = mod_decode_stream(S, S.ch, S.grp_dec, sid, tid);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
   sync();
-  if (S.st.err) return;
+  if (S.st.err) return false;
   // undo this group's own transforms (last one first), then copy the rectangles into the full planes
   for (int i = S.trs.n - 1; i >= 0; i--) {
     const DevTr t = S.trs.t[i];
@@ -282,6 +284,16 @@ JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int ti
       const int y = i / ch.w, x = i - y * ch.w;
       dst[(size_t)(cy0 + y) * (size_t)F.mod_w[fc] + (size_t)(cx0 + x)] = ch.d[i];
     }
+  }
+  return true;
+}
+
+template <class Sync>
+JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+  const int np = frame_of(B).num_passes;
+  for (int pass = 0; pass < np; pass++) {
+    if (!mod_group_pass_body(B, S, g, pass, tid, nthreads, sync)) return;
+    sync();                                               // the next pass reuses the stream state and the channel list
   }
 }
 

@@ -232,7 +232,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
   if (g >= 0 && !err) {
     if (state != 0x130000u) err = kErrAnsFinal;
     else if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) err = kErrBitstream;
-    else if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
+    else if (F.has_ec) B.pass_end_bits[(size_t)pass * (size_t)F.num_groups + (size_t)g] = b.consumed;
   }
   return err;
 }

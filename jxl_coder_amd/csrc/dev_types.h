@@ -59,6 +59,7 @@ struct DevFrame {
   int32_t xlfg, ylfg, num_lf_groups;         // 2048x2048
   int32_t num_passes;
   int32_t pass_shift[12];
+  int32_t pass_min_shift[4], pass_max_shift[4];   // Modular channels of a pass: those whose shift lies in [min, max] (Passes::GetDownsamplingBracket); one pass: 0..2
   // quantiser / LF
   float lf_fac[3];                 // lf_dequant[c] * 65536/(global_scale*quant_lf)
   float cfl_dc_x, cfl_dc_b;

@@ -34,7 +34,7 @@ struct DevBuffers {
   uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
   uint32_t *big_count;          // [3] their counts
   uint64_t *mod_end_bit;        // [1]: where the GlobalModular stream of an extra-channel frame ended (single-section frames: LfGroup 0 starts there)
-  uint64_t *pass_end_bits;      // [num_groups]: where the AC stream of a group ended (extra-channel frames: its ModularGroup stream starts there)
+  uint64_t *pass_end_bits;      // [num_passes][num_groups]: where the AC stream of a group ended (extra-channel frames: its ModularGroup stream starts there)
   uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
   uint32_t *err;
   uint8_t *out;                 // RGBA8 / RGBA16
@@ -492,7 +492,7 @@ JXL_DEV uint32_t pass_phase_decode(const DevBuffers &B, DevPassScratch &S, int g
 #endif
   if (state != 0x130000u) return kErrAnsFinal;
   if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) return kErrBitstream;
-  if (F.has_ec && pass == F.num_passes - 1) B.pass_end_bits[g] = b.consumed;
+  if (F.has_ec) B.pass_end_bits[(size_t)pass * (size_t)F.num_groups + (size_t)g] = b.consumed;
   return 0;
 }
 

@@ -767,7 +767,6 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     if (f.subsampled && !(f.flags & 128)) { plan->error = "unsupported: adaptive LF smoothing of a chroma-subsampled frame"; return -1; }
     if (f.subsampled && f.num_passes != 1) { plan->error = "unsupported: multi-pass chroma-subsampled frame"; return -1; }
   }
-  if (f.encoding == 1 && f.num_passes != 1) { plan->error = "unsupported: multi-pass Modular frame"; return -1; }
   if (f.encoding == 1 && !m.pub.xyb_encoded && (f.gab || f.epf_iters)) { f.gab = 0; f.epf_iters = 0; }   // loop filters only apply to XYB frames
   for (int i = 0; i < m.num_extra; i++) {
     // an extra channel is coded at 1 / ec_upsampling of the full size, never finer than the colour channels
@@ -824,6 +823,18 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   F.xlfg = f.xlfg; F.ylfg = f.ylfg; F.num_lf_groups = f.num_lf_groups;
   F.num_passes = f.num_passes;
   for (int i = 0; i < 12; i++) F.pass_shift[i] = i < f.num_passes - 1 ? f.pass_shift[i] : 0;
+  {
+    // which Modular channels travel in which pass (libjxl: Passes::GetDownsamplingBracket): pass p takes the shifts [min, max]; a pass that completes a
+    // downsampling level (last_pass) lowers min to that level's shift, the last pass goes down to 0, and the next pass starts just below
+    int max_shift = 2, min_shift = 3;
+    for (int p = 0; p < 4; p++) { F.pass_min_shift[p] = 3; F.pass_max_shift[p] = 2; }
+    for (int p = 0; p < f.num_passes && p < 4; p++) {
+      for (int j = 0; j < f.num_ds; j++) if (p == f.ds_last[j]) min_shift = f.ds[j] == 8 ? 3 : f.ds[j] == 4 ? 2 : f.ds[j] == 2 ? 1 : 0;
+      if (p == f.num_passes - 1) min_shift = 0;
+      F.pass_min_shift[p] = min_shift; F.pass_max_shift[p] = max_shift;
+      max_shift = min_shift - 1;
+    }
+  }
   F.nsec = nsec;
   F.cs_size = (uint32_t)csn;
   plan->tables.assign(((sizeof(DevFrame) + 15) / 16) * 16, 0);
@@ -889,9 +900,6 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   if (f.encoding == 0 && m.num_extra) {
     if (parse_modular_global(plan, pv, &sb, /*vardct=*/true)) return -1;
     plan->has_ec = true;
-    // several passes: a channel of shift 0 always travels with the LAST pass (every earlier pass's bracket starts at shift 1 or above, the last one's at 0:
-    // Passes::GetDownsamplingBracket), which is where the device looks; squeezed channels would be spread over the passes
-    if (f.num_passes != 1) for (int c = 0; c < F.mod_nch; c++) if (F.mod_hs[c] || F.mod_vs[c]) { plan->error = "unsupported: squeezed extra channels on a multi-pass VarDCT frame"; return -1; }
   }
   // quantiser-derived constants
   float inv_quant_dc = 65536.0f / ((float)global_scale * (float)quant_lf);

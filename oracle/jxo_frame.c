@@ -793,11 +793,19 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
     int x0 = gx * f->group_dim, y0 = gy * f->group_dim;
     jxo_modimg im; jxo_modimg_init(&im); im.bitdepth = s->gmod.bitdepth;
     int map[64], nmap = 0;
+    /* which channels travel in this pass (libjxl: Passes::GetDownsamplingBracket, under JxlDecoderProcessInput — reference call site interop/JxlDecoding.cpp:75):
+       a pass that completes a downsampling level lowers the bracket's lower end to that level's shift, the last pass to 0; the next pass starts just below */
+    int max_shift = 2, min_shift = 3;
+    for (int p = 0;; p++) {
+      for (int j = 0; j < f->num_ds; j++) if (p == f->ds_last[j]) min_shift = f->ds[j] == 8 ? 3 : f->ds[j] == 4 ? 2 : f->ds[j] == 2 ? 1 : 0;
+      if (p == f->num_passes - 1) min_shift = 0;
+      if (p == pass) break;
+      max_shift = min_shift - 1;
+    }
     for (int c = s->gmod_first_undecoded; c < s->gmod.nch; c++) {
       jxo_chan *fc = &s->gmod.ch[c];
       int sh = fc->hshift < fc->vshift ? fc->hshift : fc->vshift;
-      if (sh > 2 || sh < 0) continue;      /* single-pass bracket: minShift 0, maxShift 2 */
-      if (f->num_passes > 1 && sh != 0) { jxo_modimg_free(&im); JXO_FAIL("unsupported: squeezed channels over several passes"); }      /* several passes: a channel of shift 0 always travels with the LAST pass (Passes::GetDownsamplingBracket) */
+      if (sh < min_shift || sh > max_shift) continue;      /* this pass's bracket; one pass: 0..2 */
       int rx = x0 >> fc->hshift, ry = y0 >> fc->vshift;
       int rw = f->group_dim >> fc->hshift, rh = f->group_dim >> fc->vshift;
       if (rx >= fc->w || ry >= fc->h) continue;
@@ -807,7 +815,7 @@ static int read_pass_group(fstate *s, jxo_br *br, int pass, int g) {
       jxo_modimg_add(&im, rw, rh, fc->hshift, fc->vshift);
       map[nmap++] = c;
     }
-    if (pass == f->num_passes - 1 && nmap) {
+    if (nmap) {
       int sid = 1 + 3 * f->num_lf_groups + 17 + f->num_groups * pass + g;
       if (jxo_modular_decode(br, &im, sid, 0, &s->gtree, 1, NULL)) { jxo_modimg_free(&im); return -1; }
       for (int i = 0; i < nmap; i++) {

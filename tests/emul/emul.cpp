@@ -133,7 +133,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   for (int c = 0; c < 3; c++) B.lf_frame[c] = refs.p[4][c].empty() ? nullptr : refs.p[4][c].data();      // slot 4: the LF frame of a progressive_dc file
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
-  std::vector<uint64_t> pend((size_t)plan.num_groups + 1, 0); B.pass_end_bits = pend.data();
+  std::vector<uint64_t> pend((size_t)plan.num_groups * (size_t)plan.num_passes + 1, 0); B.pass_end_bits = pend.data();
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len, lzg = ((const DevFrame *)plan.tables.data())->lz_win_group;
   std::vector<uint32_t> lzw(plan.modular && lzl ? (size_t)lzl + (size_t)plan.num_groups * lzg : 1, 0); B.lz_win = plan.modular && lzl ? lzw.data() : nullptr;

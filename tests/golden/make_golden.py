@@ -116,6 +116,12 @@ CASES = {
     "vcadobe200x136_e7": (200, 136, dict(seed=9), dict(effort=7, custom_xy=(0.3127, 0.3290, 0.64, 0.33, 0.21, 0.71, 0.15, 0.06))),
     "vcprophoto200x136_e7": (200, 136, dict(seed=9), dict(effort=7, custom_xy=(0.3457, 0.3585, 0.7347, 0.2653, 0.1596, 0.8404, 0.0366, 0.0001))),
     "vapac520x300_e7": (520, 300, dict(seed=12, alpha=True), dict(effort=7, distance=1.0, extra=((17, 1),))),      # RGBA + progressive AC: the alpha's group streams follow the AC data of the LAST pass
+    # what `cjxl -p` writes for RGBA: progressive AC + a squeezed (responsive) alpha — the alpha's channels are spread over the passes by their shift
+    # (Passes::GetDownsamplingBracket: every pass has a ModularGroup stream of its own behind the AC data), single group and 3 x 2 groups
+    "vapr400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(effort=7, distance=1.0, extra=((17, 1), (16, 1)))),
+    "vaqr520x300_e7": (520, 300, dict(seed=13, alpha=True), dict(effort=7, distance=1.0, extra=((18, 1), (16, 1)))),
+    # ... and for a photograph with progressive DC: the LF frame is a Modular frame of several passes itself
+    "vlfq600x410_e7": (600, 410, dict(seed=14), dict(effort=7, distance=1.0, extra=((19, 1), (18, 1)))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
