@@ -317,13 +317,15 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   }
   for (int c = 0; c < 3; c++) B.noise[c] = nullptr;
   if (Fh->noise) {
-    HIPCHECK(S.noise_planes.ensure(3 * npx * 4));
-    for (int c = 0; c < 3; c++) B.noise[c] = (float *)S.noise_planes.p + (size_t)c * npx;
+    const size_t nn = Fh->upsampling > 1 ? (size_t)Fh->full_w * (size_t)Fh->full_h : npx;      // drawn at the resolution it is added at
+    HIPCHECK(S.noise_planes.ensure(3 * nn * 4));
+    for (int c = 0; c < 3; c++) B.noise[c] = (float *)S.noise_planes.p + (size_t)c * nn;
   }
   for (int c = 0; c < 3; c++) B.lf_frame[c] = nullptr;
   if (Fh->use_lf_frame) {
-    if (!ref_store[4].p || ref_w[4] != Fh->lf_frame_w || ref_h[4] != Fh->lf_frame_h) { set_error("LF frame missing"); return JXLAMD_ERR_INVALID; }
-    for (int c = 0; c < 3; c++) B.lf_frame[c] = (const float *)ref_store[4].p + (size_t)c * (size_t)ref_w[4] * (size_t)ref_h[4];
+    const int k = Fh->lf_frame_slot;
+    if (k < 4 || k > 7 || !ref_store[k].p || ref_w[k] != Fh->lf_frame_w || ref_h[k] != Fh->lf_frame_h) { set_error("LF frame missing"); return JXLAMD_ERR_INVALID; }
+    for (int c = 0; c < 3; c++) B.lf_frame[c] = (const float *)ref_store[k].p + (size_t)c * (size_t)ref_w[k] * (size_t)ref_h[k];
   }
   for (int c = 0; c < 4; c++) B.canvas_save[c] = nullptr;
   B.post = (S.post_active && S.post_fused && !in_flight) ? (const DevPost *)S.post_dev.p : nullptr;      // in a flight: inside the flight's tables (decode_batch)
@@ -427,7 +429,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   if (F->subsampled) launch_chroma_upsample(S.B, plan.width, plan.height, stream);      // recompressed JPEG: chroma to full resolution (no loop filters in between)
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
-  if (F->noise) launch_noise(S.B, plan.num_groups, plan.width, plan.height, stream);      // after the patches, before the colour transform (libjxl's stage order)
+  if (F->noise && F->upsampling == 1) launch_noise(S.B, plan.width, plan.height, stream);      // after the patches, before the colour transform (libjxl's stage order); an upsampled frame: after the upsampling
   if (F->blend) {
     // a frame of an animation over its canvas (dev_compose.h: blend_canvas_pixel): the background is a reference slot's canvas, the result goes out and / or
     // becomes the new canvas of the frame's slot — in place when it is the slot it was read from (every pixel reads before it writes)
@@ -457,7 +459,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   }
   if (F->no_output) return JXLAMD_OK;
   if (F->alpha_up > 1 && F->mod_out[3] >= 0) launch_upsample_alpha(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);
-  if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);
+  if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, F->noise != 0, stream);
   else launch_compose_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, stream);
   return JXLAMD_OK;
 }

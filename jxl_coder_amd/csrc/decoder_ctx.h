@@ -136,7 +136,7 @@ struct jxlamd_decoder {
   DevMem flight_tables, flight_cs;       // tables / padded compressed bytes of all frames of a flight: one upload (or one gather launch) per flight
   std::vector<FrameSlot *> slots;
   std::vector<FrameSlot *> ref_slots;     // reference frames of the file being decoded (patch dictionaries), one slot each
-  DevMem ref_store[5]; int ref_w[5] = {0, 0, 0, 0, 0}, ref_h[5] = {0, 0, 0, 0, 0}; bool ref_alpha[5] = {false, false, false, false, false};      // [4]: the LF frame of a progressive_dc file
+  DevMem ref_store[8]; int ref_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ref_h[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool ref_alpha[8] = {false, false, false, false, false, false, false, false};      // [4..7]: the LF frames (level 1..4) of a progressive_dc file
   int target_frame = -1;
   bool wpost_enabled = false; int wpost_cfg = 0, wpost_api = 34; uint64_t post_lut_gen = 0;      // jxlamd_decoder_set_writer_post     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;

@@ -145,10 +145,21 @@ JXL_DEV uint64_t noise_splitmix(uint64_t z) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+// Where the noise goes: the frame's final planes, or — an upsampled frame — the upsampled image (libjxl's stage order: Upsampling, then Noise: the random planes
+// are drawn at the full resolution, in tiles of 256 x 256 seeded by their position there; Random3Planes under PrepareNoiseInput)
+struct NoiseGeom { int w, h, stride, xtiles, ytiles; float *dst[3]; };
+JXL_DEV NoiseGeom noise_geom(const DevBuffers &B, const DevFrame &F) {
+  NoiseGeom G;
+  if (F.upsampling > 1) { G.w = F.full_w; G.h = F.full_h; G.stride = F.full_w; for (int c = 0; c < 3; c++) G.dst[c] = B.up[c]; }
+  else { G.w = F.width; G.h = F.height; G.stride = F.pw; const bool a = compose_final_is_a(F); for (int c = 0; c < 3; c++) G.dst[c] = a ? B.plane_a[c] : B.plane_b[c]; }
+  G.xtiles = (G.w + 255) / 256; G.ytiles = (G.h + 255) / 256;
+  return G;
+}
 JXL_DEV void noise_gen_lane(const DevBuffers &B, const DevFrame &F, int g, int lane) {
-  const int gx = g % F.xgroups, gy = g / F.xgroups;
+  const NoiseGeom G = noise_geom(B, F);
+  const int gx = g % G.xtiles, gy = g / G.xtiles;
   const int x0 = gx * 256, y0 = gy * 256;
-  const int xs = F.width - x0 < 256 ? F.width - x0 : 256, ys = F.height - y0 < 256 ? F.height - y0 : 256;
+  const int xs = G.w - x0 < 256 ? G.w - x0 : 256, ys = G.h - y0 < 256 ? G.h - y0 : 256;
   uint64_t s0 = noise_splitmix((((uint64_t)F.noise_seed[0]) << 32) + F.noise_seed[1] + 0x9E3779B97F4A7C15ull);
   uint64_t s1 = noise_splitmix((((uint64_t)(uint32_t)x0) << 32) + (uint32_t)y0 + 0x9E3779B97F4A7C15ull);
   for (int i = 0; i < lane; i++) { s0 = noise_splitmix(s0); s1 = noise_splitmix(s1); }
@@ -156,7 +167,7 @@ JXL_DEV void noise_gen_lane(const DevBuffers &B, const DevFrame &F, int g, int l
   while ((nfull + 1) * 16 < xs) nfull++;                      // batches with x + 16 < xsize
   for (int c = 0; c < 3; c++)
     for (int y = 0; y < ys; y++) {
-      float *row = B.noise[c] + (size_t)(y0 + y) * (size_t)F.pw + (size_t)x0;
+      float *row = B.noise[c] + (size_t)(y0 + y) * (size_t)G.stride + (size_t)x0;
       for (int f = 0; f <= nfull; f++) {
         uint64_t a = s0; const uint64_t b = s1;
         const uint64_t bits = a + b;
@@ -189,23 +200,23 @@ JXL_DEV float noise_strength(const DevFrame &F, float x) {
   return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
 }
 JXL_DEV void noise_add_pixel(const DevBuffers &B, const DevFrame &F, int x, int y) {
+  const NoiseGeom G = noise_geom(B, F);
   float rnd[3];
   int xs[5], ys[5];
-  for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.width); ys[i] = mirror(y + i - 2, F.height); }
+  for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, G.w); ys[i] = mirror(y + i - 2, G.h); }
   for (int c = 0; c < 3; c++) {
     const float *p = B.noise[c];
     float others = 0.0f;
     for (int i = 0; i < 5; i++) {
-      others += p[(size_t)ys[0] * (size_t)F.pw + (size_t)xs[i]]; others += p[(size_t)ys[1] * (size_t)F.pw + (size_t)xs[i]];
-      others += p[(size_t)ys[3] * (size_t)F.pw + (size_t)xs[i]]; others += p[(size_t)ys[4] * (size_t)F.pw + (size_t)xs[i]];
+      others += p[(size_t)ys[0] * (size_t)G.stride + (size_t)xs[i]]; others += p[(size_t)ys[1] * (size_t)G.stride + (size_t)xs[i]];
+      others += p[(size_t)ys[3] * (size_t)G.stride + (size_t)xs[i]]; others += p[(size_t)ys[4] * (size_t)G.stride + (size_t)xs[i]];
     }
-    const float *mid = p + (size_t)ys[2] * (size_t)F.pw;
+    const float *mid = p + (size_t)ys[2] * (size_t)G.stride;
     others += mid[xs[0]]; others += mid[xs[1]]; others += mid[xs[3]]; others += mid[xs[4]];
     rnd[c] = mul_add_rn(others, 0.16f, mid[xs[2]] * -3.84f) * 0.22f;
   }
-  const bool a = compose_final_is_a(F);
-  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x;
-  float *px = (a ? B.plane_a[0] : B.plane_b[0]) + po, *py = (a ? B.plane_a[1] : B.plane_b[1]) + po, *pb = (a ? B.plane_a[2] : B.plane_b[2]) + po;
+  const size_t po = (size_t)y * (size_t)G.stride + (size_t)x;
+  float *px = G.dst[0] + po, *py = G.dst[1] + po, *pb = G.dst[2] + po;
   const float vx = *px, vy = *py;
   const float sg = noise_strength(F, (vy - vx) * 0.5f), sr = noise_strength(F, (vy + vx) * 0.5f);
   const float red = sr * mul_add_rn(0.0078125f, rnd[0], 0.9921875f * rnd[2]);

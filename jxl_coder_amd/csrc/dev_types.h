@@ -69,6 +69,7 @@ struct DevFrame {
   float base_x, base_b, inv_color_factor;
   float quant_bias[4];
   int32_t skip_lf_smoothing;
+  int32_t lf_frame_slot;                          // host only: which slot holds that LF frame (4 + the frame's own LF level: slots 4..7 = LF frames of level 1..4)
   int32_t use_lf_frame, lf_frame_w, lf_frame_h;   // kUseDcFrame (progressive_dc): the LF image is an earlier LF frame's XYB pixels (DevBuffers::lf_frame, lf_frame_w x lf_frame_h = one sample per 8 x 8 cell), the LfGroup sections carry no LF coefficients
   int32_t modular_16bit;           // ImageMetadata.modular_16bit_buffers: every Modular sample fits int16 (enables 32-bit WP math)
   // block context

@@ -679,10 +679,12 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     const frame_hdr &f = recs[i].f;
     if (f.flags & 2) for (int k = 0; k < 4; k++) if (occupant_at[i * 4 + (size_t)k] >= 0) recs[(size_t)occupant_at[i * 4 + (size_t)k]].needed = true;    // patches may name any slot
     if (f.flags & 32) {
-      // kUseDcFrame (progressive_dc): the frame's LF image is the latest LF frame of level 1 before it (libjxl's dc_frames[0]) instead of LF coefficients
-      if (f.frame_type == 1) { plan->error = "unsupported: LF frame of level 2 and beyond"; return -1; }
+      // kUseDcFrame (progressive_dc): the frame's LF image is the latest LF frame of the next level before it (libjxl's dc_frames[lf_level]) instead of LF
+      // coefficients; an LF frame may itself be a VarDCT frame with an LF frame of its own (progressive_dc = 2: level 1 VarDCT over level 2 Modular)
+      const int want = (f.frame_type == 1 ? f.lf_level : 0) + 1;
+      if (want > 4) { plan->error = "LF frame level out of range"; return -1; }
       int lf = -1;
-      for (size_t j = i; j-- > 0;) if (recs[j].f.frame_type == 1 && recs[j].f.lf_level == 1) { lf = (int)j; break; }
+      for (size_t j = i; j-- > 0;) if (recs[j].f.frame_type == 1 && recs[j].f.lf_level == want) { lf = (int)j; break; }
       if (lf < 0) { plan->error = "frame refers to an LF frame the file does not have"; return -1; }
       recs[(size_t)lf].needed = true; recs[(size_t)lf].lf_needed = true;
     }
@@ -702,7 +704,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     }
   }
   // ---- the needed earlier frames first, in file order (each its own FramePlan over the same codestream bytes), then the shown frame
-  int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0}, lf_w = 0, lf_h = 0;
+  int slot_w[4] = {0, 0, 0, 0}, slot_h[4] = {0, 0, 0, 0}, lf_w[6] = {0, 0, 0, 0, 0, 0}, lf_h[6] = {0, 0, 0, 0, 0, 0};      // lf_w[level]: the latest LF frame of that level
   const auto blend_checks = [&](const FrameRec &r) -> bool {
     const frame_hdr &f = r.f;
     if (!r.blend) return true;
@@ -721,8 +723,9 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     std::shared_ptr<Priv> spv = std::make_shared<Priv>();
     sub->priv = spv;
     spv->m = m; spv->f = f;
-    memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h)); spv->lf_w = lf_w; spv->lf_h = lf_h;
-    if (f.frame_type == 1 && (!recs[i].lf_needed || (f.flags & 32))) { plan->error = "unsupported: LF frame of level 2 and beyond"; return -1; }
+    memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h)); 
+    { const int lv = (f.frame_type == 1 ? f.lf_level : 0) + 1; spv->lf_w = lf_w[lv]; spv->lf_h = lf_h[lv]; }
+    if (f.frame_type == 1 && (f.lf_level < 1 || f.lf_level > 4)) { plan->error = "LF frame level out of range"; return -1; }
     if (!recs[i].canvas_needed && f.frame_type != 1) {
       // a frame kept for a patch dictionary: stored as it is, before the colour transform
       if (f.frame_type != 2 && (recs[i].blend || !full_frame(f))) { plan->error = "unsupported: blended / cropped regular frame used as a patch source"; return -1; }
@@ -732,15 +735,15 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     spv->blend = recs[i].blend; spv->save_canvas = recs[i].canvas_needed; spv->has_src = recs[i].src_frame >= 0; spv->alpha_ec = alpha_ec;
     if (build_frame(sub.get(), spv.get(), recs[i], /*is_shown=*/false, raw_w, raw_h)) { plan->error = sub->error; return -1; }
     if (plan->refs.size() >= 2048) { plan->error = "unsupported: more than 2048 frames to decode for one shown frame"; return -1; }      // (a blend chain through every frame of a long animation)
-    sub->save_slot = f.frame_type == 1 ? 4 : (f.save_as_ref & 3);          // slot 4: the LF image of the next frame that asks for one
+    sub->save_slot = f.frame_type == 1 ? 3 + f.lf_level : (f.save_as_ref & 3);          // slots 4..7: the LF frames of level 1..4 (the LF image of the next frame of the level below that asks for one)
     sub->save_canvas = recs[i].canvas_needed;
     plan->refs.push_back(sub);
-    if (f.frame_type == 1) { lf_w = f.coded_width; lf_h = f.coded_height; continue; }
+    if (f.frame_type == 1) { lf_w[f.lf_level] = f.coded_width; lf_h[f.lf_level] = f.coded_height; continue; }
     if (recs[i].canvas_needed) { slot_w[f.save_as_ref & 3] = (int)raw_w; slot_h[f.save_as_ref & 3] = (int)raw_h; }
     else { slot_w[f.save_as_ref & 3] = f.width; slot_h[f.save_as_ref & 3] = f.height; }
   }
   if (!blend_checks(recs[last])) return -1;
-  pv->lf_w = lf_w; pv->lf_h = lf_h;
+  pv->lf_w = lf_w[1]; pv->lf_h = lf_h[1];
   pv->blend = recs[last].blend; pv->save_canvas = false; pv->has_src = recs[last].src_frame >= 0; pv->alpha_ec = alpha_ec;
   pv->f = recs[last].f;
   memcpy(pv->ref_w, slot_w, sizeof(slot_w)); memcpy(pv->ref_h, slot_h, sizeof(slot_h));
@@ -791,7 +794,6 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   if (f.flags & 16) { plan->error = "unsupported: splines"; return -1; }
   if (f.flags & 1) {
     if (f.encoding != 0 || !m.pub.xyb_encoded) { plan->error = "unsupported: noise on a frame that is not a VarDCT XYB frame"; return -1; }
-    if (f.upsampling != 1) { plan->error = "unsupported: noise on an upsampled frame"; return -1; }
     if (!is_shown) { plan->error = "unsupported: noise on a reference frame"; return -1; }
   }
   if (f.flags & 32) {
@@ -799,7 +801,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     if (f.subsampled) { plan->error = "unsupported: chroma-subsampled frame with an LF frame"; return -1; }
     if (pv->lf_w != (f.coded_width + 7) / 8 || pv->lf_h != (f.coded_height + 7) / 8) { plan->error = "LF frame does not match the frame it serves"; return -1; }
   }
-  if (f.frame_type == 1 && (f.encoding != 1 || !m.pub.xyb_encoded)) { plan->error = "unsupported: LF frame that is not a Modular XYB frame"; return -1; }      // (its extra channels, coded at an eighth too, are decoded and not used: the main frame carries its own)
+  if (f.frame_type == 1 && !m.pub.xyb_encoded) { plan->error = "unsupported: LF frame of an image that is not XYB"; return -1; }      // Modular, or VarDCT over an LF frame of its own (progressive_dc = 2)      // (its extra channels, coded at an eighth too, are decoded and not used: the main frame carries its own)
   if (f.group_dim != 256 && f.encoding != 1) { plan->error = "unsupported: group size"; return -1; }      // VarDCT frames: 256 (libjxl never writes another); Modular frames: 128 .. 1024
   const int nsec = (f.num_groups == 1 && f.num_passes == 1) ? 1 : 1 + f.num_lf_groups + 1 + f.num_groups * f.num_passes;
   { size_t end_byte = 0; if (read_toc(plan->cs, csn, f, rec.toc_bit, &secs, &end_byte, &plan->error)) return -1; }
@@ -913,6 +915,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   memcpy(F.quant_bias, m.quant_bias, sizeof(F.quant_bias));
   F.skip_lf_smoothing = (f.flags & (128 | 32)) ? 1 : 0;      // (a frame that takes its LF image from an LF frame is not smoothed either)
   F.use_lf_frame = (f.flags & 32) ? 1 : 0; F.lf_frame_w = pv->lf_w; F.lf_frame_h = pv->lf_h;
+  F.lf_frame_slot = 4 + (f.frame_type == 1 ? f.lf_level : 0);
   F.modular_16bit = m.modular_16;
   F.gab = f.gab; memcpy(F.gab_w, f.gab_w, sizeof(F.gab_w));
   F.epf_iters = f.epf_iters; memcpy(F.epf_sharp, f.epf_sharp, sizeof(F.epf_sharp)); memcpy(F.epf_chscale, f.epf_chscale, sizeof(F.epf_chscale));

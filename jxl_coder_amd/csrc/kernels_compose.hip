@@ -48,17 +48,19 @@ __global__ void __launch_bounds__(256) k_chroma_upsample(DevBuffers B) {
 __global__ void __launch_bounds__(64) k_noise_gen(DevBuffers B) {
   const DevFrame &F = frame_of(B);
   const int item = (int)(blockIdx.x * 64 + threadIdx.x);
-  if (item >= F.num_groups * 8 || frame_failed(B)) return;
+  const NoiseGeom G = noise_geom(B, F);
+  if (item >= G.xtiles * G.ytiles * 8 || frame_failed(B)) return;
   noise_gen_lane(B, F, item >> 3, item & 7);
 }
 __global__ void __launch_bounds__(256) k_noise_add(DevBuffers B) {
   const DevFrame &F = frame_of(B);
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
-  if (x >= F.width || y >= F.height || frame_failed(B)) return;
+  if (x >= (F.upsampling > 1 ? F.full_w : F.width) || y >= (F.upsampling > 1 ? F.full_h : F.height) || frame_failed(B)) return;
   noise_add_pixel(B, F, x, y);
 }
-void launch_noise(const DevBuffers &B, int num_groups, int w, int h, hipStream_t s) {
-  hipLaunchKernelGGL(k_noise_gen, dim3((unsigned)(num_groups * 8 + 63) / 64), dim3(64), 0, s, B);
+void launch_noise(const DevBuffers &B, int w, int h, hipStream_t s) {      // w x h: the resolution the noise is drawn at (the upsampled one for an upsampled frame)
+  const int tiles = ((w + 255) / 256) * ((h + 255) / 256);
+  hipLaunchKernelGGL(k_noise_gen, dim3((unsigned)(tiles * 8 + 63) / 64), dim3(64), 0, s, B);
   hipLaunchKernelGGL(k_noise_add, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B);
 }
 // frames laid over a canvas (animations): one work-item per canvas pixel
@@ -94,9 +96,10 @@ __global__ void __launch_bounds__(256) k_upsample_alpha(DevBuffers B, const uint
 void launch_upsample_alpha(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
   hipLaunchKernelGGL(k_upsample_alpha, dim3((full_w + 63) / 64, (full_h + 3) / 4), dim3(256), 0, s, B, stat);
 }
-void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
+void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, hipStream_t s) {
   const dim3 g((full_w + 63) / 64, (full_h + 3) / 4);
   hipLaunchKernelGGL(k_upsample, g, dim3(256), 0, s, B, stat);
+  if (noise) launch_noise(B, full_w, full_h, s);          // libjxl's stage order: Upsampling, Noise, colour transform
   hipLaunchKernelGGL(k_upsampled_write, g, dim3(256), 0, s, B, stat);
 }
 

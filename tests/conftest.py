@@ -100,7 +100,7 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       # RGBA at low quality: alpha coded at half size (extra-channel upsampling; its values get the writer's dither like the colour), with patches, and alpha alone at half size
                       "vua400x300_e7_d12", "vusa400x300_e7_d12", "va400x300_e7_ecup2",
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
-                      "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7",
+                      "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vlf2a520x300_e7", "vnu600x410_e7_up2", "vnu523x267_e7_d12",
                       # custom primaries (Adobe RGB) and a custom white point with custom primaries (ProPhoto, D50: Bradford on both sides as in libjxl's output stage)
                       "vcadobe200x136_e7", "vcprophoto200x136_e7"]
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW

@@ -18,6 +18,11 @@
 using namespace jxlamd;
 struct NoSync { void operator()() const {} };
 static std::string g_err;
+// the product's classification (decoder.hip: dev_err_class): any flag besides "bitstream" / "ANS final state" names something the device path does not cover
+static std::string flag_message(uint32_t err, const char *where) {
+  const bool unsupported = (err & 0xFFFFu & ~(uint32_t)(kErrBitstream | kErrAnsFinal)) != 0;
+  return std::string(unsupported ? "unsupported: " : "") + "device flags " + std::to_string(err) + " (" + where + ")";
+}
 
 extern "C" const char *emul_last_error() { return g_err.c_str(); }
 
@@ -38,17 +43,19 @@ static void filter_stages(const DevBuffers &B, const DevFrame &F) {
   }
 }
 
-struct RefStore { std::vector<float> p[5][4]; int w[5] = {0, 0, 0, 0, 0}, h[5] = {0, 0, 0, 0, 0}; };      // [slot][R, G, B, alpha (blended canvases only)]
+struct RefStore { std::vector<float> p[8][4]; int w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };      // [slot][R, G, B, alpha (blended canvases only)]
 
 // composition tail (jxlamd_decoder::launch_compose_tail): patches, copy into the reference slot, stand-alone writer
 static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F, int out_bits, RefStore &refs, const uint8_t *stat) {
   if (F.subsampled) for (int c = 0; c < 3; c++) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) chroma_upsample_pixel(B, F, c, x, y);      // k_chroma_upsample
   const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
   for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
-  if (F.noise && !getenv("JXLEMUL_NO_NOISE")) {                                           // k_noise_gen, k_noise_add
-    for (int g = 0; g < F.num_groups; g++) for (int lane = 0; lane < 8; lane++) noise_gen_lane(B, F, g, lane);
-    for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) noise_add_pixel(B, F, x, y);
-  }
+  const auto noise = [&]() {                                                              // k_noise_gen, k_noise_add
+    const NoiseGeom G = noise_geom(B, F);
+    for (int g = 0; g < G.xtiles * G.ytiles; g++) for (int lane = 0; lane < 8; lane++) noise_gen_lane(B, F, g, lane);
+    for (int y = 0; y < G.h; y++) for (int x = 0; x < G.w; x++) noise_add_pixel(B, F, x, y);
+  };
+  if (F.noise && F.upsampling == 1 && !getenv("JXLEMUL_NO_NOISE")) noise();
   if (F.blend) {                                           // jxlamd_decoder::launch_compose_tail: the frame over its canvas (k_blend_canvas)
     DevBuffers Bb = B;
     std::vector<float> keep[4];
@@ -69,6 +76,7 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   if (F.alpha_up > 1 && F.mod_out[3] >= 0) for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_alpha_pixel(B, F, stat, X, Y);
   if (F.upsampling > 1) {                                  // k_upsample, then the writer at full resolution
     for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_pixel(B, F, stat, X, Y);
+    if (F.noise && !getenv("JXLEMUL_NO_NOISE")) noise();                                  // libjxl's stage order: Upsampling, Noise, colour transform
     for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsampled_write_pixel(B, stat, out_bits, X, Y);
     return;
   }
@@ -129,8 +137,8 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (F0.alpha_up > 1) { upv[3].assign((size_t)F0.full_w * F0.full_h, 0.f); B.up[3] = upv[3].data(); }
   for (int k = 0; k < 4; k++) { for (int c = 0; c < 3; c++) B.ref[k][c] = refs.p[k][c].empty() ? nullptr : refs.p[k][c].data(); B.ref_a[k] = refs.p[k][3].empty() ? nullptr : refs.p[k][3].data(); }
   std::vector<float> noisev[3];
-  if (F0.noise) for (int c = 0; c < 3; c++) { noisev[c].assign(npx, 0.f); B.noise[c] = noisev[c].data(); }
-  for (int c = 0; c < 3; c++) B.lf_frame[c] = refs.p[4][c].empty() ? nullptr : refs.p[4][c].data();      // slot 4: the LF frame of a progressive_dc file
+  if (F0.noise) for (int c = 0; c < 3; c++) { noisev[c].assign(F0.upsampling > 1 ? (size_t)F0.full_w * F0.full_h : npx, 0.f); B.noise[c] = noisev[c].data(); }
+  { const int lk = ((const DevFrame *)plan.tables.data())->lf_frame_slot; for (int c = 0; c < 3; c++) B.lf_frame[c] = (lk < 4 || lk > 7 || refs.p[lk][c].empty()) ? nullptr : refs.p[lk][c].data(); }      // slots 4..7: the LF frames of a progressive_dc file
   std::vector<LocalTreeScratch> loc((size_t)((plan.modular || plan.has_ec) ? std::max(plan.num_groups > 1 ? plan.num_groups : 1, plan.num_lf_groups) : plan.num_lf_groups)); B.local = loc.data();
   std::vector<int32_t> mpool(plan.mod_pool_ints + 64, 0), mscr((plan.modular || plan.has_ec) ? ((size_t)plan.num_groups + 1) * mod_group_scratch_ints(*(const DevFrame *)plan.tables.data()) + (size_t)plan.num_lf_groups * (size_t)((const DevFrame *)plan.tables.data())->mod_lf_nch * 65536 + 64 : 1, 0);
   std::vector<uint64_t> pend((size_t)plan.num_groups * (size_t)plan.num_passes + 1, 0); B.pass_end_bits = pend.data();
@@ -152,7 +160,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     }
     if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS, g, 0, 1, NoSync());
     delete MS;
-    if (err) { g_err = "device flags " + std::to_string(err) + " (Modular)"; return -2; }
+    if (err) { g_err = flag_message(err, "Modular"); return -2; }
     for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
     if (!F.compose) {
       for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) mod_write_pixel(B, out_bits, x, y);
@@ -168,7 +176,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (plan.has_ec) mod_global_body(B, *MS, 0, 1, NoSync());       // GlobalModular part of the extra channels: before LfGroup 0
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
   delete MS;
-  if (err) { g_err = "device flags " + std::to_string(err) + " (LfGroup)"; return -2; }
+  if (err) { g_err = flag_message(err, "LfGroup"); return -2; }
   if (plan.single_section) {
     if (plan_parse_hf_single(&plan, endbits[0])) { g_err = plan.error; return -1; }
     tables = plan.tables; B.tables = tables.data();
@@ -196,13 +204,13 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   } else
   for (int g = 0; g < plan.num_groups; g++) pass_group_body(B, *PS, g, 0, 1, NoSync());
   delete PS;
-  if (err) { g_err = "device flags " + std::to_string(err) + " (PassGroup)"; return -2; }
+  if (err) { g_err = flag_message(err, "PassGroup"); return -2; }
   if (plan.has_ec) {                          // extra channels (alpha): same order as jxlamd_decoder::launch_extra_channels
     const DevFrame &F = *(const DevFrame *)tables.data();
     DevModScratch *MS2 = new DevModScratch();
     if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS2, g, 0, 1, NoSync());
     delete MS2;
-    if (err) { g_err = "device flags " + std::to_string(err) + " (extra channels)"; return -2; }
+    if (err) { g_err = flag_message(err, "extra channels"); return -2; }
     for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
   }
   std::vector<float> S(3 * 4096), T(4096);
@@ -212,7 +220,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
       recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
     } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());
   }
-  if (err) { g_err = "device flags " + std::to_string(err) + " (recon)"; return -2; }
+  if (err) { g_err = flag_message(err, "recon"); return -2; }
   const DevFrame &F = *(const DevFrame *)tables.data();
   filter_stages(B, F);
   if (F.compose) { compose_tail(plan, B, F, out_bits, refs, stat.data()); return 0; }

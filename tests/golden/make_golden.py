@@ -111,6 +111,9 @@ CASES = {
     "vn300x200_e7": (300, 200, dict(seed=4, grain=6), dict(effort=7, distance=1.0, extra=((6, 1),))),
     "vn600x410_e7_d15": (600, 410, dict(seed=4, grain=5), dict(effort=7, distance=1.5, extra=((6, 1),))),        # 3 x 2 groups with ragged edges: each group seeds its own generator
     "vna333x277_e7_d15": (333, 277, dict(seed=4, grain=5, alpha=True), dict(effort=7, distance=1.5, extra=((6, 1),))),
+    # noise on upsampled frames: the random planes are drawn and added at the full resolution, after the upsampling (tiles of 256 x 256 seeded by their position there)
+    "vnu600x410_e7_up2": (600, 410, dict(seed=4, grain=6), dict(effort=7, distance=2.0, extra=((6, 1), (2, 2)))),
+    "vnu523x267_e7_d12": (523, 267, dict(seed=4, grain=6), dict(effort=7, distance=12.0, extra=((6, 1),))),
     # custom chromaticities in an enum colour encoding (what encoders write for Adobe RGB / ProPhoto sources): primaries by xy, and a D50 white point that
     # libjxl's output stage adapts with Bradford (white xy, red, green, blue xy)
     "vcadobe200x136_e7": (200, 136, dict(seed=9), dict(effort=7, custom_xy=(0.3127, 0.3290, 0.64, 0.33, 0.21, 0.71, 0.15, 0.06))),
@@ -122,6 +125,9 @@ CASES = {
     "vaqr520x300_e7": (520, 300, dict(seed=13, alpha=True), dict(effort=7, distance=1.0, extra=((18, 1), (16, 1)))),
     # ... and for a photograph with progressive DC: the LF frame is a Modular frame of several passes itself
     "vlfq600x410_e7": (600, 410, dict(seed=14), dict(effort=7, distance=1.0, extra=((19, 1), (18, 1)))),
+    # two levels of LF frames (progressive DC = 2): a Modular LF frame of level 2 (1 / 64 of the size) serves a VarDCT LF frame of level 1, which serves the image
+    "vlf2_600x410_e7_d2": (600, 410, dict(seed=24), dict(effort=7, distance=2.0, extra=((19, 2),))),
+    "vlf2a520x300_e7": (520, 300, dict(seed=25, alpha=True), dict(effort=7, distance=1.5, extra=((19, 2),))),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),

@@ -127,7 +127,7 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    art = open(os.path.join(ROOT, "tests", "golden", "u300x200_lf_level2.jxl"), "rb").read()       # progressive DC with TWO levels of LF frames (JXL_ENC_FRAME_SETTING_PROGRESSIVE_DC = 2): not on the device path — and a VALID file: unsupported, not corrupt
+    art = open(os.path.join(ROOT, "tests", "golden", "u200x136_prev_channel_props.jxl"), "rb").read()       # MA tree with properties of the previous channels (JXL_ENC_FRAME_SETTING_MODULAR_NB_PREV_CHANNELS = 3, cjxl -E 3): not on the device path — and a VALID file: unsupported, not corrupt
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
         dec.decode_one_shot(art)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes

@@ -162,7 +162,7 @@ def test_jxl_art_asset_on_cpu_harness(emul):
 
 
 def test_harness_rejects_what_the_device_path_does_not_support(emul):
-    data = open(os.path.join(ROOT, "tests", "golden", "u300x200_lf_level2.jxl"), "rb").read()      # progressive DC with TWO levels of LF frames (JXL_ENC_FRAME_SETTING_PROGRESSIVE_DC = 2: the LF frame has an LF frame of its own): not on the device path — and a VALID file: unsupported, not corrupt
+    data = open(os.path.join(ROOT, "tests", "golden", "u200x136_prev_channel_props.jxl"), "rb").read()      # MA tree with properties of the previous channels (JXL_ENC_FRAME_SETTING_MODULAR_NB_PREV_CHANNELS = 3, cjxl -E 3): not on the device path — and a VALID file: unsupported, not corrupt
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
 
