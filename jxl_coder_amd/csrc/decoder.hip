@@ -431,6 +431,8 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
   if (F->noise && F->upsampling == 1) launch_noise(S.B, plan.width, plan.height, stream);      // after the patches, before the colour transform (libjxl's stage order); an upsampled frame: after the upsampling
   if (F->blend) {
+    if (F->alpha_up > 1 && F->mod_out[3] >= 0) launch_upsample_alpha(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);      // an upsampled frame is blended at its full resolution
+    if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, F->noise != 0, /*write=*/false, stream);
     // a frame of an animation over its canvas (dev_compose.h: blend_canvas_pixel): the background is a reference slot's canvas, the result goes out and / or
     // becomes the new canvas of the frame's slot — in place when it is the slot it was read from (every pixel reads before it writes)
     DevBuffers Bb = S.B;
@@ -459,7 +461,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   }
   if (F->no_output) return JXLAMD_OK;
   if (F->alpha_up > 1 && F->mod_out[3] >= 0) launch_upsample_alpha(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);
-  if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, F->noise != 0, stream);
+  if (F->upsampling > 1) launch_upsample_and_write(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, F->noise != 0, /*write=*/true, stream);
   else launch_compose_write(S.B, (const uint8_t *)stat.p, plan.width, plan.height, stream);
   return JXLAMD_OK;
 }

@@ -246,14 +246,16 @@ JXL_DEV void blend_canvas_pixel(const DevBuffers &B, const uint8_t *stat, int ou
   } else if (!has_alpha) bg[3] = 1.0f;
   float out[4] = {bg[0], bg[1], bg[2], bg[3]};
   const int fx = x - F.crop_x0, fy = y - F.crop_y0;
-  if (fx >= 0 && fy >= 0 && fx < F.width && fy < F.height) {
-    const size_t po = (size_t)fy * (size_t)F.pw + (size_t)fx;
+  const bool ups = F.upsampling > 1;                       // an upsampled frame is blended at its full resolution: the upsampled planes (DevBuffers::up), after the noise
+  if (fx >= 0 && fy >= 0 && fx < (ups ? F.full_w : F.width) && fy < (ups ? F.full_h : F.height)) {
+    const size_t po = ups ? (size_t)fy * (size_t)F.full_w + (size_t)fx : (size_t)fy * (size_t)F.pw + (size_t)fx;
     const bool a = compose_final_is_a(F);
-    const float p0 = (a ? B.plane_a[0] : B.plane_b[0])[po], p1 = (a ? B.plane_a[1] : B.plane_b[1])[po], p2 = (a ? B.plane_a[2] : B.plane_b[2])[po];
+    const float p0 = ups ? B.up[0][po] : (a ? B.plane_a[0] : B.plane_b[0])[po], p1 = ups ? B.up[1][po] : (a ? B.plane_a[1] : B.plane_b[1])[po], p2 = ups ? B.up[2][po] : (a ? B.plane_a[2] : B.plane_b[2])[po];
     float fg[3];
     if ((F.is_modular && !F.xyb_modular) || F.not_xyb) plain_to_rgb(F, p0, p1, p2, fg); else xyb_to_rgb(F, p0, p1, p2, fg);
     float fa = 1.0f;
-    if (has_alpha) fa = (float)mod_plane(B, F, F.mod_out[3])[(size_t)fy * (size_t)F.width + (size_t)fx] * (1.0f / (float)((1u << F.mod_alpha_bits) - 1));
+    if (has_alpha) fa = F.alpha_up > 1 ? B.up[3][(size_t)fy * (size_t)F.full_w + (size_t)fx]      // enlarged beforehand (upsample_alpha_pixel)
+                                       : (float)mod_plane(B, F, F.mod_out[3])[(size_t)fy * (size_t)F.alpha_w + (size_t)fx] * (1.0f / (float)((1u << F.mod_alpha_bits) - 1));
     // colour channels
     {
       float wa = fa;

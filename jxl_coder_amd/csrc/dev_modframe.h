@@ -70,7 +70,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
   modular_stream_stage(S, tid, nthreads);
   sync();
   const int n = F.mod_first_group_ch;
-  for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; }
+  for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; S.ch[c].hs = (int16_t)F.mod_hs[c]; S.ch[c].vs = (int16_t)F.mod_vs[c]; }
   sync();
   uint32_t e = mod_decode_stream(S, S.ch, n, 0, tid);
   if (tid == 0 && e) *B.err |= e | kErrStageLf;
@@ -99,7 +99,7 @@ JXL_DEV uint32_t mod_lfgroup_body(const DevBuffers &B, DevModScratch &S, int g, 
       const int gw = ld >> hs, gh = ld >> vs;
       rw = rw < 0 ? 0 : rw > gw ? gw : rw; rh = rh < 0 ? 0 : rh > gh ? gh : rh;
       if (rw == 0 || rh == 0) continue;
-      S.ch[n].d = scr + (size_t)my * 65536; S.ch[n].w = rw; S.ch[n].h = rh; S.grp_src[n] = fc;
+      S.ch[n].d = scr + (size_t)my * 65536; S.ch[n].w = rw; S.ch[n].h = rh; S.ch[n].hs = (int16_t)hs; S.ch[n].vs = (int16_t)vs; S.grp_src[n] = fc;
       n++;
     }
     S.grp_n = n;
@@ -201,7 +201,7 @@ JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, i
       const int gw = gd >> hs, gh = gd >> vs;
       rw = rw < 0 ? 0 : rw > gw ? gw : rw; rh = rh < 0 ? 0 : rh > gh ? gh : rh;
       if (rw == 0 || rh == 0) continue;
-      S.ch[n].d = scr + (size_t)c * (size_t)gd * (size_t)gd; S.ch[n].w = rw; S.ch[n].h = rh; S.grp_src[n] = fc;
+      S.ch[n].d = scr + (size_t)c * (size_t)gd * (size_t)gd; S.ch[n].w = rw; S.ch[n].h = rh; S.ch[n].hs = (int16_t)hs; S.ch[n].vs = (int16_t)vs; S.grp_src[n] = fc;
       n++;
     }
     S.grp_n = n;
@@ -226,7 +226,7 @@ JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, i
         for (int k = t.begin_c + t.num_c; k < cnt; k++) S.ch[k - (t.num_c - 1)] = S.ch[k];
         cnt -= t.num_c - 1;
         for (int k = cnt; k > 0; k--) S.ch[k] = S.ch[k - 1];
-        S.ch[0].d = pal_scr + pal_used; S.ch[0].w = t.nb_colours; S.ch[0].h = t.num_c;
+        S.ch[0].d = pal_scr + pal_used; S.ch[0].w = t.nb_colours; S.ch[0].h = t.num_c; S.ch[0].hs = S.ch[0].vs = -1;
         pal_used += need; cnt++; nmeta++;
       } else S.st.err = kErrSqueeze;                                      // group-level squeeze: not on the device
     }

@@ -17,7 +17,8 @@ constexpr int kWpMaxW = 256;
 constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
-struct DevChanOut { int32_t *d; int32_t w, h; };
+constexpr int kModMaxRefs = 12;                    // previous channels an MA tree may look at (properties 16 ..: four per channel; libjxl's encoder offers up to 11)
+struct DevChanOut { int32_t *d; int32_t w, h; int16_t hs, vs; };      // hs / vs: the channel's shifts (-1: a meta channel) — what decides, with the size, which earlier channels the "previous channel" MA properties read
 
 #ifndef JXL_MOD_POOL_BYTES
 #define JXL_MOD_POOL_BYTES 30720
@@ -55,7 +56,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t rows[3][kModMaxW + 8];      // cur / prev / prevprev rows
   uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
   int32_t wp_err[2 * (kWpMaxW + 2)];
-  int32_t props[32];
+  int32_t props[16 + 4 * kModMaxRefs];
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
   uint32_t wdiv[4][64];               // divlut pre-multiplied by the WP header weights (wave_decode_channel_wpfixed)
   uint32_t ring[128];                 // the next 512 bytes of the stream, refilled half by half far ahead of the reader (wave_decode_channel_wpfixed)
@@ -244,7 +245,17 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
       fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d props 0x%x predictors 0x%x leaves %d (mul/offset != 1/0: %d)\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop, props_used, preds_used, leaves, nonunit);
     }
 #endif
-    if (tf.max_prop > 15) return kErrUnsupportedTransform;   // previous-channel properties: not on device yet
+    // properties 16 ..: four per earlier channel of the stream with this channel's size and shifts, nearest first (libjxl: PrecomputeReferences); properties
+    // beyond the channels there are read as zero.  Only this serial loop evaluates them (the wave loops decline such trees: wave_tree_build)
+    int nref = 0, nref_props = 0;
+    const int32_t *refp[kModMaxRefs];
+    if (tf.max_prop > 15) {
+      nref_props = (tf.max_prop - 16) / 4 + 1;
+      if (nref_props > kModMaxRefs) return kErrUnsupportedTransform;
+      for (int j = ci - 1; j >= 0 && nref < nref_props; j--)
+        if (chans[j].w == w && chans[j].h == h && chans[j].hs == c.hs && chans[j].vs == c.vs) refp[nref++] = chans[j].d;
+      for (int k = 16 + 4 * nref; k < 16 + 4 * nref_props; k++) props[k] = 0;
+    }
     const bool wide = w > kModMaxW;
     if (wide && tf.uses_wp && (!S.wide_wp || w > kWideMaxW)) return kErrUnsupportedTransform;
     props[0] = ci;
@@ -284,6 +295,14 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         int64_t wp_pred = 0;
         if (tf.uses_wp) { int32_t me; wp_pred = wp_predict(S, WR, wst, wp, x, y, w, N, W, NE, NW, NN, me); props[15] = me; }
         else props[15] = 0;
+        for (int r = 0; r < nref; r++) {
+          const int32_t *rp = refp[r] + (size_t)y * (size_t)w;
+          const int64_t v = rp[x], vl = x ? rp[x - 1] : 0, vt = y ? rp[x - w] : vl, vtl = (x && y) ? rp[x - w - 1] : vl;
+          const int64_t lo = vl < vt ? vl : vt, hi = vl < vt ? vt : vl, grad = vl + vt - vtl;
+          const int64_t vp = vtl > hi ? lo : vtl < lo ? hi : grad;      // the clamped gradient of the reference channel at this position
+          props[16 + 4 * r] = (int32_t)iabs64(v); props[17 + 4 * r] = (int32_t)v;
+          props[18 + 4 * r] = (int32_t)iabs64(v - vp); props[19 + 4 * r] = (int32_t)(v - vp);
+        }
         const DevTreeNode *nd = S.tree_ncache > 0 ? &S.tree[0] : &gtree[0];
         while (nd->prop >= 0) {
           int idx = props[nd->prop] > nd->splitval ? nd->lchild : nd->rchild;

@@ -105,9 +105,9 @@ JXL_DEV uint32_t lf_phase_coeffs(const DevBuffers &B, DevModScratch &S, int g, i
   const LfGeom q = lf_geom(F, g);
   int32_t *scr = B.lf_scratch + (size_t)g * kLfScratchInts;
   DevChanOut *ch = S.ch;
-  for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; }
+  for (int c = 0; c < 3; c++) { ch[c].d = scr + (size_t)c * 65536; ch[c].w = q.bw; ch[c].h = q.bh; ch[c].hs = ch[c].vs = 0; }
   if (F.subsampled) {       // YCbCr frame with subsampled chroma: stream channels Y, Cb, Cr carry the group's rectangle >> the channel's shifts (the block grid is whole MCUs)
-    for (int i = 0; i < 3; i++) { const int c = i == 0 ? 1 : i == 1 ? 0 : 2; ch[i].w = q.bw >> F.hshift[c]; ch[i].h = q.bh >> F.vshift[c]; }
+    for (int i = 0; i < 3; i++) { const int c = i == 0 ? 1 : i == 1 ? 0 : 2; ch[i].w = q.bw >> F.hshift[c]; ch[i].h = q.bh >> F.vshift[c]; ch[i].hs = (int16_t)F.hshift[c]; ch[i].vs = (int16_t)F.vshift[c]; }
   }
   return lf_decode_stream<kWave, kGeneral>(S, ch, 3, 1 + g, tid);
 }
@@ -131,6 +131,7 @@ JXL_DEV uint32_t lf_phase_meta(const DevBuffers &B, DevModScratch &S, int g, int
   const int count = scr[kLfScratchInts - 2];
   int32_t *m_x = scr + 3 * 65536, *m_b = m_x + 1024, *m_blk = m_b + 1024, *m_sharp = m_blk + 2 * 65536;
   DevChanOut *ch = S.ch;
+  for (int i = 0; i < 4; i++) ch[i].hs = ch[i].vs = 0;
   ch[0].d = m_x; ch[0].w = q.tw; ch[0].h = q.th;
   ch[1].d = m_b; ch[1].w = q.tw; ch[1].h = q.th;
   ch[2].d = m_blk; ch[2].w = count; ch[2].h = 2;

@@ -97,6 +97,7 @@ struct Priv {                 // state between phase 1 and phase 2
   DevFrame F;
   std::vector<DevSection> secs;
   int ref_w[4] = {0, 0, 0, 0}, ref_h[4] = {0, 0, 0, 0};     // reference slots as they are when this frame is decoded
+  bool ref_patch_ok[4] = {false, false, false, false};       // ... and whether a slot holds a frame as it was before the colour transform (a patch source) rather than a blended canvas / nothing this decode keeps
   bool blend = false, save_canvas = false, has_src = false; int alpha_ec = -1, lf_w = 0, lf_h = 0;      // composition over a canvas (plan_parse: the frame walk)
   int64_t tree_bit = -1;        // where the global MA tree starts inside LfGlobal (-1: none): a RAW dequant matrix of HfGlobal may be coded with it
 };
@@ -131,6 +132,7 @@ static int parse_patches(FramePlan *plan, Priv *pv, hx_br *sb, Blob &blob) {
     P.x0 = (int32_t)hx_ec_read(&ec, sb, 3); P.y0 = (int32_t)hx_ec_read(&ec, sb, 3);
     const uint32_t pw = hx_ec_read(&ec, sb, 2), ph = hx_ec_read(&ec, sb, 2);
     if (P.ref < 0 || P.ref > 3 || pv->ref_w[P.ref] <= 0) { err = "patch dictionary: reference to an empty slot"; break; }
+    if (!pv->ref_patch_ok[P.ref]) { err = "unsupported: patch taken from a frame saved after the colour transform"; break; }
     if (pw >= (1u << 24) || ph >= (1u << 24) || P.x0 < 0 || P.y0 < 0 || (uint64_t)P.x0 + pw + 1 > (uint64_t)pv->ref_w[P.ref] || (uint64_t)P.y0 + ph + 1 > (uint64_t)pv->ref_h[P.ref]) { err = "patch dictionary: patch outside its reference frame"; break; }
     P.w = (int32_t)pw + 1; P.h = (int32_t)ph + 1;
     const uint32_t count = hx_ec_read(&ec, sb, 7);
@@ -677,7 +679,12 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
   for (size_t i = last + 1; i-- > 0;) {
     if (!recs[i].needed) continue;
     const frame_hdr &f = recs[i].f;
-    if (f.flags & 2) for (int k = 0; k < 4; k++) if (occupant_at[i * 4 + (size_t)k] >= 0) recs[(size_t)occupant_at[i * 4 + (size_t)k]].needed = true;    // patches may name any slot
+    // patches may name any slot that holds a frame as it was before the colour transform (libjxl's encoder keeps its patch frames that way: kReferenceOnly,
+    // save_before_color_transform); a slot with a frame of the animation itself, saved after it, is not a patch source — the dictionary parser refuses a patch that names one
+    if (f.flags & 2) for (int k = 0; k < 4; k++) {
+      const int occ = occupant_at[i * 4 + (size_t)k];
+      if (occ >= 0 && (recs[(size_t)occ].f.save_before_ct || recs[(size_t)occ].f.frame_type == 2 || !m.pub.xyb_encoded)) recs[(size_t)occ].needed = true;
+    }
     if (f.flags & 32) {
       // kUseDcFrame (progressive_dc): the frame's LF image is the latest LF frame of the next level before it (libjxl's dc_frames[lf_level]) instead of LF
       // coefficients; an LF frame may itself be a VarDCT frame with an LF frame of its own (progressive_dc = 2: level 1 VarDCT over level 2 Modular)
@@ -708,7 +715,6 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
   const auto blend_checks = [&](const FrameRec &r) -> bool {
     const frame_hdr &f = r.f;
     if (!r.blend) return true;
-    if (f.upsampling != 1) { plan->error = "unsupported: blending of an upsampled frame"; return false; }
     for (int ch : {0, alpha_ec >= 0 ? 1 + alpha_ec : 0}) {
       if ((f.bl_mode[ch] == 2 || f.bl_mode[ch] == 3) && m.num_extra > 0 && f.bl_alpha[ch] != alpha_ec) { plan->error = "unsupported: blending weighted by an extra channel that is not the alpha channel"; return false; }
     }
@@ -724,6 +730,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     sub->priv = spv;
     spv->m = m; spv->f = f;
     memcpy(spv->ref_w, slot_w, sizeof(slot_w)); memcpy(spv->ref_h, slot_h, sizeof(slot_h)); 
+    for (int k = 0; k < 4; k++) { const int occ = occupant_at[i * 4 + (size_t)k]; spv->ref_patch_ok[k] = occ >= 0 && recs[(size_t)occ].needed && !recs[(size_t)occ].canvas_needed; }
     { const int lv = (f.frame_type == 1 ? f.lf_level : 0) + 1; spv->lf_w = lf_w[lv]; spv->lf_h = lf_h[lv]; }
     if (f.frame_type == 1 && (f.lf_level < 1 || f.lf_level > 4)) { plan->error = "LF frame level out of range"; return -1; }
     if (!recs[i].canvas_needed && f.frame_type != 1) {
@@ -747,6 +754,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
   pv->blend = recs[last].blend; pv->save_canvas = false; pv->has_src = recs[last].src_frame >= 0; pv->alpha_ec = alpha_ec;
   pv->f = recs[last].f;
   memcpy(pv->ref_w, slot_w, sizeof(slot_w)); memcpy(pv->ref_h, slot_h, sizeof(slot_h));
+  for (int k = 0; k < 4; k++) { const int occ = occupant_at[last * 4 + (size_t)k]; pv->ref_patch_ok[k] = occ >= 0 && recs[(size_t)occ].needed && !recs[(size_t)occ].canvas_needed; }
   return build_frame(plan, pv, recs[last], /*is_shown=*/true, raw_w, raw_h);
 }
 
@@ -780,7 +788,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     // an upsampled frame (what the reference's encoder writes from distance 10 up, i.e. its quality <= 12: interop/JxlEncoding.cpp:38-46) is coded at
     // ceil(size / upsampling) and enlarged after the patches (dev_compose.h)
     if (!m.pub.xyb_encoded) { plan->error = "unsupported: upsampling of a frame that is not XYB"; return -1; }
-    if (!is_shown) { plan->error = "unsupported: upsampled reference frame"; return -1; }
+    if (!is_shown && !pv->blend) { plan->error = "unsupported: upsampled reference frame"; return -1; }      // (a frame kept as a canvas goes through the blend kernel at its full resolution; one kept as a patch source does not)
   }
   if (is_shown && !pv->blend && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {
     // a frame that does not cover the canvas shows the blend source's canvas around it: the cleared canvas (plan_parse has checked that no

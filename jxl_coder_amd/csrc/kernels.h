@@ -51,7 +51,7 @@ void launch_blend_canvas(const DevBuffers &B, const uint8_t *stat, int canvas_w,
 void launch_save_ref(const DevBuffers &B, int w, int h, float *dst, hipStream_t s);
 void launch_compose_write(const DevBuffers &B, const uint8_t *stat, int w, int h, hipStream_t s);
 void launch_upsample_alpha(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s);      // alpha coded coarser than the image -> DevBuffers::up[3]
-void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, hipStream_t s);      // upsampled frames: enlarge, then write at full resolution
+void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, bool write, hipStream_t s);      // upsampled frames: enlarge, then write at full resolution
 void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s);
 void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s);
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s);

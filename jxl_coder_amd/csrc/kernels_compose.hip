@@ -96,11 +96,11 @@ __global__ void __launch_bounds__(256) k_upsample_alpha(DevBuffers B, const uint
 void launch_upsample_alpha(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s) {
   hipLaunchKernelGGL(k_upsample_alpha, dim3((full_w + 63) / 64, (full_h + 3) / 4), dim3(256), 0, s, B, stat);
 }
-void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, hipStream_t s) {
+void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, bool write, hipStream_t s) {
   const dim3 g((full_w + 63) / 64, (full_h + 3) / 4);
   hipLaunchKernelGGL(k_upsample, g, dim3(256), 0, s, B, stat);
-  if (noise) launch_noise(B, full_w, full_h, s);          // libjxl's stage order: Upsampling, Noise, colour transform
-  hipLaunchKernelGGL(k_upsampled_write, g, dim3(256), 0, s, B, stat);
+  if (noise) launch_noise(B, full_w, full_h, s);          // libjxl's stage order: Upsampling, Noise, colour transform (, Blending)
+  if (write) hipLaunchKernelGGL(k_upsampled_write, g, dim3(256), 0, s, B, stat);      // (a blended frame: the blend kernel reads the upsampled planes and writes)
 }
 
 void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s) { hipLaunchKernelGGL(k_mod_to_planes, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B); }

@@ -87,7 +87,8 @@ LOSSLESS_CASES = LOSSLESS_CASES + SQUEEZE_LOSSLESS_CASES
 NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls700x500_e7_nopatch", "lgrad400x300_e7", "lgrad2d200x150_e3", "lflat400x300_e7",
                            "l2c400x300_e7", "lmany128x96_e3",
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
-                           "lra400x300_e7"]                                     # group streams with leaf codes of more than 64 clusters
+                           "lra400x300_e7",
+                           "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3"]      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
@@ -109,7 +110,7 @@ JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j
 # Animations with layers (cropped frames blended over reference slots: kBlend, kAdd, kMulAdd, kMul on colour and alpha, zero-duration layers, two slots):
 # every coalesced frame against what the reference's JxlAnimatedDecoder::getFrame returns.  Lossless bit-exact, lossy within the VarDCT tolerance.
 ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless"]
-ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5"]
+ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_d12_e7", "an_modes_d15_e7"]      # the last two: upsampled layers (the reference's quality <= 12)
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]

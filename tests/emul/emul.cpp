@@ -57,6 +57,11 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   };
   if (F.noise && F.upsampling == 1 && !getenv("JXLEMUL_NO_NOISE")) noise();
   if (F.blend) {                                           // jxlamd_decoder::launch_compose_tail: the frame over its canvas (k_blend_canvas)
+    if (F.alpha_up > 1 && F.mod_out[3] >= 0) for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_alpha_pixel(B, F, stat, X, Y);
+    if (F.upsampling > 1) {
+      for (int Y = 0; Y < F.full_h; Y++) for (int X = 0; X < F.full_w; X++) upsample_pixel(B, F, stat, X, Y);
+      if (F.noise && !getenv("JXLEMUL_NO_NOISE")) noise();
+    }
     DevBuffers Bb = B;
     std::vector<float> keep[4];
     const bool has_alpha = (F.has_ec || F.is_modular) && F.mod_out[3] >= 0;

@@ -84,6 +84,11 @@ CASES = {
     # nb_colours + nb_deltas wide), indices below zero = the 143 implicit deltas, every delta added to the Average4 prediction of the pixel (raster order)
     "lpl400x300_e7_nopatch": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1), (8, 0)))),   # 7 colours + 12 explicit deltas
     "lpl200x136_e7_photo": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((23, 1), (8, 0)))),                        # 1024 colours, implicit deltas only
+    # MA trees that look at previous channels (JXL_ENC_FRAME_SETTING_MODULAR_NB_PREV_CHANNELS = 29; cjxl -E): properties 16.. = |v|, v, |v - gradient|, v - gradient
+    # of the nearest earlier channels of the same size and shift
+    "lpc200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3),))),
+    "lpca300x200_e9_prev11": (300, 200, dict(seed=9, alpha=True), dict(lossless=True, effort=9, extra=((29, 11),))),       # RGBA, eleven references asked for, three there
+    "lpcr200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3), (16, 1)))),             # with squeeze: channels of many sizes, few share one
     "lra400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # squeezed RGBA at effort 7: group streams whose own leaf codes have more than 64 clusters
     "ls400x300_e7": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=7)),              # patches
     "lpl400x300_e7": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1),))),                   # lossy palette in the patch frame and in the main frame
@@ -197,6 +202,9 @@ ANIM_CASES = {
     "an_blend_d1_e7": ("blend", dict(lossless=False, distance=1.0, effort=7)),
     "an_modes_lossless": ("modes", dict(lossless=True, effort=3)),
     "an_modes_d2_e5": ("modes", dict(lossless=False, distance=2.0, effort=5)),
+    # the reference's quality <= 12 (distance >= 10): every layer coded at half size, upsampled, then blended at the full resolution
+    "an_blend_d12_e7": ("blend", dict(lossless=False, distance=12.0, effort=7)),
+    "an_modes_d15_e7": ("modes", dict(lossless=False, distance=15.0, effort=7)),
 }
 
 
@@ -291,6 +299,18 @@ def with_alpha(img):
 ASSETS = {"asset_first_jxl": "first_jxl.jxl", "asset_wide_gamut": "wide_gamut.jxl", "asset_animated": "animated_jxl.jxl"}     # data files of the reference (app/src/main/assets)
 
 
+def add_unsupported_exemplar(only):
+    """A VALID file the device path refuses (the tests' "unsupported, not corrupt, and never a CPU route" case): a flat 8200 x 8200 RGBA image, lossless with
+    squeeze — 20 squeeze steps on four channels = 84 stream channels, four more than the frame tables hold.  81 KB; decoding it is not part of any test."""
+    name = "u8200x8200_squeeze_84_channels"
+    if only and name not in only:
+        return
+    img = np.zeros((8200, 8200, 4), np.uint8); img[..., 0] = 37; img[..., 1] = 150; img[..., 2] = 190; img[..., 3] = 255
+    data = jxl_ref.encode(img, lossless=True, effort=3, extra=((16, 1),))
+    open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+    print(name, len(data))
+
+
 def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):
     """Real photographs: the reference's own demo assets (inputs) + what the reference's libjxl decodes them to."""
     for name, src in ASSETS.items():
@@ -351,6 +371,8 @@ def main():
     add_rowsum_cases(meta, only)
     add_jpeg_cases(meta, only)
     add_anim_cases(meta, only)
+    if only and "u8200x8200_squeeze_84_channels" in only:
+        add_unsupported_exemplar(only)          # (9 s and 1.5 GB of encoder memory: on request only)
     if not only or "big_assets" in only:
         add_big_assets(meta)
     if only:

@@ -35,7 +35,7 @@ def test_golden_vectors(dec, oracle, name):
     assert d2.max() <= 1 and (d2 > 0).mean() < 2e-3                           # vs the CPU oracle: same algorithm
     assert np.array_equal(out[..., 3], exp[..., 3])                          # opaque 255, or the Modular-coded alpha bit for bit
     assert info["out_bits"] == 8 and info["prefer_encoding"] == 1
-    assert info["has_alpha_in_origin"] == int(name.startswith("va"))
+    assert info["has_alpha_in_origin"] == int(name.startswith(("va", "vna")))       # va* / vna*: the RGBA fixtures
 
 
 def test_vardct_with_squeezed_alpha_beyond_2048_pixels(dec, golden_meta):
@@ -127,7 +127,7 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    art = open(os.path.join(ROOT, "tests", "golden", "u200x136_prev_channel_props.jxl"), "rb").read()       # MA tree with properties of the previous channels (JXL_ENC_FRAME_SETTING_MODULAR_NB_PREV_CHANNELS = 3, cjxl -E 3): not on the device path — and a VALID file: unsupported, not corrupt
+    art = open(os.path.join(ROOT, "tests", "golden", "u8200x8200_squeeze_84_channels.jxl"), "rb").read()      # a flat 8200 x 8200 RGBA image, lossless with squeeze: 84 stream channels, four more than the frame tables hold (tests/golden/make_golden.py: add_unsupported_exemplar) — a VALID file: unsupported, not corrupt
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
         dec.decode_one_shot(art)
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
@@ -258,7 +258,10 @@ def test_animation_frames(dec, name):
         else:
             d = np.abs(out.astype(int) - frames[i].astype(int))
             assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (i, d.max(), d.mean())
-            assert np.array_equal(out[..., 3], frames[i][..., 3])
+            if name in ("an_blend_d12_e7", "an_modes_d15_e7"):      # upsampled layers: the alpha is coded at half size, enlarged by the same float kernels as the colour and dithered — the colour's tolerance
+                assert np.abs(out[..., 3].astype(int) - frames[i][..., 3].astype(int)).max() <= 1
+            else:
+                assert np.array_equal(out[..., 3], frames[i][..., 3])
         assert info["have_animation"] == 1
         if i == 1:
             o2, _ = dec.decode_one_shot(other)

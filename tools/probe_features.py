@@ -97,6 +97,42 @@ def cases():
     yield "rgb lossless modular group 3 (1024)", big, dict(lossless=True, effort=3, extra=((MOD_GROUP, 3),))
     for p in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
         yield f"rgb lossless predictor {p}", ph[:120, :160], dict(lossless=True, effort=4, extra=((MOD_PRED, p),))
+    # progressive forms (cjxl -p), LF frames, previous-channel properties (cjxl -E), streaming encodes
+    yield "rgba d1 qprog_ac (plain alpha)", pha, dict(distance=1.0, extra=((QPROG_AC, 1),))
+    yield "big rgba d1 qprog_ac + responsive", biga, dict(distance=1.0, extra=((QPROG_AC, 1), (RESPONSIVE, 1)))
+    yield "big rgb d3 prog_dc 1 + prog_ac", big, dict(distance=3.0, extra=((PROG_DC, 1), (PROG_AC, 1)))
+    yield "big rgb d1 prog_dc 2 + qprog_ac", big, dict(distance=1.0, extra=((PROG_DC, 2), (QPROG_AC, 1)))
+    yield "big rgba d1.5 prog_dc 2", biga, dict(distance=1.5, extra=((PROG_DC, 2),))
+    yield "lossless rgb qprog_ac + responsive", ph, dict(lossless=True, extra=((QPROG_AC, 1), (RESPONSIVE, 1)))
+    yield "lossy modular rgba prog_ac", pha, dict(distance=2.0, modular=1, extra=((PROG_AC, 1),))
+    yield "big rgba lossless e7 nb_prev 5", biga, dict(lossless=True, effort=7, extra=((NB_PREV, 5),))
+    yield "rgba lossless e9 nb_prev 11", pha[:200, :300], dict(lossless=True, effort=9, extra=((NB_PREV, 11),))
+    yield "rgb lossless responsive nb_prev 3", ph, dict(lossless=True, effort=7, extra=((NB_PREV, 3), (RESPONSIVE, 1)))
+    yield "rgba d1 nb_prev 3", pha, dict(distance=1.0, extra=((NB_PREV, 3),))
+    yield "rgb lossy modular nb_prev 3", ph, dict(distance=1.0, modular=1, extra=((NB_PREV, 3),))
+    yield "shot lossless e7 nb_prev 3", shot, dict(lossless=True, effort=7, extra=((NB_PREV, 3),))
+    yield "rgb16 lossless nb_prev 2", ph16, dict(lossless=True, effort=7, extra=((NB_PREV, 2),))
+    yield "shot lossy palette, no patches", shot, dict(lossless=True, extra=((LOSSY_PALETTE, 1), (PATCHES, 0)))
+    yield "rgb lossy palette (implicit deltas)", ph[:136, :200], dict(lossless=True, extra=((LOSSY_PALETTE, 1), (PATCHES, 0)))
+    yield "shot d1 + noise", shot, dict(distance=1.0, extra=((NOISE, 1),))
+    yield "rgba d12 + noise", pha, dict(distance=12.0, extra=((NOISE, 1),))
+    for b in (2, 3):
+        yield f"shot lossless e7 buffering {b}", synth.screenshot(600, 400, seed=2), dict(lossless=True, effort=7, extra=((34, b),))
+        yield f"rgb d1 buffering {b}", synth.photo_like(600, 400, seed=3), dict(distance=1.0, extra=((34, b),))
+
+
+def animations():
+    """layered animations (libjxl's encoder API through oracle/ref_shim): every coalesced frame against the reference's getFrame sequence"""
+    def rgba(img, a=255):
+        return np.dstack([img[..., :3], np.full(img.shape[:2], a, np.uint8)])
+    s1, s2, s3 = rgba(synth.screenshot(200, 136, seed=1)), rgba(synth.screenshot(120, 80, seed=2), 200), rgba(synth.screenshot(200, 136, seed=3))
+    p1, p2 = rgba(synth.photo_like(200, 136, seed=4)), rgba(synth.photo_like(90, 70, seed=5), 160)
+    scenes = {"screenshots, replace": [dict(rgba=s1, duration=3, save=1), dict(rgba=s3, duration=3)],
+              "screenshots, blend": [dict(rgba=s1, duration=3, save=1), dict(rgba=s2, x0=30, y0=20, blend=2, source=1, duration=3, save=1), dict(rgba=s2, x0=60, y0=40, blend=2, source=1, duration=3)],
+              "photos, blend": [dict(rgba=p1, duration=3, save=1), dict(rgba=p2, x0=33, y0=21, blend=2, source=1, duration=3, save=1), dict(rgba=p2, x0=-10, y0=90, blend=2, source=1, duration=3)]}
+    for nm, frames in scenes.items():
+        for kw in (dict(lossless=True, effort=7), dict(lossless=False, distance=1.0, effort=7), dict(lossless=False, distance=12.0, effort=7)):
+            yield f"anim {nm} {'lossless' if kw['lossless'] else 'd%g' % kw['distance']}", frames, kw
 
 
 def main():
@@ -121,6 +157,20 @@ def main():
             continue
         d = np.abs(r.astype(np.int64) - got.astype(np.int64))
         print(f"{name:48s} {len(data):8d} B  ok max {int(d.max())} mean {float(d.mean()):.4f}")
+    lib.emul_set_target_frame.argtypes = [C.c_int]
+    for name, frames, kw in animations():
+        if sub not in name:
+            continue
+        data = jxl_ref.encode_anim(frames, 200, 136, **kw)
+        durs, _ = jxl_ref.anim_info(data)
+        worst, res = 0, "ok"
+        for i in range(sum(1 for j, f in enumerate(frames) if f.get("duration", 1) > 0 or j == len(frames) - 1)):
+            lib.emul_set_target_frame(i); got, err = emul_decode(lib, data); lib.emul_set_target_frame(-1)
+            if got is None:
+                res = f"REJECT frame {i}: {err}"
+                break
+            worst = max(worst, int(np.abs(got.astype(np.int64) - np.asarray(jxl_ref.decode_frame(data, i)).astype(np.int64)).max()))
+        print(f"{name:48s} {len(data):8d} B  {res} max {worst}")
 
 
 if __name__ == "__main__":
