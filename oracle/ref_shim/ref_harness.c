@@ -184,12 +184,15 @@ void ref_set_custom_xy(const double *xy8) { g_custom_xy_set = xy8 != NULL; if (x
 static int g_orientation;
 void ref_set_orientation(int o) { g_orientation = o; }
 
+/* one more extra channel for the next ref_encode: an 8-bit plane of the image's size and its JxlExtraChannelType (NULL: none) */
+static const uint8_t *g_extra_plane = NULL; static int g_extra_type = 0;
+void ref_set_extra_channel(const uint8_t *plane, int type) { g_extra_plane = plane; g_extra_type = type; }
 int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, uint8_t **out, size_t *out_size) {
   if (load_libs()) return -1;
   SYM(h_jxl, JxlEncoderSetICCProfile);
   SYM(h_jxl, JxlEncoderCreate); SYM(h_jxl, JxlEncoderDestroy); SYM(h_jxl, JxlEncoderSetParallelRunner);
   SYM(h_jxl, JxlEncoderInitBasicInfo); SYM(h_jxl, JxlEncoderSetBasicInfo); SYM(h_jxl, JxlEncoderInitExtraChannelInfo);
-  SYM(h_jxl, JxlEncoderSetExtraChannelInfo); SYM(h_jxl, JxlEncoderSetColorEncoding);
+  SYM(h_jxl, JxlEncoderSetExtraChannelInfo); SYM(h_jxl, JxlEncoderSetColorEncoding); SYM(h_jxl, JxlEncoderSetExtraChannelBuffer);
   SYM(h_jxl, JxlEncoderFrameSettingsCreate); SYM(h_jxl, JxlEncoderSetFrameDistance);
   SYM(h_jxl, JxlEncoderFrameSettingsSetOption); SYM(h_jxl, JxlEncoderSetFrameLossless);
   SYM(h_jxl, JxlEncoderAddImageFrame); SYM(h_jxl, JxlEncoderCloseInput); SYM(h_jxl, JxlEncoderProcessOutput);
@@ -208,20 +211,28 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   p_JxlEncoderInitBasicInfo(&bi);
   bi.xsize = p->xsize; bi.ysize = p->ysize; bi.bits_per_sample = p->bits;
   bi.uses_original_profile = p->lossless ? JXL_TRUE : JXL_FALSE;
-  bi.num_color_channels = p->num_channels == 1 ? 1 : 3;
+  const int has_alpha = p->num_channels == 2 || p->num_channels == 4;       /* 2: grey + alpha */
+  bi.num_color_channels = p->num_channels <= 2 ? 1 : 3;
   bi.alpha_premultiplied = JXL_FALSE;
   if (p->intensity_target > 0) bi.intensity_target = p->intensity_target;
   if (g_orientation >= 1 && g_orientation <= 8) bi.orientation = (JxlOrientation)g_orientation;
-  if (p->num_channels == 4) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
+  if (has_alpha) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
+  if (g_extra_plane) bi.num_extra_channels += 1;      /* one more extra channel (depth, spot colour, ...): ref_set_extra_channel */
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
-  if (p->num_channels == 4) {
+  if (has_alpha) {
     JxlExtraChannelInfo ci;
     p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
     ci.bits_per_sample = p->bits; ci.alpha_premultiplied = JXL_FALSE;
     if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
   }
+  if (g_extra_plane) {
+    JxlExtraChannelInfo ci;
+    p_JxlEncoderInitExtraChannelInfo((JxlExtraChannelType)g_extra_type, &ci);
+    ci.bits_per_sample = 8;
+    if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, has_alpha ? 1 : 0, &ci)) { rc = -4; goto done; }
+  }
   JxlColorEncoding ce;
-  p_JxlColorEncodingSetToSRGB(&ce, p->num_channels == 1);
+  p_JxlColorEncodingSetToSRGB(&ce, p->num_channels <= 2);
   if (p->primaries) ce.primaries = (JxlPrimaries)p->primaries;
   if (p->transfer) ce.transfer_function = (JxlTransferFunction)p->transfer;
   if (g_custom_xy_set) {
@@ -244,6 +255,10 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
     if (p->extra[i][0] >= 0)
       if (JXL_ENC_SUCCESS != p_JxlEncoderFrameSettingsSetOption(fs, (JxlEncoderFrameSettingId)p->extra[i][0], p->extra[i][1])) { rc = -20 - i; goto done; }
   if (JXL_ENC_SUCCESS != p_JxlEncoderAddImageFrame(fs, &pf, pixels, pixels_size)) { rc = -10; goto done; }
+  if (g_extra_plane) {
+    JxlPixelFormat pf1 = {1, JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+    if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelBuffer(fs, &pf1, g_extra_plane, (size_t)p->xsize * p->ysize, has_alpha ? 1 : 0)) { rc = -12; goto done; }
+  }
   p_JxlEncoderCloseInput(enc);
   size_t cap = 1 << 16;
   uint8_t *buf = (uint8_t *)malloc(cap);

@@ -88,7 +88,8 @@ NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls7
                            "l2c400x300_e7", "lmany128x96_e3",
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
                            "lra400x300_e7",
-                           "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3"]      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
+                           "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3",
+                           "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
@@ -101,7 +102,7 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       # RGBA at low quality: alpha coded at half size (extra-channel upsampling; its values get the writer's dither like the colour), with patches, and alpha alone at half size
                       "vua400x300_e7_d12", "vusa400x300_e7_d12", "va400x300_e7_ecup2",
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
-                      "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vlf2a520x300_e7", "vnu600x410_e7_up2", "vnu523x267_e7_d12",
+                      "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vlf2a520x300_e7", "vnu600x410_e7_up2", "vnu523x267_e7_d12", "vga300x200_e7_d12",
                       # custom primaries (Adobe RGB) and a custom white point with custom primaries (ProPhoto, D50: Bradford on both sides as in libjxl's output stage)
                       "vcadobe200x136_e7", "vcprophoto200x136_e7"]
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW
@@ -114,7 +115,7 @@ ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_d12_e7", "an_
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
-VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7",
+VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05

@@ -89,6 +89,11 @@ CASES = {
     "lpc200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3),))),
     "lpca300x200_e9_prev11": (300, 200, dict(seed=9, alpha=True), dict(lossless=True, effort=9, extra=((29, 11),))),       # RGBA, eleven references asked for, three there
     "lpcr200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3), (16, 1)))),             # with squeeze: channels of many sizes, few share one
+    # grey + alpha (two-channel PNGs), and images with an extra channel that is not the alpha (depth / spot colour / selection mask: decoded, not part of the RGBA output)
+    "lga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=7)),
+    "lga300x200_e1": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=1)),
+    "lxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(lossless=True, effort=7)),
+    "lxs400x300_e3_rgba_selection": (400, 300, dict(seed=6, alpha=True, extra_type=3), dict(lossless=True, effort=3)),
     "lra400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # squeezed RGBA at effort 7: group streams whose own leaf codes have more than 64 clusters
     "ls400x300_e7": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=7)),              # patches
     "lpl400x300_e7": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1),))),                   # lossy palette in the patch frame and in the main frame
@@ -126,6 +131,10 @@ CASES = {
     "vapac520x300_e7": (520, 300, dict(seed=12, alpha=True), dict(effort=7, distance=1.0, extra=((17, 1),))),      # RGBA + progressive AC: the alpha's group streams follow the AC data of the LAST pass
     # what `cjxl -p` writes for RGBA: progressive AC + a squeezed (responsive) alpha — the alpha's channels are spread over the passes by their shift
     # (Passes::GetDownsamplingBracket: every pass has a ModularGroup stream of its own behind the AC data), single group and 3 x 2 groups
+    "vga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=1.0)),                  # grey + alpha, VarDCT
+    "vga300x200_e7_d12": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=12.0)),            # ... upsampled
+    "vxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(effort=7, distance=1.0)),                     # RGB + a depth channel
+    "vxs400x300_e7_rgba_spot": (400, 300, dict(seed=6, alpha=True, extra_type=2), dict(effort=7, distance=1.0)),     # RGBA + a spot-colour channel
     "vapr400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(effort=7, distance=1.0, extra=((17, 1), (16, 1)))),
     "vaqr520x300_e7": (520, 300, dict(seed=13, alpha=True), dict(effort=7, distance=1.0, extra=((18, 1), (16, 1)))),
     # ... and for a photograph with progressive DC: the LF frame is a Modular frame of several passes itself
@@ -230,6 +239,7 @@ def add_anim_cases(meta, only):
 def make_image(w, h, sk):
     """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
     sk = dict(sk)
+    sk.pop("extra_type", None)          # (an additional extra channel: main() hands its plane to the encoder)
     gen = sk.pop("gen", "photo")
     alpha = sk.pop("alpha", False)
     grey = sk.pop("grey", False)
@@ -359,7 +369,10 @@ def main():
         if only and name not in only:
             continue
         img = make_image(w, h, sk)
-        data = jxl_ref.encode(img, **ek)
+        more = {}
+        if "extra_type" in sk:          # one more extra channel behind the alpha (JxlExtraChannelType: 1 depth, 2 spot colour, 3 selection mask, 4 black): a ramp; the reference's RGBA output ignores it
+            more["extra_channel"] = ((np.arange(w)[None, :] // 2 + np.arange(h)[:, None] // 3).astype(np.uint8), sk["extra_type"])
+        data = jxl_ref.encode(img, **ek, **more)
         out, info, _ = jxl_ref.decode(data, allow16=True)
         open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
