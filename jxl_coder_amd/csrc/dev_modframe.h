@@ -70,7 +70,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
   modular_stream_stage(S, tid, nthreads);
   sync();
   const int n = F.mod_first_group_ch;
-  for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; S.ch[c].hs = (int16_t)F.mod_hs[c]; S.ch[c].vs = (int16_t)F.mod_vs[c]; }
+  for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; S.ch[c].hs = c < F.mod_nb_meta ? (int16_t)-1 : (int16_t)F.mod_hs[c]; S.ch[c].vs = c < F.mod_nb_meta ? (int16_t)-1 : (int16_t)F.mod_vs[c]; }      // (meta channels: shift -1, never a "previous channel" of an image channel)
   sync();
   uint32_t e = mod_decode_stream(S, S.ch, n, 0, tid);
   if (tid == 0 && e) *B.err |= e | kErrStageLf;

@@ -52,6 +52,7 @@ def lib():
         _lib.ref_version.restype = C.c_int
         _lib.ref_set_custom_xy.argtypes = [C.c_void_p]
         _lib.ref_set_extra_channel.argtypes = [C.c_void_p, C.c_int]
+        _lib.ref_set_premultiplied.argtypes = [C.c_int]
     return _lib
 
 
@@ -76,7 +77,7 @@ def decode(data: bytes, threads=0, allow16=True, mode=0):
 
 
 def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
-           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1, custom_xy=None, extra_channel=None):
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1, custom_xy=None, extra_channel=None, premultiplied=False):
     """pixels: [h,w,c] u8 or u16, c in 1,2,3,4 (2: grey + alpha). Same sequence as the reference's EncodeJxlOneshot.
     extra_channel: (plane [h,w] u8, JxlExtraChannelType) — one more extra channel behind the alpha (1 depth, 2 spot colour, 3 selection mask, 4 black, ...)."""
     pixels = np.ascontiguousarray(pixels)
@@ -99,7 +100,9 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
     lib().ref_set_custom_xy(C.cast(_xy, C.c_void_p) if custom_xy else None)      # custom white point + primaries (white xy, red, green, blue xy) instead of the enum values
     _ecp = np.ascontiguousarray(extra_channel[0], dtype=np.uint8) if extra_channel is not None else None
     lib().ref_set_extra_channel(C.c_void_p(_ecp.ctypes.data) if _ecp is not None else None, int(extra_channel[1]) if extra_channel is not None else 0)
+    lib().ref_set_premultiplied(int(premultiplied))          # the alpha is declared premultiplied (pixels taken as they are)
     rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
+    lib().ref_set_premultiplied(0)
     lib().ref_set_extra_channel(None, 0)
     lib().ref_set_icc(b"", 0)
     lib().ref_set_orientation(1)
@@ -135,7 +138,7 @@ class RefAnimFrame(C.Structure):
                 ("blend_mode", C.c_int32), ("source", C.c_int32), ("save_as_reference", C.c_int32), ("duration", C.c_uint32)]
 
 
-def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1), loops=0):
+def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1), loops=0, premultiplied=False):
     """frames: list of dicts {rgba: [h,w,4] u8, x0, y0, blend (0 replace, 1 add, 2 blend, 3 muladd, 4 mul), source, save, duration (ticks)} -> an
     animated JPEG XL over a W x H RGBA canvas (libjxl's encoder API, JxlEncoderSetFrameHeader with layer_info)."""
     arr = (RefAnimFrame * len(frames))()
@@ -146,7 +149,9 @@ def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1
         arr[i].x0, arr[i].y0 = f.get("x0", 0), f.get("y0", 0)
         arr[i].blend_mode, arr[i].source, arr[i].save_as_reference, arr[i].duration = f.get("blend", 0), f.get("source", 0), f.get("save", 0), f.get("duration", 1)
     out = C.c_void_p(); n = C.c_size_t()
+    lib().ref_set_premultiplied(int(premultiplied))
     rc = lib().ref_encode_anim(arr, len(frames), W, H, int(lossless), C.c_float(distance), effort, tps[0], tps[1], loops, C.byref(out), C.byref(n))
+    lib().ref_set_premultiplied(0)
     if rc != 0:
         raise ValueError(f"ref_encode_anim failed rc={rc}")
     data = C.string_at(out.value, n.value)

@@ -184,6 +184,9 @@ void ref_set_custom_xy(const double *xy8) { g_custom_xy_set = xy8 != NULL; if (x
 static int g_orientation;
 void ref_set_orientation(int o) { g_orientation = o; }
 
+/* the alpha of the next encodes is declared premultiplied (the pixels are taken as they are) */
+static int g_premultiplied = 0;
+void ref_set_premultiplied(int on) { g_premultiplied = on; }
 /* one more extra channel for the next ref_encode: an 8-bit plane of the image's size and its JxlExtraChannelType (NULL: none) */
 static const uint8_t *g_extra_plane = NULL; static int g_extra_type = 0;
 void ref_set_extra_channel(const uint8_t *plane, int type) { g_extra_plane = plane; g_extra_type = type; }
@@ -213,7 +216,7 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   bi.uses_original_profile = p->lossless ? JXL_TRUE : JXL_FALSE;
   const int has_alpha = p->num_channels == 2 || p->num_channels == 4;       /* 2: grey + alpha */
   bi.num_color_channels = p->num_channels <= 2 ? 1 : 3;
-  bi.alpha_premultiplied = JXL_FALSE;
+  bi.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
   if (p->intensity_target > 0) bi.intensity_target = p->intensity_target;
   if (g_orientation >= 1 && g_orientation <= 8) bi.orientation = (JxlOrientation)g_orientation;
   if (has_alpha) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
@@ -222,7 +225,7 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   if (has_alpha) {
     JxlExtraChannelInfo ci;
     p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
-    ci.bits_per_sample = p->bits; ci.alpha_premultiplied = JXL_FALSE;
+    ci.bits_per_sample = p->bits; ci.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
     if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
   }
   if (g_extra_plane) {
@@ -350,13 +353,14 @@ int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_
   JxlBasicInfo bi;
   p_JxlEncoderInitBasicInfo(&bi);
   bi.xsize = W; bi.ysize = H; bi.bits_per_sample = 8; bi.num_color_channels = 3; bi.num_extra_channels = 1; bi.alpha_bits = 8;
+  bi.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
   bi.uses_original_profile = lossless ? JXL_TRUE : JXL_FALSE;
   bi.have_animation = JXL_TRUE; bi.animation.tps_numerator = tps_num; bi.animation.tps_denominator = tps_den; bi.animation.num_loops = loops;
   bi.animation.have_timecodes = JXL_FALSE;
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
   JxlExtraChannelInfo ci;
   p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
-  ci.bits_per_sample = 8;
+  ci.bits_per_sample = 8; ci.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
   JxlColorEncoding ce;
   p_JxlColorEncodingSetToSRGB(&ce, JXL_FALSE);

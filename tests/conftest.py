@@ -89,7 +89,7 @@ NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls7
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
                            "lra400x300_e7",
                            "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3",
-                           "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
+                           "lpm400x300_e7_premultiplied", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
@@ -110,12 +110,12 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
 JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j420_prog_333x277", "jgrey_160x120", "j420s_400x300"]
 # Animations with layers (cropped frames blended over reference slots: kBlend, kAdd, kMulAdd, kMul on colour and alpha, zero-duration layers, two slots):
 # every coalesced frame against what the reference's JxlAnimatedDecoder::getFrame returns.  Lossless bit-exact, lossy within the VarDCT tolerance.
-ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless"]
-ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_d12_e7", "an_modes_d15_e7"]      # the last two: upsampled layers (the reference's quality <= 12)
+ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless", "an_blend_premul_lossless"]      # (the last: premultiplied alpha)
+ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_premul_d1_e7", "an_blend_d12_e7", "an_modes_d15_e7"]      # the last two: upsampled layers (the reference's quality <= 12)
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
-VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
+VARDCT_CASES = VARDCT_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vpm400x300_e7_premultiplied", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 
 # Parity statement: lossless/Modular bit-exact; VarDCT u8 max |diff| <= 1 LSB, mean |diff| <= 0.05

@@ -90,6 +90,7 @@ CASES = {
     "lpca300x200_e9_prev11": (300, 200, dict(seed=9, alpha=True), dict(lossless=True, effort=9, extra=((29, 11),))),       # RGBA, eleven references asked for, three there
     "lpcr200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3), (16, 1)))),             # with squeeze: channels of many sizes, few share one
     # grey + alpha (two-channel PNGs), and images with an extra channel that is not the alpha (depth / spot colour / selection mask: decoded, not part of the RGBA output)
+    "lpm400x300_e7_premultiplied": (400, 300, dict(seed=6, alpha=True, premul=True), dict(lossless=True, effort=7, premultiplied=True)),      # premultiplied alpha: delivered as stored
     "lga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=7)),
     "lga300x200_e1": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=1)),
     "lxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(lossless=True, effort=7)),
@@ -131,6 +132,7 @@ CASES = {
     "vapac520x300_e7": (520, 300, dict(seed=12, alpha=True), dict(effort=7, distance=1.0, extra=((17, 1),))),      # RGBA + progressive AC: the alpha's group streams follow the AC data of the LAST pass
     # what `cjxl -p` writes for RGBA: progressive AC + a squeezed (responsive) alpha — the alpha's channels are spread over the passes by their shift
     # (Passes::GetDownsamplingBracket: every pass has a ModularGroup stream of its own behind the AC data), single group and 3 x 2 groups
+    "vpm400x300_e7_premultiplied": (400, 300, dict(seed=6, alpha=True, premul=True), dict(effort=7, distance=1.0, premultiplied=True)),
     "vga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=1.0)),                  # grey + alpha, VarDCT
     "vga300x200_e7_d12": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=12.0)),            # ... upsampled
     "vxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(effort=7, distance=1.0)),                     # RGB + a depth channel
@@ -195,6 +197,11 @@ def anim_scene(kind):
     if kind == "blend":            # alpha-blended sprite moving over a kept background; edges not multiples of four, one layer partly outside the canvas
         return W, H, [dict(rgba=rgba(bg, 255), duration=5, save=1), dict(rgba=spr, x0=20, y0=30, blend=2, source=1, duration=5, save=1),
                       dict(rgba=spr, x0=70, y0=50, blend=2, source=1, duration=5, save=1), dict(rgba=spr[:, ::-1].copy(), x0=-10, y0=90, blend=2, source=1, duration=7)]
+    if kind == "blend_premul":     # the same layers with premultiplied alpha (declared so in the file): kBlend is then fg + bg (1 - alpha)
+        W, H, fr = anim_scene("blend")
+        for f in fr:
+            px = f["rgba"].copy(); px[..., :3] = (px[..., :3].astype(int) * px[..., 3:4] // 255).astype(np.uint8); f["rgba"] = px
+        return W, H, fr
     if kind == "modes":            # kAdd / kMulAdd / kMul layers, zero-duration layers (merged into the next shown frame), two slots, a translucent background
         soft = rgba(synth.photo_like(W, H, seed=3), 200)
         dim = rgba(np.full((30, 50, 3), 40, np.uint8), 128)
@@ -212,6 +219,8 @@ ANIM_CASES = {
     "an_modes_lossless": ("modes", dict(lossless=True, effort=3)),
     "an_modes_d2_e5": ("modes", dict(lossless=False, distance=2.0, effort=5)),
     # the reference's quality <= 12 (distance >= 10): every layer coded at half size, upsampled, then blended at the full resolution
+    "an_blend_premul_lossless": ("blend_premul", dict(lossless=True, effort=3, premultiplied=True)),
+    "an_blend_premul_d1_e7": ("blend_premul", dict(lossless=False, distance=1.0, effort=7, premultiplied=True)),
     "an_blend_d12_e7": ("blend", dict(lossless=False, distance=12.0, effort=7)),
     "an_modes_d15_e7": ("modes", dict(lossless=False, distance=15.0, effort=7)),
 }
@@ -240,6 +249,7 @@ def make_image(w, h, sk):
     """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
     sk = dict(sk)
     sk.pop("extra_type", None)          # (an additional extra channel: main() hands its plane to the encoder)
+    premul = sk.pop("premul", False)
     gen = sk.pop("gen", "photo")
     alpha = sk.pop("alpha", False)
     grey = sk.pop("grey", False)
@@ -252,6 +262,8 @@ def make_image(w, h, sk):
             img = np.ascontiguousarray(img[..., :1])
         if alpha:
             img = with_alpha(img)
+        if premul:
+            img = img.copy(); img[..., :3] = (img[..., :3].astype(int) * img[..., 3:4] // 255).astype(img.dtype)
         return img
     if gen == "screenshot":
         return synth.screenshot(w, h, sk.get("seed", 0), channels=4 if alpha else 3)
