@@ -26,8 +26,8 @@ JXL_DEV void mod_to_planes_pixel(const DevBuffers &B, const DevFrame &F, int x, 
     B.plane_a[1][po] = (float)vy * F.mod_xyb_fac[1];
     B.plane_a[2][po] = (float)(vb + vy) * F.mod_xyb_fac[2];
   } else {
-    const float sc = 1.0f / (float)((1u << F.mod_bits) - 1);
-    for (int c = 0; c < 3; c++) B.plane_a[c][po] = (float)mod_plane(B, F, F.mod_out[c])[si] * sc;
+    const float sc = 1.0f / (float)(((uint64_t)1 << F.mod_bits) - 1);      // (64-bit: a float image declares 32 bits)
+    for (int c = 0; c < 3; c++) { const int32_t v = mod_plane(B, F, F.mod_out[c])[si]; B.plane_a[c][po] = F.mod_exp_bits ? sample_bits_to_float(v, F.mod_bits, F.mod_exp_bits) : (float)v * sc; }
   }
 }
 
@@ -92,10 +92,10 @@ JXL_DEV void upsample_alpha_pixel(const DevBuffers &B, const DevFrame &F, const 
   const float sc = 1.0f / (float)((1u << F.mod_alpha_bits) - 1);
   int xs[5], ys[5];
   for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.alpha_w); ys[i] = mirror(y + i - 2, F.alpha_h); }
-  float acc = 0.0f, mn = (float)src[(size_t)ys[2] * (size_t)F.alpha_w + (size_t)xs[2]] * sc, mx = mn;
+  float acc = 0.0f, mn = F.mod_alpha_exp_bits ? alpha_sample_value(F, src[(size_t)ys[2] * (size_t)F.alpha_w + (size_t)xs[2]], true) : (float)src[(size_t)ys[2] * (size_t)F.alpha_w + (size_t)xs[2]] * sc, mx = mn;
   for (int iy = 0; iy < 5; iy++)
     for (int ix = 0; ix < 5; ix++) {
-      const float v = (float)src[(size_t)ys[iy] * (size_t)F.alpha_w + (size_t)xs[ix]] * sc;
+      const float v = F.mod_alpha_exp_bits ? alpha_sample_value(F, src[(size_t)ys[iy] * (size_t)F.alpha_w + (size_t)xs[ix]], true) : (float)src[(size_t)ys[iy] * (size_t)F.alpha_w + (size_t)xs[ix]] * sc;
 #ifdef __HIPCC__
       acc = __fadd_rn(__fmul_rn(k[iy * 5 + ix], v), acc);
 #else
@@ -255,7 +255,7 @@ JXL_DEV void blend_canvas_pixel(const DevBuffers &B, const uint8_t *stat, int ou
     if ((F.is_modular && !F.xyb_modular) || F.not_xyb) plain_to_rgb(F, p0, p1, p2, fg); else xyb_to_rgb(F, p0, p1, p2, fg);
     float fa = 1.0f;
     if (has_alpha) fa = F.alpha_up > 1 ? B.up[3][(size_t)fy * (size_t)F.full_w + (size_t)fx]      // enlarged beforehand (upsample_alpha_pixel)
-                                       : (float)mod_plane(B, F, F.mod_out[3])[(size_t)fy * (size_t)F.alpha_w + (size_t)fx] * (1.0f / (float)((1u << F.mod_alpha_bits) - 1));
+                                       : alpha_sample_value(F, mod_plane(B, F, F.mod_out[3])[(size_t)fy * (size_t)F.alpha_w + (size_t)fx], true);
     // colour channels
     {
       float wa = fa;
@@ -344,7 +344,7 @@ JXL_DEV void plain_write_pixel(const DevBuffers &B, int out_bits, int x, int y) 
     float t;
     if (c < 3) t = B.plane_a[c][po];
     else if (F.mod_out[3] < 0) t = 1.0f;
-    else t = (float)mod_plane(B, F, F.mod_out[3])[si] / (float)((1u << F.mod_alpha_bits) - 1);
+    else t = alpha_sample_value(F, mod_plane(B, F, F.mod_out[3])[si], false);
     t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
     if (!(t == t)) t = 0.0f;
     px[c] = (uint32_t)(int)rintf(t * maxv);

@@ -20,6 +20,38 @@
 
 namespace jxlamd {
 
+// A Modular sample of a channel declared as floating point (bits total, exp_bits of exponent: float32 = 32 / 8, float16 = 16 / 5, ...): the integer IS the
+// float's bit pattern; narrower formats are widened to float32 (subnormals normalised) — libjxl's int_to_float.
+JXL_DEV float sample_bits_to_float(int32_t v, int bits, int exp_bits) {
+  uint32_t f = (uint32_t)v;
+  if (bits != 32) {
+    const int sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits, bias = (1 << (exp_bits - 1)) - 1;
+    const uint32_t sign = (f >> sign_shift) & 1u;
+    f &= (1u << sign_shift) - 1u;
+    if (f == 0) f = sign << 31;
+    else {
+      int e = (int)(f >> mant_bits);
+      uint32_t m = (f & ((1u << mant_bits) - 1u)) << mant_shift;
+      if (e == 0 && exp_bits < 8) { while ((m & 0x800000u) == 0) { m <<= 1; e--; } e++; m &= 0x7fffffu; }
+      e = e - bias + 127;
+      f = (sign << 31) | ((uint32_t)e << 23) | m;
+    }
+  }
+#ifdef __HIPCC__
+  return __uint_as_float(f);
+#else
+  float r; __builtin_memcpy(&r, &f, 4); return r;
+#endif
+}
+
+// the alpha sample as a float: integer alpha / (2^bits - 1) — `mul`: times the reciprocal instead (the two forms round differently; each call site keeps the
+// one its stage of the reference uses) — or the float it encodes
+JXL_DEV float alpha_sample_value(const DevFrame &F, int32_t v, bool mul) {
+  if (F.mod_alpha_exp_bits) return sample_bits_to_float(v, F.mod_alpha_bits, F.mod_alpha_exp_bits);
+  const float mx = (float)((1u << F.mod_alpha_bits) - 1);
+  return mul ? (float)v * (1.0f / mx) : (float)v / mx;
+}
+
 // ------------------------------------------------------------------ bit reader (LSB first)
 struct DevBits {
   const uint32_t *next;     // next aligned word to fetch

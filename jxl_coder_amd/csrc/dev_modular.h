@@ -41,6 +41,8 @@ struct DevModStream {                 // what lane 0 hands to the other lanes / 
   DevECView ev;
   int32_t num_ctx, num_clusters;
   int32_t m16;
+  int32_t wide32;                     // float32 samples (the planes hold bit patterns of any magnitude): serial loop only, and a neighbourhood sum that leaves 32 bits is refused —
+                                      // libjxl's specialised loops (gradient-only / weighted-only trees) evaluate such sums without the wrap of its generic loop, which is the one restated here
   uint32_t err;
 };
 
@@ -259,6 +261,8 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     const bool wide = w > kModMaxW;
     if (wide && tf.uses_wp && (!S.wide_wp || w > kWideMaxW)) return kErrUnsupportedTransform;
     props[0] = ci;
+    const bool wide32 = S.st.wide32 != 0;
+    bool wide_overflow = false;
     WPState wst;
     const WpRows WR = wp_rows(S, wide && tf.uses_wp, w);
     if (tf.uses_wp) {
@@ -286,6 +290,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         props[7] = (int32_t)W;
         props[8] = (int32_t)(W - prev_prop9);
         props[9] = (int32_t)(W + N - NW);
+        if (wide32 && (W + N - NW) != (int64_t)props[9]) wide_overflow = true;
         prev_prop9 = props[9];
         props[10] = (int32_t)(W - NW);
         props[11] = (int32_t)(NW - N);
@@ -316,6 +321,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         if (tf.uses_wp) wp_update(WR, wst, val, x, y, w);
       }
     }
+    if (wide_overflow) return kErrUnsupportedTransform;
   }
   return 0;
 }
@@ -373,6 +379,7 @@ JXL_DEV void modular_stream_begin(const uint8_t *tables, const DevFrame &F, Loca
   int ntr, use_global;
   modular_read_header(st.b, st.wp, ntr, use_global);
   st.err = 0; st.m16 = F.modular_16bit;
+  st.wide32 = (F.is_modular ? (F.mod_exp_bits && F.mod_bits == 32) : (F.mod_alpha_exp_bits && F.mod_alpha_bits == 32)) ? 1 : 0;
   if (trs) trs->n = 0;
   { uint32_t e = modular_read_transforms(st.b, ntr, trs); if (e) { st.err = e; return; } }
   if (use_global) {

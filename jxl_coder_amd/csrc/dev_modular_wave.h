@@ -779,7 +779,7 @@ template <bool kGeneral = true>
 __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
   DevModStream &st = S.st;
   if (st.err) return st.err;
-  if (st.ev.lz77) {                       // LZ77 copies: the serial walker (lane 0) only
+  if (st.ev.lz77 || st.wide32) {          // LZ77 copies, float32 samples: the serial walker (lane 0) only
     if (lane == 0) S.fallback_err = modular_stream_decode(S, chans, nch, stream_id);
     __syncthreads();
     return S.fallback_err;

@@ -467,7 +467,7 @@ JXL_DEV bool rgba_codes(const DevBuffers &B, const uint8_t *stat, const DevStati
     if (F.alpha_up > 1) alpha = B.up[3][(size_t)fy * (size_t)F.full_w + (size_t)fx];       // enlarged beforehand (upsample_alpha_pixel); fx, fy are full-resolution here
     else {
       const int32_t av = (B.mod_pool + F.mod_plane_off[F.mod_out[3]])[(size_t)fy * (size_t)F.width + (size_t)fx];
-      alpha = (float)av / (float)((1u << F.mod_alpha_bits) - 1);
+      alpha = alpha_sample_value(F, av, false);
     }
     alpha = alpha < 0.0f ? 0.0f : alpha > 1.0f ? 1.0f : alpha;
   }

@@ -112,6 +112,7 @@ struct DevFrame {
   int32_t mod_op_kind[kModMaxOps], mod_op_a[kModMaxOps], mod_op_b[kModMaxOps], mod_op_c[kModMaxOps], mod_op_x[kModMaxOps], mod_op_y[kModMaxOps], mod_op_d[kModMaxOps], mod_op_e[kModMaxOps],
           mod_op_f[kModMaxOps], mod_op_g[kModMaxOps], mod_op_h[kModMaxOps];
   int32_t mod_out[4];              // planes feeding R, G, B, A (-1: opaque / replicate grey is done by repeating the index)
+  int32_t mod_exp_bits, mod_alpha_exp_bits;   // > 0: the colour / alpha samples are floats of that many exponent bits, the integer planes hold their bit patterns (sample_bits_to_float)
   int32_t mod_bits, mod_alpha_bits;
   // Composition (frames that are not written straight from the last filter stage): reference frames of a patch dictionary, frames with patches.
   // Such a frame keeps its image in the f32 planes after the filters (Modular-encoded frames are converted into them: k_mod_to_planes), the

@@ -264,7 +264,9 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   F.mod_global_bit = (uint32_t)sb->pos;
   F.mod_group_dim = f.group_dim;
   F.mod_bits = (int)m.pub.bits_per_sample;
-  if (F.mod_bits > 16 || m.pub.exp_bits) { plan->error = "unsupported: float / >16-bit samples in Modular frames"; return -1; }
+  // float samples: the integer planes hold the floats' bit patterns (dev_entropy.h: sample_bits_to_float); an XYB Modular frame's samples are quantised XYB whatever the image declares
+  F.mod_exp_bits = (vardct || m.pub.xyb_encoded) ? 0 : (int)m.pub.exp_bits;
+  if (F.mod_exp_bits ? (F.mod_bits > 32 || F.mod_exp_bits > 8 || F.mod_bits - F.mod_exp_bits - 1 < 1 || F.mod_bits - F.mod_exp_bits - 1 > 23) : (F.mod_bits > 16 && !vardct && !m.pub.xyb_encoded)) { plan->error = "unsupported: integer samples of more than 16 bits / float format in Modular frames"; return -1; }
   const int ncol = vardct ? 0 : (m.pub.num_color_channels == 1 && !m.pub.xyb_encoded) ? 1 : 3;
   struct Ch { int w, h, hs, vs, plane; };
   std::vector<Ch> L;
@@ -287,7 +289,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   if (use_global_tree && F.tree_count <= 0) { plan->error = "modular frame: missing global MA tree"; return -1; }
   if (!hx_bool(sb)) { for (int i = 0; i < 7; i++) (void)hx_bits(sb, 5); for (int i = 0; i < 4; i++) (void)hx_bits(sb, 4); }
   const int ntr = (int)hx_u32(sb, -1, 0, -1, 1, 4, 2, 8, 18);
-  if (ntr > 4) { plan->error = "unsupported: more than 4 global transforms"; return -1; }
+  if (ntr > 32) { plan->error = "unsupported: more than 32 global transforms"; return -1; }      // (every channel may bring a palette of its own — libjxl compacts channels of few distinct values, e.g. float16 — next to RCT and squeeze; the operation list and the plane table bound the total)
   struct Sq { int horizontal, in_place, begin_c, num_c; };
   struct Tr { int id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; std::vector<Sq> sq; };
   std::vector<Tr> trs;
@@ -468,7 +470,8 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   F.mod_out[3] = -1; F.mod_alpha_bits = 8;
   F.alpha_up = 1; F.alpha_w = f.width; F.alpha_h = f.height;
   for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) {
-    F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits;
+    F.mod_out[3] = L[(size_t)(ncol + i)].plane; F.mod_alpha_bits = m.ec[i].bits; F.mod_alpha_exp_bits = m.ec[i].float_sample ? m.ec[i].exp_bits : 0;
+    if (F.mod_alpha_exp_bits ? (F.mod_alpha_bits > 32 || F.mod_alpha_exp_bits > 8 || F.mod_alpha_bits - F.mod_alpha_exp_bits - 1 < 1 || F.mod_alpha_bits - F.mod_alpha_exp_bits - 1 > 23) : F.mod_alpha_bits > 16) { plan->error = "unsupported: alpha sample format"; return -1; }
     F.alpha_up = f.ec_upsampling[i]; F.alpha_w = L[(size_t)(ncol + i)].w; F.alpha_h = L[(size_t)(ncol + i)].h;
     break;
   }

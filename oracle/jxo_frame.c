@@ -11,6 +11,26 @@
 #include "jxo_dither.h"
 
 int jxo_debug = 0;
+
+/* A Modular sample of a channel declared floating point (bits total, exp_bits of exponent): the integer is the float's bit pattern; formats narrower than float32
+   are widened, subnormals normalised (libjxl: int_to_float under JxlDecoderProcessInput — reference call site interop/JxlDecoding.cpp:75) */
+static float sample_bits_to_float(int32_t v, int bits, int exp_bits) {
+  uint32_t f = (uint32_t)v;
+  if (bits != 32) {
+    int sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits, bias = (1 << (exp_bits - 1)) - 1;
+    uint32_t sign = (f >> sign_shift) & 1u;
+    f &= (1u << sign_shift) - 1u;
+    if (f == 0) f = sign << 31;
+    else {
+      int e = (int)(f >> mant_bits);
+      uint32_t mnt = (f & ((1u << mant_bits) - 1u)) << mant_shift;
+      if (e == 0 && exp_bits < 8) { while ((mnt & 0x800000u) == 0) { mnt <<= 1; e--; } e++; mnt &= 0x7fffffu; }
+      e = e - bias + 127;
+      f = (sign << 31) | ((uint32_t)e << 23) | mnt;
+    }
+  }
+  float r; memcpy(&r, &f, 4); return r;
+}
 #define PI 3.14159265358979323846
 
 /* ================================================================= headers */
@@ -1451,8 +1471,11 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
           rgb[c][i] = v;
         }
       } else {
-        float sc = 1.0f / (float)((1u << m.pub.bits_per_sample) - 1);
-        for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)ch->d[i] * sc;
+        if (m.pub.exp_bits) for (size_t i = 0; i < npx; i++) rgb[c][i] = sample_bits_to_float(ch->d[i], (int)m.pub.bits_per_sample, (int)m.pub.exp_bits);
+        else {
+          float sc = 1.0f / (float)(((uint64_t)1 << m.pub.bits_per_sample) - 1);
+          for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)ch->d[i] * sc;
+        }
       }
     }
     if (m.pub.xyb_encoded && f->epf_iters) { jxo_set_error("unsupported: EPF on modular XYB"); goto done; }
@@ -1495,8 +1518,8 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
     }
   }
   /* alpha */
-  const jxo_chan *alpha = NULL; int alpha_bits = 0;
-  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { alpha = &s->gmod.ch[s->gmod.nch - m.num_extra + i]; alpha_bits = m.ec[i].bits; break; }
+  const jxo_chan *alpha = NULL; int alpha_bits = 0, alpha_exp = 0;
+  for (int i = 0; i < m.num_extra; i++) if (m.ec[i].type == 0) { alpha = &s->gmod.ch[s->gmod.nch - m.num_extra + i]; alpha_bits = m.ec[i].bits; alpha_exp = m.ec[i].float_sample ? m.ec[i].exp_bits : 0; break; }
   /* write RGBA with orientation */
   {
     uint32_t ow = m.pub.xsize, oh = m.pub.ysize;
@@ -1518,7 +1541,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
         size_t si = (size_t)y * (size_t)w + (size_t)x, di = ((size_t)oy * ow + (size_t)ox) * 4;
         float v[4];
         for (int c = 0; c < 3; c++) v[c] = rgb[c][si];
-        v[3] = alpha ? (float)alpha->d[si] / (float)((1u << alpha_bits) - 1) : 1.0f;
+        v[3] = !alpha ? 1.0f : alpha_exp ? sample_bits_to_float(alpha->d[si], alpha_bits, alpha_exp) : (float)alpha->d[si] / (float)((1u << alpha_bits) - 1);
         for (int c = 0; c < 4; c++) {
           float t = v[c];
           t = t < 0 ? 0 : t > 1 ? 1 : t;   /* NaN -> 0 via first compare false... keep simple */

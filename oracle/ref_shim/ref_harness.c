@@ -184,6 +184,9 @@ void ref_set_custom_xy(const double *xy8) { g_custom_xy_set = xy8 != NULL; if (x
 static int g_orientation;
 void ref_set_orientation(int o) { g_orientation = o; }
 
+/* float samples for the next ref_encode: 1 = float32 (32 bits, 8 exponent bits; float32 buffer), 2 = float16 (16 / 5; float16 buffer) */
+static int g_float = 0;
+void ref_set_float(int mode) { g_float = mode; }
 /* the alpha of the next encodes is declared premultiplied (the pixels are taken as they are) */
 static int g_premultiplied = 0;
 void ref_set_premultiplied(int on) { g_premultiplied = on; }
@@ -209,23 +212,25 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   size_t nthr = p->threads > 0 ? (size_t)p->threads : p_JxlThreadParallelRunnerDefaultNumWorkerThreads();
   void *runner = p_JxlThreadParallelRunnerCreate(NULL, nthr);
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetParallelRunner(enc, p_JxlThreadParallelRunner, runner)) goto done;
-  JxlPixelFormat pf = {p->num_channels, p->bits == 16 ? JXL_TYPE_UINT16 : JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+  JxlPixelFormat pf = {p->num_channels, g_float == 2 ? JXL_TYPE_FLOAT16 : g_float ? JXL_TYPE_FLOAT : p->bits == 16 ? JXL_TYPE_UINT16 : JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
   JxlBasicInfo bi;
   p_JxlEncoderInitBasicInfo(&bi);
   bi.xsize = p->xsize; bi.ysize = p->ysize; bi.bits_per_sample = p->bits;
+  if (g_float) { bi.bits_per_sample = g_float == 2 ? 16 : 32; bi.exponent_bits_per_sample = g_float == 2 ? 5 : 8; }      /* float samples: the pixel buffer holds float32 */
   bi.uses_original_profile = p->lossless ? JXL_TRUE : JXL_FALSE;
   const int has_alpha = p->num_channels == 2 || p->num_channels == 4;       /* 2: grey + alpha */
   bi.num_color_channels = p->num_channels <= 2 ? 1 : 3;
   bi.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
   if (p->intensity_target > 0) bi.intensity_target = p->intensity_target;
   if (g_orientation >= 1 && g_orientation <= 8) bi.orientation = (JxlOrientation)g_orientation;
-  if (has_alpha) { bi.num_extra_channels = 1; bi.alpha_bits = p->bits; }
+  if (has_alpha) { bi.num_extra_channels = 1; bi.alpha_bits = g_float ? bi.bits_per_sample : p->bits; if (g_float) bi.alpha_exponent_bits = bi.exponent_bits_per_sample; }
   if (g_extra_plane) bi.num_extra_channels += 1;      /* one more extra channel (depth, spot colour, ...): ref_set_extra_channel */
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
   if (has_alpha) {
     JxlExtraChannelInfo ci;
     p_JxlEncoderInitExtraChannelInfo(JXL_CHANNEL_ALPHA, &ci);
-    ci.bits_per_sample = p->bits; ci.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
+    ci.bits_per_sample = g_float ? bi.bits_per_sample : p->bits; if (g_float) ci.exponent_bits_per_sample = bi.exponent_bits_per_sample;
+    ci.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
     if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelInfo(enc, 0, &ci)) { rc = -4; goto done; }
   }
   if (g_extra_plane) {

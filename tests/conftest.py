@@ -89,7 +89,7 @@ NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls7
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
                            "lra400x300_e7",
                            "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3",
-                           "lpm400x300_e7_premultiplied", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
+                           "lpm400x300_e7_premultiplied", "lf16_300x200_e7_hdr", "lf16a300x200_e3", "lf32_200x136_e7", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
@@ -145,7 +145,7 @@ def vardct_mean_tol(name):
 # 16-bit output (RGBA u16): max |diff| <= 256/65535 and mean <= 16/65535.  PQ-coded frames are checked
 # statistically: the PQ curve's slope near black turns 1e-5 of linear-light float noise into hundreds of code values on a
 # handful of near-zero samples (the reference's own SSE2 arithmetic differs from any other float ordering there).
-U16_CASES = ["v160x120_16bit_e7", "va530x270_16bit_e7"]
+U16_CASES = ["v160x120_16bit_e7", "va530x270_16bit_e7", "vf16a300x200_e7", "vf32a300x200_e7"]      # the last two: float16 / float32 images (VarDCT colour, float alpha in the Modular planes as bit patterns)
 U16_PQ_CASES = ["v160x120_16bit_pq2100_epf3"]
 # further target transfer functions of the decoder proper (HLG with its inverse OOTF, DCI gamma 2.6 with P3 primaries): device code only
 # (the plain-C oracle restates sRGB / linear / PQ / 709 / gamma), same 16-bit bounds as U16_CASES

@@ -91,6 +91,10 @@ CASES = {
     "lpcr200x136_e7_prev3": (200, 136, dict(seed=5), dict(lossless=True, effort=7, extra=((29, 3), (16, 1)))),             # with squeeze: channels of many sizes, few share one
     # grey + alpha (two-channel PNGs), and images with an extra channel that is not the alpha (depth / spot colour / selection mask: decoded, not part of the RGBA output)
     "lpm400x300_e7_premultiplied": (400, 300, dict(seed=6, alpha=True, premul=True), dict(lossless=True, effort=7, premultiplied=True)),      # premultiplied alpha: delivered as stored
+    # floating-point images (cjxl from EXR / PFM): the Modular planes hold the floats' bit patterns; float16 with an HDR range (below 0, above 1), float32 in 0..1
+    "lf16_300x200_e7_hdr": (300, 200, dict(seed=5, float=16, frange=(-0.2, 1.5)), dict(lossless=True, effort=7)),
+    "lf16a300x200_e3": (300, 200, dict(seed=6, alpha=True, float=16), dict(lossless=True, effort=3)),
+    "lf32_200x136_e7": (200, 136, dict(seed=5, float=32), dict(lossless=True, effort=7)),
     "lga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=7)),
     "lga300x200_e1": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=1)),
     "lxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(lossless=True, effort=7)),
@@ -133,6 +137,8 @@ CASES = {
     # what `cjxl -p` writes for RGBA: progressive AC + a squeezed (responsive) alpha — the alpha's channels are spread over the passes by their shift
     # (Passes::GetDownsamplingBracket: every pass has a ModularGroup stream of its own behind the AC data), single group and 3 x 2 groups
     "vpm400x300_e7_premultiplied": (400, 300, dict(seed=6, alpha=True, premul=True), dict(effort=7, distance=1.0, premultiplied=True)),
+    "vf16a300x200_e7": (300, 200, dict(seed=6, alpha=True, float=16), dict(effort=7, distance=1.0)),      # float16 image, VarDCT colour + float16 alpha (Modular: bit patterns)
+    "vf32a300x200_e7": (300, 200, dict(seed=6, alpha=True, float=32), dict(effort=7, distance=1.0)),
     "vga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=1.0)),                  # grey + alpha, VarDCT
     "vga300x200_e7_d12": (300, 200, dict(seed=9, grey=True, alpha=True), dict(effort=7, distance=12.0)),            # ... upsampled
     "vxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(effort=7, distance=1.0)),                     # RGB + a depth channel
@@ -250,6 +256,7 @@ def make_image(w, h, sk):
     sk = dict(sk)
     sk.pop("extra_type", None)          # (an additional extra channel: main() hands its plane to the encoder)
     premul = sk.pop("premul", False)
+    fl = sk.pop("float", 0); frange = sk.pop("frange", (0.0, 1.0))
     gen = sk.pop("gen", "photo")
     alpha = sk.pop("alpha", False)
     grey = sk.pop("grey", False)
@@ -264,6 +271,10 @@ def make_image(w, h, sk):
             img = with_alpha(img)
         if premul:
             img = img.copy(); img[..., :3] = (img[..., :3].astype(int) * img[..., 3:4] // 255).astype(img.dtype)
+        if fl:                  # floating-point samples (float32 / float16) over frange; the alpha stays in 0..1
+            f = img.astype(np.float32) / 255.0
+            f[..., :3] = f[..., :3] * (frange[1] - frange[0]) + frange[0] if f.shape[2] >= 3 else f[..., :3]
+            img = f.astype(np.float32 if fl == 32 else np.float16)
         return img
     if gen == "screenshot":
         return synth.screenshot(w, h, sk.get("seed", 0), channels=4 if alpha else 3)
