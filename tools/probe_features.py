@@ -116,6 +116,29 @@ def cases():
     yield "rgb lossy palette (implicit deltas)", ph[:136, :200], dict(lossless=True, extra=((LOSSY_PALETTE, 1), (PATCHES, 0)))
     yield "shot d1 + noise", shot, dict(distance=1.0, extra=((NOISE, 1),))
     yield "rgba d12 + noise", pha, dict(distance=12.0, extra=((NOISE, 1),))
+    # channel layouts and sample types: grey + alpha, an extra channel that is not the alpha, premultiplied alpha, floating-point samples
+    ga = np.dstack([grey[..., 0], (128 + 100 * np.sin(np.arange(300)[None, :] * 0.05) * np.cos(np.arange(200)[:, None] * 0.04)).astype(np.uint8)])
+    depth = (np.arange(400)[None, :] // 2 + np.arange(300)[:, None] // 3).astype(np.uint8)
+    for nm, kw in (("lossless e7", dict(lossless=True, effort=7)), ("lossless e1", dict(lossless=True, effort=1)), ("d1", dict(distance=1.0)), ("d12", dict(distance=12.0))):
+        yield f"grey+alpha {nm}", ga, kw
+    yield "rgb + depth lossless", ph, dict(lossless=True, effort=7, extra_channel=(depth, 1))
+    yield "rgb + depth d1", ph, dict(distance=1.0, extra_channel=(depth, 1))
+    yield "rgba + spot colour d1", pha, dict(distance=1.0, extra_channel=(depth, 2))
+    yield "rgba + selection mask lossless e3", pha, dict(lossless=True, effort=3, extra_channel=(depth, 3))
+    yield "rgba + depth d12", pha, dict(distance=12.0, extra_channel=(depth, 1))
+    pm = pha.copy(); pm[..., :3] = (pm[..., :3].astype(int) * pm[..., 3:4] // 255).astype(np.uint8)
+    for nm, kw in (("lossless", dict(lossless=True, effort=7)), ("d1", dict(distance=1.0)), ("d12", dict(distance=12.0))):
+        yield f"premultiplied rgba {nm}", pm, dict(kw, premultiplied=True)
+    f32, f32a = ph[:200, :300].astype(np.float32) / 255, pha[:200, :300].astype(np.float32) / 255
+    hdr16 = (f32 * 1.7 - 0.2).astype(np.float16)
+    yield "float32 rgb d1", f32, dict(distance=1.0)
+    yield "float32 rgba d1", f32a, dict(distance=1.0)
+    yield "float32 rgb lossless", f32, dict(lossless=True)
+    yield "float32 rgba lossless e3", f32a, dict(lossless=True, effort=3)
+    yield "float16 rgba d1", f32a.astype(np.float16), dict(distance=1.0)
+    yield "float16 rgba lossless e3", f32a.astype(np.float16), dict(lossless=True, effort=3)
+    yield "float16 hdr range lossless e7", hdr16, dict(lossless=True, effort=7)
+    yield "float16 hdr range d1", hdr16, dict(distance=1.0)
     for b in (2, 3):
         yield f"shot lossless e7 buffering {b}", synth.screenshot(600, 400, seed=2), dict(lossless=True, effort=7, extra=((34, b),))
         yield f"rgb d1 buffering {b}", synth.photo_like(600, 400, seed=3), dict(distance=1.0, extra=((34, b),))
