@@ -360,7 +360,8 @@ int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_
   bi.xsize = W; bi.ysize = H; bi.bits_per_sample = 8; bi.num_color_channels = 3; bi.num_extra_channels = 1; bi.alpha_bits = 8;
   bi.alpha_premultiplied = g_premultiplied ? JXL_TRUE : JXL_FALSE;
   bi.uses_original_profile = lossless ? JXL_TRUE : JXL_FALSE;
-  bi.have_animation = JXL_TRUE; bi.animation.tps_numerator = tps_num; bi.animation.tps_denominator = tps_den; bi.animation.num_loops = loops;
+  bi.have_animation = tps_num ? JXL_TRUE : JXL_FALSE;          /* tps_num == 0: a layered STILL (every frame a layer of one image; durations are not written) */
+  bi.animation.tps_numerator = tps_num; bi.animation.tps_denominator = tps_den; bi.animation.num_loops = loops;
   bi.animation.have_timecodes = JXL_FALSE;
   if (JXL_ENC_SUCCESS != p_JxlEncoderSetBasicInfo(enc, &bi)) { rc = -3; goto done; }
   JxlExtraChannelInfo ci;
@@ -379,7 +380,7 @@ int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_
     if (lossless && JXL_ENC_SUCCESS != p_JxlEncoderSetFrameLossless(fs, JXL_TRUE)) { rc = -8; goto done; }
     JxlFrameHeader fh;
     p_JxlEncoderInitFrameHeader(&fh);
-    fh.duration = fr->duration;
+    fh.duration = tps_num ? fr->duration : 0;
     fh.layer_info.have_crop = (fr->x0 || fr->y0 || fr->w != W || fr->h != H) ? JXL_TRUE : JXL_FALSE;
     fh.layer_info.crop_x0 = fr->x0; fh.layer_info.crop_y0 = fr->y0; fh.layer_info.xsize = fr->w; fh.layer_info.ysize = fr->h;
     fh.layer_info.blend_info.blendmode = (JxlBlendMode)fr->blend_mode; fh.layer_info.blend_info.source = (uint32_t)fr->source;

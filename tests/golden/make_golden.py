@@ -229,6 +229,9 @@ ANIM_CASES = {
     "an_blend_premul_d1_e7": ("blend_premul", dict(lossless=False, distance=1.0, effort=7, premultiplied=True)),
     "an_blend_d12_e7": ("blend", dict(lossless=False, distance=12.0, effort=7)),
     "an_modes_d15_e7": ("modes", dict(lossless=False, distance=15.0, effort=7)),
+    # layered STILLS (have_animation = 0: every frame is a layer of the one image — what layered exports write): the same layers, composited into a single picture
+    "ly_modes_lossless": ("modes", dict(lossless=True, effort=3, still=True)),
+    "ly_blend_d1_e7": ("blend", dict(lossless=False, distance=1.0, effort=7, still=True)),
 }
 
 
@@ -237,9 +240,10 @@ def add_anim_cases(meta, only):
         if only and name not in only:
             continue
         W, H, frames = anim_scene(scene)
-        data = jxl_ref.encode_anim(frames, W, H, tps=(100, 1), loops=3, **ek)
+        ek2 = dict(ek); still = ek2.pop("still", False)
+        data = jxl_ref.encode_anim(frames, W, H, tps=(0, 1) if still else (100, 1), loops=3, **ek2)
         durations, loops = jxl_ref.anim_info(data)
-        coalesced = sum(1 for i, f in enumerate(frames) if f.get("duration", 1) > 0 or i == len(frames) - 1)
+        coalesced = 1 if still else sum(1 for i, f in enumerate(frames) if f.get("duration", 1) > 0 or i == len(frames) - 1)
         out = np.stack([jxl_ref.decode_frame(data, i) for i in range(coalesced)])
         last, info, _ = jxl_ref.decode(data)
         assert np.array_equal(last, out[-1])
