@@ -17,6 +17,7 @@ constexpr int kWpMaxW = 256;
 constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
+constexpr int kModMaxGroupCh = 40;                // channels of one ModularGroup stream (RGBA with the default squeeze: 28)
 constexpr int kModMaxRefs = 12;                    // previous channels an MA tree may look at (properties 16 ..: four per channel; libjxl's encoder offers up to 11)
 struct DevChanOut { int32_t *d; int32_t w, h; int16_t hs, vs; };      // hs / vs: the channel's shifts (-1: a meta channel) — what decides, with the size, which earlier channels the "previous channel" MA properties read
 
@@ -73,7 +74,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   DevModStream st;
   DevChanOut ch[kModMaxCh];           // channel descriptors of the current stream
   int32_t grp_dec;                    // channels the current group stream carries after its own transforms' meta-apply (palette channels in front)
-  int32_t grp_src[24], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
+  int32_t grp_src[kModMaxGroupCh], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header
   DevChanOut pal_saved[kModMaxLocalTr][3];   // group-level palettes: the colour channels 1.. each one folded away (their buffers receive the colours again)
   DevWaveTree wt;

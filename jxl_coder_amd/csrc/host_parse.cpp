@@ -391,7 +391,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     F.lz_win_len = (uint32_t)std::min<uint64_t>(total + 64, 1u << 20);
     F.lz_win_group = (uint32_t)std::min<uint64_t>((uint64_t)(F.mod_nch - first_group) * (uint64_t)f.group_dim * (uint64_t)f.group_dim + 64, 1u << 20);
   }
-  if (F.mod_nch - first_group > 24) { plan->error = "unsupported: more than 24 group channels"; return -1; }
+  if (F.mod_nch - first_group > 40) { plan->error = "unsupported: more than 40 group channels"; return -1; }      // dev_modular.h: kModMaxGroupCh
   // inverse program (last transform first)
   F.mod_nops = 0;
   for (int i = ntr - 1; i >= 0; i--) {

@@ -160,7 +160,11 @@ if gpu:
     import jxl_coder_amd as J
     from jxl_coder_amd import api
     for name, allowed_floats in (("v264x520_e7", 0), ("va300x520_e7", 0), ("l512_e7", 0), ("v160x120_16bit_pq2100_epf3", 1), ("v160x120_16bit_pq2100_epf3", 0),
-                                 ("asset_wide_gamut", 1), ("va400x300_e7_d2", 0), ("lra200x150_e5", 0)):
+                                 ("asset_wide_gamut", 1), ("va400x300_e7_d2", 0), ("lra200x150_e5", 0),
+                                 # round 4, last part: delta palette, cjxl -p RGBA, two LF levels, noise on an upsampled frame, previous-channel properties,
+                                 # float16 (lossless HDR range; VarDCT + float alpha), premultiplied alpha, grey + alpha, an extra channel besides the alpha
+                                 ("lpl400x300_e7", 0), ("vaqr520x300_e7", 0), ("vlf2a520x300_e7", 0), ("vnu523x267_e7_d12", 0), ("lpc200x136_e7_prev3", 0),
+                                 ("lf16_300x200_e7_hdr", 0), ("vf16a300x200_e7", 1), ("vpm400x300_e7_premultiplied", 0), ("lga300x200_e7", 0), ("vxs400x300_e7_rgba_spot", 0)):
         data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
         dec = J.JxlDecoder(0)
         exp, info = dec.decode_one_shot(data, allowed_floats=bool(allowed_floats))
@@ -208,7 +212,7 @@ L.refanim_get_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.P
 meta = json.load(open(os.path.join(ROOT, "tests/golden/golden.json")))
 msg = C.create_string_buffer(256)
 assert not L.refanim_open(b"GIF89a....", 10, msg, 256) and msg.value == b"Not an JXL image"
-for name in ("an_blend_lossless", "an_modes_d2_e5", "asset_animated", "v256_e7"):
+for name in ("an_blend_lossless", "an_modes_d2_e5", "asset_animated", "v256_e7", "an_blend_d12_e7", "an_blend_premul_lossless"):
     data = open(os.path.join(ROOT, "tests/golden", name + ".jxl"), "rb").read()
     h = L.refanim_open(data, len(data), msg, 256)
     assert h, (name, msg.value)
