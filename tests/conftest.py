@@ -89,7 +89,7 @@ NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls7
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
                            "lra400x300_e7",
                            "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3",
-                           "lpm400x300_e7_premultiplied", "lf16_300x200_e7_hdr", "lf16a300x200_e3", "lf32_200x136_e7", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
+                           "lra2100x130_e3", "lpm400x300_e7_premultiplied", "lf16_300x200_e7_hdr", "lf16a300x200_e3", "lf32_200x136_e7", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's

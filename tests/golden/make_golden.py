@@ -99,6 +99,7 @@ CASES = {
     "lga300x200_e1": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=1)),
     "lxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(lossless=True, effort=7)),
     "lxs400x300_e3_rgba_selection": (400, 300, dict(seed=6, alpha=True, extra_type=3), dict(lossless=True, effort=3)),
+    "lra2100x130_e3": (2100, 130, dict(seed=3, alpha=True), dict(lossless=True, effort=3, extra=((16, 1),))),      # RGBA with squeeze beyond 2048 px: 28 channels in a group's stream, residuals in the ModularLfGroup streams
     "lra400x300_e7": (400, 300, dict(seed=6, alpha=True), dict(lossless=True, effort=7, extra=((16, 1),))),  # squeezed RGBA at effort 7: group streams whose own leaf codes have more than 64 clusters
     "ls400x300_e7": (400, 300, dict(gen="screenshot", seed=1), dict(lossless=True, effort=7)),              # patches
     "lpl400x300_e7": (400, 300, dict(gen="screenshot", seed=2), dict(lossless=True, effort=7, extra=((23, 1),))),                   # lossy palette in the patch frame and in the main frame
