@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import jxl_coder_amd as J
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dec = J.JxlDecoder(0)
-data = open(os.path.join(ROOT, os.environ.get("JXLAMD_PROF_FILE", "bench_data/syn4k_q90_seed0.jxl")), "rb").read()
+data = open(os.path.join(ROOT, os.environ.get("JXLAMD_PROF_FILE", "bench_data/syn4k_q90_seed0.jxl")), "rb").read()      # (an absolute JXLAMD_PROF_FILE wins: os.path.join)
 for i in range(n):
     t = time.time()
     try:
