@@ -347,6 +347,12 @@ def add_unsupported_exemplar(only):
     data = jxl_ref.encode(img, lossless=True, effort=3, extra=((16, 1),))
     open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
     print(name, len(data))
+    # ... and a float32 image whose samples change sign (bit patterns of either sign: W + N - NW leaves 32 bits), lossless at effort 2 — DESIGN.md section 8
+    name = "u48x32_float32_mixed_sign"
+    img = (synth.photo_like(48, 32, seed=5).astype(np.float32) / 255.0 - 0.5).astype(np.float32)
+    data = jxl_ref.encode(img, lossless=True, effort=2)
+    open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+    print(name, len(data))
 
 
 def add_assets(meta, asset_dir="/root/reference/app/src/main/assets"):

@@ -130,6 +130,8 @@ def test_errors_are_loud(dec):
     art = open(os.path.join(ROOT, "tests", "golden", "u8200x8200_squeeze_84_channels.jxl"), "rb").read()      # a flat 8200 x 8200 RGBA image, lossless with squeeze: 84 stream channels, four more than the frame tables hold (tests/golden/make_golden.py: add_unsupported_exemplar) — a VALID file: unsupported, not corrupt
     with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
         dec.decode_one_shot(art)
+    with pytest.raises(J.UnsupportedJXLFeature):                              # float32 samples of mixed sign: refused, not guessed
+        dec.decode_one_shot(open(os.path.join(ROOT, "tests", "golden", "u48x32_float32_mixed_sign.jxl"), "rb").read())
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
     assert out.shape == (520, 264, 4)
 

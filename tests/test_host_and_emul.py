@@ -165,6 +165,9 @@ def test_harness_rejects_what_the_device_path_does_not_support(emul):
     data = open(os.path.join(ROOT, "tests", "golden", "u8200x8200_squeeze_84_channels.jxl"), "rb").read()      # a flat 8200 x 8200 RGBA image, lossless with squeeze: 84 stream channels, four more than the frame tables hold (tests/golden/make_golden.py: add_unsupported_exemplar) — a VALID file: unsupported, not corrupt
     with pytest.raises(ValueError, match="unsupported"):
         emul(data)
+    # a float32 image whose samples change sign: a neighbourhood sum leaves 32 bits, where libjxl's specialised loops and its generic loop part ways: refused, not guessed
+    with pytest.raises(ValueError, match="unsupported"):
+        emul(open(os.path.join(ROOT, "tests", "golden", "u48x32_float32_mixed_sign.jxl"), "rb").read())
 
 
 def test_harness_flags_corrupt_streams(emul):
