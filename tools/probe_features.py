@@ -1,7 +1,7 @@
 """Which files of the reference's encoder does the product's host parser + device code (CPU harness, tests/emul) decode, and how far from the
 reference's decoder?  A sweep over encoder settings: prints one line per case.  Needs /root/reference (oracle/_ref): a development tool.
 
-    python tools/probe_features.py [substring]
+    python tools/probe_features.py [substring] [--gpu]      (--gpu: the same sweep on the MI355X through the C-ABI; the GPU box carries oracle/_ref)
 """
 import ctypes as C
 import os
@@ -159,8 +159,25 @@ def animations():
 
 
 def main():
-    sub = sys.argv[1] if len(sys.argv) > 1 else ""
-    lib = emul_lib()
+    args = [a for a in sys.argv[1:] if a != "--gpu"]
+    gpu = "--gpu" in sys.argv           # decode on the MI355X through the C-ABI (jxlamd_decode / jxlamd_decode_frame) instead of on the CPU harness
+    sub = args[0] if args else ""
+    lib = None if gpu else emul_lib()
+    dec = J.JxlDecoder(0) if gpu else None
+
+    def emul_decode(lib_, data, frame=-1):       # (shadows the module's function: same result shape for both routes)
+        if gpu:
+            try:
+                return (dec.decode_one_shot(data)[0] if frame < 0 else dec.decode_frame(data, frame)[0]), ""
+            except Exception as e:      # noqa: BLE001
+                return None, f"{type(e).__name__}: {e}"
+        if frame >= 0:
+            lib_.emul_set_target_frame(frame)
+        try:
+            return globals()["emul_decode"](lib_, data)
+        finally:
+            if frame >= 0:
+                lib_.emul_set_target_frame(-1)
     for name, img, kw in cases():
         if sub not in name:
             continue
@@ -180,7 +197,8 @@ def main():
             continue
         d = np.abs(r.astype(np.int64) - got.astype(np.int64))
         print(f"{name:48s} {len(data):8d} B  ok max {int(d.max())} mean {float(d.mean()):.4f}")
-    lib.emul_set_target_frame.argtypes = [C.c_int]
+    if lib is not None:
+        lib.emul_set_target_frame.argtypes = [C.c_int]
     for name, frames, kw in animations():
         if sub not in name:
             continue
@@ -188,7 +206,7 @@ def main():
         durs, _ = jxl_ref.anim_info(data)
         worst, res = 0, "ok"
         for i in range(sum(1 for j, f in enumerate(frames) if f.get("duration", 1) > 0 or j == len(frames) - 1)):
-            lib.emul_set_target_frame(i); got, err = emul_decode(lib, data); lib.emul_set_target_frame(-1)
+            got, err = emul_decode(lib, data, i)
             if got is None:
                 res = f"REJECT frame {i}: {err}"
                 break
