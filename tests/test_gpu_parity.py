@@ -161,6 +161,24 @@ def test_batch_of_round3_kinds_equals_single_decodes(dec):
             assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
 
 
+def test_batch_of_round4_kinds_equals_single_decodes(dec):
+    """Flights with the kinds of files round 4 added last: progressive RGBA with the squeezed alpha spread over the passes, a multi-pass Modular LF frame and two
+    levels of LF frames (composed: decoded one by one inside the flight), noise on an upsampled frame, delta palettes, previous-channel properties, RGBA with 28
+    group channels, grey + alpha, an extra channel besides the alpha, premultiplied alpha — each output equals the single decode bit for bit, twice."""
+    import torch
+    names = ["vapr400x300_e7", "vaqr520x300_e7", "vlfq600x410_e7", "vlf2a520x300_e7", "vnu523x267_e7_d12", "lpl400x300_e7_nopatch", "lpl400x300_e7", "lpc200x136_e7_prev3",
+             "lra2100x130_e3", "lga300x200_e7", "vga300x200_e7", "vxs400x300_e7_rgba_spot", "vpm400x300_e7_premultiplied", "v264x520_e7", "an_blend_d12_e7"]
+    datas = [open(os.path.join(ROOT, "tests", "golden", n + ".jxl"), "rb").read() for n in names]
+    singles = [dec.decode_one_shot(d)[0] for d in datas]
+    for rep in range(2):
+        outs = [torch.full((s.size,), 0x5A, dtype=torch.uint8, device="cuda") for s in singles]
+        torch.cuda.synchronize()
+        dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for n, s_, o in zip(names, singles, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
+
+
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
