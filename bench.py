@@ -133,6 +133,17 @@ def _lf_retries(J, decs):
     return tot, pools
 
 
+def _sparse_state(J, decs):
+    """(contexts whose last flight handed its coefficients over as sparse per-varblock lists, flights decoded again with the dense planes)"""
+    import ctypes as C
+    f = J.api.lib().jxlamd_debug_sparse
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 2)]
+    on, missed = 0, 0
+    for d in decs:
+        o = (C.c_uint32 * 2)(); f(d._h, C.byref(o)); on += int(o[0]); missed += int(o[1])
+    return on, missed
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
@@ -461,6 +472,7 @@ def main():
                                    "timed region starts; h2d_included_MPps: the same steps fed from host buffers (H2D included); RGBA output stays in HBM",
                        "h2d_included_MPps": round(h2d_steps * B * world * mp / elapsed_h2d, 2), "h2d_included_steps": h2d_steps, "distinct_frames": len(datas),
                        "frame_bytes_mean": int(mean_in), "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "contexts_per_pool_set": SHARE, "contexts_on_general_lf_kernel": _general_contexts(J, decs), "flights_repeated_for_lf_pool": _lf_retries(J, decs)[0], "lf_pool_bytes": sorted(set(_lf_retries(J, decs)[1])), "retried_flights": int(kern.get("retried_flights", 0)),
+                       "contexts_on_sparse_coefficient_lists": _sparse_state(J, decs)[0], "flights_repeated_with_dense_coefficients": _sparse_state(J, decs)[1],
                        "single_frame_latency_ms": round(min(lat) * 1e3, 3), "single_frame_MPps": round(mp / min(lat), 2),
                        "single_frame_stage_ms": seq,
                        "parallelism": f"frames sharded over {world} GPU(s), one process per GPU, no data-path collective"},

@@ -167,6 +167,10 @@ int jxlamd_debug_lf_general(const jxlamd_decoder *dec);
 /* out[0]: decodes / flights of this context that ran a second time because the LF table pool was too small (kErrNeedPool), out[1]: ... because
  * a stream needed the general build, out[2]: the pool (bytes) the next LF launch will get. */
 int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]);
+/* Flights of single-pass VarDCT frames hand their coefficients from the PassGroup stage to the reconstruction as per-varblock sparse lists (4 bytes per
+ * nonzero coefficient) instead of dense 3 x 65 536 x int32 planes per group.  out[0]: the context's last flight did; out[1]: flights of this context that
+ * were decoded again with the dense planes because a stream did not fit its lists. */
+int jxlamd_debug_sparse(const jxlamd_decoder *dec, uint32_t out[2]);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Post-decode stages of the reference's JNI layer, on buffers that stay in HBM.

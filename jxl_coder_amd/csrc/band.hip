@@ -150,7 +150,7 @@ int jxlamd_decoder::band_reconstruct() {
   const BandGeom &q = S.band; const FramePlan &plan = S.plan;
   launch_lf_smooth(S.B, plan.xb, q.cy1 - q.cy0, stream);
   // a band of thousands of groups fills the chip with one LANE per group; below that the wave-per-group kernel has the shorter critical path
-  if (q.ng >= ((bandtab.flags & JXLAMD_BAND_SHARED_GPU) ? flat_min_groups : band_flat_min_groups) && frame_flat_ok(plan)) { launch_pass_prep(bandtab.dB, bandtab.pg_map, q.ng, stream); launch_pass_flat(bandtab.dB, bandtab.wmap, bandtab.nwg, stream); }
+  if (q.ng >= ((bandtab.flags & JXLAMD_BAND_SHARED_GPU) ? flat_min_groups : band_flat_min_groups) && frame_flat_ok(plan)) { launch_pass_prep(bandtab.dB, bandtab.pg_map, q.ng, stream); launch_pass_flat(bandtab.dB, bandtab.wmap, bandtab.nwg, /*sparse=*/false, stream); }
   else launch_pass_groups_batch(bandtab.dB, bandtab.pg_map, q.ng, stream);
   HIPCHECK(hipEventRecord(ev[2], stream));
   launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream);
@@ -177,7 +177,7 @@ int jxlamd_decoder::band_finish() {
   if (F->epf_iters >= 3) stage_mask |= 2;
   if (F->epf_iters >= 1) stage_mask |= 4;
   if (F->epf_iters >= 2) stage_mask |= 8;
-  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
+  if (F->epf_iters <= 2) stage_mask |= sweep_stage_bit(*F, (int)S.pi.out_bits, false);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, (q.py1 - q.py0) + 2 * q.halo, stage_mask, true, 2, stream);
   HIPCHECK(hipEventRecord(ev[4], stream));

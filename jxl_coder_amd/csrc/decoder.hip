@@ -69,6 +69,8 @@ static constexpr int kRetryGeneral = 0x7e7e;
 static constexpr int kRetryPool = 0x7e7f;
 // ... or the shared HF pools moved while this flight's LF stage ran (decode_batch_once): start the flight over
 static constexpr int kRetryMoved = 0x7e80;
+// ... or a frame's sparse coefficient lists did not hold its coefficients (kErrNeedDense): decode the flight again with the dense planes
+static constexpr int kRetryDense = 0x7e81;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host twin of mod_group_scratch_ints (dev_modframe.h)
@@ -197,6 +199,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     for (int i = 0; i < 2; i++) HIPCHECK(S.tiles[i].ensure(ntile));
     for (int i = 0; i < 6; i++) HIPCHECK(S.lf[i].ensure(ncell * 4));
     HIPCHECK(S.coef_off.ensure(ncell * 4));
+    HIPCHECK(S.coef_cnt.ensure(ncell * 4));
     if (own_planes) for (int c = 0; c < 3; c++) HIPCHECK(S.coef[c].ensure((size_t)q.ng * 65536 * 4));   // flights: the decoder's coefficient pool
     if (own_planes) for (int i = 0; i < 6; i++) HIPCHECK(S.planes[i].ensure(npx * 4));   // flights borrow sets of the decoder's plane pool instead
     HIPCHECK(S.lf_scratch.ensure((size_t)q.nlfg * kLfScratchInts * 4));
@@ -298,6 +301,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   for (int c = 0; c < 3; c++) { B.lf[c] = (float *)S.lf[c].p - cb; B.lf_s[c] = (float *)S.lf[3 + c].p - cb;
                                 B.coef[c] = (int32_t *)S.coef[c].p - (ptrdiff_t)q.g0 * 65536;
                                 B.plane_a[c] = (float *)S.planes[c].p - pb; B.plane_b[c] = (float *)S.planes[3 + c].p - pb; }
+  B.coef_cnt = (uint32_t *)S.coef_cnt.p - cb;      // (coef_sp / sp_group: set by decode_batch for the frames of a sparse flight)
   B.coef_off = (uint32_t *)S.coef_off.p - cb; B.lf_scratch = (int32_t *)S.lf_scratch.p - (ptrdiff_t)q.lfg0 * kLfScratchInts;
   B.local = (LocalTreeScratch *)S.local.p - q.lfg0;
   B.mod_pool = (int32_t *)S.mod_pool.p; B.mod_scratch = (int32_t *)S.mod_scratch.p; B.pass_nz = (uint8_t *)S.pass_nz.p - (ptrdiff_t)q.g0 * kPassBlkStride;
@@ -390,7 +394,7 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   if (F->epf_iters >= 3) stage_mask |= 2;
   if (F->epf_iters >= 1) stage_mask |= 4;
   if (F->epf_iters >= 2) stage_mask |= 8;
-  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
+  if (F->epf_iters <= 2) stage_mask |= sweep_stage_bit(*F, (int)S.pi.out_bits, S.post_active && S.post_fused);     // column-sweep instantiation
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   if (F->compose) stage_mask = (stage_mask & 15) | 32;           // stage by stage into the planes; patches, reference copy and writer follow (launch_compose_tail)
   if (S.post_active && S.post_fused) stage_mask |= 64 | 128;     // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>); 128: no other frame in this launch
@@ -597,16 +601,20 @@ std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
 // per frame on the same stream.  Frames that need the single-section round trip are decoded one by one.
 int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
                                  void *const *outs, const size_t *caps, jxlamd_info *infos) {
-  int rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  if (rc0 == kRetryPool) { pool_retries++; rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos); }   // with the largest table pool
-  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  if (rc0 == kRetryPool || rc0 == kRetryMoved) { set_error("LF table pool / shared HF pools: the flight was restarted too often"); return JXLAMD_ERR_DEVICE; }
-  if (rc0 != kRetryGeneral) return rc0;
-  lf_general = true; general_retries++;     // some frame needs a general lock-step loop: this context runs the general LF build from now on
-  rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  for (int moved = 0; rc0 == kRetryMoved && moved < 8; moved++) rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
-  return (rc0 == kRetryPool || rc0 == kRetryMoved || rc0 == kRetryGeneral) ? JXLAMD_ERR_DEVICE : rc0;
+  int rc0 = JXLAMD_OK, moved = 0;
+  bool pool_retried = false, general_retried = false;
+  dense_flight = false;
+  for (;;) {
+    rc0 = decode_batch_once(n, jxl, sizes, jxl_dev, flags, outs, caps, infos);
+    if (rc0 == kRetryMoved && moved++ < 16) continue;
+    if (rc0 == kRetryPool && !pool_retried) { pool_retried = true; pool_retries++; continue; }                 // with the largest table pool
+    if (rc0 == kRetryGeneral && !general_retried) { general_retried = true; lf_general = true; general_retries++; continue; }   // some frame needs a general lock-step loop: this context runs the general LF build from now on
+    if (rc0 == kRetryDense && !dense_flight) { dense_flight = true; sparse_misses++; continue; }               // with the dense coefficient planes
+    break;
+  }
+  dense_flight = false;
+  if (rc0 == kRetryPool || rc0 == kRetryMoved || rc0 == kRetryGeneral || rc0 == kRetryDense) { set_error("LF table pool / shared HF pools / coefficient lists: the flight was restarted too often"); return JXLAMD_ERR_DEVICE; }
+  return rc0;
 }
 
 int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const size_t *sizes, const void *const *jxl_dev, uint32_t flags,
@@ -701,7 +709,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (F->epf_iters >= 3) stage_mask |= 2;
     if (F->epf_iters >= 1) stage_mask |= 4;
     if (F->epf_iters >= 2) stage_mask |= 8;
-  if (F->epf_iters <= 2) stage_mask |= 1 << (8 + (F->gab ? 3 : 0) + F->epf_iters);     // column-sweep instantiation
+    if (F->epf_iters <= 2) stage_mask |= sweep_stage_bit(*F, (int)S.pi.out_bits, S.post_active && S.post_fused);     // column-sweep instantiation
     if (S.post_active && S.post_fused) stage_mask |= 64;      // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
     else all_post = false;
   }
@@ -709,14 +717,43 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
   // contexts sharing it overlap one's LF stage with the other's HF phase
   const int used_sets = std::min(hf_sets, nb);
-  const size_t coef_need = (size_t)used_sets * 3 * max_coef * 4;
+  // Sparse coefficient lists (DevBuffers::coef_sp) when every frame of the flight is a single-pass frame the flat PassGroup kernel takes: an arena per
+  // group sized from the bytes of its section (sparse_group_entries), ~16 MB per 4K q90 frame instead of the 106 MB of dense planes — written once,
+  // read once, nothing to clear.  The dense pool is then not even allocated.
+  bool sparse = sparse_enabled && !dense_flight && sparse_misses < 3;
+  int flight_groups = 0;
+  for (int i : batched) {
+    const FrameSlot &S = slot((size_t)i);
+    const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+    sparse = sparse && frame_flat_ok(S.plan) && F->num_passes == 1 && !F->subsampled;
+    flight_groups += S.plan.num_groups;
+  }
+  sparse = sparse && flight_groups >= flat_min_groups;
+  last_flight_sparse = sparse;
+  static const int sparse_cap_override = getenv("JXLAMD_SPARSE_CAP") ? atoi(getenv("JXLAMD_SPARSE_CAP")) : 0;      // test hook: entries per group (a tiny value forces the dense retry)
+  std::vector<uint32_t> sp_groups;                   // per frame: [num_groups + 1] first entry of each group's arena
+  std::vector<size_t> sp_frame_off, sp_tab_off;      // per frame: its arena inside the pool (entries); its offsets inside sp_groups
+  size_t sp_total = 0;
+  if (sparse) for (int i : batched) {
+    const FrameSlot &S = slot((size_t)i);
+    const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+    const DevSection *secs = (const DevSection *)(S.plan.tables.data() + F->sec_off);
+    sp_frame_off.push_back(sp_total); sp_tab_off.push_back(sp_groups.size());
+    uint32_t at = 0;
+    for (int g = 0; g < S.plan.num_groups; g++) { sp_groups.push_back(at); at += sparse_cap_override > 0 ? (uint32_t)sparse_cap_override : sparse_group_entries(secs[2 + F->num_lf_groups + g].size); }
+    sp_groups.push_back(at);
+    sp_total += ((size_t)at + 63) & ~(size_t)63;
+  }
+  const size_t coef_need = sparse ? 0 : (size_t)used_sets * 3 * max_coef * 4;
   uint64_t pool_gen;
   {
     std::lock_guard<std::mutex> lk(pools->mu);
-    const void *p0 = pools->plane_pool.p, *c0 = pools->coef_pool.p;
+    const void *p0 = pools->plane_pool.p, *c0 = pools->coef_pool.p, *s0 = pools->sp_pool.p;
     HIPCHECK(pools->plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
     HIPCHECK(pools->coef_pool.ensure(coef_need));
-    if (pools->plane_pool.p != p0 || pools->coef_pool.p != c0) { pools->generation++; pools->coef_pool_clean = false; }
+    HIPCHECK(pools->sp_pool.ensure(sp_total * 4));
+    if (pools->plane_pool.p != p0 || pools->coef_pool.p != c0 || pools->sp_pool.p != s0) pools->generation++;
+    if (pools->coef_pool.p != c0) pools->coef_pool_clean = false;
     pool_gen = pools->generation;
   }
   DevMem &plane_pool = pools->plane_pool, &coef_pool = pools->coef_pool;
@@ -761,7 +798,8 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * 6 * max_npx;
     int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
-    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = cset + (size_t)c * max_coef; }
+    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = sparse ? nullptr : cset + (size_t)c * max_coef; }
+    S.B.coef_sp = sparse ? (uint32_t *)pools->sp_pool.p + sp_frame_off[(size_t)k] : nullptr;      // (sp_group: below, once the flight's table block is laid out)
     hb.push_back(S.B); ha.push_back(S.A);
     if (k % hf_sets == 0) { if (k) close_subflight(); pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
     sf_groups.push_back(S.plan.num_groups);
@@ -784,10 +822,15 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const size_t o_b = 0, o_a = (hb.size() * sizeof(DevBuffers) + 255) & ~(size_t)255, o_lf = (o_a + ha.size() * sizeof(DevAux) + 255) & ~(size_t)255,
                o_pg = (o_lf + lf_map.size() * 4 + 255) & ~(size_t)255, o_ec = (o_pg + pg_map.size() * 4 + 255) & ~(size_t)255,
                o_w = (o_ec + ec_map.size() * 4 + 255) & ~(size_t)255, o_gd = (o_w + w_map.size() * 4 + 255) & ~(size_t)255,
-               o_fl = (o_gd + gdesc.size() * sizeof(GatherDesc) + 255) & ~(size_t)255, total = o_fl + (size_t)nb * kFlagWords * 4 + 4;
+               o_sp = (o_gd + gdesc.size() * sizeof(GatherDesc) + 255) & ~(size_t)255,
+               o_fl = (o_sp + sp_groups.size() * 4 + 255) & ~(size_t)255, total = o_fl + (size_t)nb * kFlagWords * 4 + 4;
   HIPCHECK(batch_tab.ensure(total));
   HIPCHECK(h_batch.ensure(total));
   uint8_t *bt = (uint8_t *)batch_tab.p, *hbt = (uint8_t *)h_batch.p;
+  if (sparse) {
+    for (int k = 0; k < nb; k++) { hb[(size_t)k].sp_group = (const uint32_t *)(bt + o_sp) + sp_tab_off[(size_t)k]; slot((size_t)batched[(size_t)k]).B.sp_group = hb[(size_t)k].sp_group; }
+    memcpy(hbt + o_sp, sp_groups.data(), sp_groups.size() * 4);
+  }
   memcpy(hbt + o_b, hb.data(), hb.size() * sizeof(DevBuffers));
   memcpy(hbt + o_a, ha.data(), ha.size() * sizeof(DevAux));
   memcpy(hbt + o_lf, lf_map.data(), lf_map.size() * 4);
@@ -808,30 +851,32 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // ---- HF phase: this context's turn on the pools (uncontended unless shared).  The wait is host-side and overlaps the LF stage launched above
   std::unique_lock<std::mutex> pool_lock(pools->mu);
   if (pools->generation != pool_gen) return kRetryMoved;      // a sharing context re-allocated the pools meanwhile (first flights only): the tables above hold stale addresses
-  if (!pools->coef_pool_clean) HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));      // fresh, or left dirty by a failed flight: clear once
-  pools->coef_pool_clean = false;                            // until every frame of this flight has been collected without error
+  if (!sparse) {
+    if (!pools->coef_pool_clean) HIPCHECK(hipMemsetAsync(coef_pool.p, 0, coef_pool.cap, stream));      // fresh, or left dirty by a failed flight: clear once
+    pools->coef_pool_clean = false;                          // until every frame of this flight has been collected without error
+  }
   for (int sf = 0, k0 = 0; k0 < nb; sf++, k0 += hf_sets) {
     const int cnt = std::min(hf_sets, nb - k0);
     const int *map = (const int *)(bt + o_pg) + 2 * pg_off[(size_t)sf];
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
     // >= flat_min_groups groups: one LANE per group (k_pass_prep + k_pass_flat, 64 streams per wavefront); below that the
     // one-wave-per-group kernel has the shorter critical path
-    if (all_flat && n_pg >= flat_min_groups) {
+    if (sparse || (all_flat && n_pg >= flat_min_groups)) {
       launch_pass_prep(dB + k0, map, n_pg, stream);
-      launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), stream);
+      launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), sparse, stream);
     } else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream);
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
   int first_rc = JXLAMD_OK;
   large_blocks_seen = false;
   uint32_t pool_want = 0;
-  bool need_pool = false;
+  bool need_pool = false, need_dense = false;
   // flags / counters of all frames in one device-to-host copy and one synchronisation
   launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
   HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
@@ -849,6 +894,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
     pool_want = std::max(pool_want, head[1]);
+    if (sparse && (head[0] & kErrNeedDense) && !(head[0] & 0xFFFFu & ~kErrNeedDense)) { need_dense = true; continue; }      // (judged again in the dense flight)
     if ((head[0] & kErrNeedPool) && !(head[0] & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) need_pool = true;
     else if ((head[0] & kErrNeedGeneral) && !lf_general) return kRetryGeneral;      // (coef_pool_clean stays false: the second attempt clears the pool)
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
@@ -856,8 +902,9 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   }
   // one miss is enough evidence that this context's frames vary: it keeps the largest pool from here on (a repeated flight costs more than a
   // fourth LF stream per CU gains; measured on 256 distinct frames: wanted pools 12 .. 25 KB, 8 % of the flights repeated with a creeping floor)
+  if (need_dense && !need_pool) return kRetryDense;
   if (need_pool) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
-  pools->coef_pool_clean = first_rc == JXLAMD_OK;
+  if (!sparse) pools->coef_pool_clean = first_rc == JXLAMD_OK;
   lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
@@ -1199,6 +1246,11 @@ int jxlamd_debug_lf_general(const jxlamd_decoder *dec) { return dec && dec->lf_g
 int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]) {
   if (!dec || !out) return JXLAMD_ERR_BUFFER;
   out[0] = dec->pool_retries; out[1] = dec->general_retries; out[2] = (uint32_t)dec->lf_pool_bytes;
+  return JXLAMD_OK;
+}
+int jxlamd_debug_sparse(const jxlamd_decoder *dec, uint32_t out[2]) {      // {did the last flight hand its coefficients over as sparse lists, flights decoded again densely}
+  if (!dec || !out) return JXLAMD_ERR_BUFFER;
+  out[0] = dec->last_flight_sparse ? 1u : 0u; out[1] = dec->sparse_misses;
   return JXLAMD_OK;
 }
 int jxlamd_debug_lf_phases_frame(jxlamd_decoder *d, int frame, int num_lf_groups, uint64_t *out) {     // frame = slot index inside the last flight

@@ -94,7 +94,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
   PinnedMem h_tables, h_cs, h_B;
   DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win, up_planes;
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef_cnt, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win, up_planes;
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -118,6 +118,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
 // the flight's time, a few MB per frame) the memory can serve another context's HF phase: contexts that share one HfPools take turns (mu).
 struct HfPools {
   DevMem plane_pool, coef_pool;
+  DevMem sp_pool;                   // sparse flights: the frames' coefficient-entry arenas (4 bytes per nonzero coefficient; ~16 bytes per byte of PassGroup section) instead of coef_pool
   bool coef_pool_clean = false;     // the reconstruction kernels clear every coefficient they consume: after a flight without errors the pool is all-zero
   uint64_t generation = 0;          // bumped whenever a buffer is (re)allocated: a flight that baked the old addresses into its tables starts over
   std::mutex mu;
@@ -152,6 +153,11 @@ struct jxlamd_decoder {
   int band_flat_min_groups = getenv("JXLAMD_FLAT_MIN_GROUPS") ? atoi(getenv("JXLAMD_FLAT_MIN_GROUPS")) : 4096;
   float timing[5] = {0, 0, 0, 0, 0};
   uint32_t pool_retries = 0, general_retries = 0;   // decodes / flights run a second time (kErrNeedPool / kErrNeedGeneral)
+  // Flights hand their coefficients over as sparse per-varblock lists (DevBuffers::coef_sp) unless JXLAMD_SPARSE=0; a flight whose streams beat the
+  // arenas' sizing or carry values / positions an entry cannot hold (kErrNeedDense) is decoded again with the dense planes, and a context that met
+  // three such flights stays dense
+  bool sparse_enabled = !(getenv("JXLAMD_SPARSE") && atoi(getenv("JXLAMD_SPARSE")) == 0);
+  uint32_t sparse_misses = 0; bool dense_flight = false, last_flight_sparse = false;
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)
   bool lf_general = false;               // the LF kernel build with the general lock-step loops (set for good the first time a frame of this context needs one)
   int lf_pool_bytes = kModPoolBytes;      // LDS table pool of the next LF launch: what the streams of the previous decode of this context asked for (first decode: the largest)

@@ -111,7 +111,8 @@ JXL_DEV void recon_block_subsampled(const DevBuffers &B, const uint8_t *stat, fl
 
 // ---- varblock reconstruction; LDS: S[3*n] + T[n]
 // kSpecial: the 8x8 special transforms can occur (small-block launch only); kPerChannel: S holds ONE channel (LDS: S[n] + T[n])
-template <bool kSpecial, bool kPerChannel = false, class Sync>
+// kSparse: the coefficients come from the varblock's sparse list (DevBuffers::coef_sp) instead of the dense planes
+template <bool kSpecial, bool kPerChannel = false, bool kSparse = false, class Sync>
 JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int nmin, int nmax,
                               int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
@@ -129,7 +130,8 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   if (kPerChannel) {
     const int R = cy * 8, C = cx * 8;
     for (int c = 0; c < 3; c++) {
-      recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads, c);
+      if (kSparse) recon_phaseA_sparse(B, stat, ST, S, n, bx, by, tid, nthreads, sync, c);
+      else recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads, c);
       sync();
       recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads, c);
       sync();
@@ -140,7 +142,8 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
     }
     return;
   }
-  recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
+  if (kSparse) recon_phaseA_sparse(B, stat, ST, S, n, bx, by, tid, nthreads, sync);
+  else recon_phaseA(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();
   recon_phaseB(B, stat, ST, S, n, bx, by, tid, nthreads);
   sync();

@@ -59,6 +59,17 @@ JXL_DEV uint32_t pass_prep_group_serial(const DevBuffers &B, int g) {
   return 0;
 }
 
+// entries of a group's sparse coefficient arena, from the bytes of its PassGroup section: four per byte (a nonzero coefficient of a photographic
+// stream costs 4 - 8 bits with its share of the zero runs and the nonzero counts; measured 1.1 - 1.9 entries per byte on the fixtures and the bench frames) + slack for tiny
+// sections, never more than the group has coefficients.  A stream that beats it ends with kErrNeedDense and its flight is decoded densely.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline uint32_t sparse_group_entries(uint32_t section_bytes) {      // (host: decoder.hip sizes the arenas with it)
+  const uint64_t e = 4ull * section_bytes + 1024u;
+  return e > 3u * 65536u ? 3u * 65536u : (uint32_t)e;
+}
+
 constexpr int kFlatBctxLds = 2560;                          // block-context map kept in LDS up to this size (39 x qf buckets x LF buckets; 39 without thresholds)
 struct FlatPassLds {                                       // per wavefront
   uint32_t ring[kSimtRing * 64];                           // lane-interleaved bit rings (sbits_*)
@@ -121,6 +132,9 @@ JXL_DEV uint32_t flat_ec_read(const uint32_t *cfg_lds, const uint8_t *ctx_map, c
 #define FLAT_NZ(c, x) L.nzcol[((((c) << 5) + (x)) << 6) + lane]
 // One pass of one group by one lane.  Every lane of the wave calls it (lanes without a group pass g < 0 and only take part in the
 // wave-wide ring top-ups).
+// kSparse: the nonzero coefficients go into the group's entry arena (DevBuffers::coef_sp) instead of the dense planes, and each varblock's
+// (first entry, entries) pair into coef_off / coef_cnt at its first cell — single-pass frames only (the host decides: decoder.hip)
+template <bool kSparse = false>
 JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, int g, int lane) {
   const DevFrame &F = frame_of(B);
   uint32_t *ring = L.ring;
@@ -158,6 +172,13 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
   uint32_t off = 0, o_cur = 0;
   const uint32_t *order = &L.order8[0][0][0];
   int32_t *blk = B.coef[0];
+  // sparse emission: this lane's arena, its fill, where the current varblock's entries began and the cell that owns them
+  const uint32_t sp_base = (kSparse && !done) ? B.sp_group[g] : 0u, sp_cap = (kSparse && !done) ? B.sp_group[g + 1] - sp_base : 0u;
+  uint32_t *ent = kSparse ? B.coef_sp + sp_base : nullptr;
+  uint32_t ne = 0, blk_start = 0;
+  size_t blk_cell = 0;
+  bool sp_bad = false;
+  const size_t cell0 = kSparse ? (size_t)((done ? 0 : g / F.xgroups) * 32) * (size_t)F.xb + (size_t)((done ? 0 : g % F.xgroups) * 32) : 0;
   while (SIMT_ANY(!done)) {
     uint32_t ctx = 0, o_next = 0;
     const bool run = nzeros > 0;                           // inside the coefficients of a (varblock, channel)
@@ -168,6 +189,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
         o_next = order[k + 1 < size ? k + 1 : k];          // the order entry one symbol ahead of its use
       } else {
         if (ci == 3) {
+          if (kSparse && bi > 0) { B.coef_off[blk_cell] = sp_base + blk_start; B.coef_cnt[blk_cell] = ne - blk_start; }      // the varblock just finished
           if (bi == nblk) done = true;
           else {
             const PassBlk d = dn;
@@ -178,6 +200,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
             log2c = lcx + lcy; covered = 1 << log2c; size = covered * 64;
             ord = (int)((d.a >> 16) & 15u); qf_idx = (int)((d.a >> 20) & 15u); lfi = (int)(d.a >> 24);
             off = d.off;
+            if (kSparse) { blk_start = ne; blk_cell = cell0 + (size_t)y * (size_t)F.xb + (size_t)x; }
             ci = 0;
           }
         }
@@ -204,6 +227,11 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
       if (run) {
         if (u) {
           const int32_t v = unpack_signed(u) * (1 << shift);
+          if (kSparse) {
+            if (ne < sp_cap) ent[ne] = sp_pack(o_cur, c, v);
+            ne++;
+            if (!sp_fits(o_cur, v)) sp_bad = true;
+          } else
           if (accumulate) blk[o_cur] += v; else blk[o_cur] = v;
         }
         o_cur = o_next;
@@ -220,7 +248,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
           for (int ix = 0; ix < cx; ix++) FLAT_NZ(c, x + ix) = nzv;
           histo = F.num_bctx * 37 + 458 * bctx;
           order = L.order_ptrs[ord * 3 + c];
-          blk = B.coef[c] + (size_t)g * 65536 + off;
+          if (!kSparse) blk = B.coef[c] + (size_t)g * 65536 + off;
           prev = nz > size / 16 ? 0 : 1;
           k = covered; nzeros = nz;
           if (nz == 0) ci++;
@@ -229,6 +257,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
       }
     }
   }
+  if (kSparse && g >= 0 && !err && (sp_bad || ne > sp_cap)) err = kErrNeedDense;
   if (g >= 0 && !err) {
     if (state != 0x130000u) err = kErrAnsFinal;
     else if (F.nsec != 1 && b.consumed > (uint64_t)sec.size * 8 + 64) err = kErrBitstream;

@@ -46,6 +46,10 @@ JXL_DEV void lf_smooth_cell(const DevBuffers &B, int x, int y) {
   for (int c = 0; c < 3; c++) B.lf_s[c][o] = (sm[c] - p0[c]) * factor + p0[c];
 }
 
+// chroma from luma: X (B) coefficient + factor * Y coefficient as ONE fused multiply-add, spelled out so that every reconstruction front end —
+// dense planes or sparse lists, whatever the compiler would have contracted — rounds the same way (batch == single decode, bit for bit)
+JXL_DEV float cfl_add(float v0, float k, float v1) { return fmaf(k, v1, v0); }
+
 // ------------------------------------------------------------------ varblock reconstruction
 // LDS layout for one varblock: S[3][n] dequantised coefficients (storage layout), T[n] scratch.
 // Phase A (tid over n): dequant + CfL.  Phase B: LLF from LF.  Phase C/D per channel: two 1-D passes.
@@ -83,10 +87,58 @@ JXL_DEV void recon_phaseA(const DevBuffers &B, const uint8_t *stat, const DevSta
       else a = (float)q - F.quant_bias[3] / (float)q;
       v[c] = a * (mul * F.dm[c] * qw[c][k]);
     }
-    if (only_c >= 0) { S[k] = only_c == 0 ? v[0] + kx * v[1] : only_c == 1 ? v[1] : v[2] + kb * v[1]; continue; }
-    S[k] = v[0] + kx * v[1];
+    if (only_c >= 0) { S[k] = only_c == 0 ? cfl_add(v[0], kx, v[1]) : only_c == 1 ? v[1] : cfl_add(v[2], kb, v[1]); continue; }
+    S[k] = cfl_add(v[0], kx, v[1]);
     S[n + k] = v[1];
-    S[2 * n + k] = v[2] + kb * v[1];
+    S[2 * n + k] = cfl_add(v[2], kb, v[1]);
+  }
+}
+
+// One entry of a sparse coefficient list, dequantised: the value recon_phaseA computes for (channel, position) from the dense planes
+JXL_DEV float sp_dequant(const DevFrame &F, uint32_t e, float mul_dm_c, const float *qw_c) {
+  const int q = sp_val(e);
+  const int c = sp_chan(e);
+  float a;
+  if (q == 1) a = F.quant_bias[c];
+  else if (q == -1) a = -F.quant_bias[c];
+  else a = (float)q - F.quant_bias[3] / (float)q;
+  return a * (mul_dm_c * qw_c[sp_pos(e)]);
+}
+// Phase A from a varblock's sparse list (DevBuffers::coef_sp, flights): clear the tile, scatter the X and B entries, then the Y entries —
+// each one also adds its chroma-from-luma share to X and B at its position, which is why they come last: cfl_add(X, kx, Y) needs X in place.
+// Same values as recon_phaseA (a zero coefficient dequantises to +0 and contributes nothing).  Contains barriers: every work-item calls it.
+template <class Sync>
+JXL_DEV void recon_phaseA_sparse(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, int n, int bx, int by,
+                                 int tid, int nthreads, Sync sync, int only_c = -1) {
+  const DevFrame &F = frame_of(B);
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  const int st = B.strategy[o];
+  const int qt = kQuantTableOf[st];
+  const uint32_t *ent = B.coef_sp + B.coef_off[o];
+  uint32_t cnt = B.coef_cnt[o];
+  if (cnt > 3u * (uint32_t)n) { if (tid == 0) *B.err |= kErrBitstream | kErrStageRecon; cnt = 0; }      // stale record (a stream that stopped early is flagged anyway)
+  const float mul = F.inv_global_scale / (float)((int)B.qfm1[o] + 1);
+  const size_t to = (size_t)(by / 8) * (size_t)F.tiles_x + (size_t)(bx / 8);
+  const float kx = F.base_x + (float)B.xfromy[to] * F.inv_color_factor;
+  const float kb = F.base_b + (float)B.bfromy[to] * F.inv_color_factor;
+  const float *qw[3] = {quant_mul(B, F, stat, ST, qt, 0), quant_mul(B, F, stat, ST, qt, 1), quant_mul(B, F, stat, ST, qt, 2)};
+  const int total = only_c >= 0 ? n : 3 * n;
+  for (int k = tid; k < total; k += nthreads) S[k] = 0.0f;
+  sync();
+  for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)nthreads) {
+    const uint32_t e = ent[i];
+    const int c = sp_chan(e);
+    if (c == 1 || c > 2 || (only_c >= 0 && c != only_c) || sp_pos(e) >= (uint32_t)n) continue;
+    S[(only_c >= 0 ? 0 : c * n) + (int)sp_pos(e)] = sp_dequant(F, e, mul * F.dm[c], qw[c]);
+  }
+  sync();
+  for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)nthreads) {
+    const uint32_t e = ent[i];
+    if (sp_chan(e) != 1 || sp_pos(e) >= (uint32_t)n) continue;
+    const int k = (int)sp_pos(e);
+    const float v1 = sp_dequant(F, e, mul * F.dm[1], qw[1]);
+    if (only_c < 0) { S[k] = cfl_add(S[k], kx, v1); S[n + k] = v1; S[2 * n + k] = cfl_add(S[2 * n + k], kb, v1); }
+    else S[k] = only_c == 0 ? cfl_add(S[k], kx, v1) : only_c == 1 ? v1 : cfl_add(S[k], kb, v1);
   }
 }
 

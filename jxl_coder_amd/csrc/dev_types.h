@@ -186,6 +186,7 @@ enum : uint32_t {
   kErrBitstream = 1, kErrUnsupportedTransform = 2, kErrUnsupportedBlock = 4, kErrAnsFinal = 8, kErrLz77 = 16,
   kErrTreeLocal = 32, kErrSqueeze = 64, kErrPalette = 128, kErrWaveFallback = 256,
   kErrNeedPool = 1024,         // not an error: the lean LF kernel met a channel whose packed tables exceed this launch's LDS table pool — the host decodes the frame again with the largest pool
+  kErrNeedDense = 2048,        // not an error: a sparse coefficient list overflowed its arena, or a value / position does not fit an entry — the host decodes the flight again with the dense coefficient planes
   kErrNeedGeneral = 512,       // not an error: the lean LF kernel met a channel that needs a general loop — the host decodes the frame again with k_lf_group*_general
   kErrStageLf = 1u << 16, kErrStagePass = 1u << 17, kErrStageRecon = 1u << 18,   // which kernel raised the flag
 };

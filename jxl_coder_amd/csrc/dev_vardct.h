@@ -48,7 +48,20 @@ struct DevBuffers {
   float *ref_a[4];              // ... and, for a slot that holds a blended canvas (frames of an animation), its alpha plane (null: the image has none)
   float *canvas_save[4];        // where blend_canvas_pixel keeps the blended canvas (R, G, B, A planes of canvas_w x canvas_h; null: not kept)
   float *ref[4][3];             // reference slots (patch dictionaries): 3 f32 planes of DevFrame::ref_w x ref_h samples each, XYB or RGB as the image is coded
+  // Sparse coefficient lists (flights, single-pass frames; null: the dense coef[] planes).  k_pass_flat appends one 32-bit entry per NONZERO
+  // coefficient to its group's arena — varblocks in stream order, inside a varblock channel Y, then X, then B — and records per varblock
+  // (at its first cell) where its entries start (coef_off, an index into coef_sp) and how many there are (coef_cnt).  The reconstruction
+  // front ends clear their LDS tile and scatter the entries into it: no 3 x 65 536 x 4-byte planes per group to write, read and clear.
+  uint32_t *coef_sp;            // entries: position in the varblock's storage layout (12 bits) | channel << 12 | quantised value << 14
+  uint32_t *coef_cnt;           // per first-cell: entries of the varblock
+  const uint32_t *sp_group;     // [num_groups + 1]: first entry of each group's arena (the host sizes it from the group's section bytes)
 };
+// entry of a sparse coefficient list; values outside 18 bits / positions beyond 4 095 do not fit (kErrNeedDense: the flight is decoded again with the dense planes)
+JXL_DEV uint32_t sp_pack(uint32_t pos, int c, int32_t v) { return pos | ((uint32_t)c << 12) | ((uint32_t)v << 14); }
+JXL_DEV bool sp_fits(uint32_t pos, int32_t v) { return pos < 4096u && v >= -(1 << 17) && v < (1 << 17); }
+JXL_DEV uint32_t sp_pos(uint32_t e) { return e & 4095u; }
+JXL_DEV int sp_chan(uint32_t e) { return (int)((e >> 12) & 3u); }
+JXL_DEV int32_t sp_val(uint32_t e) { return (int32_t)e >> 14; }
 
 constexpr int kLfScratchInts = 6 * 65536 + 2048 + 16;   // LF ints (3 planes) + CfL maps + block info + sharpness + [last] extra_precision
 

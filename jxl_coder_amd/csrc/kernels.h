@@ -15,14 +15,22 @@ int lf_pool_clamp(uint32_t wanted);
 // flights / large bands: k_pass_prep (group descriptor lists; map = {frame, group} pairs) then k_pass_flat (lane per group; wmap = {frame,
 // first group, groups <= 64} per wavefront, entries with 0 groups allowed); frames must pass flat_frame_ok (dev_pass_flat.h)
 void launch_pass_prep(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s);
-void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s);
+void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, bool sparse, hipStream_t s);      // sparse: coefficients into DevBuffers::coef_sp (single-pass frames)
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
-void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s);
+void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, bool sparse, hipStream_t s);
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s);
+// stage_mask bit of a frame's column-sweep instantiation: 8 + (gab ? 3 : 0) + epf_iters, + kSweepFastShift when the frame takes the sweep's fast writer
+// (host twin of sweep_fast_frame, kernels_filter.hip: sRGB curve, RGBA8, identity orientation, frame = canvas, no alpha plane, no post stages in the writer)
+constexpr int kSweepFastShift = 6;
+inline int sweep_stage_bit(const DevFrame &F, int out_bits, bool writer_post) {
+  const bool fast = F.transfer == 13 && F.orientation == 1 && out_bits == 8 && !(F.has_ec && F.mod_out[3] >= 0) && F.crop_x0 == 0 && F.crop_y0 == 0 &&
+                    F.canvas_w == F.width && F.canvas_h == F.height && !writer_post;
+  return 1 << (8 + (fast ? kSweepFastShift : 0) + (F.gab ? 3 : 0) + F.epf_iters);
+}
 // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
 inline void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
-                              int parts, hipStream_t s) {
-  if (parts & 1) launch_recon_batch(Bs, stat, nframes, max_cells, expect_large, s);
+                              int parts, hipStream_t s, bool sparse = false) {
+  if (parts & 1) launch_recon_batch(Bs, stat, nframes, max_cells, expect_large, sparse, s);
   if (parts & 2) launch_filters_batch(Bs, stat, nframes, max_w, max_h, stage_mask, s);
 }
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);

@@ -94,7 +94,14 @@ __device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__bu
 __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && !F.compose && F.epf_iters <= 2; }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-template <bool kGab, int kEpf>
+// kFast (sweep_fast_frame): the common output — sRGB transfer curve, RGBA8, identity orientation, the frame covers the canvas, no alpha plane.  The
+// general writer decides all of that per pixel (seven transfer functions, eight orientations, crop, alpha, 8 / 16 bits: ~90 branches in the loop body
+// and two thirds of its instructions); here the colour constants sit in scalar registers and the pixel goes straight from the filter to one 32-bit store.
+__device__ __forceinline__ bool sweep_fast_frame(const DevBuffers &B, const DevFrame &F) {
+  return F.transfer == 13 && F.orientation == 1 && B.out_bits == 8 && !(F.has_ec && F.mod_out[3] >= 0) && F.crop_x0 == 0 && F.crop_y0 == 0 &&
+         F.canvas_w == F.width && F.canvas_h == F.height && B.post == nullptr;
+}
+template <bool kGab, int kEpf, bool kFast>
 __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int strip, int seg, int rows_per_wave, int lane) {
   constexpr int DG = kGab ? 1 : 0, DE = kEpf >= 1 ? 2 : 0, DF = kEpf >= 2 ? 1 : 0;     // row delay of each stage behind its input
   constexpr int HX = DG + DE + DF, SW = 64 - 2 * HX;
@@ -120,14 +127,37 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   float in[3][3] = {}, G[4][3] = {}, Ev[3] = {}, Eh[3] = {}, E1[3][3] = {};
   float sad_up_e = 0.0f, is1 = 0.0f, is2 = 0.0f;
   int cell1 = -1, cell2 = -1;
+  // the fast writer's constants (wave-uniform: scalar registers) and this lane's column of the dither table
+  float obc[3], ob[3], oi[9];
+  const float *dith = nullptr;
+  uint32_t *orow = nullptr;
+  if (kFast) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { obc[c] = sgpr_f(F.opsin_bias_cbrt[c]); ob[c] = sgpr_f(F.opsin_bias[c]); }
+#pragma unroll
+    for (int i = 0; i < 9; i++) oi[i] = sgpr_f(F.opsin_inv[i]);
+    dith = st_f(stat, ST.dither_off) + (x & 31);
+    orow = (uint32_t *)B.out + x;
+  }
+  // the next row's samples are requested one iteration ahead: the ~300 instructions of a row hide the fetch whatever else is resident on the SIMD
+  float nx[3];
+  {
+    const size_t r0 = (size_t)mirror(y0 - HX, h) * (size_t)F.pw;
+#pragma unroll
+    for (int c = 0; c < 3; c++) nx[c] = src[c][r0];
+  }
 #ifdef JXL_SWEEP_UNROLL
 #pragma unroll JXL_SWEEP_UNROLL
 #endif
   for (int t = y0 - HX; t < y1 + HX; t++) {
-    const size_t ro = (size_t)mirror(t, h) * (size_t)F.pw;
     float v[3];
 #pragma unroll
-    for (int c = 0; c < 3; c++) { in[0][c] = in[1][c]; in[1][c] = in[2][c]; in[2][c] = src[c][ro]; }
+    for (int c = 0; c < 3; c++) { in[0][c] = in[1][c]; in[1][c] = in[2][c]; in[2][c] = nx[c]; }
+    if (t + 1 < y1 + HX) {
+      const size_t rn = (size_t)mirror(t + 1, h) * (size_t)F.pw;
+#pragma unroll
+      for (int c = 0; c < 3; c++) nx[c] = src[c][rn];
+    }
     // Gaborish at row g = t - DG
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -199,20 +229,36 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
     const int o = t - HX;                                         // the row that left the last stage
     if (o >= y0 && lane_out) {
       asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));      // keep the filter's last multiply and the writer's first add apart (no FMA across the seam)
+      if (kFast) {
+        // xyb_to_rgb + tf_srgb + the clamp + rgba_codes for the fast frame, same operations in the same order
+        const float gl = v[1] + v[0] - obc[0], gm = v[1] - v[0] - obc[1], gs = v[2] - obc[2];
+        const float mix0 = gl * gl * gl + ob[0], mix1 = gm * gm * gm + ob[1], mix2 = gs * gs * gs + ob[2];
+        const float d = dith[(o & 31) * 32];
+        uint32_t px = 0xFF000000u;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          float lin = oi[c * 3] * mix0 + oi[c * 3 + 1] * mix1 + oi[c * 3 + 2] * mix2;
+          lin = tf_srgb(lin);
+          float cv = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
+          if (!(lin == lin)) cv = 0.0f;
+          px |= (uint32_t)(uint8_t)(int)rintf(cv * 255.0f + d) << (8 * c);
+        }
+        orow[(size_t)o * (size_t)F.out_w] = px;
+      } else
       xyb_write_value(B, stat, ST, v[0], v[1], v[2], B.out_bits, x, o);
     }
   }
 }
 // one instantiation per stage combination: the register footprint of the longest pipeline (Gaborish + two EPF iterations) must not be
 // charged to the common one (Gaborish + one iteration)
-template <bool kGab, int kEpf>
+template <bool kGab, int kEpf, bool kFast>
 __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (!frame_uses_sweep(F) || frame_failed(B)) return;
-  if ((F.gab != 0) != kGab || F.epf_iters != kEpf) return;           // another instantiation's frame
+  if ((F.gab != 0) != kGab || F.epf_iters != kEpf || sweep_fast_frame(B, F) != kFast) return;           // another instantiation's frame
   const int lane = (int)(threadIdx.x & 63), seg = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)), strip = (int)blockIdx.x;
-  filter_sweep<kGab, kEpf>(B, F, stat, strip, seg, rows_per_wave, lane);
+  filter_sweep<kGab, kEpf, kFast>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
 
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
@@ -223,13 +269,20 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   {
     const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
     const dim3 g((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes);
-    const int combos = stage_mask >> 8;                        // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use
-    if (combos & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2>), g, dim3(256), 0, s, Bs, stat, rows);
+    // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use; bits 6..11: the same for its fast-writer frames (kSweepFastShift)
+    const int combos = (stage_mask >> 8) & 63, fast = (stage_mask >> (8 + kSweepFastShift)) & 63;
+    if (combos & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, false>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    if (fast & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, true>), g, dim3(256), 0, s, Bs, stat, rows);
     if (!(stage_mask & (2 | 32))) return;                       // 32: a composed frame — stage by stage whatever its filters
   }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(64) k_pass_prep(const DevBuffers *__restrict__
   if (lane == 0) { ((uint32_t *)base)[0] = total_n; ((uint32_t *)base)[1] = 0; }
 }
 // wmap: {frame, first group, number of groups <= 64} per wavefront (entries with 0 groups pad the XCD interleave, see decoder.hip)
+template <bool kSparse>
 __global__ void __launch_bounds__(64) k_pass_flat(const DevBuffers *__restrict__ Bs, const int *__restrict__ wmap) {
   __shared__ __attribute__((aligned(16))) FlatPassLds L;
   const int lane = (int)threadIdx.x;
@@ -78,13 +79,16 @@ __global__ void __launch_bounds__(64) k_pass_flat(const DevBuffers *__restrict__
     __syncthreads();
     flat_stage(B, L, pass, lane, 64);
     __syncthreads();
-    const uint32_t ep = pass_group_flat(B, L, pass, (lane < n && !e) ? g0 + lane : -1, lane);
+    const uint32_t ep = pass_group_flat<kSparse>(B, L, pass, (lane < n && !e) ? g0 + lane : -1, lane);
     e |= ep;
   }
   if (e) atomicOr(B.err, e | kErrStagePass);
 }
 void launch_pass_prep(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s) { hipLaunchKernelGGL(k_pass_prep, dim3(ngroups), dim3(64), 0, s, Bs, map); }
-void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, hipStream_t s) { hipLaunchKernelGGL(k_pass_flat, dim3(nwg), dim3(64), 0, s, Bs, wmap); }
+void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, bool sparse, hipStream_t s) {
+  if (sparse) hipLaunchKernelGGL(k_pass_flat<true>, dim3(nwg), dim3(64), 0, s, Bs, wmap);
+  else hipLaunchKernelGGL(k_pass_flat<false>, dim3(nwg), dim3(64), 0, s, Bs, wmap);
+}
 
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }

@@ -64,10 +64,21 @@ __device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const floa
 // work-items of the LLF corner, with a barrier in between.  Here every work-item first issues ALL its loads (12 coefficients and
 // their weights; wave 3 also the 16 LF samples of its LLF output), then computes; the LLF corner is skipped by the dequantiser
 // and written by wave 3, so the two need no barrier between them.  Same float operations in the same order as the generic path.
+// kSparse: the coefficients come from the varblock's sparse list (DevBuffers::coef_sp; recon_phaseA_sparse, the same values): the tile is cleared and
+// the few nonzero entries scattered into it — no 12 KB of mostly zero coefficients to fetch and to clear per block
+template <bool kSparse>
 __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *LL, int bx, int by, int tid) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
   const int qt = kQuantTableOf[kStrategyDct32];
+  const int li = tid - 192;
+  const bool llf = li >= 0 && li < 48;
+  float lf1 = 0.0f;
+  if (kSparse) {
+    if (llf) lf1 = B.lf_s[li >> 4][o + (size_t)((li >> 2) & 3) * (size_t)F.xb + (size_t)(li & 3)];      // issued before the barriers of the scatter
+    recon_phaseA_sparse(B, stat, ST, S, 1024, bx, by, tid, 256, SyncBlock());
+    __syncthreads();                                   // the corner's positions may have received entries: the LLF values below replace them
+  } else {
   const int g = (by / 32) * F.xgroups + (bx / 32);
   uint32_t off = B.coef_off[o];
   if (off + 1024u > 65536u) { if (tid == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
@@ -84,9 +95,6 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
   // LLF corner: work-item 192 + i, i < 48 (all in wave 3), produces coefficient (a, b) = (i / 4 % 4, i % 4) of channel i / 16.  Each of the
   // 48 loads ONE of the 3 x 16 LF samples (same index arithmetic: sample (iy, ix) = (i / 4 % 4, i % 4) of channel i / 16) and the wave
   // shares them through LDS — sixteen loads per work-item cost sixteen registers in every lane of the workgroup
-  const int li = tid - 192;
-  const bool llf = li >= 0 && li < 48;
-  float lf1 = 0.0f;
   if (llf) lf1 = B.lf_s[li >> 4][o + (size_t)((li >> 2) & 3) * (size_t)F.xb + (size_t)(li & 3)];
   const auto sg = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };    // per-block values are wave-uniform: scalar registers
   const float mul = sg(F.inv_global_scale / (float)((int)B.qfm1[o] + 1));
@@ -111,9 +119,10 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
       v[c] = a * (md[c] * w[c][j]);
     }
     if ((k >> 5) < 4 && (k & 31) < 4) continue;        // the LLF corner belongs to wave 3
-    S[k] = v[0] + kx * v[1];
+    S[k] = cfl_add(v[0], kx, v[1]);
     S[1024 + k] = v[1];
-    S[2048 + k] = v[2] + kb * v[1];
+    S[2048 + k] = cfl_add(v[2], kb, v[1]);
+  }
   }
   if (llf) LL[32 + li] = lf1;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");            // wave 3 only: its LDS accesses execute in order, the fences keep the compiler from reordering
@@ -139,13 +148,15 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
 // (w >> 1, w & 1) of both 64x64x64 products, 32 v_mfma_f32_32x32x2_f32 each; the 64-point cosine table is read from the static tables
 // (L2-resident).  Same operand maps as recon_dct32_mfma.
 constexpr int kStrategyDct64 = 18;
+template <bool kSparse>
 __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, int bx, int by, int tid) {
   const DevFrame &F = frame_of(B);
   const float *cc = st_f(stat, ST.cos_off[6]);
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int t0 = (wave >> 1) * 32, t1 = (wave & 1) * 32;
   for (int c = 0; c < 3; c++) {
-    recon_phaseA(B, stat, ST, S, 4096, bx, by, tid, 256, c);
+    if (kSparse) recon_phaseA_sparse(B, stat, ST, S, 4096, bx, by, tid, 256, SyncBlock(), c);
+    else recon_phaseA(B, stat, ST, S, 4096, bx, by, tid, 256, c);
     __syncthreads();
     recon_phaseB(B, stat, ST, S, 4096, bx, by, tid, 256, c);
     __syncthreads();
@@ -187,11 +198,19 @@ __global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
 // rows a lane needs (its x in the first pass, its y in the second) in registers.  Same operations in the same order as
 // recon_phaseA / recon_phaseB / recon_idct_pass1 / recon_idct_pass2 for this strategy (one tenth of their instructions: no per-element
 // index arithmetic, no table loads inside the sums).
+template <bool kSparse>
 __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, int bx, int by, int lane,
                                                  const float (&cx8)[8], const float (&cy8)[8]) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
   const int qt = kQuantTableOf[0];
+  if (kSparse) {
+    float l3[3] = {0.0f, 0.0f, 0.0f};
+    if (lane < 3) l3[0] = B.lf_s[lane][o];             // the LLF "corner" of a 1x1 block is the LF sample itself (all scales are 1)
+    recon_phaseA_sparse(B, stat, ST, S, 64, bx, by, lane, 64, SyncBlock());
+    __syncthreads();
+    if (lane < 3) S[lane * 64] = l3[0];
+  } else {
   const int g = (by / 32) * F.xgroups + (bx / 32);
   uint32_t off = B.coef_off[o];
   if (off + 64u > 65536u) { if (lane == 0) *B.err |= kErrBitstream | kErrStageRecon; off = 0; }   // see recon_phaseA
@@ -212,9 +231,10 @@ __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint
     else a = (float)q - F.quant_bias[3] / (float)q;
     v[c] = a * (mul * F.dm[c] * quant_mul(B, F, stat, ST, qt, c)[lane]);
   }
-  float s0 = v[0] + kx * v[1], s1 = v[1], s2 = v[2] + kb * v[1];
+  float s0 = cfl_add(v[0], kx, v[1]), s1 = v[1], s2 = cfl_add(v[2], kb, v[1]);
   if (lane == 0) { s0 = B.lf_s[0][o]; s1 = B.lf_s[1][o]; s2 = B.lf_s[2][o]; }      // the LLF "corner" of a 1x1 block is the LF sample itself (all scales are 1)
   S[lane] = s0; S[64 + lane] = s1; S[128 + lane] = s2;
+  }
   __syncthreads();
   const int hi = lane >> 3, lo = lane & 7;
   float t[3] = {0.0f, 0.0f, 0.0f};
@@ -235,6 +255,7 @@ __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint
   for (int c = 0; c < 3; c++) B.plane_a[c][po] = r[c];
 }
 
+template <bool kSparse>
 __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat, int skip_dct8) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
@@ -242,6 +263,7 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
   const DevFrame &F = frame_of(B);
   if (F.is_modular) return;
   if (frame_failed(B)) {
+    if (kSparse) return;                               // nothing to tidy: a sparse arena is rewritten from its start by its next user
     // A PassGroup stream that stopped early leaves coefficients nobody will consume: the set must be all-zero again before its next
     // user (the frame hf_sets later in this flight, or the next decode), so the failed frame's launch clears it instead.
     const size_t g0 = (size_t)F.band_gr0 * (size_t)F.xgroups * 65536, g1 = (size_t)F.band_gr1 * (size_t)F.xgroups * 65536;
@@ -256,11 +278,12 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, cons
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
     if (skip_dct8 && !F.subsampled) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
     __syncthreads();
-    recon_block_body<true>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+    recon_block_body<true, false, kSparse>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
 // list walkers of the one-wave-per-block families: workgroup `wg` of `nwg` takes every nwg-th entry of the class's size list and
 // reconstructs the blocks of its own strategy.  smem: the workgroup's LDS (k_recon_lists_*: one launch for several families)
+template <bool kSparse>
 __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8_t *stat, float *smem, uint32_t wg, uint32_t nwg) {
   float *S = smem, *T = smem + 3 * 64;
   const DevFrame &F = frame_of(B);
@@ -277,7 +300,7 @@ __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != 0) continue;
     __syncthreads();
-    recon_dct8_block(B, stat, ST, S, T, cell % F.xb, by, lane, cx8, cy8);
+    recon_dct8_block<kSparse>(B, stat, ST, S, T, cell % F.xb, by, lane, cx8, cy8);
   }
 }
 // DCT16x16, DCT16x8, DCT8x16 — with DCT8x8 the bulk of the varblocks of photographic content (the reference's 4K demo photograph: 9 700
@@ -285,12 +308,14 @@ __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8
 // so that the 1-D passes are register-blocked (one cosine value / one T value feeds R C / 64 multiply-adds) with both cosine tables in
 // LDS; all coefficient loads of the block are issued up front.  Same operations in the same order as the generic path
 // (recon_phaseA / recon_phaseB / recon_idct_pass1 / recon_idct_pass2, incl. the transposed storage of blocks with R >= C).
-template <int R, int C>
+template <int R, int C, bool kSparse>
 __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, float *T, const float *ccC, const float *crR,
                                                    int st, int bx, int by, int lane) {
   constexpr int N = R * C, NJ = N / 64;
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  if (kSparse) recon_phaseA_sparse(B, stat, ST, S, N, bx, by, lane, 64, SyncBlock());
+  else {
   const int qt = kQuantTableOf[st];
   const int g = (by / 32) * F.xgroups + (bx / 32);
   uint32_t off = B.coef_off[o];
@@ -319,9 +344,10 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
       else a = (float)qq - F.quant_bias[3] / (float)qq;
       v[c] = a * (mul * F.dm[c] * w[c][j]);
     }
-    S[k] = v[0] + kx * v[1];
+    S[k] = cfl_add(v[0], kx, v[1]);
     S[N + k] = v[1];
-    S[2 * N + k] = v[2] + kb * v[1];
+    S[2 * N + k] = cfl_add(v[2], kb, v[1]);
+  }
   }
   __syncthreads();
   recon_phaseB(B, stat, ST, S, N, bx, by, lane, 64);          // the LLF corner (C / 8 x R / 8 values per channel) overwrites its positions
@@ -360,7 +386,7 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
 #pragma unroll
     for (int j = 0; j < NJ; j++) B.plane_a[c][po + (size_t)j * (size_t)F.pw] = acc[c][j];
 }
-template <int R, int C, int STRAT, int LIST>      // LIST: the size-class list the strategy's blocks are on (2: <= 256 coefficients, 0: 512 / 1024)
+template <int R, int C, int STRAT, int LIST, bool kSparse>      // LIST: the size-class list the strategy's blocks are on (2: <= 256 coefficients, 0: 512 / 1024)
 __device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uint8_t *stat, float *smem, uint32_t wg, uint32_t nwg) {
   float *S = smem, *T = smem + 3 * R * C, *ccC = smem + 6 * R * C, *crR = smem + 6 * R * C + C * C;
   const DevFrame &F = frame_of(B);
@@ -375,41 +401,44 @@ __device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uin
     const int by = cell / F.xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != STRAT) continue;
     __syncthreads();
-    recon_dct_rc_block<R, C>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
+    recon_dct_rc_block<R, C, kSparse>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
   }
 }
 // The one-wave-per-block families in TWO launches instead of nine (blockIdx.y = family): every launch of a flight's stream is a
 // serialisation point — the previous kernel drains, the next one waits for slots among the kernels of 15 other contexts — and these
 // kernels carry a few per cent of the area of smooth content.  _a: DCT8x8, 16x16, 16x8, 8x16 (8 KB of LDS, <= 90 VGPRs: the bulk of
 // photographic content); _b: the 32-wide / 32-tall rectangles (17 KB).
+template <bool kSparse>
 __global__ void __launch_bounds__(64) k_recon_lists_a(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) float smem[6 * 256 + 2 * 256];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
   switch (blockIdx.y) {
-    case 0: recon_dct8_walk(B, stat, smem, blockIdx.x, gridDim.x); break;
-    case 1: recon_dct_rc_walk<16, 16, 4, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;     // AcStrategy 4: DCT16x16
-    case 2: recon_dct_rc_walk<16, 8, 6, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 6: 16 rows x 8 columns
-    default: recon_dct_rc_walk<8, 16, 7, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;     // 7: 8 x 16
+    case 0: recon_dct8_walk<kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;
+    case 1: recon_dct_rc_walk<16, 16, 4, 2, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;     // AcStrategy 4: DCT16x16
+    case 2: recon_dct_rc_walk<16, 8, 6, 2, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 6: 16 rows x 8 columns
+    default: recon_dct_rc_walk<8, 16, 7, 2, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;     // 7: 8 x 16
   }
 }
+template <bool kSparse>
 __global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) float smem[6 * 512 + 256 + 1024];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
   switch (blockIdx.y) {
-    case 0: recon_dct_rc_walk<32, 8, 8, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 8: 32 x 8
-    case 1: recon_dct_rc_walk<8, 32, 9, 2>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 9: 8 x 32
-    case 2: recon_dct_rc_walk<32, 16, 10, 0>(B, stat, smem, blockIdx.x, gridDim.x); break;    // 10: 32 x 16
-    default: recon_dct_rc_walk<16, 32, 11, 0>(B, stat, smem, blockIdx.x, gridDim.x); break;   // 11: 16 x 32
+    case 0: recon_dct_rc_walk<32, 8, 8, 2, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 8: 32 x 8
+    case 1: recon_dct_rc_walk<8, 32, 9, 2, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;      // 9: 8 x 32
+    case 2: recon_dct_rc_walk<32, 16, 10, 0, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;    // 10: 32 x 16
+    default: recon_dct_rc_walk<16, 32, 11, 0, kSparse>(B, stat, smem, blockIdx.x, gridDim.x); break;   // 11: 16 x 32
   }
 }
 // DCT32x32 blocks only (98 % of the area of smooth 4K content): half the LDS of the general medium kernel (the second pass runs in
 // place: wave c reads all of channel c before it writes) and its own, smaller register footprint — what the data-parallel kernels can
 // use next to resident entropy waves is what decides their speed in a flight mix.
 struct ReconDct32Lds { float S[3 * 1024]; float CC[1024]; float LL[96]; };
+template <bool kSparse>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_dct32_b(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) ReconDct32Lds L;
   const DevBuffers &B = Bs[blockIdx.z];
@@ -430,13 +459,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     const int bx = cell % xb, by = cell / xb;
     if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != kStrategyDct32) continue;
     __syncthreads();                                 // the previous block's second pass has finished reading S
-    recon_dct32_front(B, stat, ST, L.S, L.LL, bx, by, tid);
+    recon_dct32_front<kSparse>(B, stat, ST, L.S, L.LL, bx, by, tid);
     __syncthreads();
     recon_dct32_mfma(B, L.S, L.S, L.CC, bx, by, tid);
   }
 }
 // The 512 / 1024-coefficient blocks that are NOT DCT32x32 (DCT16x32, 32x16, 8x32, ... — a few per cent of the blocks), one channel at a
 // time: 8 KB of LDS instead of the general medium kernel's 33 KB, so that this short launch is not kept waiting for LDS by resident LF waves.
+template <bool kSparse>
 __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs, const uint8_t *stat, int skip_rc) {
   __shared__ __attribute__((aligned(16))) float S[1024];
   __shared__ __attribute__((aligned(16))) float T[1024];
@@ -451,11 +481,12 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs,
     const int st = B.strategy[cell];
     if (by < F.band_cy0 || by >= F.band_cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_lists_b
     __syncthreads();
-    recon_block_body<false, true>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
+    recon_block_body<false, true, kSparse>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
   }
 }
 // The 2048 / 4096-coefficient blocks with half the LDS of k_recon_list_b<1025, 4096>: DCT64x64 on the matrix cores with the second pass in
 // place (16 KB), the 64x32 / 32x64 blocks one channel at a time in S[2048] + T[2048].
+template <bool kSparse>
 __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) float S[4096];
   const DevBuffers &B = Bs[blockIdx.z];
@@ -469,23 +500,29 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, con
     const int bx = cell % xb, by = cell / xb;
     if (by < F.band_cy0 || by >= F.band_cy1) continue;
     __syncthreads();
-    if (B.strategy[cell] == kStrategyDct64) recon_dct64_mfma(B, stat, ST, S, S, bx, by, tid);
-    else recon_block_body<false, true>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
+    if (B.strategy[cell] == kStrategyDct64) recon_dct64_mfma<kSparse>(B, stat, ST, S, S, bx, by, tid);
+    else recon_block_body<false, true, kSparse>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
   }
 }
-void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
+template <bool kSparse>
+static void launch_recon_batch_t(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers; in a flight (16 frames per launch) 256 workgroups
   // per frame fill the chip, and the launches of the families a frame does not use cost 4 096 empty workgroups instead of 16 384
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
   const dim3 gs(std::min(max_cells, nframes == 1 ? 8192 : 256), 1, nframes);
   const dim3 gs4(gs.x, 4, nframes);
-  hipLaunchKernelGGL(k_recon_dct32_b, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
-  hipLaunchKernelGGL(k_recon_lists_a, gs4, dim3(64), 0, s, Bs, stat);                     // DCT8x8, 16x16, 16x8, 8x16
-  hipLaunchKernelGGL(k_recon_lists_b, gs4, dim3(64), 0, s, Bs, stat);                     // 32x8, 8x32, 32x16, 16x32
-  hipLaunchKernelGGL(k_recon_small_b, gs, dim3(64), 0, s, Bs, stat, 1);                   // the other <= 256-coefficient transforms (AFV, DCT4x8, ...)
-  hipLaunchKernelGGL(k_recon_medium_pc_b, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
+  hipLaunchKernelGGL(k_recon_dct32_b<kSparse>, dim3(gm, 1, nframes), dim3(256), 0, s, Bs, stat);
+  hipLaunchKernelGGL(k_recon_lists_a<kSparse>, gs4, dim3(64), 0, s, Bs, stat);                     // DCT8x8, 16x16, 16x8, 8x16
+  hipLaunchKernelGGL(k_recon_lists_b<kSparse>, gs4, dim3(64), 0, s, Bs, stat);                     // 32x8, 8x32, 32x16, 16x32
+  hipLaunchKernelGGL(k_recon_small_b<kSparse>, gs, dim3(64), 0, s, Bs, stat, 1);                   // the other <= 256-coefficient transforms (AFV, DCT4x8, ...)
+  hipLaunchKernelGGL(k_recon_medium_pc_b<kSparse>, dim3(nframes > 1 ? 64 : gm, 1, nframes), dim3(256), 0, s, Bs, stat, 1);
   // the 2048 / 4096-coefficient list: one workgroup per frame when the previous flight had none
-  hipLaunchKernelGGL(k_recon_large_b, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
+  hipLaunchKernelGGL(k_recon_large_b<kSparse>, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
+}
+// sparse: the frames' coefficients are per-varblock sparse lists (DevBuffers::coef_sp, written by k_pass_flat<true>) — every frame of the launch
+void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, bool sparse, hipStream_t s) {
+  if (sparse) launch_recon_batch_t<true>(Bs, stat, nframes, max_cells, expect_large, s);
+  else launch_recon_batch_t<false>(Bs, stat, nframes, max_cells, expect_large, s);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
 __global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {

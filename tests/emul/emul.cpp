@@ -195,6 +195,21 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     for (int i = 0; i < 27; i++) if (hist[i]) fprintf(stderr, "strategy %d (%dx%d cells): %d blocks\n", i, kCoveredX[i], kCoveredY[i], hist[i]);
     fprintf(stderr, "lists: %u medium, %u large, %u small\n", bcount[0], bcount[1], bcount[2]);
   }
+  // JXLEMUL_SPARSE (with JXLEMUL_FLAT_PASS): the flights' sparse coefficient lists — arenas sized like decoder.hip's sparse_group_entries, or by
+  // JXLEMUL_SPARSE_CAP entries per group (a tiny value exercises the overflow flag)
+  const bool sparse = getenv("JXLEMUL_FLAT_PASS") && getenv("JXLEMUL_SPARSE") && plan.num_passes == 1 && !((const DevFrame *)tables.data())->subsampled;
+  std::vector<uint32_t> sp_ent, sp_grp, sp_cnt;
+  if (sparse) {
+    const DevFrame &F0 = *(const DevFrame *)tables.data();
+    const DevSection *secs = (const DevSection *)(tables.data() + F0.sec_off);
+    sp_grp.assign((size_t)plan.num_groups + 1, 0);
+    for (int g = 0; g < plan.num_groups; g++) {
+      const uint32_t bytes = F0.nsec == 1 ? secs[0].size : secs[2 + F0.num_lf_groups + g].size;
+      sp_grp[(size_t)g + 1] = sp_grp[(size_t)g] + (getenv("JXLEMUL_SPARSE_CAP") ? (uint32_t)atoi(getenv("JXLEMUL_SPARSE_CAP")) : sparse_group_entries(bytes));
+    }
+    sp_ent.assign((size_t)sp_grp.back() + 1, 0); sp_cnt.assign(ncell, 0);
+    B.coef_sp = sp_ent.data(); B.coef_cnt = sp_cnt.data(); B.sp_group = sp_grp.data();
+  }
   if (getenv("JXLEMUL_FLAT_PASS")) {       // k_pass_prep + k_pass_flat: group descriptor lists, then the flat lane-per-group state machine, one lane at a time
     const DevFrame &F0 = *(const DevFrame *)tables.data();
     if (!flat_frame_ok(F0)) { g_err = "frame not eligible for the flat PassGroup path"; return -3; }
@@ -203,9 +218,22 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     for (int pass = 0; pass < F0.num_passes && !err; pass++)
       for (int g = 0; g < plan.num_groups; g++) {
         flat_stage(B, *L2, pass, 0, 1);                 // per lane here: the nonzero-count columns start from zero for every group
-        uint32_t e = pass_group_flat(B, *L2, pass, g, (g * 5 + 1) % 64); if (e) err |= e;
+        uint32_t e = sparse ? pass_group_flat<true>(B, *L2, pass, g, (g * 5 + 1) % 64) : pass_group_flat<false>(B, *L2, pass, g, (g * 5 + 1) % 64); if (e) err |= e;
       }
     delete L2;
+    if (sparse && getenv("JXLEMUL_STATS")) {
+      const DevSection *secs = (const DevSection *)(tables.data() + F0.sec_off);
+      double worst = 0; uint64_t tot_e = 0, tot_b = 0;
+      for (int g = 0; g < plan.num_groups; g++) {
+        uint32_t used = 0;
+        const int gx = g % F0.xgroups, gy = g / F0.xgroups;
+        for (int y = 0; y < 32 && gy * 32 + y < F0.yb; y++) for (int x = 0; x < 32 && gx * 32 + x < F0.xb; x++) { const size_t o = (size_t)(gy * 32 + y) * F0.xb + gx * 32 + x; if (B.first[o]) used += sp_cnt[o]; }
+        const uint32_t bytes = F0.nsec == 1 ? secs[0].size : secs[2 + F0.num_lf_groups + g].size;
+        tot_e += used; tot_b += bytes;
+        if (bytes && (double)used / bytes > worst) worst = (double)used / bytes;
+      }
+      fprintf(stderr, "sparse: %llu entries for %llu section bytes (%.3f per byte), worst group %.3f per byte\n", (unsigned long long)tot_e, (unsigned long long)tot_b, tot_b ? (double)tot_e / tot_b : 0.0, worst);
+    }
   } else
   for (int g = 0; g < plan.num_groups; g++) pass_group_body(B, *PS, g, 0, 1, NoSync());
   delete PS;
@@ -220,7 +248,10 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   }
   std::vector<float> S(3 * 4096), T(4096);
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
-    if (getenv("JXLEMUL_FLAT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
+    if (sparse) {
+      recon_block_body<true, false, true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
+      recon_block_body<false, true, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
+    } else if (getenv("JXLEMUL_FLAT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
       recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
       recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
     } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());

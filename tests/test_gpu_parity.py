@@ -450,6 +450,38 @@ def test_flat_passgroup_kernel_on_small_flights():
         assert r.returncode == 0 and "alternatives ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
 
 
+def test_sparse_coefficient_lists_in_flights():
+    """Flights hand the PassGroup stage's coefficients to the reconstruction as per-varblock sparse lists (DevBuffers::coef_sp, 4 bytes per nonzero
+    coefficient) instead of dense 3 x 65 536 x int32 planes per group: same pixels as the single decodes (which use the dense planes), bit for bit — mixed
+    varblock sizes, ragged groups, RGBA, three EPF iterations, a 4K frame; with JXLAMD_SPARSE=0 the flight takes the dense planes (same pixels again); an
+    arena that is too small (JXLAMD_SPARSE_CAP: test hook) is reported by the kernel and the flight decoded again densely, not overrun."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, ctypes as C, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from conftest import load_case
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        names = ["v264x520_e7", "asset_first_jxl", "va300x520_e7", "v267x131_e7", "v256_e3_gab0_epf3", "v300x300_e7_d3", "v64_hard_e7", "asset_wide_gamut", "vb520x4400_e7"]
+        datas = [load_case(n)[0] if n != "vb520x4400_e7" else open(%r + "/tests/golden/vb520x4400_e7.jxl", "rb").read() for n in names]
+        datas.append(open(%r + "/bench_data/syn4k_q90_seed0.jxl", "rb").read())
+        singles = [dec.decode_one_shot(d)[0] for d in datas]
+        f = J.api.lib().jxlamd_debug_sparse
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 2)]
+        for rep in range(2):
+            outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+            dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            torch.cuda.synchronize()
+            for n, s, o in zip(names + ["4k"], singles, outs):
+                assert np.array_equal(o.cpu().numpy().reshape(s.shape), s), n
+        st = (C.c_uint32 * 2)(); f(dec._h, C.byref(st))
+        print("sparse state", int(st[0]), int(st[1]))
+    """) % (ROOT, ROOT + "/tests", ROOT, ROOT)
+    for env, want in (({}, "sparse state 1 0"), ({"JXLAMD_SPARSE": "0"}, "sparse state 0 0"), ({"JXLAMD_SPARSE_CAP": "300"}, "sparse state 0 2")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JXLAMD_FLAT_MIN_GROUPS="1", **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and want in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
+
+
 def test_flight_of_host_buffers_of_mixed_sizes(dec):
     """A flight whose frames arrive as HOST buffers (one staging upload for all of them) and change from call to call (slots see frames of
     different sizes): same pixels as the single decodes, and as the same flight with device-resident inputs (gather launch)."""

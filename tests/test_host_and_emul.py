@@ -131,6 +131,21 @@ def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
     assert np.array_equal(base, alt)
 
 
+@pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3", "v264x520_e7", "vb520x4400_e7", "asset_first_jxl", "va300x520_e7", "v64_hard_e7", "asset_wide_gamut"])
+def test_sparse_coefficient_lists_give_identical_pixels(emul, monkeypatch, name):
+    """Flights hand the coefficients over as per-varblock sparse lists (DevBuffers::coef_sp: one 32-bit entry per nonzero coefficient, written by
+    the flat PassGroup state machine, scattered into the reconstruction's tile) instead of dense 3 x 65 536 planes per group: same pixels, bit for
+    bit, through the all-channels front end and the one-channel-at-a-time one; an arena that is too small is reported, not overrun."""
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    base = emul(data)
+    monkeypatch.setenv("JXLEMUL_FLAT_PASS", "1")
+    monkeypatch.setenv("JXLEMUL_SPARSE", "1")
+    assert np.array_equal(base, emul(data))
+    monkeypatch.setenv("JXLEMUL_SPARSE_CAP", "40")
+    with pytest.raises(ValueError, match="device flags"):
+        emul(data)
+
+
 @pytest.mark.parametrize("name", SQUEEZE_VARDCT_CASES + ["asset_alpha_jxl", "va2300x700_e7_d3"])       # the last one: ModularLfGroup stream between LF coefficients and HF metadata
 def test_squeezed_alpha_of_vardct_frames_on_cpu_harness(emul, name):
     """Extra channels coded with the squeeze transform (libjxl's lossy alpha; the reference's alpha_jxl.jxl asset): inverse squeeze steps after the
