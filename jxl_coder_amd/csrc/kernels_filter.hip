@@ -252,11 +252,11 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
 // one instantiation per stage combination: the register footprint of the longest pipeline (Gaborish + two EPF iterations) must not be
 // charged to the common one (Gaborish + one iteration)
 template <bool kGab, int kEpf, bool kFast>
-__global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave) {
+__global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave, int fast_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (!frame_uses_sweep(F) || frame_failed(B)) return;
-  if ((F.gab != 0) != kGab || F.epf_iters != kEpf || sweep_fast_frame(B, F) != kFast) return;           // another instantiation's frame
+  if ((F.gab != 0) != kGab || F.epf_iters != kEpf || (fast_on && sweep_fast_frame(B, F)) != kFast) return;           // another instantiation's frame
   const int lane = (int)(threadIdx.x & 63), seg = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)), strip = (int)blockIdx.x;
   filter_sweep<kGab, kEpf, kFast>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
@@ -270,19 +270,21 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
     const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
     const dim3 g((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes);
     // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use; bits 6..11: the same for its fast-writer frames (kSweepFastShift)
-    const int combos = (stage_mask >> 8) & 63, fast = (stage_mask >> (8 + kSweepFastShift)) & 63;
-    if (combos & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, false>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, true>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, true>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, true>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, true>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, true>), g, dim3(256), 0, s, Bs, stat, rows);
-    if (fast & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, true>), g, dim3(256), 0, s, Bs, stat, rows);
+    int combos = (stage_mask >> 8) & 63, fast = (stage_mask >> (8 + kSweepFastShift)) & 63;
+    static const int fast_on = !(getenv("JXLAMD_SWEEP_FAST") && atoi(getenv("JXLAMD_SWEEP_FAST")) == 0);      // A/B switch for measurements
+    if (!fast_on) { combos |= fast; fast = 0; }
+    if (combos & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (combos & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (combos & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (combos & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (combos & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (combos & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, false>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 1) hipLaunchKernelGGL((k_filter_sweep<false, 0, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 2) hipLaunchKernelGGL((k_filter_sweep<false, 1, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 4) hipLaunchKernelGGL((k_filter_sweep<false, 2, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    if (fast & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
     if (!(stage_mask & (2 | 32))) return;                       // 32: a composed frame — stage by stage whatever its filters
   }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);
