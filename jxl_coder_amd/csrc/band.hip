@@ -32,16 +32,31 @@ int jxlamd_decoder::band_begin(const uint8_t *jxl, size_t size, uint32_t flags, 
   const auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now();
   // The bands of one frame parse the SAME file (header, 16 642 TOC entries and the global tables of a 32768 x 32768 frame: 14 - 17 ms each): the
-  // first band of a process to see a file parses it, the others copy the plan (one entry, keyed by the caller's buffer and a sample of its bytes)
+  // first band of a process to see a file parses it, the others copy the plan.  One entry, keyed by the caller's buffer, its size, a sample of all its
+  // bytes and a FULL hash of the byte ranges a plan is made from — everything up to the end of LfGlobal (container boxes, headers, TOC) and the
+  // HfGlobal section; the group sections are not part of a plan (the kernels read them from the buffer of the decode at hand).  Only codestreams
+  // that alias the caller's buffer are cached: a plan that owns its codestream (assembled from jxlp boxes) points into its own copy.
   {
-    static std::mutex mu; static const uint8_t *k_data = nullptr; static size_t k_size = 0; static uint64_t k_sig = 0; static std::shared_ptr<FramePlan> cached;
+    static std::mutex mu; static const uint8_t *k_data = nullptr; static size_t k_size = 0; static uint64_t k_sig = 0, k_head_sig = 0; static size_t k_head_end = 0, k_hf0 = 0, k_hf1 = 0;
+    static std::shared_ptr<FramePlan> cached;
+    const auto fnv = [&](uint64_t h, size_t a, size_t b) { for (size_t i = a; i < b && i < size; i++) h = (h ^ jxl[i]) * 1099511628211ull; return h; };
     uint64_t sig = 1469598103934665603ull;
     for (size_t i = 0; i < size; i += (size <= 8192 ? 1 : (i < 4096 || i + 8192 >= size ? 1 : size / 4096))) sig = (sig ^ jxl[i]) * 1099511628211ull;
     std::lock_guard<std::mutex> lk(mu);
-    if (cached && k_data == jxl && k_size == size && k_sig == sig) S.plan = *cached;
+    if (cached && k_data == jxl && k_size == size && k_sig == sig && fnv(fnv(1469598103934665603ull, 0, k_head_end), k_hf0, k_hf1) == k_head_sig) S.plan = *cached;
     else {
       S.plan = FramePlan(); (void)plan_parse(jxl, size, &S.plan);
-      if (S.plan.error.empty() && !S.plan.tables.empty()) { cached = std::make_shared<FramePlan>(S.plan); k_data = jxl; k_size = size; k_sig = sig; }
+      cached.reset();
+      if (S.plan.error.empty() && !S.plan.tables.empty() && S.plan.cs_owned.empty() && S.plan.cs >= jxl && S.plan.cs + S.plan.cs_size <= jxl + size) {
+        const DevFrame *F = (const DevFrame *)S.plan.tables.data();
+        const DevSection *secs = (const DevSection *)(S.plan.tables.data() + F->sec_off);
+        const size_t cs_off = (size_t)(S.plan.cs - jxl);
+        k_head_end = cs_off + (size_t)secs[0].off + secs[0].size;
+        const int hf = F->nsec > 1 ? 1 + F->num_lf_groups : 0;
+        k_hf0 = cs_off + (size_t)secs[hf].off; k_hf1 = k_hf0 + secs[hf].size;
+        k_head_sig = fnv(fnv(1469598103934665603ull, 0, k_head_end), k_hf0, k_hf1);
+        cached = std::make_shared<FramePlan>(S.plan); k_data = jxl; k_size = size; k_sig = sig;
+      }
     }
   }
   int rc = prepare(S, jxl, size, nullptr, flags & ~JXLAMD_IN_DEVICE, out_ptr, out_cap, info, /*parsed=*/true, true, rows);

@@ -692,8 +692,9 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   //              of coefficient sets (106 MB per 4K frame) and, inside, sub-batches of plane_sets frames that share the
   //              f32 pixel planes (200 MB per frame).  Everything is stream-ordered, so a set is reused only after its
   //              previous user has been reconstructed (and the reconstruction leaves the coefficient planes all-zero).
-  static const int plane_sets = getenv("JXLAMD_PLANE_SETS") ? std::max(1, atoi(getenv("JXLAMD_PLANE_SETS"))) : 16;
-  static const int hf_sets = std::max(plane_sets, (getenv("JXLAMD_HF_SETS") ? atoi(getenv("JXLAMD_HF_SETS")) : 128) / plane_sets * plane_sets);
+  static const int plane_sets_env = getenv("JXLAMD_PLANE_SETS") ? std::max(1, atoi(getenv("JXLAMD_PLANE_SETS"))) : 0;
+  static const size_t plane_budget = (size_t)(getenv("JXLAMD_PLANE_BUDGET_MB") ? std::max(64, atoi(getenv("JXLAMD_PLANE_BUDGET_MB"))) : 3200) << 20;
+  static const int hf_sets_env = getenv("JXLAMD_HF_SETS") ? atoi(getenv("JXLAMD_HF_SETS")) : 128;
   const int nb = (int)batched.size();
   size_t max_npx = 0, max_coef = 0;
   int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 0;
@@ -714,6 +715,14 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     else all_post = false;
   }
   if (all_post && (stage_mask & 64)) stage_mask |= 128;       // every frame of the flight: the plain instantiation of the last stage is not launched
+  // Pixel planes of a sub-batch: the column sweep reads the reconstruction's planes and writes pixels — only frames with three EPF iterations (per-stage
+  // kernels, ping-pong) need the second plane set.  As many frames per sub-batch as the budget holds (JXLAMD_PLANE_BUDGET_MB, 3.2 GB: 32 4K frames of
+  // three planes).  Measured (round 5, quick bench, one box): sub-batches of 16 / 32 / 64 frames 13 020 - 13 050 / 12 940 / 12 590 - 13 150 MP/s — the
+  // sub-batch size is not what the rate depends on, although every launch of a busy stream takes 1.5 - 4 ms whatever it computes (k_recon_large_b:
+  // 0.07 ms alone, 4 ms in the mix).
+  const int planes_per_set = (stage_mask & 2) ? 6 : 3;
+  const int plane_sets = plane_sets_env ? plane_sets_env : (int)std::max<size_t>(1, std::min<size_t>(128, plane_budget / ((size_t)planes_per_set * std::max<size_t>(max_npx, 1) * 4)));
+  const int hf_sets = std::max(plane_sets, hf_sets_env / plane_sets * plane_sets);
   // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
   // contexts sharing it overlap one's LF stage with the other's HF phase
   const int used_sets = std::min(hf_sets, nb);
@@ -749,7 +758,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   {
     std::lock_guard<std::mutex> lk(pools->mu);
     const void *p0 = pools->plane_pool.p, *c0 = pools->coef_pool.p, *s0 = pools->sp_pool.p;
-    HIPCHECK(pools->plane_pool.ensure((size_t)plane_sets * 6 * max_npx * 4));
+    HIPCHECK(pools->plane_pool.ensure((size_t)std::min(plane_sets, nb) * planes_per_set * max_npx * 4));
     HIPCHECK(pools->coef_pool.ensure(coef_need));
     HIPCHECK(pools->sp_pool.ensure(sp_total * 4));
     if (pools->plane_pool.p != p0 || pools->coef_pool.p != c0 || pools->sp_pool.p != s0) pools->generation++;
@@ -796,9 +805,9 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   bool any_ec = false;
   for (int k = 0; k < nb; k++) {
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
-    float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * 6 * max_npx;
+    float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * planes_per_set * max_npx;
     int32_t *cset = (int32_t *)coef_pool.p + (size_t)(k % used_sets) * 3 * max_coef;
-    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = set + (size_t)(3 + c) * max_npx; S.B.coef[c] = sparse ? nullptr : cset + (size_t)c * max_coef; }
+    for (int c = 0; c < 3; c++) { S.B.plane_a[c] = set + (size_t)c * max_npx; S.B.plane_b[c] = planes_per_set == 6 ? set + (size_t)(3 + c) * max_npx : nullptr; S.B.coef[c] = sparse ? nullptr : cset + (size_t)c * max_coef; }
     S.B.coef_sp = sparse ? (uint32_t *)pools->sp_pool.p + sp_frame_off[(size_t)k] : nullptr;      // (sp_group: below, once the flight's table block is laid out)
     hb.push_back(S.B); ha.push_back(S.A);
     if (k % hf_sets == 0) { if (k) close_subflight(); pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
@@ -903,7 +912,16 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // one miss is enough evidence that this context's frames vary: it keeps the largest pool from here on (a repeated flight costs more than a
   // fourth LF stream per CU gains; measured on 256 distinct frames: wanted pools 12 .. 25 KB, 8 % of the flights repeated with a creeping floor)
   if (need_dense && !need_pool) return kRetryDense;
-  if (need_pool) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  // A miss: the flight runs again with the largest pool, and what its streams then report (every one of them, this time) becomes the floor of this
+  // process's later launches — the content's own maximum (12 - 26 KB on the bench's distinct frames), not the largest pool for good: an LF wave keeps
+  // its LDS for ~100 ms and three of them at 53 KB leave a CU's other 3 KB to nobody (round 5: their launches wait 150 - 230 ms for a slot).
+  if (need_pool) { lf_pool_bytes = kModPoolBytes; pool_missed = true; return kRetryPool; }
+  if (pool_missed) {
+    pool_missed = false;
+    const int want = lf_pool_clamp(pool_want);
+    lf_pool_floor = std::max(lf_pool_floor, want);
+    for (int cur = g_lf_pool_floor.load(); cur < want && !g_lf_pool_floor.compare_exchange_weak(cur, want);) {}
+  }
   if (!sparse) pools->coef_pool_clean = first_rc == JXLAMD_OK;
   lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(pool_want));
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one

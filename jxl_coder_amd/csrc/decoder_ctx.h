@@ -158,6 +158,7 @@ struct jxlamd_decoder {
   // three such flights stays dense
   bool sparse_enabled = !(getenv("JXLAMD_SPARSE") && atoi(getenv("JXLAMD_SPARSE")) == 0);
   uint32_t sparse_misses = 0; bool dense_flight = false, last_flight_sparse = false;
+  bool pool_missed = false;              // the flight in progress is the repeat of one that missed the pool
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)
   bool lf_general = false;               // the LF kernel build with the general lock-step loops (set for good the first time a frame of this context needs one)
   int lf_pool_bytes = kModPoolBytes;      // LDS table pool of the next LF launch: what the streams of the previous decode of this context asked for (first decode: the largest)

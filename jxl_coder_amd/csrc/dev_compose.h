@@ -286,6 +286,14 @@ JXL_DEV void blend_canvas_pixel(const DevBuffers &B, const uint8_t *stat, int ou
         case 4: { float m = fa; if (F.bl_clamp_a) m = m < 0.0f ? 0.0f : m > 1.0f ? 1.0f : m; out[3] = bg[3] * m; } break;
         default: out[3] = fa; break;
       }
+      // libjxl blends the extra channels first and the colour afterwards, and its four-channel PerformAlphaBlending writes the blended alpha
+      // 1 - (1 - fa)(1 - ba) into the colour's alpha channel whatever that channel's own mode asked for (established on the reference binary:
+      // tests/golden/an_split_modes_lossless)
+      if (F.bl_mode_c == 2) {
+        float wc = fa;
+        if (F.bl_clamp_c) wc = wc < 0.0f ? 0.0f : wc > 1.0f ? 1.0f : wc;
+        out[3] = 1.0f - (1.0f - wc) * (1.0f - bg[3]);
+      }
     }
   }
   if (B.canvas_save[0]) { for (int c = 0; c < 3; c++) B.canvas_save[c][ci] = out[c]; if (B.canvas_save[3]) B.canvas_save[3][ci] = out[3]; }

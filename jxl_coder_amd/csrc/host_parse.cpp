@@ -162,6 +162,19 @@ static int parse_patches(FramePlan *plan, Priv *pv, hx_br *sb, Blob &blob) {
   hx_ec_free(&ec);
   if (err) { plan->error = err; return -1; }
   if (!ok || sb->err) { plan->error = "patch dictionary: ANS final state"; return -1; }
+  // libjxl applies the placements in file order; the device blends them concurrently (k_patch_blend), which only kAdd survives (atomic adds commute).
+  // A kReplace / kMul placement that overlaps any other one would depend on the order: not produced by libjxl's encoder — refused, not raced
+  {
+    std::vector<size_t> ordered;
+    for (size_t i = 0; i < out.size(); i++) if (out[i].mode != 2) ordered.push_back(i);
+    if (ordered.size() > 4096) { plan->error = "unsupported: patch dictionary with more than 4096 replace / multiply placements"; return -1; }
+    for (size_t a : ordered)
+      for (size_t b = 0; b < out.size(); b++) {
+        if (b == a) continue;
+        const DevPatch &A = out[a], &Bp = out[b];
+        if (A.x < Bp.x + Bp.w && Bp.x < A.x + A.w && A.y < Bp.y + Bp.h && Bp.y < A.y + A.h) { plan->error = "unsupported: overlapping patch placements with replace / multiply blending"; return -1; }
+      }
+  }
   F.num_patches = (int32_t)out.size();
   F.patch_off = blob.append(out.data(), out.size() * sizeof(DevPatch));
   int mw = 1, mh = 1;
@@ -578,7 +591,7 @@ int parse_anim_info(const uint8_t *data, size_t size, std::vector<AnimFrame> *fr
       frames->push_back(a);
     }
     if (f.is_last) break;
-    if (n > 4096) { *error = "too many frames"; return -1; }
+    if (n > (1 << 20)) { *error = "too many frames"; return -1; }      // (a walk over headers and TOCs: the reference has no limit; this one only bounds a corrupt file's loop)
     hx_br_init(&br, cs, csn);
     br.pos = end_byte * 8;
   }
@@ -631,7 +644,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     if (read_toc(plan->cs, csn, f, r.toc_bit, nullptr, &r.end_byte, &plan->error)) return -1;
     recs.push_back(r);
     if (f.is_last) break;
-    if (recs.size() > 4096) { plan->error = "too many frames"; return -1; }
+    if (recs.size() > (1u << 20)) { plan->error = "too many frames"; return -1; }
     hx_br_init(&br, plan->cs, csn);
     br.pos = r.end_byte * 8;
   }
@@ -708,7 +721,8 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
       if (occ >= 0) {
         FrameRec &o = recs[(size_t)occ];
         if (o.f.frame_type != 0 && o.f.frame_type != 3) { plan->error = "unsupported: blending over a reference-only frame"; return -1; }
-        if (o.f.save_before_ct && (m.pub.xyb_encoded || !full_frame(o.f))) { plan->error = "unsupported: blending over a frame saved before the colour transform"; return -1; }
+        // (libjxl keeps such a frame BEFORE blending: one that is itself laid over a canvas would hand on its blended canvas here — refused)
+        if (o.f.save_before_ct && (m.pub.xyb_encoded || !full_frame(o.f) || uses_canvas(o.f))) { plan->error = "unsupported: blending over a frame saved before the colour transform"; return -1; }
         o.needed = true; o.canvas_needed = true; o.blend = true;
       }
     }

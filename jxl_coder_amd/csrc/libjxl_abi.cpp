@@ -102,6 +102,8 @@ int JxlDecoderProcessInput(D *d) {
       d->cur = std::min(d->skip, d->emit.size()); d->skip = 0; d->fstage = 0;
     }
     for (;;) {
+      // JxlDecoderSkipFrames called after a frame's events (libjxl: skips from the current position): applied between frames
+      if (d->fstage == 0 && d->skip) { d->cur = std::min(d->cur + d->skip, d->emit.size()); d->skip = 0; }
       if (d->cur >= d->emit.size()) { d->stage = 5; return JXLC_DEC_SUCCESS; }
       if (d->fstage == 0) { d->fstage = 1; d->waived = false; if (d->events & JXLC_DEC_FRAME) return JXLC_DEC_FRAME; }
       if (d->fstage == 1) {

@@ -139,7 +139,7 @@ def fnv1a64(b: bytes) -> int:
 
 class RefAnimFrame(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("x0", C.c_int32), ("y0", C.c_int32),
-                ("blend_mode", C.c_int32), ("source", C.c_int32), ("save_as_reference", C.c_int32), ("duration", C.c_uint32)]
+                ("blend_mode", C.c_int32), ("source", C.c_int32), ("save_as_reference", C.c_int32), ("duration", C.c_uint32), ("alpha_blend_mode", C.c_int32)]
 
 
 def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1), loops=0, premultiplied=False):
@@ -152,6 +152,7 @@ def encode_anim(frames, W, H, lossless=True, distance=1.0, effort=3, tps=(100, 1
         arr[i].rgba = px.ctypes.data; arr[i].h, arr[i].w = px.shape[:2]
         arr[i].x0, arr[i].y0 = f.get("x0", 0), f.get("y0", 0)
         arr[i].blend_mode, arr[i].source, arr[i].save_as_reference, arr[i].duration = f.get("blend", 0), f.get("source", 0), f.get("save", 0), f.get("duration", 1)
+        arr[i].alpha_blend_mode = f.get("alpha_blend", -1)      # the alpha channel's own blend mode (-1: as the colour)
     out = C.c_void_p(); n = C.c_size_t()
     lib().ref_set_premultiplied(int(premultiplied))
     rc = lib().ref_encode_anim(arr, len(frames), W, H, int(lossless), C.c_float(distance), effort, tps[0], tps[1], loops, C.byref(out), C.byref(n))

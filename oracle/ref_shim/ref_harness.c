@@ -337,6 +337,7 @@ done:
 typedef struct {
   const uint8_t *rgba; uint32_t w, h; int32_t x0, y0;
   int32_t blend_mode, source, save_as_reference; uint32_t duration;
+  int32_t alpha_blend_mode;      /* < 0: the alpha channel blends as libjxl's encoder defaults it (like the colour); else its own BlendingInfo mode (JxlEncoderSetExtraChannelBlendInfo) */
 } RefAnimFrame;
 
 int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_t H, int lossless, float distance, int effort,
@@ -347,7 +348,7 @@ int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_
   SYM(h_jxl, JxlColorEncodingSetToSRGB); SYM(h_jxl, JxlEncoderSetColorEncoding); SYM(h_jxl, JxlEncoderFrameSettingsCreate);
   SYM(h_jxl, JxlEncoderSetFrameDistance); SYM(h_jxl, JxlEncoderFrameSettingsSetOption); SYM(h_jxl, JxlEncoderSetFrameLossless);
   SYM(h_jxl, JxlEncoderAddImageFrame); SYM(h_jxl, JxlEncoderCloseInput); SYM(h_jxl, JxlEncoderProcessOutput);
-  SYM(h_jxl, JxlEncoderInitFrameHeader); SYM(h_jxl, JxlEncoderSetFrameHeader);
+  SYM(h_jxl, JxlEncoderInitFrameHeader); SYM(h_jxl, JxlEncoderSetFrameHeader); SYM(h_jxl, JxlEncoderSetExtraChannelBlendInfo);
   SYM(h_thr, JxlThreadParallelRunner); SYM(h_thr, JxlThreadParallelRunnerCreate); SYM(h_thr, JxlThreadParallelRunnerDestroy);
   SYM(h_thr, JxlThreadParallelRunnerDefaultNumWorkerThreads);
   int rc = -2;
@@ -387,6 +388,11 @@ int ref_encode_anim(const RefAnimFrame *frames, int nframes, uint32_t W, uint32_
     fh.layer_info.blend_info.alpha = 0; fh.layer_info.blend_info.clamp = JXL_FALSE;
     fh.layer_info.save_as_reference = (uint32_t)fr->save_as_reference;
     if (JXL_ENC_SUCCESS != p_JxlEncoderSetFrameHeader(fs, &fh)) { rc = -9; goto done; }
+    if (fr->alpha_blend_mode >= 0) {
+      JxlBlendInfo abi = fh.layer_info.blend_info;
+      abi.blendmode = (JxlBlendMode)fr->alpha_blend_mode;
+      if (JXL_ENC_SUCCESS != p_JxlEncoderSetExtraChannelBlendInfo(fs, 0, &abi)) { rc = -12; goto done; }
+    }
     if (JXL_ENC_SUCCESS != p_JxlEncoderAddImageFrame(fs, &pf, fr->rgba, (size_t)fr->w * fr->h * 4)) { rc = -10; goto done; }
   }
   p_JxlEncoderCloseInput(enc);

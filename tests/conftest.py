@@ -110,7 +110,7 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
 JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j420_prog_333x277", "jgrey_160x120", "j420s_400x300"]
 # Animations with layers (cropped frames blended over reference slots: kBlend, kAdd, kMulAdd, kMul on colour and alpha, zero-duration layers, two slots):
 # every coalesced frame against what the reference's JxlAnimatedDecoder::getFrame returns.  Lossless bit-exact, lossy within the VarDCT tolerance.
-ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless", "an_blend_premul_lossless", "ly_modes_lossless"]      # (premultiplied alpha; a layered still)
+ANIM_LOSSLESS_CASES = ["an_blend_lossless", "an_modes_lossless", "an_blend_premul_lossless", "ly_modes_lossless", "an_split_modes_lossless"]      # (premultiplied alpha; a layered still)
 ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_premul_d1_e7", "an_blend_d12_e7", "an_modes_d15_e7", "ly_blend_d1_e7"]      # the last two: upsampled layers (the reference's quality <= 12)
 # VarDCT colour + lossy (squeezed, quantised) alpha: colour within the VarDCT tolerance, alpha exact.  asset_animated: the reference's animated_jxl.jxl,
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas

@@ -216,10 +216,17 @@ def anim_scene(kind):
         return W, H, [dict(rgba=soft, duration=0, save=2), dict(rgba=dim, x0=12, y0=8, blend=1, source=2, duration=3, save=2),
                       dict(rgba=spr, x0=64, y0=40, blend=3, source=2, duration=0, save=1), dict(rgba=mul, x0=30, y0=60, blend=4, source=1, duration=4, save=1),
                       dict(rgba=spr, x0=100, y0=10, blend=2, source=2, duration=2, save=0), dict(rgba=spr, x0=0, y0=0, blend=0, source=1, duration=6)]
+    if kind == "split_modes":      # colour and alpha channel with DIFFERENT blend modes: colour kBlend over alpha kReplace / kAdd / kMul, colour kAdd over alpha kBlend
+        soft = rgba(synth.photo_like(W, H, seed=3), 180)
+        return W, H, [dict(rgba=soft, duration=2, save=1), dict(rgba=spr, x0=20, y0=30, blend=2, alpha_blend=0, source=1, duration=3, save=1),
+                      dict(rgba=spr, x0=70, y0=50, blend=2, alpha_blend=1, source=1, duration=3, save=1),
+                      dict(rgba=spr[:, ::-1].copy(), x0=90, y0=10, blend=2, alpha_blend=4, source=1, duration=3, save=1),
+                      dict(rgba=spr, x0=8, y0=70, blend=1, alpha_blend=2, source=1, duration=4)]
     raise ValueError(kind)
 
 
 ANIM_CASES = {
+    "an_split_modes_lossless": ("split_modes", dict(lossless=True, effort=3)),
     # name: (scene, encode kwargs)
     "an_blend_lossless": ("blend", dict(lossless=True, effort=3)),
     "an_blend_d1_e7": ("blend", dict(lossless=False, distance=1.0, effort=7)),
