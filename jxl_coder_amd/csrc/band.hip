@@ -168,7 +168,8 @@ int jxlamd_decoder::band_reconstruct() {
   if (q.ng >= ((bandtab.flags & JXLAMD_BAND_SHARED_GPU) ? flat_min_groups : band_flat_min_groups) && frame_flat_ok(plan)) { launch_pass_prep(bandtab.dB, bandtab.pg_map, q.ng, stream); launch_pass_flat(bandtab.dB, bandtab.wmap, bandtab.nwg, /*sparse=*/false, stream); }
   else launch_pass_groups_batch(bandtab.dB, bandtab.pg_map, q.ng, stream);
   HIPCHECK(hipEventRecord(ev[2], stream));
-  launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream);
+  HIPCHECK(huge_scratch.ensure((size_t)kHugeSlots * 2 * 65536 * 4));
+  launch_rest_batch(bandtab.dB, (const uint8_t *)stat.p, 1, plan.xb * (q.scy1 - q.scy0), plan.width, q.py1 - q.py0, 0, /*expect_large=*/true, 1, stream, false, (float *)huge_scratch.p);
   HIPCHECK(hipEventRecord(ev[3], stream));
   HIPCHECK(h_flags.ensure(256));
   HIPCHECK(hipMemcpyAsync(h_flags.p, S.B.err, 4, hipMemcpyDeviceToHost, stream));

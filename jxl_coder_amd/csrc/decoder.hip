@@ -71,6 +71,8 @@ static constexpr int kRetryPool = 0x7e7f;
 static constexpr int kRetryMoved = 0x7e80;
 // ... or a frame's sparse coefficient lists did not hold its coefficients (kErrNeedDense): decode the flight again with the dense planes
 static constexpr int kRetryDense = 0x7e81;
+// ... or a frame holds varblocks of the DCT128 / DCT256 families and the flight did not launch their kernel: decode it again with it (the context keeps launching it)
+static constexpr int kRetryHuge = 0x7e82;
 int dev_err_class(uint32_t derr) { return (derr & 0xFFFFu & ~(kErrBitstream | kErrAnsFinal)) ? JXLAMD_ERR_UNSUPPORTED : JXLAMD_ERR_INVALID; }
 
 // host twin of mod_group_scratch_ints (dev_modframe.h)
@@ -208,6 +210,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     HIPCHECK(S.big_list[0].ensure((ncell / 8 + 16) * 4));
     HIPCHECK(S.big_list[1].ensure((ncell / 32 + 16) * 4));
     HIPCHECK(S.big_list[2].ensure((ncell + 16) * 4));
+    HIPCHECK(S.big_list[3].ensure((ncell / 256 + 16) * 4));
     if (plan.has_ec) {                                   // extra channels: a Modular image next to the VarDCT one
       HIPCHECK(S.mod_pool.ensure(plan.mod_pool_ints * 4 + 256));
       HIPCHECK(S.mod_scratch.ensure(mod_scratch_total_ints(*Fh, plan.num_groups, plan.num_lf_groups) * 4 + 256));      // + 1: the GlobalModular stream's slot
@@ -338,7 +341,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     const DevPatch *P = (const DevPatch *)(plan.tables.data() + Fh->patch_off);
     for (int i = 0; i < Fh->num_patches; i++) if (!B.ref[P[i].ref][0]) { set_error("patch dictionary: reference frame missing"); return JXLAMD_ERR_INVALID; }
   }
-  B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
+  B.big_list[0] = (uint32_t *)S.big_list[0].p; B.big_list[1] = (uint32_t *)S.big_list[1].p; B.big_list[2] = (uint32_t *)S.big_list[2].p; B.big_list[3] = (uint32_t *)S.big_list[3].p; B.big_count = (uint32_t *)((uint8_t *)S.misc.p + 64);
   S.A.lf_end_bits = (uint64_t *)((uint8_t *)S.misc.p + 4096);
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   // frames of a batched flight (in_flight): one k_clear_b launch clears these for all of them
@@ -398,7 +401,8 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;
   if (F->compose) stage_mask = (stage_mask & 15) | 32;           // stage by stage into the planes; patches, reference copy and writer follow (launch_compose_tail)
   if (S.post_active && S.post_fused) stage_mask |= 64 | 128;     // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>); 128: no other frame in this launch
-  launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream);
+  if (parts & 1) HIPCHECK(huge_scratch.ensure((size_t)kHugeSlots * 2 * 65536 * 4));      // (a single decode always launches the DCT128 / DCT256 kernel: alone it costs microseconds)
+  launch_rest_batch((const DevBuffers *)S.dB.p, (const uint8_t *)stat.p, 1, plan.xb * plan.yb, plan.width, plan.height, stage_mask, /*expect_large=*/true, parts, stream, false, (float *)huge_scratch.p);
   return JXLAMD_OK;
 }
 
@@ -610,10 +614,11 @@ int jxlamd_decoder::decode_batch(int n, const uint8_t *const *jxl, const size_t 
     if (rc0 == kRetryPool && !pool_retried) { pool_retried = true; pool_retries++; continue; }                 // with the largest table pool
     if (rc0 == kRetryGeneral && !general_retried) { general_retried = true; lf_general = true; general_retries++; continue; }   // some frame needs a general lock-step loop: this context runs the general LF build from now on
     if (rc0 == kRetryDense && !dense_flight) { dense_flight = true; sparse_misses++; continue; }               // with the dense coefficient planes
+    if (rc0 == kRetryHuge && !huge_blocks_seen) { huge_blocks_seen = true; continue; }                         // with k_recon_huge_b in the launch list
     break;
   }
   dense_flight = false;
-  if (rc0 == kRetryPool || rc0 == kRetryMoved || rc0 == kRetryGeneral || rc0 == kRetryDense) { set_error("LF table pool / shared HF pools / coefficient lists: the flight was restarted too often"); return JXLAMD_ERR_DEVICE; }
+  if (rc0 == kRetryPool || rc0 == kRetryMoved || rc0 == kRetryGeneral || rc0 == kRetryDense || rc0 == kRetryHuge) { set_error("LF table pool / shared HF pools / coefficient lists: the flight was restarted too often"); return JXLAMD_ERR_DEVICE; }
   return rc0;
 }
 
@@ -851,6 +856,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   if (!gdesc.empty()) launch_gather_streams((const GatherDesc *)(bt + o_gd), (int)gdesc.size(), gather_max, stream);
   const DevBuffers *dB = (const DevBuffers *)(bt + o_b);
   const DevAux *dA = (const DevAux *)(bt + o_a);
+  if (huge_blocks_seen) HIPCHECK(huge_scratch.ensure((size_t)kHugeSlots * 2 * 65536 * 4));
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
@@ -878,14 +884,15 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets)
-      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse);
+      launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse,
+                        huge_blocks_seen ? (float *)huge_scratch.p : nullptr);
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
   int first_rc = JXLAMD_OK;
   large_blocks_seen = false;
   uint32_t pool_want = 0;
-  bool need_pool = false, need_dense = false;
+  bool need_pool = false, need_dense = false, need_huge = false;
   // flags / counters of all frames in one device-to-host copy and one synchronisation
   launch_gather_flags(dB, nb, (uint32_t *)(bt + o_fl), stream);
   HIPCHECK(h_flags.ensure((size_t)nb * kFlagWords * 4));
@@ -902,6 +909,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
+    if (head[19] > 0 && (!huge_blocks_seen || sparse)) need_huge = true;      // big_count[3]: DCT128 / DCT256 families, and their kernel was not in this flight's launch list
     pool_want = std::max(pool_want, head[1]);
     if (sparse && (head[0] & kErrNeedDense) && !(head[0] & 0xFFFFu & ~kErrNeedDense)) { need_dense = true; continue; }      // (judged again in the dense flight)
     if ((head[0] & kErrNeedPool) && !(head[0] & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) need_pool = true;
@@ -912,6 +920,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // one miss is enough evidence that this context's frames vary: it keeps the largest pool from here on (a repeated flight costs more than a
   // fourth LF stream per CU gains; measured on 256 distinct frames: wanted pools 12 .. 25 KB, 8 % of the flights repeated with a creeping floor)
   if (need_dense && !need_pool) return kRetryDense;
+  if (need_huge && !need_pool) { if (sparse) return kRetryDense; return kRetryHuge; }
   // A miss: the flight runs again with the largest pool, and what its streams then report (every one of them, this time) becomes the floor of this
   // process's later launches — the content's own maximum (12 - 26 KB on the bench's distinct frames), not the largest pool for good: an LF wave keeps
   // its LDS for ~100 ms and three of them at 53 KB leave a CU's other 3 KB to nobody (round 5: their launches wait 150 - 230 ms for a slot).

@@ -94,7 +94,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?
   PinnedMem h_tables, h_cs, h_B;
   DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
-  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef_cnt, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[3], lz_win, up_planes;
+  DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef_cnt, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[4], lz_win, up_planes;
   FramePlan plan;
   DevBuffers B;
   DevAux A;
@@ -131,6 +131,8 @@ struct jxlamd_decoder {
   std::string error;
   DevMem stat, batch_tab, mod_tab, post_lin_lut, post_gam_lut, resample_tmp, icc_lut;
   ColorMatrixDev post_dev; double post_key[13] = {0}; bool post_key_valid = false, post_plan_runs = false;   // cached colour-matrix parameters
+  bool huge_blocks_seen = false;         // DCT128 / DCT256-family varblocks met by this context: its flights launch their kernel from then on (k_recon_huge_b)
+  DevMem huge_scratch;                   // ... and its S / T tiles (kHugeSlots workgroups x 2 x 65 536 floats)
   bool large_blocks_seen = false, large_hint = true;   // 64x64-class varblocks in the previous flight? (sizes the launch of their kernel)
   std::shared_ptr<HfPools> pools = std::make_shared<HfPools>();     // HF-phase memory of this context's flights (own, or shared: jxlamd_decoder_share_pools)
   PinnedMem h_batch, h_mod_tab, h_flight_tables, h_flight_cs, h_flags;

@@ -122,7 +122,7 @@ JXL_DEV void recon_block_body(const DevBuffers &B, const uint8_t *stat, float *S
   const int st = B.strategy[o];
   const int cx = kCoveredX[st], cy = kCoveredY[st];
   const int n = cx * cy * 64;
-  if (n > 4096) { if (tid == 0 && nmax >= 4096) *B.err |= kErrUnsupportedBlock | kErrStageRecon; return; }   // DCT128+/256
+  // (the DCT128 / DCT256 families — up to 65 536 coefficients — have their own launch, with S and T in HBM: k_recon_huge_b)
   if (n < nmin || n > nmax) return;                 // another size class' launch handles it
   if (F.subsampled) { recon_block_subsampled(B, stat, S, T, bx, by, st, tid, nthreads, sync); return; }
   float *dst[3] = {B.plane_a[0], B.plane_a[1], B.plane_a[2]};

@@ -31,8 +31,8 @@ struct DevBuffers {
   LocalTreeScratch *local;      // [max(num_lf_groups, num_groups)]: local MA trees / histograms parsed on the device
   int32_t *mod_pool;            // Modular-encoded frames: int32 channel planes (DevFrame::mod_plane_off)
   int32_t *mod_scratch;         // [num_groups][group channels x 65536]: per-group channel rectangles
-  uint32_t *big_list[3];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 coefficients (filled at placement)
-  uint32_t *big_count;          // [3] their counts
+  uint32_t *big_list[4];        // cell indices of the varblocks with 512..1024 / 2048..4096 / <= 256 / more than 4096 (DCT128, DCT256 families) coefficients (filled at placement)
+  uint32_t *big_count;          // [4] their counts
   uint64_t *mod_end_bit;        // [1]: where the GlobalModular stream of an extra-channel frame ended (single-section frames: LfGroup 0 starts there)
   uint64_t *pass_end_bits;      // [num_passes][num_groups]: where the AC stream of a group ended (extra-channel frames: its ModularGroup stream starts there)
   uint8_t *pass_nz;             // [num_groups][3072]: per-group nonzero-count maps of the lane-per-stream PassGroup kernel
@@ -157,7 +157,7 @@ __device__ __forceinline__ void place_flush_lists(const DevBuffers &B, int pend,
   const int lane = tid & 63;
   const bool have = lane < n;
   const int cls = (int)((uint32_t)pend >> 28);
-  for (int c = 0; c < 3; c++) {
+  for (int c = 0; c < 4; c++) {
     const uint64_t mask = __ballot(have && cls == c);
     if (!mask) continue;
     uint32_t base = 0;
@@ -248,14 +248,14 @@ JXL_DEV uint32_t lf_phase_place(const DevBuffers &B, DevModScratch &S, int g, ui
 #ifdef __HIPCC__
         // size-class lists (the reconstruction kernels walk them): entries collect in a lane shift register and reach the lists 64 at a
         // time with one atomic per class — an atomic with return per block was the serial loop's longest wait (1.2 us per block)
-        if (ncoef <= 4096) {
-          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
+        {
+          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : ncoef <= 4096 ? 1 : 3;
           pend = __builtin_amdgcn_update_dpp((int)(((uint32_t)cls << 28) | (uint32_t)o), pend, 0x138, 0xF, 0xF, false);   // lane l: the entry of l blocks ago
           if (++npend == 64) { place_flush_lists(B, pend, npend, tid); npend = 0; }
         }
 #else
-        if (tid == 0 && ncoef <= 4096) {         // size-class lists: the reconstruction kernels walk them
-          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : 1;
+        if (tid == 0) {         // size-class lists: the reconstruction kernels walk them
+          const int cls = ncoef <= 256 ? 2 : ncoef <= 1024 ? 0 : ncoef <= 4096 ? 1 : 3;
           const uint32_t slot = B.big_count[cls]++;
           B.big_list[cls][slot] = (uint32_t)o;
         }

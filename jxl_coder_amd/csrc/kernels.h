@@ -18,6 +18,10 @@ void launch_pass_prep(const DevBuffers *Bs, const int *map, int ngroups, hipStre
 void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, bool sparse, hipStream_t s);      // sparse: coefficients into DevBuffers::coef_sp (single-pass frames)
 void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int nblocks, hipStream_t s);
 void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, bool sparse, hipStream_t s);
+// varblocks of more than 4 096 coefficients (big_list[3]); scratch: kHugeSlots x 2 x 65 536 floats.  Dense coefficient planes only (a sparse entry's
+// 12-bit position does not reach them: such a frame ends its PassGroup stage with kErrNeedDense)
+constexpr int kHugeSlots = 32;
+void launch_recon_huge(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch, hipStream_t s);
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s);
 // stage_mask bit of a frame's column-sweep instantiation: 8 + (gab ? 3 : 0) + epf_iters, + kSweepFastShift when the frame takes the sweep's fast writer
 // (host twin of sweep_fast_frame, kernels_filter.hip: sRGB curve, RGBA8, identity orientation, frame = canvas, no alpha plane, no post stages in the writer)
@@ -29,8 +33,9 @@ inline int sweep_stage_bit(const DevFrame &F, int out_bits, bool writer_post) {
 }
 // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
 inline void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,
-                              int parts, hipStream_t s, bool sparse = false) {
+                              int parts, hipStream_t s, bool sparse = false, float *huge_scratch = nullptr) {
   if (parts & 1) launch_recon_batch(Bs, stat, nframes, max_cells, expect_large, sparse, s);
+  if ((parts & 1) && huge_scratch && !sparse) launch_recon_huge(Bs, stat, nframes, huge_scratch, s);
   if (parts & 2) launch_filters_batch(Bs, stat, nframes, max_w, max_h, stage_mask, s);
 }
 void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s);

@@ -504,6 +504,29 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, con
     else recon_block_body<false, true, kSparse>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
   }
 }
+// The DCT128 / DCT256 families (AcStrategy 21 .. 26: 8 192 .. 65 536 coefficients; libjxl's encoder never selects them, its decoder takes them): one
+// workgroup per varblock, one channel at a time through the generic front end and the two separable passes, with the S and T tiles in HBM — a
+// workgroup's own 512 KB slice of the context's scratch (L2-resident while it is worked on).  kHugeSlots workgroups walk the lists of ALL frames of the launch.
+__global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch) {
+  float *S = scratch + (size_t)blockIdx.x * 2 * 65536, *T = S + 65536;
+  const int tid = (int)threadIdx.x;
+  for (int f = 0; f < nframes; f++) {
+    const DevBuffers &B = Bs[f];
+    const DevFrame &F = frame_of(B);
+    if (F.is_modular || frame_failed(B)) continue;
+    const uint32_t count = B.big_count[3];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+      const int cell = (int)B.big_list[3][i];
+      const int bx = cell % F.xb, by = cell / F.xb;
+      if (by < F.band_cy0 || by >= F.band_cy1) continue;
+      __syncthreads();
+      recon_block_body<false, true>(B, stat, S, T, bx, by, 4097, 65536, tid, 256, SyncBlock());
+    }
+  }
+}
+void launch_recon_huge(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_recon_huge_b, dim3(kHugeSlots), dim3(256), 0, s, Bs, stat, nframes, scratch);
+}
 template <bool kSparse>
 static void launch_recon_batch_t(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers; in a flight (16 frames per launch) 256 workgroups

@@ -126,7 +126,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   std::vector<float> pl[6]; for (auto &v : pl) v.assign(npx, 0.f);
   std::vector<int32_t> scr((size_t)plan.num_lf_groups * kLfScratchInts, 0);
   std::vector<uint64_t> endbits((size_t)plan.num_lf_groups, 0);
-  std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16), bl2(ncell + 16); uint32_t bcount[3] = {0, 0, 0};
+  std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16), bl2(ncell + 16), bl3(ncell / 256 + 16); uint32_t bcount[4] = {0, 0, 0, 0};
   uint32_t errw[32] = {0}; uint32_t &err = errw[0];       // the frame's flag block (word 1: LF table pool the streams asked for)
   std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
   DevBuffers B; memset(&B, 0, sizeof(B));
@@ -150,7 +150,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   B.mod_pool = mpool.data(); B.mod_scratch = mscr.data();
   const uint32_t lzl = ((const DevFrame *)plan.tables.data())->lz_win_len, lzg = ((const DevFrame *)plan.tables.data())->lz_win_group;
   std::vector<uint32_t> lzw(plan.modular && lzl ? (size_t)lzl + (size_t)plan.num_groups * lzg : 1, 0); B.lz_win = plan.modular && lzl ? lzw.data() : nullptr;
-  B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_list[2] = bl2.data(); B.big_count = bcount;
+  B.big_list[0] = bl0.data(); B.big_list[1] = bl1.data(); B.big_list[2] = bl2.data(); B.big_list[3] = bl3.data(); B.big_count = bcount;
   DevAux A; A.lf_end_bits = endbits.data(); A.lf_times = nullptr;
   const std::vector<uint8_t> &stat = static_tables();
   if (plan.modular) {
@@ -246,15 +246,15 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     if (err) { g_err = flag_message(err, "extra channels"); return -2; }
     for (int o = 0; o < F.mod_nops; o++) { size_t n = (size_t)(F.mod_op_kind[o] == 0 ? F.mod_op_y[o] : F.mod_op_c[o]); for (size_t i = 0; i < n; i++) mod_op_element(B, F, o, i); }
   }
-  std::vector<float> S(3 * 4096), T(4096);
+  std::vector<float> S(3 * 65536), T(65536);       // (on the device the DCT128 / DCT256 families keep these tiles in HBM: k_recon_huge_b)
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) {
     if (sparse) {
       recon_block_body<true, false, true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
-      recon_block_body<false, true, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
+      recon_block_body<false, true, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 65536, 0, 1, NoSync());
     } else if (getenv("JXLEMUL_FLAT_PASS")) {       // also exercise the one-channel-at-a-time path the large-block kernel uses
       recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 1024, 0, 1, NoSync());
-      recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 4096, 0, 1, NoSync());
-    } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 4096, 0, 1, NoSync());
+      recon_block_body<false, true>(B, stat.data(), S.data(), T.data(), x, y, 1025, 65536, 0, 1, NoSync());
+    } else recon_block_body<true>(B, stat.data(), S.data(), T.data(), x, y, 0, 65536, 0, 1, NoSync());
   }
   if (err) { g_err = flag_message(err, "recon"); return -2; }
   const DevFrame &F = *(const DevFrame *)tables.data();

@@ -263,6 +263,59 @@ def add_anim_cases(meta, only):
         print(name, len(data), out.shape, durations, loops)
 
 
+# ---- hand-written codestreams (tools/jxl_write.py): what libjxl's encoder never emits and its decoder takes — the DCT128 / DCT256 varblock families
+# (AcStrategy 21 .. 26).  One 256 x 256 group (or a 128 x 128 image), seeded coefficients / LF samples / chroma-from-luma factors / quant field / sharpness;
+# expected pixels = the reference's decode.
+def writer_case(name):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_write as W
+    seed = {"w_dct256": 1, "w_dct128": 2, "w_dct_mix_a": 3, "w_dct_mix_b": 4, "w_dct128_small": 5, "w_dct256_nofilter": 6}[name]
+    rng = np.random.default_rng(seed)
+    size = 128 if name == "w_dct128_small" else 256
+    nb = size // 8
+    yy, xx = np.mgrid[0:nb, 0:nb]
+    lf = np.stack([np.round(30 * np.sin(xx / 5.0 + seed)).astype(np.int64), 5000 + 60 * xx + 45 * yy + np.round(200 * np.sin(yy / 3.0 + seed)).astype(np.int64),
+                   np.round(40 * np.cos(yy / 4.0 + seed)).astype(np.int64)])
+
+    def coefs(st, n, amp):
+        total, covered = W.natural_order_len(st), W.COVERED_X[st] * W.COVERED_Y[st]
+        ks = rng.choice(np.arange(covered, total), n, replace=False)
+        return {int(k): int(v) for k, v in zip(ks, rng.integers(-amp, amp + 1, n)) if v}
+
+    def blk(bx, by, st, qf=None):
+        return dict(bx=bx, by=by, strategy=st, qf=int(rng.integers(3, 12)) if qf is None else qf, coef={1: coefs(st, 40, 30), 0: coefs(st, 10, 6), 2: coefs(st, 12, 10)})
+    layouts = {
+        "w_dct256": [(0, 0, 24)], "w_dct256_nofilter": [(0, 0, 24)], "w_dct128_small": [(0, 0, 21)],
+        "w_dct128": [(0, 0, 21), (16, 0, 21), (0, 16, 21), (16, 16, 21)],
+        # 25: 128 wide x 256 tall; 22: 64 wide x 128 tall; 23: 128 wide x 64 tall
+        "w_dct_mix_a": [(0, 0, 25), (16, 0, 22), (24, 0, 22), (16, 16, 23), (16, 24, 23)],
+        # 26: 256 wide x 128 tall; then a DCT128x128 and four DCT64x64
+        "w_dct_mix_b": [(0, 0, 26), (0, 16, 21), (16, 16, 18), (24, 16, 18), (16, 24, 18), (24, 24, 18)],
+    }
+    blocks = [blk(*b) for b in layouts[name]]
+    nt = (nb + 7) // 8
+    kw = dict(xfromy=rng.integers(-20, 20, (nt, nt)), bfromy=rng.integers(-10, 30, (nt, nt)), sharpness=rng.integers(0, 8, (nb, nb)))
+    if name == "w_dct256_nofilter":
+        kw.update(gab=False, epf_iters=0)
+    return W.write_vardct(size, size, blocks, lf, **kw)
+
+
+WRITER_CASES = ["w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
+
+
+def add_writer_cases(meta, only):
+    for name in WRITER_CASES:
+        if only and name not in only:
+            continue
+        data = writer_case(name)
+        out, info, _ = jxl_ref.decode(data, allow16=True)
+        open(os.path.join(HERE, name + ".jxl"), "wb").write(data)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), rgba=out)
+        info = {k: (v if isinstance(v, list) else float(v) if isinstance(v, float) else int(v)) for k, v in info.items()}
+        meta[name] = dict(bytes=len(data), shape=list(out.shape), dtype=str(out.dtype), info=info, source="tools/jxl_write.py (hand-written codestream), decoded by the reference")
+        print(name, len(data), out.shape, "mean", out[..., :3].mean(), "std", out[..., 1].std())
+
+
 def make_image(w, h, sk):
     """the synthetic source image of a case (sk: the case's synth kwargs; popped keys are put back by the caller)"""
     sk = dict(sk)
@@ -425,6 +478,7 @@ def main():
     add_rowsum_cases(meta, only)
     add_jpeg_cases(meta, only)
     add_anim_cases(meta, only)
+    add_writer_cases(meta, only)
     if only and "u8200x8200_squeeze_84_channels" in only:
         add_unsupported_exemplar(only)          # (9 s and 1.5 GB of encoder memory: on request only)
     if not only or "big_assets" in only:
