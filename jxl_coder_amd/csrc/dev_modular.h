@@ -17,7 +17,6 @@ constexpr int kWpMaxW = 256;
 constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
 
 struct DevWP { int32_t p1, p2, p3a, p3b, p3c, p3d, p3e, w[4]; };
-constexpr int kModMaxGroupCh = 40;                // channels of one ModularGroup stream (RGBA with the default squeeze: 28)
 constexpr int kModMaxRefs = 12;                    // previous channels an MA tree may look at (properties 16 ..: four per channel; libjxl's encoder offers up to 11)
 struct DevChanOut { int32_t *d; int32_t w, h; int16_t hs, vs; };      // hs / vs: the channel's shifts (-1: a meta channel) — what decides, with the size, which earlier channels the "previous channel" MA properties read
 

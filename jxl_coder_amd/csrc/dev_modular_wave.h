@@ -650,7 +650,8 @@ __device__ __forceinline__ bool wave_restage_compact(const DevECView &g, int num
   for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_clu, j) & 63);
   const int nc = __builtin_popcountll(used);
   const int alias_bytes = nc * (8 << la), ctx_bytes = (num_ctx + 7) & ~7;
-  if (!g.use_prefix) mod_pool_want(S, alias_bytes + ctx_bytes, lane);
+  // (no mod_pool_want here: these are the short HF-metadata channels — a few milliseconds of a stream that holds its LDS for ~100 ms; when their tables
+  // do not fit the pool the loops read them through L2 instead of making every LF wave of the process 10 KB larger for good)
   if (g.use_prefix || alias_bytes + ctx_bytes > S.pool_bytes) return false;
   __syncthreads();
   DevAlias *dst = (DevAlias *)S.pool;

@@ -30,9 +30,11 @@ struct DevEC {
   int32_t lz77, lz_min_symbol, lz_min_length; uint32_t lz_len_cfg;
 };
 
-constexpr int kModMaxCh = 80;        // stream channels of a Modular image (a full default squeeze of RGBA: 4 + ~14 residual levels x channels, capped here)
-constexpr int kModMaxPlanes = 176;   // + one output plane per inverse squeeze step
-constexpr int kModMaxOps = 112;
+constexpr int kModMaxCh = 128;       // stream channels of a Modular image (the default squeeze of RGBA: 4 x (1 + 2 per halving); 84 at 8200 x 8200 — what the reference's encoder writes
+                                     // for a large lossy RGBA image at its defaults, interop/JxlEncoding.cpp:145-160 — 108 at 65536 x 65536)
+constexpr int kModMaxPlanes = 272;   // + one output plane per inverse squeeze step
+constexpr int kModMaxOps = 144;
+constexpr int kModMaxGroupCh = 64;   // channels of one ModularGroup stream (RGBA with the default squeeze: 28 at 4K, 44 beyond 8192 pixels)
 
 // ---- MA tree node (Annex H.4), 32 bytes
 struct DevTreeNode {

@@ -372,7 +372,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     trs.push_back(t);
   }
   if (sb->err) { plan->error = "truncated GlobalModular header"; return -1; }
-  if ((int)L.size() > kModMaxCh) { plan->error = "unsupported: more than 80 modular channels"; return -1; }
+  if ((int)L.size() > kModMaxCh) { plan->error = "unsupported: more than 128 modular channels"; return -1; }
   F.mod_nch = (int)L.size(); F.mod_nb_meta = nb_meta;
   // plane offsets (in samples) accumulate in 64 bits: the inverse squeeze steps add one output plane each (~3x the image), and nothing above
   // bounds a frame's channels by 2^32 samples in total.  The device indexes the pool with 32-bit offsets: beyond that the frame is refused
@@ -404,7 +404,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
     F.lz_win_len = (uint32_t)std::min<uint64_t>(total + 64, 1u << 20);
     F.lz_win_group = (uint32_t)std::min<uint64_t>((uint64_t)(F.mod_nch - first_group) * (uint64_t)f.group_dim * (uint64_t)f.group_dim + 64, 1u << 20);
   }
-  if (F.mod_nch - first_group > 40) { plan->error = "unsupported: more than 40 group channels"; return -1; }      // dev_modular.h: kModMaxGroupCh
+  if (F.mod_nch - first_group > kModMaxGroupCh) { plan->error = "unsupported: more than 64 group channels"; return -1; }      // dev_modular.h: kModMaxGroupCh
   // inverse program (last transform first)
   F.mod_nops = 0;
   for (int i = ntr - 1; i >= 0; i--) {

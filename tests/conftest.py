@@ -152,6 +152,41 @@ U16_CASES = ["v160x120_16bit_e7", "va530x270_16bit_e7", "vf16a300x200_e7", "vf32
 U16_PQ_CASES = ["v160x120_16bit_pq2100_epf3"]
 # further target transfer functions of the decoder proper (HLG with its inverse OOTF, DCI gamma 2.6 with P3 primaries): device code only
 # (the plain-C oracle restates sRGB / linear / PQ / 709 / gamma), same 16-bit bounds as U16_CASES
-U16_TF_CASES = ["v160x120_16bit_hlg2100", "v160x120_16bit_dci_p3"]
+U16_TF_CASES = ["v160x120_16bit_hlg2100", "v160x120_16bit_dci_p3",
+                # photographs at distance 1 whose dark pixels the reference clamps to 0 under gamma 2.6 / PQ (differences of several hundred CODES on
+                # 4 - 8 samples of 180 000, none in linear light)
+                "v300x200_16bit_dci_p3_s10", "v300x200_16bit_dci_p3_s12", "v300x200_16bit_pq2100_s10"]
+
+
+def u16_to_linear(code16, transfer):
+    """16-bit code values -> linear light in [0, 1] by the inverse of the image's transfer function (JxlTransferFunction: 16 PQ, 17 DCI gamma 2.6, 18 HLG, 1 BT.709)"""
+    v = code16.astype(np.float64) / 65535
+    if transfer == 16:
+        m1, m2, c1, c2, c3 = 2610 / 16384, 2523 / 4096 * 128, 3424 / 4096, 2413 / 4096 * 32, 2392 / 4096 * 32
+        p = np.power(v, 1 / m2)
+        return np.power(np.maximum(p - c1, 0) / (c2 - c3 * p), 1 / m1)
+    if transfer == 17:
+        return np.power(v, 2.6)
+    if transfer == 18:
+        a, b, c = 0.17883277, 0.28466892, 0.55991073
+        return np.where(v <= 0.5, v * v / 3, (np.exp((v - c) / a) + b) / 12)
+    if transfer == 1:
+        return np.where(v < 0.081, v / 4.5, np.power((v + 0.099) / 1.099, 1 / 0.45))
+    raise ValueError(transfer)
+
+
+def assert_u16_non_srgb(out, exp, transfer, what=""):
+    """The bound for 16-bit output under a non-sRGB transfer function (PQ, HLG, DCI gamma, 709): there is no hard bound in CODE VALUES — the curves are
+    steep near black, where the inverse opsin matrix cancels terms of order 1, and the reference itself clamps there — so the code values are bounded
+    statistically (mean <= 16, 99th percentile <= 256, fewer than 0.2 % of the samples beyond 256) and the hard bound is stated in LINEAR light: <= 6e-3 of
+    full scale everywhere, <= 1e-3 on the samples that differ by more than 256 codes."""
+    d = np.abs(out[..., :3].astype(int) - exp[..., :3].astype(int))
+    la, lb = u16_to_linear(out[..., :3], transfer), u16_to_linear(exp[..., :3], transfer)
+    dl = np.abs(la - lb)
+    big = d > 256
+    assert d.mean() <= 16.0 and np.percentile(d, 99) <= 256 and big.mean() < 2e-3, (what, d.mean(), np.percentile(d, 99), int(big.sum()))
+    assert dl.max() <= 6e-3, (what, dl.max())
+    if big.any():
+        assert dl[big].max() <= 1e-3, (what, dl[big].max())
 U16_MAX_ABS = 256
 U16_MEAN_ABS = 16.0

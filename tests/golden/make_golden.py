@@ -37,6 +37,10 @@ CASES = {
     "v160x120_16bit_pq2100_epf3": (160, 120, dict(seed=21, bits=16), dict(effort=7, epf=3, primaries=9, transfer=16, intensity_target=10000.0)),
     "v160x120_16bit_hlg2100": (160, 120, dict(seed=22, bits=16), dict(effort=7, primaries=9, transfer=18, intensity_target=1000.0)),     # HLG: inverse OOTF + OETF in the decoder
     "v160x120_16bit_dci_p3": (160, 120, dict(seed=23, bits=16), dict(effort=7, primaries=11, transfer=17)),                        # DCI gamma 2.6, P3 primaries
+    # photographs whose dark pixels clamp to 0 under gamma 2.6 / PQ — code-value differences of hundreds on a handful of samples, nothing in linear light
+    "v300x200_16bit_dci_p3_s10": (300, 200, dict(seed=10, bits=16), dict(effort=7, distance=1.0, primaries=11, transfer=17)),
+    "v300x200_16bit_dci_p3_s12": (300, 200, dict(seed=12, bits=16), dict(effort=7, distance=1.0, primaries=11, transfer=17)),
+    "v300x200_16bit_pq2100_s10": (300, 200, dict(seed=10, bits=16), dict(effort=7, distance=1.0, primaries=9, transfer=16, intensity_target=10000.0)),
     # RGBA through the reference's encoder call sequence: VarDCT colour + Modular-coded (lossless, no squeeze) alpha
     "va300x520_e7": (300, 520, dict(seed=5, alpha=True), dict(effort=7)),
     "va530x270_16bit_e7": (530, 270, dict(seed=8, bits=16, alpha=True), dict(effort=7)),
@@ -483,6 +487,15 @@ def main():
         add_unsupported_exemplar(only)          # (9 s and 1.5 GB of encoder memory: on request only)
     if not only or "big_assets" in only:
         add_big_assets(meta)
+    # The VarDCT goldens depend on the CPU that made them: the reference's SSE2-only libjxl normalises the EPF sums with the host's 12-bit rcpps, which
+    # differs between CPU vendors / generations (tests/test_oracle_golden.py::test_epf_offset_is_the_reference_builds_rcpps) — recorded with the vectors
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:  # noqa: BLE001
+        cpu = "unknown"
+    meta["_generated_on"] = dict(cpu_model=cpu, note="VarDCT expected pixels come from the reference's prebuilt SSE2-only libjxl 0.12 run on this CPU: its EPF normalisation uses "
+                                 "the host's rcpps (12-bit reciprocal estimate), so the vectors are reproducible on this host class only; where oracle/_ref travels the GPU "
+                                 "tests also compare against the reference run live")
     if only:
         json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
         return

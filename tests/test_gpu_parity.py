@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, U16_MAX_ABS, U16_MEAN_ABS,
+from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, assert_u16_non_srgb, U16_MAX_ABS, U16_MEAN_ABS,
                       LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, ANIM_LOSSLESS_CASES, ANIM_VARDCT_CASES, load_anim_case, load_case)
 
 pytestmark = pytest.mark.gpu
@@ -127,13 +127,21 @@ def test_errors_are_loud(dec):
         bad[i] ^= 0x5A
     with pytest.raises((J.InvalidJXLException, J.UnsupportedJXLFeature)):
         dec.decode_one_shot(bytes(bad))
-    art = open(os.path.join(ROOT, "tests", "golden", "u8200x8200_squeeze_84_channels.jxl"), "rb").read()      # a flat 8200 x 8200 RGBA image, lossless with squeeze: 84 stream channels, four more than the frame tables hold (tests/golden/make_golden.py: add_unsupported_exemplar) — a VALID file: unsupported, not corrupt
-    with pytest.raises(J.UnsupportedJXLFeature):                              # never silently routed to a CPU path
-        dec.decode_one_shot(art)
     with pytest.raises(J.UnsupportedJXLFeature):                              # float32 samples of mixed sign: refused, not guessed
         dec.decode_one_shot(open(os.path.join(ROOT, "tests", "golden", "u48x32_float32_mixed_sign.jxl"), "rb").read())
     out, _ = dec.decode_one_shot(data)                                        # the context survives failed decodes
     assert out.shape == (520, 264, 4)
+
+
+def test_rgba_with_squeeze_beyond_8192_pixels_84_stream_channels(dec):
+    """A lossless RGBA image with squeeze beyond 8192 x 8192: 20 squeeze steps on four channels = 84 stream channels, 44 of them in every group stream (rounds 1 - 4:
+    the frame tables held 80 / 40 and the file was the tests' "valid but unsupported" exemplar).  What the reference's encoder writes at its defaults for large RGBA
+    images (interop/JxlEncoding.cpp:145-160) and what DecodeJpegXlOneShot decodes (269 MB, below its INT32_MAX guard).  Bit-exact: the flat image the fixture was made of."""
+    data = open(os.path.join(ROOT, "tests", "golden", "u8200x8200_squeeze_84_channels.jxl"), "rb").read()
+    out, info = dec.decode_one_shot(data)
+    assert out.shape == (8200, 8200, 4) and out.dtype == np.uint8
+    flat = out.reshape(-1, 4)
+    assert (flat == np.array([37, 150, 190, 255], np.uint8)).all()           # = the reference's output (tests/golden/make_golden.py: add_unsupported_exemplar; fnv1a64 e5ce6f6eda8ba225)
 
 
 def test_jxlcoder_surface(dec):
@@ -202,10 +210,10 @@ def test_16bit_output(dec, name):
     d = np.abs(out.astype(int) - exp.astype(int))
     assert d.mean() <= U16_MEAN_ABS
     assert np.array_equal(out[..., 3], exp[..., 3])                     # opaque 65535 or the Modular-coded alpha, bit for bit
-    if name in U16_CASES + U16_TF_CASES:
+    if name in U16_CASES:
         assert d.max() <= U16_MAX_ABS
-    else:
-        assert (d > U16_MAX_ABS).mean() < 2e-3 and info["transfer_function"] == 16 and info["primaries"] == 9
+    else:         # PQ, HLG, DCI gamma: statistical bound in code values, hard bound in linear light (conftest.assert_u16_non_srgb)
+        assert_u16_non_srgb(out, exp, info["transfer_function"], name)
     out8, info8 = dec.decode_one_shot(data, allowed_floats=False)       # API < 26 branch: 8-bit output
     assert out8.dtype == np.uint8 and info8["out_bits"] == 8
 
@@ -626,6 +634,23 @@ def test_reference_demo_assets_match_the_reference(dec, golden_meta, name):
         assert [int(x) for x in out[..., 3].astype(np.int64).sum(axis=1)] == meta["alpha_row_sums"]
     if name == "asset_art":                                                   # Modular (integer) path: exact
         assert np.array_equal(rs, np.array(meta["row_sums"], np.int64)) and blk_err.max() < 1e-3
+
+
+def test_forced_epf_fixtures_against_the_reference_run_live(dec):
+    """The two effort-3 fixtures with EPF forced to 2 / 3 iterations carry loosened golden bounds (conftest.VARDCT_MEAN_ABS_CASE: 0.06 / 0.09): the
+    golden host's rcpps leaves the reference's SSE2 build 0.036 LSB per iteration darker than the exact quotient.  Where oracle/_ref travels
+    the comparison is made against the reference run on THIS box's CPU, at the ordinary bound."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("oracle/_ref did not travel to this box")
+    for name in ("v256_e3_gab0_epf1", "v256_e3_gab0_epf2", "v256_e3_gab0_epf3"):
+        data, _ = load_case(name)
+        out, _ = dec.decode_one_shot(data)
+        ref = jxl_ref.decode(data)[0]
+        d = np.abs(out.astype(int) - ref.astype(int))
+        print("[epf live] %s max %d mean %.4f" % (name, d.max(), d.mean()))
+        assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (name, d.max(), d.mean())
 
 
 def _pq_eotf(code16):
