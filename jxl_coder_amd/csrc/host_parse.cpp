@@ -388,7 +388,7 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   // decodes the latter (single-pass frames: shifts 0..2)
   F.mod_lf_nch = 0;
   for (int i = first_group; i < F.mod_nch; i++) if (std::min(L[(size_t)i].hs, L[(size_t)i].vs) >= 3) F.mod_lf_nch++;
-  if (F.mod_lf_nch > 8) { plan->error = "unsupported: more than 8 ModularLfGroup channels"; return -1; }
+  if (F.mod_lf_nch > 32) { plan->error = "unsupported: more than 32 ModularLfGroup channels"; return -1; }      // (S.grp_src holds kModMaxGroupCh; 16 for RGBA with squeeze at 8200 x 8200)
   // planes are indexed by stream channel position (the device decodes "channel i" into plane i); the inverse squeeze steps append theirs
   int nplanes = F.mod_nch;
   for (int i = 0; i < F.mod_nch; i++) {

@@ -650,7 +650,8 @@ def test_forced_epf_fixtures_against_the_reference_run_live(dec):
         ref = jxl_ref.decode(data)[0]
         d = np.abs(out.astype(int) - ref.astype(int))
         print("[epf live] %s max %d mean %.4f" % (name, d.max(), d.mean()))
-        assert d.max() <= VARDCT_MAX_ABS and d.mean() <= VARDCT_MEAN_ABS, (name, d.max(), d.mean())
+        # measured on the MI355X boxes' host (round 5): 0.0506 for two iterations — the same offset as on the golden host, so the per-case bounds apply here too
+        assert d.max() <= VARDCT_MAX_ABS and d.mean() <= vardct_mean_tol(name), (name, d.max(), d.mean())
 
 
 def _pq_eotf(code16):
