@@ -437,6 +437,7 @@ int jxlamd_decoder::launch_compose_tail(FrameSlot &S) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   if (F->subsampled) launch_chroma_upsample(S.B, plan.width, plan.height, stream);      // recompressed JPEG: chroma to full resolution (no loop filters in between)
   launch_patch_blend(S.B, F->num_patches, plan.patch_max_px, stream);
+  if (F->num_spline_segs > 0) launch_splines(S.B, plan.width, plan.height, stream);
   if (F->noise && F->upsampling == 1) launch_noise(S.B, plan.width, plan.height, stream);      // after the patches, before the colour transform (libjxl's stage order); an upsampled frame: after the upsampling
   if (F->blend) {
     if (F->alpha_up > 1 && F->mod_out[3] >= 0) launch_upsample_alpha(S.B, (const uint8_t *)stat.p, F->full_w, F->full_h, stream);      // an upsampled frame is blended at its full resolution

@@ -227,6 +227,43 @@ JXL_DEV void noise_add_pixel(const DevBuffers &B, const DevFrame &F, int x, int 
   *pb = mul_add_rn(F.base_b, rg, *pb);
 }
 
+// ---- Splines (K.4; libjxl's "Splines" stage, after the patches): pixel (x, y) of the frame receives, from every spline sample whose box reaches it, colour x
+// sigma / 4 x intensity x (erf((d / 2 + 1 / (2 sqrt 2)) / sigma) - erf((d / 2 - 1 / (2 sqrt 2)) / sigma))^2 at its distance d — in the order libjxl adds them (the
+// row's segment list).  erf as libjxl evaluates it: 1 - 1 / (1 + a1 |x| + a2 x^2 + a3 |x|^3 + a4 x^4)^4 (its FastErff; 5e-4 of a blob's peak at most from the exact one).
+JXL_DEV float spline_erf(float v) {
+  const float a = fabsf(v);
+  float d = a * 7.77394369e-02f + 2.05260015e-04f;
+  d = d * a + 2.32120216e-01f;
+  d = d * a + 2.77820801e-01f;
+  d = d * a + 1.0f;
+  const float d2 = d * d, inv = 1.0f / d2;
+  const float r = 1.0f - inv * inv;
+  return v <= 0.0f ? -r : r;
+}
+JXL_DEV void spline_pixel(const DevBuffers &B, const DevFrame &F, int x, int y) {
+  const DevSplineSeg *segs = (const DevSplineSeg *)(B.tables + F.spline_seg_off);
+  const uint32_t *rows = (const uint32_t *)(B.tables + F.spline_row_off), *idx = (const uint32_t *)(B.tables + F.spline_idx_off);
+  const uint32_t i0 = rows[y], i1 = rows[y + 1];
+  if (i0 == i1) return;
+  const bool a = compose_final_is_a(F);
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x;
+  float acc[3];
+  for (int c = 0; c < 3; c++) acc[c] = (a ? B.plane_a[c] : B.plane_b[c])[po];
+  bool any = false;
+  for (uint32_t i = i0; i < i1; i++) {
+    const DevSplineSeg sg = segs[idx[i]];
+    const long long xs = llroundf(sg.cx - sg.maxdist), xe = llroundf(sg.cx + sg.maxdist);
+    if ((long long)x < xs || (long long)x > xe) continue;
+    const float dx = (float)x - sg.cx, dy = (float)y - sg.cy;
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float f = spline_erf((dist * 0.5f + 0.353553391f) * sg.inv_sigma) - spline_erf((dist * 0.5f - 0.353553391f) * sg.inv_sigma);
+    const float li = sg.sigma_over_4_times_intensity * f * f;
+    for (int c = 0; c < 3; c++) acc[c] += sg.color[c] * li;
+    any = true;
+  }
+  if (any) for (int c = 0; c < 3; c++) (a ? B.plane_a[c] : B.plane_b[c])[po] = acc[c];
+}
+
 // ---- Blending (libjxl's "Blending" stage, after the colour transform): one pixel (x, y) of the CANVAS.  Background = the blend source's canvas (reference
 // slot bl_src; transparent black when the slot is empty); inside the frame's rectangle the frame's colour (in the image's colour encoding, not clamped) and
 // alpha are combined with it by the frame's BlendingInfo, outside the background shows.  The result is kept (canvas_save: a later frame's background)

@@ -48,7 +48,10 @@ struct DevTreeNode {
 
 struct DevSection { uint32_t off, size; };
 // One placement of a patch (ISO/IEC 18181-1 K.3): the w x h rectangle at (x0, y0) of reference slot `ref` is blended onto the frame at (x, y)
-struct DevPatch { int32_t ref, x0, y0, w, h, x, y, mode; };       // mode: 0 none, 1 replace, 2 add, 3 multiply (colour channels)   // byte range inside the codestream buffer
+struct DevPatch { int32_t ref, x0, y0, w, h, x, y, mode; };
+// One sample point of a spline (ISO/IEC 18181-1 K.4; libjxl's SplineSegment): a Gaussian blob of colour `color` (X, Y, B) around (cx, cy), drawn into the pixels
+// within `maxdist` of it.  The host resamples every spline at unit arc length and evaluates its colour / sigma DCTs there (host_parse.cpp: build_splines).
+struct DevSplineSeg { float cx, cy, color[3], inv_sigma, sigma_over_4_times_intensity, maxdist; };       // mode: 0 none, 1 replace, 2 add, 3 multiply (colour channels)   // byte range inside the codestream buffer
 
 // ---- per-frame parameters (host -> device, by value in the tables blob header)
 struct DevFrame {
@@ -134,6 +137,9 @@ struct DevFrame {
   // group's origin), high-pass filtered and added to X, Y, B with a strength read off an 8-point curve of the local intensity (dev_compose.h)
   int32_t noise; float noise_lut[8]; uint32_t noise_seed[2];
   int32_t num_patches; uint32_t patch_off;     // DevPatch[num_patches] (one per patch POSITION) in the frame blob
+  // Splines (flag kSplines): DevSplineSeg[num_spline_segs]; per pixel row y the segments that reach it are spline_idx[spline_row[y] .. spline_row[y + 1]) (u32 each),
+  // in the order libjxl draws them (by row, then by segment index); added to X, Y, B after the patches (dev_compose.h: spline_pixel)
+  int32_t num_spline_segs; uint32_t spline_seg_off, spline_row_off, spline_idx_off;
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter
   int32_t gab; float gab_w[3][2];

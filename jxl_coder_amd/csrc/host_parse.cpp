@@ -115,6 +115,162 @@ static void fill_info(const img_meta &m, ImageInfo *i) {
 
 // Patch dictionary (K.3.1), at the head of LfGlobal when FrameHeader.flags has kPatches: entropy-coded with 10 contexts.  Every placement
 // becomes one DevPatch; the device blends them after the loop filters (dev_compose.h).
+// Splines (K.4), in LfGlobal behind the patch dictionary when FrameHeader.flags has kSplines: quantised control points (double deltas from a starting point),
+// 32 DCT coefficients per colour channel and for the thickness (sigma), one quantisation adjustment for all splines; 6 contexts.  What libjxl's
+// Splines::Decode / QuantizedSpline::Dequantize / InitializeDrawCache do before a pixel is touched: the curve through the control points (centripetal
+// Catmull-Rom, 16 steps per span), resampled at unit arc length; colour and sigma of every sample from the continuous inverse DCTs; one segment per sample.
+struct QSpline { std::vector<std::pair<int64_t, int64_t>> cp; int32_t color[3][32]; int32_t sigma[32]; float sx, sy; };
+static int parse_splines(FramePlan *plan, hx_br *sb, uint64_t num_pixels, std::vector<QSpline> *out, int32_t *quant_adjust) {
+  hx_ec ec;
+  if (hx_ec_read_header(&ec, sb, 6)) { plan->error = "splines: bad entropy header"; return -1; }
+  hx_ec_begin(&ec, sb, 0);
+  const char *err = nullptr;
+  const uint64_t max_cp = std::min<uint64_t>(1u << 20, num_pixels / 2);
+  const uint64_t num = (uint64_t)hx_ec_read(&ec, sb, 2) + 1;
+  if (num > max_cp + 1) err = "splines: too many splines";
+  std::vector<QSpline> q;
+  if (!err) q.resize((size_t)num);
+  int64_t lx = 0, ly = 0;
+  for (size_t i = 0; i < q.size() && !err; i++) {
+    int64_t x = hx_ec_read(&ec, sb, 1), y = hx_ec_read(&ec, sb, 1);
+    if (i) { x = hx_unpack_signed((uint32_t)x) + lx; y = hx_unpack_signed((uint32_t)y) + ly; }
+    if (x >= (1 << 23) || x <= -(1 << 23) || y >= (1 << 23) || y <= -(1 << 23)) { err = "splines: starting point out of range"; break; }
+    q[i].sx = (float)x; q[i].sy = (float)y; lx = x; ly = y;
+  }
+  if (!err) *quant_adjust = hx_unpack_signed(hx_ec_read(&ec, sb, 0));
+  uint64_t total_cp = 0;
+  for (size_t i = 0; i < q.size() && !err; i++) {
+    const uint64_t n = hx_ec_read(&ec, sb, 3);
+    total_cp += n;
+    if (total_cp > max_cp) { err = "splines: too many control points"; break; }
+    q[i].cp.resize((size_t)n);
+    for (auto &p : q[i].cp) {
+      p.first = hx_unpack_signed(hx_ec_read(&ec, sb, 4)); p.second = hx_unpack_signed(hx_ec_read(&ec, sb, 4));
+      if (std::llabs(p.first) >= (1 << 30) || std::llabs(p.second) >= (1 << 30)) { err = "splines: control point delta out of range"; break; }
+    }
+    for (int c = 0; c < 3 && !err; c++) for (int k = 0; k < 32; k++) q[i].color[c][k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5));
+    for (int k = 0; k < 32 && !err; k++) q[i].sigma[k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5));
+    if (sb->err) { err = "truncated splines"; break; }
+  }
+  const int ok = hx_ec_final_ok(&ec);
+  hx_ec_free(&ec);
+  if (err) { plan->error = err; return -1; }
+  if (!ok || sb->err) { plan->error = "splines: ANS final state"; return -1; }
+  out->swap(q);
+  return 0;
+}
+struct SPoint { float x, y; };
+static float spline_idct(const float *dct, float t) {       // libjxl's ContinuousIDCT: a 32-point DCT-III evaluated at a real position, sqrt(2)-scaled (dct[0] carries 1 / sqrt(2))
+  float r = 0.0f;
+  for (int i = 0; i < 32; i++) r += dct[i] * cosf((3.14159265358979323846f / 32.0f) * (float)i * (t + 0.5f));
+  return 1.41421356237f * r;
+}
+static int build_splines(FramePlan *plan, Blob &blob, DevFrame &F, const std::vector<QSpline> &qs, int32_t quant_adjust, float y_to_x, float y_to_b, int width, int height) {
+  static const float kChannelWeight[4] = {0.0042f, 0.075f, 0.07f, 0.3333f};
+  const float inv_quant = quant_adjust >= 0 ? 1.0f / (1.0f + 0.125f * (float)quant_adjust) : 1.0f - 0.125f * (float)quant_adjust;
+  std::vector<DevSplineSeg> segs;
+  std::vector<std::pair<int32_t, uint32_t>> by_y;
+  for (const QSpline &q : qs) {
+    // control points: the starting point, then running sums of running sums of the coded deltas
+    std::vector<SPoint> cp;
+    cp.push_back({q.sx, q.sy});
+    int64_t cx = (int64_t)llroundf(q.sx), cy = (int64_t)llroundf(q.sy), dx = 0, dy = 0;
+    for (const auto &p : q.cp) {
+      dx += p.first; dy += p.second; cx += dx; cy += dy;
+      if (std::llabs(cx) >= (1ll << 30) || std::llabs(cy) >= (1ll << 30) || std::llabs(dx) >= (1ll << 30) || std::llabs(dy) >= (1ll << 30)) { plan->error = "splines: control point out of range"; return -1; }
+      cp.push_back({(float)cx, (float)cy});
+    }
+    float cdct[3][32], sdct[32];
+    for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) cdct[c][i] = (float)q.color[c][i] * (i == 0 ? 0.70710678118f : 1.0f) * kChannelWeight[c] * inv_quant;
+    for (int i = 0; i < 32; i++) { cdct[0][i] += y_to_x * cdct[1][i]; cdct[2][i] += y_to_b * cdct[1][i]; }
+    for (int i = 0; i < 32; i++) sdct[i] = (float)q.sigma[i] * (i == 0 ? 0.70710678118f : 1.0f) * kChannelWeight[3] * inv_quant;
+    // centripetal Catmull-Rom through the control points, 16 intermediate points per span
+    std::vector<SPoint> pts;
+    if (cp.size() == 1) pts.push_back(cp[0]);
+    else {
+      std::vector<SPoint> e;
+      e.push_back({cp[0].x + (cp[0].x - cp[1].x), cp[0].y + (cp[0].y - cp[1].y)});
+      e.insert(e.end(), cp.begin(), cp.end());
+      const size_t n = cp.size();
+      e.push_back({cp[n - 1].x + (cp[n - 1].x - cp[n - 2].x), cp[n - 1].y + (cp[n - 1].y - cp[n - 2].y)});
+      for (size_t st = 0; st + 3 < e.size(); st++) {
+        const SPoint *p = &e[st];
+        pts.push_back(p[1]);
+        float d[3], t[4]; t[0] = 0.0f;
+        for (int k = 0; k < 3; k++) { d[k] = sqrtf(hypotf(p[k + 1].x - p[k].x, p[k + 1].y - p[k].y)); t[k + 1] = t[k] + d[k]; }
+        for (int i = 1; i < 16; i++) {
+          const float tt = d[0] + ((float)i / 16.0f) * d[1];
+          SPoint a[3], b[2];
+          for (int k = 0; k < 3; k++) { const float w = (tt - t[k]) / d[k]; a[k] = {p[k].x + w * (p[k + 1].x - p[k].x), p[k].y + w * (p[k + 1].y - p[k].y)}; }
+          for (int k = 0; k < 2; k++) { const float w = (tt - t[k]) / (d[k] + d[k + 1]); b[k] = {a[k].x + w * (a[k + 1].x - a[k].x), a[k].y + w * (a[k + 1].y - a[k].y)}; }
+          const float w = (tt - t[1]) / d[1];
+          pts.push_back({b[0].x + w * (b[1].x - b[0].x), b[0].y + w * (b[1].y - b[0].y)});
+        }
+      }
+      pts.push_back(e[e.size() - 2]);
+    }
+    // samples at unit arc length along that polyline; the last one carries what is left of the last step as its weight
+    std::vector<std::pair<SPoint, float>> draw;
+    {
+      SPoint current = pts[0];
+      draw.push_back({current, 1.0f});
+      size_t next_id = 0;
+      bool done = false;
+      while (!done && next_id < pts.size()) {
+        SPoint previous = current;
+        float from_prev = 0.0f;
+        for (;;) {
+          if (next_id >= pts.size()) { draw.push_back({previous, from_prev}); done = true; break; }
+          const SPoint nx = pts[next_id];
+          const float to_next = sqrtf((nx.x - previous.x) * (nx.x - previous.x) + (nx.y - previous.y) * (nx.y - previous.y));
+          if (from_prev + to_next >= 1.0f) {
+            const float w = (1.0f - from_prev) / to_next;
+            current = {previous.x + w * (nx.x - previous.x), previous.y + w * (nx.y - previous.y)};
+            draw.push_back({current, 1.0f});
+            break;
+          }
+          from_prev += to_next; previous = nx; next_id++;
+        }
+        if (draw.size() > (1u << 22)) { plan->error = "unsupported: spline longer than 2^22 pixels"; return -1; }
+      }
+    }
+    const float arc = (float)((double)draw.size() - 2.0) + draw.back().second;
+    if (!(arc > 0.0f)) continue;                               // no effect
+    const float inv_arc = 1.0f / arc;
+    for (size_t k = 0; k < draw.size(); k++) {
+      const float prog = std::min(1.0f, (float)k * inv_arc);
+      float color[3];
+      for (int c = 0; c < 3; c++) color[c] = spline_idct(cdct[c], 31.0f * prog);
+      const float sigma = spline_idct(sdct, 31.0f * prog);
+      const float mult = draw[k].second;
+      if (!std::isfinite(sigma) || sigma == 0.0f || !std::isfinite(1.0f / sigma) || !std::isfinite(color[0]) || !std::isfinite(color[1]) || !std::isfinite(color[2])) continue;
+      float max_color = 0.01f;
+      for (int c = 0; c < 3; c++) max_color = std::max(max_color, fabsf(color[c] * mult));
+      // beyond this distance the blob is below 1e-5 of an intensity step
+      const float maxdist = sqrtf(-2.0f * sigma * sigma * (logf(0.1f) * 5.0f - logf(max_color)));
+      DevSplineSeg sg;
+      sg.cx = draw[k].first.x; sg.cy = draw[k].first.y;
+      for (int c = 0; c < 3; c++) sg.color[c] = color[c];
+      sg.inv_sigma = 1.0f / sigma; sg.sigma_over_4_times_intensity = 0.25f * sigma * mult; sg.maxdist = maxdist;
+      if (!std::isfinite(maxdist)) continue;
+      const long long y0 = llroundf(sg.cy - maxdist), y1 = llroundf(sg.cy + maxdist) + 1;
+      for (long long y = std::max<long long>(y0, 0); y < std::min<long long>(y1, height); y++) by_y.push_back({(int32_t)y, (uint32_t)segs.size()});
+      segs.push_back(sg);
+      if (by_y.size() > (1u << 25) || segs.size() > (1u << 22)) { plan->error = "unsupported: splines cover more than 2^25 row segments"; return -1; }
+    }
+  }
+  std::stable_sort(by_y.begin(), by_y.end(), [](const std::pair<int32_t, uint32_t> &a, const std::pair<int32_t, uint32_t> &b) { return a.first < b.first; });
+  std::vector<uint32_t> rows((size_t)height + 1, 0), idx(by_y.size());
+  for (size_t i = 0; i < by_y.size(); i++) { rows[(size_t)by_y[i].first + 1]++; idx[i] = by_y[i].second; }
+  for (int y = 0; y < height; y++) rows[(size_t)y + 1] += rows[(size_t)y];
+  F.num_spline_segs = (int32_t)segs.size();
+  F.spline_seg_off = blob.append(segs.data(), segs.size() * sizeof(DevSplineSeg));
+  F.spline_row_off = blob.append(rows.data(), rows.size() * 4);
+  F.spline_idx_off = blob.append(idx.data(), idx.size() * 4);
+  (void)width;
+  return 0;
+}
+
 static int parse_patches(FramePlan *plan, Priv *pv, hx_br *sb, Blob &blob) {
   DevFrame &F = pv->F; const frame_hdr &f = pv->f; const img_meta &m = pv->m;
   hx_ec ec;
@@ -816,7 +972,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   }
   if (!is_shown && (f.width < 1 || f.height < 1)) { plan->error = "empty frame"; return -1; }
   if (f.do_ycbcr && f.encoding == 1) { plan->error = "unsupported: YCbCr Modular frame"; return -1; }
-  if (f.flags & 16) { plan->error = "unsupported: splines"; return -1; }
+  if ((f.flags & 16) && (f.frame_type == 1 || !m.pub.xyb_encoded)) { plan->error = "unsupported: splines on an LF frame / an image that is not XYB"; return -1; }
   if (f.flags & 1) {
     if (f.encoding != 0 || !m.pub.xyb_encoded) { plan->error = "unsupported: noise on a frame that is not a VarDCT XYB frame"; return -1; }
     if (!is_shown) { plan->error = "unsupported: noise on a reference frame"; return -1; }
@@ -870,6 +1026,8 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // ---- LfGlobal (section 0)
   hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
   if ((f.flags & 2) && parse_patches(plan, pv, &sb, blob)) return -1;
+  std::vector<QSpline> qsplines; int32_t spline_quant_adjust = 0;
+  if ((f.flags & 16) && parse_splines(plan, &sb, (uint64_t)f.coded_width * (uint64_t)f.coded_height, &qsplines, &spline_quant_adjust)) return -1;
   if (f.flags & 1) for (int i = 0; i < 8; i++) F.noise_lut[i] = (float)hx_bits(&sb, 10) * (1.0f / 1024);      // NoiseParameters: eight points of the strength curve
   float lf_dequant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   if (!hx_bool(&sb)) for (int c = 0; c < 3; c++) lf_dequant[c] = hx_f16(&sb) * (1.0f / 128);
@@ -901,6 +1059,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     ytox_dc = (int)hx_bits(&sb, 8) - 128; ytob_dc = (int)hx_bits(&sb, 8) - 128;
   }
   }
+  if (!qsplines.empty() && build_splines(plan, blob, F, qsplines, spline_quant_adjust, base_x, base_b, f.coded_width, f.coded_height)) return -1;
   // GlobalModular: MA tree flag (+ tree); no channels on this path (no extra channels)
   hx_tree tree; memset(&tree, 0, sizeof(tree));
   const bool have_tree = hx_bool(&sb);
@@ -1027,7 +1186,7 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   // composition: a reference frame keeps its image in the f32 planes (copied into its slot), a frame with patches blends them there; the
   // writer then runs as a stage of its own.  A Modular-encoded frame of an XYB image (libjxl's patch frames) always takes this route
   F.noise = (f.flags & 1) ? 1 : 0; F.noise_seed[0] = (uint32_t)rec.visible_index; F.noise_seed[1] = (uint32_t)rec.nonvisible_index;
-  F.compose = (!is_shown || pv->blend || F.noise || F.num_patches > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
+  F.compose = (!is_shown || pv->blend || F.noise || F.num_patches > 0 || F.num_spline_segs > 0 || (f.encoding == 1 && m.pub.xyb_encoded) || f.upsampling != 1 || F.alpha_up > 1 || F.not_xyb) ? 1 : 0;
   plan->compose = F.compose != 0;
   memcpy(F.ref_w, pv->ref_w, sizeof(F.ref_w)); memcpy(F.ref_h, pv->ref_h, sizeof(F.ref_h));
   F.band_gr0 = 0; F.band_gr1 = F.ygroups; F.band_cy0 = 0; F.band_cy1 = F.yb; F.band_py0 = 0; F.band_py1 = F.height;

@@ -58,6 +58,7 @@ void launch_mod_write(const DevBuffers &B, int width, int height, int out_bits, 
 // composition stages (dev_compose.h): frames with a patch dictionary and the reference frames it draws on
 void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s);
 void launch_patch_blend(const DevBuffers &B, int num_patches, size_t max_px, hipStream_t s);
+void launch_splines(const DevBuffers &B, int w, int h, hipStream_t s);      // after the patches (dev_compose.h: spline_pixel)
 void launch_noise(const DevBuffers &B, int w, int h, hipStream_t s);
 void launch_chroma_upsample(const DevBuffers &B, int w, int h, hipStream_t s);
 void launch_blend_canvas(const DevBuffers &B, const uint8_t *stat, int canvas_w, int canvas_h, hipStream_t s);

@@ -20,6 +20,12 @@ __global__ void __launch_bounds__(256) k_patch_blend(DevBuffers B) {
   const int n = P.w * P.h;          // <= 2^31: both bounded by the reference frame's size
   for (int item = (int)(blockIdx.y * 256 + threadIdx.x); item < n; item += (int)(gridDim.y * 256)) patch_blend_sample(B, F, P, item);
 }
+__global__ void __launch_bounds__(256) k_splines(DevBuffers B) {
+  const DevFrame &F = frame_of(B);
+  const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+  if (x >= F.width || y >= F.height || frame_failed(B)) return;
+  spline_pixel(B, F, x, y);
+}
 __global__ void __launch_bounds__(256) k_save_ref(DevBuffers B, float *d0, float *d1, float *d2) {
   const DevFrame &F = frame_of(B);
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -104,6 +110,9 @@ void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int ful
 }
 
 void launch_mod_to_planes(const DevBuffers &B, int w, int h, hipStream_t s) { hipLaunchKernelGGL(k_mod_to_planes, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B); }
+void launch_splines(const DevBuffers &B, int w, int h, hipStream_t s) {
+  hipLaunchKernelGGL(k_splines, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, B);
+}
 void launch_patch_blend(const DevBuffers &B, int num_patches, size_t max_px, hipStream_t s) {
   if (num_patches <= 0) return;
   // placements beyond 2^22 are refused by the parser; large patches loop

@@ -464,6 +464,9 @@ typedef struct {
   int xb, yb;                       /* 8x8 cells */
   /* LfGlobal */
   float noise_lut[8];
+  /* splines (K.4), as coded: per spline a starting point, control-point double deltas, 3 x 32 colour and 32 sigma DCT coefficients */
+  int num_splines, spline_quant_adjust;
+  struct jxo_qspline { double sx, sy; int ncp; int64_t *cp; int color[3][32], sigma[32]; } *splines;
   float lf_dequant[3];
   uint32_t global_scale, quant_lf;
   int nb_lf_thr[3]; int32_t lf_thr[3][16]; int nb_qf_thr; uint32_t qf_thr[16];
@@ -489,9 +492,46 @@ typedef struct {
 
 static int ceil_log2u(uint32_t x) { int r = 0; while ((1u << r) < x) r++; return r; }
 
+/* Splines::Decode (libjxl; ISO/IEC 18181-1 K.4.1): six contexts — 0 quantisation adjustment, 1 starting positions, 2 number of splines, 3 number of control
+ * points, 4 control points, 5 DCT coefficients.  Reached through JxlDecoderProcessInput (reference call site jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:75). */
+static int read_splines(fstate *s, jxo_br *br) {
+  jxo_ec ec;
+  if (jxo_ec_read_header(&ec, br, 6)) JXO_FAIL("splines: bad entropy header");
+  jxo_ec_begin(&ec, br, 0);
+  uint64_t num_pixels = (uint64_t)s->f.width * (uint64_t)s->f.height, max_cp = num_pixels / 2 < (1u << 20) ? num_pixels / 2 : (1u << 20);
+  uint64_t n = (uint64_t)jxo_ec_read(&ec, br, 2) + 1;
+  if (n > max_cp + 1) { jxo_ec_free(&ec); JXO_FAIL("splines: too many"); }
+  s->num_splines = (int)n;
+  s->splines = (struct jxo_qspline *)calloc((size_t)n, sizeof(*s->splines));
+  int64_t lx = 0, ly = 0;
+  for (int i = 0; i < s->num_splines; i++) {
+    int64_t x = jxo_ec_read(&ec, br, 1), y = jxo_ec_read(&ec, br, 1);
+    if (i) { x = jxo_unpack_signed((uint32_t)x) + lx; y = jxo_unpack_signed((uint32_t)y) + ly; }
+    s->splines[i].sx = (double)x; s->splines[i].sy = (double)y; lx = x; ly = y;
+  }
+  s->spline_quant_adjust = jxo_unpack_signed(jxo_ec_read(&ec, br, 0));
+  uint64_t total = 0;
+  for (int i = 0; i < s->num_splines; i++) {
+    struct jxo_qspline *q = &s->splines[i];
+    uint64_t ncp = jxo_ec_read(&ec, br, 3);
+    total += ncp;
+    if (total > max_cp || br->err) { jxo_ec_free(&ec); JXO_FAIL("splines: too many control points"); }
+    q->ncp = (int)ncp;
+    q->cp = (int64_t *)calloc((size_t)ncp * 2 + 1, sizeof(int64_t));
+    for (int k = 0; k < q->ncp; k++) { q->cp[2 * k] = jxo_unpack_signed(jxo_ec_read(&ec, br, 4)); q->cp[2 * k + 1] = jxo_unpack_signed(jxo_ec_read(&ec, br, 4)); }
+    for (int c = 0; c < 3; c++) for (int k = 0; k < 32; k++) q->color[c][k] = jxo_unpack_signed(jxo_ec_read(&ec, br, 5));
+    for (int k = 0; k < 32; k++) q->sigma[k] = jxo_unpack_signed(jxo_ec_read(&ec, br, 5));
+  }
+  int ok = jxo_ec_final_ok(&ec);
+  jxo_ec_free(&ec);
+  if (!ok || br->err) JXO_FAIL("splines: ANS final state / truncated");
+  return 0;
+}
+
 static int read_lf_global(fstate *s, jxo_br *br) {
   const frame_hdr *f = &s->f;
-  if (f->flags & (2 | 16)) JXO_FAIL("unsupported: patches/splines");
+  if (f->flags & 2) JXO_FAIL("unsupported: patches");
+  if ((f->flags & 16) && read_splines(s, br)) return -1;
   if (f->flags & 1) for (int i = 0; i < 8; i++) s->noise_lut[i] = (float)jxo_bits(br, 10) * (1.0f / 1024);      /* NoiseParameters: eight points of the strength curve */
   s->lf_dequant[0] = 1.0f / 4096; s->lf_dequant[1] = 1.0f / 512; s->lf_dequant[2] = 1.0f / 256;
   if (!jxo_bool(br)) for (int c = 0; c < 3; c++) s->lf_dequant[c] = jxo_f16(br) * (1.0f / 128);
@@ -1049,6 +1089,118 @@ static float noise_strength(const float *lut, float x) {
   float v = (lut[i + 1] - lut[i]) * fr + lut[i];
   return v < 0.0f ? 0.0f : v > 1.0f ? 1.0f : v;
 }
+/* ---- splines: libjxl's QuantizedSpline::Dequantize, DrawCentripetalCatmullRomSpline, ForEachEquallySpacedPoint, SegmentsFromPoints / ComputeSegments and
+ * DrawSegment, drawn segment by segment into the XYB planes after the loop filters (stage "Splines").  Its erf is the rational approximation below. */
+static float spl_erf(float v) {
+  float a = fabsf(v), d = a * 7.77394369e-02f + 2.05260015e-04f;
+  d = d * a + 2.32120216e-01f; d = d * a + 2.77820801e-01f; d = d * a + 1.0f;
+  float d2 = d * d, inv = 1.0f / d2, r = 1.0f - inv * inv;
+  return v <= 0.0f ? -r : r;
+}
+static float spl_idct(const float *dct, float t) {
+  float r = 0.0f;
+  for (int i = 0; i < 32; i++) r += dct[i] * cosf((3.14159265358979323846f / 32.0f) * (float)i * (t + 0.5f));
+  return 1.41421356237f * r;
+}
+typedef struct { float x, y; } spl_pt;
+static void draw_splines(fstate *s, int w, int h) {
+  static const float kw[4] = {0.0042f, 0.075f, 0.07f, 0.3333f};
+  int qa = s->spline_quant_adjust;
+  float inv_quant = qa >= 0 ? 1.0f / (1.0f + 0.125f * (float)qa) : 1.0f - 0.125f * (float)qa;
+  float y_to_x = s->f.encoding == 0 ? s->base_x : 0.0f, y_to_b = s->f.encoding == 0 ? s->base_b : 1.0f;
+  /* all segments of all splines first (libjxl's draw cache), then row by row in creation order */
+  typedef struct { float cx, cy, col[3], inv_sigma, s4i, maxd; } seg_t;
+  size_t nseg = 0, cap = 1024;
+  seg_t *segs = (seg_t *)malloc(cap * sizeof(seg_t));
+  for (int si = 0; si < s->num_splines; si++) {
+    struct jxo_qspline *q = &s->splines[si];
+    int ncp = q->ncp + 1;
+    spl_pt *cp = (spl_pt *)malloc(sizeof(spl_pt) * (size_t)(ncp + 2));
+    spl_pt *e = cp;                                   /* e[0] and e[ncp + 1]: the mirrored end points */
+    e[1].x = (float)q->sx; e[1].y = (float)q->sy;
+    int64_t cx = (int64_t)llroundf((float)q->sx), cy = (int64_t)llroundf((float)q->sy), dx = 0, dy = 0;
+    for (int k = 0; k < q->ncp; k++) { dx += q->cp[2 * k]; dy += q->cp[2 * k + 1]; cx += dx; cy += dy; e[2 + k].x = (float)cx; e[2 + k].y = (float)cy; }
+    float cd[3][32], sd[32];
+    for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) cd[c][i] = (float)q->color[c][i] * (i == 0 ? 0.70710678118f : 1.0f) * kw[c] * inv_quant;
+    for (int i = 0; i < 32; i++) { cd[0][i] += y_to_x * cd[1][i]; cd[2][i] += y_to_b * cd[1][i]; }
+    for (int i = 0; i < 32; i++) sd[i] = (float)q->sigma[i] * (i == 0 ? 0.70710678118f : 1.0f) * kw[3] * inv_quant;
+    size_t npts = 0; spl_pt *pts = (spl_pt *)malloc(sizeof(spl_pt) * ((size_t)ncp * 16 + 2));
+    if (ncp == 1) pts[npts++] = e[1];
+    else {
+      e[0].x = e[1].x + (e[1].x - e[2].x); e[0].y = e[1].y + (e[1].y - e[2].y);
+      e[ncp + 1].x = e[ncp].x + (e[ncp].x - e[ncp - 1].x); e[ncp + 1].y = e[ncp].y + (e[ncp].y - e[ncp - 1].y);
+      for (int st = 0; st + 3 < ncp + 2; st++) {
+        const spl_pt *p = &e[st];
+        pts[npts++] = p[1];
+        float d[3], t[4]; t[0] = 0.0f;
+        for (int k = 0; k < 3; k++) { d[k] = sqrtf(hypotf(p[k + 1].x - p[k].x, p[k + 1].y - p[k].y)); t[k + 1] = t[k] + d[k]; }
+        for (int i = 1; i < 16; i++) {
+          float tt = d[0] + ((float)i / 16.0f) * d[1];
+          spl_pt a[3], b[2];
+          for (int k = 0; k < 3; k++) { float wv = (tt - t[k]) / d[k]; a[k].x = p[k].x + wv * (p[k + 1].x - p[k].x); a[k].y = p[k].y + wv * (p[k + 1].y - p[k].y); }
+          for (int k = 0; k < 2; k++) { float wv = (tt - t[k]) / (d[k] + d[k + 1]); b[k].x = a[k].x + wv * (a[k + 1].x - a[k].x); b[k].y = a[k].y + wv * (a[k + 1].y - a[k].y); }
+          float wv = (tt - t[1]) / d[1];
+          pts[npts].x = b[0].x + wv * (b[1].x - b[0].x); pts[npts].y = b[0].y + wv * (b[1].y - b[0].y); npts++;
+        }
+      }
+      pts[npts++] = e[ncp];
+    }
+    /* unit arc-length samples: (point, weight) */
+    size_t nd = 0, dcap = 256; spl_pt *dp = (spl_pt *)malloc(dcap * sizeof(spl_pt)); float *dm = (float *)malloc(dcap * sizeof(float));
+#define SPL_PUSH(P, M) do { if (nd == dcap) { dcap *= 2; dp = (spl_pt *)realloc(dp, dcap * sizeof(spl_pt)); dm = (float *)realloc(dm, dcap * sizeof(float)); } dp[nd] = (P); dm[nd] = (M); nd++; } while (0)
+    {
+      spl_pt cur = pts[0];
+      SPL_PUSH(cur, 1.0f);
+      size_t next = 0; int done = 0;
+      while (!done && next < npts && nd < (1u << 22)) {
+        spl_pt prev = cur; float from = 0.0f;
+        for (;;) {
+          if (next >= npts) { SPL_PUSH(prev, from); done = 1; break; }
+          spl_pt nx = pts[next];
+          float to = sqrtf((nx.x - prev.x) * (nx.x - prev.x) + (nx.y - prev.y) * (nx.y - prev.y));
+          if (from + to >= 1.0f) { float wv = (1.0f - from) / to; cur.x = prev.x + wv * (nx.x - prev.x); cur.y = prev.y + wv * (nx.y - prev.y); SPL_PUSH(cur, 1.0f); break; }
+          from += to; prev = nx; next++;
+        }
+      }
+    }
+    float arc = (float)((double)nd - 2.0) + dm[nd - 1];
+    if (arc > 0.0f) {
+      float inv_arc = 1.0f / arc;
+      for (size_t k = 0; k < nd; k++) {
+        float prog = (float)k * inv_arc; if (prog > 1.0f) prog = 1.0f;
+        float col[3], sigma = spl_idct(sd, 31.0f * prog), mult = dm[k];
+        for (int c = 0; c < 3; c++) col[c] = spl_idct(cd[c], 31.0f * prog);
+        if (!isfinite(sigma) || sigma == 0.0f || !isfinite(1.0f / sigma) || !isfinite(col[0]) || !isfinite(col[1]) || !isfinite(col[2])) continue;
+        float maxc = 0.01f;
+        for (int c = 0; c < 3; c++) if (fabsf(col[c] * mult) > maxc) maxc = fabsf(col[c] * mult);
+        float maxd = sqrtf(-2.0f * sigma * sigma * (logf(0.1f) * 5.0f - logf(maxc)));
+        if (!isfinite(maxd)) continue;
+        if (nseg == cap) { cap *= 2; segs = (seg_t *)realloc(segs, cap * sizeof(seg_t)); }
+        seg_t *g = &segs[nseg++];
+        g->cx = dp[k].x; g->cy = dp[k].y; for (int c = 0; c < 3; c++) g->col[c] = col[c];
+        g->inv_sigma = 1.0f / sigma; g->s4i = 0.25f * sigma * mult; g->maxd = maxd;
+      }
+    }
+    free(dp); free(dm); free(pts); free(cp);
+  }
+  for (int y = 0; y < h; y++)
+    for (size_t i = 0; i < nseg; i++) {
+      const seg_t *g = &segs[i];
+      long long y0 = llroundf(g->cy - g->maxd), y1 = llroundf(g->cy + g->maxd);
+      if (y < y0 || y > y1) continue;
+      long long x0 = llroundf(g->cx - g->maxd), x1 = llroundf(g->cx + g->maxd);
+      if (x0 < 0) x0 = 0;
+      if (x1 > w - 1) x1 = w - 1;
+      for (long long x = x0; x <= x1; x++) {
+        float ddx = (float)x - g->cx, ddy = (float)y - g->cy, dist = sqrtf(ddx * ddx + ddy * ddy);
+        float fct = spl_erf((dist * 0.5f + 0.353553391f) * g->inv_sigma) - spl_erf((dist * 0.5f - 0.353553391f) * g->inv_sigma);
+        float li = g->s4i * fct * fct;
+        for (int c = 0; c < 3; c++) s->plane[c][(size_t)y * (size_t)s->pw + (size_t)x] += g->col[c] * li;
+      }
+    }
+  free(segs);
+}
+
 static void add_noise(fstate *s, int w, int h) {
   const frame_hdr *f = &s->f;
   float *nz[3];
@@ -1449,6 +1601,7 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
     if (jxo_debug) { FILE *fp = fopen("/tmp/jxo_xyb.bin", "wb"); for (int c = 0; c < 3; c++) fwrite(s->plane[c], 4, (size_t)s->pw * (size_t)s->ph, fp); fclose(fp); }
     if (f->gab) gaborish(s, w, h);
     if (f->epf_iters) epf(s, w, h);
+    if (f->flags & 16) draw_splines(s, w, h);
     if (f->flags & 1) add_noise(s, w, h);
     for (int c = 0; c < 3; c++) rgb[c] = (float *)malloc(4 * npx);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int c = 0; c < 3; c++) rgb[c][(size_t)y * (size_t)w + (size_t)x] = s->plane[c][(size_t)y * (size_t)s->pw + (size_t)x];

@@ -116,8 +116,8 @@ ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_premul_d1_e7"
 # 48 such frames — the reference keeps the last coalesced frame: a cropped, replacing frame over the cleared (transparent) canvas
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
 # hand-written codestreams (tools/jxl_write.py -> tests/golden/make_golden.py: writer_case): the DCT128 / DCT256 varblock families (AcStrategy 21 .. 26), which
-# libjxl's encoder never selects and its decoder takes; expected pixels = the reference's decode
-WRITER_CASES = ["w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
+# libjxl's encoder never selects and its decoder takes, and splines (K.4: what jxl-art files draw with); expected pixels = the reference's decode
+WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
 VARDCT_CASES = VARDCT_CASES + WRITER_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vpm400x300_e7_premultiplied", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 

@@ -50,6 +50,7 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   if (F.subsampled) for (int c = 0; c < 3; c++) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) chroma_upsample_pixel(B, F, c, x, y);      // k_chroma_upsample
   const DevPatch *P = (const DevPatch *)(B.tables + F.patch_off);
   for (int i = 0; i < F.num_patches; i++) for (int k = 0; k < P[i].w * P[i].h; k++) patch_blend_sample(B, F, P[i], k);
+  if (F.num_spline_segs > 0) for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) spline_pixel(B, F, x, y);      // k_splines
   const auto noise = [&]() {                                                              // k_noise_gen, k_noise_add
     const NoiseGeom G = noise_geom(B, F);
     for (int g = 0; g < G.xtiles * G.ytiles; g++) for (int lane = 0; lane < 8; lane++) noise_gen_lane(B, F, g, lane);

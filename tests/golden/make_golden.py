@@ -273,6 +273,8 @@ def add_anim_cases(meta, only):
 def writer_case(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import jxl_write as W
+    if name.startswith("w_spline"):
+        return spline_case(name, W)
     seed = {"w_dct256": 1, "w_dct128": 2, "w_dct_mix_a": 3, "w_dct_mix_b": 4, "w_dct128_small": 5, "w_dct256_nofilter": 6}[name]
     rng = np.random.default_rng(seed)
     size = 128 if name == "w_dct128_small" else 256
@@ -304,7 +306,47 @@ def writer_case(name):
     return W.write_vardct(size, size, blocks, lf, **kw)
 
 
-WRITER_CASES = ["w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
+def spline_case(name, W):
+    """Splines (K.4) — libjxl's encoder API cannot place them, jxl-art files do: curves of one to seven control points, colour and thickness varying along the
+    arc (higher DCT coefficients), negative colours, a dot (one control point), a curve that leaves the image, thin and thick lines, both signs of the
+    quantisation adjustment; over a flat image without loop filters (w_spline_a) and over texture with Gaborish + EPF (w_spline_b / _c)."""
+    rng = np.random.default_rng({"w_spline_a": 11, "w_spline_b": 12, "w_spline_c": 13}[name])
+    size = 128 if name == "w_spline_a" else 256
+    nb = size // 8
+    yy, xx = np.mgrid[0:nb, 0:nb]
+
+    def dct(v0, *rest):
+        v = [0] * 32; v[0] = v0
+        for i, r in enumerate(rest):
+            v[1 + i] = r
+        return v
+    if name == "w_spline_a":
+        lf = np.stack([np.zeros((nb, nb), np.int64), 5000 + 0 * xx, np.zeros((nb, nb), np.int64)])
+        blocks = [dict(bx=x, by=y, strategy=0, qf=8) for y in range(nb) for x in range(nb)]
+        spl = [dict(points=[(20, 20), (60, 40), (100, 30), (110, 100)], color=[dct(8), dct(40, 10), dct(-6)], sigma=dct(12))]
+        return W.write_vardct(size, size, blocks, lf, gab=False, epf_iters=0, splines=spl)
+    lf = np.stack([np.round(30 * np.sin(xx / 5.0)).astype(np.int64), 5000 + 60 * xx + 45 * yy + np.round(200 * np.sin(yy / 3.0)).astype(np.int64),
+                   np.round(40 * np.cos(yy / 4.0)).astype(np.int64)])
+
+    def coefs(st, n, amp):
+        total, covered = W.natural_order_len(st), W.COVERED_X[st] * W.COVERED_Y[st]
+        ks = rng.choice(np.arange(covered, min(total, covered + 600)), n, replace=False)
+        return {int(k): int(v) for k, v in zip(ks, rng.integers(-amp, amp + 1, n)) if v}
+    blocks = [dict(bx=x, by=y, strategy=5, qf=int(rng.integers(4, 10)), coef={1: coefs(5, 12, 12), 0: coefs(5, 3, 3), 2: coefs(5, 4, 4)}) for y in range(0, nb, 4) for x in range(0, nb, 4)]
+    spl = [dict(points=[(10, 200), (50, 120), (90, 180), (130, 60), (180, 140), (220, 40), (250, 100)], color=[dct(10, -8, 3), dct(60, 25, -12, 6), dct(-10, 5)], sigma=dct(10, 6, -3)),
+           dict(points=[(128, 128)], color=[dct(0), dct(90), dct(20)], sigma=dct(25)),                                             # a dot
+           dict(points=[(200, 230), (270, 250), (300, 180)], color=[dct(-12), dct(-50, 10), dct(8)], sigma=dct(4, 1)),                 # darker than the image, leaves it on the right
+           dict(points=[(30, 30), (31, 90)], color=[dct(4), dct(30), dct(0)], sigma=dct(2))]                                          # thin
+    if name == "w_spline_c":
+        # (the long curve's thickness crosses zero at 5/6 of its arc — kept in w_spline_b; with this file's quantisation adjustment the reference's own
+        # cosine approximation decides two pixels there by 8 levels, so here it stays positive)
+        spl[0] = dict(spl[0], sigma=dct(14, 5, -3))
+        spl = spl[:1] + [dict(points=[(40, 20), (120, 20), (120, 100), (40, 100), (40, 21)], color=[dct(0, 6), dct(45, -20, 10, -5, 3), dct(12, 4)], sigma=dct(30, -10))]
+    return W.write_vardct(size, size, blocks, lf, splines=spl, spline_quant_adjust=-3 if name == "w_spline_b" else 5,
+                          xfromy=rng.integers(-20, 20, (4, 4)), bfromy=rng.integers(-10, 30, (4, 4)), sharpness=rng.integers(0, 8, (nb, nb)))
+
+
+WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
 
 
 def add_writer_cases(meta, only):
