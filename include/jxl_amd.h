@@ -151,6 +151,15 @@ int jxlamd_band_export(jxlamd_decoder *dec, int kind, int side, void *halo_dev, 
 int jxlamd_band_import(jxlamd_decoder *dec, int kind, int side, const void *halo_dev, size_t size);
 int jxlamd_band_reconstruct(jxlamd_decoder *dec);
 int jxlamd_band_finish(jxlamd_decoder *dec);
+/* The cut of a frame of `ygroups` group rows (ceil(ysize / 256)) into `nbands` bands: rows[2 b] .. rows[2 b + 1] = the group rows of band b (borders on whole
+ * 2048-pixel LF groups when there are enough of them). */
+int jxlamd_band_rows(int ygroups, int nbands, int *rows);
+/* BASELINE config 4 for the bands ONE process holds, without a host-language driver (SURVEY.md §8b "decode_sharded"; the reference has no counterpart: libjxl
+ * decodes a frame in one process under interop/JxlDecoding.cpp:75): the frame as `nbands` bands of group rows (jxlamd_band_rows), band b on decoder context
+ * decs[b] (all on one device, one context per band), its tight RGBA rows into the device buffer outs[b] of caps[b] bytes.  The bands go through every phase of
+ * the protocol above side by side and hand their halo rows to their neighbours through device buffers.  Pixels = the same rows of a whole-frame decode. */
+int jxlamd_decode_sharded_local(jxlamd_decoder *const *decs, int nbands, const uint8_t *jxl, size_t size, uint32_t flags, void *const *outs, const size_t *caps,
+                                jxlamd_info *info);
 
 /* Timing of the last decode in milliseconds (HIP events on the decoder's stream):
  * [0]=LF groups, [1]=pass groups, [2]=reconstruction, [3]=filters+write, [4]=total device time. */

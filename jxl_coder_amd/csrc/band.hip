@@ -14,7 +14,9 @@
 // The reference has no counterpart (libjxl decodes a frame in one process); the boundary it sits under is the size guard of
 // DecodeJpegXlOneShot (jxlcoder/src/main/cpp/interop/JxlDecoding.cpp:103-109): a band is smaller than a Bitmap.
 #include <chrono>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include "decoder_ctx.h"
 
 namespace {
@@ -215,4 +217,70 @@ int jxlamd_band_export(jxlamd_decoder *d, int kind, int side, void *dev_buf, siz
 int jxlamd_band_import(jxlamd_decoder *d, int kind, int side, const void *dev_buf, size_t size) { return d ? d->band_import(kind, side, dev_buf, size) : JXLAMD_ERR_DEVICE; }
 int jxlamd_band_reconstruct(jxlamd_decoder *d) { return d ? d->band_reconstruct() : JXLAMD_ERR_DEVICE; }
 int jxlamd_band_finish(jxlamd_decoder *d) { return d ? d->band_finish() : JXLAMD_ERR_DEVICE; }
+
+// The cut of a frame of `ygroups` group rows into `nbands` bands (jxl_coder_amd/shard.py: band_rows): borders on multiples of 8 group rows — whole 2048-pixel
+// LF groups, no LF stream decoded twice — whenever there are at least nbands LF-group rows.  rows[2 b], rows[2 b + 1] = first / one past the last group row of band b.
+int jxlamd_band_rows(int ygroups, int nbands, int *rows) {
+  if (!rows || nbands < 1 || nbands > ygroups) { tls_error() = "band rows: cannot cut the frame that way"; return JXLAMD_ERR_BUFFER; }
+  const int lf_rows = (ygroups + 7) / 8;
+  const int unit = lf_rows >= nbands ? 8 : 1, units = lf_rows >= nbands ? lf_rows : ygroups;
+  for (int b = 0; b <= nbands; b++) {
+    int cut = std::min(ygroups, (int)((int64_t)units * b / nbands) * unit);
+    if (b == nbands) cut = ygroups;
+    if (b < nbands) rows[2 * b] = cut;
+    if (b > 0) rows[2 * b - 1] = cut;
+  }
+  return JXLAMD_OK;
+}
+
+// BASELINE config 4 for the bands ONE process holds, without Python (SURVEY.md §8b "decode_sharded"; what jxl_coder_amd/shard.py: decode_sharded does for a
+// rank's bands): band b of `nbands` on decoder context decs[b] (same device; one context per band), its pixel rows into outs[b].  Every phase of the protocol
+// runs the bands side by side — one host thread each, their own HIP streams — and the halo rows of neighbouring bands are handed from one context to the
+// next through device buffers; a multi-process decode uses the same calls per band and moves the rank-border halos itself (ncclSend / ncclRecv).
+int jxlamd_decode_sharded_local(jxlamd_decoder *const *decs, int nbands, const uint8_t *jxl, size_t size, uint32_t flags, void *const *outs, const size_t *caps,
+                                jxlamd_info *info) {
+  if (!decs || nbands < 1 || !jxl || !outs || !caps) { tls_error() = "decode_sharded_local: bad arguments"; return JXLAMD_ERR_BUFFER; }
+  for (int b = 0; b < nbands; b++) if (!decs[b]) { tls_error() = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  jxlamd_info bi;
+  int rc = jxlamd_basic_info(jxl, size, &bi);
+  if (rc) return rc;
+  const int ygroups = (int)((bi.ysize + 255) / 256);
+  std::vector<int> rows((size_t)nbands * 2);
+  if ((rc = jxlamd_band_rows(ygroups, nbands, rows.data()))) return rc;
+  const uint32_t fl = (flags & ~(uint32_t)JXLAMD_BAND_SHARED_GPU) | (nbands > 1 ? JXLAMD_BAND_SHARED_GPU : 0u);
+  std::vector<int> rcs((size_t)nbands, JXLAMD_OK);
+  std::vector<std::string> errs((size_t)nbands);
+  const auto phase = [&](const std::function<int(int)> &fn) -> int {
+    if (nbands == 1) { rcs[0] = fn(0); if (rcs[0]) errs[0] = decs[0]->error; }
+    else {
+      std::vector<std::thread> th;
+      for (int b = 0; b < nbands; b++) th.emplace_back([&, b] { rcs[(size_t)b] = fn(b); if (rcs[(size_t)b]) errs[(size_t)b] = decs[b]->error; });
+      for (auto &t : th) t.join();
+    }
+    for (int b = 0; b < nbands; b++) if (rcs[(size_t)b]) { tls_error() = errs[(size_t)b]; return rcs[(size_t)b]; }
+    return JXLAMD_OK;
+  };
+  std::vector<jxlamd_info> infos((size_t)nbands);
+  if ((rc = phase([&](int b) { return jxlamd_band_begin(decs[b], jxl, size, fl, rows[2 * (size_t)b], rows[2 * (size_t)b + 1], outs[b], caps[b], &infos[(size_t)b]); }))) return rc;
+  if (info) *info = infos[0];
+  DevMem halo[2];
+  const auto exchange = [&](int kind) -> int {
+    for (int b = 0; b + 1 < nbands; b++) {
+      size_t n = 0;
+      int e = jxlamd_band_halo_bytes(decs[b], kind, &n);
+      if (e) return e;
+      if (n == 0) continue;
+      if (halo[0].ensure(n) != hipSuccess || halo[1].ensure(n) != hipSuccess) { tls_error() = "decode_sharded_local: no memory for the halo rows"; return JXLAMD_ERR_DEVICE; }
+      if ((e = jxlamd_band_export(decs[b], kind, 1, halo[0].p, n)) || (e = jxlamd_band_export(decs[b + 1], kind, 0, halo[1].p, n))) { tls_error() = decs[b]->error.empty() ? decs[b + 1]->error : decs[b]->error; return e; }
+      if ((e = jxlamd_band_import(decs[b + 1], kind, 0, halo[0].p, n)) || (e = jxlamd_band_import(decs[b], kind, 1, halo[1].p, n))) { tls_error() = decs[b]->error.empty() ? decs[b + 1]->error : decs[b]->error; return e; }
+      // the imports are copies on the two contexts' streams: done before the buffers carry the next border
+      if (hipStreamSynchronize(decs[b]->stream) != hipSuccess || hipStreamSynchronize(decs[b + 1]->stream) != hipSuccess) { tls_error() = "decode_sharded_local: halo copy failed"; return JXLAMD_ERR_DEVICE; }
+    }
+    return JXLAMD_OK;
+  };
+  if ((rc = exchange(kHaloLf))) return rc;
+  if ((rc = phase([&](int b) { return jxlamd_band_reconstruct(decs[b]); }))) return rc;
+  if ((rc = exchange(kHaloPixels))) return rc;
+  return phase([&](int b) { return jxlamd_band_finish(decs[b]); });
+}
 }  // extern "C"

@@ -173,6 +173,42 @@ def test_bands_equal_whole_frame_decode(golden_meta, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", BAND_CASES)
+def test_c_abi_sharded_local_equals_whole_frame_decode(name):
+    """jxlamd_decode_sharded_local (include/jxl_amd.h): the band protocol for the bands of one process driven from C — what a C++ binding of the reference
+    calls for BASELINE config 4 without a Python driver.  2, 3 and 8 bands on as many decoder contexts; band cut by jxlamd_band_rows (= shard.band_rows);
+    the assembled rows equal the whole-frame decode bit for bit."""
+    import ctypes as C
+    import jxl_coder_amd as J
+    from jxl_coder_amd.shard import band_rows
+    L = J.api.lib()
+    L.jxlamd_band_rows.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.jxlamd_decode_sharded_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+    data = open(os.path.join(GOLDEN, name + ".jxl"), "rb").read()
+    dec = J.JxlDecoder(0)
+    whole, info = dec.decode_one_shot(data)
+    h, w = whole.shape[:2]
+    ygroups = (h + 255) // 256
+    decs = [J.JxlDecoder(0) for _ in range(8)]
+    for nbands in (2, 3, 8):
+        rows = (C.c_int * (2 * nbands))()
+        assert L.jxlamd_band_rows(ygroups, nbands, rows) == 0
+        assert [(rows[2 * b], rows[2 * b + 1]) for b in range(nbands)] == band_rows(ygroups, nbands)
+        outs = [torch.zeros((min(rows[2 * b + 1] * 256, h) - rows[2 * b] * 256) * w * 4, dtype=torch.uint8, device="cuda:0") for b in range(nbands)]
+        torch.cuda.synchronize()
+        hs = (C.c_void_p * nbands)(*[d._h for d in decs[:nbands]])
+        ps = (C.c_void_p * nbands)(*[o.data_ptr() for o in outs])
+        caps = (C.c_size_t * nbands)(*[o.numel() for o in outs])
+        rc = L.jxlamd_decode_sharded_local(hs, nbands, data, len(data), J.api.JXLAMD_OUT_DEVICE, ps, caps, None)
+        assert rc == 0, L.jxlamd_last_error(None)
+        torch.cuda.synchronize()
+        img = np.concatenate([o.cpu().numpy().reshape(-1, w, 4) for o in outs])
+        assert np.array_equal(img, whole), nbands
+    for d in decs + [dec]:
+        d.close()
+
+
+@pytest.mark.gpu
 def test_sharded_large_frame_against_the_reference():
     """A 2048x4352 frame (17 group rows, 8 x 17 groups, 3 LF groups) from the reference's encoder, decoded as 2 / 4 / 8 bands."""
     sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
