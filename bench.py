@@ -463,6 +463,9 @@ def main():
             "metric": "decoded MP/s (4K Rec.2100 PQ 16-bit EPF3 -> tone map -> RGBA_F16)" if c5 else "decoded MP/s (4K VarDCT q90 -> RGBA8)", "value": round(value, 2), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # which rate `value` is: the measurement contract of this build ("whole-job throughput with inputs already resident in HBM when the timed region
+            # starts; the PCIe-inclusive rate is never `value`") against SURVEY.md §8(d), which counts the H2D of the compressed bytes — both are on the line
+            "value_inputs": "compressed bytes resident in HBM", "value_h2d_included": round(h2d_steps * B * world * mp / elapsed_h2d, 2),
             "config": {"workload": (f"configs[4] on one GPU: one step = a batch of {B} x 3840x2160 Rec.2100 PQ 16-bit VarDCT (distance 1.0, effort 7, EPF forced to 3 iterations) "
                                     + ("frames -> colour matrix + Rec.2408 tone map -> RGBA_F16 INSIDE the decoder's writer (the last EPF stage emits the Bitmap format; the RGBA16 image is never stored) " if c5_writer else
                                        "frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (A10 + A11 fused into one pass per frame) ") if c5 else
