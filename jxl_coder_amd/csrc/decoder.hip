@@ -250,7 +250,8 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
     S.post_premul = !S.pi.alpha_premultiplied && S.pi.has_alpha_in_origin; S.post_att = !S.pi.alpha_premultiplied;
     S.post_stride = ri.stride; S.post_bytes = ri.bytes;
     // inside the writer where the frame's last stage is a per-stage kernel (three EPF iterations: BASELINE config 5); elsewhere one pass behind it
-    S.post_fused = !plan.modular && !plan.compose && !plan.cropped && plan.refs.empty() && Fh->epf_iters == 3 && Fh->orientation >= 1;
+    // (round 5: the column sweep's writer has the post instantiation too — every VarDCT frame that is written straight from its last filter stage)
+    S.post_fused = !plan.modular && !plan.compose && !plan.cropped && plan.refs.empty() && Fh->orientation >= 1;
     S.post_final = out_ptr;
     if (!(flags & JXLAMD_OUT_DEVICE)) { HIPCHECK(S.out.ensure(ri.bytes)); S.post_final = S.out.p; S.host_out = out_ptr; }
     const uint32_t line = ri.format == JXLAMD_FMT_RGB_565 ? S.pi.xsize * 2 : ri.format == JXLAMD_FMT_RGBA_F16 ? S.pi.xsize * 8 : S.pi.xsize * 4;
@@ -928,7 +929,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   if (need_pool) { lf_pool_bytes = kModPoolBytes; pool_missed = true; return kRetryPool; }
   if (pool_missed) {
     pool_missed = false;
-    const int want = lf_pool_clamp(pool_want);
+    const int want = lf_pool_clamp(pool_want + 4096);      // + headroom: the next flights' frames differ a little (256 distinct bench frames: 12 - 25 KB), every further miss repeats a flight
     lf_pool_floor = std::max(lf_pool_floor, want);
     for (int cur = g_lf_pool_floor.load(); cur < want && !g_lf_pool_floor.compare_exchange_weak(cur, want);) {}
   }

@@ -453,7 +453,7 @@ JXL_DEV float tf_srgb(float v) {
   // negative value is 12.92 v (established on the reference binary's float output of a blended animation; it only shows where values are not clamped
   // straight away, i.e. in the background a later frame is blended over)
   if (v <= 0.0031308f) return 12.92f * v;
-  return 1.055f * pow_pos(v, 1.0f / 2.4f) - 0.055f;
+  return fmaf(1.055f, pow_pos(v, 1.0f / 2.4f), -0.055f);      // (spelled out: every writer instantiation must round alike)
 }
 JXL_DEV float tf_pq(float v, float intensity_target) {
   float a = fabsf(v) * (intensity_target * 1e-4f);
@@ -527,8 +527,8 @@ JXL_DEV bool rgba_codes(const DevBuffers &B, const uint8_t *stat, const DevStati
     // libjxl's 8-bit writer dither (oracle/README.md): indexed by the OUTPUT position; for the transposing orientations (5..8) with row
     // and column swapped (established on the reference's output: tests/golden/vo72x40_e3_o5..8)
     const float d = st_f(stat, ST.dither_off)[F.orientation > 4 ? (ox & 31) * 32 + (oy & 31) : (oy & 31) * 32 + (ox & 31)];
-    for (int c = 0; c < 3; c++) px[c] = (uint32_t)(uint8_t)(int)rintf(v[c] * 255.0f + d);
-    px[3] = (uint32_t)(uint8_t)(int)rintf(alpha * 255.0f + d);        // the dither goes on every channel; it only shows on a fractional (upsampled) alpha: |d| < 0.5
+    for (int c = 0; c < 3; c++) px[c] = (uint32_t)(uint8_t)(int)rintf(fmaf(v[c], 255.0f, d));
+    px[3] = (uint32_t)(uint8_t)(int)rintf(fmaf(alpha, 255.0f, d));        // the dither goes on every channel; it only shows on a fractional (upsampled) alpha: |d| < 0.5
   } else {
     for (int c = 0; c < 3; c++) px[c] = (uint32_t)(uint16_t)(int)rintf(v[c] * 65535.0f);
     px[3] = (uint32_t)(uint16_t)(int)rintf(alpha * 65535.0f);
@@ -545,19 +545,27 @@ JXL_DEV void rgba_store(const DevBuffers &B, const uint8_t *stat, const DevStati
 
 // XYB -> the image's colour encoding (opsin inverse, target primaries, transfer function), NOT clamped: what libjxl's "XYB" + "FromLinear" stages hand to
 // the blending stage / the writer
+// XYB -> linear light of the target primaries: the cube of the biased gamma-domain values, then the (scaled) inverse opsin matrix.  Every multiply-add is
+// spelled out, so that the writer instantiations (general, the sweep's fast one, the ones that hand the pixel to the post stages) give the same bits whatever
+// the compiler would have contracted in each of them — jxlamd_decoder_set_writer_post promises the bytes of decode + jxlamd_post_fused.
+JXL_DEV void opsin_mix(const float *bias_cbrt, const float *bias, float X, float Y, float Bc, float (&mix)[3]) {
+  const float gl = (Y + X) - bias_cbrt[0], gm = (Y - X) - bias_cbrt[1], gs = Bc - bias_cbrt[2];
+  mix[0] = fmaf(gl * gl, gl, bias[0]); mix[1] = fmaf(gm * gm, gm, bias[1]); mix[2] = fmaf(gs * gs, gs, bias[2]);
+}
+JXL_DEV float opsin_lin(const float *inv, int c, const float (&mix)[3]) { return fmaf(inv[c * 3], mix[0], fmaf(inv[c * 3 + 1], mix[1], inv[c * 3 + 2] * mix[2])); }
 JXL_DEV void xyb_to_rgb(const DevFrame &F, float X, float Y, float Bc, float (&v)[3]) {
-  const float gl = Y + X - F.opsin_bias_cbrt[0], gm = Y - X - F.opsin_bias_cbrt[1], gs = Bc - F.opsin_bias_cbrt[2];
-  const float mix0 = gl * gl * gl + F.opsin_bias[0], mix1 = gm * gm * gm + F.opsin_bias[1], mix2 = gs * gs * gs + F.opsin_bias[2];
+  float mix[3];
+  opsin_mix(F.opsin_bias_cbrt, F.opsin_bias, X, Y, Bc, mix);
   float hlg_ratio = 1.0f;
   if (F.transfer == 18 && F.hlg_exponent != 0.0f) {        // inverse OOTF: scale by luminance^(gamma - 1)
     float lum = 0.0f;
-    for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * (F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2);
+    for (int c = 0; c < 3; c++) lum += F.hlg_lum[c] * opsin_lin(F.opsin_inv, c, mix);
     // libjxl: min(pow(luminance, exponent), 1e9) — pow(0, negative exponent) is +inf there, i.e. the clamp value
     hlg_ratio = lum > 0.0f ? pow_pos(lum, F.hlg_exponent) : (lum == 0.0f && F.hlg_exponent < 0.0f) ? 1e9f : 0.0f;
     if (hlg_ratio > 1e9f) hlg_ratio = 1e9f;
   }
   for (int c = 0; c < 3; c++) {
-    float lin = F.opsin_inv[c * 3] * mix0 + F.opsin_inv[c * 3 + 1] * mix1 + F.opsin_inv[c * 3 + 2] * mix2;
+    float lin = opsin_lin(F.opsin_inv, c, mix);
     switch (F.transfer) {
       case 18: lin = tf_hlg(lin * hlg_ratio); break;
       case 17: { float a = pow_pos(fabsf(lin), 1.0f / 2.6f); lin = lin < 0 ? -a : a; } break;

@@ -25,11 +25,12 @@ void launch_recon_huge(const DevBuffers *Bs, const uint8_t *stat, int nframes, f
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s);
 // stage_mask bit of a frame's column-sweep instantiation: 8 + (gab ? 3 : 0) + epf_iters, + kSweepFastShift when the frame takes the sweep's fast writer
 // (host twin of sweep_fast_frame, kernels_filter.hip: sRGB curve, RGBA8, identity orientation, frame = canvas, no alpha plane, no post stages in the writer)
-constexpr int kSweepFastShift = 6;
+// ... + kSweepPostShift when the frame's writer emits the Bitmap format through the post stages (jxlamd_decoder_set_writer_post: k_filter_sweep<.., .., false, 1 / 2>)
+constexpr int kSweepFastShift = 6, kSweepPostShift = 12;
 inline int sweep_stage_bit(const DevFrame &F, int out_bits, bool writer_post) {
   const bool fast = F.transfer == 13 && F.orientation == 1 && out_bits == 8 && !(F.has_ec && F.mod_out[3] >= 0) && F.crop_x0 == 0 && F.crop_y0 == 0 &&
                     F.canvas_w == F.width && F.canvas_h == F.height && !writer_post;
-  return 1 << (8 + (fast ? kSweepFastShift : 0) + (F.gab ? 3 : 0) + F.epf_iters);
+  return 1 << (8 + (writer_post ? kSweepPostShift : fast ? kSweepFastShift : 0) + (F.gab ? 3 : 0) + F.epf_iters);
 }
 // parts: 1 = reconstruction kernels, 2 = filters + writer, 3 = both
 inline void launch_rest_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, int max_w, int max_h, int stage_mask, bool expect_large,

@@ -101,7 +101,10 @@ __device__ __forceinline__ bool sweep_fast_frame(const DevBuffers &B, const DevF
   return F.transfer == 13 && F.orientation == 1 && B.out_bits == 8 && !(F.has_ec && F.mod_out[3] >= 0) && F.crop_x0 == 0 && F.crop_y0 == 0 &&
          F.canvas_w == F.width && F.canvas_h == F.height && B.post == nullptr;
 }
-template <bool kGab, int kEpf, bool kFast>
+// kPost (SURVEY.md §8f-1 for the common path, round 5): 1 = the frame's pixels leave through A10 + A11 (post_emit: colour matrix / tone map, premultiply, Bitmap
+// format) instead of the RGBA store — bit for bit what k_post_fused makes of the stored RGBA; 2 = the pass behind it that rewrites, un-mapped, the pixels at or
+// behind their row's first zero-luma pixel (the reference's tone mapper stops there, Rec2408ToneMapper.cpp:91-93): same sweep, segments without such a row leave at once.
+template <bool kGab, int kEpf, bool kFast, int kPost>
 __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int strip, int seg, int rows_per_wave, int lane) {
   constexpr int DG = kGab ? 1 : 0, DE = kEpf >= 1 ? 2 : 0, DF = kEpf >= 2 ? 1 : 0;     // row delay of each stage behind its input
   constexpr int HX = DG + DE + DF, SW = 64 - 2 * HX;
@@ -110,6 +113,10 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   const int y0 = F.band_py0 + seg * rows_per_wave;
   if (x0 >= w || y0 >= F.band_py1) return;
   const int y1 = y0 + rows_per_wave < F.band_py1 ? y0 + rows_per_wave : F.band_py1;
+  if (kPost == 2 && F.orientation == 1) {                        // (output row = frame row: a frame that takes this path is not cropped)
+    const int yr = y0 + lane;
+    if (__ballot(yr < y1 && B.post->row_fz[1 + yr] != 0xFFFFFFFFu) == 0) return;
+  }
   const int x = x0 - HX + lane;                                  // virtual column of this lane
   const int ex = mirror(x < w + 8 ? x : w + 7, w);               // lanes far beyond the image never produce output
   const bool lane_out = lane >= HX && lane < 64 - HX && x < w;
@@ -231,19 +238,24 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
       asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));      // keep the filter's last multiply and the writer's first add apart (no FMA across the seam)
       if (kFast) {
         // xyb_to_rgb + tf_srgb + the clamp + rgba_codes for the fast frame, same operations in the same order
-        const float gl = v[1] + v[0] - obc[0], gm = v[1] - v[0] - obc[1], gs = v[2] - obc[2];
-        const float mix0 = gl * gl * gl + ob[0], mix1 = gm * gm * gm + ob[1], mix2 = gs * gs * gs + ob[2];
+        float mix[3];
+        opsin_mix(obc, ob, v[0], v[1], v[2], mix);
         const float d = dith[(o & 31) * 32];
         uint32_t px = 0xFF000000u;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          float lin = oi[c * 3] * mix0 + oi[c * 3 + 1] * mix1 + oi[c * 3 + 2] * mix2;
-          lin = tf_srgb(lin);
+          float lin = tf_srgb(opsin_lin(oi, c, mix));
           float cv = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
           if (!(lin == lin)) cv = 0.0f;
-          px |= (uint32_t)(uint8_t)(int)rintf(cv * 255.0f + d) << (8 * c);
+          px |= (uint32_t)(uint8_t)(int)rintf(fmaf(cv, 255.0f, d)) << (8 * c);
         }
         orow[(size_t)o * (size_t)F.out_w] = px;
+      } else if (kPost != 0) {
+        float c[3];
+        xyb_to_rgb(F, v[0], v[1], v[2], c);
+        for (int k = 0; k < 3; k++) { const float lin = c[k]; c[k] = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin; if (!(lin == lin)) c[k] = 0.0f; }
+        uint32_t px[4]; int ox, oy;
+        if (rgba_codes(B, stat, ST, c, B.out_bits, x, o, px, ox, oy)) post_emit<kPost == 2 ? 2 : 1>(*B.post, px[0], px[1], px[2], px[3], ox, oy, B.out_bits == 16);
       } else
       xyb_write_value(B, stat, ST, v[0], v[1], v[2], B.out_bits, x, o);
     }
@@ -251,14 +263,15 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
 }
 // one instantiation per stage combination: the register footprint of the longest pipeline (Gaborish + two EPF iterations) must not be
 // charged to the common one (Gaborish + one iteration)
-template <bool kGab, int kEpf, bool kFast>
+template <bool kGab, int kEpf, bool kFast, int kPost = 0>
 __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave, int fast_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (!frame_uses_sweep(F) || frame_failed(B)) return;
-  if ((F.gab != 0) != kGab || F.epf_iters != kEpf || (fast_on && sweep_fast_frame(B, F)) != kFast) return;           // another instantiation's frame
+  if ((F.gab != 0) != kGab || F.epf_iters != kEpf || (fast_on && sweep_fast_frame(B, F)) != kFast || (B.post != nullptr) != (kPost != 0)) return;           // another instantiation's frame
+  if (kPost == 2 && (B.post->row_fz[0] == 0 || !(B.post->matrix && B.post->P.tone_map))) return;      // no pixel of zero luma anywhere / nothing is tone-mapped: the first pass was final
   const int lane = (int)(threadIdx.x & 63), seg = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)), strip = (int)blockIdx.x;
-  filter_sweep<kGab, kEpf, kFast>(B, F, stat, strip, seg, rows_per_wave, lane);
+  filter_sweep<kGab, kEpf, kFast, kPost>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
 
 void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
@@ -285,6 +298,12 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
     if (fast & 8) hipLaunchKernelGGL((k_filter_sweep<true, 0, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
     if (fast & 16) hipLaunchKernelGGL((k_filter_sweep<true, 1, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
     if (fast & 32) hipLaunchKernelGGL((k_filter_sweep<true, 2, true>), g, dim3(256), 0, s, Bs, stat, rows, fast_on);
+    // frames whose writer hands the pixels to the post stages (DevBuffers::post): the emitting pass, then the zero-luma repair pass
+    const int pst = (stage_mask >> (8 + kSweepPostShift)) & 63;
+#define JXL_SWEEP_POST(bit, G, E) if (pst & (bit)) { hipLaunchKernelGGL((k_filter_sweep<G, E, false, 1>), g, dim3(256), 0, s, Bs, stat, rows, fast_on); \
+                                                        hipLaunchKernelGGL((k_filter_sweep<G, E, false, 2>), g, dim3(256), 0, s, Bs, stat, rows, fast_on); }
+    JXL_SWEEP_POST(1, false, 0) JXL_SWEEP_POST(2, false, 1) JXL_SWEEP_POST(4, false, 2) JXL_SWEEP_POST(8, true, 0) JXL_SWEEP_POST(16, true, 1) JXL_SWEEP_POST(32, true, 2)
+#undef JXL_SWEEP_POST
     if (!(stage_mask & (2 | 32))) return;                       // 32: a composed frame — stage by stage whatever its filters
   }
   dim3 grid((max_w + 63) / 64, (max_h + 3) / 4, nframes);

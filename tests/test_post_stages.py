@@ -308,6 +308,9 @@ def test_writer_post_equals_decode_then_fused_post_stage():
             img = synth.photo_like(520, 300, seed=5, bits=16)
             img[:40] = 0; img[120:180, 100:400] = 0; img[:, 500:] = 0                      # letterbox bars and a black rectangle: rows with pixels of zero luma
             files["live_pq16_epf3_black_bars"] = jxl_ref.encode(img, effort=7, distance=1.0, epf=3, primaries=9, transfer=16, intensity_target=4000.0)
+            # the same picture with the encoder's own filter choice (Gaborish + one EPF iteration: the column sweep's post instantiations, round 5) and an 8-bit HLG one
+            files["live_pq16_sweep_black_bars"] = jxl_ref.encode(img, effort=7, distance=1.0, primaries=9, transfer=16, intensity_target=4000.0)
+            files["live_hlg8_sweep_black_bars"] = jxl_ref.encode((img >> 8).astype(np.uint8), effort=7, distance=2.0, primaries=9, transfer=18, intensity_target=1000.0)
     except Exception:
         pass
     dec = J.JxlDecoder(0)
@@ -344,6 +347,17 @@ def test_writer_post_equals_decode_then_fused_post_stage():
     # a batch: frames that emit the Bitmap from their last stage next to frames that take the pass behind the writer
     api, cfg = 29, J.PreferredColorConfig.RGBA_F16
     names = ["v160x120_16bit_pq2100_epf3", "v160x120_16bit_pq2100_epf3", "v160x120_16bit_pq2100_epf3"]
+    wants = [expected(files[n], cfg, api)[0] for n in names]
+    dec.set_writer_post(True, cfg, api)
+    outs = [torch.zeros(wv.size, dtype=torch.uint8, device="cuda") for wv in wants]
+    torch.cuda.synchronize()
+    dec.decode_batch_to_device([files[n] for n in names], [o.data_ptr() for o in outs], [o.numel() for o in outs])
+    torch.cuda.synchronize()
+    for o, wv, n in zip(outs, wants, names):
+        assert np.array_equal(o.cpu().numpy(), wv), n
+    # ... and a batch of column-sweep frames (RGB and RGBA) whose sweep emits the Bitmap format
+    api, cfg = 29, J.PreferredColorConfig.RGB_565
+    names = ["v264x520_e7", "va300x520_e7", "v264x520_e7"]
     wants = [expected(files[n], cfg, api)[0] for n in names]
     dec.set_writer_post(True, cfg, api)
     outs = [torch.zeros(wv.size, dtype=torch.uint8, device="cuda") for wv in wants]
