@@ -929,7 +929,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   if (need_pool) { lf_pool_bytes = kModPoolBytes; pool_missed = true; return kRetryPool; }
   if (pool_missed) {
     pool_missed = false;
-    const int want = lf_pool_clamp(pool_want + 4096);      // + headroom: the next flights' frames differ a little (256 distinct bench frames: 12 - 25 KB), every further miss repeats a flight
+    const int want = lf_pool_clamp(pool_want + 2048);      // + headroom: the next flights' frames differ a little (256 distinct bench frames: 12 - 25 KB), every further miss repeats a flight
     lf_pool_floor = std::max(lf_pool_floor, want);
     for (int cur = g_lf_pool_floor.load(); cur < want && !g_lf_pool_floor.compare_exchange_weak(cur, want);) {}
   }
