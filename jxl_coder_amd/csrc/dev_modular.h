@@ -12,6 +12,7 @@
 
 namespace jxlamd {
 
+constexpr int kLfMaxCh = 40;          // channel descriptors of an LF-group workgroup: 3 LF channels, 4 HF-metadata channels, <= 32 ModularLfGroup channels (host_parse.cpp)
 constexpr int kModMaxW = 256;         // widest channel a device stream may carry (LF group = 256 LF samples; 256-px lossless groups)
 constexpr int kWpMaxW = 256;
 constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS
@@ -71,7 +72,8 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   const DevTreeNode *tree;            // first tree_ncache nodes of the stream's tree
   int32_t alias_lds, ctx_lds, tree_ncache, ctx_off;   // ctx_off: byte offset of the context map inside the pool
   DevModStream st;
-  DevChanOut ch[kModMaxCh];           // channel descriptors of the current stream
+  DevChanOut *ch;                     // channel descriptors of the current stream: an array of the KERNEL's choosing (LDS) — the LF kernels keep 40 behind their table pool,
+                                      // the Modular-frame kernels kModMaxCh (round 5: 3 KB of every LF workgroup's fixed LDS were descriptors only the latter use)
   int32_t grp_dec;                    // channels the current group stream carries after its own transforms' meta-apply (palette channels in front)
   int32_t grp_src[kModMaxGroupCh], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header

@@ -322,17 +322,29 @@ __device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <
 // libjxl's non-streaming encoder writes ONE global tree for all Modular streams of a frame (39 clusters and log_alpha 7 in the
 // reference's 4K demo photographs; the LF channels use 28 of them).  log_alpha 5..8: 4 << log_alpha bytes of entries per cluster.
 // Returns false (pool untouched) when the tables do not fit or a symbol >= 128 can occur.
-__device__ __forceinline__ int wave_packed_bytes(uint64_t used, int log_alpha) { return __builtin_popcountll(used) * ((4 << log_alpha) + 256); }
-__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t used, int log_alpha, DevModScratch &S, int lane) {
-  if (log_alpha < 5 || log_alpha > 8 || wave_packed_bytes(used, log_alpha) > S.pool_bytes) return false;
-  const int table = 1 << log_alpha, nc = __builtin_popcountll(used);
-  bool bad = false;
-  if (log_alpha == 8)
-    for (uint64_t m = used; m; m &= m - 1) {
-      const int s = __builtin_ctzll(m);
-      for (int i = lane; i < table; i += 64) { const DevAlias e = galias[(s << 8) + i]; bad |= (i >= 128 && e.freq0 != 0) || e.right >= 128; }
+// Frequency tables sized by the alphabet (round 5): the largest symbol the used clusters can produce + 1, rounded up to a power of two >= 16 — libjxl's LF
+// residual tokens stay below 64, so a cluster costs 512 + 128 bytes at log_alpha 7 instead of 768: 28 clusters 17.5 KB instead of 21 KB, which with the channel
+// descriptors out of the fixed part lets a fourth LF stream into a CU.  0: a symbol >= 128 can occur (not packed).
+__device__ __forceinline__ int wave_alias_dsz(const DevAlias *galias, uint64_t used, int log_alpha, int lane) {
+  const int table = 1 << log_alpha;
+  int mx = 0;
+  for (uint64_t m = used; m; m &= m - 1) {
+    const int s = __builtin_ctzll(m);
+    for (int i = lane; i < table; i += 64) {
+      const DevAlias e = galias[(s << log_alpha) + i];
+      if (e.freq0 != 0 && i > mx) mx = i;
+      if (e.freq1 != 0 && (int)e.right > mx) mx = (int)e.right;
     }
-  if (__ballot(bad)) return false;
+  }
+  for (int d = 32; d; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+  int dsz = 16;
+  while (dsz <= mx) dsz <<= 1;
+  return dsz > 128 ? 0 : dsz;
+}
+__device__ __forceinline__ int wave_packed_bytes(uint64_t used, int log_alpha, int dsz) { return __builtin_popcountll(used) * ((4 << log_alpha) + 2 * dsz); }
+__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t used, int log_alpha, int dsz, DevModScratch &S, int lane) {
+  if (log_alpha < 5 || log_alpha > 8 || dsz <= 0 || wave_packed_bytes(used, log_alpha, dsz) > S.pool_bytes) return false;
+  const int table = 1 << log_alpha, nc = __builtin_popcountll(used);
   __syncthreads();
   uint32_t *ent = (uint32_t *)S.pool;
   uint16_t *D = (uint16_t *)((uint8_t *)S.pool + ((size_t)nc << (log_alpha + 2)));
@@ -342,9 +354,9 @@ __device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t
     for (int i = lane; i < table; i += 64) {
       const DevAlias e = galias[(s << log_alpha) + i];
       ent[(cid << log_alpha) + i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
-      if (i < 128) D[(cid << 7) + i] = e.freq0;
+      if (i < dsz) D[cid * dsz + i] = e.freq0;
     }
-    for (int i = table + lane; i < 128; i += 64) D[(cid << 7) + i] = 0;       // symbols beyond the table never occur
+    for (int i = table + lane; i < dsz; i += 64) D[cid * dsz + i] = 0;       // symbols beyond the table never occur
   }
   __syncthreads();
   return true;
@@ -699,10 +711,12 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       uint64_t used = 0;                             // clusters of this channel's leaves
       for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_lclu, j) & 63);
       const int la_p = ev.log_alpha;
-      mod_pool_want(S, wave_packed_bytes(used, la_p), lane);
+      const int dsz = wave_alias_dsz(evg.alias, used, la_p, lane);
+      const int packed = dsz ? wave_packed_bytes(used, la_p, dsz) : kModPoolBytes + 1;
+      if (dsz) mod_pool_want(S, packed, lane);
       // the lean build has no general loop to fall back to: a pool sized by the previous flight that is too small for this channel is a retry
-      if (!kGeneral && wave_packed_bytes(used, la_p) > S.pool_bytes && wave_packed_bytes(used, la_p) <= kModPoolBytes) return kErrNeedPool;
-      if (wave_packed_bytes(used, la_p) <= S.pool_bytes) {
+      if (!kGeneral && packed > S.pool_bytes && packed <= kModPoolBytes) return kErrNeedPool;
+      if (packed <= S.pool_bytes) {
       // rank the thresholds; lane c then holds a value with exactly c thresholds below it
       int rank = 0;
       for (int j = 0; j < ni; j++) { const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }
@@ -718,11 +732,11 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
         const int cid = __builtin_popcountll(used & ((1ull << (clu & 63)) - 1ull));      // compact index of the cluster in the packed pool
-        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + (cid << 8); my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
+        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + cid * 2 * dsz; my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
       }
       __syncthreads();
       // once the pool holds packed tables the other loops of this stream read their tables through L2 (or restage them compactly)
-      if (wave_pack_alias(evg.alias, used, la_p, S, lane)) {   // per channel: the set of clusters may differ
+      if (wave_pack_alias(evg.alias, used, la_p, dsz, S, lane)) {   // per channel: the set of clusters may differ
         pool_packed = true;                            // the pool no longer holds the stream's 8-byte tables / context map
         wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/0);
         continue;

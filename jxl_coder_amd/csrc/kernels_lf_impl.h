@@ -11,7 +11,9 @@ namespace jxlamd {
 template <bool kGeneral>
 __device__ __forceinline__ void lf_group_kernel(const DevBuffers &B, const DevAux &A, int g, int pool_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lf_smem[];
-  lf_group_body<true, kGeneral>(B, A, *(DevModScratch *)lf_smem, g, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
+  DevModScratch &S = *(DevModScratch *)lf_smem;
+  S.ch = (DevChanOut *)(lf_smem + offsetof(DevModScratch, pool) + pool_bytes);      // every lane stores the same value; the body's first barrier orders it
+  lf_group_body<true, kGeneral>(B, A, S, g, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
 // batch variants: block -> (frame, local group) through a small map; the per-frame DevBuffers live in HBM
 template <bool kGeneral>
@@ -27,8 +29,8 @@ __device__ __forceinline__ void lf_group_batch_kernel(const DevBuffers *__restri
 }
 // dynamic LDS of a launch; `kernel`: opt in once to more than the default limit
 inline size_t lf_lds_bytes(const void *kernel, bool *once, int pool_bytes) {
-  if (!*once) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(offsetof(DevModScratch, pool) + kModPoolBytes)); *once = true; }
-  return offsetof(DevModScratch, pool) + (size_t)pool_bytes;
+  if (!*once) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(offsetof(DevModScratch, pool) + kModPoolBytes + kLfMaxCh * sizeof(DevChanOut))); *once = true; }
+  return offsetof(DevModScratch, pool) + (size_t)pool_bytes + kLfMaxCh * sizeof(DevChanOut);
 }
 // the general builds' launchers (their own translation units)
 void launch_lf_groups_general(const DevBuffers &B, const DevAux &A, int n, int pool_bytes, hipStream_t s);

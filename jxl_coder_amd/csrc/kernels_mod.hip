@@ -9,10 +9,16 @@ namespace jxlamd {
 // ---- Modular-encoded frames
 __global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock());
 }
 __global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
 }
 // ModularLfGroup streams of a Modular-encoded frame (section 1 + g holds nothing else there)
@@ -31,6 +37,9 @@ __device__ __forceinline__ void mod_lfgroup_kernel(const DevBuffers &B, DevModSc
 }
 __global__ void __launch_bounds__(64) k_mod_lfgroup(DevBuffers B) {
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   mod_lfgroup_kernel(B, S, (int)blockIdx.x);
 }
 __global__ void __launch_bounds__(256) k_mod_op(DevBuffers B, int op, size_t n) {
@@ -53,12 +62,18 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
 // ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
 __global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   const DevFrame &F = frame_of(Bs[blockIdx.x]);
   if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
   mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
 }
 __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map) {
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   const DevBuffers &B = Bs[f];
   const DevFrame &F = frame_of(B);
@@ -67,6 +82,9 @@ __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const 
 }
 __global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *Bs) {      // grid (max LF groups, frames)
   __shared__ DevModScratch S;
+  __shared__ DevChanOut chbuf[kModMaxCh];
+  S.ch = chbuf;                                       // (every lane stores the same value)
+  __syncthreads();
   const DevBuffers &B = Bs[blockIdx.y];
   const DevFrame &F = frame_of(B);
   if (!F.is_modular || F.mod_lf_nch <= 0 || (int)blockIdx.x >= F.num_lf_groups || frame_failed(B)) return;

@@ -156,7 +156,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   const std::vector<uint8_t> &stat = static_tables();
   if (plan.modular) {
     const DevFrame &F = *(const DevFrame *)tables.data();
-    DevModScratch *MS = new DevModScratch();
+    DevModScratch *MS = new DevModScratch(); std::vector<DevChanOut> chbuf(kModMaxCh); MS->ch = chbuf.data();
     mod_global_body(B, *MS, 0, 1, NoSync());
     for (int g = 0; F.mod_lf_nch > 0 && g < plan.num_lf_groups && !err; g++) {       // ModularLfGroup streams (k_mod_lfgroup)
       const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
@@ -177,7 +177,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     compose_tail(plan, B, F, out_bits, refs, stat.data());
     return 0;
   }
-  DevModScratch *MS = new DevModScratch();
+  DevModScratch *MS = new DevModScratch(); std::vector<DevChanOut> chbuf(kModMaxCh); MS->ch = chbuf.data();
   uint64_t mod_end = 0; B.mod_end_bit = &mod_end;
   if (plan.has_ec) mod_global_body(B, *MS, 0, 1, NoSync());       // GlobalModular part of the extra channels: before LfGroup 0
   for (int g = 0; g < plan.num_lf_groups; g++) lf_group_body(B, A, *MS, g, 0, 1, NoSync());
@@ -241,7 +241,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (err) { g_err = flag_message(err, "PassGroup"); return -2; }
   if (plan.has_ec) {                          // extra channels (alpha): same order as jxlamd_decoder::launch_extra_channels
     const DevFrame &F = *(const DevFrame *)tables.data();
-    DevModScratch *MS2 = new DevModScratch();
+    DevModScratch *MS2 = new DevModScratch(); std::vector<DevChanOut> chbuf2(kModMaxCh); MS2->ch = chbuf2.data();
     if (F.mod_first_group_ch < F.mod_nch) for (int g = 0; g < plan.num_groups && !err; g++) mod_group_body(B, *MS2, g, 0, 1, NoSync());
     delete MS2;
     if (err) { g_err = flag_message(err, "extra channels"); return -2; }
