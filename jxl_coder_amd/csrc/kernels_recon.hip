@@ -24,7 +24,9 @@ constexpr int kStrategyDct32 = 5;
 // On gfx950 the f32 MFMA peak equals the f32 VALU peak (157 TFLOP/s both), so this is a change of execution unit — it takes the
 // multiply-adds off the VALU that the co-resident entropy waves compete for — not a change of arithmetic throughput.
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-__device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const float *S, float *T, const float *CC, int bx, int by, int tid) {
+// ccr[st] = cc[2 st + (lane >> 5)][lane & 31]: the cosine operand of step st of BOTH passes (pass 1 multiplies by cc[u][x], pass 2 by cc[v][y], same lane map) —
+// sixteen registers loaded once per workgroup instead of a 4 KB table in LDS (round 5: LDS next to resident LF streams is what these workgroups wait for)
+__device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const float *S, float *T, const float (&ccr)[16], int bx, int by, int tid) {
   const DevFrame &F = frame_of(B);
   const int wave = tid >> 6, lane = tid & 63;
   const int j = lane & 31, kh = lane >> 5;
@@ -37,7 +39,7 @@ __device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const floa
 #pragma unroll
     for (int st = 0; st < 16; st++) {
       const int u = 2 * st + kh;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Sc[u * 32 + j], CC[u * 32 + j], acc, 0, 0, 0);      // A[v][u] = S[u][v], B[u][x] = cc[u][x]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Sc[u * 32 + j], ccr[st], acc, 0, 0, 0);      // A[v][u] = S[u][v], B[u][x] = cc[u][x]
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) Tc[((r & 3) + 8 * (r >> 2) + 4 * kh) * 32 + j] = acc[r];
@@ -50,7 +52,7 @@ __device__ __forceinline__ void recon_dct32_mfma(const DevBuffers &B, const floa
 #pragma unroll
     for (int st = 0; st < 16; st++) {
       const int v = 2 * st + kh;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(CC[v * 32 + j], Tc[v * 32 + j], acc, 0, 0, 0);      // A[y][v] = cc[v][y], B[v][x] = T[v][x]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ccr[st], Tc[v * 32 + j], acc, 0, 0, 0);      // A[y][v] = cc[v][y], B[v][x] = T[v][x]
     }
     float *out = B.plane_a[wave] + (size_t)(by * 8) * (size_t)F.pw + (size_t)(bx * 8 + j);
 #pragma unroll
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *Bs, cons
 // DCT32x32 blocks only (98 % of the area of smooth 4K content): half the LDS of the general medium kernel (the second pass runs in
 // place: wave c reads all of channel c before it writes) and its own, smaller register footprint — what the data-parallel kernels can
 // use next to resident entropy waves is what decides their speed in a flight mix.
-struct ReconDct32Lds { float S[3 * 1024]; float CC[1024]; float LL[96]; };
+struct ReconDct32Lds { float S[3 * 1024]; float LL[96]; };
 template <bool kSparse>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_dct32_b(const DevBuffers *Bs, const uint8_t *stat) {
   __shared__ __attribute__((aligned(16))) ReconDct32Lds L;
@@ -448,9 +450,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   const DevStatic &ST = *(const DevStatic *)stat;
   const uint32_t count = B.big_count[0];
   if (blockIdx.x >= count) return;
+  float ccr[16];
   {
     const float *cc = st_f(stat, ST.cos_off[5]);
-    for (int i = tid; i < 1024; i += 256) L.CC[i] = cc[i];
+    const int lane = tid & 63;
+#pragma unroll
+    for (int st = 0; st < 16; st++) ccr[st] = cc[(2 * st + (lane >> 5)) * 32 + (lane & 31)];
     if (tid < 16) L.LL[tid] = st_f(stat, ST.cos_off[2])[tid];
     else if (tid < 20) L.LL[tid] = (st_f(stat, ST.llf_off) + 64)[tid - 16];
   }
@@ -461,7 +466,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     __syncthreads();                                 // the previous block's second pass has finished reading S
     recon_dct32_front<kSparse>(B, stat, ST, L.S, L.LL, bx, by, tid);
     __syncthreads();
-    recon_dct32_mfma(B, L.S, L.S, L.CC, bx, by, tid);
+    recon_dct32_mfma(B, L.S, L.S, ccr, bx, by, tid);
   }
 }
 // The 512 / 1024-coefficient blocks that are NOT DCT32x32 (DCT16x32, 32x16, 8x32, ... — a few per cent of the blocks), one channel at a
