@@ -51,7 +51,9 @@ def distinct_frames(n, budget_s=420, kind="c3"):
                        capture_output=True, text=True, timeout=budget_s, cwd="/tmp")
     except Exception:  # noqa: BLE001 — whatever was finished in time is used
         pass
-    files = [os.path.join(out, (f"syn4k_q90_seed{i}.jxl" if kind == "c3" else f"syn4k_pq16_epf3_seed{i}.jxl")) for i in range(n)]
+    files = [os.path.join(out, (f"syn4k_q90_seed{i}.jxl" if kind == "c3" else f"mixed_seed{i}.jxl" if kind == "mixed" else f"syn4k_pq16_epf3_seed{i}.jxl")) for i in range(n)]
+    if kind == "mixed":
+        return files if all(os.path.exists(f) for f in files) else None
     files = [f for f in files if os.path.exists(f)]
     return files if len(files) > (len(FRAMES) if kind == "c3" else 0) else None
 
@@ -219,6 +221,133 @@ def run_c4(args, rank, local, world):
         "cpu_baseline": cpu}))
 
 
+def run_mixed(args, rank, local, world):
+    """Content that is NOT a q90 photograph, at the reference encoder's own defaults: a step = a batch of --batch (64) frames, by seed % 3
+    a 1920x1080 screenshot (distance 1, effort 7: patch dictionary = a reference frame + the main frame), a 1920x1080 lossy RGBA photograph (VarDCT colour +
+    squeezed lossy Modular alpha) and a 3840x2160 photograph at distance 12 (coded at half size and upsampled 2x) -> RGBA8.  Frames go through
+    jxlamd_decode_batch_resident in flights like the c3 workload; value = OUTPUT megapixels / s."""
+    import threading
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import jxl_coder_amd as J
+    from jxl_coder_amd.shard import max_over_ranks
+    argv = " ".join(sys.argv[1:])
+    B = args.batch if "--batch" in argv else 64
+    P = max(1, min(args.inflight if "--inflight" in argv else 16, B))
+    ndist = args.distinct if "--distinct" in argv else 64
+    if world > 1:
+        if rank == 0:
+            distinct_frames(ndist, kind="mixed")
+        dist.barrier()
+    files = distinct_frames(ndist, kind="mixed")
+    if not files:
+        raise SystemExit("--workload mixed needs the reference's encoder (oracle/_ref) to make its frames on this box")
+    datas = [open(f, "rb").read() for f in files]
+    sizes = [J.JxlCoder.getSize(d) for d in datas]
+    L = J.api.lib()
+    outb = []
+    for d in datas:
+        n = C.c_size_t()
+        if L.jxlamd_output_size(d, len(d), 0, C.byref(n)) != 0:
+            raise SystemExit("jxlamd_output_size failed on a generated frame")
+        outb.append(int(n.value))
+    total = args.steps * B
+    NCTX = max(1, min(args.contexts if "--contexts" in argv else 8, (total + P - 1) // P))
+    decs = [J.JxlDecoder(local) for _ in range(NCTX)]
+    d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(f"cuda:{local}") for d in datas]
+    d_outs = [[torch.empty(max(outb), dtype=torch.uint8, device=f"cuda:{local}") for _ in range(P)] for _ in range(NCTX)]
+
+    def run_frames(n):
+        lock = threading.Lock(); todo = []; done = 0; errors = []; acc = {}
+        while done < n:
+            p = min(P, n - done); todo.append((done, p)); done += p
+        todo.reverse()
+
+        def worker(c):
+            try:
+                torch.cuda.set_device(local)
+                while True:
+                    with lock:
+                        if not todo:
+                            return
+                        first, p = todo.pop()
+                    ids = [(rank + first + j) % len(datas) for j in range(p)]
+                    decs[c].decode_batch_to_device([datas[i] for i in ids], [t.data_ptr() for t in d_outs[c][:p]], [outb[i] for i in ids], [d_ins[i].data_ptr() for i in ids])
+                    t = decs[c].last_timing()
+                    with lock:
+                        for k, v in t.items():
+                            acc[k] = acc.get(k, 0.0) + v
+                        acc["flights"] = acc.get("flights", 0) + 1
+                        acc["mp"] = acc.get("mp", 0.0) + sum(sizes[i][0] * sizes[i][1] for i in ids) / 1e6
+                        acc["bytes"] = acc.get("bytes", 0) + sum(len(datas[i]) + outb[i] for i in ids)
+            except BaseException as e:  # noqa: BLE001 — re-raised in the main thread
+                errors.append(e)
+        th = [threading.Thread(target=worker, args=(c,)) for c in range(NCTX)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+        return acc
+    run_frames(P * NCTX)
+    for _ in range(args.warmup):
+        run_frames(B)
+    # sequential single-frame latency of one frame of each kind
+    lat = {}
+    for k, name in enumerate(("screenshot_1080p_patches", "rgba_1080p_lossy_alpha", "photo_4k_distance12_upsampled")):
+        i = next((j for j in range(len(datas)) if j % 3 == k), None)
+        if i is None:
+            continue
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter(); decs[0].decode_to_device(datas[i], d_outs[0][0].data_ptr(), outb[i], data_dev_ptr=d_ins[i].data_ptr()); best = min(best, time.perf_counter() - t)
+        lat[name] = round(best * 1e3, 3)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = run_frames(total)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    if rank != 0:
+        return
+    mp_total = acc["mp"] * world
+    value = mp_total / elapsed
+    gbps = acc["bytes"] * world / elapsed / 1e9
+    flights = max(int(acc.get("flights", 1)), 1)
+    cpu = {"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": "skipped"}
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import jxl_ref        # checker / baseline only
+            tt, mm, n = 0.0, 0.0, 0
+            t_end = time.time() + 12.0
+            while time.time() < t_end and n < 3 * len(datas):
+                i = n % len(datas)
+                t = time.perf_counter(); jxl_ref.decode(datas[i], threads=0); tt += time.perf_counter() - t; mm += sizes[i][0] * sizes[i][1] / 1e6; n += 1
+            cpu = {"value": round(mm / tt, 1), "unit": "MP/s", "cores": min(os.cpu_count() or 1, 135), "kind": "reference",
+                   "sample": f"{n} decodes walking the same mixed batch, one frame at a time, by the reference's libjxl 0.12 (oracle/_ref), threads = JxlResizableParallelRunnerSuggestThreads: {tt:.1f} s"}
+        except Exception as e:  # noqa: BLE001
+            cpu["sample"] = f"CPU baseline unavailable: {e}"
+    print(json.dumps({
+        "metric": "decoded MP/s (mixed content: screenshots with patches, lossy RGBA, distance-12 upsampled photographs -> RGBA8)", "value": round(value, 2), "unit": "MP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "value_inputs": "compressed bytes resident in HBM",
+        "config": {"workload": f"mixed (not a BASELINE config; VERDICT r4 2c): one step = {B} frames, seed % 3 -> 1920x1080 screenshot d1 e7 (patches: reference frame + main frame) / 1920x1080 lossy RGBA photograph "
+                               f"d1 e7 (VarDCT + squeezed Modular alpha) / 3840x2160 photograph d12 e7 (2x upsampled); {len(datas)} distinct frames made on this box by the reference's encoder; "
+                               "every frame a complete decode; compressed bytes and RGBA8 outputs resident in HBM",
+                   "frames_per_step_per_gpu": B, "frames_in_flight": P, "decoder_contexts": NCTX, "distinct_frames": len(datas), "output_MP_per_step": round(acc["mp"] / args.steps, 2),
+                   "frame_bytes_mean": int(sum(map(len, datas)) / len(datas)), "single_frame_latency_ms": lat,
+                   "stage_ms_per_flight": {k: round(v / flights, 3) for k, v in acc.items() if k.endswith("_ms")}},
+        "roofline": {"bound": "hbm", "achieved": round(gbps, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 6), "traffic": None,
+                     "kernel": "whole decode (all kernels of all frames; per-kernel figures: the c3 line and profiles/)", "algorithmic_bytes_per_launch": int(acc["bytes"] / flights)},
+        "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,10 +359,11 @@ def main():
     ap.add_argument("--share", type=int, default=1, help="contexts per set of HF-phase pools (jxlamd_decoder_share_pools): with 2, --contexts 32 keeps 16 pool sets busy — a context's LF stage "
                     "overlaps its partner's PassGroup / reconstruction / filter stages")
     ap.add_argument("--inflight", type=int, default=64, help="frames decoded per batched flight (1 = strictly sequential)")
-    ap.add_argument("--workload", choices=["c3", "c5", "c4"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
+    ap.add_argument("--workload", choices=["c3", "c5", "c4", "mixed"], default="c3", help="c3 (default): BASELINE configs[2], 256 x 4K VarDCT q90 -> RGBA8.  c5: configs[4], a batch of 64 x "
                     "4K Rec.2100 PQ 16-bit EPF=3 frames -> RGBA16 -> colour matrix + Rec.2408 tone map -> RGBA_F16 (post stages fused, jxlamd_post_fused).  "
                     "c4: configs[3], ONE 32768x32768 VarDCT q90 frame (JXLAMD_C4_SIZE) as bands of group rows over the ranks (8 bands on one GPU), "
-                    "halo rows by RCCL send/recv; a step = one decode of the frame (strong scaling)")
+                    "halo rows by RCCL send/recv; a step = one decode of the frame (strong scaling).  mixed: 64 frames per step of content that is not a q90 photograph "
+                    "(screenshots with patches, lossy RGBA, distance-12 upsampled photographs), see run_mixed")
     ap.add_argument("--c5-post", choices=["writer", "pass"], default="writer", help="--workload c5: A10 + A11 inside the decoder's writer (jxlamd_decoder_set_writer_post: the last "
                     "EPF stage emits RGBA_F16, the RGBA16 image is never stored) or as one fused pass over the stored RGBA16 (jxlamd_post_fused, rounds 2-3)")
     ap.add_argument("--distinct", type=int, default=256, help="distinct seeded frames to generate for the batch (SURVEY.md §8d: 256; 0 = cycle the 8 committed ones)")
@@ -265,6 +395,8 @@ def main():
     from jxl_coder_amd.shard import max_over_ranks
     if args.workload == "c4":
         return run_c4(args, rank, local, world)
+    if args.workload == "mixed":
+        return run_mixed(args, rank, local, world)
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
     frames = FRAMES

@@ -347,6 +347,8 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   S.A.lf_times = (uint64_t *)((uint8_t *)S.misc.p + 4096 + (size_t)plan.num_lf_groups * 8);
   // frames of a batched flight (in_flight): one k_clear_b launch clears these for all of them
   if (!in_flight) HIPCHECK(hipMemsetAsync(S.misc.p, 0, 4096 + (size_t)plan.num_lf_groups * 72, stream));
+  { static const uint32_t dbg_mod = getenv("JXLAMD_DEBUG_MOD") ? (uint32_t)atoi(getenv("JXLAMD_DEBUG_MOD")) : 0u;      // measurement switches of the block-form tree loop (single decodes only)
+    if (dbg_mod && !in_flight) { static uint32_t word; word = dbg_mod; HIPCHECK(hipMemcpyAsync((uint8_t *)S.misc.p + 16, &word, 4, hipMemcpyHostToDevice, stream)); } }
   if (!plan.modular) {
     if (!in_flight) HIPCHECK(hipMemsetAsync(S.cells8[1].p, 0, ncell, stream));
     // The reconstruction kernels clear every coefficient they consume, so a slot whose previous decode completed is
@@ -497,6 +499,7 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   (void)flags;
   memcpy(head, h_flags.p, sizeof(head));
   derr = head[0];
+  serial_streams += head[2]; block_tree_channels += head[3];
   if (!S.plan.modular) lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(head[1]));
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
   if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
@@ -645,7 +648,17 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   if (trace) HIPCHECK(hipEventRecord(ev[5], stream));
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
-    const bool composed = S.plan.compose || !S.plan.refs.empty();      // patches / reference frames: one by one, like a single decode
+    // Frames that draw on other frames (patch dictionaries, LF frames, animation layers over a canvas) keep state in the context's reference slots and are
+    // decoded one by one, like a single decode.  A composed frame that stands alone — coded at a lower resolution and upsampled (the reference's quality
+    // <= 12), with noise, with splines — rides in the flight: its entropy stages in the flight's launches, its
+    // filters stage by stage into the plane set it borrows, its composition stages (launch_compose_tail) right behind its sub-batch's filters.
+    bool rides = false;
+    if (S.plan.compose && S.plan.refs.empty() && S.plan.error.empty() && !S.plan.tables.empty() && !S.plan.modular && !S.plan.single_section && S.plan.save_slot < 0) {
+      const DevFrame *Fc = (const DevFrame *)S.plan.tables.data();
+      static const bool compose_in_flights = !(getenv("JXLAMD_COMPOSE_IN_FLIGHTS") && atoi(getenv("JXLAMD_COMPOSE_IN_FLIGHTS")) == 0);      // A/B switch for measurements
+      rides = compose_in_flights && !Fc->blend && !Fc->use_lf_frame && !Fc->no_output && Fc->num_patches == 0 && !Fc->subsampled;      // (subsampled chroma: the flights' list-driven reconstruction kernels do not place such blocks)
+    }
+    const bool composed = (S.plan.compose || !S.plan.refs.empty()) && !rides;
     if (composed && S.plan.error.empty()) { int rc = decode_refs(S, flags); if (rc) return rc; }
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
@@ -705,11 +718,11 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const int nb = (int)batched.size();
   size_t max_npx = 0, max_coef = 0;
   int max_cells = 0, max_w = 0, max_h = 0, stage_mask = 0;
-  bool all_post = true;
+  bool all_post = true, compose_filters = false;
   for (int i : batched) {
     const FrameSlot &S = slot((size_t)i);
     const DevFrame *F = (const DevFrame *)S.plan.tables.data();
-    if (!F->gab && !F->epf_iters) stage_mask |= 1 << 4;       // no filter stage to fuse the writer into: stand-alone writer launch
+    if (!F->gab && !F->epf_iters && !F->compose) stage_mask |= 1 << 4;       // no filter stage to fuse the writer into: stand-alone writer launch
     max_npx = std::max(max_npx, (size_t)S.plan.xb * S.plan.yb * 64);
     max_coef = std::max(max_coef, (size_t)S.plan.num_groups * 65536);
     max_cells = std::max(max_cells, S.plan.xb * S.plan.yb); max_w = std::max(max_w, S.plan.width); max_h = std::max(max_h, S.plan.height);
@@ -717,7 +730,8 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (F->epf_iters >= 3) stage_mask |= 2;
     if (F->epf_iters >= 1) stage_mask |= 4;
     if (F->epf_iters >= 2) stage_mask |= 8;
-    if (F->epf_iters <= 2) stage_mask |= sweep_stage_bit(*F, (int)S.pi.out_bits, S.post_active && S.post_fused);     // column-sweep instantiation
+    if (F->compose) { stage_mask |= 32; if (F->gab || F->epf_iters) compose_filters = true; }      // stage by stage into the planes (the per-stage kernels skip the sweep's frames and vice versa)
+    else if (F->epf_iters <= 2) stage_mask |= sweep_stage_bit(*F, (int)S.pi.out_bits, S.post_active && S.post_fused);     // column-sweep instantiation
     if (S.post_active && S.post_fused) stage_mask |= 64;      // the last filter stage emits the Bitmap format (k_filter_b<3, 1> / <3, 2>)
     else all_post = false;
   }
@@ -727,7 +741,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // three planes).  Measured (round 5, quick bench, one box): sub-batches of 16 / 32 / 64 frames 13 020 - 13 050 / 12 940 / 12 590 - 13 150 MP/s — the
   // sub-batch size is not what the rate depends on, although every launch of a busy stream takes 1.5 - 4 ms whatever it computes (k_recon_large_b:
   // 0.07 ms alone, 4 ms in the mix).
-  const int planes_per_set = (stage_mask & 2) ? 6 : 3;
+  const int planes_per_set = ((stage_mask & 2) || compose_filters) ? 6 : 3;      // (a composed frame's filter stages ping-pong too)
   const int plane_sets = plane_sets_env ? plane_sets_env : (int)std::max<size_t>(1, std::min<size_t>(128, plane_budget / ((size_t)planes_per_set * std::max<size_t>(max_npx, 1) * 4)));
   const int hf_sets = std::max(plane_sets, hf_sets_env / plane_sets * plane_sets);
   // HF-phase memory (HfPools): sized now — the frames' DevBuffers carry its addresses — but only held from the PassGroup stage on, so that
@@ -885,9 +899,14 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
-    for (int j0 = 0; j0 < cnt; j0 += plane_sets)
+    for (int j0 = 0; j0 < cnt; j0 += plane_sets) {
       launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse,
                         huge_blocks_seen ? (float *)huge_scratch.p : nullptr);
+      if (stage_mask & 32) for (int j = j0; j < std::min(j0 + plane_sets, cnt); j++) {      // composed frames of the sub-batch: splines / noise / upsampling + their writer, before the plane set moves on
+        FrameSlot &S = slot((size_t)batched[(size_t)(k0 + j)]);
+        if (S.plan.compose) { const int rc = launch_compose_tail(S); if (rc) return rc; }
+      }
+    }
   }
   HIPCHECK(hipEventRecord(ev[4], stream));
   const double t_launched = now();
@@ -911,6 +930,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     const uint32_t *head = (const uint32_t *)h_flags.p + (size_t)k * kFlagWords;
     if (head[17] > 0) large_blocks_seen = true;            // big_count[1]: varblocks with 2048 / 4096 coefficients
+    serial_streams += head[2]; block_tree_channels += head[3];
     if (head[19] > 0 && (!huge_blocks_seen || sparse)) need_huge = true;      // big_count[3]: DCT128 / DCT256 families, and their kernel was not in this flight's launch list
     pool_want = std::max(pool_want, head[1]);
     if (sparse && (head[0] & kErrNeedDense) && !(head[0] & 0xFFFFu & ~kErrNeedDense)) { need_dense = true; continue; }      // (judged again in the dense flight)
@@ -1280,6 +1300,11 @@ int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]) {
 int jxlamd_debug_sparse(const jxlamd_decoder *dec, uint32_t out[2]) {      // {did the last flight hand its coefficients over as sparse lists, flights decoded again densely}
   if (!dec || !out) return JXLAMD_ERR_BUFFER;
   out[0] = dec->last_flight_sparse ? 1u : 0u; out[1] = dec->sparse_misses;
+  return JXLAMD_OK;
+}
+int jxlamd_debug_modular(const jxlamd_decoder *dec, uint64_t out[2]) {      // {Modular streams decoded by the serial walker, channels decoded with their MA tree in block form} since the context was created
+  if (!dec || !out) return JXLAMD_ERR_BUFFER;
+  out[0] = dec->serial_streams; out[1] = dec->block_tree_channels;
   return JXLAMD_OK;
 }
 int jxlamd_debug_lf_phases_frame(jxlamd_decoder *d, int frame, int num_lf_groups, uint64_t *out) {     // frame = slot index inside the last flight

@@ -21,7 +21,7 @@ struct DevAux {
 template <bool kWave = true, bool kGeneral = true, class Sync>
 JXL_DEV void lf_group_body(const DevBuffers &B, const DevAux &A, DevModScratch &S, int g, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
   JXL_STAMP(0);
-  if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = B.err + 1; S.wide_wp = nullptr; }      // word 1 of the frame's flag block: LDS table pool the streams would have liked
+  if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = B.err + 1; S.walk_stat = B.err + 2; S.wide_wp = nullptr; }      // word 1 of the frame's flag block: LDS table pool the streams would have liked
 #ifdef __HIPCC__
   const uint64_t cyc0 = __builtin_readcyclecounter();      // shader clock (s_memtime): with the 100 MHz wall stamps it gives the effective clock
 #endif

@@ -53,6 +53,17 @@ JXL_DEV float alpha_sample_value(const DevFrame &F, int32_t v, bool mul) {
 }
 
 // ------------------------------------------------------------------ bit reader (LSB first)
+// Loads / stores whose address is KNOWN to be HBM (codestream words, frame tables, sample planes), spelled as global-memory accesses: through a generic
+// pointer the compiler emits FLAT instructions, which count on the LDS counter too — every later wait for an LDS read then also waits for the memory
+// access (hundreds of ns), and a lock-step Modular loop does that several times per sample.  (The CPU harness reads the pointer as it is.)
+#ifdef __HIPCC__
+template <class T> __device__ __forceinline__ T gld(const T *p) { return *(const T __attribute__((address_space(1))) *)(uintptr_t)p; }
+template <class T> __device__ __forceinline__ void gst(T *p, T v) { *(T __attribute__((address_space(1))) *)(uintptr_t)p = v; }
+#else
+template <class T> inline T gld(const T *p) { return *p; }
+template <class T> inline void gst(T *p, T v) { *p = v; }
+#endif
+
 struct DevBits {
   const uint32_t *next;     // next aligned word to fetch
   const uint32_t *end;      // first word past the (padded) codestream: reads beyond it yield zeros, never a fault
@@ -68,8 +79,8 @@ JXL_DEV void bits_init(DevBits &b, const uint8_t *base, uint64_t byte_off, uint6
   b.end = (const uint32_t *)(base + ((total_bytes + 48) & ~(uint64_t)3));   // buffers carry >= 64 zero bytes of padding
   uint64_t mis = (uint64_t)(uintptr_t)p & 3;
   b.next = (const uint32_t *)(p - mis);
-  b.buf = (uint64_t)b.next[0] | ((uint64_t)b.next[1] << 32);
-  b.ahead = b.next[2];
+  b.buf = (uint64_t)gld(b.next) | ((uint64_t)gld(b.next + 1) << 32);
+  b.ahead = gld(b.next + 2);
   b.next += 3;
   b.buf >>= 8 * mis;
   b.n = 64 - 8 * (int32_t)mis;
@@ -86,7 +97,7 @@ JXL_DEV void bits_refill(DevBits &b) {     // guarantees >= 32 valid bits
   if (b.n <= 32) {
     b.buf |= (uint64_t)b.ahead << b.n;
     b.n += 32;
-    b.ahead = b.next < b.end ? *b.next : 0u;
+    b.ahead = b.next < b.end ? gld(b.next) : 0u;
     b.next++;
   }
 }

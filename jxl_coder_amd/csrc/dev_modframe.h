@@ -18,10 +18,11 @@ JXL_DEV size_t mod_group_scratch_ints(const DevFrame &F) {
 JXL_DEV int32_t *mod_plane(const DevBuffers &B, const DevFrame &F, int p) { return B.mod_pool + F.mod_plane_off[p]; }
 
 // one stream's channels: whole wave on the GPU, lane 0 alone in the CPU harness
-template <bool kGeneral = true>
+// kBig: with the block form of trees beyond one ballot (the Modular kernels; the LF kernels' ModularLfGroup streams keep the serial walker for those)
+template <bool kGeneral = true, bool kBig = false>
 JXL_DEV uint32_t mod_decode_stream(DevModScratch &S, const DevChanOut *ch, int nch, int stream_id, int tid) {
 #ifdef __HIPCC__
-  return modular_stream_decode_wave<kGeneral>(S, ch, nch, stream_id, tid);
+  return modular_stream_decode_wave<kGeneral, kBig>(S, ch, nch, stream_id, tid);
 #else
   return tid == 0 ? modular_stream_decode(S, ch, nch, stream_id) : 0;
 #endif
@@ -52,7 +53,7 @@ JXL_DEV void inv_rct_planes(int32_t *p0, int32_t *p1, int32_t *p2, size_t n, int
 // ---- GlobalModular: one workgroup; decodes the meta channels and every channel that fits one group
 template <class Sync>
 JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int nthreads, Sync sync) {
-  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
+  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
   const DevFrame &F = frame_of(B);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
@@ -72,7 +73,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
   const int n = F.mod_first_group_ch;
   for (int c = tid; c < n; c += nthreads) { S.ch[c].d = mod_plane(B, F, c); S.ch[c].w = F.mod_w[c]; S.ch[c].h = F.mod_h[c]; S.ch[c].hs = c < F.mod_nb_meta ? (int16_t)-1 : (int16_t)F.mod_hs[c]; S.ch[c].vs = c < F.mod_nb_meta ? (int16_t)-1 : (int16_t)F.mod_vs[c]; }      // (meta channels: shift -1, never a "previous channel" of an image channel)
   sync();
-  uint32_t e = mod_decode_stream(S, S.ch, n, 0, tid);
+  uint32_t e = mod_decode_stream<true, true>(S, S.ch, n, 0, tid);
   if (tid == 0 && e) *B.err |= e | kErrStageLf;
   if (tid == 0 && F.has_ec) *B.mod_end_bit = S.st.b.consumed;      // absolute: the reader started at the section and skipped mod_global_bit
   sync();
@@ -82,7 +83,7 @@ JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int
 // are both >= 3 — squeeze residuals of images beyond 2048 pixels — decoded into the frame planes.  The caller has S.st.b at the stream (in a
 // VarDCT frame it follows the LF coefficients of the same section); rectangles are at most 256 x 256 samples (2048 >> 3).
 JXL_DEV size_t mod_lf_scratch_base(const DevFrame &F) { return ((size_t)F.num_groups + 1) * mod_group_scratch_ints(F); }
-template <bool kGeneral = true, class Sync>
+template <bool kGeneral = true, bool kBig = false, class Sync>
 JXL_DEV uint32_t mod_lfgroup_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xlfg, gy = g / F.xlfg;
@@ -117,7 +118,7 @@ JXL_DEV uint32_t mod_lfgroup_body(const DevBuffers &B, DevModScratch &S, int g, 
   modular_stream_stage(S, tid, nthreads);
   sync();
   const int nst = S.grp_n;
-  uint32_t e = mod_decode_stream<kGeneral>(S, S.ch, nst, 1 + F.num_lf_groups + g, tid);
+  uint32_t e = mod_decode_stream<kGeneral, kBig>(S, S.ch, nst, 1 + F.num_lf_groups + g, tid);
   sync();
   if (e) return e;
   for (int c = 0; c < nst; c++) {
@@ -172,7 +173,7 @@ JXL_DEV int32_t palette_value(const int32_t *pal, int psize, int index, int c, i
 // ModularLfGroup streams); a pass without such a channel in this group has no stream.  Returns false when the group's decode must stop (flagged).
 template <class Sync>
 JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, int pass, int tid, int nthreads, Sync sync) {
-  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; }
+  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xgroups, gy = g / F.xgroups;
   const int gd = F.mod_group_dim;
@@ -240,7 +241,7 @@ JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, i
   sync();
   const int nst = S.grp_n;
   const int sid = 1 + 3 * F.num_lf_groups + 17 + pass * F.num_groups + g;      // ModularAC(group, pass)
-  uint32_t e = mod_decode_stream(S, S.ch, S.grp_dec, sid, tid);
+  uint32_t e = mod_decode_stream<true, true>(S, S.ch, S.grp_dec, sid, tid);
   if (tid == 0 && e) { S.st.err = e; *B.err |= e | kErrStagePass; }
   sync();
   if (S.st.err) return false;

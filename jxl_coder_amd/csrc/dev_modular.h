@@ -71,6 +71,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   const uint8_t *ctx_map;             // LDS when ctx_lds
   const DevTreeNode *tree;            // first tree_ncache nodes of the stream's tree
   int32_t alias_lds, ctx_lds, tree_ncache, ctx_off;   // ctx_off: byte offset of the context map inside the pool
+  int32_t pool_used;                  // bytes of the pool the stream's [alias tables | context map] occupy: what follows is the tree head — or, in the big-tree wave loop, the channel's tree in block form
   DevModStream st;
   DevChanOut *ch;                     // channel descriptors of the current stream: an array of the KERNEL's choosing (LDS) — the LF kernels keep 40 behind their table pool,
                                       // the Modular-frame kernels kModMaxCh (round 5: 3 KB of every LF workgroup's fixed LDS were descriptors only the latter use)
@@ -84,6 +85,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   DevLz lz;                           // LZ77 state of the current stream (serial walker; window in HBM, set by the stream's caller)
   int32_t pool_bytes;                 // bytes of `pool` actually backed by LDS in this launch (kModPoolMin .. kModPoolBytes)
   uint32_t *pool_want;                // where to report (max) the pool bytes this stream's per-channel table sets need; may be null
+  uint32_t *walk_stat;                // two counters (words 2 and 3 of the frame's flag block): streams that went to the serial walker, channels decoded with their tree in block form; may be null
   uint64_t pool[kModPoolBytes / 8];   // LAST member: the kernels allocate only pool_bytes of it
 };
 JXL_DEV void mod_pool_want(DevModScratch &S, int bytes, int tid) {
@@ -224,6 +226,129 @@ JXL_DEV TreeFacts tree_facts(const DevTreeNode *tree, int count, int chan, int s
     stack[sp++] = nd.lchild; stack[sp++] = nd.rchild;
   }
   return f;
+}
+
+// ---- MA trees beyond one ballot (more than 64 decision nodes or leaves after pruning): the tree in BLOCKS for the wave loop (dev_modular_wave.h).
+// A block is a connected piece of the tree with at most 63 decision nodes — so at most 64 exits, each a leaf or the root of another block — cut breadth
+// first, so that a walk crosses ~depth / 6 blocks.  Inside a block the wave evaluates as it does a small tree: lane i decides node i, lane j tests exit j's
+// (must-be-1, must-be-0) masks over the block's decisions.  libjxl's one-shot encoder writes ONE tree for all Modular streams of a frame (a default lossy
+// RGBA photograph: 1015 nodes, 459 leaves for the alpha channel's group streams); the serial walker took 3.6 - 6 us per sample there.
+// Layout (32-bit words from the area's start): DevBigHdr | nodes (prop, split) | exit masks (need1, need0: 4 words) | exit words | (mul, off) of the exits
+// when some leaf has a multiplier / offset | builder's block queue.  Exit word: bit 31 set = block (ni << 25 | first node << 13 | first exit), else leaf
+// (bit 30: has multiplier / offset, predictor << 26, cluster << 18, context).
+constexpr int kBigBlkNodes = 63;
+struct DevBigHdr {
+  int32_t ok, nblocks, nnodes, nexits, nonunit, uses_wp;
+  int32_t off_nodes, off_need, off_exit, off_mulo, off_blk, capB, capE;
+  uint32_t root_word;
+  int32_t pad[2];
+};
+static_assert(sizeof(DevBigHdr) == 64, "DevBigHdr: 16 words");
+struct BigCount { int32_t ni, nl, nonunit, uses_wp, ok; };
+// how large is the tree reachable for (chan, stream)?  ok = 0: a property the wave loops do not evaluate (previous channels), or deeper than the stack
+JXL_DEV BigCount big_tree_count(const DevTreeNode *tree, int count, int chan, int stream, int32_t *stack) {
+  BigCount r; r.ni = r.nl = r.nonunit = r.uses_wp = 0; r.ok = 1;
+  int sp = 0, guard = 0;
+  stack[sp++] = 0;
+  while (sp > 0) {
+    if (++guard > 4 * count + 16) { r.ok = 0; return r; }
+    const DevTreeNode nd = tree[stack[--sp]];
+    if (nd.prop < 0) { r.nl++; if (nd.lchild == 6) r.uses_wp = 1; if (nd.rchild != 1 || nd.offset != 0) r.nonunit = 1; continue; }
+    if (nd.prop == 0 || nd.prop == 1) { const int v = nd.prop == 0 ? chan : stream; stack[sp++] = v > nd.splitval ? nd.lchild : nd.rchild; continue; }
+    if (nd.prop > 15 || sp + 2 > 64) { r.ok = 0; return r; }
+    if (nd.prop == 15) r.uses_wp = 1;
+    r.ni++;
+    stack[sp++] = nd.lchild; stack[sp++] = nd.rchild;
+  }
+  return r;
+}
+// one work-item builds the blocks into `big` (big_bytes of LDS); queue = three arrays of 64 entries (the small-tree builder's DFS stacks)
+JXL_DEV bool big_tree_build(const DevTreeNode *tree, int count, int chan, int stream, const uint8_t *ctx_map, const BigCount &cnt,
+                            int32_t *q_node, uint64_t *q_n1, uint64_t *q_n0, uint32_t *big, int big_bytes) {
+  DevBigHdr &H = *(DevBigHdr *)big;
+  H.ok = 0;
+  if (!cnt.ok || cnt.ni > 4095 || big_bytes < (int)sizeof(DevBigHdr) + 64) return false;
+  const int total = big_bytes / 4, E = 5 + (cnt.nonunit ? 2 : 0);
+  const int off_nodes = 16, off_need = (off_nodes + 2 * cnt.ni + 3) & ~3;
+  int capB = (total - off_need - (cnt.nl - 1) * E) / (E + 2);
+  if (capB < 1) return false;
+  if (capB > cnt.ni + 1) capB = cnt.ni + 1;
+  int capE = cnt.nl + capB - 1;
+  if (capE > 8191) return false;
+  H.nonunit = cnt.nonunit; H.uses_wp = cnt.uses_wp;
+  H.off_nodes = off_nodes; H.off_need = off_need; H.off_exit = off_need + 4 * capE; H.off_mulo = H.off_exit + capE;
+  H.off_blk = H.off_mulo + (cnt.nonunit ? 2 * capE : 0); H.capB = capB; H.capE = capE;
+  int32_t *nodes = (int32_t *)big + off_nodes;
+  uint32_t *need = big + off_need, *exw = big + H.off_exit;
+  int32_t *mulo = (int32_t *)big + H.off_mulo, *blk = (int32_t *)big + H.off_blk;     // blk[2 * b] = root node, blk[2 * b + 1] = the exit (index) of its parent block that names it
+  int nblocks = 1, nnodes = 0, nexits = 0;
+  blk[0] = 0; blk[1] = -1;
+  for (int bk = 0; bk < nblocks; bk++) {
+    const int node_off = nnodes, exit_off = nexits;
+    int ni = 0, nl = 0, head = 0, pend = 1;
+    q_node[0] = blk[2 * bk]; q_n1[0] = 0; q_n0[0] = 0;
+    while (pend > 0) {
+      int idx = q_node[head]; const uint64_t n1 = q_n1[head], n0 = q_n0[head];
+      head = (head + 1) & 63; pend--;
+      DevTreeNode nd = tree[idx];
+      for (int guard = 0; nd.prop == 0 || nd.prop == 1; guard++) {      // static decisions: the channel and the stream are known
+        if (guard > count) return false;
+        const int v = nd.prop == 0 ? chan : stream;
+        idx = v > nd.splitval ? nd.lchild : nd.rchild; nd = tree[idx];
+      }
+      if (nd.prop >= 0 && ni < kBigBlkNodes) {
+        const int i = ni++;
+        if (nnodes >= cnt.ni) return false;
+        nodes[2 * nnodes] = nd.prop; nodes[2 * nnodes + 1] = nd.splitval; nnodes++;
+        int t = (head + pend) & 63;
+        q_node[t] = nd.lchild; q_n1[t] = n1 | (1ull << i); q_n0[t] = n0; pend++;      // decision true  -> left
+        t = (head + pend) & 63;
+        q_node[t] = nd.rchild; q_n1[t] = n1; q_n0[t] = n0 | (1ull << i); pend++;      // decision false -> right
+        continue;
+      }
+      if (nexits >= capE) return false;
+      const int ex = nexits++; nl++;
+      need[4 * ex] = (uint32_t)n1; need[4 * ex + 1] = (uint32_t)(n1 >> 32); need[4 * ex + 2] = (uint32_t)n0; need[4 * ex + 3] = (uint32_t)(n0 >> 32);
+      if (nd.prop < 0) {
+        const uint32_t ctx = (uint32_t)nd.splitval, pred = (uint32_t)nd.lchild;
+        if (ctx >= (1u << 18) || pred > 13) return false;
+        const bool nonunit = nd.rchild != 1 || nd.offset != 0;
+        exw[ex] = (nonunit ? 1u << 30 : 0u) | (pred << 26) | ((uint32_t)ctx_map[ctx] << 18) | ctx;
+        if (cnt.nonunit) { mulo[2 * ex] = nd.rchild; mulo[2 * ex + 1] = nd.offset; }
+      } else {                                       // the block is full: this node roots another one (its word is written when that block is built)
+        if (nblocks >= capB) return false;
+        blk[2 * nblocks] = idx; blk[2 * nblocks + 1] = ex; nblocks++;
+        exw[ex] = 0x80000000u;
+      }
+    }
+    (void)nl;
+    if (exit_off > 8191 || node_off > 4095) return false;
+    const uint32_t word = 0x80000000u | ((uint32_t)ni << 25) | ((uint32_t)node_off << 13) | (uint32_t)exit_off;
+    if (bk == 0) H.root_word = word; else exw[blk[2 * bk + 1]] = word;
+  }
+  H.nblocks = nblocks; H.nnodes = nnodes; H.nexits = nexits; H.ok = 1;
+  return true;
+}
+// reference evaluation of a tree in block form (one work-item; the CPU harness checks the builder with it against the plain walk)
+JXL_DEV uint32_t big_tree_eval(const uint32_t *big, const int32_t *props, int *exit_index) {
+  const DevBigHdr &H = *(const DevBigHdr *)big;
+  uint32_t e = H.root_word; int eidx = 0;
+  while (e >> 31) {
+    const int ni = (int)((e >> 25) & 63), noff = (int)((e >> 13) & 4095), eoff = (int)(e & 8191);
+    uint64_t dec = 0;
+    for (int i = 0; i < ni; i++) { const int32_t *nd = (const int32_t *)big + H.off_nodes + 2 * (noff + i); if (props[nd[0]] > nd[1]) dec |= 1ull << i; }
+    int leaf = -1;
+    for (int j = 0; j <= ni && leaf < 0; j++) {
+      const uint32_t *m = big + H.off_need + 4 * (eoff + j);
+      const uint64_t n1 = m[0] | ((uint64_t)m[1] << 32), n0 = m[2] | ((uint64_t)m[3] << 32);
+      if ((dec & n1) == n1 && (~dec & n0) == n0) leaf = j;
+    }
+    if (leaf < 0) return 0xFFFFFFFFu;
+    eidx = eoff + leaf; e = big[H.off_exit + eidx];
+    if (e == 0x80000000u) return 0xFFFFFFFFu;      // (a block word always carries ni >= 0 and offsets; the bare flag means "never built")
+  }
+  *exit_index = eidx;
+  return e;
 }
 
 // Decode the channels of one modular stream (lane 0 only).  `chans[i].d` are dense w*h int32 planes in HBM.
@@ -431,7 +556,7 @@ JXL_DEV void modular_stream_stage(DevModScratch &S, int tid, int nthreads) {
   if (ncache > st.count) ncache = st.count;
   S.alias = alias_lds ? l_alias : st.ev.alias; S.alias_lds = alias_lds;
   S.ctx_map = ctx_lds ? l_ctx : st.ev.ctx_map; S.ctx_lds = ctx_lds; S.ctx_off = (int32_t)(l_ctx - pool);
-  S.tree = l_tree; S.tree_ncache = ncache;
+  S.tree = l_tree; S.tree_ncache = ncache; S.pool_used = used;
   for (int i = tid; i < ncache; i += nthreads) l_tree[i] = st.tree[i];
   for (int i = tid; i < 64; i += nthreads) S.divlut[i] = (1u << 24) / (uint32_t)(i + 1);
   if (ctx_lds) for (int i = tid; i < st.num_ctx; i += nthreads) l_ctx[i] = st.ev.ctx_map[i];

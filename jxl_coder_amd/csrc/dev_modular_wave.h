@@ -75,6 +75,26 @@ __device__ __forceinline__ uint32_t wave_ec_read(const DevECView &v, DevModScrat
   return ec_hybrid(b, cfg, sym);
 }
 
+// rANS symbol + hybrid uint with the alias tables in HBM (a code of more clusters than the LDS pool holds: libjxl's one-shot encoder writes 128 for an RGBA
+// photograph): alias entry and configuration as two global loads issued together; `cluster` comes from the tree's exit word
+__device__ __forceinline__ uint32_t wave_ec_read_global(const DevECView &v, DevModScratch &S, DevBits &b, uint32_t &state, uint32_t cluster, bool cfg_lds) {
+  if (v.use_prefix) { const uint32_t token = ec_token(v, b, state, cluster); return ec_hybrid(b, v.cfg[cluster], token); }
+  const int lb = 12 - v.log_alpha;
+  const uint32_t res = state & 0xfff;
+  const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
+  const uint64_t raw8 = gld((const uint64_t *)&v.alias[(cluster << v.log_alpha) + i]);
+  const uint32_t raw_x = (uint32_t)raw8, raw_y = (uint32_t)(raw8 >> 32);
+  const uint32_t cfg = cfg_lds ? S.cfg[cluster] : gld(&S.st.ev.cfg[cluster]);
+  const uint32_t cutoff = raw_x & 255u, rsym = (raw_x >> 8) & 255u, off1 = raw_x >> 16, freq0 = raw_y & 0xffffu, freq1 = raw_y >> 16;      // DevAlias, field by field
+  const bool right = pos >= cutoff;
+  const uint32_t sym = right ? rsym : i;
+  const uint32_t off = right ? off1 + pos : pos;
+  const uint32_t freq = right ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  if (state < (1u << 16)) state = (state << 16) | bits_read(b, 16);
+  return ec_hybrid(b, cfg, sym);
+}
+
 template <class T> __device__ __forceinline__ T tabs(T v) { return v < 0 ? -v : v; }
 template <class T>
 __device__ __forceinline__ T predict_plain_t(int predictor, T W, T N, T NW, T NE, T NN, T WW, T NEE, T wp) {
@@ -101,21 +121,41 @@ __device__ __forceinline__ T predict_plain_t(int predictor, T W, T N, T NW, T NE
 // neighbourhood, the properties, the predictors and the weighted predictor run in 32-bit arithmetic (exactly the
 // same results as the 64-bit reference arithmetic, half the vector instructions).  kWP: this channel's pruned tree
 // uses the weighted predictor (property 15 or predictor 6).
-template <bool kLds, bool kM16, bool kWP>
+// kBig: the channel's tree is in block form (big_tree_build) in the LDS area `big`: block 0 sits in registers like a small tree, an exit that names
+// another block costs one more round (that block's nodes and masks from LDS, the property values by ds_bpermute from a lane-indexed vector).
+template <bool kLds, bool kM16, bool kWP, bool kBig = false>
 __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
-                                                    DevWaveTree &WT, const DevChanOut c, int lane, int y_end = 0x7fffffff) {
+                                                    DevWaveTree &WT, const DevChanOut c, int lane, int y_end = 0x7fffffff, const uint32_t *big = nullptr) {
   typedef typename std::conditional<kM16, int32_t, int64_t>::type T;
   const int w = c.w, h = c.h < y_end ? c.h : y_end;      // rows [0, y_end): the specialised loops below take over from there
   const bool wide = w > kModMaxW;
-  const int ni = WT.ni, nl = WT.nl;
-  const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
-  const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
-  const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull;
-  const uint64_t my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+  const DevBigHdr *BH = (const DevBigHdr *)big;
+  const uint32_t root_word = kBig ? BH->root_word : 0u;
+  const int ni = kBig ? (int)((root_word >> 25) & 63) : WT.ni, nl = kBig ? ni + 1 : WT.nl;
+  const uint64_t *big_nodes = kBig ? (const uint64_t *)(big + BH->off_nodes) : nullptr;      // (prop, split) pairs
+  const uint4 *big_need = kBig ? (const uint4 *)(big + BH->off_need) : nullptr;
+  const uint32_t *big_exit = kBig ? big + BH->off_exit : nullptr;
+  const int32_t *big_mulo = kBig ? (const int32_t *)big + BH->off_mulo : nullptr;
+  const bool big_cfg_lds = S.st.num_clusters <= kLocMaxClusters;      // (then ev.cfg is S.cfg)
+  const uint32_t dbg = (kBig && S.walk_stat) ? S.walk_stat[2] : 0u;      // MEASUREMENT ONLY (JXLAMD_DEBUG_MOD, word 4 of the flag block): 1 = every symbol from cluster 0's tables, 2 = block 0's exits taken as leaves — wrong pixels, same loop
+  int my_prop, my_split; uint64_t my_need1, my_need0;
+  uint32_t my_exit = 0;
+  if (kBig) {
+    const uint64_t nd = lane < ni ? big_nodes[lane] : 0x7fffffff00000000ull;
+    my_prop = (int)(uint32_t)nd; my_split = (int)(nd >> 32);
+    const uint4 m = lane < nl ? big_need[lane] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    my_need1 = m.x | ((uint64_t)m.y << 32); my_need0 = m.z | ((uint64_t)m.w << 32);
+    my_exit = lane < nl ? big_exit[lane] : 0u;
+  } else {
+    my_prop = lane < ni ? WT.int_prop[lane] : 0;
+    my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+    my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull;
+    my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+  }
   // lane j keeps leaf j's record in registers; the selected leaf's record is fetched with v_readlane (no LDS trip)
-  const int my_lctx = lane < nl ? WT.leaf_ctx[lane] : 0, my_lpred = lane < nl ? WT.leaf_pred[lane] : 0;
-  const int my_loff = lane < nl ? WT.leaf_off[lane] : 0, my_lmul = lane < nl ? WT.leaf_mul[lane] : 1;
-  const int my_lclu = (kLds && lane < nl) ? (int)((const uint8_t *)S.pool)[S.ctx_off + my_lctx] : 0;
+  const int my_lctx = (!kBig && lane < nl) ? WT.leaf_ctx[lane] : 0, my_lpred = (!kBig && lane < nl) ? WT.leaf_pred[lane] : 0;
+  const int my_loff = (!kBig && lane < nl) ? WT.leaf_off[lane] : 0, my_lmul = (!kBig && lane < nl) ? WT.leaf_mul[lane] : 1;
+  const int my_lclu = (!kBig && kLds && lane < nl) ? (int)((const uint8_t *)S.pool)[S.ctx_off + my_lctx] : 0;
   // the WP's reciprocal table (1<<24)/(i+1), i < 64: lane i holds entry i; lookups are v_readlane with a uniform index
   // kM16: every MA property is a signed sum of per-sample inputs (W, N, NW, NE, NN, WW, the previous sample's property 9,
   // x, y, the WP's max error), two of them under |.|.  Lane i keeps the coefficient row of ITS decision node and splits
@@ -175,7 +215,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       int32_t pv[16];
       #define M24(a, b) __mul24((a), (int)(b))
       int32_t early = 0;
-      if (kM16) {
+      if (kM16 && !kBig) {
         // the raw window registers, not the edge-substituted W_/N_/...: at the image edges the substitutes ARE late values
         early = (M24(cN, N_) + M24(cNW, NW_)) + (M24(cNE, NE_) + M24(cNN, NN_)) + (M24(cWW, WW_) + M24(cP9, p9_prev)) + (M24(cX, x) + M24(cY, y));
       } else {
@@ -226,7 +266,16 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       }
       // MA tree by ballot: lane i decides node i, lane j tests leaf j, the chosen leaf's record comes by readlane
       int32_t myv;
-      if (kM16) {
+      if (kBig) {
+        // the 14 property values (wave-uniform) go to LDS once per sample — lane 0, four 16-byte stores — and every lane of every block reads the one its
+        // node tests: a single wave issues one instruction every four cycles whatever its kind, so what counts here is the instruction count (a lane-indexed
+        // vector for ds_bpermute took 14 selects whose lane masks the compiler kept spilling: 56 instructions per sample)
+        if (lane == 0) {
+          #pragma unroll
+          for (int k = 0; k < 16; k++) S.props[k] = k < 2 ? 0 : pv[k];
+        }
+        myv = S.props[my_prop & 15];
+      } else if (kM16) {
         myv = early + M24(cW, W_) + M24(cE, pv[15]);
         if (cAbs) myv = myv < 0 ? -myv : myv;
       } else {
@@ -238,14 +287,42 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       const uint64_t dec = __ballot(lane < ni && myv > my_split);
       const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
       const int leaf = lm ? __builtin_ctzll(lm) : 0;
-      const int l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf), l_pred = __builtin_amdgcn_readlane(my_lpred, leaf);
-      const int l_off = __builtin_amdgcn_readlane(my_loff, leaf), l_mul = __builtin_amdgcn_readlane(my_lmul, leaf);
+      int l_ctx, l_pred, l_off, l_mul, l_clu;
+      if (kBig) {
+        uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_exit, leaf);
+        int eidx = (int)(root_word & 8191u) + leaf;
+        if ((dbg & 2u) && (e >> 31)) e = 5u << 26;
+        while (e >> 31) {                    // (uniform) the exit names another block
+          const int bni = (int)((e >> 25) & 63), noff = (int)((e >> 13) & 4095), eoff = (int)(e & 8191);
+          const int jl = lane < bni ? lane : bni;      // lanes beyond the block read its last exit / the entry behind its last node (inside the area; masked below): no branches around the loads
+          const uint64_t nd = big_nodes[noff + jl];
+          const uint4 m = big_need[eoff + jl];
+          const uint32_t bex = big_exit[eoff + jl];
+          const int bv = S.props[(uint32_t)nd & 15u];
+          const uint64_t bdec = __ballot(lane < bni && bv > (int)(nd >> 32));
+          const uint64_t b1 = m.x | ((uint64_t)m.y << 32), b0 = m.z | ((uint64_t)m.w << 32);
+          const uint64_t blm = __ballot(lane <= bni && (bdec & b1) == b1 && (~bdec & b0) == b0);
+          const int bleaf = blm ? __builtin_ctzll(blm) : 0;
+          e = (uint32_t)__builtin_amdgcn_readlane((int)bex, bleaf);
+          eidx = eoff + bleaf;
+          if (!blm) e = 0;                   // (cannot happen for a built tree; keeps the loop finite)
+        }
+        l_ctx = (int)(e & 0x3ffffu); l_clu = (int)((e >> 18) & 255u); l_pred = (int)((e >> 26) & 15u);
+        if (dbg & 1u) l_clu = 0;
+        l_mul = 1; l_off = 0;
+        if (e & (1u << 30)) { l_mul = big_mulo[2 * eidx]; l_off = big_mulo[2 * eidx + 1]; }
+      } else {
+        l_ctx = __builtin_amdgcn_readlane(my_lctx, leaf); l_pred = __builtin_amdgcn_readlane(my_lpred, leaf);
+        l_off = __builtin_amdgcn_readlane(my_loff, leaf); l_mul = __builtin_amdgcn_readlane(my_lmul, leaf);
+        l_clu = __builtin_amdgcn_readlane(my_lclu, leaf);
+      }
       const T guess = predict_plain_t<T>(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
-      const int l_clu = __builtin_amdgcn_readlane(my_lclu, leaf);
-      const uint32_t u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
+      uint32_t u;
+      if (kBig && !kLds) u = wave_ec_read_global(ev, S, b, state, (uint32_t)l_clu, big_cfg_lds);      // the exit word carries the cluster: no context-map trip
+      else u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
       const T res = (T)unpack_signed(u);
       const T val = (l_mul == 1 ? res : res * (T)l_mul) + (T)l_off + guess;      // l_mul is wave-uniform: the multiply is branched around
-      if (lane == 0) { row[x] = (int32_t)val; if (!wide) out[x] = (int32_t)val; }
+      if (lane == 0) { if (!wide) row[x] = (int32_t)val; gst(&out[x], (int32_t)val); }      // (a wide channel's row IS the plane)
       vWW = vW; vW = (int32_t)val;
       vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
       if (kWP) {
@@ -683,7 +760,8 @@ __device__ __forceinline__ bool wave_restage_compact(const DevECView &g, int num
 // All 64 lanes call this with identical arguments.  Returns error bits (uniform).
 // kGeneral = false: the kernel carries no general lock-step loop (wave_decode_channel: ~180 VGPRs for the lifetime of the wave); a channel
 // that needs one ends the stream with kErrNeedGeneral and the host decodes the frame again with the general kernel.
-template <bool kLds, bool kGeneral>
+// kBig: trees beyond one ballot go through the block form (big_tree_build) when it fits what the pool has left behind the stream's tables.
+template <bool kLds, bool kGeneral, bool kBig = false>
 __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView &ev, DevBits &b, uint32_t &state, const DevTreeNode *gtree,
                                                         int tree_count, const DevWP &wp, DevModScratch &S, DevWaveTree &WT,
                                                         const DevChanOut *chans, int nch, int stream_id, int lane, bool m16) {
@@ -696,7 +774,29 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     __syncthreads();
     if (lane == 0) wave_tree_build(gtree, tree_count, ci, stream_id, WT);
     __syncthreads();
-    if (!WT.ok) return kErrWaveFallback;                    // caller re-runs the stream with the serial walker
+    if (!WT.ok) {
+      if (!kBig || !kGeneral) return kErrWaveFallback;      // caller re-runs the stream with the serial walker
+      const int at = (S.pool_used + 15) & ~15;              // the head of the tree cached there serves only the serial walker (which stages the stream again)
+      uint32_t *big = (uint32_t *)((uint8_t *)S.pool + at);
+      if (lane == 0) {
+        const BigCount cnt = big_tree_count(gtree, tree_count, ci, stream_id, WT.stack_node);
+        (void)big_tree_build(gtree, tree_count, ci, stream_id, S.st.ev.ctx_map, cnt, WT.stack_node, WT.stack_n1, WT.stack_n0, big, S.pool_bytes - at);
+      }
+      __syncthreads();
+      const DevBigHdr *BH = (const DevBigHdr *)big;
+      if (S.pool_bytes - at < (int)sizeof(DevBigHdr) + 64 || !BH->ok) return kErrWaveFallback;
+      const bool bwp = BH->uses_wp != 0;
+      if (c.w > kModMaxW && bwp) return kErrWaveFallback;
+      if (lane == 0 && S.walk_stat) atomicAdd(S.walk_stat + 1, 1u);
+      if (kLds && !pool_packed) {
+        if (m16) { if (bwp) wave_decode_channel<true, true, true, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); else wave_decode_channel<true, true, false, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); }
+        else { if (bwp) wave_decode_channel<true, false, true, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); else wave_decode_channel<true, false, false, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); }
+      } else {
+        if (m16) { if (bwp) wave_decode_channel<false, true, true, true>(evg, b, state, wp, S, WT, c, lane, 0x7fffffff, big); else wave_decode_channel<false, true, false, true>(evg, b, state, wp, S, WT, c, lane, 0x7fffffff, big); }
+        else { if (bwp) wave_decode_channel<false, false, true, true>(evg, b, state, wp, S, WT, c, lane, 0x7fffffff, big); else wave_decode_channel<false, false, false, true>(evg, b, state, wp, S, WT, c, lane, 0x7fffffff, big); }
+      }
+      continue;
+    }
     const bool uses_wp = WT.uses_wp != 0;
     if (c.w > kModMaxW && uses_wp) return kErrWaveFallback;       // the serial walker keeps the predictor's error rows of such channels in HBM
     // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
@@ -790,7 +890,7 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
 }
 
 // Stream-level wrapper: every lane calls it; falls back to the serial walker when the tree is too large.
-template <bool kGeneral = true>
+template <bool kGeneral = true, bool kBig = false>
 __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S, const DevChanOut *chans, int nch, int stream_id, int lane) {
   DevModStream &st = S.st;
   if (st.err) return st.err;
@@ -806,10 +906,11 @@ __device__ __forceinline__ uint32_t modular_stream_decode_wave(DevModScratch &S,
   DevBits b = st.b;
   uint32_t state = ans_init(ev, b);
   const bool lds = S.ctx_lds && S.alias_lds && !ev.use_prefix;
-  uint32_t err = lds ? modular_decode_channels_wave<true, kGeneral>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
-                     : modular_decode_channels_wave<false, kGeneral>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
+  uint32_t err = lds ? modular_decode_channels_wave<true, kGeneral, kBig>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0)
+                     : modular_decode_channels_wave<false, kGeneral, kBig>(ev, b, state, st.tree, st.count, st.wp, S, S.wt, chans, nch, stream_id, lane, st.m16 != 0);
   __syncthreads();
   if (err == kErrWaveFallback) {
+    if (lane == 0 && S.walk_stat) atomicAdd(S.walk_stat, 1u);
     // An earlier channel of the stream may have re-used the table pool (packed alias tables of the weighted-predictor loop, compact restaging):
     // the serial walker starts the stream over and needs the tables as modular_stream_stage laid them out
     modular_stream_stage(S, lane, 64);

@@ -25,14 +25,14 @@ __global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
 __device__ __forceinline__ void mod_lfgroup_kernel(const DevBuffers &B, DevModScratch &S, int g) {
   const DevFrame &F = frame_of(B);
   if (threadIdx.x == 0) {
-    S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.wide_wp = nullptr;
+    S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; S.wide_wp = nullptr;
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
     DevBits b;
     bits_init(b, B.codestream, secs[1 + g].off, F.cs_size);
     S.st.b = b;
   }
   __syncthreads();
-  const uint32_t e = mod_lfgroup_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+  const uint32_t e = mod_lfgroup_body<true, true>(B, S, g, (int)threadIdx.x, 64, SyncBlock());
   if (threadIdx.x == 0 && e) *B.err |= e | kErrStageLf;
 }
 __global__ void __launch_bounds__(64) k_mod_lfgroup(DevBuffers B) {

@@ -266,3 +266,60 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) xyb_write_pixel(B, stat.data(), *(const DevStatic *)stat.data(), src, out_bits, x, y);
   return 0;
 }
+
+// ---- the block form of large MA trees (dev_modular.h: big_tree_build) against the plain walk: random trees (seeded), random property vectors.
+// Returns mismatches (0 = good), -1 when the tree could not be built in big_bytes, -2 when the count pass disagrees with the tree.  stats[0..2] = blocks, nodes, exits.
+extern "C" int emul_bigtree_selftest(uint32_t seed, int internal_nodes, int big_bytes, int trials, int with_nonunit, int32_t *stats) {
+  using namespace jxlamd;
+  uint64_t rs = seed * 0x9E3779B97F4A7C15ull + 12345;
+  auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 11); };
+  // a random full binary tree in libjxl's order (a node's children come later): grow by turning random leaves into decision nodes
+  std::vector<DevTreeNode> tree(1);
+  std::vector<int> leaves{0};
+  tree[0].prop = -1;
+  for (int i = 0; i < internal_nodes; i++) {
+    const size_t pick = (rnd() % 4 == 0) ? leaves.size() - 1 : rnd() % leaves.size();      // sometimes the newest leaf: deep chains
+    const int at = leaves[pick];
+    leaves.erase(leaves.begin() + (long)pick);
+    const int l = (int)tree.size(), r = l + 1;
+    tree.resize(tree.size() + 2);
+    const uint32_t k = rnd() % 20;
+    tree[(size_t)at].prop = k < 2 ? (int)k : 2 + (int)(rnd() % 14);       // properties 0 / 1 (static) now and then
+    tree[(size_t)at].splitval = (int)(rnd() % 9) - 4;
+    tree[(size_t)at].lchild = l; tree[(size_t)at].rchild = r; tree[(size_t)at].offset = 0;
+    tree[(size_t)l].prop = tree[(size_t)r].prop = -1;
+    leaves.push_back(l); leaves.push_back(r);
+  }
+  int nctx = 0;
+  for (auto &nd : tree) if (nd.prop < 0) { nd.splitval = nctx++; nd.lchild = (int)(rnd() % 14); nd.rchild = 1; nd.offset = 0; if (with_nonunit && rnd() % 7 == 0) { nd.rchild = 1 + (int)(rnd() % 5); nd.offset = (int)(rnd() % 11) - 5; } }
+  std::vector<uint8_t> ctx_map((size_t)nctx);
+  for (auto &c : ctx_map) c = (uint8_t)(rnd() % 200);
+  const int chan = (int)(rnd() % 5) - 2, stream = (int)(rnd() % 5) - 2;
+  int32_t stack[64]; int32_t qn[64]; uint64_t q1[64], q0[64];
+  const BigCount cnt = big_tree_count(tree.data(), (int)tree.size(), chan, stream, stack);
+  if (!cnt.ok) return -3;           // deeper than the stack: the decoder falls back, nothing to compare
+  // plain count of the pruned tree
+  { int ni = 0, nl = 0; std::vector<int> st{0}; while (!st.empty()) { const DevTreeNode nd = tree[(size_t)st.back()]; st.pop_back();
+      if (nd.prop < 0) { nl++; continue; } if (nd.prop < 2) { const int v = nd.prop == 0 ? chan : stream; st.push_back(v > nd.splitval ? nd.lchild : nd.rchild); continue; }
+      ni++; st.push_back(nd.lchild); st.push_back(nd.rchild); }
+    if (ni != cnt.ni || nl != cnt.nl) return -2; }
+  std::vector<uint32_t> big((size_t)big_bytes / 4 + 16);
+  if (!big_tree_build(tree.data(), (int)tree.size(), chan, stream, ctx_map.data(), cnt, qn, q1, q0, big.data(), big_bytes)) return -1;
+  const DevBigHdr &H = *(const DevBigHdr *)big.data();
+  if (stats) { stats[0] = H.nblocks; stats[1] = H.nnodes; stats[2] = H.nexits; }
+  if (H.nnodes != cnt.ni || H.nexits != cnt.nl + H.nblocks - 1) return -2;
+  int bad = 0;
+  for (int t = 0; t < trials; t++) {
+    int32_t props[16];
+    props[0] = chan; props[1] = stream;
+    for (int k = 2; k < 16; k++) props[k] = (int)(rnd() % 13) - 6;
+    const DevTreeNode *nd = &tree[0];
+    while (nd->prop >= 0) nd = &tree[(size_t)(props[nd->prop] > nd->splitval ? nd->lchild : nd->rchild)];
+    int eidx = -1;
+    const uint32_t e = big_tree_eval(big.data(), props, &eidx);
+    const uint32_t want = ((nd->rchild != 1 || nd->offset != 0) ? 1u << 30 : 0u) | ((uint32_t)nd->lchild << 26) | ((uint32_t)ctx_map[(size_t)nd->splitval] << 18) | (uint32_t)nd->splitval;
+    if (e != want) { bad++; continue; }
+    if (e & (1u << 30)) { const int32_t *mulo = (const int32_t *)big.data() + H.off_mulo; if (mulo[2 * eidx] != nd->rchild || mulo[2 * eidx + 1] != nd->offset) bad++; }
+  }
+  return bad;
+}

@@ -144,6 +144,53 @@ def test_rgba_with_squeeze_beyond_8192_pixels_84_stream_channels(dec):
     assert (flat == np.array([37, 150, 190, 255], np.uint8)).all()           # = the reference's output (tests/golden/make_golden.py: add_unsupported_exemplar; fnv1a64 e5ce6f6eda8ba225)
 
 
+def _modular_walk_state(dec):
+    import ctypes as C
+    import jxl_coder_amd as J
+    f = J.api.lib().jxlamd_debug_modular
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 2)]
+    st = (C.c_uint64 * 2)(); f(dec._h, C.byref(st))
+    return int(st[0]), int(st[1])
+
+
+def test_alpha_streams_with_a_tree_of_hundreds_of_leaves_run_from_its_block_form(dec):
+    """A default-settings (distance 1, effort 7) RGBA photograph from the reference's encoder: one MA tree for every Modular stream of the frame (~1000 nodes, ~450
+    leaves and ~100 clusters for the alpha channel's group streams).  Such a tree does not fit one ballot (64 decision nodes / leaves): the wave evaluates it
+    block by block (dev_modular.h: big_tree_build; dev_modular_wave.h: kBig) — rounds 1 - 4 sent these streams to the one-lane serial walker at 3.6 - 6 us per
+    sample.  Alpha is coded losslessly: bit-exact against the reference run live; colour within the VarDCT bounds; as a single decode and inside a flight;
+    and the context's counters say which loop ran (jxlamd_debug_modular)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_ref
+    if not jxl_ref.available():
+        pytest.skip("oracle/_ref (the reference's libjxl) did not travel to this box")
+    import synth
+    import jxl_coder_amd as J
+    d = J.JxlDecoder(0)
+    for (w, h, seed) in ((1920, 1080, 2001), (700, 523, 2002)):
+        img = synth.photo_like(w, h, seed=seed, channels=4)
+        data = jxl_ref.encode(img, effort=7, distance=1.0, threads=0)
+        ref = jxl_ref.decode(data, threads=0)[0]
+        s0 = _modular_walk_state(d)
+        out, info = d.decode_one_shot(data)
+        s1 = _modular_walk_state(d)
+        assert out.shape == ref.shape == (h, w, 4)
+        assert np.array_equal(out[..., 3], ref[..., 3]), "alpha (lossless Modular)"
+        diff = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
+        assert diff.max() <= VARDCT_MAX_ABS and diff.mean() <= 0.06, (diff.max(), diff.mean())
+        if w == 1920:
+            assert s1[1] - s0[1] >= 40 and s1[0] == s0[0], ("the 40 group streams' alpha channel from the block form, nothing on the serial walker", s0, s1)
+        # the same frame three times in a flight next to a plain VarDCT frame
+        other, _ = load_case("v264x520_e7")
+        datas = [data, other, data, data]
+        singles = [out, d.decode_one_shot(other)[0], out, out]
+        outs = [torch.zeros(x.size, dtype=torch.uint8, device="cuda") for x in singles]
+        d.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for x, o in zip(singles, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(x.shape), x)
+
+
 def test_jxlcoder_surface(dec):
     import jxl_coder_amd as J
     data, exp = load_case("v256_e7")

@@ -17,6 +17,15 @@ def encode(seed, threads, kind="c3"):
     if kind == "c5":     # BASELINE configs[4]: 4K Rec.2100 PQ 16-bit, distance 1.0, EPF forced to 3 iterations
         return jxl_ref.encode(synth.photo_like(3840, 2160, seed=1000 + seed, bits=16), effort=7, distance=1.0, epf=3, primaries=9, transfer=16,
                               intensity_target=10000.0, threads=threads)
+    if kind == "mixed":  # content that is not a q90 photograph, at the reference encoder's defaults (interop/JxlEncoding.cpp:145-160): by seed % 3 a 1920x1080 screenshot at
+        # distance 1 effort 7 (patch dictionary: a reference frame + the main frame), a 1920x1080 lossy RGBA photograph (VarDCT colour + squeezed lossy alpha), a
+        # 3840x2160 photograph at quality <= 12 (distance 12: coded at half size, 2x upsampled)
+        k = seed % 3
+        if k == 0:
+            return jxl_ref.encode(synth.screenshot(1920, 1080, seed=2000 + seed), effort=7, distance=1.0, threads=threads)
+        if k == 1:
+            return jxl_ref.encode(synth.photo_like(1920, 1080, seed=2000 + seed, channels=4), effort=7, distance=1.0, threads=threads)
+        return jxl_ref.encode(synth.photo_like(3840, 2160, seed=2000 + seed), effort=7, distance=12.0, threads=threads)
     return jxl_ref.encode(synth.photo_like(3840, 2160, seed=seed), effort=7, distance=1.0, threads=threads)
 
 
@@ -31,7 +40,7 @@ def one(seed):
 
 def one_to(args):
     seed, out, kind = args
-    dst = os.path.join(out, f"syn4k_q90_seed{seed}.jxl" if kind == "c3" else f"syn4k_pq16_epf3_seed{seed}.jxl")
+    dst = os.path.join(out, f"syn4k_q90_seed{seed}.jxl" if kind == "c3" else f"mixed_seed{seed}.jxl" if kind == "mixed" else f"syn4k_pq16_epf3_seed{seed}.jxl")
     if os.path.exists(dst):
         return seed
     src = os.path.join(ROOT, "bench_data", f"syn4k_q90_seed{seed}.jxl")
