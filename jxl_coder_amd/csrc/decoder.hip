@@ -652,18 +652,32 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     // decoded one by one, like a single decode.  A composed frame that stands alone — coded at a lower resolution and upsampled (the reference's quality
     // <= 12), with noise, with splines — rides in the flight: its entropy stages in the flight's launches, its
     // filters stage by stage into the plane set it borrows, its composition stages (launch_compose_tail) right behind its sub-batch's filters.
-    bool rides = false;
-    if (S.plan.compose && S.plan.refs.empty() && S.plan.error.empty() && !S.plan.tables.empty() && !S.plan.modular && !S.plan.single_section && S.plan.save_slot < 0) {
+    // A frame whose references are plain patch sources (a screenshot: the patch dictionary's sprite frame, then the image) rides too: its reference frames are
+    // decoded first — one by one — and their images move from the context's slots into the frame's own (FrameSlot::own_ref), so that the next such frame of
+    // the flight does not overwrite what this one's patch stage reads much later.
+    bool rides = false, rides_with_refs = false;
+    if (S.plan.compose && S.plan.error.empty() && !S.plan.tables.empty() && !S.plan.modular && !S.plan.single_section && S.plan.save_slot < 0) {
       const DevFrame *Fc = (const DevFrame *)S.plan.tables.data();
-      static const bool compose_in_flights = !(getenv("JXLAMD_COMPOSE_IN_FLIGHTS") && atoi(getenv("JXLAMD_COMPOSE_IN_FLIGHTS")) == 0);      // A/B switch for measurements
-      rides = compose_in_flights && !Fc->blend && !Fc->use_lf_frame && !Fc->no_output && Fc->num_patches == 0 && !Fc->subsampled;      // (subsampled chroma: the flights' list-driven reconstruction kernels do not place such blocks)
+      static const bool compose_in_flights = !(getenv("JXLAMD_COMPOSE_IN_FLIGHTS") && atoi(getenv("JXLAMD_COMPOSE_IN_FLIGHTS")) == 0);      // A/B switch for measurements (2: only frames without references)
+      static const bool refs_in_flights = !(getenv("JXLAMD_COMPOSE_IN_FLIGHTS") && atoi(getenv("JXLAMD_COMPOSE_IN_FLIGHTS")) == 2);
+      rides = compose_in_flights && !Fc->blend && !Fc->use_lf_frame && !Fc->no_output && !Fc->subsampled;      // (subsampled chroma: the flights' list-driven reconstruction kernels do not place such blocks)
+      if (S.plan.refs.empty()) rides = rides && Fc->num_patches == 0;
+      else {
+        rides = rides && refs_in_flights;
+        for (const auto &r : S.plan.refs) if (!r || r->save_canvas || r->save_slot < 0 || r->save_slot > 3) rides = false;
+        rides_with_refs = rides;
+      }
     }
     const bool composed = (S.plan.compose || !S.plan.refs.empty()) && !rides;
-    if (composed && S.plan.error.empty()) { int rc = decode_refs(S, flags); if (rc) return rc; }
+    if ((composed || rides_with_refs) && S.plan.error.empty()) { int rc = decode_refs(S, flags); if (rc) return rc; }
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
                      /*own_planes=*/S.plan.modular || S.plan.single_section || composed);
     if (rc) return rc;
+    if (rides_with_refs) for (int k = 0; k < 4; k++) if (S.B.ref[k][0]) {      // (prepare pointed the frame at the context's slots: they are this frame's from here on)
+      S.own_ref[k].swap(ref_store[k]);
+      ref_w[k] = ref_h[k] = 0; ref_alpha[k] = false;      // the slot now holds an older image (or nothing): not a reference any more
+    }
     if (composed) { rc = run_frame(S, flags, false); if (rc) return rc; continue; }
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section) {

@@ -48,6 +48,7 @@ struct DevMem {
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void swap(DevMem &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
 };
 
 struct PinnedMem {             // page-locked host staging: true async DMA, no shared pageable-copy staging in the runtime
@@ -95,6 +96,7 @@ struct FrameSlot {             // HBM work buffers of one in-flight frame
   PinnedMem h_tables, h_cs, h_B;
   DevMem dB;                     // device copy of B: single decodes run the flight kernels over a one-frame array (same pixels on every path)
   DevMem cs, tables, cells8[5], tiles[2], lf[6], coef_off, coef_cnt, coef[3], planes[6], lf_scratch, local, misc, out, mod_pool, mod_scratch, pass_nz, pass_end, big_list[4], lz_win, up_planes;
+  DevMem own_ref[4];             // a frame of a flight that draws patches from reference frames: their images, taken over from the context's slots (decode_batch_once)
   FramePlan plan;
   DevBuffers B;
   DevAux A;

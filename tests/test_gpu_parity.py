@@ -234,6 +234,36 @@ def test_batch_of_round4_kinds_equals_single_decodes(dec):
             assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
 
 
+def test_composed_frames_ride_in_flights(dec):
+    """Composed frames inside a flight (decoder.hip: decode_batch_once): frames coded at a fraction of their size and upsampled 2x / 4x / 8x, noise, noise on an
+    upsampled frame, splines, and screenshots — a patch dictionary's reference frame decoded first, its image handed to the frame's own slot, the frame itself in
+    the flight's launches, its patch / spline / noise / upsampling stages behind its sub-batch's filters.  Two different screenshots and the same one twice in one
+    flight (each must read ITS reference image), next to plain VarDCT frames: every output equals the single decode bit for bit, twice; and with
+    JXLAMD_COMPOSE_IN_FLIGHTS=0 (every composed frame one by one, rounds 1 - 4) the pixels are the same again."""
+    import subprocess, textwrap
+    code = textwrap.dedent("""
+        import sys, os, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        names = ["vs400x300_e7_d1", "vu400x300_e7_d10", "vs400x300_e7_d3", "v264x520_e7", "vu523x267_e7_up4", "vs400x300_e7_d1", "vu523x267_e7_up8", "vus400x300_e7_d12",
+                 "vn300x200_e7", "vnu523x267_e7_d12", "w_spline_a", "w_spline_b", "vs400x300_e9_d1", "vusa400x300_e7_d12", "vua400x300_e7_d12", "v300x300_e7_d3", "vn600x410_e7_d15"]
+        datas = [open(os.path.join(%r, "tests", "golden", n + ".jxl"), "rb").read() for n in names]
+        singles = [dec.decode_one_shot(d)[0] for d in datas]
+        for rep in range(2):
+            outs = [torch.full((s.size,), 0x5A, dtype=torch.uint8, device="cuda") for s in singles]
+            torch.cuda.synchronize()
+            dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            torch.cuda.synchronize()
+            for n, s_, o in zip(names, singles, outs):
+                assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
+        print("flights ok", len(names))
+    """) % (ROOT, ROOT + "/tests", ROOT)
+    for env in ({}, {"JXLAMD_COMPOSE_IN_FLIGHTS": "2"}, {"JXLAMD_COMPOSE_IN_FLIGHTS": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "flights ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
+
+
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
