@@ -409,13 +409,14 @@ int jxlamd_decoder::launch_rest(FrameSlot &S, int parts, bool upload_B) {
   return JXLAMD_OK;
 }
 
+int mod_group_pool_bytes(const FramePlan &plan);
 // Extra channels of a VarDCT frame (alpha).  The GlobalModular part (meta channels, channels that fit one group) is decoded
 // BEFORE the LF stage (launch_mod_global at the call sites: in a single-section frame LfGroup 0 starts where it ends); this is the
 // rest: the ModularGroup stream that follows each group's AC stream, then the inverse global transforms.  The writer reads the planes.
 int jxlamd_decoder::launch_extra_channels(FrameSlot &S) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
+  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, mod_group_pool_bytes(plan), stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
   return JXLAMD_OK;
 }
@@ -426,7 +427,7 @@ int jxlamd_decoder::launch_modular(FrameSlot &S) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
   launch_mod_global(S.B, stream);
   if (F->mod_lf_nch > 0) launch_mod_lfgroups(S.B, plan.num_lf_groups, stream);
-  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, stream);
+  if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, mod_group_pool_bytes(plan), stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
   if (!F->compose) { launch_mod_write(S.B, plan.width, plan.height, (int)S.pi.out_bits, stream); return JXLAMD_OK; }
   launch_mod_to_planes(S.B, plan.width, plan.height, stream);
@@ -580,6 +581,46 @@ int jxlamd_decoder::run_frame(FrameSlot &S, uint32_t flags, bool single_latency)
   return rc;
 }
 
+// LDS table pool (bytes) the ModularGroup streams of a frame should run with — the kernels clamp it to kModPoolMin .. kModPoolBytes; any size decodes the
+// same pixels, what fits stays out of HBM.  Streams with their own trees (no global tree in the frame) get the full pool: their tables are only known on the
+// device.  With the frame's global tree and code: [alias tables, when the LDS form takes them | context map | the tree: its head for a small one, the block
+// form (dev_modular.h: big_tree_build) of the largest pruned tree any sampled (channel, stream) reaches for one beyond a ballot].
+int mod_group_pool_bytes(const FramePlan &plan) {
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  if (plan.tables.empty() || F->tree_count <= 0) return kModPoolBytes;
+  const DevEC &ec = F->tree_ec;
+  const int alias_bytes = ec.use_prefix ? 0 : (int)((size_t)(ec.num_clusters << ec.log_alpha) * sizeof(DevAlias));
+  const bool alias_lds = !ec.use_prefix && ec.num_clusters <= kLocMaxClusters && alias_bytes <= kModPoolBytes;
+  int used = (alias_lds ? alias_bytes : 0) + ((ec.num_ctx + (ec.lz77 ? 1 : 0) + 7) & ~7);
+  if (used > kModPoolBytes) return kModPoolBytes;
+  const DevTreeNode *tree = (const DevTreeNode *)(plan.tables.data() + F->tree_off);
+  int ni_max = 0, nl_max = 0;
+  const int nch = std::min(std::max(F->mod_nch - F->mod_first_group_ch, 1), (int)kModMaxGroupCh), ng = std::max(plan.num_groups, 1);
+  std::vector<int> stack;
+  for (int pass = 0; pass < std::max(F->num_passes, 1); pass++)
+    for (int gs = 0; gs < 3; gs++) {
+      const int g = gs == 0 ? 0 : gs == 1 ? ng / 2 : ng - 1;
+      const int stream = 1 + 3 * F->num_lf_groups + 17 + pass * ng + g;
+      for (int c = 0; c < nch; c++) {
+        int ni = 0, nl = 0; size_t guard = 0;
+        stack.assign(1, 0);
+        while (!stack.empty() && guard++ < (size_t)4 * (size_t)F->tree_count + 16) {
+          const int idx = stack.back(); stack.pop_back();
+          if (idx < 0 || idx >= F->tree_count) break;
+          const DevTreeNode &nd = tree[idx];
+          if (nd.prop < 0) { nl++; continue; }
+          if (nd.prop == 0 || nd.prop == 1) { stack.push_back((nd.prop == 0 ? c : stream) > nd.splitval ? nd.lchild : nd.rchild); continue; }
+          ni++; stack.push_back(nd.lchild); stack.push_back(nd.rchild);
+        }
+        ni_max = std::max(ni_max, ni); nl_max = std::max(nl_max, nl);
+      }
+    }
+  int tree_bytes;
+  if (ni_max <= 64 && nl_max <= 64) return kModPoolBytes;      // one ballot: the specialised loops re-pack the tables of the clusters a channel uses into whatever the pool has (measured: a lossless e3 4K frame 81 -> 85 ms with a pool cut to the stream's own tables)
+  tree_bytes = (int)sizeof(DevBigHdr) + 8 * ni_max + 28 * (nl_max + ni_max / 6 + 16) + 512;                  // nodes + (masks, word, queue entry) per exit and per block, with room
+  return ((used + 15) & ~15) + tree_bytes + 64;
+}
+
 // host-side twin of flat_frame_ok (dev_pass_flat.h)
 bool frame_flat_ok(const FramePlan &plan) {
   const DevFrame *F = (const DevFrame *)plan.tables.data();
@@ -695,9 +736,10 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   // launch per stage over all of them (GlobalModular streams, then every 256x256 group stream, inverse transforms, writer)
   if (!mod_batched.empty()) {
     std::vector<DevBuffers> hb; std::vector<int> gmap;
-    int max_ops = 0, mw = 0, mh = 0;
+    int max_ops = 0, mw = 0, mh = 0, mod_pool = kModPoolMin;
     for (size_t k = 0; k < mod_batched.size(); k++) {
       const FrameSlot &S = slot((size_t)mod_batched[k]);
+      mod_pool = std::max(mod_pool, mod_group_pool_bytes(S.plan));
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
       hb.push_back(S.B);
       if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { gmap.push_back((int)k); gmap.push_back(g); }
@@ -709,7 +751,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     memcpy(h_mod_tab.p, hb.data(), hb.size() * sizeof(DevBuffers));
     if (!gmap.empty()) memcpy((uint8_t *)h_mod_tab.p + o_g, gmap.data(), gmap.size() * 4);
     HIPCHECK(hipMemcpyAsync(mod_tab.p, h_mod_tab.p, total, hipMemcpyHostToDevice, stream));
-    launch_modular_batch((const DevBuffers *)mod_tab.p, (const int *)((uint8_t *)mod_tab.p + o_g), (int)hb.size(), (int)gmap.size() / 2, max_ops, mw, mh, stream);
+    launch_modular_batch((const DevBuffers *)mod_tab.p, (const int *)((uint8_t *)mod_tab.p + o_g), (int)hb.size(), (int)gmap.size() / 2, max_ops, mw, mh, mod_pool, stream);
     int first_mod_rc = JXLAMD_OK;
     for (int i : mod_batched) { int rc = collect(slot((size_t)i), flags); if (rc && !first_mod_rc) first_mod_rc = rc; }
     if (first_mod_rc) return first_mod_rc;
@@ -838,6 +880,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const auto close_subflight = [&] { const std::vector<int> m = flat_wave_map(sf_groups); w_map.insert(w_map.end(), m.begin(), m.end()); sf_groups.clear(); };
   std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
   bool any_ec = false;
+  int ec_pool = kModPoolMin;                                 // LDS table pool of the extra channels' group streams: the largest any frame of the flight asks for
   for (int k = 0; k < nb; k++) {
     FrameSlot &S = slot((size_t)batched[(size_t)k]);
     float *set = (float *)plane_pool.p + (size_t)(k % plane_sets) * planes_per_set * max_npx;
@@ -851,6 +894,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
       any_ec = true;
+      ec_pool = std::max(ec_pool, mod_group_pool_bytes(S.plan));
       ec_ops.back() = std::max(ec_ops.back(), (int)F->mod_nops);
       if (F->mod_first_group_ch < F->mod_nch) for (int g = 0; g < S.plan.num_groups; g++) { ec_map.push_back(k - k / hf_sets * hf_sets); ec_map.push_back(g); }
     }
@@ -911,7 +955,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
       launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), sparse, stream);
     } else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
-                                       ec_ops[(size_t)sf], stream);
+                                       ec_ops[(size_t)sf], ec_pool, stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
     for (int j0 = 0; j0 < cnt; j0 += plane_sets) {
       launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse,

@@ -172,8 +172,8 @@ JXL_DEV int32_t palette_value(const int32_t *pal, int psize, int index, int c, i
 // lies in the pass's bracket (Passes::GetDownsamplingBracket; DevFrame::pass_min_shift / pass_max_shift — a single pass takes 0..2, shifts of 3 and more travel in the
 // ModularLfGroup streams); a pass without such a channel in this group has no stream.  Returns false when the group's decode must stop (flagged).
 template <class Sync>
-JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, int pass, int tid, int nthreads, Sync sync) {
-  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
+JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, int pass, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
+  if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
   const DevFrame &F = frame_of(B);
   const int gx = g % F.xgroups, gy = g / F.xgroups;
   const int gd = F.mod_group_dim;
@@ -217,7 +217,7 @@ JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, i
       if (t.id == 0) { if (t.begin_c + 3 > cnt) S.st.err = kErrBitstream; }
       else if (t.id == 1) {
         if (t.num_c < 1 || t.num_c > 4 || t.nb_deltas > 0 || t.d_pred != 0 || t.begin_c < nmeta) { S.st.err = kErrPalette; break; }      // predicted (delta) entries in a group's own palette / palettes of meta channels: not on the device
-        if (t.begin_c + t.num_c > cnt || cnt + 1 > kModMaxCh) { S.st.err = kErrBitstream; break; }
+        if (t.begin_c + t.num_c > cnt || cnt + 1 > kModGroupDesc) { S.st.err = kErrBitstream; break; }
         const size_t need = (size_t)t.nb_colours * (size_t)t.num_c;
         if (pal_used + need > (size_t)gd * (size_t)gd) { S.st.err = kErrPalette; break; }
         for (int c = 1; c < t.num_c; c++) {
@@ -290,10 +290,10 @@ JXL_DEV bool mod_group_pass_body(const DevBuffers &B, DevModScratch &S, int g, i
 }
 
 template <class Sync>
-JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync) {
+JXL_DEV void mod_group_body(const DevBuffers &B, DevModScratch &S, int g, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
   const int np = frame_of(B).num_passes;
   for (int pass = 0; pass < np; pass++) {
-    if (!mod_group_pass_body(B, S, g, pass, tid, nthreads, sync)) return;
+    if (!mod_group_pass_body(B, S, g, pass, tid, nthreads, sync, pool_bytes)) return;
     sync();                                               // the next pass reuses the stream state and the channel list
   }
 }

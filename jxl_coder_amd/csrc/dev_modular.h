@@ -13,6 +13,7 @@
 namespace jxlamd {
 
 constexpr int kLfMaxCh = 40;          // channel descriptors of an LF-group workgroup: 3 LF channels, 4 HF-metadata channels, <= 32 ModularLfGroup channels (host_parse.cpp)
+constexpr int kModGroupDesc = 80;     // channel descriptors of a ModularGroup workgroup: <= 64 channel rectangles (host_parse.cpp: kModMaxGroupCh) + the palettes of its own transforms (kModMaxLocalTr)
 constexpr int kModMaxW = 256;         // widest channel a device stream may carry (LF group = 256 LF samples; 256-px lossless groups)
 constexpr int kWpMaxW = 256;
 constexpr int kTreeLds = 128;         // MA-tree nodes cached in LDS

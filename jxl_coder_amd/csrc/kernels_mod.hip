@@ -14,12 +14,20 @@ __global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
   __syncthreads();
   mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock());
 }
-__global__ void __launch_bounds__(64) k_mod_group(DevBuffers B) {
-  __shared__ DevModScratch S;
-  __shared__ DevChanOut chbuf[kModMaxCh];
-  S.ch = chbuf;                                       // (every lane stores the same value)
+// The group streams' workgroup lives in DYNAMIC LDS like the LF kernels': offsetof(pool) + the table pool of this launch + kModGroupDesc channel descriptors.
+// A frame's group streams are as many as its 256 x 256 groups and each keeps its LDS for the ~100 ms it runs: with the full 30 KB pool (54 KB per
+// workgroup) a CU holds two of them, with the 16 KB that libjxl's one-shot streams need (context map + the channel's tree in block form; their 128
+// clusters' alias tables never fit) four (mod_group_pool_bytes, decoder.hip).
+__device__ __forceinline__ DevModScratch &mod_group_smem(int pool_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t mod_smem[];
+  DevModScratch &S = *(DevModScratch *)mod_smem;
+  S.ch = (DevChanOut *)(mod_smem + offsetof(DevModScratch, pool) + pool_bytes);      // (every lane stores the same value)
   __syncthreads();
-  mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
+  return S;
+}
+__global__ void __launch_bounds__(64) k_mod_group(DevBuffers B, int pool_bytes) {
+  DevModScratch &S = mod_group_smem(pool_bytes);
+  mod_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
 // ModularLfGroup streams of a Modular-encoded frame (section 1 + g holds nothing else there)
 __device__ __forceinline__ void mod_lfgroup_kernel(const DevBuffers &B, DevModScratch &S, int g) {
@@ -52,7 +60,16 @@ __global__ void __launch_bounds__(256) k_mod_write(DevBuffers B, int out_bits, i
   mod_write_pixel(B, out_bits, x, y);
 }
 void launch_mod_global(const DevBuffers &B, hipStream_t s) { hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), 0, s, B); }
-void launch_mod_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_group, dim3(n), dim3(64), 0, s, B); }
+static size_t mod_group_lds(const void *kernel, bool *once, int pool_bytes) {
+  if (!*once) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(offsetof(DevModScratch, pool) + kModPoolBytes + kModGroupDesc * sizeof(DevChanOut))); *once = true; }
+  return offsetof(DevModScratch, pool) + (size_t)pool_bytes + kModGroupDesc * sizeof(DevChanOut);
+}
+static int mod_pool_clamp(int pool_bytes) { return pool_bytes < kModPoolMin ? kModPoolMin : pool_bytes > kModPoolBytes ? kModPoolBytes : (pool_bytes + 255) & ~255; }
+void launch_mod_groups(const DevBuffers &B, int n, int pool_bytes, hipStream_t s) {
+  static bool once = false;
+  pool_bytes = mod_pool_clamp(pool_bytes);
+  hipLaunchKernelGGL(k_mod_group, dim3(n), dim3(64), mod_group_lds((const void *)k_mod_group, &once, pool_bytes), s, B, pool_bytes);
+}
 void launch_mod_lfgroups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_mod_lfgroup, dim3(n), dim3(64), 0, s, B); }
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_mod_op, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, op, n); }
 void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream_t s) {
@@ -69,16 +86,13 @@ __global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
   if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
   mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
 }
-__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map) {
-  __shared__ DevModScratch S;
-  __shared__ DevChanOut chbuf[kModMaxCh];
-  S.ch = chbuf;                                       // (every lane stores the same value)
-  __syncthreads();
+__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map, int pool_bytes) {
+  DevModScratch &S = mod_group_smem(pool_bytes);
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   const DevBuffers &B = Bs[f];
   const DevFrame &F = frame_of(B);
   if (F.mod_first_group_ch >= F.mod_nch) return;
-  mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock());
+  mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
 __global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *Bs) {      // grid (max LF groups, frames)
   __shared__ DevModScratch S;
@@ -107,15 +121,20 @@ __global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
 // extra channels (alpha) of the VarDCT frames of a flight: GlobalModular parts before the LF stage, the per-group streams and the
 // inverse transforms after the PassGroup stage of each sub-flight
 void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s) { hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs); }
-void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, hipStream_t s) {
-  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+static void launch_mod_group_b(const DevBuffers *Bs, const int *group_map, int ngroups, int pool_bytes, hipStream_t s) {
+  static bool once = false;
+  pool_bytes = mod_pool_clamp(pool_bytes);
+  hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), mod_group_lds((const void *)k_mod_group_b, &once, pool_bytes), s, Bs, group_map, pool_bytes);
+}
+void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int pool_bytes, hipStream_t s) {
+  if (ngroups > 0) launch_mod_group_b(Bs, group_map, ngroups, pool_bytes, s);
   for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
 }
-void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, hipStream_t s) {
+void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, int pool_bytes, hipStream_t s) {
   hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);
   const int max_lfg = ((max_w + 1023) / 1024) * ((max_h + 1023) / 1024);       // LF groups are 8 x group_dim pixels wide (>= 1024)
   if (max_w > 1024 || max_h > 1024) hipLaunchKernelGGL(k_mod_lfgroup_b, dim3(max_lfg, nframes), dim3(64), 0, s, Bs);   // only images beyond one LF group can carry such streams
-  if (ngroups > 0) hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), 0, s, Bs, group_map);
+  if (ngroups > 0) launch_mod_group_b(Bs, group_map, ngroups, pool_bytes, s);
   for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
   hipLaunchKernelGGL(k_mod_write_b, dim3((max_w + 63) / 64, (max_h + 3) / 4, nframes), dim3(256), 0, s, Bs);
 }
