@@ -60,7 +60,7 @@ JXL_DEV void upsample_pixel(const DevBuffers &B, const DevFrame &F, const uint8_
   const DevStatic &ST = *(const DevStatic *)stat;
   const int N = F.upsampling, sh = N == 2 ? 1 : N == 4 ? 2 : 3;
   const int x = X >> sh, y = Y >> sh, ox = X & (N - 1), oy = Y & (N - 1);
-  const float *k = (const float *)(stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
+  const float *k = (const float *)(F.ups_custom_off[sh - 1] ? B.tables + F.ups_custom_off[sh - 1] : stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
   const bool a = compose_final_is_a(F);
   int xs[5], ys[5];
   for (int i = 0; i < 5; i++) { xs[i] = mirror(x + i - 2, F.width); ys[i] = mirror(y + i - 2, F.height); }
@@ -87,7 +87,7 @@ JXL_DEV void upsample_alpha_pixel(const DevBuffers &B, const DevFrame &F, const 
   const DevStatic &ST = *(const DevStatic *)stat;
   const int N = F.alpha_up, sh = N == 2 ? 1 : N == 4 ? 2 : 3;
   const int x = X >> sh, y = Y >> sh, ox = X & (N - 1), oy = Y & (N - 1);
-  const float *k = (const float *)(stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
+  const float *k = (const float *)(F.ups_custom_off[sh - 1] ? B.tables + F.ups_custom_off[sh - 1] : stat + ST.ups_off[sh - 1]) + (size_t)(oy * N + ox) * 25;
   const int32_t *src = mod_plane(B, F, F.mod_out[3]);
   const float sc = 1.0f / (float)((1u << F.mod_alpha_bits) - 1);
   int xs[5], ys[5];

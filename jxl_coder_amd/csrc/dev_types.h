@@ -140,6 +140,7 @@ struct DevFrame {
   // Splines (flag kSplines): DevSplineSeg[num_spline_segs]; per pixel row y the segments that reach it are spline_idx[spline_row[y] .. spline_row[y + 1]) (u32 each),
   // in the order libjxl draws them (by row, then by segment index); added to X, Y, B after the patches (dev_compose.h: spline_pixel)
   int32_t num_spline_segs; uint32_t spline_seg_off, spline_row_off, spline_idx_off;
+  uint32_t ups_custom_off[3];      // custom upsampling weights of the image (metadata): float[N][N][5][5] per factor in the frame blob like DevStatic::ups_off; 0: the default kernels
   int32_t ref_w[4], ref_h[4];      // the reference slots as they are when this frame is decoded (0: empty); planes in DevBuffers::ref
   // loop filter
   int32_t gab; float gab_w[3][2];

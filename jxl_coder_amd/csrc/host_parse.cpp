@@ -102,6 +102,19 @@ struct Priv {                 // state between phase 1 and phase 2
   int64_t tree_bit = -1;        // where the global MA tree starts inside LfGlobal (-1: none): a RAW dequant matrix of HfGlobal may be coded with it
 };
 
+// the upper triangle of the symmetric 5n x 5n matrix of factor N = 2n = 2 << t (15 / 55 / 210 weights: the defaults of upsampling_weights.h or an image's own)
+// expanded to one 5 x 5 kernel per output phase (the phases of the right / lower half are the mirror images of the left / upper half)
+static std::vector<float> expand_upsampling_kernels(const float *w, int t) {
+  const int N = 2 << t, n = N / 2;
+  std::vector<float> sym((size_t)(5 * n) * (size_t)(5 * n)), k((size_t)N * N * 25);
+  for (int i = 0; i < 5 * n; i++) for (int j = 0; j < 5 * n; j++) { const int y = std::min(i, j), x = std::max(i, j); sym[(size_t)j * (size_t)(5 * n) + (size_t)i] = w[5 * n * y - y * (y - 1) / 2 + x - y]; }
+  for (int oy = 0; oy < N; oy++) for (int ox = 0; ox < N; ox++) for (int iy = 0; iy < 5; iy++) for (int ix = 0; ix < 5; ix++) {
+    const int py = oy < n ? oy : N - 1 - oy, px = ox < n ? ox : N - 1 - ox, ty = oy < n ? iy : 4 - iy, tx = ox < n ? ix : 4 - ix;
+    k[(size_t)((oy * N + ox) * 25 + iy * 5 + ix)] = sym[(size_t)(py * 5 + ty) * (size_t)(5 * n) + (size_t)(px * 5 + tx)];      // kernel[py][px][ty][tx] = sym[5 py + ty][5 px + tx]
+  }
+  return k;
+}
+
 static void fill_info(const img_meta &m, ImageInfo *i) {
   const hx_info &p = m.pub;
   i->xsize = p.xsize; i->ysize = p.ysize; i->bits_per_sample = p.bits_per_sample; i->exp_bits = p.exp_bits;
@@ -717,6 +730,21 @@ static int read_toc(const uint8_t *cs, size_t csn, const frame_hdr &f, size_t to
 
 static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_shown, uint32_t raw_w, uint32_t raw_h);
 
+// The preview frame (image metadata have_preview): a frame of the PreviewHeader's size in front of the image's frames.  DecodeJpegXlOneShot never subscribes
+// to it (interop/JxlDecoding.cpp:60-75), libjxl then walks over it: its header and TOC are read, its sections skipped.
+static int skip_preview_frame(hx_br *br, const img_meta &m, const uint8_t *cs, size_t csn, std::string *error) {
+  if (m.have_animation) { *error = "unsupported: preview frame of an animation"; return -1; }
+  hx_align(br);
+  frame_hdr pf;
+  if (read_frame_header(br, &m, m.preview_w, m.preview_h, &pf)) { *error = hx_last_error(); return -1; }
+  if (pf.frame_type != 0) { *error = "invalid: the preview is not a regular frame"; return -1; }
+  size_t end_byte = 0;
+  if (read_toc(cs, csn, pf, br->pos, nullptr, &end_byte, error)) return -1;
+  hx_br_init(br, cs, csn);
+  br->pos = end_byte * 8;
+  return 0;
+}
+
 int parse_anim_info(const uint8_t *data, size_t size, std::vector<AnimFrame> *frames, AnimHeader *hdr, std::string *error) {
   uint8_t *cs0; size_t csn; int owned_flag;
   if (extract_codestream(data, size, &cs0, &csn, &owned_flag)) { *error = hx_last_error(); return -1; }
@@ -727,7 +755,7 @@ int parse_anim_info(const uint8_t *data, size_t size, std::vector<AnimFrame> *fr
   img_meta m;
   if (read_image_header(&br, &m)) { *error = hx_last_error(); return -1; }
   if (m.pub.want_icc && read_icc_stream(&br, nullptr)) { *error = hx_last_error(); return -1; }
-  if (m.have_preview) { *error = "unsupported: preview frame"; return -1; }
+  if (m.have_preview && skip_preview_frame(&br, m, cs, csn, error)) return -1;
   const uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
   hdr->have_animation = (uint32_t)m.have_animation; hdr->tps_numerator = m.have_animation ? m.tps_num : 0; hdr->tps_denominator = m.have_animation ? m.tps_den : 0;
   hdr->num_loops = m.have_animation ? m.num_loops : 0; hdr->have_timecodes = m.have_animation ? (uint32_t)m.have_timecodes : 0;
@@ -783,8 +811,7 @@ int plan_parse(const uint8_t *data, size_t size, FramePlan *plan, int target_fra
     std::vector<uint8_t> tmp;                                  // linear-light enum encoding: the synthesised data profile (parse_basic_info)
     if (icc_synth::synthesize(m.pub, m.wp_xy, m.prim_xy, &tmp)) plan->info.icc_size = (uint32_t)tmp.size();
   }
-  if (m.have_preview) { plan->error = "unsupported: preview frame"; return -1; }
-  if (m.custom_upsampling) { plan->error = "unsupported: custom upsampling weights"; return -1; }
+  if (m.have_preview && skip_preview_frame(&br, m, plan->cs, csn, &plan->error)) return -1;
   const uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
   // ---- the frame walk: every frame's header and TOC (its sections are skipped by their sizes), up to the frame marked is_last
   std::vector<FrameRec> recs;
@@ -1023,6 +1050,10 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   plan->tables.assign(((sizeof(DevFrame) + 15) / 16) * 16, 0);
   Blob blob(plan->tables);
   F.sec_off = blob.append(secs.data(), secs.size() * sizeof(DevSection));
+  if (m.custom_upsampling) {      // the image's own upsampling weights (metadata), expanded like the defaults of the static tables
+    const float *cw[3] = {m.up_w2, m.up_w4, m.up_w8};
+    for (int t = 0; t < 3; t++) if (m.custom_upsampling & (1 << t)) { const std::vector<float> k = expand_upsampling_kernels(cw[t], t); F.ups_custom_off[t] = blob.append(k.data(), k.size() * 4); }
+  }
   // ---- LfGlobal (section 0)
   hx_br sb; hx_br_init(&sb, plan->cs + secs[0].off, nsec == 1 ? csn - secs[0].off : secs[0].size);
   if ((f.flags & 2) && parse_patches(plan, pv, &sb, blob)) return -1;
@@ -1247,13 +1278,7 @@ static void build_static_tables(std::vector<uint8_t> &tab) {
     // of the right / lower half are the mirror images of the left / upper half)
     const float *w[3] = {kUpsampling2, kUpsampling4, kUpsampling8};
     for (int t = 0; t < 3; t++) {
-      const int N = 2 << t, n = N / 2;
-      std::vector<float> sym((size_t)(5 * n) * (size_t)(5 * n)), k((size_t)N * N * 25);
-      for (int i = 0; i < 5 * n; i++) for (int j = 0; j < 5 * n; j++) { const int y = std::min(i, j), x = std::max(i, j); sym[(size_t)j * (size_t)(5 * n) + (size_t)i] = w[t][5 * n * y - y * (y - 1) / 2 + x - y]; }
-      for (int oy = 0; oy < N; oy++) for (int ox = 0; ox < N; ox++) for (int iy = 0; iy < 5; iy++) for (int ix = 0; ix < 5; ix++) {
-        const int py = oy < n ? oy : N - 1 - oy, px = ox < n ? ox : N - 1 - ox, ty = oy < n ? iy : 4 - iy, tx = ox < n ? ix : 4 - ix;
-        k[(size_t)((oy * N + ox) * 25 + iy * 5 + ix)] = sym[(size_t)(py * 5 + ty) * (size_t)(5 * n) + (size_t)(px * 5 + tx)];      // kernel[py][px][ty][tx] = sym[5 py + ty][5 px + tx]
-      }
+      const std::vector<float> k = expand_upsampling_kernels(w[t], t);
       ST.ups_off[t] = blob.append(k.data(), k.size() * 4);
     }
   }

@@ -40,6 +40,7 @@ typedef struct {
   int num_extra; extra_ch ec[16];
   int modular_16;
   int have_preview, have_animation, have_timecodes;
+  uint32_t preview_w, preview_h;      /* PreviewHeader (A.3) */
   int orientation;
   float opsin_inv[9], opsin_bias[3], quant_bias[4];
   int custom_upsampling;
@@ -114,9 +115,11 @@ static int read_image_header(jxo_br *br, img_meta *m) {
       m->have_preview = jxo_bool(br);
       if (m->have_preview) {
         int div8 = jxo_bool(br);
-        if (div8) (void)jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33); else (void)jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345);
-        uint32_t ratio = jxo_bits(br, 3);
-        if (ratio == 0) { if (div8) (void)jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33); else (void)jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345); }
+        uint32_t ph = div8 ? 8u * jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33) : jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345);
+        uint32_t ratio = jxo_bits(br, 3), pw;
+        if (ratio == 0) pw = div8 ? 8u * jxo_u32(br, -1, 16, -1, 32, 5, 1, 9, 33) : jxo_u32(br, 6, 1, 8, 65, 10, 321, 12, 1345);
+        else { static const uint32_t num[8] = {0, 1, 12, 4, 3, 16, 5, 2}, den[8] = {1, 1, 10, 3, 2, 9, 4, 1}; pw = (uint32_t)((uint64_t)ph * num[ratio] / den[ratio]); }
+        m->preview_w = pw; m->preview_h = ph;
       }
       m->have_animation = jxo_bool(br);
       if (m->have_animation) {
@@ -1502,7 +1505,31 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
   if (read_image_header(&br, &m)) goto done;
   if (info) *info = m.pub;
   if (m.pub.want_icc) { jxo_set_error("unsupported: embedded ICC profile"); goto done; }
-  if (m.have_preview) { jxo_set_error("unsupported: preview frame"); goto done; }
+  if (m.have_preview) {
+    /* the preview frame in front of the image's frames: the reference's one-shot decode (interop/JxlDecoding.cpp:60-75) never subscribes to it and libjxl
+     * walks over it — frame header, TOC, then past the sections by their sizes */
+    frame_hdr pf;
+    jxo_align(&br);
+    if (m.have_animation) { jxo_set_error("unsupported: preview frame of an animation"); goto done; }
+    if (read_frame_header(&br, &m, m.preview_w, m.preview_h, &pf)) goto done;
+    int pn = (pf.num_groups == 1 && pf.num_passes == 1) ? 1 : 1 + pf.num_lf_groups + 1 + pf.num_groups * pf.num_passes;
+    if (jxo_bool(&br)) {
+      jxo_ec tc;
+      if (jxo_ec_read_header(&tc, &br, 8)) { jxo_set_error("bad TOC permutation code"); goto done; }
+      jxo_ec_begin(&tc, &br, 0);
+      uint32_t *pp = (uint32_t *)malloc(4 * (size_t)pn);
+      int e = jxo_read_permutation(&tc, &br, pp, (uint32_t)pn, 0);
+      int ok = jxo_ec_final_ok(&tc);
+      jxo_ec_free(&tc); free(pp);
+      if (e || !ok) { jxo_set_error("bad TOC permutation"); goto done; }
+    }
+    jxo_align(&br);
+    size_t total = 0;
+    for (int i = 0; i < pn; i++) total += jxo_u32(&br, 10, 0, 14, 1024, 22, 17408, 30, 4211712);
+    jxo_align(&br);
+    if (br.err || br.pos / 8 + total > csn) { jxo_set_error("truncated file (preview frame)"); goto done; }
+    br.pos += total * 8;
+  }
   if (m.custom_upsampling) { jxo_set_error("unsupported: custom upsampling weights"); goto done; }
   uint32_t raw_w = m.orientation > 4 ? m.pub.ysize : m.pub.xsize, raw_h = m.orientation > 4 ? m.pub.xsize : m.pub.ysize;
   jxo_align(&br);

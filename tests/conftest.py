@@ -104,7 +104,9 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
                       "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vlf2a520x300_e7", "vnu600x410_e7_up2", "vnu523x267_e7_d12", "vga300x200_e7_d12",
                       # custom primaries (Adobe RGB) and a custom white point with custom primaries (ProPhoto, D50: Bradford on both sides as in libjxl's output stage)
-                      "vcadobe200x136_e7", "vcprophoto200x136_e7"]
+                      "vcadobe200x136_e7", "vcprophoto200x136_e7",
+                      # custom upsampling weights in the image metadata (tools/jxl_write.py: no encoder option writes them), factors 2 / 4 / 8
+                      "w_up2_custom", "w_up4_custom", "w_up8_custom"]
 # JPEG transcodes (what the reference's construct / JXLJpegInterop path writes, cpp/JXLJpegInterop.cpp:40): VarDCT frames that are not XYB — YCbCr, RAW
 # dequant matrices, 4:4:4 / 4:2:0 / 4:2:2 chroma, progressive source, grey, several groups.  Same tolerance as every VarDCT file (measured 1e-5 - 5e-5).
 JPEG_CASES = ["j444_200x136", "j420_200x136", "j422_200x136", "j420_600x410", "j420_prog_333x277", "jgrey_160x120", "j420s_400x300"]
@@ -117,7 +119,8 @@ ANIM_VARDCT_CASES = ["an_blend_d1_e7", "an_modes_d2_e5", "an_blend_premul_d1_e7"
 SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
 # hand-written codestreams (tools/jxl_write.py -> tests/golden/make_golden.py: writer_case): the DCT128 / DCT256 varblock families (AcStrategy 21 .. 26), which
 # libjxl's encoder never selects and its decoder takes, and splines (K.4: what jxl-art files draw with); expected pixels = the reference's decode
-WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
+WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
+                "w_preview"]      # ... + a preview frame in front of the image's frame (walked over)
 VARDCT_CASES = VARDCT_CASES + WRITER_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vpm400x300_e7_premultiplied", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 

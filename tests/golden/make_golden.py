@@ -270,11 +270,36 @@ def add_anim_cases(meta, only):
 # ---- hand-written codestreams (tools/jxl_write.py): what libjxl's encoder never emits and its decoder takes — the DCT128 / DCT256 varblock families
 # (AcStrategy 21 .. 26).  One 256 x 256 group (or a 128 x 128 image), seeded coefficients / LF samples / chroma-from-luma factors / quant field / sharpness;
 # expected pixels = the reference's decode.
+def metadata_case(name, W):
+    """What only the image metadata can ask for (no option of libjxl's encoder writes them): custom upsampling weights for factors 2 / 4 / 8 — the defaults scaled and
+    shifted by seeded noise, far enough that the default kernels miss the reference's pixels by 18 - 21 codes — and a preview frame in front of the image's frame
+    (DecodeJpegXlOneShot never subscribes to it: the decoder walks over it)."""
+    def img(size, seed, **kw):
+        nb = size // 8
+        rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:nb, 0:nb]
+        lf = np.stack([np.round(30 * np.sin(xx / 5.0 + seed)).astype(np.int64), 5000 + 60 * xx + 45 * yy, np.round(40 * np.cos(yy / 4.0 + seed)).astype(np.int64)])
+        blocks = [dict(bx=x, by=y, strategy=0, qf=8, coef={1: {int(k): int(v) for k, v in zip(rng.choice(np.arange(1, 64), 5, replace=False), rng.integers(-20, 21, 5)) if v}})
+                  for y in range(nb) for x in range(nb)]
+        return W.write_vardct(size, size, blocks, lf, **kw)
+    if name == "w_preview":
+        return img(64, 1, preview=img(32, 7, as_frame=True))
+    fac = {"w_up2_custom": 2, "w_up4_custom": 4, "w_up8_custom": 8}[name]
+    txt = open(os.path.join(ROOT, "jxl_coder_amd", "csrc", "upsampling_weights.h")).read()
+    body = txt[txt.index("kUpsampling%d[" % fac):]
+    body = body[body.index("{") + 1:body.index("}")]
+    w = [float(x.rstrip("f")) for x in body.replace("\n", " ").split(",") if x.strip()]
+    rng = np.random.default_rng(50 + fac)
+    return img(64, fac, upsampling=fac, up_weights={fac: [x * (1 + 0.5 * rng.standard_normal()) + 0.02 * rng.standard_normal() for x in w]})
+
+
 def writer_case(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import jxl_write as W
     if name.startswith("w_spline"):
         return spline_case(name, W)
+    if name.startswith("w_up") or name == "w_preview":
+        return metadata_case(name, W)
     seed = {"w_dct256": 1, "w_dct128": 2, "w_dct_mix_a": 3, "w_dct_mix_b": 4, "w_dct128_small": 5, "w_dct256_nofilter": 6}[name]
     rng = np.random.default_rng(seed)
     size = 128 if name == "w_dct128_small" else 256
@@ -346,7 +371,8 @@ def spline_case(name, W):
                           xfromy=rng.integers(-20, 20, (4, 4)), bfromy=rng.integers(-10, 30, (4, 4)), sharpness=rng.integers(0, 8, (nb, nb)))
 
 
-WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter"]
+WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
+                "w_up2_custom", "w_up4_custom", "w_up8_custom", "w_preview"]
 
 
 def add_writer_cases(meta, only):

@@ -295,8 +295,21 @@ def natural_order_len(strategy):
     return COVERED_X[strategy] * COVERED_Y[strategy] * 64
 
 
+def write_size_header(bw, width, height):
+    """SizeHeader (A.2): the small form for multiples of 8 up to 256, else explicit sizes (ratio 0)."""
+    if width % 8 == 0 and height % 8 == 0 and width <= 256 and height <= 256:
+        bw.bool(1); bw.w(5, height // 8 - 1); bw.w(3, 0); bw.w(5, width // 8 - 1)
+    else:
+        enc = [(9, 1), (13, 1), (18, 1), (30, 1)]
+        bw.bool(0); bw.u32(height, enc); bw.w(3, 0); bw.u32(width, enc)
+
+
 def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=None, global_scale=32768, quant_lf=64, gab=True, epf_iters=2,
-                 splines=None, spline_quant_adjust=0, x_qm=3, b_qm=2):
+                 splines=None, spline_quant_adjust=0, x_qm=3, b_qm=2, upsampling=1, up_weights=None, preview=None, as_frame=False):
+    """upsampling: 1 / 2 / 4 / 8 — the image is width * upsampling x height * upsampling, the frame is coded at width x height;
+    up_weights: {2: [15 floats], 4: [55], 8: [210]} custom upsampling weights in the image metadata (upper triangles of the symmetric kernel matrices);
+    preview: the bytes of a frame (write_vardct(..., as_frame=True)) of pw x ph = preview[1], preview[2] pixels, put in front of the image's frames as its preview;
+    as_frame: return (frame bytes, width, height) without the file header."""
     """A one-group VarDCT image.
     blocks: [dict(bx, by, strategy, qf (1..256), coef={channel (0 X, 1 Y, 2 B): {scan position k >= covered cells: quantised value}})] tiling the cell
             grid exactly; lf: int array [3][yb][xb] (X, Y, B quantised LF samples); xfromy / bfromy: int8-range arrays of [ceil(yb/8)][ceil(xb/8)]."""
@@ -313,22 +326,53 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
         occ[b["by"]:b["by"] + cy, b["bx"]:b["bx"] + cx] = True
     assert occ.all()
     bw = BW()
-    bw.w(16, 0x0AFF)
-    # SizeHeader
-    if width % 8 == 0 and height % 8 == 0 and width <= 256 and height <= 256:
-        bw.bool(1); bw.w(5, height // 8 - 1); bw.w(3, 0); bw.w(5, width // 8 - 1)
-    bw.bool(1)                                              # ImageMetadata all_default
-    bw.bool(1)                                              # default_m
-    bw.align()
+    if not as_frame:
+        bw.w(16, 0x0AFF)
+        write_size_header(bw, width * upsampling, height * upsampling)
+        if preview is None:
+            bw.bool(1)                                      # ImageMetadata all_default
+        else:
+            bw.bool(0); bw.bool(1)                          # not all_default, extra_fields
+            bw.w(3, 0)                                      # orientation 1
+            bw.bool(0)                                      # no intrinsic size
+            bw.bool(1)                                      # have_preview: PreviewHeader (A.3)
+            pw, ph = preview[1], preview[2]
+            assert pw % 8 == 0 and ph % 8 == 0 and pw <= 256 and ph <= 256
+            bw.bool(1)                                      # div8
+            bw.u32(ph // 8, [(-1, 16), (-1, 32), (5, 1), (9, 33)]); bw.w(3, 0); bw.u32(pw // 8, [(-1, 16), (-1, 32), (5, 1), (9, 33)])
+            bw.bool(0)                                      # no animation
+            bw.bool(0); bw.w(2, 0)                          # BitDepth: integer samples, 8 bits
+            bw.bool(1)                                      # modular_16bit_buffers
+            bw.w(2, 0)                                      # no extra channels
+            bw.bool(1)                                      # xyb_encoded
+            bw.bool(1)                                      # ColourEncoding all_default (sRGB)
+            bw.bool(1)                                      # ToneMapping all_default
+            bw.u64(0)                                       # extensions
+        if up_weights is None:
+            bw.bool(1)                                      # default_m
+        else:
+            bw.bool(0)
+            bw.bool(1)                                      # default opsin inverse matrix
+            bw.w(3, (1 if 2 in up_weights else 0) | (2 if 4 in up_weights else 0) | (4 if 8 in up_weights else 0))
+            for fac, cnt in ((2, 15), (4, 55), (8, 210)):
+                if fac in up_weights:
+                    assert len(up_weights[fac]) == cnt
+                    for x in up_weights[fac]:
+                        bw.f16(float(x))
+        if preview is not None:
+            bw.align()
+            for byte in preview[0]:
+                bw.w(8, byte)
+        bw.align()
     # FrameHeader
     flags = 16 if splines else 0
-    if flags == 0 and gab and epf_iters == 2 and x_qm == 3 and b_qm == 2:
+    if flags == 0 and gab and epf_iters == 2 and x_qm == 3 and b_qm == 2 and upsampling == 1:
         bw.bool(1)
     else:
         bw.bool(0)
         bw.w(2, 0); bw.w(1, 0)                              # regular frame, VarDCT
         bw.u64(flags)
-        bw.w(2, 0)                                          # upsampling 1
+        bw.w(2, {1: 0, 2: 1, 4: 2, 8: 3}[upsampling])       # upsampling
         bw.w(3, x_qm); bw.w(3, b_qm)
         bw.w(2, 0)                                          # one pass
         bw.bool(0)                                          # no crop
@@ -391,6 +435,8 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
     bw.align()
     bw.u32(len(body), [(10, 0), (14, 1024), (22, 17408), (30, 4211712)])
     bw.align()
+    if as_frame:
+        return bw.bytes() + body, width, height
     return bw.bytes() + body
 
 
