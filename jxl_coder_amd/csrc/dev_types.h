@@ -30,6 +30,7 @@ struct DevEC {
   int32_t lz77, lz_min_symbol, lz_min_length; uint32_t lz_len_cfg;
 };
 
+constexpr int kMaxPasses = 11;        // passes of a frame (the format's limit: u32(1, 2, 3, 4 + 3 bits))
 constexpr int kModMaxCh = 128;       // stream channels of a Modular image (the default squeeze of RGBA: 4 x (1 + 2 per halving); 84 at 8200 x 8200 — what the reference's encoder writes
                                      // for a large lossy RGBA image at its defaults, interop/JxlEncoding.cpp:145-160 — 108 at 65536 x 65536)
 constexpr int kModMaxPlanes = 272;   // + one output plane per inverse squeeze step
@@ -64,7 +65,7 @@ struct DevFrame {
   int32_t xlfg, ylfg, num_lf_groups;         // 2048x2048
   int32_t num_passes;
   int32_t pass_shift[12];
-  int32_t pass_min_shift[4], pass_max_shift[4];   // Modular channels of a pass: those whose shift lies in [min, max] (Passes::GetDownsamplingBracket); one pass: 0..2
+  int32_t pass_min_shift[kMaxPasses], pass_max_shift[kMaxPasses];   // Modular channels of a pass: those whose shift lies in [min, max] (Passes::GetDownsamplingBracket); one pass: 0..2
   // quantiser / LF
   float lf_fac[3];                 // lf_dequant[c] * 65536/(global_scale*quant_lf)
   float cfl_dc_x, cfl_dc_b;
@@ -90,8 +91,8 @@ struct DevFrame {
   uint32_t single_lf_bit;          // single-section frames: bit offset of LfGroup 0 / of the PassGroup inside section 0
   uint32_t single_pass_bit;
   // HF
-  DevEC hf_ec[4];                  // per pass (up to 4 passes supported on device)
-  uint32_t order_off[4][13][3];    // u32 order arrays: offset in the frame blob, or kOrderInStatic | offset in the static tables (order_ptr)
+  DevEC hf_ec[kMaxPasses];         // per pass
+  uint32_t order_off[kMaxPasses][13][3];    // u32 order arrays: offset in the frame blob, or kOrderInStatic | offset in the static tables (order_ptr)
   // sections
   uint32_t cs_size;                // bytes of the codestream buffer (device copy carries >= 64 B of zero padding)
   uint32_t sec_off;                // DevSection[nsec]: [0]=LfGlobal, 1..=LfGroup, then HfGlobal, then PassGroups

@@ -357,9 +357,8 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
   const frame_hdr &f = pv->f;
   Blob blob(plan->tables);
   if (!hx_bool(br)) {
-    // DequantMatrices (ISO/IEC 18181-1 I.2.4), one encoding per quant table: 0 library, 6 DCT band parameters, 7 RAW (a Modular image of three
-    // channels — libjxl's 8x8 table of a recompressed JPEG).  The multipliers go into the frame blob (DevFrame::qw_frame_off); the parametrised
-    // special 8x8 tables (modes 1 - 5), which no encoder writes, are reported unsupported.
+    // DequantMatrices (ISO/IEC 18181-1 I.2.4), one encoding per quant table: 0 library, 1 - 5 the special 8 x 8 tables from their own parameters, 6 DCT band parameters,
+    // 7 RAW (a Modular image of three channels — libjxl's 8x8 table of a recompressed JPEG).  The multipliers go into the frame blob (DevFrame::qw_frame_off).
     for (int t = 0; t < 17; t++) {
       const int mode = (int)hx_bits(br, 3);
       const int rows = kQTRows[t] * 8, cols = kQTCols[t] * 8, n = rows * cols;
@@ -396,13 +395,17 @@ static int parse_hf_global(FramePlan *plan, Priv *pv, hx_br *br) {
           if (wgt >= 1e8f || wgt < 1e-8f) { plan->error = "RAW quant table entry out of range"; return -1; }
           mul[c][(size_t)i] = 1.0f / wgt;
         }
-      } else { plan->error = "unsupported: parametrised 8x8 dequant matrices (encoding mode " + std::to_string(mode) + ")"; return -1; }
+      } else {                                          // modes 1 - 5: the special 8 x 8 tables from their own parameters (host_format.inc: read_special_quant_weights)
+        float wbuf[3][64]; float *w[3] = {wbuf[0], wbuf[1], wbuf[2]};
+        if (read_special_quant_weights(br, t, mode, w)) { plan->error = "invalid: dequant matrix parameters (encoding mode " + std::to_string(mode) + " for table " + std::to_string(t) + ")"; return -1; }
+        for (int c = 0; c < 3; c++) for (int i = 0; i < 64; i++) mul[c][(size_t)i] = 1.0f / w[c][i];
+      }
       if (br->err) { plan->error = "truncated HfGlobal"; return -1; }
       for (int c = 0; c < 3; c++) F.qw_frame_off[t][c] = blob.append(mul[c].data(), (size_t)n * 4);
     }
   }
   F.num_presets = 1 + (int)hx_bits(br, ceil_log2u((uint32_t)f.num_groups));
-  if (f.num_passes > 4) { plan->error = "unsupported: more than 4 passes"; return -1; }
+  if (f.num_passes > kMaxPasses) { plan->error = "invalid: more than 11 passes"; return -1; }
   if (getenv("JXLAMD_PARSE_TRACE")) fprintf(stderr, "HfGlobal: %d presets, %d block contexts, %d groups\n", F.num_presets, F.num_bctx, f.num_groups);
   for (int p = 0; p < f.num_passes; p++) {
     uint32_t used = hx_u32(br, -1, 0x5F, -1, 0x13, -1, 0, 13, 0);
@@ -1037,8 +1040,8 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     // which Modular channels travel in which pass (libjxl: Passes::GetDownsamplingBracket): pass p takes the shifts [min, max]; a pass that completes a
     // downsampling level (last_pass) lowers min to that level's shift, the last pass goes down to 0, and the next pass starts just below
     int max_shift = 2, min_shift = 3;
-    for (int p = 0; p < 4; p++) { F.pass_min_shift[p] = 3; F.pass_max_shift[p] = 2; }
-    for (int p = 0; p < f.num_passes && p < 4; p++) {
+    for (int p = 0; p < kMaxPasses; p++) { F.pass_min_shift[p] = 3; F.pass_max_shift[p] = 2; }
+    for (int p = 0; p < f.num_passes && p < kMaxPasses; p++) {
       for (int j = 0; j < f.num_ds; j++) if (p == f.ds_last[j]) min_shift = f.ds[j] == 8 ? 3 : f.ds[j] == 4 ? 2 : f.ds[j] == 2 ? 1 : 0;
       if (p == f.num_passes - 1) min_shift = 0;
       F.pass_min_shift[p] = min_shift; F.pass_max_shift[p] = max_shift;

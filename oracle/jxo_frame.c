@@ -379,6 +379,90 @@ static void quant_weights_dct(const jxo_dctparams *p, int rows, int cols, float 
       }
   }
 }
+
+/* ---- the parametrised forms of the special 8 x 8 quant tables (ISO/IEC 18181-1 I.2.4: encoding modes 1 - 5; libjxl's library tables are these forms with
+   its default parameters).  b: distance bands as read (b[c][0] already x 64), nb of them. */
+typedef struct { int nb; double b[3][17]; } qparams;
+static void qparams_from(const jxo_dctparams *p, qparams *q) { q->nb = p->nbands; for (int c = 0; c < 3; c++) for (int i = 0; i < p->nbands; i++) q->b[c][i] = p->b[c][i]; }
+static int quant_weights_bands(const qparams *p, int rows, int cols, float *out[3]) {
+  for (int c = 0; c < 3; c++) {
+    double bands[17];
+    bands[0] = p->b[c][0];
+    if (bands[0] < 1e-8) return -1;
+    for (int i = 1; i < p->nb; i++) { bands[i] = bands[i - 1] * band_mult(p->b[c][i]); if (bands[i] < 1e-8) return -1; }
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        double dx = (double)x / (cols - 1), dy = (double)y / (rows - 1);
+        out[c][y * cols + x] = (float)interp_bands(sqrt(dx * dx + dy * dy), sqrt(2.0) + 1e-6, bands, p->nb);
+      }
+  }
+  return 0;
+}
+/* table 1 (IDENTITY): idw[c][3];  table 2 (DCT2X2): d2[c][6];  table 3 (DCT4X4): 4 x 4 bands + mul4[c][2];  table 9 (DCT4X8 / 8X4): 4 x 8 bands + mul48[c];
+   table 10 (AFV): afv[c][9] + the 4 x 8 and the 4 x 4 bands.  Returns -1 on parameters libjxl rejects. */
+static int special_quant_weights(int t, const float idw[3][3], const float d2[3][6], const qparams *p4, const float mul4[3][2], const qparams *p48, const float mul48[3],
+                                 const float afv[3][9], float *w[3]) {
+  if (t == 1) {
+    for (int c = 0; c < 3; c++) { for (int i = 0; i < 64; i++) w[c][i] = idw[c][0]; w[c][1] = w[c][8] = idw[c][1]; w[c][9] = idw[c][2]; }
+  } else if (t == 2) {
+    for (int c = 0; c < 3; c++) {
+      const float *d = d2[c];
+      w[c][0] = 1.0f; w[c][1] = w[c][8] = d[0]; w[c][9] = d[1];
+      for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { w[c][y * 8 + x + 2] = d[2]; w[c][(y + 2) * 8 + x] = d[2]; w[c][(y + 2) * 8 + x + 2] = d[3]; }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { w[c][y * 8 + x + 4] = d[4]; w[c][(y + 4) * 8 + x] = d[4]; w[c][(y + 4) * 8 + x + 4] = d[5]; }
+    }
+  } else if (t == 3) {
+    float b4[3][16]; float *p4o[3] = {b4[0], b4[1], b4[2]};
+    if (quant_weights_bands(p4, 4, 4, p4o)) return -1;
+    for (int c = 0; c < 3; c++) {
+      for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b4[c][(y / 2) * 4 + x / 2];
+      w[c][1] /= mul4[c][0]; w[c][8] /= mul4[c][0]; w[c][9] /= mul4[c][1];
+    }
+  } else if (t == 9) {
+    float b48[3][32]; float *p48o[3] = {b48[0], b48[1], b48[2]};
+    if (quant_weights_bands(p48, 4, 8, p48o)) return -1;
+    for (int c = 0; c < 3; c++) { for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b48[c][(y / 2) * 8 + x]; w[c][8] /= mul48[c]; }
+  } else if (t == 10) {
+    float b48[3][32]; float *p48o[3] = {b48[0], b48[1], b48[2]};
+    float b4[3][16]; float *p4o[3] = {b4[0], b4[1], b4[2]};
+    if (quant_weights_bands(p48, 4, 8, p48o) || quant_weights_bands(p4, 4, 4, p4o)) return -1;
+    const double lo = 0.8517778890324296, hi = 12.97166202570235 - lo + 1e-6;
+    for (int c = 0; c < 3; c++) {
+      double bands[4];
+      bands[0] = afv[c][5];
+      if (bands[0] < 1e-8) return -1;
+      for (int i = 1; i < 4; i++) { bands[i] = bands[i - 1] * band_mult(afv[c][i + 5]); if (bands[i] < 1e-8) return -1; }
+      w[c][0] = 1.0f;
+      #define SETW(x, y, v) w[c][(y) * 8 + (x)] = (float)(v)
+      SETW(0, 1, afv[c][0]); SETW(1, 0, afv[c][1]);
+      SETW(0, 2, afv[c][2]); SETW(2, 0, afv[c][3]); SETW(2, 2, afv[c][4]);
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
+        if (x < 2 && y < 2) continue;
+        SETW(2 * x, 2 * y, interp_bands(kAfvFreqs[y * 4 + x] - lo, hi, bands, 4));
+      }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y + 1) * 8 + x] = b48[c][y * 8 + x]; }
+      for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y) * 8 + 2 * x + 1] = b4[c][y * 4 + x]; }
+      #undef SETW
+    }
+  } else return -1;
+  for (int c = 0; c < 3; c++) for (int i = 0; i < 64; i++) if (!(w[c][i] > 1e-8f) || !(w[c][i] < 1e8f)) { if (i == 0 && (t == 2 || t == 10)) continue; return -1; }
+  return 0;
+}
+/* reads the parameters of encoding mode 1 - 5 for table t and computes the weights; -1: wrong table for the mode or parameters out of range, -2: truncated */
+#define QP_READ_DCT(q) do { (q).nb = (int)jxo_bits(br, 4) + 1; for (int c = 0; c < 3; c++) { for (int i = 0; i < (q).nb; i++) (q).b[c][i] = jxo_f16(br); if ((q).b[c][0] < 1e-8) return -1; (q).b[c][0] *= 64.0; } } while (0)
+static int read_special_quant_weights(jxo_br *br, int t, int mode, float *w[3]) {
+  float idw[3][3] = {{0}}, d2[3][6] = {{0}}, mul4[3][2] = {{1, 1}, {1, 1}, {1, 1}}, mul48[3] = {1, 1, 1}, afv[3][9] = {{0}};
+  qparams p4, p48; p4.nb = p48.nb = 1;
+  if (mode == 1) { if (t != 1) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) { idw[c][i] = jxo_f16(br); if (idw[c][i] < 1e-8f) return -1; idw[c][i] *= 64.0f; } }
+  else if (mode == 2) { if (t != 2) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) { d2[c][i] = jxo_f16(br); if (d2[c][i] < 1e-8f) return -1; d2[c][i] *= 64.0f; } }
+  else if (mode == 3) { if (t != 3) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) { mul4[c][i] = jxo_f16(br); if (mul4[c][i] < 1e-8f) return -1; } QP_READ_DCT(p4); }
+  else if (mode == 4) { if (t != 9) return -1; for (int c = 0; c < 3; c++) { mul48[c] = jxo_f16(br); if (mul48[c] < 1e-8f) return -1; } QP_READ_DCT(p48); }
+  else if (mode == 5) { if (t != 10) return -1; for (int c = 0; c < 3; c++) { for (int i = 0; i < 9; i++) afv[c][i] = jxo_f16(br); for (int i = 0; i < 6; i++) afv[c][i] *= 64.0f; } QP_READ_DCT(p48); QP_READ_DCT(p4); }
+  else return -1;
+  return special_quant_weights(t, idw, d2, &p4, mul4, &p48, mul48, afv, w);
+}
+#undef QP_READ_DCT
+
 static void init_quant_tables(void) {
   if (qt_weights[0][0]) return;
   static const jxo_dctparams *dctp[17] = {&kDct8, 0, 0, 0, &kDct16, &kDct32, &kDct8x16, &kDct8x32, &kDct16x32, 0, 0,
@@ -388,46 +472,11 @@ static void init_quant_tables(void) {
     float *w[3];
     for (int c = 0; c < 3; c++) w[c] = qt_weights[t][c] = (float *)calloc((size_t)rows * (size_t)cols, 4);
     if (dctp[t]) { quant_weights_dct(dctp[t], rows, cols, w); continue; }
-    if (t == 1) {
-      for (int c = 0; c < 3; c++) { for (int i = 0; i < 64; i++) w[c][i] = kIdWeights[c][0]; w[c][1] = w[c][8] = kIdWeights[c][1]; w[c][9] = kIdWeights[c][2]; }
-    } else if (t == 2) {
-      for (int c = 0; c < 3; c++) {
-        const float *d = kDct2Weights[c];
-        w[c][0] = 1.0f; w[c][1] = w[c][8] = d[0]; w[c][9] = d[1];
-        for (int y = 0; y < 2; y++) for (int x = 0; x < 2; x++) { w[c][y * 8 + x + 2] = d[2]; w[c][(y + 2) * 8 + x] = d[2]; w[c][(y + 2) * 8 + x + 2] = d[3]; }
-        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { w[c][y * 8 + x + 4] = d[4]; w[c][(y + 4) * 8 + x] = d[4]; w[c][(y + 4) * 8 + x + 4] = d[5]; }
-      }
-    } else if (t == 3) {
-      float b4[3][16]; float *p4[3] = {b4[0], b4[1], b4[2]};
-      quant_weights_dct(&kDct4, 4, 4, p4);
-      for (int c = 0; c < 3; c++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b4[c][(y / 2) * 4 + x / 2];
-      /* dct4multipliers are all 1.0 in the default library */
-    } else if (t == 9) {
-      float b48[3][32]; float *p48[3] = {b48[0], b48[1], b48[2]};
-      quant_weights_dct(&kDct4x8, 4, 8, p48);
-      for (int c = 0; c < 3; c++) for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) w[c][y * 8 + x] = b48[c][(y / 2) * 8 + x];
-    } else if (t == 10) {
-      float b48[3][32]; float *p48[3] = {b48[0], b48[1], b48[2]};
-      float b4[3][16]; float *p4[3] = {b4[0], b4[1], b4[2]};
-      quant_weights_dct(&kDct4x8, 4, 8, p48);
-      quant_weights_dct(&kDct4, 4, 4, p4);
-      const double lo = 0.8517778890324296, hi = 12.97166202570235 - lo + 1e-6;
-      for (int c = 0; c < 3; c++) {
-        double bands[4];
-        bands[0] = kAfvWeights[c][5];
-        for (int i = 1; i < 4; i++) bands[i] = bands[i - 1] * band_mult(kAfvWeights[c][i + 5]);
-        w[c][0] = 1.0f;
-        #define SETW(x, y, v) w[c][(y) * 8 + (x)] = (float)(v)
-        SETW(0, 1, kAfvWeights[c][0]); SETW(1, 0, kAfvWeights[c][1]);
-        SETW(0, 2, kAfvWeights[c][2]); SETW(2, 0, kAfvWeights[c][3]); SETW(2, 2, kAfvWeights[c][4]);
-        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) {
-          if (x < 2 && y < 2) continue;
-          SETW(2 * x, 2 * y, interp_bands(kAfvFreqs[y * 4 + x] - lo, hi, bands, 4));
-        }
-        for (int y = 0; y < 4; y++) for (int x = 0; x < 8; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y + 1) * 8 + x] = b48[c][y * 8 + x]; }
-        for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) { if (x == 0 && y == 0) continue; w[c][(2 * y) * 8 + 2 * x + 1] = b4[c][y * 4 + x]; }
-        #undef SETW
-      }
+    {
+      static const float one2[3][2] = {{1, 1}, {1, 1}, {1, 1}}, one1[3] = {1, 1, 1};
+      qparams p4, p48;
+      qparams_from(&kDct4, &p4); qparams_from(&kDct4x8, &p48);
+      (void)special_quant_weights(t, kIdWeights, kDct2Weights, &p4, one2, &p48, one1, kAfvWeights, w);      /* the library's own parameters */
     }
   }
 }
@@ -719,7 +768,7 @@ static int read_hf_global(fstate *s, jxo_br *br) {
   const frame_hdr *f = &s->f;
   if (!jxo_bool(br)) {
     /* DequantMatrices (ISO/IEC 18181-1 I.2.4): one encoding per quant table.  Mode 0 library, 6 DCT band parameters, 7 RAW (a Modular image of
-       3 channels: what libjxl writes for the 8x8 table of a recompressed JPEG); the parametrised 8x8 special tables (modes 1-5) are not restated */
+       3 channels: what libjxl writes for the 8x8 table of a recompressed JPEG); modes 1 - 5 the special 8x8 tables from their own parameters */
     for (int t = 0; t < 17; t++) {
       int mode = (int)jxo_bits(br, 3);
       int rows = kQTRows[t] * 8, cols = kQTCols[t] * 8, n = rows * cols;
@@ -751,7 +800,7 @@ static int read_hf_global(fstate *s, jxo_br *br) {
           w[c][i] = 1.0f / (den * (float)q);          /* the "weight" as the library tables hold it; the dequant multiplier is its reciprocal, ~ den * q */
         }
         jxo_modimg_free(&im);
-      } else JXO_FAIL("unsupported: parametrised 8x8 quant tables (mode %d)", mode);
+      } else if (read_special_quant_weights(br, t, mode, w)) JXO_FAIL("invalid: dequant matrix parameters (mode %d for table %d)", mode, t);      /* modes 1 - 5 */
     }
   }
   s->num_presets = 1 + (int)jxo_bits(br, ceil_log2u((uint32_t)f->num_groups));

@@ -120,7 +120,9 @@ SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
 # hand-written codestreams (tools/jxl_write.py -> tests/golden/make_golden.py: writer_case): the DCT128 / DCT256 varblock families (AcStrategy 21 .. 26), which
 # libjxl's encoder never selects and its decoder takes, and splines (K.4: what jxl-art files draw with); expected pixels = the reference's decode
 WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
-                "w_preview"]      # ... + a preview frame in front of the image's frame (walked over)
+                "w_preview",      # ... + a preview frame in front of the image's frame (walked over)
+                "w_dequant_a", "w_dequant_b",      # DequantMatrices encodings 1 - 6: every special 8 x 8 table from its own parameters
+                "w_passes6", "w_passes11"]         # more passes than any encoder writes (the format allows 11)
 VARDCT_CASES = VARDCT_CASES + WRITER_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vpm400x300_e7_premultiplied", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)
 

@@ -293,9 +293,93 @@ def metadata_case(name, W):
     return img(64, fac, upsampling=fac, up_weights={fac: [x * (1 + 0.5 * rng.standard_normal()) + 0.02 * rng.standard_normal() for x in w]})
 
 
+def dequant_case(name, W):
+    """DequantMatrices encodings 1 - 5 (the special 8 x 8 tables from their own parameters: IDENTITY, DCT2X2, DCT4X4 with multipliers, DCT4X8 / DCT8X4 with a
+    multiplier, AFV) and 6 (distance bands) for DCT8, on an image whose varblocks use every one of those transforms; with libjxl's library tables instead the
+    reference's pixels are up to 46 codes away.  w_dequant_b: other parameters, 17 distance bands for DCT16, library tables for the rest."""
+    seed = {"w_dequant_a": 9, "w_dequant_b": 10}[name]
+    rng = np.random.default_rng(seed)
+    size = 64 if name == "w_dequant_a" else 128
+    nb = size // 8
+    yy, xx = np.mgrid[0:nb, 0:nb]
+    lf = np.stack([np.round(30 * np.sin(xx / 5.0 + seed)).astype(np.int64), 5000 + 60 * xx + 45 * yy, np.round(40 * np.cos(yy / 4.0 + seed)).astype(np.int64)])
+
+    def co(st, n, amp):
+        total, covered = W.natural_order_len(st), W.COVERED_X[st] * W.COVERED_Y[st]
+        return {int(k): int(v) for k, v in zip(rng.choice(np.arange(covered, total), n, replace=False), rng.integers(-amp, amp + 1, n)) if v}
+    f16 = lambda v: float(np.float16(v))
+    r = lambda lo, hi: f16(rng.uniform(lo, hi))
+    if name == "w_dequant_a":
+        strategies = [1, 2, 3, 12, 13, 14, 15, 16, 17, 0]
+        blocks = [dict(bx=x, by=y, strategy=strategies[(y * nb + x) % len(strategies)], qf=int(rng.integers(4, 12)), coef={1: co(0, 12, 25), 0: co(0, 4, 5), 2: co(0, 5, 8)})
+                  for y in range(nb) for x in range(nb)]
+    else:
+        blocks = []
+        for by in range(0, nb, 2):
+            for bx in range(0, nb, 2):
+                if (bx // 2 + by // 2) % 3 == 0:
+                    blocks.append(dict(bx=bx, by=by, strategy=4, qf=int(rng.integers(4, 12)), coef={1: co(4, 30, 25), 0: co(4, 6, 5), 2: co(4, 8, 8)}))
+                else:
+                    for (dx, dy) in ((0, 0), (1, 0), (0, 1), (1, 1)):
+                        st = [3, 14, 12, 2, 1, 17][(bx + by + dx + 2 * dy) % 6]
+                        blocks.append(dict(bx=bx + dx, by=by + dy, strategy=st, qf=int(rng.integers(4, 12)), coef={1: co(0, 12, 25), 0: co(0, 4, 5), 2: co(0, 5, 8)}))
+    b48 = [[r(28, 40), r(-1, -0.5), r(-0.9, -0.5), r(-0.7, -0.5)], [r(10, 14), r(-1, -0.6), r(-1, -0.2), r(-0.4, -0.2)], [r(7, 10), r(-1.5, -1), r(-1.5, -1), r(-1.6, -1.2)]]
+    b4 = [[r(30, 40), r(-0.1, 0.1), r(-0.1, 0.1), r(-0.1, 0.1)], [r(5, 7), r(-0.1, 0.1), r(-0.1, 0.1), r(-0.1, 0.1)], [r(1.5, 2), r(-0.3, -0.2), r(-0.3, -0.2), r(-0.6, -0.4)]]
+    deq = {
+        1: (1, [[r(2, 6), r(30, 60), r(30, 60)], [r(0.5, 1.5), r(8, 16), r(8, 16)], [r(0.2, 0.5), r(2, 4), r(2, 4)]]),
+        2: (2, [[r(40, 70), r(30, 50), r(15, 25), r(8, 12), r(6, 9), r(4, 6)], [r(10, 18), r(8, 12), r(4, 6), r(2, 3.5), r(2, 2.5), r(1.5, 2)],
+                [r(8, 12), r(4, 6), r(1.5, 2.5), r(0.8, 1.2), r(0.4, 0.6), r(0.2, 0.3)]]),
+        3: (3, ([[r(0.7, 1.4), r(0.7, 1.4)] for _ in range(3)], [[r(25, 40), r(-0.3, 0.1), r(-0.3, 0.1), r(-0.5, 0)], [r(5, 8), r(-0.3, 0.1), r(-0.2, 0), r(-0.2, 0)],
+                                                                   [r(1.5, 2.5), r(-0.4, -0.1), r(-0.4, -0.1), r(-0.6, -0.2)]])),
+        9: (4, ([r(0.7, 1.4) for _ in range(3)], [row[:3] for row in b48])),
+        10: (5, ([[r(40, 55), r(40, 55), r(3, 5), r(3, 5), r(3, 5), r(5, 8), r(-0.2, 0.1), r(-0.2, 0.1), r(-0.2, 0.1)],
+                  [r(14, 18), r(14, 18), r(0.6, 1), r(0.6, 1), r(0.6, 1), r(0.7, 1.1), r(-0.2, 0.1), r(-0.2, 0.1), r(-0.2, 0.1)],
+                  [r(5, 7), r(5, 7), r(0.15, 0.25), r(0.15, 0.25), r(0.15, 0.25), r(0.3, 0.4), r(-0.3, -0.2), r(-0.3, -0.2), r(-0.3, -0.2)]], b48, b4)),
+    }
+    if name == "w_dequant_a":
+        deq[0] = (6, [[r(40, 60), r(-0.2, 0), r(-0.5, -0.3), r(-0.5, -0.3)], [r(7, 10), r(-0.1, 0), r(-0.4, -0.2), r(-0.4, -0.2)], [r(6, 9), r(-2, -1), r(-1, -0.5), r(-0.5, 0)]])
+    else:
+        del deq[9]
+        deq[4] = (6, [[r(120, 150)] + [r(-0.5, -0.1) for _ in range(15)], [r(40, 60)] + [r(-0.4, -0.1) for _ in range(15)], [r(15, 20)] + [r(-0.8, -0.2) for _ in range(15)]])
+    return W.write_vardct(size, size, blocks, lf, dequant=deq)
+
+
+def passes_case(name, W):
+    """Frames of 6 and 11 passes (the format's maximum; libjxl's encoder writes at most 4): every pass adds its coefficients << its shift; mixed varblock sizes
+    (DCT8, DCT16, DCT32, DCT2X2, DCT4X4), sections apart (TOC of 3 + passes entries)."""
+    shifts = {"w_passes6": [3, 2, 1, 0, 0], "w_passes11": [3, 3, 2, 2, 1, 1, 0, 0, 0, 0]}[name]
+    size, seed, N = 128, len(shifts), len(shifts) + 1
+    nb = size // 8
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:nb, 0:nb]
+    lf = np.stack([np.round(30 * np.sin(xx / 5.0 + seed)).astype(np.int64), 5000 + 60 * xx + 45 * yy, np.round(40 * np.cos(yy / 4.0 + seed)).astype(np.int64)])
+    sts = [0, 0, 4, 0, 5, 2, 3]
+    blocks = []
+    occ = np.zeros((nb, nb), bool)
+    for y in range(nb):
+        for x in range(nb):
+            if occ[y, x]:
+                continue
+            st = sts[int(rng.integers(0, len(sts)))]
+            cx, cy = W.COVERED_X[st], W.COVERED_Y[st]
+            if x + cx > nb or y + cy > nb or occ[y:y + cy, x:x + cx].any():
+                st = 0; cx = cy = 1
+            occ[y:y + cy, x:x + cx] = True
+            total, cov = W.natural_order_len(st), cx * cy
+
+            def co(n, amp):
+                return {int(k): int(v) for k, v in zip(rng.choice(np.arange(cov, total), min(n, total - cov), replace=False), rng.integers(-amp, amp + 1, n)) if v}
+            blocks.append(dict(bx=x, by=y, strategy=st, qf=int(rng.integers(4, 12)), coef_passes=[{1: co(6, 6), 0: co(2, 2), 2: co(3, 3)} for _ in range(N)]))
+    return W.write_vardct(size, size, blocks, lf, pass_shifts=shifts)
+
+
 def writer_case(name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import jxl_write as W
+    if name.startswith("w_passes"):
+        return passes_case(name, W)
+    if name.startswith("w_dequant"):
+        return dequant_case(name, W)
     if name.startswith("w_spline"):
         return spline_case(name, W)
     if name.startswith("w_up") or name == "w_preview":
@@ -372,7 +456,7 @@ def spline_case(name, W):
 
 
 WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
-                "w_up2_custom", "w_up4_custom", "w_up8_custom", "w_preview"]
+                "w_up2_custom", "w_up4_custom", "w_up8_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_passes6", "w_passes11"]
 
 
 def add_writer_cases(meta, only):

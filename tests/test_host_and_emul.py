@@ -182,6 +182,25 @@ def test_harness_rejects_what_the_device_path_does_not_support(emul):
         emul(open(os.path.join(ROOT, "tests", "golden", "u48x32_float32_mixed_sign.jxl"), "rb").read())
 
 
+def test_dequant_encodings_for_the_wrong_table_or_with_bad_parameters_are_invalid(emul):
+    """DequantMatrices (I.2.4): encoding 1 belongs to the IDENTITY table alone, 2 to DCT2X2, 3 to DCT4X4, 4 to DCT4X8, 5 to AFV, and a first band /
+    weight / multiplier below 1e-8 is rejected — as libjxl does (tools/jxl_write.py writes such headers; the parser says invalid, it does not guess)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_write as W
+    nb = 4
+    lf = np.stack([np.zeros((nb, nb), np.int64), np.full((nb, nb), 5000, np.int64), np.zeros((nb, nb), np.int64)])
+    blocks = [dict(bx=x, by=y, strategy=0, qf=8, coef={1: {3: 4}}) for y in range(nb) for x in range(nb)]
+    idw = [[4.0, 40.0, 40.0]] * 3
+    emul(W.write_vardct(32, 32, blocks, lf, dequant={1: (1, idw)}))                    # the right table: decodes
+    with pytest.raises(ValueError, match="invalid"):
+        emul(W.write_vardct(32, 32, blocks, lf, dequant={0: (1, idw)}))                # IDENTITY parameters for the DCT8 table
+    with pytest.raises(ValueError, match="invalid"):
+        emul(W.write_vardct(32, 32, blocks, lf, dequant={2: (4, ([1.0] * 3, [[30.0, -0.5]] * 3))}))      # DCT4X8 parameters for the DCT2X2 table
+    with pytest.raises(ValueError, match="invalid"):
+        emul(W.write_vardct(32, 32, blocks, lf, dequant={1: (1, [[0.0, 40.0, 40.0]] * 3)}))            # a zero weight
+
+
 def test_harness_flags_corrupt_streams(emul):
     data, _ = load_case("v264x520_e7")
     bad = bytearray(data)

@@ -305,11 +305,17 @@ def write_size_header(bw, width, height):
 
 
 def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=None, global_scale=32768, quant_lf=64, gab=True, epf_iters=2,
-                 splines=None, spline_quant_adjust=0, x_qm=3, b_qm=2, upsampling=1, up_weights=None, preview=None, as_frame=False):
+                 splines=None, spline_quant_adjust=0, x_qm=3, b_qm=2, upsampling=1, up_weights=None, preview=None, as_frame=False, dequant=None, pass_shifts=None):
     """upsampling: 1 / 2 / 4 / 8 — the image is width * upsampling x height * upsampling, the frame is coded at width x height;
     up_weights: {2: [15 floats], 4: [55], 8: [210]} custom upsampling weights in the image metadata (upper triangles of the symmetric kernel matrices);
     preview: the bytes of a frame (write_vardct(..., as_frame=True)) of pw x ph = preview[1], preview[2] pixels, put in front of the image's frames as its preview;
-    as_frame: return (frame bytes, width, height) without the file header."""
+    as_frame: return (frame bytes, width, height) without the file header;
+    dequant: {quant table index: (mode, parameters)} — DequantMatrices encodings (I.2.4), values as STORED (the decoder multiplies most of them by 64):
+             1 (table 1, IDENTITY): [3][3]; 2 (table 2, DCT2X2): [3][6]; 3 (table 3, DCT4X4): ([3][2] multipliers, bands [3][nb]); 4 (table 9, DCT4X8 / DCT8X4):
+             ([3] multipliers, bands); 5 (table 10, AFV): ([3][9], bands of the 4 x 8 part, bands of the 4 x 4 part); 6 (any DCT table): bands [3][nb];
+    pass_shifts: [shift of pass 0, ..., shift of pass N - 2] (0..3 each) makes a frame of N = len + 1 passes (2..11): every block then carries
+             "coef_passes" = [coef dict of pass 0, ..., of pass N - 1] instead of "coef"; the decoder adds value << shift of every pass (the last pass's shift is 0).
+             Such a frame has its LfGlobal / LfGroup / HfGlobal / PassGroup sections apart (TOC of 3 + N entries)."""
     """A one-group VarDCT image.
     blocks: [dict(bx, by, strategy, qf (1..256), coef={channel (0 X, 1 Y, 2 B): {scan position k >= covered cells: quantised value}})] tiling the cell
             grid exactly; lf: int array [3][yb][xb] (X, Y, B quantised LF samples); xfromy / bfromy: int8-range arrays of [ceil(yb/8)][ceil(xb/8)]."""
@@ -366,7 +372,9 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
         bw.align()
     # FrameHeader
     flags = 16 if splines else 0
-    if flags == 0 and gab and epf_iters == 2 and x_qm == 3 and b_qm == 2 and upsampling == 1:
+    npass = 1 + len(pass_shifts) if pass_shifts else 1
+    assert 1 <= npass <= 11
+    if flags == 0 and gab and epf_iters == 2 and x_qm == 3 and b_qm == 2 and upsampling == 1 and npass == 1:
         bw.bool(1)
     else:
         bw.bool(0)
@@ -374,7 +382,13 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
         bw.u64(flags)
         bw.w(2, {1: 0, 2: 1, 4: 2, 8: 3}[upsampling])       # upsampling
         bw.w(3, x_qm); bw.w(3, b_qm)
-        bw.w(2, 0)                                          # one pass
+        if npass == 1:
+            bw.w(2, 0)                                      # one pass
+        else:
+            bw.u32(npass, [(-1, 1), (-1, 2), (-1, 3), (3, 4)])
+            bw.w(2, 0)                                      # num_downsample 0
+            for sh in pass_shifts:
+                bw.w(2, sh)
         bw.bool(0)                                          # no crop
         bw.w(2, 0)                                          # blend mode: replace (full frame: no source)
         bw.bool(1)                                          # is_last
@@ -390,8 +404,10 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
                 bw.bool(0); bw.bool(0); bw.bool(0)          # default sharpness LUT / channel scales / pass parameters
             bw.u64(0)                                       # loop-filter extensions
         bw.u64(0)                                           # frame extensions
-    # ---- the single section
+    # ---- the single section (one pass), or LfGlobal / LfGroup / HfGlobal / one PassGroup section per pass
     sec = BW()
+    sec_lfgroup = sec if npass == 1 else BW()
+    sec_hfglobal = sec if npass == 1 else BW()
     if splines:
         write_splines(sec, splines, spline_quant_adjust)
     sec.bool(1)                                             # default LF dequantisation
@@ -401,39 +417,82 @@ def write_vardct(width, height, blocks, lf, xfromy=None, bfromy=None, sharpness=
     sec.bool(1)                                             # default colour correlation
     sec.bool(0)                                             # no global MA tree
     # LfGroup: LF coefficients (channels Y, X, B), then HF metadata
-    sec.w(2, 0)                                             # extra_precision
+    sec_lfgroup.w(2, 0)                                             # extra_precision
     lf = np.asarray(lf, dtype=np.int64)
     grad = ("leaf", 5, 0)
-    write_modular(sec, [lf[1], lf[0], lf[2]], grad, 1)
+    write_modular(sec_lfgroup, [lf[1], lf[0], lf[2]], grad, 1)
     nblk = len(order)
-    sec.w(max(0, (xb * yb - 1).bit_length()), nblk - 1)
+    sec_lfgroup.w(max(0, (xb * yb - 1).bit_length()), nblk - 1)
     xf = np.zeros((th, tw), np.int64) if xfromy is None else np.asarray(xfromy, np.int64)
     bf = np.zeros((th, tw), np.int64) if bfromy is None else np.asarray(bfromy, np.int64)
     info = np.array([[b["strategy"] for b in order], [b["qf"] - 1 for b in order]], np.int64)
     sh = np.zeros((yb, xb), np.int64) if sharpness is None else np.asarray(sharpness, np.int64)
     west = ("leaf", 1, 0)
-    write_modular(sec, [xf, bf, info, sh], west, 3)
+    write_modular(sec_lfgroup, [xf, bf, info, sh], west, 3)
     # HfGlobal
-    sec.bool(1)                                             # default dequant matrices
-    sec.w(2, 2)                                             # used_orders = 0 (selector 2): natural coefficient orders      (num_presets: 0 bits for one group)
-    hf = EC(495 * 15)
+    if not dequant:
+        sec_hfglobal.bool(1)                                         # default dequant matrices
+    else:
+        def bands(b):
+            nb = len(b[0]); assert all(len(r) == nb for r in b) and 1 <= nb <= 16
+            sec_hfglobal.w(4, nb - 1)
+            for c in range(3):
+                for v in b[c]:
+                    sec_hfglobal.f16(v)
+        sec_hfglobal.bool(0)
+        for t in range(17):
+            mode, prm = dequant.get(t, (0, None))
+            sec_hfglobal.w(3, mode)
+            if mode == 1 or mode == 2:
+                for c in range(3):
+                    for v in prm[c]:
+                        sec_hfglobal.f16(v)
+            elif mode == 3:
+                for c in range(3):
+                    for v in prm[0][c]:
+                        sec_hfglobal.f16(v)
+                bands(prm[1])
+            elif mode == 4:
+                for c in range(3):
+                    sec_hfglobal.f16(prm[0][c])
+                bands(prm[1])
+            elif mode == 5:
+                for c in range(3):
+                    for v in prm[0][c]:
+                        sec_hfglobal.f16(v)
+                bands(prm[1]); bands(prm[2])
+            elif mode == 6:
+                bands(prm)
+            else:
+                assert mode == 0
+    sec_hfglobal.w(2, 2)                                             # used_orders = 0 (selector 2): natural coefficient orders      (num_presets: 0 bits for one group)
     # PassGroup: per varblock (raster order of first cells), channels Y, X, B: nonzero count, then the coefficients up to the last nonzero one
-    for b in order:
-        size, covered = natural_order_len(b["strategy"]), COVERED_X[b["strategy"]] * COVERED_Y[b["strategy"]]
-        for c in (1, 0, 2):
-            co = {int(k): int(v) for k, v in b.get("coef", {}).get(c, {}).items() if v}
-            assert all(covered <= k < size for k in co), (b["strategy"], sorted(co)[:4], covered, size)
-            hf.add(0, len(co))
-            if co:
-                for k in range(covered, max(co) + 1):
-                    hf.add(0, pack_signed(co.get(k, 0)))
-    hf.write_header(sec)
-    hf.write_symbols(sec)
-    body = sec.bytes()
+    pass_secs = []
+    for p in range(npass):
+        hf = EC(495 * 15)
+        for b in order:
+            size, covered = natural_order_len(b["strategy"]), COVERED_X[b["strategy"]] * COVERED_Y[b["strategy"]]
+            src = b.get("coef", {}) if npass == 1 else b["coef_passes"][p]
+            for c in (1, 0, 2):
+                co = {int(k): int(v) for k, v in src.get(c, {}).items() if v}
+                assert all(covered <= k < size for k in co), (b["strategy"], sorted(co)[:4], covered, size)
+                hf.add(0, len(co))
+                if co:
+                    for k in range(covered, max(co) + 1):
+                        hf.add(0, pack_signed(co.get(k, 0)))
+        if p > 0:
+            sec_hfglobal.w(2, 2)                            # used_orders = 0 for this pass too
+        hf.write_header(sec_hfglobal)                       # HfPass: the pass's histograms
+        ps = sec if npass == 1 else BW()
+        hf.write_symbols(ps)
+        pass_secs.append(ps)
+    parts = [sec.bytes()] if npass == 1 else [sec.bytes(), sec_lfgroup.bytes(), sec_hfglobal.bytes()] + [ps.bytes() for ps in pass_secs]
+    body = b"".join(parts)
     # TOC
     bw.bool(0)                                              # not permuted
     bw.align()
-    bw.u32(len(body), [(10, 0), (14, 1024), (22, 17408), (30, 4211712)])
+    for part in parts:
+        bw.u32(len(part), [(10, 0), (14, 1024), (22, 17408), (30, 4211712)])
     bw.align()
     if as_frame:
         return bw.bytes() + body, width, height
