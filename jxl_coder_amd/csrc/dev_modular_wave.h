@@ -402,39 +402,57 @@ __device__ __forceinline__ uint32_t ubits_read(DevBits &b, int n) {       // n <
 // Frequency tables sized by the alphabet (round 5): the largest symbol the used clusters can produce + 1, rounded up to a power of two >= 16 — libjxl's LF
 // residual tokens stay below 64, so a cluster costs 512 + 128 bytes at log_alpha 7 instead of 768: 28 clusters 17.5 KB instead of 21 KB, which with the channel
 // descriptors out of the fixed part lets a fourth LF stream into a CU.  0: a symbol >= 128 can occur (not packed).
-__device__ __forceinline__ int wave_alias_dsz(const DevAlias *galias, uint64_t used, int log_alpha, int lane) {
+// the clusters a channel's leaves use (a context map holds up to 256): libjxl's one-shot encoder writes ONE code of ~128 clusters for every Modular stream of a
+// frame, of which an LF channel touches ~30
+struct CluSet {
+  uint64_t w[4];
+  __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = 0; }
+  __device__ __forceinline__ void add(int clu) { const uint64_t bit = 1ull << (clu & 63); const int k = (clu >> 6) & 3; w[0] |= k == 0 ? bit : 0; w[1] |= k == 1 ? bit : 0; w[2] |= k == 2 ? bit : 0; w[3] |= k == 3 ? bit : 0; }
+  __device__ __forceinline__ int count() const { return __builtin_popcountll(w[0]) + __builtin_popcountll(w[1]) + __builtin_popcountll(w[2]) + __builtin_popcountll(w[3]); }
+  __device__ __forceinline__ int rank(int clu) const {      // members below clu = its index in the packed pool
+    const int k = (clu >> 6) & 3;
+    int r = __builtin_popcountll((k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3]) & ((1ull << (clu & 63)) - 1ull));
+    if (k > 0) r += __builtin_popcountll(w[0]);
+    if (k > 1) r += __builtin_popcountll(w[1]);
+    if (k > 2) r += __builtin_popcountll(w[2]);
+    return r;
+  }
+};
+__device__ __forceinline__ int wave_alias_dsz(const DevAlias *galias, const CluSet &used, int log_alpha, int lane) {
   const int table = 1 << log_alpha;
   int mx = 0;
-  for (uint64_t m = used; m; m &= m - 1) {
-    const int s = __builtin_ctzll(m);
-    for (int i = lane; i < table; i += 64) {
-      const DevAlias e = galias[(s << log_alpha) + i];
-      if (e.freq0 != 0 && i > mx) mx = i;
-      if (e.freq1 != 0 && (int)e.right > mx) mx = (int)e.right;
+  for (int k = 0; k < 4; k++)
+    for (uint64_t m = used.w[k]; m; m &= m - 1) {
+      const int s = 64 * k + __builtin_ctzll(m);
+      for (int i = lane; i < table; i += 64) {
+        const DevAlias e = galias[(s << log_alpha) + i];
+        if (e.freq0 != 0 && i > mx) mx = i;
+        if (e.freq1 != 0 && (int)e.right > mx) mx = (int)e.right;
+      }
     }
-  }
   for (int d = 32; d; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
   int dsz = 16;
   while (dsz <= mx) dsz <<= 1;
   return dsz > 128 ? 0 : dsz;
 }
-__device__ __forceinline__ int wave_packed_bytes(uint64_t used, int log_alpha, int dsz) { return __builtin_popcountll(used) * ((4 << log_alpha) + 2 * dsz); }
-__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, uint64_t used, int log_alpha, int dsz, DevModScratch &S, int lane) {
+__device__ __forceinline__ int wave_packed_bytes(const CluSet &used, int log_alpha, int dsz) { return used.count() * ((4 << log_alpha) + 2 * dsz); }
+__device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, const CluSet &used, int log_alpha, int dsz, DevModScratch &S, int lane) {
   if (log_alpha < 5 || log_alpha > 8 || dsz <= 0 || wave_packed_bytes(used, log_alpha, dsz) > S.pool_bytes) return false;
-  const int table = 1 << log_alpha, nc = __builtin_popcountll(used);
+  const int table = 1 << log_alpha, nc = used.count();
   __syncthreads();
   uint32_t *ent = (uint32_t *)S.pool;
   uint16_t *D = (uint16_t *)((uint8_t *)S.pool + ((size_t)nc << (log_alpha + 2)));
   int cid = 0;
-  for (uint64_t m = used; m; m &= m - 1, cid++) {
-    const int s = __builtin_ctzll(m);
-    for (int i = lane; i < table; i += 64) {
-      const DevAlias e = galias[(s << log_alpha) + i];
-      ent[(cid << log_alpha) + i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
-      if (i < dsz) D[cid * dsz + i] = e.freq0;
+  for (int k = 0; k < 4; k++)
+    for (uint64_t m = used.w[k]; m; m &= m - 1, cid++) {
+      const int s = 64 * k + __builtin_ctzll(m);
+      for (int i = lane; i < table; i += 64) {
+        const DevAlias e = galias[(s << log_alpha) + i];
+        ent[(cid << log_alpha) + i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
+        if (i < dsz) D[cid * dsz + i] = e.freq0;
+      }
+      for (int i = table + lane; i < dsz; i += 64) D[cid * dsz + i] = 0;       // symbols beyond the table never occur
     }
-    for (int i = table + lane; i < dsz; i += 64) D[cid * dsz + i] = 0;       // symbols beyond the table never occur
-  }
   __syncthreads();
   return true;
 }
@@ -801,15 +819,15 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     if (c.w > kModMaxW && uses_wp) return kErrWaveFallback;       // the serial walker keeps the predictor's error rows of such channels in HBM
     // the threshold-tree / weighted-predictor specialisation (see wave_decode_channel_wpfixed)
     if (m16 && uses_wp && !ev.use_prefix && c.w >= 4 && c.h >= 2 && WT.ni >= 1 && WT.ni <= 63 && WT.nl <= 64 &&
-        S.st.num_clusters <= kLocMaxClusters && ev.log_alpha >= 5 && ev.log_alpha <= 8 &&
+        ev.log_alpha >= 5 && ev.log_alpha <= 8 &&      // (any number of clusters: the channel's own are packed into the pool — round 5: the 128-cluster codes of libjxl's one-shot files took the general loop here, 1.4 us per LF sample instead of 0.4)
         __ballot(lane < WT.ni && WT.int_prop[lane] != 15) == 0 &&
         __ballot(lane < WT.nl && (WT.leaf_pred[lane] != 6 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0) {
       const int ni = WT.ni, nl = WT.nl;
       const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
       const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
       const int my_lclu = lane < nl ? (int)evg.ctx_map[WT.leaf_ctx[lane]] : 0;
-      uint64_t used = 0;                             // clusters of this channel's leaves
-      for (int j = 0; j < nl; j++) used |= 1ull << (__builtin_amdgcn_readlane(my_lclu, j) & 63);
+      CluSet used; used.clear();                      // clusters of this channel's leaves
+      for (int j = 0; j < nl; j++) used.add(__builtin_amdgcn_readlane(my_lclu, j));
       const int la_p = ev.log_alpha;
       const int dsz = wave_alias_dsz(evg.alias, used, la_p, lane);
       const int packed = dsz ? wave_packed_bytes(used, la_p, dsz) : kModPoolBytes + 1;
@@ -831,8 +849,8 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
-        const int cid = __builtin_popcountll(used & ((1ull << (clu & 63)) - 1ull));      // compact index of the cluster in the packed pool
-        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (__builtin_popcountll(used) << (la_p + 2)) + cid * 2 * dsz; my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
+        const int cid = used.rank(clu);      // compact index of the cluster in the packed pool
+        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (used.count() << (la_p + 2)) + cid * 2 * dsz; my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
       }
       __syncthreads();
       // once the pool holds packed tables the other loops of this stream read their tables through L2 (or restage them compactly)
