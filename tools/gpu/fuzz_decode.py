@@ -16,8 +16,18 @@ t0 = time.time()
 for name in ("v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7", "l700x500_e7", "asset_first_jxl", "l530x300_e1", "v300x300_e7_d3",
              "j420_200x136", "j444_200x136", "jgrey_160x120", "an_blend_lossless", "an_modes_d2_e5", "u96x64_lf_frame", "vlf600x410_e7", "vs400x300_e7_d1", "vu400x300_e7_d10",
              # round 4, last part: delta palettes, Modular channels spread over passes, two levels of LF frames, noise on an upsampled frame, previous-channel properties, upsampled animation layers
-             "lpl400x300_e7_nopatch", "lpl200x136_e7_photo", "vapr400x300_e7", "vaqr520x300_e7", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vnu523x267_e7_d12", "lpc200x136_e7_prev3", "an_blend_d12_e7"):      # round 4: JPEGs, animations, LF frames, patches, upsampling
-    d0 = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+             "lpl400x300_e7_nopatch", "lpl200x136_e7_photo", "vapr400x300_e7", "vaqr520x300_e7", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vnu523x267_e7_d12", "lpc200x136_e7_prev3", "an_blend_d12_e7",      # round 4: JPEGs, animations, LF frames, patches, upsampling
+             # round 5: the writer's files (splines, DCT128 / 256, custom upsampling weights, preview, dequant encodings, 6 / 11 passes) and — made here by the reference's
+             # encoder when it travelled — an RGBA photograph whose alpha streams run from the block form of a 459-leaf tree
+             "w_spline_b", "w_dct_mix_a", "w_dct256", "w_up4_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_passes6", "w_passes11", "FUZZ_LIVE_RGBA"):
+    if name == "FUZZ_LIVE_RGBA":
+        sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import jxl_ref, synth
+        if not jxl_ref.available():
+            continue
+        d0 = jxl_ref.encode(synth.photo_like(700, 523, seed=2002, channels=4), effort=7, distance=1.0, threads=0)
+    else:
+        d0 = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
     ref = dec.decode_one_shot(d0)[0]
     for it in range(n):
         d = bytearray(d0)
