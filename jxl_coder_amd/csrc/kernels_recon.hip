@@ -510,8 +510,53 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, con
   }
 }
 // The DCT128 / DCT256 families (AcStrategy 21 .. 26: 8 192 .. 65 536 coefficients; libjxl's encoder never selects them, its decoder takes them): one
-// workgroup per varblock, one channel at a time through the generic front end and the two separable passes, with the S and T tiles in HBM — a
+// workgroup per varblock, one channel at a time through the generic front end and the two separable passes — matrix products on the matrix cores (recon_huge_block) —, with the S and T tiles in HBM — a
 // workgroup's own 512 KB slice of the context's scratch (L2-resident while it is worked on).  kHugeSlots workgroups walk the lists of ALL frames of the launch.
+// OUT (M x N) = A (M x K) * B (K x N) on the matrix cores, operands straight from HBM / L2 (the S and T tiles of one block and the cosine tables: 64 KB - 256 KB each,
+// L2-resident while the block is worked on): one wave per 32 x 32 output tile, v_mfma_f32_32x32x2_f32 over K two at a time — operand maps as in recon_dct32_mfma.
+template <class FA, class FB, class FO>
+__device__ __forceinline__ void huge_gemm_mfma(int M, int N, int K, FA a, FB b, FO out, int tid) {
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
+  const int tn_count = N >> 5, tiles = (M >> 5) * tn_count;
+  for (int t = wave; t < tiles; t += 4) {
+    const int tm = t / tn_count, tn = t - tm * tn_count;
+    const int row = tm * 32 + j, col = tn * 32 + j;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(row, k + kh), b(k + kh, col), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out(tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, col, acc[r]);
+  }
+}
+// one varblock of the DCT128 / DCT256 families, one channel at a time: the generic front end (dequantisation, chroma from luma, LLF) into S, then both separable
+// passes as matrix products (recon_idct_pass1 / pass2 restated: T = A x CC with A[v][u] = S[v][u] or, for R >= C, S's transposed storage; pixels = CR^T x T)
+__device__ __forceinline__ void recon_huge_block(const DevBuffers &B, const uint8_t *stat, float *S, float *T, int bx, int by, int tid) {
+  const DevFrame &F = frame_of(B);
+  const DevStatic &ST = *(const DevStatic *)stat;
+  const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
+  if (!B.first[o]) return;
+  const int st = B.strategy[o];
+  const int cx = kCoveredX[st], cy = kCoveredY[st];
+  const int n = cx * cy * 64;
+  if (n <= 4096 || F.subsampled) return;
+  const int R = cy * 8, C = cx * 8;
+  const float *cc = st_f(stat, ST.cos_off[ilog2(C)]), *cr = st_f(stat, ST.cos_off[ilog2(R)]);
+  const size_t po = (size_t)by * 8 * (size_t)F.pw + (size_t)bx * 8;
+  for (int c = 0; c < 3; c++) {
+    recon_phaseA(B, stat, ST, S, n, bx, by, tid, 256, c);
+    __syncthreads();
+    recon_phaseB(B, stat, ST, S, n, bx, by, tid, 256, c);
+    __syncthreads();
+    if (R < C) huge_gemm_mfma(R, C, C, [&](int v, int u) { return S[v * C + u]; }, [&](int u, int x) { return cc[u * C + x]; }, [&](int v, int x, float val) { T[v * C + x] = val; }, tid);
+    else huge_gemm_mfma(R, C, C, [&](int v, int u) { return S[u * R + v]; }, [&](int u, int x) { return cc[u * C + x]; }, [&](int v, int x, float val) { T[v * C + x] = val; }, tid);
+    __syncthreads();
+    float *dst = B.plane_a[c] + po;
+    const size_t pw = (size_t)F.pw;
+    huge_gemm_mfma(R, C, R, [&](int y, int v) { return cr[v * R + y]; }, [&](int v, int x) { return T[v * C + x]; }, [&](int y, int x, float val) { dst[(size_t)y * pw + (size_t)x] = val; }, tid);
+    __syncthreads();
+  }
+}
 __global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch) {
   float *S = scratch + (size_t)blockIdx.x * 2 * 65536, *T = S + 65536;
   const int tid = (int)threadIdx.x;
@@ -525,7 +570,7 @@ __global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *Bs, cons
       const int bx = cell % F.xb, by = cell / F.xb;
       if (by < F.band_cy0 || by >= F.band_cy1) continue;
       __syncthreads();
-      recon_block_body<false, true>(B, stat, S, T, bx, by, 4097, 65536, tid, 256, SyncBlock());
+      recon_huge_block(B, stat, S, T, bx, by, tid);
     }
   }
 }
