@@ -61,6 +61,7 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
   int32_t wp_err[2 * (kWpMaxW + 2)];
   int32_t props[16 + 4 * kModMaxRefs];
+  const int32_t *refp[kModMaxRefs];    // wave loop, block-form trees: the previous channels whose samples feed properties 16 .. (same size and shifts, nearest first)
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
   uint32_t wdiv[4][64];               // divlut pre-multiplied by the WP header weights (wave_decode_channel_wpfixed)
   uint32_t ring[128];                 // the next 512 bytes of the stream, refilled half by half far ahead of the reader (wave_decode_channel_wpfixed)
@@ -242,13 +243,14 @@ struct DevBigHdr {
   int32_t ok, nblocks, nnodes, nexits, nonunit, uses_wp;
   int32_t off_nodes, off_need, off_exit, off_mulo, off_blk, capB, capE;
   uint32_t root_word;
-  int32_t pad[2];
+  int32_t max_prop;              // largest property the tree tests (> 15: properties of previous channels)
+  int32_t pad[1];
 };
 static_assert(sizeof(DevBigHdr) == 64, "DevBigHdr: 16 words");
-struct BigCount { int32_t ni, nl, nonunit, uses_wp, ok; };
-// how large is the tree reachable for (chan, stream)?  ok = 0: a property the wave loops do not evaluate (previous channels), or deeper than the stack
+struct BigCount { int32_t ni, nl, nonunit, uses_wp, ok, max_prop; };
+// how large is the tree reachable for (chan, stream), and which is the largest property it tests?  ok = 0: a property beyond the previous channels the loops keep, or deeper than the stack
 JXL_DEV BigCount big_tree_count(const DevTreeNode *tree, int count, int chan, int stream, int32_t *stack) {
-  BigCount r; r.ni = r.nl = r.nonunit = r.uses_wp = 0; r.ok = 1;
+  BigCount r; r.ni = r.nl = r.nonunit = r.uses_wp = 0; r.ok = 1; r.max_prop = 0;
   int sp = 0, guard = 0;
   stack[sp++] = 0;
   while (sp > 0) {
@@ -256,8 +258,9 @@ JXL_DEV BigCount big_tree_count(const DevTreeNode *tree, int count, int chan, in
     const DevTreeNode nd = tree[stack[--sp]];
     if (nd.prop < 0) { r.nl++; if (nd.lchild == 6) r.uses_wp = 1; if (nd.rchild != 1 || nd.offset != 0) r.nonunit = 1; continue; }
     if (nd.prop == 0 || nd.prop == 1) { const int v = nd.prop == 0 ? chan : stream; stack[sp++] = v > nd.splitval ? nd.lchild : nd.rchild; continue; }
-    if (nd.prop > 15 || sp + 2 > 64) { r.ok = 0; return r; }
+    if (nd.prop >= 16 + 4 * kModMaxRefs || sp + 2 > 64) { r.ok = 0; return r; }      // (properties 16 ..: four per previous channel, up to kModMaxRefs of them)
     if (nd.prop == 15) r.uses_wp = 1;
+    if (nd.prop > r.max_prop) r.max_prop = nd.prop;
     r.ni++;
     stack[sp++] = nd.lchild; stack[sp++] = nd.rchild;
   }
@@ -276,7 +279,7 @@ JXL_DEV bool big_tree_build(const DevTreeNode *tree, int count, int chan, int st
   if (capB > cnt.ni + 1) capB = cnt.ni + 1;
   int capE = cnt.nl + capB - 1;
   if (capE > 8191) return false;
-  H.nonunit = cnt.nonunit; H.uses_wp = cnt.uses_wp;
+  H.nonunit = cnt.nonunit; H.uses_wp = cnt.uses_wp; H.max_prop = cnt.max_prop;
   H.off_nodes = off_nodes; H.off_need = off_need; H.off_exit = off_need + 4 * capE; H.off_mulo = H.off_exit + capE;
   H.off_blk = H.off_mulo + (cnt.nonunit ? 2 * capE : 0); H.capB = capB; H.capE = capE;
   int32_t *nodes = (int32_t *)big + off_nodes;
@@ -337,7 +340,7 @@ JXL_DEV uint32_t big_tree_eval(const uint32_t *big, const int32_t *props, int *e
   while (e >> 31) {
     const int ni = (int)((e >> 25) & 63), noff = (int)((e >> 13) & 4095), eoff = (int)(e & 8191);
     uint64_t dec = 0;
-    for (int i = 0; i < ni; i++) { const int32_t *nd = (const int32_t *)big + H.off_nodes + 2 * (noff + i); if (props[nd[0]] > nd[1]) dec |= 1ull << i; }
+    for (int i = 0; i < ni; i++) { const int32_t *nd = (const int32_t *)big + H.off_nodes + 2 * (noff + i); if (props[nd[0]] > nd[1]) dec |= 1ull << i; }      // (props: 16 + 4 per previous channel)
     int leaf = -1;
     for (int j = 0; j <= ni && leaf < 0; j++) {
       const uint32_t *m = big + H.off_need + 4 * (eoff + j);

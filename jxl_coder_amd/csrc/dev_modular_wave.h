@@ -137,6 +137,8 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
   const uint32_t *big_exit = kBig ? big + BH->off_exit : nullptr;
   const int32_t *big_mulo = kBig ? (const int32_t *)big + BH->off_mulo : nullptr;
   const bool big_cfg_lds = S.st.num_clusters <= kLocMaxClusters;      // (then ev.cfg is S.cfg)
+  const bool big_refs = kBig && BH->max_prop > 15;
+  const int32_t *my_ref = (big_refs && lane < kModMaxRefs) ? S.refp[lane] : nullptr;
   const uint32_t dbg = (kBig && S.walk_stat) ? S.walk_stat[2] : 0u;      // MEASUREMENT ONLY (JXLAMD_DEBUG_MOD, word 4 of the flag block): 1 = every symbol from cluster 0's tables, 2 = block 0's exits taken as leaves — wrong pixels, same loop
   int my_prop, my_split; uint64_t my_need1, my_need0;
   uint32_t my_exit = 0;
@@ -274,7 +276,20 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
           #pragma unroll
           for (int k = 0; k < 16; k++) S.props[k] = k < 2 ? 0 : pv[k];
         }
-        myv = S.props[my_prop & 15];
+        if (big_refs) {                      // (uniform) lane r: the four properties of previous channel r at this position — |v|, v, |v - g|, v - g with g the clamped gradient of its W, N, NW
+          if (lane < kModMaxRefs) {
+            int32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+            if (my_ref) {
+              const int32_t *rp = my_ref + (size_t)y * (size_t)w;
+              const int64_t v = rp[x], vl = x ? rp[x - 1] : 0, vt = y ? rp[x - w] : vl, vtl = (x && y) ? rp[x - w - 1] : vl;
+              const int64_t lo = vl < vt ? vl : vt, hi = vl < vt ? vt : vl, grad = vl + vt - vtl;
+              const int64_t vp = vtl > hi ? lo : vtl < lo ? hi : grad;
+              q0 = (int32_t)(v < 0 ? -v : v); q1 = (int32_t)v; q2 = (int32_t)(v - vp < 0 ? vp - v : v - vp); q3 = (int32_t)(v - vp);
+            }
+            S.props[16 + 4 * lane] = q0; S.props[17 + 4 * lane] = q1; S.props[18 + 4 * lane] = q2; S.props[19 + 4 * lane] = q3;
+          }
+        }
+        myv = S.props[my_prop & 63];
       } else if (kM16) {
         myv = early + M24(cW, W_) + M24(cE, pv[15]);
         if (cAbs) myv = myv < 0 ? -myv : myv;
@@ -298,7 +313,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
           const uint64_t nd = big_nodes[noff + jl];
           const uint4 m = big_need[eoff + jl];
           const uint32_t bex = big_exit[eoff + jl];
-          const int bv = S.props[(uint32_t)nd & 15u];
+          const int bv = S.props[(uint32_t)nd & 63u];
           const uint64_t bdec = __ballot(lane < bni && bv > (int)(nd >> 32));
           const uint64_t b1 = m.x | ((uint64_t)m.y << 32), b0 = m.z | ((uint64_t)m.w << 32);
           const uint64_t blm = __ballot(lane <= bni && (bdec & b1) == b1 && (~bdec & b0) == b0);
@@ -805,6 +820,20 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       if (S.pool_bytes - at < (int)sizeof(DevBigHdr) + 64 || !BH->ok) return kErrWaveFallback;
       const bool bwp = BH->uses_wp != 0;
       if (c.w > kModMaxW && bwp) return kErrWaveFallback;
+      if (BH->max_prop > 15) {
+        // properties 16 ..: four per earlier channel of the stream with this channel's size and shifts, nearest first (libjxl: PrecomputeReferences; the serial
+        // statement is in modular_decode_channels); lane r of the loop evaluates the four of reference r for every sample
+        if (c.w > kModMaxW) return kErrWaveFallback;
+        const int want = (BH->max_prop - 16) / 4 + 1;
+        if (lane == 0) {
+          int nref = 0;
+          for (int j = ci - 1; j >= 0 && nref < want; j--)
+            if (chans[j].w == c.w && chans[j].h == c.h && chans[j].hs == c.hs && chans[j].vs == c.vs) S.refp[nref++] = chans[j].d;
+          for (int k = nref; k < kModMaxRefs; k++) S.refp[k] = nullptr;
+        }
+        __threadfence();                                    // the reference planes were written by this wave (lane 0) moments ago
+        __syncthreads();
+      }
       if (lane == 0 && S.walk_stat) atomicAdd(S.walk_stat + 1, 1u);
       if (kLds && !pool_packed) {
         if (m16) { if (bwp) wave_decode_channel<true, true, true, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); else wave_decode_channel<true, true, false, true>(ev, b, state, wp, S, WT, c, lane, 0x7fffffff, big); }
