@@ -379,7 +379,7 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     }
 #endif
     // properties 16 ..: four per earlier channel of the stream with this channel's size and shifts, nearest first (libjxl: PrecomputeReferences); properties
-    // beyond the channels there are read as zero.  Only this serial loop evaluates them (the wave loops decline such trees: wave_tree_build)
+    // beyond the channels there are read as zero.  This is their serial statement; on the GPU the block-form wave loop evaluates them too (dev_modular_wave.h: kBig — the one-ballot loops pass such trees on to it)
     int nref = 0, nref_props = 0;
     const int32_t *refp[kModMaxRefs];
     if (tf.max_prop > 15) {
