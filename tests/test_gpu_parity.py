@@ -191,6 +191,32 @@ def test_alpha_streams_with_a_tree_of_hundreds_of_leaves_run_from_its_block_form
             assert np.array_equal(o.cpu().numpy().reshape(x.shape), x)
 
 
+def test_previous_channel_properties_run_in_the_block_form_loop(dec):
+    """cjxl -E files: MA trees that test properties of previous channels (16 ..: |v|, v, |v - g|, v - g of up to eleven earlier channels at the same position).  The one-ballot
+    loops pass such trees to the block form, whose loop computes the four properties of reference r in lane r per sample: bit-exact (lossless) against the golden vectors
+    — and against the reference run live on a larger image —, with no stream left to the one-lane serial walker (rounds 4: 0.8 s per 2 MP there)."""
+    import jxl_coder_amd as J
+    d = J.JxlDecoder(0)
+    for name in ("lpc200x136_e7_prev3", "lpcr200x136_e7_prev3"):
+        data, exp = load_case(name)
+        s0 = _modular_walk_state(d)
+        out, _ = d.decode_one_shot(data)
+        s1 = _modular_walk_state(d)
+        assert np.array_equal(out, exp), name
+        assert s1[0] == s0[0] and s1[1] > s0[1], (name, s0, s1)
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jxl_ref
+    if not jxl_ref.available():
+        return
+    import synth
+    data = jxl_ref.encode(synth.photo_like(700, 500, seed=5), lossless=True, effort=7, extra=((29, 2),), threads=0)
+    ref = jxl_ref.decode(data, threads=0)[0]
+    s0 = _modular_walk_state(d)
+    out, _ = d.decode_one_shot(data)
+    s1 = _modular_walk_state(d)
+    assert np.array_equal(out, ref) and s1[0] == s0[0] and s1[1] > s0[1], (s0, s1)
+
+
 def test_jxlcoder_surface(dec):
     import jxl_coder_amd as J
     data, exp = load_case("v256_e7")
