@@ -375,6 +375,7 @@ def main():
         if "--contexts" not in argv: args.contexts = 16         # (8 contexts: 2 680 MP/s, 12 or 16: 3 200; flights of 16 or 24: 1 670 - 1 790 while the flat PassGroup kernel started at 4 096 groups, 2 770 since it starts at 1 024)
         if "--inflight" not in argv: args.inflight = 32
         if "--distinct" not in argv: args.distinct = 64
+        if "--steps" not in argv: args.steps = 16              # (8 steps = one flight per context in the timed region: 2 557 / 2 926 / 3 103 MP/s in three runs of round 5; two flights each are steadier)
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
