@@ -351,8 +351,8 @@ def run_mixed(args, rank, local, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8, help="timed steps; one step = one batch of --batch 4K frames")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; one step = one batch of --batch 4K frames (round 5: 20 by default — 8 steps are two flights per context, a run that is mostly start and tail: 11 451 - 12 551 MP/s where 20 steps give 14 083 - 14 177)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per step (BASELINE configs[2]: 256 x 3840x2160 q90)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contexts", type=int, default=16, help="decoder contexts taking flights alternately (overlaps one flight's LF stage with another's later stages)")
