@@ -97,7 +97,11 @@ JXL_DEV void bits_refill(DevBits &b) {     // guarantees >= 32 valid bits
   if (b.n <= 32) {
     b.buf |= (uint64_t)b.ahead << b.n;
     b.n += 32;
-    b.ahead = b.next < b.end ? gld(b.next) : 0u;
+    // (an UNCONDITIONAL load through a clamped pointer — the last word of the buffer's zero padding stands for everything beyond it: with the load under its own
+    // condition the compiler materialised the 0, loaded into a scratch register and had to WAIT for the word right here to copy it into `ahead` — the round
+    // trip this prefetch exists to hide; measured in the block-form Modular loop, ISA in tools/experiments/block_tree_timers)
+    const uint32_t *p = b.next < b.end ? b.next : b.end - 1;
+    b.ahead = gld(p);
     b.next++;
   }
 }
