@@ -290,6 +290,23 @@ def test_composed_frames_ride_in_flights(dec):
         assert r.returncode == 0 and "flights ok" in r.stdout, (env, r.stdout[-500:] + r.stderr[-1500:])
 
 
+def test_flight_of_hand_written_codestreams_equals_single_decodes(dec):
+    """The files only tools/jxl_write.py writes, inside ONE flight next to an encoder-made frame: 6 and 11 passes (dense coefficient planes: sparse lists are for
+    single-pass frames), every DequantMatrices encoding, custom upsampling weights (composed: rides in the flight), a preview frame in front of the image, splines,
+    DCT128 / DCT256 varblocks (the flight is repeated with the huge-block kernel in its launch list) — each output equals the single decode bit for bit, twice."""
+    import torch
+    names = ["w_passes6", "w_dequant_a", "w_up4_custom", "v264x520_e7", "w_preview", "w_passes11", "w_dequant_b", "w_spline_b", "w_dct_mix_a", "w_up2_custom", "w_dct256"]
+    datas = [open(os.path.join(ROOT, "tests", "golden", n + ".jxl"), "rb").read() for n in names]
+    singles = [dec.decode_one_shot(d)[0] for d in datas]
+    for rep in range(2):
+        outs = [torch.full((s.size,), 0x5A, dtype=torch.uint8, device="cuda") for s in singles]
+        torch.cuda.synchronize()
+        dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+        torch.cuda.synchronize()
+        for n, s_, o in zip(names, singles, outs):
+            assert np.array_equal(o.cpu().numpy().reshape(s_.shape), s_), (n, rep)
+
+
 def test_batch_equals_single_decodes(dec):
     """jxlamd_decode_batch (one entropy launch for the whole flight) must give exactly what n single decodes give."""
     import torch
