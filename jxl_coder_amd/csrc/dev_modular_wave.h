@@ -231,7 +231,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       pv[15] = 0;
       prev_prop9 = p9;
       T wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
-      if (kWP) {
+      if (kWP && !(dbg & 8u)) {
         uint32_t wgt[4];
         for (int k = 0; k < 4; k++) {
           const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
@@ -307,6 +307,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)my_exit, leaf);
         int eidx = (int)(root_word & 8191u) + leaf;
         if ((dbg & 2u) && (e >> 31)) e = 5u << 26;
+        if (dbg & 32u) e = 5u << 26;
         while (e >> 31) {                    // (uniform) the exit names another block
           const int bni = (int)((e >> 25) & 63), noff = (int)((e >> 13) & 4095), eoff = (int)(e & 8191);
           const int jl = lane < bni ? lane : bni;      // lanes beyond the block read its last exit / the entry behind its last node (inside the area; masked below): no branches around the loads
@@ -333,14 +334,15 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       }
       const T guess = predict_plain_t<T>(l_pred, W_, N_, NW_, NE_, NN_, WW_, NEE_, wp_pred);
       uint32_t u;
-      if (kBig && !kLds) u = wave_ec_read_global(ev, S, b, state, (uint32_t)l_clu, big_cfg_lds);      // the exit word carries the cluster: no context-map trip
+      if (kBig && (dbg & 16u)) u = (uint32_t)(x & 3);
+      else if (kBig && !kLds) u = wave_ec_read_global(ev, S, b, state, (uint32_t)l_clu, big_cfg_lds);      // the exit word carries the cluster: no context-map trip
       else u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
       const T res = (T)unpack_signed(u);
       const T val = (l_mul == 1 ? res : res * (T)l_mul) + (T)l_off + guess;      // l_mul is wave-uniform: the multiply is branched around
       if (lane == 0) { if (!wide) row[x] = (int32_t)val; gst(&out[x], (int32_t)val); }      // (a wide channel's row IS the plane)
       vWW = vW; vW = (int32_t)val;
       vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
-      if (kWP) {
+      if (kWP && !(dbg & 8u)) {
         const T v8 = val * 8;
         const int32_t terr = (int32_t)(wp_raw - v8);
         uint32_t err[4];
