@@ -203,15 +203,19 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       teN = S.wp_err[prev_row]; teNW = teN; teNE = w > 1 ? S.wp_err[prev_row + 1] : teN;
     }
     int32_t prev_prop9 = 0;
-    for (int x = 0; x < w; x++) {
-      const T W_ = x > 0 ? vW : (y > 0 ? vN : 0);
-      const T N_ = y > 0 ? vN : W_;
-      const T NW_ = (x > 0 && y > 0) ? vNW : W_;
-      const T NE_ = (x + 1 < w && y > 0) ? vNE : N_;
-      const T NN_ = y > 1 ? rNN[x] : N_;
-      const T NEE_ = (x + 2 < w && y > 0) ? vNEE : NE_;
-      const T WW_ = x > 1 ? vWW : W_;
-      const int32_t nextNEE = (y > 0 && x + 3 < w) ? rN[x + 3] : 0;     // independent of this sample: issued early
+    // One sample.  kE = false: an INTERIOR sample (y >= 2, 2 <= x, x + 3 < w) — every edge substitution below is known not to apply, and with it go ~45 of the
+    // ~510 instructions a sample costs (profiles/r05_pmc_block_form_loop_by_removal_rgba4k.json: the loop is bound by its instruction count)
+    #define E(cond) (!kE || (cond))
+    auto step = [&](auto edge_c, const int x) __attribute__((always_inline)) {
+      constexpr bool kE = decltype(edge_c)::value;
+      const T W_ = E(x > 0) ? vW : (y > 0 ? vN : 0);
+      const T N_ = E(y > 0) ? vN : W_;
+      const T NW_ = E(x > 0 && y > 0) ? vNW : W_;
+      const T NE_ = E(x + 1 < w && y > 0) ? vNE : N_;
+      const T NN_ = E(y > 1) ? rNN[x] : N_;
+      const T NEE_ = E(x + 2 < w && y > 0) ? vNEE : NE_;
+      const T WW_ = E(x > 1) ? vWW : W_;
+      const int32_t nextNEE = E(y > 0 && x + 3 < w) ? rN[x + 3] : 0;     // independent of this sample: issued early
       const int32_t p9 = (int32_t)(W_ + N_ - NW_);
       const int32_t p9_prev = prev_prop9;
       int32_t pv[16];
@@ -234,13 +238,13 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       if (kWP && !(dbg & 8u)) {
         uint32_t wgt[4];
         for (int k = 0; k < 4; k++) {
-          const uint32_t e = peN[k] + (x < w - 1 ? peNE[k] : peN[k]) + (x > 0 ? peNW[k] : peN[k]);
+          const uint32_t e = peN[k] + (E(x < w - 1) ? peNE[k] : peN[k]) + (E(x > 0) ? peNW[k] : peN[k]);
           int shift = floor_log2_u32(e + 1) - 5;
           if (shift < 0) shift = 0;
           wgt[k] = 4 + (((uint32_t)wp.w[k] * WAVE_DIV(e >> shift)) >> shift);
         }
         const T N8 = N_ * 8, W8 = W_ * 8, NE8 = NE_ * 8, NW8 = NW_ * 8, NN8 = NN_ * 8;
-        const T tW = x == 0 ? 0 : teW, tN = teN, tNW = x > 0 ? teNW : teN, tNE = x < w - 1 ? teNE : teN;
+        const T tW = E(x > 0) ? teW : 0, tN = teN, tNW = E(x > 0) ? teNW : teN, tNE = E(x < w - 1) ? teNE : teN;
         const T sumWN = tN + tW;
         T p = tW;
         if (tabs<T>(tN) > tabs<T>(p)) p = tN;
@@ -339,7 +343,11 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       else u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
       const T res = (T)unpack_signed(u);
       const T val = (l_mul == 1 ? res : res * (T)l_mul) + (T)l_off + guess;      // l_mul is wave-uniform: the multiply is branched around
+#ifdef JXL_EXP_ROWSTORE
+      if (lane == 0) { if (!wide) row[x] = (int32_t)val; else gst(&out[x], (int32_t)val); }
+#else
       if (lane == 0) { if (!wide) row[x] = (int32_t)val; gst(&out[x], (int32_t)val); }      // (a wide channel's row IS the plane)
+#endif
       vWW = vW; vW = (int32_t)val;
       vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
       if (kWP && !(dbg & 8u)) {
@@ -350,11 +358,19 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         if (lane == 0) { S.wp_err[cur_row + x] = terr; for (int k = 0; k < 4; k++) S.wp_pred_err[k][cur_row + x] = err[k]; }
         for (int k = 0; k < 4; k++) { peNW[k] = peN[k]; peN[k] = peNE[k] + err[k]; }   // carry to (x+1) of the previous row
         teNW = teN; teN = teNE; teW = terr;
-        if (x + 2 < w) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
+        if (E(x + 2 < w)) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
         else { for (int k = 0; k < 4; k++) peNE[k] = peN[k]; teNE = teN; }
       }
+    };
+    #undef E
+    for (int x = 0; x < w;) {
+      if (y > 1 && x >= 2 && x + 3 < w) { for (const int xe = w - 3; x < xe; x++) step(std::false_type(), x); }
+      else { step(std::true_type(), x); x++; }
     }
     __syncthreads();     // row[] written by lane 0 is read by every lane in the next row
+#ifdef JXL_EXP_ROWSTORE
+    if (!wide) for (int i = lane; i < w; i += 64) gst(&out[i], row[i]);
+#endif
   }
   #undef WAVE_DIV
 }
