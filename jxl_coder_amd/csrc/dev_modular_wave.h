@@ -96,6 +96,12 @@ __device__ __forceinline__ uint32_t wave_ec_read_global(const DevECView &v, DevM
 }
 
 template <class T> __device__ __forceinline__ T tabs(T v) { return v < 0 ? -v : v; }
+// sum over the four lanes of every quad, in each of them (two DPP quad-permute adds)
+__device__ __forceinline__ int quad_sum_i32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  return v;
+}
 template <class T>
 __device__ __forceinline__ T predict_plain_t(int predictor, T W, T N, T NW, T NE, T NN, T WW, T NEE, T wp) {
   switch (predictor) {
@@ -139,7 +145,11 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
   const bool big_cfg_lds = S.st.num_clusters <= kLocMaxClusters;      // (then ev.cfg is S.cfg)
   const bool big_refs = kBig && BH->max_prop > 15;
   const int32_t *my_ref = (big_refs && lane < kModMaxRefs) ? S.refp[lane] : nullptr;
+#ifdef JXL_MOD_DEBUG_SWITCHES      // tools/build_variant.sh <name> kernels_mod.hip -DJXL_MOD_DEBUG_SWITCHES: the removal switches of DESIGN 7d (six tests per sample the product does not pay for)
   const uint32_t dbg = (kBig && S.walk_stat) ? S.walk_stat[2] : 0u;      // MEASUREMENT ONLY (JXLAMD_DEBUG_MOD, word 4 of the flag block): 1 = every symbol from cluster 0's tables, 2 = block 0's exits taken as leaves — wrong pixels, same loop
+#else
+  constexpr uint32_t dbg = 0u;
+#endif
   int my_prop, my_split; uint64_t my_need1, my_need0;
   uint32_t my_exit = 0;
   if (kBig) {
@@ -184,8 +194,23 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
   }
   const int my_div = (int)S.divlut[lane];
   #define WAVE_DIV(idx) ((uint32_t)__builtin_amdgcn_readlane(my_div, __builtin_amdgcn_readfirstlane((int)(idx))))
+  // kPack (32-bit arithmetic): the weighted predictor with lane l on sub-predictor l & 3, as in wave_decode_channel_wpfixed — one error-weight chain, one
+  // prediction and one error update per sample instead of four of each on wave-uniform values; the sums over the four are DPP quad adds (every quad holds the same
+  // four, so the sums are wave-uniform again).  The prediction of sub-predictor k as base_k - ((sum_j a_kj * in_j) >> 5): the same ring arithmetic term by term.
+  constexpr bool kPack = kWP && kM16;
+  constexpr int kPeStride = 2 * (kWpMaxW + 2);
+  static_assert(offsetof(DevModScratch, wp_err) == offsetof(DevModScratch, wp_pred_err) + 4 * kPeStride * sizeof(uint32_t), "wp_err is row 4 behind the four error rows");
+  const int kk = lane & 3;
+  const int32_t a_tW = kk == 1 ? wp.p1 : kk == 2 ? wp.p2 : 0, a_tN = kk == 1 ? wp.p1 : kk == 2 ? wp.p2 : kk == 3 ? wp.p3b : 0;
+  const int32_t a_tNW = kk == 2 ? wp.p2 : kk == 3 ? wp.p3a : 0, a_tNE = kk == 1 ? wp.p1 : kk == 3 ? wp.p3c : 0;
+  const int32_t a_d1 = kk == 3 ? wp.p3d : 0, a_d2 = kk == 3 ? wp.p3e : 0;
+  const bool baseW = (kk & 1) == 0, base0 = kk == 0;
+  const uint32_t *my_wdiv = S.wdiv[kk];
+  uint32_t *my_pe = S.wp_pred_err[kk];
+  uint32_t *pe_flat = &S.wp_pred_err[0][0];
   if (kWP) {
     for (int i = lane; i < 2 * (w + 2); i += 64) { S.wp_err[i] = 0; for (int k = 0; k < 4; k++) S.wp_pred_err[k][i] = 0; }
+    if (kPack) for (int i = lane; i < 256; i += 64) S.wdiv[i >> 6][i & 63] = (uint32_t)wp.w[i >> 6] * S.divlut[i & 63];
   }
   __syncthreads();
   for (int y = 0; y < h; y++) {
@@ -198,8 +223,10 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
     const int cur_row = (y & 1) ? 0 : (w + 2), prev_row = (y & 1) ? (w + 2) : 0;
     uint32_t peNW[4] = {0, 0, 0, 0}, peN[4] = {0, 0, 0, 0}, peNE[4] = {0, 0, 0, 0};
     int32_t teNW = 0, teN = 0, teNE = 0, teW = 0;
+    uint32_t qNW = 0, qN = 0, qNE = 0;      // kPack: the error sums of sub-predictor kk
     if (kWP) {
-      for (int k = 0; k < 4; k++) { peN[k] = S.wp_pred_err[k][prev_row]; peNW[k] = peN[k]; peNE[k] = w > 1 ? S.wp_pred_err[k][prev_row + 1] : peN[k]; }
+      if (kPack) { qN = my_pe[prev_row]; qNW = qN; qNE = w > 1 ? my_pe[prev_row + 1] : qN; }
+      else for (int k = 0; k < 4; k++) { peN[k] = S.wp_pred_err[k][prev_row]; peNW[k] = peN[k]; peNE[k] = w > 1 ? S.wp_pred_err[k][prev_row + 1] : peN[k]; }
       teN = S.wp_err[prev_row]; teNW = teN; teNE = w > 1 ? S.wp_err[prev_row + 1] : teN;
     }
     int32_t prev_prop9 = 0;
@@ -235,9 +262,16 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       pv[15] = 0;
       prev_prop9 = p9;
       T wp_pred = 0, wpred[4] = {0, 0, 0, 0}, wp_raw = 0;
+      int32_t my_pred = 0;
       if (kWP && !(dbg & 8u)) {
-        uint32_t wgt[4];
-        for (int k = 0; k < 4; k++) {
+        uint32_t wgt[4] = {0, 0, 0, 0};
+        uint32_t my_wd = 0; int my_sh = 0;
+        if (kPack) {
+          const uint32_t e = qN + (E(x < w - 1) ? qNE : qN) + (E(x > 0) ? qNW : qN);
+          my_sh = 26 - __builtin_clz(e + 1);
+          my_sh = my_sh < 0 ? 0 : my_sh;
+          my_wd = my_wdiv[e >> my_sh];                     // LDS, lane-indexed: (weight * reciprocal) of this sub-predictor's error sum
+        } else for (int k = 0; k < 4; k++) {
           const uint32_t e = peN[k] + (E(x < w - 1) ? peNE[k] : peN[k]) + (E(x > 0) ? peNW[k] : peN[k]);
           int shift = floor_log2_u32(e + 1) - 5;
           if (shift < 0) shift = 0;
@@ -251,6 +285,16 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         if (tabs<T>(tNW) > tabs<T>(p)) p = tNW;
         if (tabs<T>(tNE) > tabs<T>(p)) p = tNE;
         pv[15] = (int32_t)p;
+        if (kPack) {
+          const int32_t inner = a_tW * (int32_t)tW + a_tN * (int32_t)tN + a_tNW * (int32_t)tNW + a_tNE * (int32_t)tNE + a_d1 * (int32_t)(NN8 - N8) + a_d2 * (int32_t)(NW8 - W8);
+          my_pred = (int32_t)(baseW ? W8 : N8) + (base0 ? (int32_t)(NE8 - N8) : 0) - (inner >> 5);
+          uint32_t g = 4 + (my_wd >> my_sh);
+          const uint32_t wsum = (uint32_t)quad_sum_i32((int)g);
+          g >>= (27 - __builtin_clz(wsum));
+          const uint32_t wsum2 = (uint32_t)quad_sum_i32((int)g);
+          const int32_t sum = quad_sum_i32(my_pred * (int32_t)g) + (int32_t)(wsum2 >> 1) - 1;
+          wp_raw = (T)__mulhi(sum, (int32_t)(WAVE_DIV(wsum2 - 1) << 8));      // (sum * dv) >> 24; wsum2 - 1 in [12, 30]: dv < 2^21
+        } else {
         wpred[0] = W8 + NE8 - N8;
         wpred[1] = N8 - (((sumWN + tNE) * wp.p1) >> 5);
         wpred[2] = W8 - (((sumWN + tNW) * wp.p2) >> 5);
@@ -262,6 +306,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         T sum = (T)(wsum >> 1) - 1;
         for (int k = 0; k < 4; k++) sum += wpred[k] * (T)wgt[k];
         wp_raw = (T)(((int64_t)sum * (int64_t)WAVE_DIV(wsum - 1)) >> 24);
+        }
         if (!((((tN ^ tW) | (tN ^ tNW))) > 0)) {
           T mx = W8 > NE8 ? W8 : NE8; if (N8 > mx) mx = N8;
           T mn = W8 < NE8 ? W8 : NE8; if (N8 < mn) mn = N8;
@@ -343,16 +388,20 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       else u = wave_ec_read<kLds>(ev, S, b, state, (uint32_t)l_ctx, (uint32_t)l_clu);
       const T res = (T)unpack_signed(u);
       const T val = (l_mul == 1 ? res : res * (T)l_mul) + (T)l_off + guess;      // l_mul is wave-uniform: the multiply is branched around
-#ifdef JXL_EXP_ROWSTORE
-      if (lane == 0) { if (!wide) row[x] = (int32_t)val; else gst(&out[x], (int32_t)val); }
-#else
-      if (lane == 0) { if (!wide) row[x] = (int32_t)val; gst(&out[x], (int32_t)val); }      // (a wide channel's row IS the plane)
-#endif
+      if (lane == 0) { if (!wide) row[x] = (int32_t)val; else gst(&out[x], (int32_t)val); }      // (a wide channel's row IS the plane; the others go to HBM row by row, below)
       vWW = vW; vW = (int32_t)val;
       vNW = vN; vN = vNE; vNE = vNEE; vNEE = nextNEE;
       if (kWP && !(dbg & 8u)) {
         const T v8 = val * 8;
         const int32_t terr = (int32_t)(wp_raw - v8);
+        if (kPack) {
+          const uint32_t my_err = (uint32_t)((tabs<int32_t>(my_pred - (int32_t)v8) + 3) >> 3);
+          if (lane < 5) pe_flat[lane * kPeStride + cur_row + x] = lane < 4 ? my_err : (uint32_t)terr;      // lanes 0..3: their sub-predictor's error, lane 4: the true error (S.wp_err)
+          qNW = qN; qN = qNE + my_err;                   // carry to (x+1) of the previous row
+          teNW = teN; teN = teNE; teW = terr;
+          if (E(x + 2 < w)) { qNE = my_pe[prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
+          else { qNE = qN; teNE = teN; }
+        } else {
         uint32_t err[4];
         for (int k = 0; k < 4; k++) err[k] = (uint32_t)((tabs<T>(wpred[k] - v8) + 3) >> 3);
         if (lane == 0) { S.wp_err[cur_row + x] = terr; for (int k = 0; k < 4; k++) S.wp_pred_err[k][cur_row + x] = err[k]; }
@@ -360,6 +409,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         teNW = teN; teN = teNE; teW = terr;
         if (E(x + 2 < w)) { for (int k = 0; k < 4; k++) peNE[k] = S.wp_pred_err[k][prev_row + x + 2]; teNE = S.wp_err[prev_row + x + 2]; }
         else { for (int k = 0; k < 4; k++) peNE[k] = peN[k]; teNE = teN; }
+        }
       }
     };
     #undef E
@@ -368,9 +418,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
       else { step(std::true_type(), x); x++; }
     }
     __syncthreads();     // row[] written by lane 0 is read by every lane in the next row
-#ifdef JXL_EXP_ROWSTORE
-    if (!wide) for (int i = lane; i < w; i += 64) gst(&out[i], row[i]);
-#endif
+    if (!wide) for (int i = lane; i < w; i += 64) gst(&out[i], row[i]);      // one coalesced store per row instead of a one-lane store per sample
   }
   #undef WAVE_DIV
 }
@@ -397,11 +445,6 @@ struct DevWpFixedLds {                   // overlays DevWaveTree (dead once the 
 };
 static_assert(sizeof(DevWpFixedLds) <= sizeof(DevWaveTree), "the chunk records live in the tree's LDS");
 
-__device__ __forceinline__ int quad_sum_i32(int v) {
-  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
-  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
-  return v;
-}
 // lane l takes `keep` from lane l - 1 (wave_shr:1) / l - 4 within its row of 16 (row_shr:4); the lanes without a source take `fresh`
 __device__ __forceinline__ int shift_in_wave1(int fresh, int keep) { return __builtin_amdgcn_update_dpp(fresh, keep, 0x138, 0xF, 0xF, false); }
 __device__ __forceinline__ int shift_in_row4(int fresh, int keep) { return __builtin_amdgcn_update_dpp(fresh, keep, 0x114, 0xF, 0xF, false); }
