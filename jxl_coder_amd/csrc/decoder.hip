@@ -373,7 +373,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   HIPCHECK(hipMemcpyAsync((uint8_t *)h_flags.p + 8, S.B.err, 4, hipMemcpyDeviceToHost, stream));
   HIPCHECK(hipStreamSynchronize(stream));
   memcpy(&end_bit, h_flags.p, 8); memcpy(&derr, (uint8_t *)h_flags.p + 8, 4);
-  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  if ((derr & kErrNeedPool) && lf_pool_bytes < kModPoolBytes) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }      // (the other flags of an attempt that stopped for the pool say nothing: see decode_batch_once)
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
@@ -501,9 +501,10 @@ int jxlamd_decoder::collect(FrameSlot &S, uint32_t flags) {
   memcpy(head, h_flags.p, sizeof(head));
   derr = head[0];
   serial_streams += head[2]; block_tree_channels += head[3];
+  const int pool_of_this_attempt = lf_pool_bytes;
   if (!S.plan.modular) lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(head[1]));
   if (!S.plan.modular && head[17] > 0) large_blocks_seen = true;      // big_count[1]: varblocks with 2048 / 4096 coefficients
-  if ((derr & kErrNeedPool) && !(derr & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }
+  if ((derr & kErrNeedPool) && pool_of_this_attempt < kModPoolBytes) { lf_pool_floor = kModPoolBytes; g_lf_pool_floor.store(kModPoolBytes); lf_pool_bytes = kModPoolBytes; return kRetryPool; }      // (the other flags of an attempt that stopped for the pool say nothing: see decode_batch_once)
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ")"); return dev_err_class(derr); }
   S.coef_clean = !S.plan.modular;
@@ -992,7 +993,10 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (head[19] > 0 && (!huge_blocks_seen || sparse)) need_huge = true;      // big_count[3]: DCT128 / DCT256 families, and their kernel was not in this flight's launch list
     pool_want = std::max(pool_want, head[1]);
     if (sparse && (head[0] & kErrNeedDense) && !(head[0] & 0xFFFFu & ~kErrNeedDense)) { need_dense = true; continue; }      // (judged again in the dense flight)
-    if ((head[0] & kErrNeedPool) && !(head[0] & ~(kErrNeedPool | kErrNeedGeneral | kErrStageLf))) need_pool = true;
+    // A stream that stopped for a larger pool leaves its frame's later stages to decode whatever the slot held before (a fresh slot: zeros, nothing flagged; a used one: another
+    // frame's metadata, flagged as corrupt by the PassGroup kernels): with kErrNeedPool set and the pool not yet the largest, the other flags of this attempt say nothing —
+    // the flight runs again and is judged then (kErrNeedPool cannot be raised with the largest pool, so this repeats at most once)
+    if ((head[0] & kErrNeedPool) && lf_pool_bytes < kModPoolBytes) { need_pool = true; continue; }
     else if ((head[0] & kErrNeedGeneral) && !lf_general) return kRetryGeneral;      // (coef_pool_clean stays false: the second attempt clears the pool)
     if (head[0]) { set_error("corrupt or unsupported stream (device flags " + std::to_string(head[0]) + ")"); if (!first_rc) first_rc = dev_err_class(head[0]); }
     (void)S;        // S.coef_clean describes the slot's OWN coefficient planes (single decodes); a flight uses the decoder's pool and leaves it as it is
@@ -1013,6 +1017,8 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   }
   if (!sparse) pools->coef_pool_clean = first_rc == JXLAMD_OK;
   lf_pool_bytes = std::max(std::max(lf_pool_floor, g_lf_pool_floor.load()), lf_pool_clamp(pool_want));
+  { static const bool forget = getenv("JXLAMD_LF_POOL_FORGET") != nullptr;      // tests: every flight starts from the smallest pool again, so that flights on USED slots miss it and are repeated
+    if (forget) { lf_pool_floor = 0; g_lf_pool_floor.store(0); lf_pool_bytes = kModPoolMin; } }
   large_hint = large_blocks_seen;                      // the next flight of this context most likely looks like this one
   (void)hipEventElapsedTime(&timing[0], ev[0], ev[1]); (void)hipEventElapsedTime(&timing[1], ev[1], ev[2]);   // LF; first sub-flight's PassGroup
   (void)hipEventElapsedTime(&timing[2], ev[2], ev[4]); timing[3] = 0; (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);

@@ -474,6 +474,39 @@ def test_flight_subflights_and_pools_in_a_small_configuration():
     assert r.returncode == 0 and "subflights ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_flight_that_misses_the_lf_table_pool_on_used_slots_is_repeated():
+    """A flight whose LF stage stops for a larger LDS table pool (kErrNeedPool) leaves its frames' later stages to decode whatever the slots held before: on a USED
+    context those flag 'corrupt' — flags of an attempt that is going to be repeated, which must not fail the flight (round 5: `bench.py --workload mixed` died on this once
+    its timing changed).  JXLAMD_LF_POOL_FORGET makes every flight start from the smallest pool again: 4K bench frames (24.5 KB of packed tables) between flights of other
+    frames; every flight equals the single decodes, and the second and third flights were repeated."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, os, ctypes as C, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from conftest import load_case
+        import jxl_coder_amd as J
+        dec = J.JxlDecoder(0)
+        big = [open(os.path.join(%r, "bench_data", "syn4k_q90_seed%%d.jxl" %% i), "rb").read() for i in range(4)]
+        small = [load_case(n)[0] for n in ["va300x520_e7", "v264x520_e7", "asset_first_jxl", "v300x300_e7_d3"]]
+        sets = [big[:2] + small[:2], small + big[2:], big[1:3] + small[1:3]]
+        ref = J.JxlDecoder(0)
+        L = J.api.lib(); st = (C.c_uint32 * 3)()
+        for k, datas in enumerate(sets):
+            singles = [ref.decode_one_shot(d)[0] for d in datas]
+            outs = [torch.zeros(s.size, dtype=torch.uint8, device="cuda") for s in singles]
+            dec.decode_batch_to_device(datas, [o.data_ptr() for o in outs], [o.numel() for o in outs])
+            torch.cuda.synchronize()
+            for s, o in zip(singles, outs):
+                assert np.array_equal(o.cpu().numpy().reshape(s.shape), s)
+            L.jxlamd_debug_lf_retries(C.c_void_p(dec._h), st)
+            print("flight", k, "pool retries so far", st[0])
+        assert st[0] >= 2, st[0]      # (the context's first flight runs with the largest pool)
+        print("pool retries ok")
+    """) % (ROOT, ROOT + "/tests", ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JXLAMD_LF_POOL_FORGET="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pool retries ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the driver's fields plus `roofline` and `cpu_baseline` (short run, CPU leg skipped)."""
     import json, subprocess, sys

@@ -8,7 +8,7 @@ with tempfile.TemporaryDirectory() as tmp:
     for tu in sorted(f[:-6] for f in os.listdir(os.path.join(ROOT, "jxl_coder_amd", "build")) if f.endswith(".hip.o")):
         obj = os.path.join(ROOT, "jxl_coder_amd", "build", tu + ".hip.o")
         fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "co.o")
-        if subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj], capture_output=True).returncode:
+        if subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(tmp, "copy.o")], capture_output=True).returncode:      # (an output file: without one objcopy rewrites `obj` in place and its new mtime hides a stale object from jxl_coder_amd.build)
             continue
         subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
         notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
