@@ -397,6 +397,8 @@ def main():
     if args.workload == "c4":
         return run_c4(args, rank, local, world)
     if args.workload == "mixed":
+        if "--steps" not in " ".join(sys.argv[1:]): args.steps = 16      # 16 steps x 64 frames = two flights of 32 for each of the 16 contexts; the general default of 20 ends with half the contexts idle (1 726 MP/s where 8 or 16 steps give 2 430)
+        if "--warmup" not in " ".join(sys.argv[1:]): args.warmup = 4
         return run_mixed(args, rank, local, world)
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
