@@ -192,6 +192,27 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
     case 15: cE = 1; break;
     default: break;
   }
+#ifdef JXL_EXP_LANE_PROPS      // experiment: lane k computes property k of the sample from ITS coefficient row and stores it — one LDS store of 16 lanes instead of four 16-byte stores of one
+  int dW = 0, dN = 0, dNW = 0, dNE = 0, dNN = 0, dWW = 0, dP9 = 0, dX = 0, dY = 0, dE = 0;
+  bool dAbs = false;
+  switch (lane) {
+    case 2: dY = 1; break;
+    case 3: dX = 1; break;
+    case 4: dN = 1; dAbs = true; break;
+    case 5: dW = 1; dAbs = true; break;
+    case 6: dN = 1; break;
+    case 7: dW = 1; break;
+    case 8: dW = 1; dP9 = -1; break;
+    case 9: dW = 1; dN = 1; dNW = -1; break;
+    case 10: dW = 1; dNW = -1; break;
+    case 11: dNW = 1; dN = -1; break;
+    case 12: dN = 1; dNE = -1; break;
+    case 13: dN = 1; dNN = -1; break;
+    case 14: dW = 1; dWW = -1; break;
+    case 15: dE = 1; break;
+    default: break;
+  }
+#endif
   const int my_div = (int)S.divlut[lane];
   #define WAVE_DIV(idx) ((uint32_t)__builtin_amdgcn_readlane(my_div, __builtin_amdgcn_readfirstlane((int)(idx))))
   // kPack (32-bit arithmetic): the weighted predictor with lane l on sub-predictor l & 3, as in wave_decode_channel_wpfixed — one error-weight chain, one
@@ -321,6 +342,13 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         // the 14 property values (wave-uniform) go to LDS once per sample — lane 0, four 16-byte stores — and every lane of every block reads the one its
         // node tests: a single wave issues one instruction every four cycles whatever its kind, so what counts here is the instruction count (a lane-indexed
         // vector for ds_bpermute took 14 selects whose lane masks the compiler kept spilling: 56 instructions per sample)
+#ifdef JXL_EXP_LANE_PROPS
+        if (kM16) {
+          int32_t pvl = (M24(dN, N_) + M24(dNW, NW_)) + (M24(dNE, NE_) + M24(dNN, NN_)) + (M24(dWW, WW_) + M24(dP9, p9_prev)) + (M24(dX, x) + M24(dY, y)) + (M24(dW, W_) + M24(dE, pv[15]));
+          if (dAbs) pvl = pvl < 0 ? -pvl : pvl;
+          if (lane < 16) S.props[lane] = pvl;
+        } else
+#endif
         if (lane == 0) {
           #pragma unroll
           for (int k = 0; k < 16; k++) S.props[k] = k < 2 ? 0 : pv[k];
