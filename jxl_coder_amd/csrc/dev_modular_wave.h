@@ -192,7 +192,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
     case 15: cE = 1; break;
     default: break;
   }
-#ifdef JXL_EXP_LANE_PROPS      // experiment: lane k computes property k of the sample from ITS coefficient row and stores it — one LDS store of 16 lanes instead of four 16-byte stores of one
+#ifndef JXL_NO_LANE_PROPS      // (-DJXL_NO_LANE_PROPS: the lane-0 form) lane k computes property k of the sample from ITS coefficient row and stores it — one LDS store of 16 lanes instead of four 16-byte stores of one
   int dW = 0, dN = 0, dNW = 0, dNE = 0, dNN = 0, dWW = 0, dP9 = 0, dX = 0, dY = 0, dE = 0;
   bool dAbs = false;
   switch (lane) {
@@ -342,7 +342,7 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
         // the 14 property values (wave-uniform) go to LDS once per sample — lane 0, four 16-byte stores — and every lane of every block reads the one its
         // node tests: a single wave issues one instruction every four cycles whatever its kind, so what counts here is the instruction count (a lane-indexed
         // vector for ds_bpermute took 14 selects whose lane masks the compiler kept spilling: 56 instructions per sample)
-#ifdef JXL_EXP_LANE_PROPS
+#ifndef JXL_NO_LANE_PROPS
         if (kM16) {
           int32_t pvl = (M24(dN, N_) + M24(dNW, NW_)) + (M24(dNE, NE_) + M24(dNN, NN_)) + (M24(dWW, WW_) + M24(dP9, p9_prev)) + (M24(dX, x) + M24(dY, y)) + (M24(dW, W_) + M24(dE, pv[15]));
           if (dAbs) pvl = pvl < 0 ? -pvl : pvl;

@@ -21,7 +21,7 @@ for f in ('/tmp/rgba4k_d1.jxl', '/tmp/rgba4k_ll7.jxl', '/tmp/rgba4k_ll3.jxl'):
         if best is None or tot < best[0]: best = (tot, t)
     print(os.path.basename(f), hashlib.md5(out.tobytes()).hexdigest()[:12], 'total %.1f' % best[0], {k: round(v, 1) for k, v in best[1].items() if k.endswith('_ms') and v > 0.5})
 PY
-for v in "" _laneprops; do
+for v in ""; do
   lib=jxl_coder_amd/libjxlamd$v.so
   [ -f $lib ] || continue
   echo "== $lib"; JXLAMD_LIB=$PWD/$lib timeout 300 python /tmp/ab.py 2>&1 | tail -4
