@@ -82,6 +82,14 @@ int jxlamd_output_size(const uint8_t *jxl, size_t size, uint32_t flags, size_t *
 int jxlamd_decode(jxlamd_decoder *dec, const uint8_t *jxl, size_t size, uint32_t flags, void *out, size_t out_capacity,
                   jxlamd_info *info);
 
+/* The Edge-Preserving Filter's normalisation, 1 / (sum of weights).  libjxl spells it ApproximateReciprocal; in the reference's prebuilt x86_64 library
+ * (cpp/lib/x86_64/libjxl.so, an SSE2-only build reached through interop/JxlDecoding.cpp:75) that is the CPU's 12-bit rcpps, which leaves a filtered sample up to
+ * 3e-4 (relative) off the exact quotient — at most one 8-bit code on photographs, up to 4 codes on a channel near 0 beside two near 1 (saturated hard edges),
+ * where the inverse opsin matrix amplifies it.  mode 0 (default): the exact quotient (what libjxl's other builds approximate).  mode 1: that build's
+ * instruction as a 2 048-entry table of the golden host's results (csrc/rcp12_lut.h) — the pixels the reference returned there, max |difference| 1 on every
+ * fixture.  Applies to every later decode of this context.  Environment default for new decoders: JXLAMD_EPF_RCP=x86. */
+int jxlamd_decoder_set_epf_reciprocal(jxlamd_decoder *dec, int mode);
+
 /* A10 + A11 with the decode ("fuse the colour matrix / tone map and the reformat into the writer").  Once set, every decode of this
  * context (single, batch, resident) delivers the Bitmap format of jxlamd_reformat_query(xsize, ysize, out_bits == 16, cfg, has_alpha_in_origin, api_level)
  * into `out` — rows of that stride — instead of RGBA8 / RGBA16: the colour matrix / Rec.2408 tone map where the reference's JNI layer applies it

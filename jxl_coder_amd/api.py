@@ -174,6 +174,7 @@ def lib():
         L.jxlamd_output_size.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_size_t)]
         L.jxlamd_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_decoder_set_writer_post.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.jxlamd_decoder_set_epf_reciprocal.argtypes = [C.c_void_p, C.c_int]
         L.jxlamd_decode_frame.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
         L.jxlamd_anim_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.jxlamd_decode_resident.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(Info)]
@@ -261,6 +262,13 @@ class JxlDecoder:
         if rc:
             _raise(rc, self._h)
         return info.as_dict()
+
+    def set_epf_reciprocal(self, x86_reference_build: bool):
+        """jxlamd_decoder_set_epf_reciprocal: False (default) the EPF normalises with the exact quotient; True with the reference x86 build's 12-bit rcpps
+        (a table of the golden host's results) — the pixels interop/JxlDecoding.cpp:75 returned there, bit for bit where the rest of the path allows."""
+        rc = lib().jxlamd_decoder_set_epf_reciprocal(self._h, int(bool(x86_reference_build)))
+        if rc:
+            _raise(rc, self._h)
 
     def set_writer_post(self, enabled: bool, config=PreferredColorConfig.DEFAULT, api_level=34):
         """A10 + A11 with the decode (jxlamd_decoder_set_writer_post): decodes of this context deliver the Bitmap format of

@@ -133,6 +133,7 @@ int jxlamd_decoder::prepare(FrameSlot &S, const uint8_t *jxl, size_t size, const
   }
   const BandGeom q = band_geometry(*Fh, band_rows ? band_rows[0] : 0, band_rows ? band_rows[1] : Fh->ygroups);
   S.band = q;
+  Fh->epf_rcp_x86 = epf_rcp_mode;
   Fh->band_gr0 = q.gr0; Fh->band_gr1 = q.gr1; Fh->band_cy0 = q.cy0; Fh->band_cy1 = q.cy1; Fh->band_py0 = q.py0; Fh->band_py1 = q.py1;
   Fh->band_scy0 = q.scy0; Fh->band_scy1 = q.scy1; Fh->band_g0 = q.g0; Fh->band_lfg0 = q.lfg0;
   const size_t bpp = S.pi.out_bits == 16 ? 8 : 4;
@@ -377,6 +378,7 @@ int jxlamd_decoder::finish_single_section(FrameSlot &S) {
   if ((derr & kErrNeedGeneral) && !lf_general) return kRetryGeneral;
   if (derr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(derr) + ", LfGroup)"); return dev_err_class(derr); }
   if (plan_parse_hf_single(&S.plan, end_bit)) { set_error(S.plan.error); return err_class(S.plan.error); }
+  ((DevFrame *)S.plan.tables.data())->epf_rcp_x86 = epf_rcp_mode;      // (the blob was built again from the parser's own copy of the frame parameters)
   HIPCHECK(S.tables.ensure(S.plan.tables.size()));
   S.B.tables = (const uint8_t *)S.tables.p;              // ensure() may have moved the buffer
   HIPCHECK(S.h_tables.ensure(S.plan.tables.size()));
@@ -1124,6 +1126,12 @@ int jxlamd_decode(jxlamd_decoder *d, const uint8_t *jxl, size_t size, uint32_t f
 // A10 + A11 with the decode: from now on this context's decodes deliver the Bitmap format of jxlamd_reformat_query(w, h, 16-bit?, cfg,
 // has alpha, api_level) — colour matrix / tone map when the reference's JNI layer would apply it (cpp/JniDecoding.cpp:131-137), premultiply, conversion —
 // INSIDE the writer for frames whose last filter stage is a per-stage kernel (three EPF iterations: BASELINE config 5), one pass behind it otherwise.
+int jxlamd_decoder_set_epf_reciprocal(jxlamd_decoder *d, int mode) {
+  if (!d) return JXLAMD_ERR_INVALID;
+  if (mode != 0 && mode != 1) { d->set_error("EPF reciprocal mode must be 0 (exact) or 1 (reference x86 build)"); return JXLAMD_ERR_INVALID; }
+  d->epf_rcp_mode = mode;
+  return JXLAMD_OK;
+}
 int jxlamd_decoder_set_writer_post(jxlamd_decoder *d, int enabled, int cfg, int api_level) {
   if (!d) { g_tls_error = "null decoder"; return JXLAMD_ERR_DEVICE; }
   if (enabled && (cfg < 1 || cfg > 6)) { d->set_error("Invalid Color Config: " + std::to_string(cfg) + " was passed"); return JXLAMD_ERR_BUFFER; }

@@ -31,6 +31,9 @@ template <class Fn> static inline int jxlamd_guarded(jxlamd_decoder *d, Fn &&fn)
 
 
 
+// default of jxlamd_decoder_set_epf_reciprocal for decoders of this process: JXLAMD_EPF_RCP=x86 (callers without a handle on the decoder — the libjxl-named compat library)
+static inline int epf_rcp_mode_default() { const char *e = getenv("JXLAMD_EPF_RCP"); return e && (!strcmp(e, "x86") || !strcmp(e, "1")) ? 1 : 0; }
+
 struct DevMem {
   void *p = nullptr; size_t cap = 0;
   DevMem() = default;
@@ -143,6 +146,7 @@ struct jxlamd_decoder {
   std::vector<FrameSlot *> ref_slots;     // reference frames of the file being decoded (patch dictionaries), one slot each
   DevMem ref_store[8]; int ref_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ref_h[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool ref_alpha[8] = {false, false, false, false, false, false, false, false};      // [4..7]: the LF frames (level 1..4) of a progressive_dc file
   int target_frame = -1;
+  int epf_rcp_mode = epf_rcp_mode_default();      // jxlamd_decoder_set_epf_reciprocal: 0 exact quotient, 1 the reference x86 build's rcpps (rcp12_lut.h)
   bool wpost_enabled = false; int wpost_cfg = 0, wpost_api = 34; uint64_t post_lut_gen = 0;      // jxlamd_decoder_set_writer_post     // the four reference slots: 3 dense f32 planes each
   bool stat_uploaded = false;
   std::vector<uint8_t> icc_lut_key;        // the profile whose lattice icc_lut holds

@@ -311,6 +311,19 @@ JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[
   for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)F.pw + (size_t)x] = v[c];
 }
 
+// 1 / (sum of weights).  libjxl spells it ApproximateReciprocal: exact in its AVX2 / NEON-with-refinement builds to within float rounding, but in the reference's
+// SSE2-only x86_64 build the host CPU's 12-bit rcpps, biased low by up to 3e-4 relative — invisible in most pixels, up to 4 codes where the inverse opsin matrix
+// amplifies it (one channel near 0 beside two near 1 on hard edges).  Default: the exact quotient.  epf_rcp_x86: the golden host's instruction as a table
+// (rcp12_lut.h: a function of the operand's top 11 mantissa bits, scaled exactly by its exponent), for "what that reference build returned" bit for bit.
+JXL_DEV float epf_reciprocal(const DevBuffers &B, const DevFrame &F, float wsum) {
+  if (!F.epf_rcp_x86) return 1.0f / wsum;
+  uint32_t u; memcpy(&u, &wsum, 4);                     // wsum is in [1, 13]: a normal positive number
+  const uint16_t *lut = (const uint16_t *)(B.stat + ((const DevStatic *)B.stat)->rcp12_off);
+  uint32_t r = 0x3f000000u + ((uint32_t)lut[(u >> 12) & 2047u] << 11) - (((u >> 23) - 127u) << 23);
+  float inv; memcpy(&inv, &r, 4);
+  return inv;
+}
+
 JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y) {
   if (F.is_modular) return -1.1715728752538099024f / F.epf_sigma_modular;      // Modular-encoded XYB frame: one sigma, no quant field / sharpness map
   const size_t o = (size_t)(y >> 3) * (size_t)F.xb + (size_t)(x >> 3);
@@ -364,7 +377,7 @@ JXL_DEV void epf_value_t(const DevBuffers &B, const DevFrame &F, float *const sr
     for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, ty, tx);
   }
   #undef PX
-  const float inv = 1.0f / wsum;
+  const float inv = epf_reciprocal(B, F, wsum);
   for (int c = 0; c < 3; c++) out[c] = acc[c] * inv;
 }
 template <int kPass>
@@ -434,7 +447,7 @@ JXL_DEV void epf_value_acc(const DevBuffers &B, const DevFrame &F, const Acc &ac
     wsum += wgt;
     for (int c = 0; c < 3; c++) accv[c] += wgt * acc(c, y + ty, x + tx);
   }
-  const float inv = 1.0f / wsum;
+  const float inv = epf_reciprocal(B, F, wsum);
   for (int c = 0; c < 3; c++) out[c] = accv[c] * inv;
 }
 

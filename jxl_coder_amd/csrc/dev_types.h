@@ -147,6 +147,8 @@ struct DevFrame {
   int32_t gab; float gab_w[3][2];
   int32_t epf_iters; float epf_sharp[8], epf_chscale[3], epf_quant_mul, epf_pass0, epf_pass2, epf_border_sad;
   float epf_sigma_modular;         // Modular-encoded XYB frames: one sigma for the whole frame
+  int32_t epf_rcp_x86;             // jxlamd_decoder_set_epf_reciprocal(1): the EPF's 1 / (sum of weights) is the reference x86 build's ApproximateReciprocal = the golden
+                                   // host's 12-bit rcpps (DevStatic::rcp12_off) instead of the exact quotient; patched in by the decoder before the upload
   // colour
   float opsin_inv[9];              // already scaled by 255/intensity_target and target-primaries matrix
   float opsin_bias[3], opsin_bias_cbrt[3];
@@ -185,6 +187,7 @@ struct DevStatic {
   uint32_t cos_off[9];         // float[n*n], n = 1<<i: c_k cos((2i+1)k pi/2n), row k
   uint32_t afv_off;            // float[16*16]
   uint32_t dither_off;         // float[32*32]
+  uint32_t rcp12_off;          // u16[2048]: the golden host's rcpps as a table (rcp12_lut.h; DevFrame::epf_rcp_x86)
   uint32_t llf_off;            // float[6][32]: 1/(cos t cos 2t cos 4t), t = k pi/(16 N), N = 1<<i
   uint32_t ups_off[3];         // float[N][N][5][5], N = 2 / 4 / 8: the default upsampling kernels of every output phase (mirrored phases expanded)
   uint32_t nat_order_off[13];  // u32[covered cells * 64]: the natural coefficient order of each order bucket (frames without a coded permutation)

@@ -25,6 +25,7 @@ typedef struct { int nbands; float b[3][8]; } hx_dctparams;
 #include "host_format.inc"
 #include "host_icc.inc"
 #include "dither_lut.h"
+#include "rcp12_lut.h"
 #include "upsampling_weights.h"
 #include "host_icc_synth.inc"
 #include "host_modular_small.inc"
@@ -1156,7 +1157,11 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     else if (m.pub.white_point == 11) { dst[6] = 0.314; dst[7] = 0.351; custom = true; }
     else if (m.pub.white_point != 1) { plan->error = "unsupported: white point"; return -1; }
     for (int k = 0; k < 4; k++) if (!(dst[2 * k + 1] > 1e-6)) { plan->error = "bad chromaticities"; return -1; }
-    if (m.pub.primaries != 1 || custom) {
+    // A grey target (ColourEncoding.colour_space = kGrey; the reference's own encoder writes it for mono bitmaps, interop/JxlEncoding.cpp:66-68,103-106): libjxl keeps
+    // the sRGB inverse matrix whatever the white point says and multiplies it from the left by three identical rows of the sRGB luminances, so the three
+    // channels of the pipeline carry the same value and the 4-channel output the reference asks for (interop/JxlDecoding.cpp:63) has R = G = B on every sample.
+    const bool grey_target = m.grey_target != 0;
+    if ((m.pub.primaries != 1 || custom) && !grey_target) {
       // linear sRGB -> the target's linear RGB.  Same white point on both sides: the two RGB -> XYZ matrices.  Another white point (custom, E, DCI): both
       // sides go to XYZ-D50 through the Bradford adaptation of their white point, as libjxl's output stage does (PrimariesToXYZD50 on the image's encoding and
       // on sRGB); for a D65 target the two adaptations cancel, and the enum cases keep the arithmetic they had
@@ -1188,6 +1193,14 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
       double s = 0; for (int k = 0; k < 3; k++) s += T[r * 3 + k] * (double)m.opsin_inv[k * 3 + c];
       F.opsin_inv[r * 3 + c] = (float)(s * itscale);
+    }
+    if (grey_target) {
+      static const float kLuma[3] = {0.2126f, 0.7152f, 0.0722f};
+      for (int c = 0; c < 3; c++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += (double)(kLuma[k] * m.opsin_inv[k * 3 + c]);       // float products summed in a double, stored as a float
+        const float g = (float)s;
+        for (int r = 0; r < 3; r++) F.opsin_inv[r * 3 + c] = g * itscale;
+      }
     }
     for (int c = 0; c < 3; c++) { F.opsin_bias[c] = m.opsin_bias[c]; F.opsin_bias_cbrt[c] = cbrtf(m.opsin_bias[c]); }
     F.transfer = m.pub.have_gamma ? -1 : (int)m.pub.transfer_function;
@@ -1276,6 +1289,7 @@ static void build_static_tables(std::vector<uint8_t> &tab) {
   }
   { float a[256]; for (int j = 0; j < 16; j++) for (int i = 0; i < 16; i++) a[j * 16 + i] = (float)kAFVBasis[j][i]; ST.afv_off = blob.append(a, sizeof(a)); }
   ST.dither_off = blob.append(kDither32, sizeof(kDither32));
+  ST.rcp12_off = blob.append(kRcp12, sizeof(kRcp12));
   {
     // default upsampling kernels: the symmetric 5n x 5n matrix of each factor N = 2n, expanded to one 5 x 5 kernel per output phase (the phases
     // of the right / lower half are the mirror images of the left / upper half)

@@ -103,7 +103,10 @@ __device__ __forceinline__ void delta_palette_wave(const DevBuffers &B, const De
 }
 __global__ void __launch_bounds__(256) k_mod_op(DevBuffers B, int op, size_t n) {
   const DevFrame &F = frame_of(B);
-  if (F.mod_op_kind[op] == 4) { if (threadIdx.x < 64 && blockIdx.x < (unsigned)F.mod_op_c[op]) delta_palette_wave(B, F, op, (int)blockIdx.x, (int)threadIdx.x); return; }
+  if (F.mod_op_kind[op] == 4) {         // one wave per colour channel; the grid may hold fewer workgroups than the palette has channels
+    if (threadIdx.x < 64) for (int c = (int)blockIdx.x; c < F.mod_op_c[op]; c += (int)gridDim.x) delta_palette_wave(B, F, op, c, (int)threadIdx.x);
+    return;
+  }
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) mod_op_element(B, F, op, i);
 }
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) 
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if ((!F.is_modular && !F.has_ec) || op >= F.mod_nops) return;
-  if (F.mod_op_kind[op] == 4) { if (threadIdx.x < 64 && blockIdx.x < (unsigned)F.mod_op_c[op]) delta_palette_wave(B, F, op, (int)blockIdx.x, (int)threadIdx.x); return; }      // one wave per colour channel
+  if (F.mod_op_kind[op] == 4) { if (threadIdx.x < 64) for (int c = (int)blockIdx.x; c < F.mod_op_c[op]; c += (int)gridDim.x) delta_palette_wave(B, F, op, c, (int)threadIdx.x); return; }      // one wave per colour channel
   const size_t n = (size_t)(F.mod_op_kind[op] == 0 ? F.mod_op_y[op] : F.mod_op_c[op]);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mod_op_element(B, F, op, i);
 }

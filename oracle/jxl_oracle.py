@@ -45,7 +45,9 @@ def basic_info(data: bytes):
     return info.as_dict()
 
 
-def decode(data: bytes, out_bits=8, debug=False):
+def decode(data: bytes, out_bits=8, debug=False, epf_x86=None):
+    """epf_x86: True = the EPF normalises with the reference x86 build's rcpps (oracle/jxo_rcp12.h), False = the exact quotient, None = as JXO_EPF_RCPPS says"""
+    C.c_int.in_dll(lib(), "jxo_epf_rcp").value = -1 if epf_x86 is None else int(bool(epf_x86))
     out = C.c_void_p()
     n = C.c_size_t()
     info = Info()

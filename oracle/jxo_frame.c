@@ -1384,11 +1384,18 @@ static void gaborish(fstate *s, int w, int h) {
   }
 }
 
-#include <xmmintrin.h>
-static int jxo_epf_rcpps = -1;
-static float rcpps1(float v) { return _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(v))); }
+#include "jxo_rcp12.h"
+/* The reference's x86_64 libjxl is an SSE2-only build: ApproximateReciprocal in the EPF's normalisation is the CPU's 12-bit rcpps.  jxo_epf_rcp = 1 (or
+   JXO_EPF_RCPPS=1 in the environment) puts the golden host's instruction — as the table oracle/tools/extract_rcp12.py wrote, so that any host reproduces it —
+   in place of the exact quotient.  Default 0: the quotient, what the product computes unless jxlamd_decoder_set_epf_reciprocal(1). */
+int jxo_epf_rcp = -1;
+static float rcpps1(float v) {
+  uint32_t u, r; memcpy(&u, &v, 4);
+  r = 0x3f000000u + ((uint32_t)jxo_rcp12[(u >> 12) & 2047u] << 11) - (((u >> 23) - 127u) << 23);
+  float o; memcpy(&o, &r, 4); return o;
+}
 static void epf_pass(fstate *s, int w, int h, int pass, const float *inv_sigma) {
-  if (jxo_epf_rcpps < 0) jxo_epf_rcpps = getenv("JXO_EPF_RCPPS") && atoi(getenv("JXO_EPF_RCPPS")) ? 1 : 0;
+  const int jxo_epf_rcpps = jxo_epf_rcp >= 0 ? jxo_epf_rcp : (getenv("JXO_EPF_RCPPS") && atoi(getenv("JXO_EPF_RCPPS")) ? 1 : 0);
   const frame_hdr *f = &s->f;
   float sm = 1.65f * (pass == 0 ? f->epf_pass0 : pass == 2 ? f->epf_pass2 : 1.0f);
   float bsm = sm * f->epf_border_sad;
@@ -1425,7 +1432,7 @@ static void epf_pass(fstate *s, int w, int h, int pass, const float *inv_sigma) 
         wsum += wgt;
         for (int c = 0; c < 3; c++) acc[c] += wgt * PX(c, y + ty, x + tx);
       }
-      if (jxo_epf_rcpps) {                /* experiment (JXO_EPF_RCPPS=1): the reference build's ApproximateReciprocal = the host CPU's 12-bit rcpps */
+      if (jxo_epf_rcpps) {                /* the reference build's ApproximateReciprocal = the golden host's 12-bit rcpps */
         float inv = rcpps1(wsum);
         for (int c = 0; c < 3; c++) dst[c][(size_t)y * (size_t)s->pw + (size_t)x] = acc[c] * inv;
       } else
@@ -1725,6 +1732,14 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
       double A[9], B[9], Bi[9];
       primaries_to_xyz(srgb, A); primaries_to_xyz(dst, B); inv3(B, Bi);
       for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { T[r * 3 + c] = 0; for (int k = 0; k < 3; k++) T[r * 3 + c] += Bi[r * 3 + k] * A[k * 3 + c]; }
+    }
+    /* grey target (colour_space kGrey): libjxl multiplies the sRGB inverse matrix from the left by three rows of the sRGB luminances — the three channels carry one
+       value, the reference's 4-channel output (interop/JxlDecoding.cpp:63) has R = G = B on every sample */
+    if (m.pub.color_space == 1) {
+      static const float kLuma[3] = {0.2126f, 0.7152f, 0.0722f};
+      float g[3];
+      for (int c = 0; c < 3; c++) { double e = 0; for (int k = 0; k < 3; k++) e += (double)(kLuma[k] * m.opsin_inv[k * 3 + c]); g[c] = (float)e; }
+      for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m.opsin_inv[r * 3 + c] = g[c];
     }
     for (size_t i = 0; i < npx; i++) {
       float X = rgb[0][i], Y = rgb[1][i], B = rgb[2][i];

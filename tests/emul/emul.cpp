@@ -98,6 +98,8 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
 static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs);
 
 static int g_target_frame = -1;
+static int g_epf_rcp = 0;
+extern "C" void emul_set_epf_reciprocal(int mode) { g_epf_rcp = mode; }      // what jxlamd_decoder_set_epf_reciprocal patches into the frame parameters
 extern "C" void emul_set_target_frame(int i) { g_target_frame = i; }
 extern "C" int emul_decode(const uint8_t *jxl, size_t size, int allow16, uint8_t *out, size_t out_cap, uint32_t *w, uint32_t *h, uint32_t *bits) {
   FramePlan plan;
@@ -130,6 +132,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   std::vector<uint32_t> bl0(ncell / 8 + 16), bl1(ncell / 32 + 16), bl2(ncell + 16), bl3(ncell / 256 + 16); uint32_t bcount[4] = {0, 0, 0, 0};
   uint32_t errw[32] = {0}; uint32_t &err = errw[0];       // the frame's flag block (word 1: LF table pool the streams asked for)
   std::vector<uint8_t> tables = plan.tables; tables.reserve(tables.size() + (8u << 20));
+  ((DevFrame *)tables.data())->epf_rcp_x86 = g_epf_rcp;
   DevBuffers B; memset(&B, 0, sizeof(B));
   B.codestream = cs.data(); B.tables = tables.data(); B.stat = static_tables().data();
   memset(c8[0].data(), 0xFF, ncell);
@@ -186,6 +189,7 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
   if (plan.single_section) {
     if (plan_parse_hf_single(&plan, endbits[0])) { g_err = plan.error; return -1; }
     tables = plan.tables; B.tables = tables.data();
+    ((DevFrame *)tables.data())->epf_rcp_x86 = g_epf_rcp;
   }
   for (int y = 0; y < plan.yb; y++) for (int x = 0; x < plan.xb; x++) lf_smooth_cell(B, x, y);
   DevPassScratch *PS = new DevPassScratch();

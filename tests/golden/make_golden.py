@@ -155,6 +155,13 @@ CASES = {
     # two levels of LF frames (progressive DC = 2): a Modular LF frame of level 2 (1 / 64 of the size) serves a VarDCT LF frame of level 1, which serves the image
     "vlf2_600x410_e7_d2": (600, 410, dict(seed=24), dict(effort=7, distance=2.0, extra=((19, 2),))),
     "vlf2a520x300_e7": (520, 300, dict(seed=25, alpha=True), dict(effort=7, distance=1.5, extra=((19, 2),))),
+    # hard-edged saturated content (synth.hard_edged): grey images (the reference returns R = G = B for them), RGB at distances where the encoder switches
+    # two and three EPF iterations on, RGBA.  These are the files on which the EPF's reciprocal (the reference build's rcpps) shows in the MAX difference
+    "vhg800x600_e7_d1": (800, 600, dict(gen="hard_edged", seed=1, grey=True), dict(effort=7, distance=1.0)),
+    "vhg800x600_e7_d2": (800, 600, dict(gen="hard_edged", seed=2, grey=True), dict(effort=7, distance=2.0)),
+    "vh1000x700_e7_d2": (1000, 700, dict(gen="hard_edged", seed=3), dict(effort=7, distance=2.0)),
+    "vh800x600_e7_d4": (800, 600, dict(gen="hard_edged", seed=4), dict(effort=7, distance=4.0)),
+    "vha640x480_e7_d1": (640, 480, dict(gen="hard_edged", seed=5, alpha=True), dict(effort=7, distance=1.0)),
     "vflat400x300_e7": (400, 300, dict(gen="flat"), dict(effort=7)),
     "vgrad200x150_e7": (200, 150, dict(gen="gradient"), dict(effort=7)),
     "v2c400x300_e7": (400, 300, dict(gen="two_colour", seed=1), dict(effort=7)),
@@ -499,6 +506,8 @@ def make_image(w, h, sk):
         return img
     if gen == "screenshot":
         return synth.screenshot(w, h, sk.get("seed", 0), channels=4 if alpha else 3)
+    if gen == "hard_edged":
+        return synth.hard_edged(w, h, sk.get("seed", 0), channels=1 if grey else 4 if alpha else 3)
     if gen == "flat":
         return synth.flat(w, h)
     if gen == "gradient":

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import (ROOT, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, assert_u16_non_srgb, U16_MAX_ABS, U16_MEAN_ABS,
+from conftest import (ROOT, HARD_EDGED_CASES, assert_vardct_hard_edged, VARDCT_CASES, VARDCT_MAX_ABS, VARDCT_MEAN_ABS, vardct_mean_tol, U16_CASES, U16_PQ_CASES, U16_TF_CASES, assert_u16_non_srgb, U16_MAX_ABS, U16_MEAN_ABS,
                       LOSSLESS_DEVICE_CASES, SQUEEZE_VARDCT_CASES, PATCH_LOSSLESS_CASES, PATCH_VARDCT_CASES, JPEG_CASES, ANIM_LOSSLESS_CASES, ANIM_VARDCT_CASES, load_anim_case, load_case)
 
 pytestmark = pytest.mark.gpu
@@ -36,6 +36,52 @@ def test_golden_vectors(dec, oracle, name, golden_meta):
     assert np.array_equal(out[..., 3], exp[..., 3])                          # opaque 255, or the Modular-coded alpha bit for bit
     assert info["out_bits"] == 8 and info["prefer_encoding"] == 1
     assert info["has_alpha_in_origin"] == int(golden_meta[name]["info"]["alpha_bits"] > 0)       # what the reference reports for the file (an extra channel of another type is not an alpha)
+
+
+@pytest.mark.parametrize("name", HARD_EDGED_CASES)
+def test_hard_edged_content(dec, oracle, name):
+    """Hard-edged saturated content against the reference's goldens, single decode and in a flight.  Grey images: R = G = B on every sample,
+    as the reference returns them (interop/JxlDecoding.cpp:63: four channels of a one-channel image).  Default decoder: the stated bound
+    (conftest.assert_vardct_hard_edged); with jxlamd_decoder_set_epf_reciprocal(1), the reference x86 build's reciprocal: max 1 on every sample."""
+    import torch
+    data, exp = load_case(name)
+    out, _ = dec.decode_one_shot(data)
+    assert_vardct_hard_edged(out, exp, False, name)
+    other, _ = load_case("v264x520_e7")
+    outs = [torch.zeros(exp.size, dtype=torch.uint8, device="cuda"), torch.zeros(264 * 520 * 4, dtype=torch.uint8, device="cuda"), torch.zeros(exp.size, dtype=torch.uint8, device="cuda")]
+    try:
+        dec.set_epf_reciprocal(True)
+        out86, _ = dec.decode_one_shot(data)
+        dec.decode_batch_to_device([data, other, data], [o.data_ptr() for o in outs], [o.numel() for o in outs])      # the column sweep's instantiations of the same filter
+        torch.cuda.synchronize()
+    finally:
+        dec.set_epf_reciprocal(False)
+    assert_vardct_hard_edged(out86, exp, True, name)
+    for o in (outs[0], outs[2]):
+        assert np.array_equal(o.cpu().numpy().reshape(exp.shape), out86), name
+    if name.startswith("vhg"):
+        for o in (out, out86):
+            assert np.array_equal(o[..., 0], o[..., 1]) and np.array_equal(o[..., 1], o[..., 2]), name
+    if name != "vha640x480_e7_d1":            # (a patch dictionary: two frames — the C oracle does not walk multi-frame files)
+        for x86, mine in ((False, out), (True, out86)):
+            ora, _ = oracle.decode(data, 8, epf_x86=x86)
+            d2 = np.abs(mine.astype(int) - ora.astype(int))
+            assert d2.max() <= 1 and (d2 > 0).mean() < 1e-2, (name, x86, d2.max(), (d2 > 0).mean())      # same algorithm, another summation order (grey: a pixel one code apart counts three times; measured 5e-3)
+
+
+def test_forced_epf_fixtures_meet_the_ordinary_bound_with_the_reference_builds_reciprocal(dec):
+    """conftest.VARDCT_MEAN_ABS_CASE loosens two fixtures (EPF forced to 2 / 3 iterations on every pixel: 0.051 / 0.076) — the golden host's rcpps.  With that
+    instruction's table in the kernels' normalisation (jxlamd_decoder_set_epf_reciprocal(1)) they agree with the goldens like every other file."""
+    try:
+        dec.set_epf_reciprocal(True)
+        for name in ("v256_e3_gab0_epf1", "v256_e3_gab0_epf2", "v256_e3_gab0_epf3", "v256_e7", "v300x300_e7_d3"):
+            data, exp = load_case(name)
+            out, _ = dec.decode_one_shot(data)
+            d = np.abs(out.astype(int) - exp.astype(int))
+            print("[epf x86] %s max %d mean %.4f" % (name, d.max(), d.mean()))
+            assert d.max() <= 1 and d.mean() <= 0.012, (name, d.max(), d.mean())
+    finally:
+        dec.set_epf_reciprocal(False)
 
 
 def test_vardct_with_squeezed_alpha_beyond_2048_pixels(dec, golden_meta):
@@ -177,7 +223,7 @@ def test_alpha_streams_with_a_tree_of_hundreds_of_leaves_run_from_its_block_form
         assert out.shape == ref.shape == (h, w, 4)
         assert np.array_equal(out[..., 3], ref[..., 3]), "alpha (lossless Modular)"
         diff = np.abs(out[..., :3].astype(int) - ref[..., :3].astype(int))
-        assert diff.max() <= VARDCT_MAX_ABS and diff.mean() <= 0.06, (diff.max(), diff.mean())
+        assert diff.max() <= VARDCT_MAX_ABS and diff.mean() <= VARDCT_MEAN_ABS, (diff.max(), diff.mean())
         if w == 1920:
             assert s1[1] - s0[1] >= 40 and s1[0] == s0[0], ("the 40 group streams' alpha channel from the block form, nothing on the serial walker", s0, s1)
         # the same frame three times in a flight next to a plain VarDCT frame

@@ -99,47 +99,55 @@ def test_reference_binary_is_the_pinned_one():
     assert hashlib.sha256(open(p, "rb").read()).hexdigest() == "25bd94ff22ae13a62027e266e96fa040c05d116544a75816156d4c540b6c4abe"
 
 
-def test_epf_offset_is_the_reference_builds_rcpps():
+def test_epf_offset_is_the_reference_builds_rcpps(oracle):
     """The fixtures with EPF forced to 1 / 2 / 3 iterations sit 0.037 / 0.068 / 0.10 (mean, always the same sign) from the reference.  The reference's
-    libjxl is an SSE2-only build: its ApproximateReciprocal in the EPF's normalisation is the CPU's 12-bit rcpps.  JXO_EPF_RCPPS=1 puts that very
-    instruction into the C oracle's normalisation (x86 hosts only): the three fixtures then agree with the goldens like any other file (<= 0.012),
-    which pins the cause; without it they show the offset.  (The goldens come from the build container's CPU; rcpps differs between vendors, which
-    is why the product divides exactly instead of imitating one table.)"""
-    import platform, subprocess, sys, textwrap
-    if platform.machine() not in ("x86_64", "AMD64"):
-        pytest.skip("rcpps is an x86 instruction")
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        import jxl_oracle
-        from conftest import load_case
+    libjxl is an SSE2-only build: its ApproximateReciprocal in the EPF's normalisation is the CPU's 12-bit rcpps.  With the golden host's instruction in the C
+    oracle's normalisation (epf_x86=True: the table oracle/tools/extract_rcp12.py wrote, so any host reproduces it) the three fixtures agree with the goldens
+    like any other file (<= 0.012), which pins the cause; without it they show the offset.  rcpps differs between CPU vendors, which is why the product divides
+    exactly by default and offers that table as an option (jxlamd_decoder_set_epf_reciprocal)."""
+    res = {False: {}, True: {}}
+    for x86 in (False, True):
         for name in ["v256_e3_gab0_epf1", "v256_e3_gab0_epf2", "v256_e3_gab0_epf3"]:
             data, exp = load_case(name)
-            out, _ = jxl_oracle.decode(data, 8)
+            out, _ = oracle.decode(data, 8, epf_x86=x86)
             d = out.astype(int)[..., :3] - exp.astype(int)[..., :3]
-            print(name, abs(d).max(), round(float(abs(d).mean()), 4), round(float(d.mean()), 4))
+            res[x86][name] = (abs(d).max(), float(abs(d).mean()), float(d.mean()))
         data, exp = load_case("v160x120_16bit_pq2100_epf3")            # config 5's arithmetic: three EPF iterations, PQ 16-bit
-        out, _ = jxl_oracle.decode(data, 16)
+        out, _ = oracle.decode(data, 16, epf_x86=x86)
         d = abs(out.astype(int)[..., :3] - exp.astype(int)[..., :3])
-        print("pq16", d.max(), round(float(d.mean()), 4), int((d > 256).sum()))
-    """) % (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"))
-    res = {}
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, JXO_EPF_RCPPS=flag), capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-1500:]
-        res[flag] = {ln.split()[0]: [float(v) for v in ln.split()[1:]] for ln in r.stdout.strip().splitlines()}
-    pq_exact, pq_approx = res["0"].pop("pq16"), res["1"].pop("pq16")
-    exact, approx = res["0"], res["1"]
+        res[x86]["pq16"] = (d.max(), float(d.mean()), int((d > 256).sum()))
+    pq_exact, pq_approx = res[False].pop("pq16"), res[True].pop("pq16")
+    exact, approx = res[False], res[True]
     # exact division: the offset grows by ~0.03 per iteration and is one-sided (mean |d| == mean d within rounding)
     assert exact["v256_e3_gab0_epf3"][1] > exact["v256_e3_gab0_epf2"][1] > exact["v256_e3_gab0_epf1"][1] > 0.02
     assert all(abs(v[1] - v[2]) < 0.004 for v in exact.values())
-    # the golden host's rcpps: only meaningful on the CPU family that produced the goldens (elsewhere the offset merely changes)
-    if all(v[1] <= 0.012 for v in approx.values()):
-        assert all(v[0] <= 1 for v in approx.values())
-        # ... and the same instruction accounts for the PQ 16-bit outliers (samples near zero in out-of-gamut pixels, where the inverse opsin matrix
-        # cancels terms of order 1 and a 3e-4 relative offset of the filtered XYB becomes thousands of PQ codes): max 11 262 -> 815, 23 -> 5 samples
-        # beyond 256 codes, mean 1.11 -> 0.16
-        assert pq_exact[0] > 4 * pq_approx[0] and pq_approx[2] < pq_exact[2] and pq_approx[1] < 0.4 * pq_exact[1], (pq_exact, pq_approx)
-    else:
+    # the golden host's rcpps
+    assert all(v[0] <= 1 and v[1] <= 0.012 for v in approx.values()), approx
+    # ... and the same instruction accounts for the PQ 16-bit outliers (samples near zero in out-of-gamut pixels, where the inverse opsin matrix
+    # cancels terms of order 1 and a 3e-4 relative offset of the filtered XYB becomes thousands of PQ codes): max 11 262 -> 815, 23 -> 5 samples
+    # beyond 256 codes, mean 1.11 -> 0.16
+    assert pq_exact[0] > 4 * pq_approx[0] and pq_approx[2] < pq_exact[2] and pq_approx[1] < 0.4 * pq_exact[1], (pq_exact, pq_approx)
+
+
+def test_rcp12_table_is_this_hosts_rcpps_where_the_goldens_were_made(golden_meta):
+    """oracle/jxo_rcp12.h and csrc/rcp12_lut.h hold the golden host's rcpps (oracle/tools/extract_rcp12.py).  On a host of the same CPU model the instruction and
+    the table agree on every entry; elsewhere (AMD's table differs) this only records that it does not."""
+    import platform, re, subprocess, tempfile
+    if platform.machine() not in ("x86_64", "AMD64"):
+        pytest.skip("rcpps is an x86 instruction")
+    a = [int(x) for x in re.findall(r"\b\d+\b", open(os.path.join(ROOT, "oracle", "jxo_rcp12.h")).read().split("{", 1)[1])]
+    b = [int(x) for x in re.findall(r"\b\d+\b", open(os.path.join(ROOT, "jxl_coder_amd", "csrc", "rcp12_lut.h")).read().split("{", 1)[1])]
+    assert a == b and len(a) == 2048 and max(a) <= 4096 and min(a) >= 0          # identical in product and checker
+    src = ("#include <xmmintrin.h>\n#include <stdio.h>\n#include <string.h>\n#include <stdint.h>\n"
+           "int main(void){for(uint32_t i=0;i<2048;i++){uint32_t u=0x3f800000u|(i<<12),r;float f;memcpy(&f,&u,4);"
+           "f=_mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(f)));memcpy(&r,&f,4);printf(\"%u\\n\",(r-0x3f000000u)>>11);}return 0;}\n")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "r.c"), "w").write(src)
+        subprocess.run(["gcc", "-O1", "-o", os.path.join(d, "r"), os.path.join(d, "r.c")], check=True)
+        here = [int(x) for x in subprocess.run([os.path.join(d, "r")], check=True, capture_output=True, text=True).stdout.split()]
+    cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    if cpu == golden_meta["_generated_on"]["cpu_model"]:
+        assert here == a
+    elif here != a:
         import warnings
-        warnings.warn("this host's rcpps differs from the golden host's: %r" % approx)
+        warnings.warn("this host's rcpps (%s) differs from the golden host's table in %d of 2048 entries" % (cpu, sum(x != y for x, y in zip(here, a))))

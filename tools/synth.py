@@ -92,3 +92,28 @@ def many_colours(w, h, seed=0, n=1000):
     rng = np.random.default_rng(seed)
     lut = rng.integers(0, 256, size=(n, 3)).astype(np.uint8)
     return lut[np.sort(rng.integers(0, n, size=(h, w)), axis=1)]
+
+
+def hard_edged(w, h, seed=0, channels=3):
+    """Hard-edged, saturated content: axis-aligned rectangles in saturated and near-saturated colours, a band of 1-px stripes, a corner
+    of uniform noise.  What photographs-like fixtures do not have: pixels with one channel near 0 beside two near 1 right at an edge, where libjxl's inverse
+    opsin matrix amplifies any 1e-4 difference upstream (the EPF's reciprocal) into several 8-bit codes.  channels: 1 (grey), 3, or 4 (RGB + a hard-edged alpha)."""
+    rng = np.random.default_rng(0xED6E ^ seed)
+    c = 1 if channels == 1 else 3
+    sat = np.array([[255, 255, 0], [0, 255, 255], [255, 0, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 210, 210], [240, 240, 20]], np.uint8)
+    img = np.zeros((h, w, c), np.uint8)
+    img[:] = rng.integers(0, 256, c)
+    for _ in range(60):
+        x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+        x1, y1 = x0 + int(rng.integers(4, max(5, w // 4))), y0 + int(rng.integers(4, max(5, h // 4)))
+        img[y0:y1, x0:x1] = sat[rng.integers(0, len(sat))][:c]
+    img[h // 2: h // 2 + 40, ::4] = sat[1][:c]
+    img[h // 2: h // 2 + 40, 1::4] = sat[3][:c]
+    img[: h // 6, : w // 6] = rng.integers(0, 256, (h // 6, w // 6, c))
+    if channels == 4:
+        a = np.full((h, w, 1), 255, np.uint8)
+        for _ in range(12):
+            x0, y0 = int(rng.integers(0, w)), int(rng.integers(0, h))
+            a[y0:y0 + int(rng.integers(4, max(5, h // 3))), x0:x0 + int(rng.integers(4, max(5, w // 3)))] = int(rng.choice([0, 64, 128, 200]))
+        img = np.concatenate([img, a], axis=2)
+    return img
