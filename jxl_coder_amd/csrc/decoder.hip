@@ -937,7 +937,8 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   HIPCHECK(hipEventRecord(ev[0], stream));
   launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
-  launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_general, stream);
+  static const int lf_pool_min_env = getenv("JXLAMD_LF_POOL_MIN") ? atoi(getenv("JXLAMD_LF_POOL_MIN")) : 0;      // measurement switch: the LDS of an LF workgroup as a variable (streams per CU)
+  launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::min(kModPoolBytes, std::max(std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_pool_min_env)), lf_general, stream);
   HIPCHECK(hipEventRecord(ev[1], stream));
   launch_lf_smooth_batch(dB, nb, max_cells, stream);
   // ---- HF phase: this context's turn on the pools (uncontended unless shared).  The wait is host-side and overlaps the LF stage launched above

@@ -8,6 +8,7 @@
 // state, the property vector and the head of the MA tree live in LDS so that the serial lane never waits on
 // HBM for its neighbourhood.
 #pragma once
+#include <stddef.h>
 #include "dev_echeader.h"
 
 namespace jxlamd {
@@ -53,15 +54,12 @@ struct alignas(16) DevWaveTree {      // LDS: the pruned tree of one channel in 
   uint64_t leaf_need1[64], leaf_need0[64];
   int32_t leaf_ctx[64], leaf_pred[64], leaf_off[64], leaf_mul[64];
   int32_t ni, nl, ok, uses_wp;
-  int32_t stack_node[64]; uint64_t stack_n1[64], stack_n0[64];   // DFS stacks of the builders (LDS, not scratch)
-};
+};      // (the builders' DFS stacks — 1.25 KB — no longer live here: mod_stack_node / _n1 / _n0 below lay them over the weighted predictor's error rows)
 
 struct DevModScratch {                // per-wave working memory (LDS on the GPU)
   int32_t rows[3][kModMaxW + 8];      // cur / prev / prevprev rows
-  uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];
+  uint32_t wp_pred_err[4][2 * (kWpMaxW + 2)];      // (between channels: the tree builders' DFS stacks, mod_stack_*)
   int32_t wp_err[2 * (kWpMaxW + 2)];
-  int32_t props[16 + 4 * kModMaxRefs];
-  const int32_t *refp[kModMaxRefs];    // wave loop, block-form trees: the previous channels whose samples feed properties 16 .. (same size and shifts, nearest first)
   uint32_t divlut[64];                // (1<<24)/(i+1): the WP's division-free reciprocal table
   uint32_t wdiv[4][64];               // divlut pre-multiplied by the WP header weights (wave_decode_channel_wpfixed)
   uint32_t ring[128];                 // the next 512 bytes of the stream, refilled half by half far ahead of the reader (wave_decode_channel_wpfixed)
@@ -81,7 +79,11 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   int32_t grp_src[kModMaxGroupCh], grp_n;         // a group stream's channels: which stream channel of the frame each one is a rectangle of (LDS: keeps the kernel free of scratch)
   DevTrList trs;                      // transforms of the current stream header
   DevChanOut pal_saved[kModMaxLocalTr][3];   // group-level palettes: the colour channels 1.. each one folded away (their buffers receive the colours again)
+  // wt, props, refp in this order: the weighted-predictor loop's chunk records (dev_modular_wave.h: DevWpFixedLds, 2 816 bytes) overlay the three — the tree sits in
+  // registers by then, props serve the serial walker and refp the block-form loops only
   DevWaveTree wt;
+  int32_t props[16 + 4 * kModMaxRefs];
+  const int32_t *refp[kModMaxRefs];    // wave loop, block-form trees: the previous channels whose samples feed properties 16 .. (same size and shifts, nearest first)
   uint32_t fallback_err;
   uint32_t *wide_wp;                  // HBM: the weighted predictor's error rows for channels wider than the LDS rows (kWideWpInts; null: such channels are rejected)
   DevLz lz;                           // LZ77 state of the current stream (serial walker; window in HBM, set by the stream's caller)
@@ -90,6 +92,12 @@ struct DevModScratch {                // per-wave working memory (LDS on the GPU
   uint32_t *walk_stat;                // two counters (words 2 and 3 of the frame's flag block): streams that went to the serial walker, channels decoded with their tree in block form; may be null
   uint64_t pool[kModPoolBytes / 8];   // LAST member: the kernels allocate only pool_bytes of it
 };
+// DFS stacks of the tree builders (wave_tree_build, tree_facts, big_tree_count / big_tree_build): they run at the start of a channel, when the weighted predictor's error
+// rows of the previous channel are dead and this channel's are not yet cleared — LDS, not scratch, and no bytes of their own
+JXL_DEV int32_t *mod_stack_node(DevModScratch &S) { return (int32_t *)&S.wp_pred_err[0][0]; }
+JXL_DEV uint64_t *mod_stack_n1(DevModScratch &S) { return (uint64_t *)&S.wp_pred_err[1][0]; }
+JXL_DEV uint64_t *mod_stack_n0(DevModScratch &S) { return (uint64_t *)&S.wp_pred_err[2][0]; }
+static_assert(sizeof(((DevModScratch *)0)->wp_pred_err[0]) >= 64 * 8 && (offsetof(DevModScratch, wp_pred_err) % 8) == 0 && (sizeof(((DevModScratch *)0)->wp_pred_err[0]) % 8) == 0, "the DFS stacks fit one error row each");
 JXL_DEV void mod_pool_want(DevModScratch &S, int bytes, int tid) {
   if (tid != 0 || !S.pool_want) return;
 #ifdef __HIPCC__
@@ -367,15 +375,16 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     const DevChanOut &c = chans[ci];
     const int w = c.w, h = c.h;
     if (w == 0 || h == 0) continue;
-    const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id, S.wt.stack_node);
+    const TreeFacts tf = tree_facts(gtree, tree_count, ci, stream_id, mod_stack_node(S));
 #ifdef JXL_EMUL_TRACE
     {
       unsigned props_used = 0, preds_used = 0; int leaves = 0, nonunit = 0, sp = 0, st[256]; st[sp++] = 0;
+      bool reach[256] = {false}; int nreach = 0;
       while (sp > 0) { const DevTreeNode nd = gtree[st[--sp]];
-        if (nd.prop < 0) { preds_used |= 1u << nd.lchild; leaves++; if (nd.rchild != 1 || nd.offset != 0) nonunit++; continue; }
+        if (nd.prop < 0) { preds_used |= 1u << nd.lchild; leaves++; if (nd.rchild != 1 || nd.offset != 0) nonunit++; const int cl = ev.ctx_map[nd.splitval]; if (!reach[cl]) { reach[cl] = true; nreach++; } continue; }
         if (nd.prop == 0 || nd.prop == 1) { int v = nd.prop == 0 ? ci : stream_id; st[sp++] = v > nd.splitval ? nd.lchild : nd.rchild; continue; }
         props_used |= 1u << nd.prop; if (sp + 2 < 256) { st[sp++] = nd.lchild; st[sp++] = nd.rchild; } }
-      fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d props 0x%x predictors 0x%x leaves %d (mul/offset != 1/0: %d)\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop, props_used, preds_used, leaves, nonunit);
+      fprintf(stderr, "stream %d chan %d %dx%d: tree %d nodes uses_wp=%d max_prop=%d props 0x%x predictors 0x%x leaves %d (mul/offset != 1/0: %d) clusters reachable %d\n", stream_id, ci, w, h, tree_count, tf.uses_wp, tf.max_prop, props_used, preds_used, leaves, nonunit, nreach);
     }
 #endif
     // properties 16 ..: four per earlier channel of the stream with this channel's size and shifts, nearest first (libjxl: PrecomputeReferences); properties
@@ -393,6 +402,9 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
     if (wide && tf.uses_wp && (!S.wide_wp || w > kWideMaxW)) return kErrUnsupportedTransform;
     props[0] = ci;
     const bool wide32 = S.st.wide32 != 0;
+#ifdef JXL_EMUL_TRACE
+    long trace_clu[256]; for (int i = 0; i < 256; i++) trace_clu[i] = 0;
+#endif
     bool wide_overflow = false;
     WPState wst;
     const WpRows WR = wp_rows(S, wide && tf.uses_wp, w);
@@ -445,6 +457,9 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
           nd = idx < S.tree_ncache ? &S.tree[idx] : &gtree[idx];
         }
         int64_t guess = predict_plain(nd->lchild, W, N, NW, NE, NN, WW, NEE, wp_pred);
+#ifdef JXL_EMUL_TRACE
+        trace_clu[ev.ctx_map[nd->splitval]]++;
+#endif
         uint32_t u = ev.lz77 ? ec_read_lz(ev, b, state, (uint32_t)nd->splitval, S.lz) : ec_read(ev, b, state, (uint32_t)nd->splitval);
         int64_t val = (int64_t)unpack_signed(u) * (int64_t)(uint32_t)nd->rchild + nd->offset + guess;
         row[x] = (int32_t)val;
@@ -452,6 +467,14 @@ JXL_DEV uint32_t modular_decode_channels(const DevECView &ev, DevBits &b, uint32
         if (tf.uses_wp) wp_update(WR, wst, val, x, y, w);
       }
     }
+#ifdef JXL_EMUL_TRACE
+    {                                     // samples per cluster of this channel: how many clusters carry 99 % / 99.9 % of them (what an LDS cache of hot clusters would have to hold)
+      long tot = 0; int used = 0; long v[256]; for (int i = 0; i < 256; i++) { v[i] = trace_clu[i]; tot += v[i]; used += v[i] != 0; }
+      for (int i = 0; i < 256; i++) for (int j = i + 1; j < 256; j++) if (v[j] > v[i]) { long t = v[i]; v[i] = v[j]; v[j] = t; }
+      long acc = 0; int n99 = 0, n999 = 0; for (int i = 0; i < 256 && tot; i++) { acc += v[i]; if (!n99 && acc * 100 >= tot * 99) n99 = i + 1; if (!n999 && acc * 1000 >= tot * 999) { n999 = i + 1; break; } }
+      fprintf(stderr, "  stream %d chan %d: %ld samples over %d clusters (log_alpha %d); 99 %% in %d, 99.9 %% in %d; top: %ld %ld %ld %ld\n", stream_id, ci, tot, used, ev.log_alpha, n99, n999, v[0], v[1], v[2], v[3]);
+    }
+#endif
     if (wide_overflow) return kErrUnsupportedTransform;
   }
   return 0;

@@ -21,9 +21,8 @@
 namespace jxlamd {
 
 // lane 0: flatten the tree reachable for (chan, stream) into ballot form
-__device__ __forceinline__ void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W) {
+__device__ __forceinline__ void wave_tree_build(const DevTreeNode *tree, int count, int chan, int stream, DevWaveTree &W, int32_t *stack_node, uint64_t *stack_n1, uint64_t *stack_n0) {
   W.ni = 0; W.nl = 0; W.ok = 1; W.uses_wp = 0;
-  int32_t *stack_node = W.stack_node; uint64_t *stack_n1 = W.stack_n1, *stack_n0 = W.stack_n0;
   int sp = 0;
   stack_node[0] = 0; stack_n1[0] = 0; stack_n0[0] = 0; sp = 1;
   int guard = 0;
@@ -467,11 +466,12 @@ __device__ __forceinline__ void wave_decode_channel(const DevECView &ev, DevBits
 // Same integer arithmetic as wave_decode_channel<true, true, true> (bit-exact).  Row 0 runs through the same step with constant records:
 // there every neighbour is the late value W and every previous-row error is 0, so sub-predictor k predicts W8 - ((tW * {0, p1, p2, 0}[k]) >> 5),
 // the clamp interval is [W8, W8] and the max-error property is tW — no generic loop (and none of its ~180 registers) in this path.
-struct DevWpFixedLds {                   // overlays DevWaveTree (dead once the channel's tree sits in registers)
-  int32_t U[32][8];                      // per sample of the chunk: q, |q|, tN, tN ^ tNW, max(N8, NE8), min(N8, NE8)
+struct alignas(16) DevWpFixedLds {       // overlays DevModScratch::wt, props, refp (the tree sits in registers by then; the other two serve other loops)
+  int32_t U[32][4];                      // per sample of the chunk: q, |q|, tN, tN ^ tNW
+  int32_t V[32][2];                      // ... max(N8, NE8), min(N8, NE8)
   int32_t K[32][4][4];                   // per sample and sub-predictor k: error-sum base, A_k, B_k
 };
-static_assert(sizeof(DevWpFixedLds) <= sizeof(DevWaveTree), "the chunk records live in the tree's LDS");
+static_assert(sizeof(DevWpFixedLds) <= offsetof(DevModScratch, fallback_err) - offsetof(DevModScratch, wt) && offsetof(DevModScratch, wt) % 16 == 0, "the chunk records live in the LDS of the tree, the property vector and the reference pointers");
 
 // lane l takes `keep` from lane l - 1 (wave_shr:1) / l - 4 within its row of 16 (row_shr:4); the lanes without a source take `fresh`
 __device__ __forceinline__ int shift_in_wave1(int fresh, int keep) { return __builtin_amdgcn_update_dpp(fresh, keep, 0x138, 0xF, 0xF, false); }
@@ -539,20 +539,30 @@ __device__ __forceinline__ int wave_alias_dsz(const DevAlias *galias, const CluS
   while (dsz <= mx) dsz <<= 1;
   return dsz > 128 ? 0 : dsz;
 }
-__device__ __forceinline__ int wave_packed_bytes(const CluSet &used, int log_alpha, int dsz) { return used.count() * ((4 << log_alpha) + 2 * dsz); }
+// Round 6: THREE bytes per alias entry instead of four — a cluster is [u16 x table: offsets1 | (cutoff & 15) << 12][u8 x table: right symbol | (cutoff >> 4) << log2(dsz)].
+// offsets1 < 4096 (a slot of the 4096), the right symbol < dsz, and the cutoff < bucket size = 4096 >> log_alpha takes 12 - log_alpha bits, of which the byte has
+// 8 - log2(dsz) to spare: log_alpha 8 / 7 / 6 / 5 with alphabets of at most 128 / 128 / 64 / 32 symbols (an alphabet never exceeds its table) always fit.  At log_alpha 8
+// (every LF stream of libjxl's streaming encoder, i.e. the bench's frames) a cluster is 768 + 128 bytes instead of 1 024 + 128: 21 clusters 18.4 KB instead of 23.6 KB —
+// LDS that every LF workgroup of the process holds for ~100 ms.
+__device__ __forceinline__ int wave_dsz_log2(int dsz) { return 31 - __builtin_clz((unsigned)dsz); }
+__device__ __forceinline__ int wave_packed_bytes(const CluSet &used, int log_alpha, int dsz) { return used.count() * ((3 << log_alpha) + 2 * dsz); }
 __device__ __forceinline__ bool wave_pack_alias(const DevAlias *galias, const CluSet &used, int log_alpha, int dsz, DevModScratch &S, int lane) {
   if (log_alpha < 5 || log_alpha > 8 || dsz <= 0 || wave_packed_bytes(used, log_alpha, dsz) > S.pool_bytes) return false;
-  const int table = 1 << log_alpha, nc = used.count();
+  const int table = 1 << log_alpha, nc = used.count(), rbits = wave_dsz_log2(dsz);
+  if (12 - log_alpha > 4 + 8 - rbits) return false;       // (cannot happen: see above)
   __syncthreads();
-  uint32_t *ent = (uint32_t *)S.pool;
-  uint16_t *D = (uint16_t *)((uint8_t *)S.pool + ((size_t)nc << (log_alpha + 2)));
+  uint8_t *base = (uint8_t *)S.pool;
+  uint16_t *D = (uint16_t *)(base + (size_t)nc * (size_t)(3 << log_alpha));
   int cid = 0;
   for (int k = 0; k < 4; k++)
     for (uint64_t m = used.w[k]; m; m &= m - 1, cid++) {
       const int s = 64 * k + __builtin_ctzll(m);
+      uint16_t *e16 = (uint16_t *)(base + (size_t)cid * (size_t)(3 << log_alpha));
+      uint8_t *e8 = (uint8_t *)(e16 + table);
       for (int i = lane; i < table; i += 64) {
         const DevAlias e = galias[(s << log_alpha) + i];
-        ent[(cid << log_alpha) + i] = (uint32_t)e.cutoff | ((uint32_t)e.right << 8) | ((uint32_t)e.off1 << 16);
+        e16[i] = (uint16_t)((uint32_t)e.off1 | (((uint32_t)e.cutoff & 15u) << 12));
+        e8[i] = (uint8_t)((uint32_t)e.right | (((uint32_t)e.cutoff >> 4) << rbits));
         if (i < dsz) D[cid * dsz + i] = e.freq0;
       }
       for (int i = table + lane; i < dsz; i += 64) D[cid * dsz + i] = 0;       // symbols beyond the table never occur
@@ -594,7 +604,7 @@ __device__ __forceinline__ uint32_t ring_read(uint32_t *ring, RingBits &r, int n
 }
 
 __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev, DevBits &b, uint32_t &state, const DevWP &wp, DevModScratch &S,
-                                                            const DevChanOut c, int lane, int my_split, int my_off, int my_doff, int my_cfg, int y_begin) {
+                                                            const DevChanOut c, int lane, int my_split, int my_off, int my_doff, int my_cfg, int y_begin, int rbits) {
   const int w = c.w, h = c.h;
   DevWpFixedLds &R = *(DevWpFixedLds *)&S.wt;
   const int k = lane & 3;
@@ -605,6 +615,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
   const uint32_t *wdiv = S.wdiv[k];
   const int la = ev.log_alpha, lb = 12 - la;
   const uint8_t *pool8 = (const uint8_t *)S.pool;          // packed alias entries + per-symbol frequencies (wave_pack_alias)
+  const uint32_t e8_base = 2u << la, rmask = (1u << rbits) - 1u;      // a cluster's byte array follows its 16-bit array
   for (int i = lane; i < 256; i += 64) S.wdiv[i >> 6][i & 63] = (uint32_t)wp.w[i >> 6] * S.divlut[i & 63];
   RingBits rb;
   ring_open(S.ring, rb, b, lane);
@@ -623,7 +634,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
       if (row0) {
         if (lane < n) {
           int4 u0; int2 u1; u0.x = 0; u0.y = 0; u0.z = 0; u0.w = 0; u1.x = (int)0x80000000; u1.y = 0x7fffffff;
-          *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.U[lane][4] = u1;
+          *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.V[lane][0] = u1;
           int4 z; z.x = 0; z.y = 0; z.z = 0; z.w = 0;
 #pragma unroll
           for (int kk = 0; kk < 4; kk++) *(int4 *)&R.K[lane][kk][0] = z;
@@ -639,7 +650,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         if (tabs<int32_t>(tNE) > tabs<int32_t>(q)) q = tNE;
         int4 u0; int2 u1;
         u0.x = q; u0.y = tabs<int32_t>(q); u0.z = tN; u0.w = tN ^ tNW; u1.x = N8 > NE8 ? N8 : NE8; u1.y = N8 < NE8 ? N8 : NE8;
-        *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.U[lane][4] = u1;
+        *(int4 *)&R.U[lane][0] = u0; *(int2 *)&R.V[lane][0] = u1;
         #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
           const uint32_t EN = S.wp_pred_err[kk][pos], ENE = has_r ? S.wp_pred_err[kk][pos + 1] : EN, ENW = has_l ? S.wp_pred_err[kk][pos - 1] : EN;
@@ -656,7 +667,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
       // ---- serial part.  The results leave through lane shift registers (one DPP move each per sample, no masked stores): after the
       // chunk lane l holds value and true error of sample n - 1 - l; lanes 0..15 hold the sub-predictor errors of the last four samples.
       int32_t keep_val = 0, keep_te = 0, keep_e = 0;
-      int4 u0 = *(const int4 *)&R.U[0][0]; int2 u1 = *(const int2 *)&R.U[0][4];
+      int4 u0 = *(const int4 *)&R.U[0][0]; int2 u1 = *(const int2 *)&R.V[0][0];
       int4 kr = *(const int4 *)&R.K[0][k][0];
       auto step = [&](const int i, auto last_tag) {
         constexpr bool kLastOfRow = decltype(last_tag)::value;
@@ -669,7 +680,8 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         const uint32_t doff = (uint32_t)__builtin_amdgcn_readlane(my_doff, cnt);      // ... and of its frequency table
         const uint32_t cfg = (uint32_t)__builtin_amdgcn_readlane(my_cfg, cnt);
         const uint32_t ai = __builtin_amdgcn_ubfe(state, lb, la);
-        const uint32_t ent = *(const uint32_t *)(pool8 + aoff + (ai << 2));           // LDS: cutoff | right << 8 | off1 << 16
+        const uint32_t e16 = *(const uint16_t *)(pool8 + aoff + (ai << 1));           // LDS: offsets1 | (cutoff & 15) << 12
+        const uint32_t e8 = *(const uint8_t *)(pool8 + aoff + e8_base + ai);          // LDS: right symbol | (cutoff >> 4) << rbits
         // weighted predictor, sub-predictor k per lane: error weight
         uint32_t e = (uint32_t)kr.x + e1 + e2;
         if (kLastOfRow) e += e1;              // no NE: the N error sum (which carries e1) counts twice
@@ -678,7 +690,7 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         const uint32_t wd = wdiv[e >> sh];                                            // LDS
         // records of the next sample: issued behind the two reads this sample waits for (LDS returns in order), used next step
         const int inext = i + 1 < 32 ? i + 1 : 31;
-        const int4 u0n = *(const int4 *)&R.U[inext][0]; const int2 u1n = *(const int2 *)&R.U[inext][4];
+        const int4 u0n = *(const int4 *)&R.U[inext][0]; const int2 u1n = *(const int2 *)&R.V[inext][0];
         const int4 krn = *(const int4 *)&R.K[inext][k][0];
         __builtin_amdgcn_sched_barrier(0);
         // ... prediction of sub-predictor k and the clamp bounds while the tables come in
@@ -695,9 +707,9 @@ __device__ __forceinline__ void wave_decode_channel_wpfixed(const DevECView &ev,
         const int32_t sum = quad_sum_i32(__mul24(wpk, (int32_t)wgt)) + (int32_t)(wsum2 >> 1) - 1;
         // rANS symbol + hybrid uint
         const uint32_t apos = state & ((1u << lb) - 1);
-        const bool right = apos >= (ent & 0xff);
-        uint32_t u = right ? (ent >> 8) & 0xff : ai;
-        const uint32_t off = right ? (ent >> 16) + apos : apos;
+        const bool right = apos >= ((e16 >> 12) | ((e8 >> rbits) << 4));
+        uint32_t u = right ? e8 & rmask : ai;
+        const uint32_t off = right ? (e16 & 4095u) + apos : apos;
         const uint32_t freq = *(const uint16_t *)(pool8 + doff + (u << 1));           // LDS, dependent: the symbol's frequency
         state = __umul24(freq, state >> 12) + off;                                    // freq <= 4096, state >> 12 < 2^20
         if (__ballot(state < (1u << 16))) state = (state << 16) | ring_read(S.ring, rb, 16, lane);
@@ -894,15 +906,15 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
     const DevChanOut c = chans[ci];
     if (c.w == 0 || c.h == 0) continue;
     __syncthreads();
-    if (lane == 0) wave_tree_build(gtree, tree_count, ci, stream_id, WT);
+    if (lane == 0) wave_tree_build(gtree, tree_count, ci, stream_id, WT, mod_stack_node(S), mod_stack_n1(S), mod_stack_n0(S));
     __syncthreads();
     if (!WT.ok) {
       if (!kBig || !kGeneral) return kErrWaveFallback;      // caller re-runs the stream with the serial walker
       const int at = (S.pool_used + 15) & ~15;              // the head of the tree cached there serves only the serial walker (which stages the stream again)
       uint32_t *big = (uint32_t *)((uint8_t *)S.pool + at);
       if (lane == 0) {
-        const BigCount cnt = big_tree_count(gtree, tree_count, ci, stream_id, WT.stack_node);
-        (void)big_tree_build(gtree, tree_count, ci, stream_id, S.st.ev.ctx_map, cnt, WT.stack_node, WT.stack_n1, WT.stack_n0, big, S.pool_bytes - at);
+        const BigCount cnt = big_tree_count(gtree, tree_count, ci, stream_id, mod_stack_node(S));
+        (void)big_tree_build(gtree, tree_count, ci, stream_id, S.st.ev.ctx_map, cnt, mod_stack_node(S), mod_stack_n1(S), mod_stack_n0(S), big, S.pool_bytes - at);
       }
       __syncthreads();
       const DevBigHdr *BH = (const DevBigHdr *)big;
@@ -968,13 +980,13 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
         const int leaf = lm ? __builtin_ctzll(lm) : 0;
         const int clu = __builtin_amdgcn_readlane(my_lclu, leaf);
         const int cid = used.rank(clu);      // compact index of the cluster in the packed pool
-        if (lane == cc) { my_off = cid << (la_p + 2); my_doff = (used.count() << (la_p + 2)) + cid * 2 * dsz; my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
+        if (lane == cc) { my_off = cid * (3 << la_p); my_doff = used.count() * (3 << la_p) + cid * 2 * dsz; my_cfg = (int)S.st.ev.cfg[clu]; }      // the stream's own config table (S.cfg may hold a compact renumbering)
       }
       __syncthreads();
       // once the pool holds packed tables the other loops of this stream read their tables through L2 (or restage them compactly)
       if (wave_pack_alias(evg.alias, used, la_p, dsz, S, lane)) {   // per channel: the set of clusters may differ
         pool_packed = true;                            // the pool no longer holds the stream's 8-byte tables / context map
-        wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/0);
+        wave_decode_channel_wpfixed(ev, b, state, wp, S, c, lane, my_split, my_off, my_doff, my_cfg, /*y_begin=*/0, wave_dsz_log2(dsz));
         continue;
       }
       // symbols >= 128 in an LF stream (not produced by libjxl): the pool is untouched, the general loops below take the channel

@@ -8,6 +8,7 @@
 // the test suite can drive the identical code from a CPU loop (tests/emul, test-only).
 #pragma once
 #include <math.h>
+#include <string.h>
 #include "dev_vardct.h"
 
 namespace jxlamd {
@@ -315,13 +316,17 @@ JXL_DEV void gab_pixel(const DevFrame &F, float *const src[3], float *const dst[
 // SSE2-only x86_64 build the host CPU's 12-bit rcpps, biased low by up to 3e-4 relative — invisible in most pixels, up to 4 codes where the inverse opsin matrix
 // amplifies it (one channel near 0 beside two near 1 on hard edges).  Default: the exact quotient.  epf_rcp_x86: the golden host's instruction as a table
 // (rcp12_lut.h: a function of the operand's top 11 mantissa bits, scaled exactly by its exponent), for "what that reference build returned" bit for bit.
-JXL_DEV float epf_reciprocal(const DevBuffers &B, const DevFrame &F, float wsum) {
-  if (!F.epf_rcp_x86) return 1.0f / wsum;
+JXL_DEV float rcp12_lookup(const uint16_t *lut, float wsum) {
   uint32_t u; memcpy(&u, &wsum, 4);                     // wsum is in [1, 13]: a normal positive number
-  const uint16_t *lut = (const uint16_t *)(B.stat + ((const DevStatic *)B.stat)->rcp12_off);
   uint32_t r = 0x3f000000u + ((uint32_t)lut[(u >> 12) & 2047u] << 11) - (((u >> 23) - 127u) << 23);
   float inv; memcpy(&inv, &r, 4);
   return inv;
+}
+// the table when the frame asks for it, else null (the column sweep resolves this once per launch)
+JXL_DEV const uint16_t *epf_rcp_table(const DevFrame &F, const uint8_t *stat) { return F.epf_rcp_x86 ? (const uint16_t *)(stat + ((const DevStatic *)stat)->rcp12_off) : nullptr; }
+JXL_DEV float epf_reciprocal(const DevBuffers &B, const DevFrame &F, float wsum) {
+  if (!F.epf_rcp_x86) return 1.0f / wsum;
+  return rcp12_lookup(epf_rcp_table(F, B.stat), wsum);
 }
 
 JXL_DEV float epf_inv_sigma(const DevBuffers &B, const DevFrame &F, int x, int y) {

@@ -123,6 +123,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   const bool lane_border = (ex & 7) == 0 || (ex & 7) == 7;
   const float *src[3] = {B.plane_a[0] + ex, B.plane_a[1] + ex, B.plane_a[2] + ex};
   const DevStatic &ST = *(const DevStatic *)stat;
+  const uint16_t *rcp_lut = epf_rcp_table(F, stat);              // null: the EPF normalises with the exact quotient (wave-uniform)
   float gn[3], g1[3], g2[3], cs[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
@@ -195,7 +196,8 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
       const float isig = is1 * (border ? sm1b : sm1);
       float wu = 1.0f + sad_up_e * isig, wl = 1.0f + sad_lf * isig, wr = 1.0f + sad_rt * isig, wd = 1.0f + sad_dn * isig;
       wu = wu < 0.0f ? 0.0f : wu; wl = wl < 0.0f ? 0.0f : wl; wr = wr < 0.0f ? 0.0f : wr; wd = wd < 0.0f ? 0.0f : wd;
-      const float inv = 1.0f / (1.0f + wu + wl + wr + wd);
+      const float wsum = 1.0f + wu + wl + wr + wd;
+      const float inv = rcp_lut ? rcp12_lookup(rcp_lut, wsum) : 1.0f / wsum;       // (uniform; jxlamd_decoder_set_epf_reciprocal)
       const bool skip = is1 < -3.90524291751269967465540850526868f;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -224,7 +226,8 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
       }
       float wu = 1.0f + su * isig, wl = 1.0f + sl * isig, wr = 1.0f + sr * isig, wd = 1.0f + sd * isig;
       wu = wu < 0.0f ? 0.0f : wu; wl = wl < 0.0f ? 0.0f : wl; wr = wr < 0.0f ? 0.0f : wr; wd = wd < 0.0f ? 0.0f : wd;
-      const float inv = 1.0f / (1.0f + wu + wl + wr + wd);
+      const float wsum = 1.0f + wu + wl + wr + wd;
+      const float inv = rcp_lut ? rcp12_lookup(rcp_lut, wsum) : 1.0f / wsum;       // (uniform; jxlamd_decoder_set_epf_reciprocal)
       const bool skip = is2 < -3.90524291751269967465540850526868f;
 #pragma unroll
       for (int c = 0; c < 3; c++) {

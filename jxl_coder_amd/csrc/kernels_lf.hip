@@ -19,7 +19,7 @@ int lf_pool_clamp(uint32_t wanted) {        // the pool the next launch gets for
 #ifdef JXL_LF_POOL_FORCE
   wanted = JXL_LF_POOL_FORCE;               // experiment builds (tools/build_variant.sh)
 #endif
-  const int w = (int)((wanted + 2047u) & ~2047u);
+  const int w = (int)((wanted + 511u) & ~511u);          // (round 6: steps of 512 bytes, not 2 048 — every LF workgroup of the process carries the rounding)
   return w < kModPoolMin ? kModPoolMin : w > kModPoolBytes ? kModPoolBytes : w;
 }
 void launch_lf_groups(const DevBuffers &B, const DevAux &A, int n, int pool_bytes, bool general, hipStream_t s) {

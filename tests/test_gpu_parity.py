@@ -523,7 +523,7 @@ def test_flight_subflights_and_pools_in_a_small_configuration():
 def test_flight_that_misses_the_lf_table_pool_on_used_slots_is_repeated():
     """A flight whose LF stage stops for a larger LDS table pool (kErrNeedPool) leaves its frames' later stages to decode whatever the slots held before: on a USED
     context those flag 'corrupt' — flags of an attempt that is going to be repeated, which must not fail the flight (round 5: `bench.py --workload mixed` died on this once
-    its timing changed).  JXLAMD_LF_POOL_FORGET makes every flight start from the smallest pool again: 4K bench frames (24.5 KB of packed tables) between flights of other
+    its timing changed).  JXLAMD_LF_POOL_FORGET makes every flight start from the smallest pool again: 4K bench frames (13 - 16 KB of packed tables) between flights of other
     frames; every flight equals the single decodes, and the second and third flights were repeated."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -532,7 +532,7 @@ def test_flight_that_misses_the_lf_table_pool_on_used_slots_is_repeated():
         from conftest import load_case
         import jxl_coder_amd as J
         dec = J.JxlDecoder(0)
-        big = [open(os.path.join(%r, "bench_data", "syn4k_q90_seed%%d.jxl" %% i), "rb").read() for i in range(4)]
+        big = [open(os.path.join(%r, "bench_data", "syn4k_q90_seed%%d.jxl" %% i), "rb").read() for i in (3, 4, 6, 7)]      # 18 / 15 / 17 / 15 clusters per LF channel: 13.4 - 16.1 KB of packed tables (round 6: 896 bytes per cluster), above the smallest pool (12 KB)
         small = [load_case(n)[0] for n in ["va300x520_e7", "v264x520_e7", "asset_first_jxl", "v300x300_e7_d3"]]
         sets = [big[:2] + small[:2], small + big[2:], big[1:3] + small[1:3]]
         ref = J.JxlDecoder(0)
