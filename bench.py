@@ -629,6 +629,11 @@ def main():
         }
         line["cpu_baseline"] = ({"value": None, "unit": "MP/s", "cores": 0, "kind": "reference", "sample": "skipped"}
                                 if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, c5=c5))
+        # BASELINE configs[1] (one frame, latency) stated, not left to divide: this decoder's single-frame rate over the reference's libjxl decoding the same
+        # frame with its thread pool on this box's host cores.  Below 1: a lone frame is bounded by ONE LfGroup stream — 196 608 samples walked by one lane at ~1 100 shader
+        # clocks each (k_lf_group_general, ~90 ms of the ~112) — where a host core takes a few tens of cycles per sample; the GPU wins on batches, not on a lone frame.
+        thr = line["cpu_baseline"].get("single_frame_threaded_MPps")
+        line["config"]["single_frame_vs_cpu_threaded"] = round(line["config"]["single_frame_MPps"] / thr, 3) if thr else None
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

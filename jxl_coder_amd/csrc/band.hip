@@ -241,10 +241,14 @@ int jxlamd_decode_sharded_local(jxlamd_decoder *const *decs, int nbands, const u
                                 jxlamd_info *info) {
   if (!decs || nbands < 1 || !jxl || !outs || !caps) { tls_error() = "decode_sharded_local: bad arguments"; return JXLAMD_ERR_BUFFER; }
   for (int b = 0; b < nbands; b++) if (!decs[b]) { tls_error() = "null decoder"; return JXLAMD_ERR_DEVICE; }
+  // the halo buffers below are allocated by THIS thread and handed between the contexts' streams: one device for all bands, and this thread on it (on a
+  // non-default GPU they landed on device 0 and every export / import became a cross-device copy)
+  for (int b = 1; b < nbands; b++) if (decs[b]->device != decs[0]->device) { tls_error() = "decode_sharded_local: the bands' decoder contexts must be on one device"; return JXLAMD_ERR_DEVICE; }
+  if (hipSetDevice(decs[0]->device) != hipSuccess) { tls_error() = "decode_sharded_local: cannot select the decoders' device"; return JXLAMD_ERR_DEVICE; }
   jxlamd_info bi;
   int rc = jxlamd_basic_info(jxl, size, &bi);
   if (rc) return rc;
-  const int ygroups = (int)((bi.ysize + 255) / 256);
+  const int ygroups = (int)((bi.ysize + 255) / 256);      // (oriented height: a frame with orientation > 4 is refused by jxlamd_band_begin before its rows are looked at)
   std::vector<int> rows((size_t)nbands * 2);
   if ((rc = jxlamd_band_rows(ygroups, nbands, rows.data()))) return rc;
   const uint32_t fl = (flags & ~(uint32_t)JXLAMD_BAND_SHARED_GPU) | (nbands > 1 ? JXLAMD_BAND_SHARED_GPU : 0u);

@@ -26,8 +26,7 @@ JXL_DEV void mod_to_planes_pixel(const DevBuffers &B, const DevFrame &F, int x, 
     B.plane_a[1][po] = (float)vy * F.mod_xyb_fac[1];
     B.plane_a[2][po] = (float)(vb + vy) * F.mod_xyb_fac[2];
   } else {
-    const float sc = 1.0f / (float)(((uint64_t)1 << F.mod_bits) - 1);      // (64-bit: a float image declares 32 bits)
-    for (int c = 0; c < 3; c++) { const int32_t v = mod_plane(B, F, F.mod_out[c])[si]; B.plane_a[c][po] = F.mod_exp_bits ? sample_bits_to_float(v, F.mod_bits, F.mod_exp_bits) : (float)v * sc; }
+    for (int c = 0; c < 3; c++) { const int32_t v = mod_plane(B, F, F.mod_out[c])[si]; B.plane_a[c][po] = F.mod_exp_bits ? sample_bits_to_float(v, F.mod_bits, F.mod_exp_bits) : int_sample_to_unit(v, F.mod_bits); }
   }
 }
 

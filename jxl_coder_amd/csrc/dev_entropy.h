@@ -22,6 +22,12 @@ namespace jxlamd {
 
 // A Modular sample of a channel declared as floating point (bits total, exp_bits of exponent: float32 = 32 / 8, float16 = 16 / 5, ...): the integer IS the
 // float's bit pattern; narrower formats are widened to float32 (subnormals normalised) — libjxl's int_to_float.
+// integer sample of `bits` bits -> [0, 1].  libjxl multiplies by a float factor up to 22 bits and, from 23 bits on, by a DOUBLE factor before rounding to float (its
+// "accurate" conversion: a 24-bit sample times a float factor would lose the last bit) — restated so that 17 .. 24-bit images come out bit for bit (round 6)
+JXL_DEV float int_sample_to_unit(int32_t v, int bits) {
+  if (bits < 23) return (float)v * (1.0f / (float)(((uint64_t)1 << bits) - 1));
+  return (float)((double)v * (1.0 / (double)(((uint64_t)1 << bits) - 1)));
+}
 JXL_DEV float sample_bits_to_float(int32_t v, int bits, int exp_bits) {
   uint32_t f = (uint32_t)v;
   if (bits != 32) {

@@ -380,14 +380,13 @@ JXL_DEV void mod_write_pixel(const DevBuffers &B, int out_bits, int x, int y) {
   const DevFrame &F = frame_of(B);
   const int w = F.width, h = F.height;
   const size_t si = (size_t)y * (size_t)w + (size_t)x;
-  const float sc = 1.0f / (float)(((uint64_t)1 << F.mod_bits) - 1);      // (64-bit: a float image declares 32 bits)
   const float maxv = out_bits == 16 ? 65535.0f : 255.0f;
   uint32_t px[4];
   for (int c = 0; c < 4; c++) {
     float t;
     if (F.mod_out[c] < 0) t = 1.0f;
     else if (c == 3) t = alpha_sample_value(F, mod_plane(B, F, F.mod_out[c])[si], false);
-    else t = F.mod_exp_bits ? sample_bits_to_float(mod_plane(B, F, F.mod_out[c])[si], F.mod_bits, F.mod_exp_bits) : (float)mod_plane(B, F, F.mod_out[c])[si] * sc;
+    else t = F.mod_exp_bits ? sample_bits_to_float(mod_plane(B, F, F.mod_out[c])[si], F.mod_bits, F.mod_exp_bits) : int_sample_to_unit(mod_plane(B, F, F.mod_out[c])[si], F.mod_bits);
     if (!(t == t)) t = 0.0f;                           // (a float sample can be a NaN)
     t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
     px[c] = (uint32_t)(int)rintf(t * maxv);

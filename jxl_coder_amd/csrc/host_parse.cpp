@@ -141,7 +141,7 @@ static int parse_splines(FramePlan *plan, hx_br *sb, uint64_t num_pixels, std::v
   const char *err = nullptr;
   const uint64_t max_cp = std::min<uint64_t>(1u << 20, num_pixels / 2);
   const uint64_t num = (uint64_t)hx_ec_read(&ec, sb, 2) + 1;
-  if (num > max_cp + 1) err = "splines: too many splines";
+  if (num > max_cp) err = "splines: too many splines";      // (libjxl: num_splines > max_control_points fails — ADVICE r5: one more was accepted here)
   std::vector<QSpline> q;
   if (!err) q.resize((size_t)num);
   int64_t lx = 0, ly = 0;
@@ -162,8 +162,8 @@ static int parse_splines(FramePlan *plan, hx_br *sb, uint64_t num_pixels, std::v
       p.first = hx_unpack_signed(hx_ec_read(&ec, sb, 4)); p.second = hx_unpack_signed(hx_ec_read(&ec, sb, 4));
       if (std::llabs(p.first) >= (1 << 30) || std::llabs(p.second) >= (1 << 30)) { err = "splines: control point delta out of range"; break; }
     }
-    for (int c = 0; c < 3 && !err; c++) for (int k = 0; k < 32; k++) q[i].color[c][k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5));
-    for (int k = 0; k < 32 && !err; k++) q[i].sigma[k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5));
+    for (int c = 0; c < 3 && !err; c++) for (int k = 0; k < 32; k++) { q[i].color[c][k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5)); if (q[i].color[c][k] == INT32_MIN) err = "splines: DCT coefficient out of range"; }
+    for (int k = 0; k < 32 && !err; k++) { q[i].sigma[k] = hx_unpack_signed(hx_ec_read(&ec, sb, 5)); if (q[i].sigma[k] == INT32_MIN) err = "splines: DCT coefficient out of range"; }      // (libjxl refuses INT_MIN: its magnitude does not exist)
     if (sb->err) { err = "truncated splines"; break; }
   }
   const int ok = hx_ec_final_ok(&ec);
@@ -184,13 +184,22 @@ static int build_splines(FramePlan *plan, Blob &blob, DevFrame &F, const std::ve
   const float inv_quant = quant_adjust >= 0 ? 1.0f / (1.0f + 0.125f * (float)quant_adjust) : 1.0f - 0.125f * (float)quant_adjust;
   std::vector<DevSplineSeg> segs;
   std::vector<std::pair<int32_t, uint32_t>> by_y;
+  // libjxl's complexity limits (QuantizedSpline::Dequantize): a spline's control polygon may not be longer (Manhattan) than area_limit, and the sum over the
+  // splines of [estimated width x that length] may not exceed it either — a few hundred bytes of a crafted file could otherwise ask for 2^25 row entries x the image width
+  // of work in k_splines.  The estimate is libjxl's: per sigma coefficient ceil(inv_quant |q|) clamped to [1, weight_limit], squared, times log2 of the largest colour sum.
+  const uint64_t image_size = (uint64_t)width * (uint64_t)height;
+  const uint64_t area_limit = std::min<uint64_t>(1024ull * image_size + (1ull << 32), 1ull << 42);
+  uint64_t total_estimated_area = 0;
   for (const QSpline &q : qs) {
     // control points: the starting point, then running sums of running sums of the coded deltas
     std::vector<SPoint> cp;
     cp.push_back({q.sx, q.sy});
     int64_t cx = (int64_t)llroundf(q.sx), cy = (int64_t)llroundf(q.sy), dx = 0, dy = 0;
+    uint64_t manhattan = 0;
     for (const auto &p : q.cp) {
       dx += p.first; dy += p.second; cx += dx; cy += dy;
+      manhattan += (uint64_t)std::llabs(dx) + (uint64_t)std::llabs(dy);
+      if (manhattan > area_limit) { plan->error = "splines: control polygon beyond the area limit"; return -1; }
       if (std::llabs(cx) >= (1ll << 30) || std::llabs(cy) >= (1ll << 30) || std::llabs(dx) >= (1ll << 30) || std::llabs(dy) >= (1ll << 30)) { plan->error = "splines: control point out of range"; return -1; }
       cp.push_back({(float)cx, (float)cy});
     }
@@ -198,6 +207,22 @@ static int build_splines(FramePlan *plan, Blob &blob, DevFrame &F, const std::ve
     for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) cdct[c][i] = (float)q.color[c][i] * (i == 0 ? 0.70710678118f : 1.0f) * kChannelWeight[c] * inv_quant;
     for (int i = 0; i < 32; i++) { cdct[0][i] += y_to_x * cdct[1][i]; cdct[2][i] += y_to_b * cdct[1][i]; }
     for (int i = 0; i < 32; i++) sdct[i] = (float)q.sigma[i] * (i == 0 ? 0.70710678118f : 1.0f) * kChannelWeight[3] * inv_quant;
+    {
+      uint64_t col[3] = {0, 0, 0};
+      for (int c = 0; c < 3; c++) for (int i = 0; i < 32; i++) col[c] += (uint64_t)ceilf(inv_quant * fabsf((float)q.color[c][i]));
+      col[0] += (uint64_t)ceilf(fabsf(y_to_x)) * col[1]; col[2] += (uint64_t)ceilf(fabsf(y_to_b)) * col[1];
+      const uint64_t max_col = std::max(col[1], std::max(col[0], col[2]));
+      uint64_t logcolor = 1; while (logcolor < 64 && (1ull << logcolor) < 1ull + max_col) logcolor++;           // max(1, ceil(log2(1 + max colour sum)))
+      const float weight_limit = ceilf(sqrtf(((float)area_limit / (float)logcolor) / (float)std::max<uint64_t>(1, manhattan)));
+      uint64_t width_estimate = 0;
+      for (int i = 0; i < 32; i++) {
+        const float wf = ceilf(inv_quant * fabsf((float)q.sigma[i]));
+        const uint64_t wgt = (uint64_t)std::min(weight_limit, std::max(1.0f, wf));
+        width_estimate += wgt * wgt * logcolor;
+      }
+      total_estimated_area += width_estimate * manhattan;
+      if (total_estimated_area > area_limit) { plan->error = "splines: estimated area beyond the limit"; return -1; }
+    }
     // centripetal Catmull-Rom through the control points, 16 intermediate points per span
     std::vector<SPoint> pts;
     if (cp.size() == 1) pts.push_back(cp[0]);
@@ -338,6 +363,9 @@ static int parse_patches(FramePlan *plan, Priv *pv, hx_br *sb, Blob &blob) {
     std::vector<size_t> ordered;
     for (size_t i = 0; i < out.size(); i++) if (out[i].mode != 2) ordered.push_back(i);
     if (ordered.size() > 4096) { plan->error = "unsupported: patch dictionary with more than 4096 replace / multiply placements"; return -1; }
+    // the check below is ordered x all rectangle tests on the parse thread: bounded at 4096 x 65536 (a fraction of a second) — an untrusted file with millions of
+    // placements beside one replacing placement is refused here instead of costing tens of seconds
+    if (!ordered.empty() && out.size() > 65536) { plan->error = "unsupported: patch dictionary with replace / multiply placements among more than 65536 placements"; return -1; }
     for (size_t a : ordered)
       for (size_t b = 0; b < out.size(); b++) {
         if (b == a) continue;
@@ -452,7 +480,10 @@ static int parse_modular_global(FramePlan *plan, Priv *pv, hx_br *sb, bool vardc
   F.mod_bits = (int)m.pub.bits_per_sample;
   // float samples: the integer planes hold the floats' bit patterns (dev_entropy.h: sample_bits_to_float); an XYB Modular frame's samples are quantised XYB whatever the image declares
   F.mod_exp_bits = (vardct || m.pub.xyb_encoded) ? 0 : (int)m.pub.exp_bits;
-  if (F.mod_exp_bits ? (F.mod_bits > 32 || F.mod_exp_bits > 8 || F.mod_bits - F.mod_exp_bits - 1 < 1 || F.mod_bits - F.mod_exp_bits - 1 > 23) : (F.mod_bits > 16 && !vardct && !m.pub.xyb_encoded)) { plan->error = "unsupported: integer samples of more than 16 bits / float format in Modular frames"; return -1; }
+  if (F.mod_exp_bits ? (F.mod_bits > 32 || F.mod_exp_bits > 8 || F.mod_bits - F.mod_exp_bits - 1 < 1 || F.mod_bits - F.mod_exp_bits - 1 > 23) : (F.mod_bits > 24 && !vardct && !m.pub.xyb_encoded)) { plan->error = "unsupported: integer samples of more than 24 bits / float format in Modular frames"; return -1; }
+  // (round 6: integer samples of 17 .. 24 bits — what libjxl's encoder writes at most, from 24-bit PNM / PNG-16 + padding sources: the planes are int32 like libjxl's, the
+  // decode loops of images without modular_16bit_buffers run on 64-bit neighbourhoods, and RCT / palette / squeeze sums of 24-bit samples stay inside 32 bits; 25 .. 31 bits
+  // would need the inverse transforms' intermediate sums audited against libjxl's 64-bit-then-truncate arithmetic)
   const int ncol = vardct ? 0 : (m.pub.num_color_channels == 1 && !m.pub.xyb_encoded) ? 1 : 3;
   struct Ch { int w, h, hs, vs, plane; };
   std::vector<Ch> L;

@@ -78,7 +78,7 @@ def decode(data: bytes, threads=0, allow16=True, mode=0):
 
 
 def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_speed=0, gaborish=-1, epf=-1,
-           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1, custom_xy=None, extra_channel=None, premultiplied=False):
+           primaries=0, transfer=0, intensity_target=0.0, modular=-1, threads=0, extra=(), icc=None, orientation=1, custom_xy=None, extra_channel=None, premultiplied=False, int_bits=0):
     """pixels: [h,w,c] u8 or u16 — or float32 / float16: a floating-point image (32 bits / 8 exponent bits, 16 / 5), nominal range 0..1 —, c in 1,2,3,4
     (2: grey + alpha). Same sequence as the reference's EncodeJxlOneshot.
     extra_channel: (plane [h,w] u8, JxlExtraChannelType) — one more extra channel behind the alpha (1 depth, 2 spot colour, 3 selection mask, 4 black, ...)."""
@@ -104,8 +104,10 @@ def encode(pixels: np.ndarray, lossless=False, distance=1.0, effort=7, decoding_
     lib().ref_set_extra_channel(C.c_void_p(_ecp.ctypes.data) if _ecp is not None else None, int(extra_channel[1]) if extra_channel is not None else 0)
     lib().ref_set_premultiplied(int(premultiplied))          # the alpha is declared premultiplied (pixels taken as they are)
     lib().ref_set_float(1 if pixels.dtype == np.float32 else 2 if pixels.dtype == np.float16 else 0)
+    lib().ref_set_int_bits(int(int_bits))      # float32 pixels of an INTEGER image of int_bits bits (17 .. 31): values k / (2^bits - 1)
     rc = lib().ref_encode(pixels.ctypes.data, pixels.nbytes, C.byref(p), C.byref(out), C.byref(n))
     lib().ref_set_float(0)
+    lib().ref_set_int_bits(0)
     lib().ref_set_premultiplied(0)
     lib().ref_set_extra_channel(None, 0)
     lib().ref_set_icc(b"", 0)

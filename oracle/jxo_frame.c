@@ -451,15 +451,18 @@ static int special_quant_weights(int t, const float idw[3][3], const float d2[3]
 /* reads the parameters of encoding mode 1 - 5 for table t and computes the weights; -1: wrong table for the mode or parameters out of range, -2: truncated */
 #define QP_READ_DCT(q) do { (q).nb = (int)jxo_bits(br, 4) + 1; for (int c = 0; c < 3; c++) { for (int i = 0; i < (q).nb; i++) (q).b[c][i] = jxo_f16(br); if ((q).b[c][0] < 1e-8) return -1; (q).b[c][0] *= 64.0; } } while (0)
 static int read_special_quant_weights(jxo_br *br, int t, int mode, float *w[3]) {
+  /* modes 1 - 5 need a table of one 8 x 8 block (tables 0, 1, 2, 3, 9, 10); the weights follow from the mode, whichever of those tables they are stored for */
+  if (!(t == 0 || t == 1 || t == 2 || t == 3 || t == 9 || t == 10)) return -1;
   float idw[3][3] = {{0}}, d2[3][6] = {{0}}, mul4[3][2] = {{1, 1}, {1, 1}, {1, 1}}, mul48[3] = {1, 1, 1}, afv[3][9] = {{0}};
   qparams p4, p48; p4.nb = p48.nb = 1;
-  if (mode == 1) { if (t != 1) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) { idw[c][i] = jxo_f16(br); if (idw[c][i] < 1e-8f) return -1; idw[c][i] *= 64.0f; } }
-  else if (mode == 2) { if (t != 2) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) { d2[c][i] = jxo_f16(br); if (d2[c][i] < 1e-8f) return -1; d2[c][i] *= 64.0f; } }
-  else if (mode == 3) { if (t != 3) return -1; for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) { mul4[c][i] = jxo_f16(br); if (mul4[c][i] < 1e-8f) return -1; } QP_READ_DCT(p4); }
-  else if (mode == 4) { if (t != 9) return -1; for (int c = 0; c < 3; c++) { mul48[c] = jxo_f16(br); if (mul48[c] < 1e-8f) return -1; } QP_READ_DCT(p48); }
-  else if (mode == 5) { if (t != 10) return -1; for (int c = 0; c < 3; c++) { for (int i = 0; i < 9; i++) afv[c][i] = jxo_f16(br); for (int i = 0; i < 6; i++) afv[c][i] *= 64.0f; } QP_READ_DCT(p48); QP_READ_DCT(p4); }
+  int form;
+  if (mode == 1) { form = 1; for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) { idw[c][i] = jxo_f16(br); if (idw[c][i] < 1e-8f) return -1; idw[c][i] *= 64.0f; } }
+  else if (mode == 2) { form = 2; for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) { d2[c][i] = jxo_f16(br); if (d2[c][i] < 1e-8f) return -1; d2[c][i] *= 64.0f; } }
+  else if (mode == 3) { form = 3; for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) { mul4[c][i] = jxo_f16(br); if (mul4[c][i] < 1e-8f) return -1; } QP_READ_DCT(p4); }
+  else if (mode == 4) { form = 9; for (int c = 0; c < 3; c++) { mul48[c] = jxo_f16(br); if (mul48[c] < 1e-8f) return -1; } QP_READ_DCT(p48); }
+  else if (mode == 5) { form = 10; for (int c = 0; c < 3; c++) { for (int i = 0; i < 9; i++) afv[c][i] = jxo_f16(br); for (int i = 0; i < 6; i++) afv[c][i] *= 64.0f; } QP_READ_DCT(p48); QP_READ_DCT(p4); }
   else return -1;
-  return special_quant_weights(t, idw, d2, &p4, mul4, &p48, mul48, afv, w);
+  return special_quant_weights(form, idw, d2, &p4, mul4, &p48, mul48, afv, w);
 }
 #undef QP_READ_DCT
 
@@ -1709,8 +1712,9 @@ int jxo_decode(const uint8_t *data, size_t size, int out_bits, uint8_t **out, si
       } else {
         if (m.pub.exp_bits) for (size_t i = 0; i < npx; i++) rgb[c][i] = sample_bits_to_float(ch->d[i], (int)m.pub.bits_per_sample, (int)m.pub.exp_bits);
         else {
-          float sc = 1.0f / (float)(((uint64_t)1 << m.pub.bits_per_sample) - 1);
-          for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)ch->d[i] * sc;
+          /* libjxl: a float factor up to 22 bits, from 23 bits on a DOUBLE factor before the result is rounded to float (a 24-bit sample times a float factor loses its last bit) */
+          if (m.pub.bits_per_sample < 23) { float sc = 1.0f / (float)(((uint64_t)1 << m.pub.bits_per_sample) - 1); for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)ch->d[i] * sc; }
+          else { double sc = 1.0 / (double)(((uint64_t)1 << m.pub.bits_per_sample) - 1); for (size_t i = 0; i < npx; i++) rgb[c][i] = (float)((double)ch->d[i] * sc); }
         }
       }
     }

@@ -187,6 +187,8 @@ void ref_set_orientation(int o) { g_orientation = o; }
 /* float samples for the next ref_encode: 1 = float32 (32 bits, 8 exponent bits; float32 buffer), 2 = float16 (16 / 5; float16 buffer) */
 static int g_float = 0;
 void ref_set_float(int mode) { g_float = mode; }
+static int g_int_bits = 0;      /* > 0 with ref_set_float(1): the float32 pixel buffer is an INTEGER image of that many bits (17 .. 31; what cjxl makes of 24- / 32-bit PNM sources) */
+void ref_set_int_bits(int bits) { g_int_bits = bits; }
 /* the alpha of the next encodes is declared premultiplied (the pixels are taken as they are) */
 static int g_premultiplied = 0;
 void ref_set_premultiplied(int on) { g_premultiplied = on; }
@@ -217,6 +219,7 @@ int ref_encode(const void *pixels, size_t pixels_size, const RefEncParams *p, ui
   p_JxlEncoderInitBasicInfo(&bi);
   bi.xsize = p->xsize; bi.ysize = p->ysize; bi.bits_per_sample = p->bits;
   if (g_float) { bi.bits_per_sample = g_float == 2 ? 16 : 32; bi.exponent_bits_per_sample = g_float == 2 ? 5 : 8; }      /* float samples: the pixel buffer holds float32 */
+  if (g_float == 1 && g_int_bits > 0) { bi.bits_per_sample = (uint32_t)g_int_bits; bi.exponent_bits_per_sample = 0; }
   bi.uses_original_profile = p->lossless ? JXL_TRUE : JXL_FALSE;
   const int has_alpha = p->num_channels == 2 || p->num_channels == 4;       /* 2: grey + alpha */
   bi.num_color_channels = p->num_channels <= 2 ? 1 : 3;

@@ -91,7 +91,7 @@ NONPHOTO_LOSSLESS_CASES = ["ls400x300_e1", "ls400x300_e3", "lsa400x300_e3", "ls7
                            "lpl400x300_e7_nopatch", "lpl200x136_e7_photo",      # libjxl's lossy palette: explicit + implicit delta entries over the Average4 predictor
                            "lra400x300_e7",
                            "lpc200x136_e7_prev3", "lpca300x200_e9_prev11", "lpcr200x136_e7_prev3",
-                           "lra2100x130_e3", "lpm400x300_e7_premultiplied", "lf16_300x200_e7_hdr", "lf16a300x200_e3", "lf32_200x136_e7", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
+                           "lra2100x130_e3", "lpm400x300_e7_premultiplied", "lf16_300x200_e7_hdr", "lf16a300x200_e3", "lf32_200x136_e7", "l24_200x136_e7", "l20g_200x136_e3", "l24_300x200_e1", "lga300x200_e7", "lga300x200_e1", "lxd400x300_e7_depth", "lxs400x300_e3_rgba_selection"]      # grey + alpha; an extra channel that is not the alpha (decoded, not shown) | previous:      # MA-tree properties of previous channels (cjxl -E)                                     # group streams with leaf codes of more than 64 clusters
 LOSSLESS_CASES = LOSSLESS_CASES + NONPHOTO_LOSSLESS_CASES
 LOSSLESS_DEVICE_CASES = list(LOSSLESS_CASES)
 # Patches (ISO/IEC 18181-1 K.3): a kReferenceOnly Modular frame with the glyph-like patches + a main frame that adds them back — what the reference's
@@ -123,7 +123,7 @@ SQUEEZE_VARDCT_CASES = ["va400x300_e7_d2", "asset_animated"]
 # libjxl's encoder never selects and its decoder takes, and splines (K.4: what jxl-art files draw with); expected pixels = the reference's decode
 WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
                 "w_preview",      # ... + a preview frame in front of the image's frame (walked over)
-                "w_dequant_a", "w_dequant_b",      # DequantMatrices encodings 1 - 6: every special 8 x 8 table from its own parameters
+                "w_dequant_a", "w_dequant_b", "w_dequant_c",      # DequantMatrices encodings 1 - 6: every special 8 x 8 table from its own parameters; _c: the forms rotated over the tables of one 8 x 8 block (a form belongs to the mode)
                 "w_passes6", "w_passes11"]         # more passes than any encoder writes (the format allows 11)
 VARDCT_CASES = VARDCT_CASES + WRITER_CASES + ["va400x300_e7_d2", "vflat400x300_e7", "vgrad200x150_e7", "v2c400x300_e7", "vapac520x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vpm400x300_e7_premultiplied", "vga300x200_e7", "vxd400x300_e7_depth", "vxs400x300_e7_rgba_spot",
                                "vn300x200_e7", "vn600x410_e7_d15", "vna333x277_e7_d15"]      # + RGBA with progressive AC, noise synthesis (the C oracle restates both)      # + flat / gradient / two-colour content at the encoder's defaults          # (the oracle decodes squeezed alpha; it does not walk multi-frame files: asset_animated stays out)

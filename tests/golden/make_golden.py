@@ -99,6 +99,11 @@ CASES = {
     "lf16_300x200_e7_hdr": (300, 200, dict(seed=5, float=16, frange=(-0.2, 1.5)), dict(lossless=True, effort=7)),
     "lf16a300x200_e3": (300, 200, dict(seed=6, alpha=True, float=16), dict(lossless=True, effort=3)),
     "lf32_200x136_e7": (200, 136, dict(seed=5, float=32), dict(lossless=True, effort=7)),
+    # integer samples of more than 16 bits (what cjxl writes from 24-bit PNM sources; libjxl's encoder stops at 24): int32 planes, 64-bit neighbourhoods, and from 23 bits
+    # on libjxl's double-precision conversion to [0, 1]; the reference returns RGBA16 for them (interop/JxlDecoding.cpp:92-101)
+    "l24_200x136_e7": (200, 136, dict(seed=5, int_bits=24), dict(lossless=True, effort=7, int_bits=24)),
+    "l20g_200x136_e3": (200, 136, dict(seed=6, int_bits=20, grey=True), dict(lossless=True, effort=3, int_bits=20)),
+    "l24_300x200_e1": (300, 200, dict(seed=7, int_bits=24), dict(lossless=True, effort=1, int_bits=24)),
     "lga300x200_e7": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=7)),
     "lga300x200_e1": (300, 200, dict(seed=9, grey=True, alpha=True), dict(lossless=True, effort=1)),
     "lxd400x300_e7_depth": (400, 300, dict(seed=5, extra_type=1), dict(lossless=True, effort=7)),
@@ -304,9 +309,9 @@ def dequant_case(name, W):
     """DequantMatrices encodings 1 - 5 (the special 8 x 8 tables from their own parameters: IDENTITY, DCT2X2, DCT4X4 with multipliers, DCT4X8 / DCT8X4 with a
     multiplier, AFV) and 6 (distance bands) for DCT8, on an image whose varblocks use every one of those transforms; with libjxl's library tables instead the
     reference's pixels are up to 46 codes away.  w_dequant_b: other parameters, 17 distance bands for DCT16, library tables for the rest."""
-    seed = {"w_dequant_a": 9, "w_dequant_b": 10}[name]
+    seed = {"w_dequant_a": 9, "w_dequant_b": 10, "w_dequant_c": 11}[name]
     rng = np.random.default_rng(seed)
-    size = 64 if name == "w_dequant_a" else 128
+    size = 128 if name == "w_dequant_b" else 64
     nb = size // 8
     yy, xx = np.mgrid[0:nb, 0:nb]
     lf = np.stack([np.round(30 * np.sin(xx / 5.0 + seed)).astype(np.int64), 5000 + 60 * xx + 45 * yy, np.round(40 * np.cos(yy / 4.0 + seed)).astype(np.int64)])
@@ -316,7 +321,7 @@ def dequant_case(name, W):
         return {int(k): int(v) for k, v in zip(rng.choice(np.arange(covered, total), n, replace=False), rng.integers(-amp, amp + 1, n)) if v}
     f16 = lambda v: float(np.float16(v))
     r = lambda lo, hi: f16(rng.uniform(lo, hi))
-    if name == "w_dequant_a":
+    if name != "w_dequant_b":
         strategies = [1, 2, 3, 12, 13, 14, 15, 16, 17, 0]
         blocks = [dict(bx=x, by=y, strategy=strategies[(y * nb + x) % len(strategies)], qf=int(rng.integers(4, 12)), coef={1: co(0, 12, 25), 0: co(0, 4, 5), 2: co(0, 5, 8)})
                   for y in range(nb) for x in range(nb)]
@@ -343,7 +348,11 @@ def dequant_case(name, W):
                   [r(14, 18), r(14, 18), r(0.6, 1), r(0.6, 1), r(0.6, 1), r(0.7, 1.1), r(-0.2, 0.1), r(-0.2, 0.1), r(-0.2, 0.1)],
                   [r(5, 7), r(5, 7), r(0.15, 0.25), r(0.15, 0.25), r(0.15, 0.25), r(0.3, 0.4), r(-0.3, -0.2), r(-0.3, -0.2), r(-0.3, -0.2)]], b48, b4)),
     }
-    if name == "w_dequant_a":
+    if name == "w_dequant_c":
+        # the five special forms belong to the MODE, not to a table — any table of one 8 x 8 block may carry any of them (libjxl checks the table's size only).
+        # Here they are rotated: DCT8 <- IDENTITY form, IDENTITY <- DCT2X2 form, DCT2X2 <- DCT4X4 form, DCT4X4 <- DCT4X8 form, DCT4X8 <- AFV form, AFV <- IDENTITY form
+        deq = {0: deq[1], 1: deq[2], 2: deq[3], 3: deq[9], 9: deq[10], 10: deq[1]}
+    elif name == "w_dequant_a":
         deq[0] = (6, [[r(40, 60), r(-0.2, 0), r(-0.5, -0.3), r(-0.5, -0.3)], [r(7, 10), r(-0.1, 0), r(-0.4, -0.2), r(-0.4, -0.2)], [r(6, 9), r(-2, -1), r(-1, -0.5), r(-0.5, 0)]])
     else:
         del deq[9]
@@ -463,7 +472,7 @@ def spline_case(name, W):
 
 
 WRITER_CASES = ["w_spline_a", "w_spline_b", "w_spline_c", "w_dct256", "w_dct128", "w_dct_mix_a", "w_dct_mix_b", "w_dct128_small", "w_dct256_nofilter",
-                "w_up2_custom", "w_up4_custom", "w_up8_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_passes6", "w_passes11"]
+                "w_up2_custom", "w_up4_custom", "w_up8_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_dequant_c", "w_passes6", "w_passes11"]
 
 
 def add_writer_cases(meta, only):
@@ -489,6 +498,13 @@ def make_image(w, h, sk):
     alpha = sk.pop("alpha", False)
     grey = sk.pop("grey", False)
     grain = sk.pop("grain", 0)
+    int_bits = sk.pop("int_bits", 0)
+    if int_bits:                # an integer image of 17 .. 24 bits as float32 k / (2^bits - 1): a 16-bit photograph with seeded low bits, every bit of the sample in use
+        base = synth.photo_like(w, h, seed=sk.get("seed", 0), bits=16).astype(np.uint64)
+        if grey:
+            base = base[..., :1]
+        iv = (base << (int_bits - 16)) | np.random.default_rng(3000 + sk.get("seed", 0)).integers(0, 1 << (int_bits - 16), base.shape, dtype=np.uint64)
+        return np.ascontiguousarray((iv.astype(np.float64) / ((1 << int_bits) - 1)).astype(np.float32))
     if gen == "photo":
         img = synth.photo_like(w, h, **sk)
         if grain:               # sensor-like grain (seeded): what makes the encoder's noise estimation find something to model

@@ -216,8 +216,9 @@ def test_harness_rejects_what_the_device_path_does_not_support(emul):
 
 
 def test_dequant_encodings_for_the_wrong_table_or_with_bad_parameters_are_invalid(emul):
-    """DequantMatrices (I.2.4): encoding 1 belongs to the IDENTITY table alone, 2 to DCT2X2, 3 to DCT4X4, 4 to DCT4X8, 5 to AFV, and a first band /
-    weight / multiplier below 1e-8 is rejected — as libjxl does (tools/jxl_write.py writes such headers; the parser says invalid, it does not guess)."""
+    """DequantMatrices (I.2.4): encodings 1 - 5 (IDENTITY, DCT2X2, DCT4X4, DCT4X8, AFV forms) may be stored for ANY table of one 8 x 8 block — libjxl checks the
+    table's size, the weights follow from the mode (golden w_dequant_c pins the pixels) — but not for a larger table, and a first band / weight /
+    multiplier below 1e-8 is rejected, as libjxl does (tools/jxl_write.py writes such headers; the parser says invalid, it does not guess)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import jxl_write as W
@@ -225,11 +226,13 @@ def test_dequant_encodings_for_the_wrong_table_or_with_bad_parameters_are_invali
     lf = np.stack([np.zeros((nb, nb), np.int64), np.full((nb, nb), 5000, np.int64), np.zeros((nb, nb), np.int64)])
     blocks = [dict(bx=x, by=y, strategy=0, qf=8, coef={1: {3: 4}}) for y in range(nb) for x in range(nb)]
     idw = [[4.0, 40.0, 40.0]] * 3
-    emul(W.write_vardct(32, 32, blocks, lf, dequant={1: (1, idw)}))                    # the right table: decodes
+    emul(W.write_vardct(32, 32, blocks, lf, dequant={1: (1, idw)}))                    # the form's own table: decodes
+    a = emul(W.write_vardct(32, 32, blocks, lf, dequant={0: (1, idw)}))                # IDENTITY form for the DCT8 table: valid, and the blocks (all DCT8) use it
+    b = emul(W.write_vardct(32, 32, blocks, lf))
+    assert not np.array_equal(a, b)
+    emul(W.write_vardct(32, 32, blocks, lf, dequant={2: (4, ([1.0] * 3, [[30.0, -0.5]] * 3))}))      # DCT4X8 form for the DCT2X2 table: valid
     with pytest.raises(ValueError, match="invalid"):
-        emul(W.write_vardct(32, 32, blocks, lf, dequant={0: (1, idw)}))                # IDENTITY parameters for the DCT8 table
-    with pytest.raises(ValueError, match="invalid"):
-        emul(W.write_vardct(32, 32, blocks, lf, dequant={2: (4, ([1.0] * 3, [[30.0, -0.5]] * 3))}))      # DCT4X8 parameters for the DCT2X2 table
+        emul(W.write_vardct(32, 32, blocks, lf, dequant={4: (1, idw)}))                # ... but not for DCT16 (2 x 2 blocks)
     with pytest.raises(ValueError, match="invalid"):
         emul(W.write_vardct(32, 32, blocks, lf, dequant={1: (1, [[0.0, 40.0, 40.0]] * 3)}))            # a zero weight
 
