@@ -515,6 +515,8 @@ def main():
 
     prime = run_frames(P * NCTX)             # untimed setup: every context allocates the HBM work buffers of a full flight
     warm = run_frames(args.warmup * B) if args.warmup > 0 else {}   # W untimed warmup steps
+    if os.environ.get("JXLAMD_BENCH_ABLATE"):       # measurement only (stage floors): the timed steps leave stages of the flight out — the line is then NOT a decode rate
+        J.api.lib().jxlamd_debug_set_ablate(int(os.environ["JXLAMD_BENCH_ABLATE"]))
     # sequential single-frame latency (one context; BASELINE configs[1]), reported next to the throughput
     lat = []
     for _ in range(3):
@@ -632,6 +634,8 @@ def main():
         # BASELINE configs[1] (one frame, latency) stated, not left to divide: this decoder's single-frame rate over the reference's libjxl decoding the same
         # frame with its thread pool on this box's host cores.  Below 1: a lone frame is bounded by ONE LfGroup stream — 196 608 samples walked by one lane at ~1 100 shader
         # clocks each (k_lf_group_general, ~90 ms of the ~112) — where a host core takes a few tens of cycles per sample; the GPU wins on batches, not on a lone frame.
+        if os.environ.get("JXLAMD_BENCH_ABLATE"):
+            line["config"]["ABLATED_STAGES_not_a_decode_rate"] = int(os.environ["JXLAMD_BENCH_ABLATE"])
         thr = line["cpu_baseline"].get("single_frame_threaded_MPps")
         line["config"]["single_frame_vs_cpu_threaded"] = round(line["config"]["single_frame_MPps"] / thr, 3) if thr else None
         print(json.dumps(line))

@@ -181,6 +181,9 @@ int jxlamd_debug_lf_phases_frame(jxlamd_decoder *dec, int frame, int num_lf_grou
 /* 1 once a frame of this context needed the LF kernel build with the general lock-step loops (decoded again with it, and every later
  * decode of the context uses it): the lean build covers libjxl's LF-coefficient and HF-metadata streams. */
 int jxlamd_debug_lf_general(const jxlamd_decoder *dec);
+/* Measurement only: flights of every decoder of the process leave stages out — 1 the LF stage, 2 the PassGroup stage, 4 reconstruction + filters + writer (the pixels are
+ * then whatever the slots held; 0 restores the decoder).  Stage floors of the flight pipeline: tools/gpu/ab.sh with JXLAMD_BENCH_ABLATE, profiles/r06_ablations_stage_floors.json. */
+int jxlamd_debug_set_ablate(int mask);
 /* out[0]: decodes / flights of this context that ran a second time because the LF table pool was too small (kErrNeedPool), out[1]: ... because
  * a stream needed the general build, out[2]: the pool (bytes) the next LF launch will get. */
 int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]);

@@ -64,6 +64,9 @@ static int err_class(const std::string &e) { return e.rfind("unsupported", 0) ==
 // internal return code: the lean LF kernel met a channel that needs a general lock-step loop (kErrNeedGeneral) — decode again with the general build
 // what one decoder context learnt about the frames of this process serves the others (contexts of a service see the same kind of content)
 static std::atomic<int> g_lf_pool_floor{0};
+// measurement only (jxlamd_debug_set_ablate; profiles/r06_ablations_stage_floors.json): stages the FLIGHT path leaves out — 1 the LF stage (clear, extra-channel globals, LfGroup
+// streams, LF smoothing), 2 the PassGroup stage, 4 reconstruction + filters + writer.  The frames then decode to whatever the slots held before: only the clock is of interest.
+static std::atomic<int> g_ablate{0};
 static constexpr int kRetryGeneral = 0x7e7e;
 // ... or a channel whose packed tables did not fit the LDS table pool this launch was sized with (kErrNeedPool): decode again with the largest
 static constexpr int kRetryPool = 0x7e7f;
@@ -935,12 +938,15 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const DevAux *dA = (const DevAux *)(bt + o_a);
   if (huge_blocks_seen) HIPCHECK(huge_scratch.ensure((size_t)kHugeSlots * 2 * 65536 * 4));
   HIPCHECK(hipEventRecord(ev[0], stream));
+  const int ablate = g_ablate.load();
+  if (!(ablate & 1)) {
   launch_clear_batch(dB, nb, max_cells, stream);
   if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
   static const int lf_pool_min_env = getenv("JXLAMD_LF_POOL_MIN") ? atoi(getenv("JXLAMD_LF_POOL_MIN")) : 0;      // measurement switch: the LDS of an LF workgroup as a variable (streams per CU)
   launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::min(kModPoolBytes, std::max(std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_pool_min_env)), lf_general, stream);
+  }
   HIPCHECK(hipEventRecord(ev[1], stream));
-  launch_lf_smooth_batch(dB, nb, max_cells, stream);
+  if (!(ablate & 1)) launch_lf_smooth_batch(dB, nb, max_cells, stream);
   // ---- HF phase: this context's turn on the pools (uncontended unless shared).  The wait is host-side and overlaps the LF stage launched above
   std::unique_lock<std::mutex> pool_lock(pools->mu);
   if (pools->generation != pool_gen) return kRetryMoved;      // a sharing context re-allocated the pools meanwhile (first flights only): the tables above hold stale addresses
@@ -954,14 +960,15 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     const int n_pg = (int)(pg_off[(size_t)sf + 1] - pg_off[(size_t)sf]);
     // >= flat_min_groups groups: one LANE per group (k_pass_prep + k_pass_flat, 64 streams per wavefront); below that the
     // one-wave-per-group kernel has the shorter critical path
-    if (sparse || (all_flat && n_pg >= flat_min_groups)) {
+    if (ablate & 2) {
+    } else if (sparse || (all_flat && n_pg >= flat_min_groups)) {
       launch_pass_prep(dB + k0, map, n_pg, stream);
       launch_pass_flat(dB + k0, (const int *)(bt + o_w) + 3 * w_off[(size_t)sf], (int)(w_off[(size_t)sf + 1] - w_off[(size_t)sf]), sparse, stream);
     } else launch_pass_groups_batch(dB + k0, map, n_pg, stream);
     if (any_ec) launch_ec_groups_batch(dB + k0, (const int *)(bt + o_ec) + 2 * ec_off[(size_t)sf], cnt, (int)(ec_off[(size_t)sf + 1] - ec_off[(size_t)sf]),
                                        ec_ops[(size_t)sf], ec_pool, stream);
     if (sf == 0) HIPCHECK(hipEventRecord(ev[2], stream));
-    for (int j0 = 0; j0 < cnt; j0 += plane_sets) {
+    for (int j0 = 0; j0 < cnt && !(ablate & 4); j0 += plane_sets) {
       launch_rest_batch(dB + k0 + j0, (const uint8_t *)stat.p, std::min(plane_sets, cnt - j0), max_cells, max_w, max_h, stage_mask, large_hint, 3, stream, sparse,
                         huge_blocks_seen ? (float *)huge_scratch.p : nullptr);
       if (stage_mask & 32) for (int j = j0; j < std::min(j0 + plane_sets, cnt); j++) {      // composed frames of the sub-batch: splines / noise / upsampling + their writer, before the plane set moves on
@@ -1365,6 +1372,7 @@ int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) 
 }
 
 int jxlamd_debug_lf_general(const jxlamd_decoder *dec) { return dec && dec->lf_general ? 1 : 0; }
+int jxlamd_debug_set_ablate(int mask) { g_ablate.store(mask & 7); return JXLAMD_OK; }
 int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]) {
   if (!dec || !out) return JXLAMD_ERR_BUFFER;
   out[0] = dec->pool_retries; out[1] = dec->general_retries; out[2] = (uint32_t)dec->lf_pool_bytes;
