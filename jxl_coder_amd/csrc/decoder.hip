@@ -88,6 +88,7 @@ static size_t mod_scratch_total_ints(const DevFrame &F, int num_groups, int num_
   return ((size_t)num_groups + 1) * mod_scratch_ints_host(F) + (size_t)num_lf_groups * (size_t)F.mod_lf_nch * 65536;
 }
 
+__global__ void k_or_flags(const uint32_t *src, uint32_t *dst) { if (threadIdx.x == 0 && *src) atomicOr(dst, *src); }
 __global__ void __launch_bounds__(256) k_fill_opaque_alpha(void *out, size_t npx, int bits) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= npx) return;
@@ -430,7 +431,7 @@ int jxlamd_decoder::launch_extra_channels(FrameSlot &S) {
 int jxlamd_decoder::launch_modular(FrameSlot &S) {
   const FramePlan &plan = S.plan;
   const DevFrame *F = (const DevFrame *)plan.tables.data();
-  launch_mod_global(S.B, stream);
+  launch_mod_global(S.B, mod_group_pool_bytes(plan), stream);
   if (F->mod_lf_nch > 0) launch_mod_lfgroups(S.B, plan.num_lf_groups, stream);
   if (F->mod_first_group_ch < F->mod_nch) launch_mod_groups(S.B, plan.num_groups, mod_group_pool_bytes(plan), stream);
   for (int o = 0; o < F->mod_nops; o++) launch_mod_op(S.B, o, (size_t)(F->mod_op_kind[o] == 0 ? F->mod_op_y[o] : F->mod_op_c[o]), stream);
@@ -532,6 +533,7 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
   S.plan = FramePlan();
   (void)plan_parse(jxl, size, &S.plan, target_frame);
   if (!S.plan.error.empty() || S.plan.tables.empty()) { set_error(S.plan.error); return err_class(S.plan.error); }
+  ref_cursor = 0;
   int rc = decode_refs(S, flags);
   if (rc) return rc;
   rc = prepare(S, jxl, size, jxl_dev, flags, out_ptr, out_cap, info, /*parsed=*/true);
@@ -541,13 +543,23 @@ int jxlamd_decoder::decode_once(const uint8_t *jxl, size_t size, const void *jxl
 
 // The frames a patch dictionary draws on (FramePlan::refs), in file order: each one is decoded like a frame of its own — same kernels — and
 // its image copied into its reference slot instead of being written out.
-int jxlamd_decoder::decode_refs(FrameSlot &main, uint32_t flags) {
+int jxlamd_decoder::decode_refs(FrameSlot &main, uint32_t flags, bool deferred) {
+  // deferred (frames of a flight whose references are Modular frames — a screenshot's patch sprites): no flag read-back and no synchronisation per reference frame (655
+  // one-wave launches each behind a host round trip per mixed run in round 5); the frame's kernels are queued, its flags OR-ed into ref_err_dev, the batch checks that word once
+  for (const auto &r : main.plan.refs) if (!r || !r->modular) deferred = false;
   for (size_t k = 0; k < main.plan.refs.size(); k++) {
-    while (ref_slots.size() <= k) ref_slots.push_back(new FrameSlot());
-    FrameSlot &RS = *ref_slots[k];
+    const size_t si = deferred ? ref_cursor++ : ref_cursor + k;      // (synchronous reference decodes reuse the slots behind the deferred ones of this batch, whose staging may still be read)
+    while (ref_slots.size() <= si) ref_slots.push_back(new FrameSlot());
+    FrameSlot &RS = *ref_slots[si];
     RS.plan = *main.plan.refs[k];
     int rc = prepare(RS, nullptr, 0, nullptr, (flags & ~(uint32_t)(JXLAMD_IN_DEVICE | JXLAMD_OUT_DEVICE)) | JXLAMD_NO_SIZE_GUARD, nullptr, ~(size_t)0, nullptr, /*parsed=*/true);
     if (rc) return rc;
+    if (deferred) {
+      rc = launch_modular(RS); if (rc) return rc;
+      hipLaunchKernelGGL(k_or_flags, dim3(1), dim3(64), 0, stream, (const uint32_t *)RS.B.err, (uint32_t *)ref_err_dev.p);
+      refs_deferred = true;
+      continue;
+    }
     rc = run_frame(RS, flags, false);
     if (rc) return rc;
   }
@@ -566,7 +578,7 @@ int jxlamd_decoder::run_frame(FrameSlot &S, uint32_t flags, bool single_latency)
     (void)hipEventElapsedTime(&timing[4], ev[0], ev[4]);
     return rc;
   }
-  if (S.plan.has_ec) launch_mod_global(S.B, stream);
+  if (S.plan.has_ec) launch_mod_global(S.B, mod_group_pool_bytes(S.plan), stream);
   // a single decode is the latency path and has the chip to itself: the general build (181 VGPRs) runs a lone stream ~5 % faster than the lean
   // one (125), whose smaller footprint only pays next to the data-parallel kernels of other flights
   launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, /*general=*/single_latency || lf_general, stream);
@@ -693,6 +705,9 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   }
   const double t_parsed = now();
   if (trace) HIPCHECK(hipEventRecord(ev[5], stream));
+  HIPCHECK(ref_err_dev.ensure(256)); HIPCHECK(h_ref_err.ensure(256));
+  HIPCHECK(hipMemsetAsync(ref_err_dev.p, 0, 4, stream));
+  ref_cursor = 0; refs_deferred = false;
   for (int i = 0; i < n; i++) {
     FrameSlot &S = slot((size_t)i);
     // Frames that draw on other frames (patch dictionaries, LF frames, animation layers over a canvas) keep state in the context's reference slots and are
@@ -716,7 +731,10 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
       }
     }
     const bool composed = (S.plan.compose || !S.plan.refs.empty()) && !rides;
-    if ((composed || rides_with_refs) && S.plan.error.empty()) { int rc = decode_refs(S, flags); if (rc) return rc; }
+    if ((composed || rides_with_refs) && S.plan.error.empty()) {
+      static const bool refs_async = !(getenv("JXLAMD_REFS_ASYNC") && atoi(getenv("JXLAMD_REFS_ASYNC")) == 0);      // A/B switch for measurements
+      int rc = decode_refs(S, flags, /*deferred=*/rides_with_refs && refs_async); if (rc) return rc;
+    }
     int rc = prepare(S, jxl[i], sizes[i], jxl_dev ? jxl_dev[i] : nullptr, jxl_dev && jxl_dev[i] ? (flags | JXLAMD_IN_DEVICE) : (flags & ~JXLAMD_IN_DEVICE),
                      outs[i], caps[i], infos ? &infos[i] : nullptr, /*parsed=*/true,
                      /*own_planes=*/S.plan.modular || S.plan.single_section || composed);
@@ -728,7 +746,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     if (composed) { rc = run_frame(S, flags, false); if (rc) return rc; continue; }
     if (S.plan.modular) { mod_batched.push_back(i); continue; }
     if (S.plan.single_section) {
-      if (S.plan.has_ec) launch_mod_global(S.B, stream);
+      if (S.plan.has_ec) launch_mod_global(S.B, mod_group_pool_bytes(S.plan), stream);
       launch_lf_groups(S.B, S.A, S.plan.num_lf_groups, lf_pool_bytes, lf_general, stream);
       if (S.plan.single_section) { rc = finish_single_section(S); if (rc) return rc; }
       launch_lf_smooth(S.B, S.plan.xb, S.plan.yb, stream);
@@ -737,6 +755,12 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
       launch_rest(S);
       rc = collect(S, flags); if (rc) return rc;
     } else batched.push_back(i);
+  }
+  if (refs_deferred) {      // the reference frames queued above: one read-back for all of them
+    HIPCHECK(hipMemcpyAsync(h_ref_err.p, ref_err_dev.p, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHECK(hipStreamSynchronize(stream));
+    uint32_t rerr = 0; memcpy(&rerr, h_ref_err.p, 4);
+    if (rerr) { set_error("corrupt or unsupported stream (device flags " + std::to_string(rerr) + ", reference frame of a flight)"); return dev_err_class(rerr); }
   }
   // ---- Modular-encoded (lossless) frames of the batch: their streams are as serial as the LF streams, so they too go into one
   // launch per stage over all of them (GlobalModular streams, then every 256x256 group stream, inverse transforms, writer)
@@ -941,7 +965,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   const int ablate = g_ablate.load();
   if (!(ablate & 1)) {
   launch_clear_batch(dB, nb, max_cells, stream);
-  if (any_ec) launch_ec_global_batch(dB, nb, stream);          // GlobalModular parts of the extra channels (skips frames without)
+  if (any_ec) launch_ec_global_batch(dB, nb, ec_pool, stream);          // GlobalModular parts of the extra channels (skips frames without)
   static const int lf_pool_min_env = getenv("JXLAMD_LF_POOL_MIN") ? atoi(getenv("JXLAMD_LF_POOL_MIN")) : 0;      // measurement switch: the LDS of an LF workgroup as a variable (streams per CU)
   launch_lf_groups_batch(dB, dA, (const int *)(bt + o_lf), (int)lf_map.size() / 2, std::min(kModPoolBytes, std::max(std::max(lf_pool_bytes, g_lf_pool_floor.load()), lf_pool_min_env)), lf_general, stream);
   }

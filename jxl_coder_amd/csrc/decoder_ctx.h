@@ -186,7 +186,10 @@ struct jxlamd_decoder {
   int finish_single_section(FrameSlot &S);
   int launch_rest(FrameSlot &S, int parts = 3, bool upload_B = false);     // parts: 1 = reconstruction, 2 = filters + writer
   int launch_compose_tail(FrameSlot &S);
-  int decode_refs(FrameSlot &main, uint32_t flags);
+  int decode_refs(FrameSlot &main, uint32_t flags, bool deferred = false);
+  // reference frames of a flight's frames decoded WITHOUT a host synchronisation each (round 6): every one in a slot of its own (the page-locked staging of a slot is reused
+  // only after the batch's one synchronisation), their device flags OR-ed into ref_err_dev, which decode_batch_once reads once behind the last of them
+  DevMem ref_err_dev; PinnedMem h_ref_err; size_t ref_cursor = 0; bool refs_deferred = false;
   int run_frame(FrameSlot &S, uint32_t flags, bool single_latency);
   int launch_modular(FrameSlot &S);
   int launch_extra_channels(FrameSlot &S);

@@ -52,8 +52,8 @@ JXL_DEV void inv_rct_planes(int32_t *p0, int32_t *p1, int32_t *p2, size_t n, int
 
 // ---- GlobalModular: one workgroup; decodes the meta channels and every channel that fits one group
 template <class Sync>
-JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int nthreads, Sync sync) {
-  if (tid == 0) { S.pool_bytes = kModPoolBytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
+JXL_DEV void mod_global_body(const DevBuffers &B, DevModScratch &S, int tid, int nthreads, Sync sync, int pool_bytes = kModPoolBytes) {
+  if (tid == 0) { S.pool_bytes = pool_bytes; S.pool_want = nullptr; S.walk_stat = B.err + 2; }
   const DevFrame &F = frame_of(B);
   if (tid == 0) {
     const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);

@@ -358,6 +358,70 @@ JXL_DEV void epf_value_t(const DevBuffers &B, const DevFrame &F, float *const sr
                                    : src[c][(size_t)mirror(y + (dy), h) * (size_t)pw + (size_t)mirror(x + (dx), w)])
   float wsum = 1.0f, acc[3];
   for (int c = 0; c < 3; c++) acc[c] = src[c][po];
+  if (kPass == 0) {
+    // The 12-tap iteration, channel by channel (round 6): one channel's 25-sample neighbourhood is live at a time instead of all three (k_filter_b<1>: 178 VGPRs ->
+    // what lets more of its waves sit between the resident entropy waves; BASELINE config 5 spends a fifth of its kernel time here).  Every sum keeps its order — a
+    // tap's SAD over the channels 0, 1, 2, the weights over the taps, a channel's accumulator over the taps — so the values are the very same.
+    float sadv[12], wgtv[12];
+#ifdef __HIPCC__
+    #pragma unroll
+#endif
+    for (int t = 0; t < 12; t++) sadv[t] = 0.0f;
+    if (kInterior) {
+#ifdef __HIPCC__
+      #pragma unroll 1
+#endif
+      for (int c = 0; c < 3; c++) {
+        const float cs = F.epf_chscale[c];
+#ifdef __HIPCC__
+        #pragma unroll
+#endif
+        for (int t = 0; t < 12; t++) {
+          float sc = 0.0f;
+#ifdef __HIPCC__
+          #pragma unroll
+#endif
+          for (int k = 0; k < 5; k++) sc += fabsf(PX(c, py[k], px[k]) - PX(c, t0y[t] + py[k], t0x[t] + px[k]));
+          sadv[t] += sc * cs;
+        }
+      }
+    } else {
+      // pixels within three of an edge (every coordinate mirrored): few, and their 75 mirrored addresses are what the kernel's register count used to be sized by —
+      // rolled loops here
+#ifdef __HIPCC__
+      #pragma unroll 1
+#endif
+      for (int c = 0; c < 3; c++) {
+        const float cs = F.epf_chscale[c];
+#ifdef __HIPCC__
+        #pragma unroll 1
+#endif
+        for (int t = 0; t < 12; t++) {
+          float sc = 0.0f;
+#ifdef __HIPCC__
+          #pragma unroll 1
+#endif
+          for (int k = 0; k < 5; k++) sc += fabsf(PX(c, py[k], px[k]) - PX(c, t0y[t] + py[k], t0x[t] + px[k]));
+          sadv[t] += sc * cs;
+        }
+      }
+    }
+#ifdef __HIPCC__
+    #pragma unroll
+#endif
+    for (int t = 0; t < 12; t++) { float wgt = 1.0f + sadv[t] * isig; if (wgt < 0.0f) wgt = 0.0f; wgtv[t] = wgt; wsum += wgt; }
+#ifdef __HIPCC__
+    #pragma unroll 1
+#endif
+    for (int c = 0; c < 3; c++) {
+      float a = acc[c];
+#ifdef __HIPCC__
+      #pragma unroll
+#endif
+      for (int t = 0; t < 12; t++) a += wgtv[t] * PX(c, t0y[t], t0x[t]);
+      acc[c] = a;
+    }
+  } else
 #ifdef __HIPCC__
   #pragma unroll
 #endif

@@ -51,7 +51,7 @@ void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s);
 void launch_pass_groups(const DevBuffers &B, int num_groups, hipStream_t s);
 // filters ping-pong between plane_a and plane_b; `src_is_a` tells where the current image is; returns the new flag
 // Modular-encoded (lossless) frames
-void launch_mod_global(const DevBuffers &B, hipStream_t s);
+void launch_mod_global(const DevBuffers &B, int pool_bytes, hipStream_t s);
 void launch_mod_groups(const DevBuffers &B, int num_groups, int pool_bytes, hipStream_t s);      // pool_bytes: LDS table pool of every group stream's workgroup (mod_group_pool_bytes, decoder.hip)
 void launch_mod_lfgroups(const DevBuffers &B, int num_lf_groups, hipStream_t s);      // ModularLfGroup streams of a Modular-encoded frame
 void launch_mod_op(const DevBuffers &B, int op, size_t n, hipStream_t s);
@@ -67,7 +67,7 @@ void launch_save_ref(const DevBuffers &B, int w, int h, float *dst, hipStream_t 
 void launch_compose_write(const DevBuffers &B, const uint8_t *stat, int w, int h, hipStream_t s);
 void launch_upsample_alpha(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, hipStream_t s);      // alpha coded coarser than the image -> DevBuffers::up[3]
 void launch_upsample_and_write(const DevBuffers &B, const uint8_t *stat, int full_w, int full_h, bool noise, bool write, hipStream_t s);      // upsampled frames: enlarge, then write at full resolution
-void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s);
+void launch_ec_global_batch(const DevBuffers *Bs, int nframes, int pool_bytes, hipStream_t s);
 void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int pool_bytes, hipStream_t s);
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, int pool_bytes, hipStream_t s);
 }  // namespace jxlamd

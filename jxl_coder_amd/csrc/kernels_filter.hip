@@ -33,8 +33,11 @@ __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F);
 // tone map) and A11 (premultiply, Bitmap format) — nothing but the Bitmap is written; 2 = the pass behind it that re-writes, un-mapped, the pixels at or
 // behind their row's first zero-luma pixel (dev_post.h: post_emit).  Separate instantiations: the LUT lookups and the format switch stay out of the
 // ordinary writer's registers.
+#ifndef JXL_FILTER_B_WAVES
+#define JXL_FILTER_B_WAVES 1
+#endif
 template <int STAGE, int POST = 0>
-__global__ void __launch_bounds__(256) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JXL_FILTER_B_WAVES))) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if ((F.is_modular && !F.xyb_modular) || !stage_runs(F, STAGE) || frame_failed(B)) return;

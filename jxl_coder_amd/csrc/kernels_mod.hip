@@ -7,12 +7,19 @@
 namespace jxlamd {
 
 // ---- Modular-encoded frames
-__global__ void __launch_bounds__(64) k_mod_global(DevBuffers B) {
-  __shared__ DevModScratch S;
-  __shared__ DevChanOut chbuf[kModMaxCh];
-  S.ch = chbuf;                                       // (every lane stores the same value)
+// GlobalModular workgroups in DYNAMIC LDS too (round 6): offsetof(pool) + the table pool the frame's tree and code need + kModMaxCh channel descriptors.  With the
+// static 54.9 KB of rounds 1 - 5 a reference frame of a screenshot — one wave, a few milliseconds of work — waited for a CU with 55 KB of free LDS next to the LF
+// and PassGroup waves of fifteen other flights; a patch-sprite frame needs 12 KB of pool: 35 KB.
+__device__ __forceinline__ DevModScratch &mod_global_smem(int pool_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t mod_smem_g[];
+  DevModScratch &S = *(DevModScratch *)mod_smem_g;
+  S.ch = (DevChanOut *)(mod_smem_g + offsetof(DevModScratch, pool) + pool_bytes);      // (every lane stores the same value)
   __syncthreads();
-  mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock());
+  return S;
+}
+__global__ void __launch_bounds__(64) k_mod_global(DevBuffers B, int pool_bytes) {
+  DevModScratch &S = mod_global_smem(pool_bytes);
+  mod_global_body(B, S, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
 // The group streams' workgroup lives in DYNAMIC LDS like the LF kernels': offsetof(pool) + the table pool of this launch + kModGroupDesc channel descriptors.
 // A frame's group streams are as many as its 256 x 256 groups and each keeps its LDS for the ~100 ms it runs: with the full 30 KB pool (54 KB per
@@ -115,7 +122,16 @@ __global__ void __launch_bounds__(256) k_mod_write(DevBuffers B, int out_bits, i
   if (x >= w || y >= h) return;
   mod_write_pixel(B, out_bits, x, y);
 }
-void launch_mod_global(const DevBuffers &B, hipStream_t s) { hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), 0, s, B); }
+static size_t mod_global_lds(const void *kernel, bool *once, int pool_bytes) {
+  if (!*once) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(offsetof(DevModScratch, pool) + kModPoolBytes + kModMaxCh * sizeof(DevChanOut))); *once = true; }
+  return offsetof(DevModScratch, pool) + (size_t)pool_bytes + kModMaxCh * sizeof(DevChanOut);
+}
+static int mod_pool_clamp(int pool_bytes);
+void launch_mod_global(const DevBuffers &B, int pool_bytes, hipStream_t s) {
+  static bool once = false;
+  pool_bytes = mod_pool_clamp(pool_bytes);
+  hipLaunchKernelGGL(k_mod_global, dim3(1), dim3(64), mod_global_lds((const void *)k_mod_global, &once, pool_bytes), s, B, pool_bytes);
+}
 static size_t mod_group_lds(const void *kernel, bool *once, int pool_bytes) {
   if (!*once) { (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(offsetof(DevModScratch, pool) + kModPoolBytes + kModGroupDesc * sizeof(DevChanOut))); *once = true; }
   return offsetof(DevModScratch, pool) + (size_t)pool_bytes + kModGroupDesc * sizeof(DevChanOut);
@@ -133,14 +149,11 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
 }
 
 // ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
-__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs) {
-  __shared__ DevModScratch S;
-  __shared__ DevChanOut chbuf[kModMaxCh];
-  S.ch = chbuf;                                       // (every lane stores the same value)
-  __syncthreads();
+__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs, int pool_bytes) {
+  DevModScratch &S = mod_global_smem(pool_bytes);
   const DevFrame &F = frame_of(Bs[blockIdx.x]);
   if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
-  mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock());
+  mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
 __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map, int pool_bytes) {
   DevModScratch &S = mod_group_smem(pool_bytes);
@@ -177,7 +190,12 @@ __global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
 }
 // extra channels (alpha) of the VarDCT frames of a flight: GlobalModular parts before the LF stage, the per-group streams and the
 // inverse transforms after the PassGroup stage of each sub-flight
-void launch_ec_global_batch(const DevBuffers *Bs, int nframes, hipStream_t s) { hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs); }
+static void launch_mod_global_b(const DevBuffers *Bs, int nframes, int pool_bytes, hipStream_t s) {
+  static bool once = false;
+  pool_bytes = mod_pool_clamp(pool_bytes);
+  hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), mod_global_lds((const void *)k_mod_global_b, &once, pool_bytes), s, Bs, pool_bytes);
+}
+void launch_ec_global_batch(const DevBuffers *Bs, int nframes, int pool_bytes, hipStream_t s) { launch_mod_global_b(Bs, nframes, pool_bytes, s); }
 static void launch_mod_group_b(const DevBuffers *Bs, const int *group_map, int ngroups, int pool_bytes, hipStream_t s) {
   static bool once = false;
   pool_bytes = mod_pool_clamp(pool_bytes);
@@ -188,7 +206,7 @@ void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nfra
   for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
 }
 void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, int pool_bytes, hipStream_t s) {
-  hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), 0, s, Bs);
+  launch_mod_global_b(Bs, nframes, pool_bytes, s);
   const int max_lfg = ((max_w + 1023) / 1024) * ((max_h + 1023) / 1024);       // LF groups are 8 x group_dim pixels wide (>= 1024)
   if (max_w > 1024 || max_h > 1024) hipLaunchKernelGGL(k_mod_lfgroup_b, dim3(max_lfg, nframes), dim3(64), 0, s, Bs);   // only images beyond one LF group can carry such streams
   if (ngroups > 0) launch_mod_group_b(Bs, group_map, ngroups, pool_bytes, s);
