@@ -375,7 +375,8 @@ def main():
         if "--contexts" not in argv: args.contexts = 16         # (8 contexts: 2 680 MP/s, 12 or 16: 3 200; flights of 16 or 24: 1 670 - 1 790 while the flat PassGroup kernel started at 4 096 groups, 2 770 since it starts at 1 024)
         if "--inflight" not in argv: args.inflight = 32
         if "--distinct" not in argv: args.distinct = 64
-        if "--steps" not in argv: args.steps = 16              # (8 steps = one flight per context in the timed region: 2 557 / 2 926 / 3 103 MP/s in three runs of round 5; two flights each are steadier)
+        if "--steps" not in argv: args.steps = 32              # four flights of 32 frames per context (round 6: 3 211 - 3 355 MP/s over four runs, +- 2.2 %; 8 steps = one flight each gave 2 557 - 3 103 in round 5)
+        if "--warmup" not in argv: args.warmup = 8
 
     # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver does for N > 1
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -397,8 +398,8 @@ def main():
     if args.workload == "c4":
         return run_c4(args, rank, local, world)
     if args.workload == "mixed":
-        if "--steps" not in " ".join(sys.argv[1:]): args.steps = 16      # 16 steps x 64 frames = two flights of 32 for each of the 16 contexts; the general default of 20 ends with half the contexts idle (1 726 MP/s where 8 or 16 steps give 2 430)
-        if "--warmup" not in " ".join(sys.argv[1:]): args.warmup = 4
+        if "--steps" not in " ".join(sys.argv[1:]): args.steps = 48      # six flights of 32 for each of the 16 contexts: the rate a run settles at (round 6, one box: 8 steps 2 508 - one flight per context, all in step -, 16 steps 1 652 - 1 933, 32 steps 1 815 - 2 193, 48 steps 2 098 - 2 253 MP/s)
+        if "--warmup" not in " ".join(sys.argv[1:]): args.warmup = 8
         return run_mixed(args, rank, local, world)
 
     # the batch: distinct seeded frames (tools/make_bench_frames.py), cycled to --batch frames; rank r starts at seed r
