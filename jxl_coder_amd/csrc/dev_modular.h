@@ -29,8 +29,8 @@ struct DevChanOut { int32_t *d; int32_t w, h; int16_t hs, vs; };      // hs / vs
 constexpr int kModPoolBytes = JXL_MOD_POOL_BYTES;  // LARGEST LDS table pool of one stream: 8-byte alias tables of up to 15 clusters + context map + tree head, or the packed tables of up to 23 clusters (dev_modular_wave.h)
 // The pool is the tail of DevModScratch and the LF kernels allocate it as dynamic LDS: what a stream's tables need decides how many LF
 // streams a CU holds (a stream keeps its LDS for ~100 ms, and LDS-time is what the flights of several decoder contexts run out of first).
-// libjxl's streaming encoder: 9 clusters x 1.25 KB packed for the LF coefficients, <= 7 x 2 KB for the HF metadata; its one-shot encoder
-// (global tree, 39 clusters): 28 x 768 B.  Streams report what they would have liked (DevModScratch::pool_want), the host sizes the next launch.
+// libjxl's streaming encoder (log_alpha 8): 8 - 21 clusters x 896 B packed for the LF coefficients of the 256 bench frames (round 6: three-byte entries), <= 7 x 2 KB for the HF
+// metadata; its one-shot encoder (global tree, 39 clusters, log_alpha 7): 28 x 512 B.  Streams report what they would have liked (DevModScratch::pool_want), the host sizes the next launch.
 constexpr int kModPoolMin = 12288;                 // header parser's working arrays (LocalTmp) and the placement bitmap (8 KB) live there too
 
 struct DevTr { int32_t id, begin_c, rct_type, num_c, nb_colours, nb_deltas, d_pred; };

@@ -5,8 +5,8 @@
 
 namespace jxlamd {
 
-// An LF stream holds its LDS for ~100 ms; 51 KB per stream (the full table pool) lets three streams into a CU, 33 KB (12 KB pool: what libjxl's
-// streaming encoder needs for smooth content) four.
+// An LF stream holds its LDS for ~100 ms; round 6: 19.9 KB of fixed scratch + the table pool + 1 KB of descriptors — 39.3 KB with the 18.4 KB pool the bench's
+// frames need (four streams per CU), 33.1 KB with the smallest pool.
 // Two builds of each kernel.  The lean one (here, the default of flights) carries the specialised lock-step loops only — weighted-predictor
 // threshold trees (libjxl's LF coefficients), uniform-leaf channels and y / x / N / W channels with predictors 0..5 (its HF metadata), the serial
 // walker — in 125 VGPRs; a channel that needs a general lock-step loop ends its frame with kErrNeedGeneral and the host runs the *_general build
