@@ -17,7 +17,9 @@ NAMES = ["v256_e7", "v264x520_e7", "l200x120_e7", "va300x520_e7", "v64_hard_e7",
          "lpl400x300_e7_nopatch", "lpl200x136_e7_photo", "lpl400x300_e7", "vapr400x300_e7", "vaqr520x300_e7", "vlfq600x410_e7", "vlf2_600x410_e7_d2",
          "vlf2a520x300_e7", "vnu523x267_e7_d12", "lpc200x136_e7_prev3", "lpcr200x136_e7_prev3", "an_blend_d12_e7", "an_modes_d15_e7",
          # round 5: what tools/jxl_write.py writes — splines, DCT128 / 256, custom upsampling weights, a preview frame, dequant encodings 1 - 6, 6 / 11 passes
-         "w_spline_b", "w_dct_mix_a", "w_dct256", "w_up4_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_passes6", "w_passes11"]
+         "w_spline_b", "w_dct_mix_a", "w_dct256", "w_up4_custom", "w_preview", "w_dequant_a", "w_dequant_b", "w_passes6", "w_passes11",
+         # round 6: dequant forms rotated over the 8 x 8 tables, 24- / 20-bit integer samples, grey and hard-edged VarDCT frames, splines with the area limits
+         "w_dequant_c", "l24_200x136_e7", "l20g_200x136_e3", "vhg800x600_e7_d1", "vha640x480_e7_d1", "w_spline_a", "w_spline_c"]
 
 CHILD = r"""
 import ctypes as C, random, sys, os
