@@ -647,10 +647,35 @@ bool frame_flat_ok(const FramePlan &plan) {
   return true;
 }
 
-std::vector<int> flat_wave_map(const std::vector<int> &ngroups) {
+// A frame whose groups are not a multiple of 64 ends with a wave of few lanes (4K: 135 = 64 + 64 + 7) that holds a wave's LDS and registers as long as a full one.  When the
+// tail is short (<= 16 groups) and each tail group, added to the group of the lane it would follow (the last lanes of the last full wave: with a frame height that is not a
+// multiple of 256 both are groups of the short bottom row), stays within the frame's largest group — judged by the sections' bytes, which is what a stream's length follows —
+// the tail rides on those lanes and the wave is not launched.
+static bool flat_tail_chain(const FramePlan &plan) {
+  static const bool on = !(getenv("JXLAMD_PASS_CHAIN") && atoi(getenv("JXLAMD_PASS_CHAIN")) == 0);      // A/B switch for measurements
+  const DevFrame *F = (const DevFrame *)plan.tables.data();
+  const int G = plan.num_groups, tail = G % 64;
+  if (!on || plan.tables.empty() || F->num_passes != 1 || F->nsec == 1 || G < 64 || tail == 0 || tail > 16) return false;
+  const DevSection *secs = (const DevSection *)(plan.tables.data() + F->sec_off);
+  const DevSection *pg = secs + 2 + F->num_lf_groups;      // PassGroup sections of the one pass
+  uint32_t largest = 0;
+  for (int g = 0; g < G; g++) largest = std::max(largest, pg[g].size);
+  const int full = G - tail;
+  for (int j = 0; j < tail; j++) if ((uint64_t)pg[full - tail + j].size + (uint64_t)pg[full + j].size > (uint64_t)largest + largest / 16) return false;
+  return true;
+}
+// chain[k] (round 6): frame k's tail groups (num_groups % 64 of them) ride as SECOND groups of the last lanes of its last full wave instead of in a wave of their own
+// (flat_tail_chain decides; dev_pass_flat.h: pass_group_flat's g2)
+std::vector<int> flat_wave_map(const std::vector<int> &ngroups, const std::vector<int> &chain) {
   std::vector<int> per_xcd[8];
-  for (size_t k = 0; k < ngroups.size(); k++)
-    for (int g = 0; g < ngroups[k]; g += 64) { std::vector<int> &v = per_xcd[k & 7]; v.push_back((int)k); v.push_back(g); v.push_back(std::min(64, ngroups[k] - g)); }
+  for (size_t k = 0; k < ngroups.size(); k++) {
+    const int tail = (k < chain.size() && chain[k]) ? ngroups[k] % 64 : 0, full = ngroups[k] - tail;
+    for (int g = 0; g < full; g += 64) {
+      std::vector<int> &v = per_xcd[k & 7];
+      const int cnt = std::min(64, full - g);
+      v.push_back((int)k); v.push_back(g); v.push_back(cnt | ((g + cnt == full ? tail : 0) << 8));
+    }
+  }
   size_t rows = 0;
   for (const auto &v : per_xcd) rows = std::max(rows, v.size() / 3);
   std::vector<int> out;
@@ -907,7 +932,8 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
   std::vector<size_t> pg_off, ec_off, w_off;                 // per sub-flight: first entry of its PassGroup map / extra-channel group map / wavefront map
   bool all_flat = true;
   for (int i : batched) all_flat = all_flat && frame_flat_ok(slot((size_t)i).plan);
-  const auto close_subflight = [&] { const std::vector<int> m = flat_wave_map(sf_groups); w_map.insert(w_map.end(), m.begin(), m.end()); sf_groups.clear(); };
+  std::vector<int> sf_chain;
+  const auto close_subflight = [&] { const std::vector<int> m = flat_wave_map(sf_groups, sf_chain); w_map.insert(w_map.end(), m.begin(), m.end()); sf_groups.clear(); sf_chain.clear(); };
   std::vector<int> ec_ops;                                   // per sub-flight: most inverse transforms any of its frames has
   bool any_ec = false;
   int ec_pool = kModPoolMin;                                 // LDS table pool of the extra channels' group streams: the largest any frame of the flight asks for
@@ -919,7 +945,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     S.B.coef_sp = sparse ? (uint32_t *)pools->sp_pool.p + sp_frame_off[(size_t)k] : nullptr;      // (sp_group: below, once the flight's table block is laid out)
     hb.push_back(S.B); ha.push_back(S.A);
     if (k % hf_sets == 0) { if (k) close_subflight(); pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
-    sf_groups.push_back(S.plan.num_groups);
+    sf_groups.push_back(S.plan.num_groups); sf_chain.push_back(flat_tail_chain(S.plan) ? 1 : 0);
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();

@@ -92,7 +92,7 @@ int dev_err_class(uint32_t derr);
 bool frame_flat_ok(const FramePlan &plan);
 // {frame, first group, groups} entries of k_pass_flat for frames [0, n) with ngroups[i] groups each, ordered so that the wavefronts of one frame
 // land on one XCD (workgroup b runs on XCD b % 8): its tables are then read through ONE 4 MB L2 instead of all eight
-std::vector<int> flat_wave_map(const std::vector<int> &ngroups);
+std::vector<int> flat_wave_map(const std::vector<int> &ngroups, const std::vector<int> &chain = std::vector<int>());
 
 struct FrameSlot {             // HBM work buffers of one in-flight frame
   bool coef_clean = false; size_t coef_clean_bytes = 0; const void *coef_clean_ptr[3] = {nullptr, nullptr, nullptr};   // own coefficient planes known all-zero?

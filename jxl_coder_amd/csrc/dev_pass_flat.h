@@ -134,22 +134,26 @@ JXL_DEV uint32_t flat_ec_read(const uint32_t *cfg_lds, const uint8_t *ctx_map, c
 // wave-wide ring top-ups).
 // kSparse: the nonzero coefficients go into the group's entry arena (DevBuffers::coef_sp) instead of the dense planes, and each varblock's
 // (first entry, entries) pair into coef_off / coef_cnt at its first cell — single-pass frames only (the host decides: decoder.hip)
+// g2 >= 0 (round 6): the lane takes a SECOND group the moment its first one ends — a frame's groups are not a multiple of 64 (a 4K frame: 135 = 64 + 64 + 7), and a wave of
+// seven lanes holds a wave's LDS and registers for as long as a full one.  The host chains the tail groups onto lanes of the last full wave whose first group is short
+// (decoder.hip: flat_wave_map — the bottom row of a frame whose height is not a multiple of 256), so the wave ends no later than before.
 template <bool kSparse = false>
-JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, int g, int lane) {
+JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, int g, int lane, int g2 = -1) {
   const DevFrame &F = frame_of(B);
   uint32_t *ring = L.ring;
   SimtBits b;
   bool done = g < 0;
   uint32_t err = 0;
   const DevSection *secs = (const DevSection *)(B.tables + F.sec_off);
-  const DevSection sec = secs[done ? 0 : (F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g)];
+  DevSection sec = secs[done ? 0 : (F.nsec == 1 ? 0 : 2 + F.num_lf_groups + pass * F.num_groups + g)];
   sbits_init(b, ring, lane, B.codestream, sec.off, F.cs_size);
   if (F.nsec == 1) {
     uint32_t skip = F.single_pass_bit;
     while (skip >= 32) { sbits_read(b, ring, lane, 32); skip -= 32; if (SIMT_ANY(b.wr - b.rd < 6u)) sbits_topup(b, ring, lane); }
     sbits_read(b, ring, lane, (int)skip);
+    g2 = -1;                                               // (single-section frames do not ride in flights; their one group has no successor)
   }
-  const int sel = (int)sbits_read(b, ring, lane, ceil_log2u((uint32_t)F.num_presets));
+  int sel = (int)sbits_read(b, ring, lane, ceil_log2u((uint32_t)F.num_presets));
   if (!done && sel >= F.num_presets) { err = kErrBitstream; done = true; }
   const int nslice = 495 * F.num_bctx;
   const uint8_t *ctx_map = B.tables + F.hf_ec[pass].ctx_map_off + (size_t)(done ? 0 : sel) * (size_t)nslice;
@@ -161,7 +165,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
   const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1), nqf = F.nb_qf_thr + 1;
   const uint8_t *bctx_map = L.bctx_ptr;
   const uint8_t *blkbase = B.pass_nz + (size_t)(done ? 0 : g) * kPassBlkStride;
-  const uint32_t nblk = done ? 0u : *(const uint32_t *)blkbase;
+  uint32_t nblk = done ? 0u : *(const uint32_t *)blkbase;
   const PassBlk *desc = (const PassBlk *)(blkbase + 8);
   PassBlk dn = {0u, 0u};
   if (nblk) dn = desc[0];
@@ -173,12 +177,12 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
   const uint32_t *order = &L.order8[0][0][0];
   int32_t *blk = B.coef[0];
   // sparse emission: this lane's arena, its fill, where the current varblock's entries began and the cell that owns them
-  const uint32_t sp_base = (kSparse && !done) ? B.sp_group[g] : 0u, sp_cap = (kSparse && !done) ? B.sp_group[g + 1] - sp_base : 0u;
+  uint32_t sp_base = (kSparse && !done) ? B.sp_group[g] : 0u, sp_cap = (kSparse && !done) ? B.sp_group[g + 1] - sp_base : 0u;
   uint32_t *ent = kSparse ? B.coef_sp + sp_base : nullptr;
   uint32_t ne = 0, blk_start = 0;
   size_t blk_cell = 0;
   bool sp_bad = false;
-  const size_t cell0 = kSparse ? (size_t)((done ? 0 : g / F.xgroups) * 32) * (size_t)F.xb + (size_t)((done ? 0 : g % F.xgroups) * 32) : 0;
+  size_t cell0 = kSparse ? (size_t)((done ? 0 : g / F.xgroups) * 32) * (size_t)F.xb + (size_t)((done ? 0 : g % F.xgroups) * 32) : 0;
   while (SIMT_ANY(!done)) {
     uint32_t ctx = 0, o_next = 0;
     const bool run = nzeros > 0;                           // inside the coefficients of a (varblock, channel)
@@ -190,8 +194,38 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
       } else {
         if (ci == 3) {
           if (kSparse && bi > 0) { B.coef_off[blk_cell] = sp_base + blk_start; B.coef_cnt[blk_cell] = ne - blk_start; }      // the varblock just finished
-          if (bi == nblk) done = true;
-          else {
+          if (bi == nblk) {
+            done = true;
+            if (g2 >= 0) {
+              // ---- this lane's first group is complete: close it, open the second one (the same steps as above, for this lane alone)
+              if (kSparse && (sp_bad || ne > sp_cap)) err = kErrNeedDense;
+              else if (state != 0x130000u) err = kErrAnsFinal;
+              else if (b.consumed > (uint64_t)sec.size * 8 + 64) err = kErrBitstream;
+              else {
+                if (F.has_ec) B.pass_end_bits[(size_t)pass * (size_t)F.num_groups + (size_t)g] = b.consumed;
+                g = g2; g2 = -1;
+                sec = secs[2 + F.num_lf_groups + pass * F.num_groups + g];
+                sbits_init(b, ring, lane, B.codestream, sec.off, F.cs_size);
+                sel = (int)sbits_read(b, ring, lane, ceil_log2u((uint32_t)F.num_presets));
+                if (sel >= F.num_presets) err = kErrBitstream;
+                else {
+                  ctx_map = B.tables + F.hf_ec[pass].ctx_map_off + (size_t)sel * (size_t)nslice;
+                  state = sbits_read(b, ring, lane, 32);
+                  blkbase = B.pass_nz + (size_t)g * kPassBlkStride;
+                  nblk = *(const uint32_t *)blkbase;
+                  desc = (const PassBlk *)(blkbase + 8);
+                  dn.a = 0u; dn.off = 0u;
+                  if (nblk) dn = desc[0];
+                  bi = 0; nzeros = 0; k = 0; prev = 0;
+                  for (int i = 0; i < 3 * 32; i++) L.nzcol[(i << 6) + lane] = 0;      // the nonzero-count columns of the new group start from zero
+                  if (kSparse) { sp_base = B.sp_group[g]; sp_cap = B.sp_group[g + 1] - sp_base; ent = B.coef_sp + sp_base; ne = 0; blk_start = 0; sp_bad = false;
+                                 cell0 = (size_t)((g / F.xgroups) * 32) * (size_t)F.xb + (size_t)((g % F.xgroups) * 32); }
+                  done = nblk == 0;                          // (an empty group: nothing to read)
+                }
+              }
+            }
+          }
+          if (!done) {
             const PassBlk d = dn;
             bi++;
             dn = desc[bi < nblk ? bi : bi - 1];            // the following descriptor, a whole varblock ahead of its use

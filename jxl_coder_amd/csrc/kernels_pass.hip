@@ -63,12 +63,13 @@ __global__ void __launch_bounds__(64) k_pass_prep(const DevBuffers *__restrict__
   }
   if (lane == 0) { ((uint32_t *)base)[0] = total_n; ((uint32_t *)base)[1] = 0; }
 }
-// wmap: {frame, first group, number of groups <= 64} per wavefront (entries with 0 groups pad the XCD interleave, see decoder.hip)
+// wmap: {frame, first group, number of groups <= 64 | chained tail groups << 8} per wavefront (entries with 0 groups pad the XCD interleave, see decoder.hip)
 template <bool kSparse>
 __global__ void __launch_bounds__(64) k_pass_flat(const DevBuffers *__restrict__ Bs, const int *__restrict__ wmap) {
   __shared__ __attribute__((aligned(16))) FlatPassLds L;
   const int lane = (int)threadIdx.x;
-  const int f = wmap[3 * blockIdx.x], g0 = wmap[3 * blockIdx.x + 1], n = wmap[3 * blockIdx.x + 2];
+  const int f = wmap[3 * blockIdx.x], g0 = wmap[3 * blockIdx.x + 1], nf = wmap[3 * blockIdx.x + 2];
+  const int n = nf & 255, nch = (nf >> 8) & 255;      // nch: the wave's last nch lanes take a second group each — the frame's tail groups g0 + n .. (decoder.hip: flat_wave_map)
   if (n <= 0) return;
   const DevBuffers &B = Bs[f];
   if (frame_failed(B)) return;
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(64) k_pass_flat(const DevBuffers *__restrict__
     __syncthreads();
     flat_stage(B, L, pass, lane, 64);
     __syncthreads();
-    const uint32_t ep = pass_group_flat<kSparse>(B, L, pass, (lane < n && !e) ? g0 + lane : -1, lane);
+    const uint32_t ep = pass_group_flat<kSparse>(B, L, pass, (lane < n && !e) ? g0 + lane : -1, lane, (lane >= n - nch && lane < n && !e) ? g0 + n + (lane - (n - nch)) : -1);
     e |= ep;
   }
   if (e) atomicOr(B.err, e | kErrStagePass);

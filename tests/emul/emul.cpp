@@ -223,7 +223,10 @@ static int run_frame(FramePlan &plan, int out_bits, uint8_t *out, RefStore &refs
     for (int pass = 0; pass < F0.num_passes && !err; pass++)
       for (int g = 0; g < plan.num_groups; g++) {
         flat_stage(B, *L2, pass, 0, 1);                 // per lane here: the nonzero-count columns start from zero for every group
-        uint32_t e = sparse ? pass_group_flat<true>(B, *L2, pass, g, (g * 5 + 1) % 64) : pass_group_flat<false>(B, *L2, pass, g, (g * 5 + 1) % 64); if (e) err |= e;
+        // JXLEMUL_FLAT_CHAIN: groups in pairs, the second one as the lane's chained group (what k_pass_flat does with a frame's tail groups)
+        const int g2 = (getenv("JXLEMUL_FLAT_CHAIN") && g + 1 < plan.num_groups && F0.nsec != 1) ? g + 1 : -1;
+        uint32_t e = sparse ? pass_group_flat<true>(B, *L2, pass, g, (g * 5 + 1) % 64, g2) : pass_group_flat<false>(B, *L2, pass, g, (g * 5 + 1) % 64, g2); if (e) err |= e;
+        if (g2 >= 0) g++;
       }
     delete L2;
     if (sparse && getenv("JXLEMUL_STATS")) {

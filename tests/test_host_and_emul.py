@@ -162,6 +162,12 @@ def test_flat_passgroup_path_gives_identical_pixels(emul, monkeypatch, name):
     monkeypatch.setenv("JXLEMUL_FLAT_PASS", "1")
     alt = emul(data)
     assert np.array_equal(base, alt)
+    # round 6: a lane that takes a SECOND group the moment its first one ends (k_pass_flat chains a frame's tail groups that way): groups in pairs, with the dense planes
+    # and with the sparse lists
+    monkeypatch.setenv("JXLEMUL_FLAT_CHAIN", "1")
+    assert np.array_equal(base, emul(data))
+    monkeypatch.setenv("JXLEMUL_SPARSE", "1")
+    assert np.array_equal(base, emul(data))
 
 
 @pytest.mark.parametrize("name", ["v256_e7", "v300x300_e7_d3", "v264x520_e7", "vb520x4400_e7", "asset_first_jxl", "va300x520_e7", "v64_hard_e7", "asset_wide_gamut"])
