@@ -191,6 +191,9 @@ int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]);
  * nonzero coefficient) instead of dense 3 x 65 536 x int32 planes per group.  out[0]: the context's last flight did; out[1]: flights of this context that
  * were decoded again with the dense planes because a stream did not fit its lists. */
 int jxlamd_debug_sparse(const jxlamd_decoder *dec, uint32_t out[2]);
+/* *out: frames of this context's flights whose tail PassGroups (num_groups % 64, e.g. 7 of a 4K frame's 135) were decoded as second groups of the last full wave's lanes
+ * instead of in a wave of their own (k_pass_flat, round 6; JXLAMD_PASS_CHAIN=0 switches it off for A/B measurements). */
+int jxlamd_debug_pass_chain(const jxlamd_decoder *dec, uint32_t *out);
 /* Modular streams (lossless frames, alpha, LF coefficients) are decoded by one wavefront in lock-step; an MA tree with more than 64 decision nodes or
  * leaves after pruning runs from its block form (at most 63 nodes per block), and what fits neither goes to a one-lane serial walker.  out[0]: streams
  * this context sent to the serial walker, out[1]: channels decoded from the block form — since the context was created. */

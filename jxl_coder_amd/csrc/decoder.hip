@@ -946,6 +946,7 @@ int jxlamd_decoder::decode_batch_once(int n, const uint8_t *const *jxl, const si
     hb.push_back(S.B); ha.push_back(S.A);
     if (k % hf_sets == 0) { if (k) close_subflight(); pg_off.push_back(pg_map.size() / 2); ec_off.push_back(ec_map.size() / 2); ec_ops.push_back(0); w_off.push_back(w_map.size() / 3); }
     sf_groups.push_back(S.plan.num_groups); sf_chain.push_back(flat_tail_chain(S.plan) ? 1 : 0);
+    if (sf_chain.back() && (sparse || (all_flat && flight_groups >= flat_min_groups))) chained_tail_frames++;
     for (int g = 0; g < S.plan.num_groups; g++) { pg_map.push_back(k - k / hf_sets * hf_sets); pg_map.push_back(g); }   // frame index inside its sub-flight
     if (S.plan.has_ec) {
       const DevFrame *F = (const DevFrame *)S.plan.tables.data();
@@ -1422,6 +1423,7 @@ int jxlamd_debug_lf_phases(jxlamd_decoder *d, int num_lf_groups, uint64_t *out) 
 }
 
 int jxlamd_debug_lf_general(const jxlamd_decoder *dec) { return dec && dec->lf_general ? 1 : 0; }
+int jxlamd_debug_pass_chain(const jxlamd_decoder *dec, uint32_t *out) { if (!dec || !out) return JXLAMD_ERR_BUFFER; *out = dec->chained_tail_frames; return JXLAMD_OK; }
 int jxlamd_debug_set_ablate(int mask) { g_ablate.store(mask & 7); return JXLAMD_OK; }
 int jxlamd_debug_lf_retries(const jxlamd_decoder *dec, uint32_t out[3]) {
   if (!dec || !out) return JXLAMD_ERR_BUFFER;

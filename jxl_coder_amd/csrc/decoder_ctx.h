@@ -166,6 +166,7 @@ struct jxlamd_decoder {
   // three such flights stays dense
   bool sparse_enabled = !(getenv("JXLAMD_SPARSE") && atoi(getenv("JXLAMD_SPARSE")) == 0);
   uint32_t sparse_misses = 0; bool dense_flight = false, last_flight_sparse = false;
+  uint32_t chained_tail_frames = 0;       // frames of flat flights whose tail groups rode as second groups (flat_tail_chain)
   uint64_t serial_streams = 0, block_tree_channels = 0;      // Modular streams that went to the serial walker / channels decoded with their MA tree in block form (device counters, summed over decodes)
   bool pool_missed = false;              // the flight in progress is the repeat of one that missed the pool
   int lf_pool_floor = 0;                 // the pool never shrinks below what a stream of this context once missed (kErrNeedPool)

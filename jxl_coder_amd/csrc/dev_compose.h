@@ -109,7 +109,8 @@ JXL_DEV void upsample_alpha_pixel(const DevBuffers &B, const DevFrame &F, const 
 JXL_DEV void upsampled_write_pixel(const DevBuffers &B, const uint8_t *stat, int out_bits, int X, int Y) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)Y * (size_t)F.full_w + (size_t)X;
-  xyb_write_value(B, stat, *(const DevStatic *)stat, B.up[0][o], B.up[1][o], B.up[2][o], out_bits, X, Y);
+  if ((F.is_modular && !F.xyb_modular) || F.not_xyb) plain_write_value(B, stat, *(const DevStatic *)stat, B.up[0][o], B.up[1][o], B.up[2][o], out_bits, X, Y);      // the image's own samples
+  else xyb_write_value(B, stat, *(const DevStatic *)stat, B.up[0][o], B.up[1][o], B.up[2][o], out_bits, X, Y);
 }
 
 // Chroma upsampling of a YCbCr frame whose chroma is coded at half resolution (libjxl's render stages HChromaUps, then VChromaUps, in front of the
@@ -378,38 +379,13 @@ JXL_DEV void save_ref_pixel(const DevBuffers &B, const DevFrame &F, float *const
   for (int c = 0; c < 3; c++) dst[c][ro] = (a ? B.plane_a[c] : B.plane_b[c])[po];
 }
 
-// writer of a composed frame that is not XYB (Modular-encoded, samples already in the image's own colour space): clamp, scale, round
-JXL_DEV void plain_write_pixel(const DevBuffers &B, int out_bits, int x, int y) {
+// writer of a composed frame that is not XYB (Modular-encoded, samples already in the image's own colour space): clamp, scale, round — through the common store
+// (rgba_codes: the 8-bit writer's dither, which leaves exact n / 255 samples where they are — its largest entry is 0.492 — and shows on a fractional value only: the
+// alpha of a frame whose alpha channel is coded at a lower resolution, round 6; crop, orientation)
+JXL_DEV void plain_write_pixel(const DevBuffers &B, const uint8_t *stat, int out_bits, int x, int y) {
   const DevFrame &F = frame_of(B);
-  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x, si = (size_t)y * (size_t)F.width + (size_t)x;
-  const float maxv = out_bits == 16 ? 65535.0f : 255.0f;
-  uint32_t px[4];
-  for (int c = 0; c < 4; c++) {
-    float t;
-    if (c < 3) t = B.plane_a[c][po];
-    else if (F.mod_out[3] < 0) t = 1.0f;
-    else t = alpha_sample_value(F, mod_plane(B, F, F.mod_out[3])[si], false);
-    t = t < 0.0f ? 0.0f : t > 1.0f ? 1.0f : t;
-    if (!(t == t)) t = 0.0f;
-    px[c] = (uint32_t)(int)rintf(t * maxv);
-  }
-  x += F.crop_x0; y += F.crop_y0;
-  const int W = F.canvas_w, H = F.canvas_h;
-  if ((unsigned)x >= (unsigned)W || (unsigned)y >= (unsigned)H) return;
-  int ox = x, oy = y;
-  switch (F.orientation) {
-    case 2: ox = W - 1 - x; break;
-    case 3: ox = W - 1 - x; oy = H - 1 - y; break;
-    case 4: oy = H - 1 - y; break;
-    case 5: ox = y; oy = x; break;
-    case 6: ox = H - 1 - y; oy = x; break;
-    case 7: ox = H - 1 - y; oy = W - 1 - x; break;
-    case 8: ox = y; oy = W - 1 - x; break;
-    default: break;
-  }
-  const size_t di = ((size_t)oy * (size_t)F.out_w + (size_t)ox) * 4;
-  if (out_bits == 8) *(uint32_t *)(B.out + di) = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-  else { uint16_t *o = (uint16_t *)B.out + di; for (int c = 0; c < 4; c++) o[c] = (uint16_t)px[c]; }
+  const size_t po = (size_t)y * (size_t)F.pw + (size_t)x;
+  plain_write_value(B, stat, *(const DevStatic *)stat, B.plane_a[0][po], B.plane_a[1][po], B.plane_a[2][po], out_bits, x, y);
 }
 
 }  // namespace jxlamd

@@ -1017,12 +1017,13 @@ static int build_frame(FramePlan *plan, Priv *pv, const FrameRec &rec, bool is_s
   for (int i = 0; i < m.num_extra; i++) {
     // an extra channel is coded at 1 / ec_upsampling of the full size, never finer than the colour channels
     if (f.ec_upsampling[i] < f.upsampling) { plan->error = "extra channel upsampling below the frame's"; return -1; }
-    if (f.ec_upsampling[i] != 1 && (f.encoding == 1 && !m.pub.xyb_encoded)) { plan->error = "unsupported: extra channel upsampling in a Modular frame that is not XYB"; return -1; }
   }
   if (f.upsampling != 1) {
     // an upsampled frame (what the reference's encoder writes from distance 10 up, i.e. its quality <= 12: interop/JxlEncoding.cpp:38-46) is coded at
     // ceil(size / upsampling) and enlarged after the patches (dev_compose.h)
-    if (!m.pub.xyb_encoded) { plan->error = "unsupported: upsampling of a frame that is not XYB"; return -1; }
+    // (round 6: also frames that are not XYB — `cjxl --resampling=2 -d 0` through the reference's encoder writes a Modular frame of the image's own samples at half size —:
+    // the integer planes become [0, 1] floats (k_mod_to_planes), are enlarged like any other, and leave through the plain writer)
+    if (!m.pub.xyb_encoded && f.encoding == 0) { plan->error = "unsupported: upsampling of a VarDCT frame that is not XYB"; return -1; }
     if (!is_shown && !pv->blend) { plan->error = "unsupported: upsampled reference frame"; return -1; }      // (a frame kept as a canvas goes through the blend kernel at its full resolution; one kept as a patch source does not)
   }
   if (is_shown && !pv->blend && f.have_crop && (f.x0 || f.y0 || f.width != (int)raw_w || f.height != (int)raw_h)) {

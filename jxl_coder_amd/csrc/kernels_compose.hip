@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_compose_write(DevBuffers B, const uint8
   const DevFrame &F = frame_of(B);
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
   if (x >= F.width || y >= F.height || frame_failed(B)) return;
-  if (F.is_modular && !F.xyb_modular) { plain_write_pixel(B, B.out_bits, x, y); return; }
+  if (F.is_modular && !F.xyb_modular) { plain_write_pixel(B, stat, B.out_bits, x, y); return; }
   float *src[3];
   for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
   if (F.not_xyb) { const size_t po = (size_t)y * (size_t)F.pw + (size_t)x; plain_write_value(B, stat, *(const DevStatic *)stat, src[0][po], src[1][po], src[2][po], B.out_bits, x, y); return; }

@@ -103,6 +103,8 @@ PATCH_VARDCT_CASES = ["vs400x300_e7_d1", "vs400x300_e7_d3", "vs400x300_e9_d1",  
                       "vu400x300_e7_d10", "vu523x267_e7_up4", "vu523x267_e7_up8", "vus400x300_e7_d12",
                       # RGBA at low quality: alpha coded at half size (extra-channel upsampling; its values get the writer's dither like the colour), with patches, and alpha alone at half size
                       "vua400x300_e7_d12", "vusa400x300_e7_d12", "va400x300_e7_ecup2",
+                      # ... on frames that are not XYB (round 6): a Modular frame of the image's own samples at half / quarter size, a lossless RGBA frame whose alpha alone is at half size
+                      "lu400x300_e3_up2", "lua400x300_e3_ecup2", "lu523x267_e5_up4",
                       # progressive DC: an LF frame (Modular XYB, an eighth of the size) decoded into its slot, the main frame's LF image read from it
                       "vlf600x410_e7", "vlf2100x100_e7_d2", "vlfa520x300_e7_d15", "u96x64_lf_frame", "vlfq600x410_e7", "vlf2_600x410_e7_d2", "vlf2a520x300_e7", "vnu600x410_e7_up2", "vnu523x267_e7_d12", "vga300x200_e7_d12",
                       # custom primaries (Adobe RGB) and a custom white point with custom primaries (ProPhoto, D50: Bradford on both sides as in libjxl's output stage)

@@ -89,7 +89,7 @@ static void compose_tail(FramePlan &plan, const DevBuffers &B, const DevFrame &F
   float *src[3];
   for (int c = 0; c < 3; c++) src[c] = compose_final_is_a(F) ? B.plane_a[c] : B.plane_b[c];
   for (int y = 0; y < F.height; y++) for (int x = 0; x < F.width; x++) {
-    if (F.is_modular && !F.xyb_modular) plain_write_pixel(B, out_bits, x, y);
+    if (F.is_modular && !F.xyb_modular) plain_write_pixel(B, stat, out_bits, x, y);
     else if (F.not_xyb) { const size_t po = (size_t)y * (size_t)F.pw + (size_t)x; plain_write_value(B, stat, *(const DevStatic *)stat, src[0][po], src[1][po], src[2][po], out_bits, x, y); }
     else xyb_write_pixel(B, stat, *(const DevStatic *)stat, src, out_bits, x, y);
   }

@@ -127,6 +127,11 @@ CASES = {
     "vua400x300_e7_d12": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=12.0)),
     "vusa400x300_e7_d12": (400, 300, dict(gen="screenshot", seed=3, alpha=True), dict(effort=7, distance=12.0)),
     "va400x300_e7_ecup2": (400, 300, dict(seed=3, alpha=True), dict(effort=7, distance=1.0, extra=((3, 2),))),
+    # ... and the same on frames that are NOT XYB (round 6; `cjxl --resampling=2 -d 0`): a Modular frame of the image's own samples coded at half size and enlarged, and a
+    # lossless RGBA frame whose alpha alone is coded at half size (its enlarged, fractional values get the 8-bit writer's dither)
+    "lu400x300_e3_up2": (400, 300, dict(seed=3), dict(lossless=True, effort=3, extra=((2, 2),))),
+    "lua400x300_e3_ecup2": (400, 300, dict(seed=3, alpha=True), dict(lossless=True, effort=3, extra=((3, 2),))),
+    "lu523x267_e5_up4": (523, 267, dict(seed=4, alpha=True), dict(lossless=True, effort=5, extra=((2, 4),))),
     # progressive DC (JXL_ENC_FRAME_SETTING_PROGRESSIVE_DC = 19): the LF image travels as an LF frame of its own (a Modular XYB frame at an eighth of the size),
     # the main frame's LfGroup sections carry no LF coefficients; one and two LF groups
     "vlf600x410_e7": (600, 410, dict(seed=11), dict(effort=7, distance=1.0, extra=((19, 1),))),

@@ -595,6 +595,11 @@ def test_config3_flight_of_distinct_4k_frames_equals_single_decodes(dec, golden_
             rs = [int(x) for x in singles[i][::240].astype(np.int64).sum(axis=(1, 2))]
             assert max(abs(a - b) / b for a, b in zip(rs, golden_meta[names[i]]["row_sums"])) < 1e-4, names[i]
         assert np.array_equal(outs[k].cpu().numpy().reshape(2160, 3840, 4), singles[i]), (k, i)
+    # round 6: the seven tail groups of each of these frames (135 = 64 + 64 + 7) rode as second groups of the second wave's last lanes
+    import ctypes as C
+    import jxl_coder_amd as J
+    n = C.c_uint32()
+    assert J.api.lib().jxlamd_debug_pass_chain(C.c_void_p(dec._h), C.byref(n)) == 0 and n.value >= len(order), n.value
 
 
 def test_config5_full_size_pq16_epf3_tone_map_f16(dec):
