@@ -13,10 +13,11 @@ import jxl_coder_amd as J
 from jxl_coder_amd import shard
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
+DEV = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()      # one GPU: both ranks on cuda:0; more: one each
+torch.cuda.set_device(DEV)
 try:
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
-    t = torch.ones(4, device="cuda:0") * (rank + 1)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{DEV}"))
+    t = torch.ones(4, device=f"cuda:{DEV}") * (rank + 1)
     dist.all_reduce(t)                                   # the communicator is created here: a duplicate-GPU refusal shows now
     torch.cuda.synchronize()
 except Exception as e:  # noqa: BLE001
@@ -25,9 +26,9 @@ except Exception as e:  # noqa: BLE001
 print(f"[rank {rank}] nccl communicator over one GPU up, all_reduce -> {t[0].item()}")
 name = "vb520x4400_e7"          # 17 group rows = 3 LF-group rows
 data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
-whole, info = J.JxlDecoder(0).decode_one_shot(data)
+whole, info = J.JxlDecoder(DEV).decode_one_shot(data)
 for nbands in (2, 4):
-    got = shard.decode_sharded(data, nbands=nbands, rank=rank, world=world, device=0)
+    got = shard.decode_sharded(data, nbands=nbands, rank=rank, world=world, device=DEV)
     torch.cuda.synchronize()
     for (y0, y1, rows) in got:
         a = rows.cpu().numpy().reshape(y1 - y0, whole.shape[1], 4)
