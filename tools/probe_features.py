@@ -59,6 +59,17 @@ def cases():
     yield "rgba d2 resampling 2", pha, dict(distance=2.0, extra=((RESAMPLING, 2),))
     yield "rgba d2 ec_resampling 2", pha, dict(distance=2.0, extra=((EC_RESAMPLING, 2),))
     yield "rgb d2 noise + resampling 2", ph, dict(distance=2.0, extra=((NOISE, 1), (RESAMPLING, 2)))
+    # round 6: the same options on frames that are NOT XYB (lossless), hard-edged content in grey and colour, responsive + resampling, modular lossy grey
+    yield "rgb lossless resampling 2", ph, dict(lossless=True, effort=3, extra=((RESAMPLING, 2),))
+    yield "rgba lossless resampling 4", pha, dict(lossless=True, effort=5, extra=((RESAMPLING, 4),))
+    yield "rgba lossless ec_resampling 2", pha, dict(lossless=True, effort=3, extra=((EC_RESAMPLING, 2),))
+    yield "rgba lossless ec_resampling 4 + resampling 2", pha, dict(lossless=True, effort=3, extra=((EC_RESAMPLING, 4), (RESAMPLING, 2)))
+    yield "shot lossless e7 resampling 2", shot, dict(lossless=True, effort=7, extra=((RESAMPLING, 2),))
+    yield "rgb lossless responsive resampling 2", ph, dict(lossless=True, effort=5, extra=((RESPONSIVE, 1), (RESAMPLING, 2)))
+    yield "grey hard-edged d2", synth.hard_edged(400, 300, 9, 1), dict(distance=2.0)
+    yield "grey hard-edged lossy modular d1", synth.hard_edged(400, 300, 9, 1), dict(distance=1.0, modular=1)
+    yield "rgb hard-edged d3", synth.hard_edged(400, 300, 9, 3), dict(distance=3.0)
+    yield "rgba hard-edged d1", synth.hard_edged(400, 300, 9, 4), dict(distance=1.0)
     yield "rgb d5 (auto prog_dc)", big, dict(distance=5.0)
     yield "rgba d5", biga, dict(distance=5.0)
     yield "rgb lossy modular d1", ph, dict(distance=1.0, modular=1)
