@@ -24,6 +24,10 @@ coef = (tt[:, :, 2].astype(np.int64) - tt[:, :, 1].astype(np.int64)) / 1e5
 begin = (tt[:, :, 0].astype(np.int64) - int(start)) / 1e5
 print("per-stream total ms (group 0): min %.1f max %.1f; LF coeffs min %.1f max %.1f; latest start %.1f ms; latest end %.1f ms" % (
     tot[:, 0].min(), tot[:, 0].max(), coef[:, 0].min(), coef[:, 0].max(), begin.max(), ((tt[:, :, 6].astype(np.int64) - int(start)) / 1e5).max()))
+meta = (tt[:, :, 4].astype(np.int64) - tt[:, :, 3].astype(np.int64)) / 1e5
+place = (tt[:, :, 5].astype(np.int64) - tt[:, :, 4].astype(np.int64)) / 1e5
+for f in range(min(n, 8)):
+    print(" frame", f, "g0 coeffs %.1f meta %.1f place %.1f | g1 coeffs %.1f meta %.1f place %.1f | bytes %d" % (coef[f, 0], meta[f, 0], place[f, 0], coef[f, 1], meta[f, 1], place[f, 1], len(datas[f])))
 for f in range(min(n, 8)):
     print(" frame", f, "g0 total %.1f coeffs %.1f start %.1f | g1 total %.1f start %.1f" % (tot[f, 0], coef[f, 0], begin[f, 0], tot[f, 1], begin[f, 1]))
 L.jxlamd_debug_lf_phases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
