@@ -18,6 +18,9 @@
 #include <type_traits>
 
 #ifdef __HIPCC__
+#ifndef JXL_MOD_CHAIN
+#define JXL_MOD_CHAIN 1      // the chain form of the lean loop (0: an A/B build without it)
+#endif
 namespace jxlamd {
 
 // lane 0: flatten the tree reachable for (chan, stream) into ballot form
@@ -812,8 +815,8 @@ __device__ __forceinline__ void wave_decode_channel_uniform(const DevECView &ev,
 // block-info channel: thousands of samples x 2 rows, W and y only) eligible.
 template <bool kLds>
 __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, DevBits &b, uint32_t &state, DevModScratch &S, DevWaveTree &WT,
-                                                         const DevChanOut c, int lane, bool needs_n) {
-  const int w = c.w, h = c.h;
+                                                         const DevChanOut c, int lane, bool needs_n, int y_end) {
+  const int w = c.w, h = y_end;            // rows [0, y_end): the rest of an eligible channel goes through wave_decode_channel_chain
   const int ni = WT.ni, nl = WT.nl;
   const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
   const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
@@ -854,6 +857,117 @@ __device__ __forceinline__ void wave_decode_channel_lean(const DevECView &ev, De
         const int32_t val = (l_mul == 1 ? res : res * l_mul) + l_off + guess;
         keep = shift_in_wave1(val, keep);
         vNW = vN; vW = val; vN = nextN;
+      }
+      if (lane < m) { const int32_t v = keep; out[x0 + m - 1 - lane] = v; if (needs_n) row[x0 + m - 1 - lane] = v; }
+    }
+    __syncthreads();        // the row written above is the next row's N
+  }
+}
+
+// "Chain" form of the lean loop (round 6) for the two long channels of libjxl's HF-metadata streams — block info (count x 2: `y > 0`, then thresholds on W) and the
+// EPF sharpness when its contexts do not share a cluster (`N > 3`, then `W > 3`): 9 000 .. 55 000 + 65 536 samples per 2048 x 2048 LF group at ~850 clocks each in the
+// lean loop.  Every decision node is a threshold, so with the decisions on y, x, N fixed (a "class": known for a whole row segment before its first sample is decoded,
+// evaluated by 64 lanes for 64 samples at once) the leaf is a function of HOW MANY of the tree's W thresholds lie below W — the weighted-predictor loop's counting form:
+// one v_cmp + s_bcnt1 + two v_readlane (lane e = class * (nW + 1) + count keeps the leaf's alias-table offset and its hybrid-uint configuration | predictor << 24)
+// instead of two ballots over 64-bit need masks and five readlanes; the bit reader in its wave-uniform form.  Eligible: properties y, x, N, |N| on at most six nodes,
+// W nodes of ONE kind (W or |W|), (1 << classes) * (nW + 1) <= 64 entries, leaves with predictor zero / W / N, multiplier 1, offset 0, tables in LDS.  Row 0 of a channel
+// whose tree or predictors read N (there N stands for W: not known ahead) is left to the lean loop.  Bit-exact with it by construction: same samples, same order.
+struct ChainPlan { int nW, nC, wabs; uint64_t wmask, cmask; bool ok; };
+__device__ __forceinline__ ChainPlan wave_chain_plan(const DevWaveTree &WT, int lane) {
+  ChainPlan P;
+  const int ni = WT.ni, nl = WT.nl;
+  const int pr = lane < ni ? WT.int_prop[lane] : 0;
+  const uint64_t w7 = __ballot(lane < ni && pr == 7), w5 = __ballot(lane < ni && pr == 5);
+  P.cmask = __ballot(lane < ni && (pr == 2 || pr == 3 || pr == 4 || pr == 6));
+  P.wabs = w5 != 0; P.wmask = w5 | w7;
+  P.nW = __builtin_popcountll(P.wmask); P.nC = __builtin_popcountll(P.cmask);
+  const bool leaves_ok = __ballot(lane < nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 2 || WT.leaf_mul[lane] != 1 || WT.leaf_off[lane] != 0)) == 0;
+  P.ok = leaves_ok && !(w5 && w7) && P.nW + P.nC == ni && P.nC <= 6 && ((P.nW + 1) << P.nC) <= 64;
+  return P;
+}
+__device__ __forceinline__ void wave_decode_channel_chain(const DevECView &ev, DevBits &b, uint32_t &state, DevModScratch &S, DevWaveTree &WT,
+                                                          const DevChanOut c, int lane, bool needs_n, int y_begin, const ChainPlan P) {
+  const int w = c.w, h = c.h;
+  const int ni = WT.ni, nl = WT.nl, nW = P.nW, nC = P.nC, stride = nW + 1;
+  const int la = ev.log_alpha, lb = 12 - la;
+  const int my_prop = lane < ni ? WT.int_prop[lane] : 0;
+  const int my_split = lane < ni ? WT.int_split[lane] : 0x7fffffff;
+  const bool isW = (P.wmask >> lane) & 1, isC = (P.cmask >> lane) & 1;
+  const int my_wsplit = isW ? my_split : 0x7fffffff;                    // the counting compare: lanes that are no W node never count
+  const int my_cbit = __builtin_popcountll(P.cmask & ((1ull << lane) - 1ull));      // a class node's bit in the class number
+  const uint64_t my_need1 = lane < nl ? WT.leaf_need1[lane] : ~0ull, my_need0 = lane < nl ? WT.leaf_need0[lane] : ~0ull;
+  const int my_lctx = lane < nl ? WT.leaf_ctx[lane] : 0, my_lpred = lane < nl ? WT.leaf_pred[lane] : 0;
+  const int my_lclu = lane < nl ? (int)((const uint8_t *)S.pool)[S.ctx_off + my_lctx] : 0;
+  // the W thresholds in ascending order (S.wdiv: the weighted-predictor loop's table, idle in a channel without that predictor)
+  int32_t *sorted = (int32_t *)&S.wdiv[0][0];
+  {
+    int rank = 0;
+    for (uint64_t m = P.wmask; m; m &= m - 1) { const int j = __builtin_ctzll(m); const int tj = __builtin_amdgcn_readlane(my_split, j); rank += (tj < my_split || (tj == my_split && j < lane)) ? 1 : 0; }
+    __syncthreads();
+    if (isW) sorted[rank] = my_split;
+    __syncthreads();
+  }
+  // entry e = class * stride + count: a property value with exactly `count` thresholds below it stands for W, the class bits for the other decisions
+  int my_aoff = 0, my_cp = 0;
+  for (int k = 0, e = 0; k < (1 << nC); k++)
+  for (int cc = 0; cc < stride; cc++, e++) {
+    const int pc = cc == 0 ? (nW ? sorted[0] : 0) : (int)((uint32_t)sorted[cc - 1] + 1u);
+    const uint64_t dec = __ballot(lane < ni && (isW ? pc > my_split : ((k >> my_cbit) & 1) != 0));
+    const uint64_t lm = __ballot(lane < nl && (dec & my_need1) == my_need1 && (~dec & my_need0) == my_need0);
+    const int leaf = lm ? __builtin_ctzll(lm) : 0;
+    const int clu = __builtin_amdgcn_readlane(my_lclu, leaf), pred = __builtin_amdgcn_readlane(my_lpred, leaf);
+    if (lane == e) { my_aoff = (clu << la) * (int)sizeof(DevAlias); my_cp = (int)(S.cfg[clu] & 0xffffffu) | (pred << 24); }
+  }
+  const uint8_t *pool8 = (const uint8_t *)S.pool;
+  const bool any_n_pred = __ballot(lane < nl && my_lpred == 2) != 0;
+  __syncthreads();
+  for (int y = y_begin; y < h; y++) {
+    int32_t *out = c.d + (size_t)y * (size_t)w;
+    int32_t *row = S.rows[y & 1];
+    const int32_t *rN = S.rows[(y + 1) & 1];
+    int32_t W_ = y > 0 ? (needs_n ? rN[0] : out[-(ptrdiff_t)w]) : 0;      // x == 0: the sample above stands in for W (0 in the first row)
+    int32_t keep = 0;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+      const int m = w - x0 < 64 ? w - x0 : 64;
+      // ---- parallel part: the class of sample x0 + lane
+      const int x = x0 + lane;
+      const int32_t Nx = (needs_n && y > 0) ? rN[x < w ? x : w - 1] : 0;
+      int cls = 0;
+      for (uint64_t cm = P.cmask; cm; cm &= cm - 1) {
+        const int j = __builtin_ctzll(cm);
+        const int pj = __builtin_amdgcn_readlane(my_prop, j), sj = __builtin_amdgcn_readlane(my_split, j), bj = __builtin_amdgcn_readlane(my_cbit, j);
+        const int32_t v = pj == 2 ? y : pj == 3 ? x : pj == 4 ? (Nx < 0 ? -Nx : Nx) : Nx;
+        cls |= (v > sj ? 1 : 0) << bj;
+      }
+      const int my_base = cls * stride;
+      // ---- serial part
+      #pragma unroll 1
+      for (int i = 0; i < m; i++) {
+        const int base_i = __builtin_amdgcn_readlane(my_base, i);
+        const int32_t pv = P.wabs ? (W_ < 0 ? -W_ : W_) : W_;
+        const int en = base_i + __builtin_popcountll(__ballot(pv > my_wsplit));
+        const uint32_t aoff = (uint32_t)__builtin_amdgcn_readlane(my_aoff, en), cp = (uint32_t)__builtin_amdgcn_readlane(my_cp, en);
+        const uint32_t res = state & 0xfff, bi = res >> lb, pos = res & ((1u << lb) - 1);
+        const DevAlias e = *(const DevAlias *)(pool8 + aoff + bi * (uint32_t)sizeof(DevAlias));
+        const bool right = pos >= e.cutoff;
+        uint32_t u = right ? e.right : bi;
+        state = (right ? e.freq1 : e.freq0) * (state >> 12) + (right ? (uint32_t)e.off1 + pos : pos);
+        if (__ballot(state < (1u << 16))) state = (state << 16) | ubits_read(b, 16);
+        const uint32_t split_exp = cp & 0xff;
+        if (__ballot(u >= (1u << split_exp))) {
+          const uint32_t msb = (cp >> 8) & 0xff, lsb = (cp >> 16) & 0xff;
+          uint32_t nbits = split_exp - (msb + lsb) + ((u - (1u << split_exp)) >> (msb + lsb));
+          if (nbits > 31) nbits = 31;           // corrupt stream; the final-state check flags it
+          const uint32_t low = u & ((1u << lsb) - 1), tok = u >> lsb;
+          const uint32_t bits = ubits_read(b, (int)nbits);
+          u = (((((1u << msb) | (tok & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+        }
+        const uint32_t pred = cp >> 24;
+        int32_t guess = pred == 1 ? W_ : 0;
+        if (any_n_pred) { const int32_t N_i = y > 0 ? __builtin_amdgcn_readlane(Nx, i) : W_; guess = pred == 2 ? N_i : guess; }
+        const int32_t val = unpack_signed(u) + guess;
+        keep = shift_in_wave1(val, keep);
+        W_ = val;
       }
       if (lane < m) { const int32_t v = keep; out[x0 + m - 1 - lane] = v; if (needs_n) row[x0 + m - 1 - lane] = v; }
     }
@@ -1020,8 +1134,15 @@ __device__ __forceinline__ uint32_t modular_decode_channels_wave(const DevECView
       const bool preds_ok = __ballot(lane < WT.nl && (WT.leaf_pred[lane] < 0 || WT.leaf_pred[lane] > 5)) == 0;
       const bool needs_n = __ballot((lane < WT.ni && (WT.int_prop[lane] == 4 || WT.int_prop[lane] == 6)) || (lane < WT.nl && WT.leaf_pred[lane] >= 2)) != 0;
       if (props_ok && preds_ok && (!needs_n || c.w <= kModMaxW)) {
-        if (lds_now) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n);
-        else wave_decode_channel_lean<false>(evg, b, state, S, WT, c, lane, needs_n);
+        // rows [0, y_split) in the lean loop, the rest in its chain form where the tree allows it (see wave_decode_channel_chain)
+        ChainPlan P; P.nW = P.nC = P.wabs = 0; P.wmask = P.cmask = 0; P.ok = false;
+        if (lds_now && JXL_MOD_CHAIN) P = wave_chain_plan(WT, lane);
+        const int y_split = P.ok ? (needs_n ? 1 : 0) : c.h;
+        if (y_split > 0) {
+          if (lds_now) wave_decode_channel_lean<true>(ev, b, state, S, WT, c, lane, needs_n, y_split);
+          else wave_decode_channel_lean<false>(evg, b, state, S, WT, c, lane, needs_n, y_split);
+        }
+        if (y_split < c.h) wave_decode_channel_chain(ev, b, state, S, WT, c, lane, needs_n, y_split, P);
         continue;
       }
     }
