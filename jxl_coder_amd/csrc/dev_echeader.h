@@ -158,30 +158,47 @@ JXL_DEV uint32_t d_read_histogram(DevBits &b, uint16_t *D, int table, LocalTmp &
 
 JXL_DEV void d_build_alias(const uint16_t *D, int log_alpha, DevAlias *a, LocalTmp &T) {
   const int table = 1 << log_alpha, bucket = 4096 >> log_alpha;
-  for (int s = 0; s < table; s++)
-    if (D[s] == 4096) {
-      for (int i = 0; i < table; i++) { a[i].cutoff = 0; a[i].right = (uint8_t)s; a[i].off1 = (uint16_t)(bucket * i); a[i].freq0 = 4096; a[i].freq1 = 4096; }
-      return;
-    }
-  uint16_t *cut = T.cut, *under = T.under, *over = T.over; uint8_t *right = T.right; uint16_t *off = T.off;
-  int nu = 0, no = 0;
+  // (every entry is put together in registers and leaves as ONE 8-byte store: the tables lie in HBM, and a field stored there and read back — the right symbol's
+  // frequency used to be looked up through a[i].right — costs the serial lane a store-to-load round trip per entry, 0.25 ms per cluster as measured in round 6)
   int n = table;
   while (n > 0 && D[n - 1] == 0) n--;
-  for (int i = 0; i < table; i++) { right[i] = 0; off[i] = 0; }
-  for (int i = 0; i < n; i++) { cut[i] = D[i]; if (cut[i] > bucket) over[no++] = (uint16_t)i; else if (cut[i] < bucket) under[nu++] = (uint16_t)i; }
-  for (int i = n; i < table; i++) { cut[i] = 0; under[nu++] = (uint16_t)i; }
-  while (no > 0 && nu > 0) {
-    int o = over[--no], u = under[--nu];
-    int by = bucket - cut[u];
-    cut[o] = (uint16_t)(cut[o] - by);
-    right[u] = (uint8_t)o; off[u] = cut[o];
-    if (cut[o] < bucket) under[nu++] = (uint16_t)o; else if (cut[o] > bucket) over[no++] = (uint16_t)o;
+  // a symbol of frequency 4096 is the histogram's only one (the frequencies sum to 4096), hence its last
+  if (n > 0 && D[n - 1] == 4096) {
+    const int s = n - 1;
+    for (int i = 0; i < table; i++) { DevAlias e; e.cutoff = 0; e.right = (uint8_t)s; e.off1 = (uint16_t)(bucket * i); e.freq0 = 4096; e.freq1 = 4096; a[i] = e; }
+    return;
   }
+  uint16_t *cut = T.cut, *under = T.under, *over = T.over; uint8_t *right = T.right; uint16_t *off = T.off;
+  // libjxl's InitAliasTable pairs the top of a stack of overfull buckets with the top of a stack of underfull ones until one of them is empty.  The same pairs
+  // in the same order with the stacks' tops in registers (the working arrays are LDS or HBM: every read is a round trip of the serial lane): the overfull bucket
+  // stays `cur` while it remains overfull (the reference pushes it back and pops it again); the underfull stack is, from the top, the bucket that has just dropped
+  // below full (`pend`: at most one, taken next), the empty buckets table - 1 .. n (implicit: nothing to read) and the underfull buckets below n (`under`).
+  int nr = 0, no = 0;
+  for (int i = 0; i < table; i++) { right[i] = 0; off[i] = 0; }
+  for (int i = 0; i < n; i++) { const uint16_t c = D[i]; cut[i] = c; if (c > bucket) over[no++] = (uint16_t)i; else if (c < bucket) under[nr++] = (uint16_t)i; }
+  for (int i = n; i < table; i++) cut[i] = 0;
+  int ne = table - n, cur = -1, co = 0, pend = -1, pcut = 0;
+  for (;;) {
+    if (cur < 0) { if (no == 0) break; cur = over[--no]; co = cut[cur]; }
+    int u, cu;
+    if (pend >= 0) { u = pend; cu = pcut; pend = -1; }
+    else if (ne > 0) { u = n + --ne; cu = 0; }
+    else if (nr > 0) { u = under[--nr]; cu = cut[u]; }
+    else break;
+    co -= bucket - cu;
+    right[u] = (uint8_t)cur; off[u] = (uint16_t)co;
+    if (co < bucket) { cut[cur] = (uint16_t)co; pend = cur; pcut = co; cur = -1; }
+    else if (co == bucket) { cut[cur] = (uint16_t)co; cur = -1; }
+  }
+  if (cur >= 0) cut[cur] = (uint16_t)co;
   for (int i = 0; i < table; i++) {
-    if (cut[i] == bucket) { a[i].right = (uint8_t)i; a[i].off1 = 0; a[i].cutoff = 0; }
-    else { a[i].right = right[i]; a[i].off1 = (uint16_t)(off[i] - cut[i]); a[i].cutoff = (uint8_t)cut[i]; }
-    a[i].freq0 = D[i];
-    a[i].freq1 = D[a[i].right];
+    DevAlias e;
+    const uint16_t ci = cut[i];
+    if (ci == bucket) { e.right = (uint8_t)i; e.off1 = 0; e.cutoff = 0; }
+    else { e.right = right[i]; e.off1 = (uint16_t)(off[i] - ci); e.cutoff = (uint8_t)ci; }
+    e.freq0 = D[i];
+    e.freq1 = D[e.right];
+    a[i] = e;
   }
 }
 
