@@ -92,8 +92,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JXL_FI
 // 120.  Coordinates outside the image are evaluated at their mirror image (virtual rows / columns hold the stage output AT the
 // mirrored position, which is what the per-stage kernels read there); summation order differs from the per-stage kernels in the
 // last bits only.  Frames with three EPF iterations (12-tap first pass) stay on the per-stage kernels.
-__device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }    // lane - 1: x - 1
-__device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }   // lane + 1: x + 1
+__device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }    // lane - 1: x - 1
+__device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }   // lane + 1: x + 1
 __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && !F.compose && F.epf_iters <= 2; }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -111,11 +111,15 @@ template <bool kGab, int kEpf, bool kFast, int kPost>
 __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame &F, const uint8_t *stat, int strip, int seg, int rows_per_wave, int lane) {
   constexpr int DG = kGab ? 1 : 0, DE = kEpf >= 1 ? 2 : 0, DF = kEpf >= 2 ? 1 : 0;     // row delay of each stage behind its input
   constexpr int HX = DG + DE + DF, SW = 64 - 2 * HX;
-  const int w = F.width, h = F.height;
-  const int x0 = strip * SW;
-  const int y0 = F.band_py0 + seg * rows_per_wave;
-  if (x0 >= w || y0 >= F.band_py1) return;
-  const int y1 = y0 + rows_per_wave < F.band_py1 ? y0 + rows_per_wave : F.band_py1;
+  // the frame's dimensions and strides in scalar registers: read through F inside the loop they are re-loaded behind every pixel store (the compiler cannot rule out
+  // that the store hits the DevFrame), and a row index mirrored against a vector-register height is a masked vector loop instead of three scalar instructions
+  const int w = __builtin_amdgcn_readfirstlane(F.width), h = __builtin_amdgcn_readfirstlane(F.height);
+  const int plane_w = __builtin_amdgcn_readfirstlane(F.pw), out_stride = __builtin_amdgcn_readfirstlane(F.out_w);
+  const int band_py1 = __builtin_amdgcn_readfirstlane(F.band_py1);
+  const int x0 = __builtin_amdgcn_readfirstlane(strip * SW);     // (strip and seg come from the wave's index: uniform)
+  const int y0 = __builtin_amdgcn_readfirstlane(F.band_py0 + seg * rows_per_wave);
+  if (x0 >= w || y0 >= band_py1) return;
+  const int y1 = y0 + rows_per_wave < band_py1 ? y0 + rows_per_wave : band_py1;
   if (kPost == 2 && F.orientation == 1) {                        // (output row = frame row: a frame that takes this path is not cropped)
     const int yr = y0 + lane;
     if (__ballot(yr < y1 && B.post->row_fz[1 + yr] != 0xFFFFFFFFu) == 0) return;
@@ -153,7 +157,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
   // the next row's samples are requested one iteration ahead: the ~300 instructions of a row hide the fetch whatever else is resident on the SIMD
   float nx[3];
   {
-    const size_t r0 = (size_t)mirror(y0 - HX, h) * (size_t)F.pw;
+    const size_t r0 = (size_t)mirror(y0 - HX, h) * (size_t)plane_w;
 #pragma unroll
     for (int c = 0; c < 3; c++) nx[c] = src[c][r0];
   }
@@ -165,7 +169,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
 #pragma unroll
     for (int c = 0; c < 3; c++) { in[0][c] = in[1][c]; in[1][c] = in[2][c]; in[2][c] = nx[c]; }
     if (t + 1 < y1 + HX) {
-      const size_t rn = (size_t)mirror(t + 1, h) * (size_t)F.pw;
+      const size_t rn = (size_t)mirror(t + 1, h) * (size_t)plane_w;
 #pragma unroll
       for (int c = 0; c < 3; c++) nx[c] = src[c][rn];
     }
@@ -250,12 +254,11 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
         uint32_t px = 0xFF000000u;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-          float lin = tf_srgb(opsin_lin(oi, c, mix));
-          float cv = lin < 0.0f ? 0.0f : lin > 1.0f ? 1.0f : lin;
-          if (!(lin == lin)) cv = 0.0f;
+          const float lin = tf_srgb(opsin_lin(oi, c, mix));
+          const float cv = fminf(fmaxf(lin, 0.0f), 1.0f);          // the writer's clamp, a NaN becomes 0 (fmaxf returns its other operand): two instructions instead of seven
           px |= (uint32_t)(uint8_t)(int)rintf(fmaf(cv, 255.0f, d)) << (8 * c);
         }
-        orow[(size_t)o * (size_t)F.out_w] = px;
+        orow[(size_t)o * (size_t)out_stride] = px;
       } else if (kPost != 0) {
         float c[3];
         xyb_to_rgb(F, v[0], v[1], v[2], c);
