@@ -1,5 +1,6 @@
 // jxl_coder_amd/csrc/kernels_filter.hip — HIP kernels (gfx950): Gaborish / EPF iterations, the last one fused with the XYB -> RGB -> RGBA8/16 writer.
 // Bodies live in dev_*.h (shared with the CPU test harness); this file only maps blockIdx/threadIdx.
+#include <stdlib.h>
 #include "kernels_common.h"
 #include "dev_post.h"
 
@@ -289,7 +290,8 @@ void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes
   // pass) go through the per-stage kernels, which skip the frames the sweep has produced.
   const int sweep = 1;
   {
-    const int rows = nframes == 1 ? 16 : 64;                   // a single decode has the chip to itself: shorter segments, more waves
+    static const int batch_rows = [] { const char *e = getenv("JXLAMD_SWEEP_ROWS"); const int v = e ? atoi(e) : 0; return v >= 8 && v <= 4096 ? v : 64; }();     // (measurement knob)
+    const int rows = nframes == 1 ? 16 : batch_rows;           // a single decode has the chip to itself: shorter segments, more waves
     const dim3 g((max_w + 55) / 56, (max_h + 4 * rows - 1) / (4 * rows), nframes);
     // bit (gab ? 3 : 0) + epf_iters: which stage combinations the frames of this launch use; bits 6..11: the same for its fast-writer frames (kSweepFastShift)
     int combos = (stage_mask >> 8) & 63, fast = (stage_mask >> (8 + kSweepFastShift)) & 63;

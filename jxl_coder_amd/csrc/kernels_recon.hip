@@ -258,7 +258,7 @@ __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint
 }
 
 template <bool kSparse>
-__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *Bs, const uint8_t *stat, int skip_dct8) {
+__global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int skip_dct8) {
   __shared__ float S[3 * 256];
   __shared__ float T[256];
   const DevBuffers &B = Bs[blockIdx.z];
@@ -411,7 +411,7 @@ __device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uin
 // kernels carry a few per cent of the area of smooth content.  _a: DCT8x8, 16x16, 16x8, 8x16 (8 KB of LDS, <= 90 VGPRs: the bulk of
 // photographic content); _b: the 32-wide / 32-tall rectangles (17 KB).
 template <bool kSparse>
-__global__ void __launch_bounds__(64) k_recon_lists_a(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(64) k_recon_lists_a(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat) {
   __shared__ __attribute__((aligned(16))) float smem[6 * 256 + 2 * 256];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(64) k_recon_lists_a(const DevBuffers *Bs, cons
   }
 }
 template <bool kSparse>
-__global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat) {
   __shared__ __attribute__((aligned(16))) float smem[6 * 512 + 256 + 1024];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(64) k_recon_lists_b(const DevBuffers *Bs, cons
 // use next to resident entropy waves is what decides their speed in a flight mix.
 struct ReconDct32Lds { float S[3 * 1024]; float LL[96]; };
 template <bool kSparse>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_dct32_b(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k_recon_dct32_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat) {
   __shared__ __attribute__((aligned(16))) ReconDct32Lds L;
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
@@ -459,10 +459,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
     if (tid < 16) L.LL[tid] = st_f(stat, ST.cos_off[2])[tid];
     else if (tid < 20) L.LL[tid] = (st_f(stat, ST.llf_off) + 64)[tid - 16];
   }
+  // (the list, the strategy map and the band limits in registers: read through B / F inside the loop they are re-loaded behind every barrier, each a round trip in
+  // front of the block's own dependent loads)
+  const uint32_t *list0 = B.big_list[0];
+  const uint8_t *strategy = B.strategy;
+  const int cy0 = F.band_cy0, cy1 = F.band_cy1;
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[0][i];
+    const int cell = (int)list0[i];
     const int bx = cell % xb, by = cell / xb;
-    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != kStrategyDct32) continue;
+    if (by < cy0 || by >= cy1 || strategy[cell] != kStrategyDct32) continue;
     __syncthreads();                                 // the previous block's second pass has finished reading S
     recon_dct32_front<kSparse>(B, stat, ST, L.S, L.LL, bx, by, tid);
     __syncthreads();
@@ -472,7 +477,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
 // The 512 / 1024-coefficient blocks that are NOT DCT32x32 (DCT16x32, 32x16, 8x32, ... — a few per cent of the blocks), one channel at a
 // time: 8 KB of LDS instead of the general medium kernel's 33 KB, so that this short launch is not kept waiting for LDS by resident LF waves.
 template <bool kSparse>
-__global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs, const uint8_t *stat, int skip_rc) {
+__global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int skip_rc) {
   __shared__ __attribute__((aligned(16))) float S[1024];
   __shared__ __attribute__((aligned(16))) float T[1024];
   const DevBuffers &B = Bs[blockIdx.z];
@@ -492,7 +497,7 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *Bs,
 // The 2048 / 4096-coefficient blocks with half the LDS of k_recon_list_b<1025, 4096>: DCT64x64 on the matrix cores with the second pass in
 // place (16 KB), the 64x32 / 32x64 blocks one channel at a time in S[2048] + T[2048].
 template <bool kSparse>
-__global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *Bs, const uint8_t *stat) {
+__global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat) {
   __shared__ __attribute__((aligned(16))) float S[4096];
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
@@ -557,7 +562,7 @@ __device__ __forceinline__ void recon_huge_block(const DevBuffers &B, const uint
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch) {
+__global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int nframes, float *scratch) {
   float *S = scratch + (size_t)blockIdx.x * 2 * 65536, *T = S + 65536;
   const int tid = (int)threadIdx.x;
   for (int f = 0; f < nframes; f++) {
@@ -574,11 +579,11 @@ __global__ void __launch_bounds__(256) k_recon_huge_b(const DevBuffers *Bs, cons
     }
   }
 }
-void launch_recon_huge(const DevBuffers *Bs, const uint8_t *stat, int nframes, float *scratch, hipStream_t s) {
+void launch_recon_huge(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int nframes, float *scratch, hipStream_t s) {
   hipLaunchKernelGGL(k_recon_huge_b, dim3(kHugeSlots), dim3(256), 0, s, Bs, stat, nframes, scratch);
 }
 template <bool kSparse>
-static void launch_recon_batch_t(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
+static void launch_recon_batch_t(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int nframes, int max_cells, bool expect_large, hipStream_t s) {
   // a single decode has the chip to itself: more, shorter workgroups for the list walkers; in a flight (16 frames per launch) 256 workgroups
   // per frame fill the chip, and the launches of the families a frame does not use cost 4 096 empty workgroups instead of 16 384
   const int gm = nframes == 1 ? 2048 : 256, gl = nframes == 1 ? 512 : 64;
@@ -593,7 +598,7 @@ static void launch_recon_batch_t(const DevBuffers *Bs, const uint8_t *stat, int 
   hipLaunchKernelGGL(k_recon_large_b<kSparse>, dim3(expect_large ? gl : 1, 1, nframes), dim3(256), 0, s, Bs, stat);
 }
 // sparse: the frames' coefficients are per-varblock sparse lists (DevBuffers::coef_sp, written by k_pass_flat<true>) — every frame of the launch
-void launch_recon_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_cells, bool expect_large, bool sparse, hipStream_t s) {
+void launch_recon_batch(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int nframes, int max_cells, bool expect_large, bool sparse, hipStream_t s) {
   if (sparse) launch_recon_batch_t<true>(Bs, stat, nframes, max_cells, expect_large, s);
   else launch_recon_batch_t<false>(Bs, stat, nframes, max_cells, expect_large, s);
 }
