@@ -38,7 +38,7 @@ __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F);
 #define JXL_FILTER_B_WAVES 1
 #endif
 template <int STAGE, int POST = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JXL_FILTER_B_WAVES))) k_filter_b(const DevBuffers *Bs, const uint8_t *stat, int sweep_on) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JXL_FILTER_B_WAVES))) k_filter_b(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int sweep_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if ((F.is_modular && !F.xyb_modular) || !stage_runs(F, STAGE) || frame_failed(B)) return;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
 // one instantiation per stage combination: the register footprint of the longest pipeline (Gaborish + two EPF iterations) must not be
 // charged to the common one (Gaborish + one iteration)
 template <bool kGab, int kEpf, bool kFast, int kPost = 0>
-__global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, const uint8_t *stat, int rows_per_wave, int fast_on) {
+__global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int rows_per_wave, int fast_on) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (!frame_uses_sweep(F) || frame_failed(B)) return;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) k_filter_sweep(const DevBuffers *Bs, cons
   filter_sweep<kGab, kEpf, kFast, kPost>(B, F, stat, strip, seg, rows_per_wave, lane);
 }
 
-void launch_filters_batch(const DevBuffers *Bs, const uint8_t *stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
+void launch_filters_batch(const DevBuffers *__restrict__ Bs, const uint8_t *__restrict__ stat, int nframes, int max_w, int max_h, int stage_mask, hipStream_t s) {
   const bool post = (stage_mask & 64) != 0;                      // some frame of the launch hands its pixels to the post stages (DevBuffers::post)
   // Column sweep (k_filter_sweep) for every frame with at most two EPF iterations; frames with three (stage_mask & 2: the 12-tap first
   // pass) go through the per-stage kernels, which skip the frames the sweep has produced.

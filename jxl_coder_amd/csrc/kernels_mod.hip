@@ -149,13 +149,13 @@ void launch_mod_write(const DevBuffers &B, int w, int h, int out_bits, hipStream
 }
 
 // ---- Modular-encoded frames of a flight: the same bodies, (frame, group) through a map / blockIdx.z = frame
-__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *Bs, int pool_bytes) {
+__global__ void __launch_bounds__(64) k_mod_global_b(const DevBuffers *__restrict__ Bs, int pool_bytes) {
   DevModScratch &S = mod_global_smem(pool_bytes);
   const DevFrame &F = frame_of(Bs[blockIdx.x]);
   if (!F.is_modular && !F.has_ec) return;          // VarDCT frame without extra channels: no Modular image
   mod_global_body(Bs[blockIdx.x], S, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
-__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const int *map, int pool_bytes) {
+__global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *__restrict__ Bs, const int *__restrict__ map, int pool_bytes) {
   DevModScratch &S = mod_group_smem(pool_bytes);
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   const DevBuffers &B = Bs[f];
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64) k_mod_group_b(const DevBuffers *Bs, const 
   if (F.mod_first_group_ch >= F.mod_nch) return;
   mod_group_body(B, S, g, (int)threadIdx.x, 64, SyncBlock(), pool_bytes);
 }
-__global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *Bs) {      // grid (max LF groups, frames)
+__global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *__restrict__ Bs) {      // grid (max LF groups, frames)
   __shared__ DevModScratch S;
   __shared__ DevChanOut chbuf[kModMaxCh];
   S.ch = chbuf;                                       // (every lane stores the same value)
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) k_mod_lfgroup_b(const DevBuffers *Bs) {   
   if (!F.is_modular || F.mod_lf_nch <= 0 || (int)blockIdx.x >= F.num_lf_groups || frame_failed(B)) return;
   mod_lfgroup_kernel(B, S, (int)blockIdx.x);
 }
-__global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) {
+__global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *__restrict__ Bs, int op) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if ((!F.is_modular && !F.has_ec) || op >= F.mod_nops) return;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_mod_op_b(const DevBuffers *Bs, int op) 
   const size_t n = (size_t)(F.mod_op_kind[op] == 0 ? F.mod_op_y[op] : F.mod_op_c[op]);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) mod_op_element(B, F, op, i);
 }
-__global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
+__global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *__restrict__ Bs) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)), y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
@@ -190,22 +190,22 @@ __global__ void __launch_bounds__(256) k_mod_write_b(const DevBuffers *Bs) {
 }
 // extra channels (alpha) of the VarDCT frames of a flight: GlobalModular parts before the LF stage, the per-group streams and the
 // inverse transforms after the PassGroup stage of each sub-flight
-static void launch_mod_global_b(const DevBuffers *Bs, int nframes, int pool_bytes, hipStream_t s) {
+static void launch_mod_global_b(const DevBuffers *__restrict__ Bs, int nframes, int pool_bytes, hipStream_t s) {
   static bool once = false;
   pool_bytes = mod_pool_clamp(pool_bytes);
   hipLaunchKernelGGL(k_mod_global_b, dim3(nframes), dim3(64), mod_global_lds((const void *)k_mod_global_b, &once, pool_bytes), s, Bs, pool_bytes);
 }
-void launch_ec_global_batch(const DevBuffers *Bs, int nframes, int pool_bytes, hipStream_t s) { launch_mod_global_b(Bs, nframes, pool_bytes, s); }
-static void launch_mod_group_b(const DevBuffers *Bs, const int *group_map, int ngroups, int pool_bytes, hipStream_t s) {
+void launch_ec_global_batch(const DevBuffers *__restrict__ Bs, int nframes, int pool_bytes, hipStream_t s) { launch_mod_global_b(Bs, nframes, pool_bytes, s); }
+static void launch_mod_group_b(const DevBuffers *__restrict__ Bs, const int *group_map, int ngroups, int pool_bytes, hipStream_t s) {
   static bool once = false;
   pool_bytes = mod_pool_clamp(pool_bytes);
   hipLaunchKernelGGL(k_mod_group_b, dim3(ngroups), dim3(64), mod_group_lds((const void *)k_mod_group_b, &once, pool_bytes), s, Bs, group_map, pool_bytes);
 }
-void launch_ec_groups_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int pool_bytes, hipStream_t s) {
+void launch_ec_groups_batch(const DevBuffers *__restrict__ Bs, const int *group_map, int nframes, int ngroups, int max_ops, int pool_bytes, hipStream_t s) {
   if (ngroups > 0) launch_mod_group_b(Bs, group_map, ngroups, pool_bytes, s);
   for (int o = 0; o < max_ops; o++) hipLaunchKernelGGL(k_mod_op_b, dim3(1024, 1, nframes), dim3(256), 0, s, Bs, o);
 }
-void launch_modular_batch(const DevBuffers *Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, int pool_bytes, hipStream_t s) {
+void launch_modular_batch(const DevBuffers *__restrict__ Bs, const int *group_map, int nframes, int ngroups, int max_ops, int max_w, int max_h, int pool_bytes, hipStream_t s) {
   launch_mod_global_b(Bs, nframes, pool_bytes, s);
   const int max_lfg = ((max_w + 1023) / 1024) * ((max_h + 1023) / 1024);       // LF groups are 8 x group_dim pixels wide (>= 1024)
   if (max_w > 1024 || max_h > 1024) hipLaunchKernelGGL(k_mod_lfgroup_b, dim3(max_lfg, nframes), dim3(64), 0, s, Bs);   // only images beyond one LF group can carry such streams

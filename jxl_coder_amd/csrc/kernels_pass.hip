@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(64) k_pass_group(DevBuffers B) {
   pass_group_body(B, S, (int)blockIdx.x, (int)threadIdx.x, 64, SyncBlock());
 }
 
-__global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *Bs, const int *map) {
+__global__ void __launch_bounds__(64) k_pass_group_batch(const DevBuffers *__restrict__ Bs, const int *__restrict__ map) {
   __shared__ DevPassScratch S;
   const int f = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x]), g = __builtin_amdgcn_readfirstlane(map[2 * blockIdx.x + 1]);
   if (frame_failed(Bs[f])) return;
@@ -85,13 +85,13 @@ __global__ void __launch_bounds__(64) k_pass_flat(const DevBuffers *__restrict__
   }
   if (e) atomicOr(B.err, e | kErrStagePass);
 }
-void launch_pass_prep(const DevBuffers *Bs, const int *map, int ngroups, hipStream_t s) { hipLaunchKernelGGL(k_pass_prep, dim3(ngroups), dim3(64), 0, s, Bs, map); }
-void launch_pass_flat(const DevBuffers *Bs, const int *wmap, int nwg, bool sparse, hipStream_t s) {
+void launch_pass_prep(const DevBuffers *__restrict__ Bs, const int *__restrict__ map, int ngroups, hipStream_t s) { hipLaunchKernelGGL(k_pass_prep, dim3(ngroups), dim3(64), 0, s, Bs, map); }
+void launch_pass_flat(const DevBuffers *__restrict__ Bs, const int *wmap, int nwg, bool sparse, hipStream_t s) {
   if (sparse) hipLaunchKernelGGL(k_pass_flat<true>, dim3(nwg), dim3(64), 0, s, Bs, wmap);
   else hipLaunchKernelGGL(k_pass_flat<false>, dim3(nwg), dim3(64), 0, s, Bs, wmap);
 }
 
 void launch_pass_groups(const DevBuffers &B, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group, dim3(n), dim3(64), 0, s, B); }
-void launch_pass_groups_batch(const DevBuffers *Bs, const int *map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
+void launch_pass_groups_batch(const DevBuffers *__restrict__ Bs, const int *__restrict__ map, int n, hipStream_t s) { hipLaunchKernelGGL(k_pass_group_batch, dim3(n), dim3(64), 0, s, Bs, map); }
 
 }  // namespace jxlamd

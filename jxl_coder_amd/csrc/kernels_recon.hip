@@ -188,7 +188,7 @@ __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint
   }
 }
 
-__global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *Bs) {
+__global__ void __launch_bounds__(256) k_lf_smooth_b(const DevBuffers *__restrict__ Bs) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular || frame_failed(B)) return;
@@ -274,13 +274,18 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *__restri
     return;
   }
   const uint32_t count = B.big_count[2];
+  // (the list, the strategy map, the row of cells and the band limits in registers: read through B / F inside the loop they are re-loaded behind every barrier)
+  const uint32_t *list2 = B.big_list[2];
+  const uint8_t *strategy = B.strategy;
+  const int xb = F.xb, cy0 = F.band_cy0, cy1 = F.band_cy1;
+  const bool skip_here = skip_dct8 && !F.subsampled;
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[2][i];
-    const int by = cell / F.xb;
-    if (by < F.band_cy0 || by >= F.band_cy1) continue;
-    if (skip_dct8 && !F.subsampled) { const int st = B.strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
+    const int cell = (int)list2[i];
+    const int by = cell / xb;
+    if (by < cy0 || by >= cy1) continue;
+    if (skip_here) { const int st = strategy[cell]; if (st == 0 || st == 4 || (st >= 6 && st <= 9)) continue; }      // k_recon_lists_a / _b have reconstructed it
     __syncthreads();
-    recon_block_body<true, false, kSparse>(B, stat, S, T, cell % F.xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
+    recon_block_body<true, false, kSparse>(B, stat, S, T, cell % xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
 // list walkers of the one-wave-per-block families: workgroup `wg` of `nwg` takes every nwg-th entry of the class's size list and
@@ -297,12 +302,16 @@ __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8
   { const float *cc = st_f(stat, ST.cos_off[3]);
 #pragma unroll
     for (int k = 0; k < 8; k++) { cx8[k] = cc[k * 8 + (lane & 7)]; cy8[k] = cc[k * 8 + (lane >> 3)]; } }
+  // (the list, the strategy map, the row of cells and the band limits in registers: read through B / F inside the loop they are re-loaded behind every barrier)
+  const uint32_t *list2 = B.big_list[2];
+  const uint8_t *strategy = B.strategy;
+  const int xb = F.xb, cy0 = F.band_cy0, cy1 = F.band_cy1;
   for (uint32_t i = wg; i < count; i += nwg) {
-    const int cell = (int)B.big_list[2][i];
-    const int by = cell / F.xb;
-    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != 0) continue;
+    const int cell = (int)list2[i];
+    const int by = cell / xb;
+    if (by < cy0 || by >= cy1 || strategy[cell] != 0) continue;
     __syncthreads();
-    recon_dct8_block<kSparse>(B, stat, ST, S, T, cell % F.xb, by, lane, cx8, cy8);
+    recon_dct8_block<kSparse>(B, stat, ST, S, T, cell % xb, by, lane, cx8, cy8);
   }
 }
 // DCT16x16, DCT16x8, DCT8x16 — with DCT8x8 the bulk of the varblocks of photographic content (the reference's 4K demo photograph: 9 700
@@ -398,12 +407,15 @@ __device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uin
   const DevStatic &ST = *(const DevStatic *)stat;
   for (int i = lane; i < C * C; i += 64) ccC[i] = st_f(stat, ST.cos_off[C == 8 ? 3 : C == 16 ? 4 : 5])[i];
   for (int i = lane; i < R * R; i += 64) crR[i] = st_f(stat, ST.cos_off[R == 8 ? 3 : R == 16 ? 4 : 5])[i];
+  const uint32_t *list = B.big_list[LIST];         // (in registers: see recon_dct8_walk)
+  const uint8_t *strategy = B.strategy;
+  const int xb = F.xb, cy0 = F.band_cy0, cy1 = F.band_cy1;
   for (uint32_t i = wg; i < count; i += nwg) {
-    const int cell = (int)B.big_list[LIST][i];
-    const int by = cell / F.xb;
-    if (by < F.band_cy0 || by >= F.band_cy1 || B.strategy[cell] != STRAT) continue;
+    const int cell = (int)list[i];
+    const int by = cell / xb;
+    if (by < cy0 || by >= cy1 || strategy[cell] != STRAT) continue;
     __syncthreads();
-    recon_dct_rc_block<R, C, kSparse>(B, stat, ST, S, T, ccC, crR, STRAT, cell % F.xb, by, lane);
+    recon_dct_rc_block<R, C, kSparse>(B, stat, ST, S, T, ccC, crR, STRAT, cell % xb, by, lane);
   }
 }
 // The one-wave-per-block families in TWO launches instead of nine (blockIdx.y = family): every launch of a flight's stream is a
@@ -485,11 +497,14 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *__r
   if (F.is_modular || frame_failed(B)) return;
   const int tid = (int)threadIdx.x, xb = F.xb;
   const uint32_t count = B.big_count[0];
+  const uint32_t *list0 = B.big_list[0];           // (in registers: see recon_dct8_walk)
+  const uint8_t *strategy = B.strategy;
+  const int cy0 = F.band_cy0, cy1 = F.band_cy1;
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[0][i];
+    const int cell = (int)list0[i];
     const int bx = cell % xb, by = cell / xb;
-    const int st = B.strategy[cell];
-    if (by < F.band_cy0 || by >= F.band_cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_lists_b
+    const int st = strategy[cell];
+    if (by < cy0 || by >= cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_lists_b
     __syncthreads();
     recon_block_body<false, true, kSparse>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
   }
@@ -505,12 +520,15 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *__restr
   const int tid = (int)threadIdx.x, xb = F.xb;
   const DevStatic &ST = *(const DevStatic *)stat;
   const uint32_t count = B.big_count[1];
+  const uint32_t *list1 = B.big_list[1];           // (in registers: see recon_dct8_walk)
+  const uint8_t *strategy = B.strategy;
+  const int cy0 = F.band_cy0, cy1 = F.band_cy1;
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)B.big_list[1][i];
+    const int cell = (int)list1[i];
     const int bx = cell % xb, by = cell / xb;
-    if (by < F.band_cy0 || by >= F.band_cy1) continue;
+    if (by < cy0 || by >= cy1) continue;
     __syncthreads();
-    if (B.strategy[cell] == kStrategyDct64) recon_dct64_mfma<kSparse>(B, stat, ST, S, S, bx, by, tid);
+    if (strategy[cell] == kStrategyDct64) recon_dct64_mfma<kSparse>(B, stat, ST, S, S, bx, by, tid);
     else recon_block_body<false, true, kSparse>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
   }
 }
@@ -603,7 +621,7 @@ void launch_recon_batch(const DevBuffers *__restrict__ Bs, const uint8_t *__rest
   else launch_recon_batch_t<false>(Bs, stat, nframes, max_cells, expect_large, s);
 }
 // one launch clears what hipMemsetAsync cleared per frame: the placement map and the flags / counters / LF bookkeeping block
-__global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *Bs) {
+__global__ void __launch_bounds__(256) k_clear_b(const DevBuffers *__restrict__ Bs) {
   const DevBuffers &B = Bs[blockIdx.z];
   const DevFrame &F = frame_of(B);
   if (F.is_modular) return;
@@ -639,20 +657,20 @@ void launch_gather_streams(const GatherDesc *descs, int n, uint32_t max_bytes, h
   const uint32_t words = (max_bytes + 64 + 3) / 4;
   hipLaunchKernelGGL(k_gather_streams, dim3(std::min<uint32_t>((words + 1023) / 1024, 256u), n), dim3(256), 0, s, descs);
 }
-__global__ void __launch_bounds__(256) k_gather_flags(const DevBuffers *Bs, int n, uint32_t *out) {
+__global__ void __launch_bounds__(256) k_gather_flags(const DevBuffers *__restrict__ Bs, int n, uint32_t *out) {
   const int i = (int)(blockIdx.x * 256 + threadIdx.x);
   if (i < n * kFlagWords) out[i] = Bs[i / kFlagWords].err[i % kFlagWords];
 }
-void launch_gather_flags(const DevBuffers *Bs, int n, uint32_t *out, hipStream_t s) {
+void launch_gather_flags(const DevBuffers *__restrict__ Bs, int n, uint32_t *out, hipStream_t s) {
   hipLaunchKernelGGL(k_gather_flags, dim3((n * kFlagWords + 255) / 256), dim3(256), 0, s, Bs, n, out);
 }
-void launch_clear_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+void launch_clear_batch(const DevBuffers *__restrict__ Bs, int nframes, int max_cells, hipStream_t s) {
   hipLaunchKernelGGL(k_clear_b, dim3((max_cells + 4095) / 4096 + 1, 1, nframes), dim3(256), 0, s, Bs);
 }
 void launch_lf_smooth(const DevBuffers &B, int xb, int yb, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth, dim3((xb * yb + 255) / 256), dim3(256), 0, s, B);
 }
-void launch_lf_smooth_batch(const DevBuffers *Bs, int nframes, int max_cells, hipStream_t s) {
+void launch_lf_smooth_batch(const DevBuffers *__restrict__ Bs, int nframes, int max_cells, hipStream_t s) {
   hipLaunchKernelGGL(k_lf_smooth_b, dim3((max_cells + 255) / 256, 1, nframes), dim3(256), 0, s, Bs);
 }
 
