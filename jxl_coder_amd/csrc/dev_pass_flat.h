@@ -70,16 +70,23 @@ static inline uint32_t sparse_group_entries(uint32_t section_bytes) {      // (h
   return e > 3u * 65536u ? 3u * 65536u : (uint32_t)e;
 }
 
-constexpr int kFlatBctxLds = 2560;                          // block-context map kept in LDS up to this size (39 x qf buckets x LF buckets; 39 without thresholds)
+// LDS of a PassGroup wave is what the data-parallel kernels of the other contexts do not get (round 6: 7.9 KB more per wave cost 8 % of the headline): the tables are sized
+// for what libjxl writes — a block-context map of 39 x qf buckets x LF buckets bytes (78 on the bench's frames), 58 - 119 clusters — and anything larger is read from the
+// frame tables in HBM / L2
+constexpr int kFlatBctxLds = 256;                           // block-context map kept in LDS up to this size
+constexpr int kFlatCfgLds = 128;                            // hybrid-uint configurations of the first clusters in LDS
 struct FlatPassLds {                                       // per wavefront
   uint32_t ring[kSimtRing * 64];                           // lane-interleaved bit rings (sbits_*)
-  uint32_t cfg[256];                                       // hybrid-uint configs per cluster
+  uint32_t cfg[kFlatCfgLds];                               // hybrid-uint configs per cluster (clusters beyond: from the frame tables)
   uint32_t order8[2][3][64];                               // the two 64-coefficient orders
   const uint32_t *order_ptrs[13 * 3];                      // coefficient order of (bucket, channel) for this pass
   uint16_t freq_ctx[64], nnz_ctx[64];
   uint8_t nzcol[3 * 32 * 64];                              // [channel][column][lane]: nonzero-count context value of the last varblock that covered the column
   uint8_t bctx[kFlatBctxLds];
   const uint8_t *bctx_ptr;                                 // bctx above, or the frame tables
+  // (round 6, measured and not kept: the context map of the pass's code — 495 entries per block context, 7.4 KB — in LDS as well, so that a symbol's cluster is not a
+  // load from the frame tables in front of the alias entry's.  The PassGroup stage went from 146.6 to 142 ms per flight, but a wave of 23.8 instead of 15.9 KB took the
+  // LDS the data-parallel kernels run in: reconstruction + filters 148 -> 170 ms, headline 17 078 / 16 852 -> 15 680 / 15 479 MP/s)
 };
 // frames the flat kernel takes (host twin: frame_flat_ok in decoder.hip): ANS codes with <= 256 clusters
 JXL_DEV bool flat_frame_ok(const DevFrame &F) {
@@ -90,7 +97,7 @@ JXL_DEV void flat_stage(const DevBuffers &B, FlatPassLds &L, int pass, int tid, 
   const DevFrame &F = frame_of(B);
   const DevEC &e = F.hf_ec[pass];
   const uint32_t *cfg = (const uint32_t *)(B.tables + e.cfg_off);
-  for (int i = tid; i < e.num_clusters && i < 256; i += nthreads) L.cfg[i] = cfg[i];
+  for (int i = tid; i < e.num_clusters && i < kFlatCfgLds; i += nthreads) L.cfg[i] = cfg[i];
   for (int i = tid; i < 64; i += nthreads) { L.freq_ctx[i] = kCoeffFreqContext[i]; L.nnz_ctx[i] = kCoeffNumNonzeroContext[i]; }
   for (int i = tid; i < 2 * 3 * 64; i += nthreads) {
     const int o = i / 192, c = (i / 64) % 3, k = i & 63;
@@ -100,18 +107,22 @@ JXL_DEV void flat_stage(const DevBuffers &B, FlatPassLds &L, int pass, int tid, 
   const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1);
   const int nb = 39 * (F.nb_qf_thr + 1) * nlf;
   const uint8_t *src = B.tables + F.bctx_map_off;
+#ifdef JXL_EMUL_TRACE
+  if (tid == 0 && getenv("JXLEMUL_STATS")) fprintf(stderr, "flat_stage pass %d: %d clusters, log_alpha %d, block-context map %d bytes, %d block contexts, %d presets\n", pass, e.num_clusters, e.log_alpha, nb, F.num_bctx, F.num_presets);
+#endif
   if (nb <= kFlatBctxLds) for (int i = tid; i < nb; i += nthreads) L.bctx[i] = src[i];
   if (tid == 0) L.bctx_ptr = nb <= kFlatBctxLds ? L.bctx : src;
   for (int i = tid; i < 3 * 32 * 64; i += nthreads) L.nzcol[i] = 0;
+
 }
-JXL_DEV uint32_t flat_ec_read(const uint32_t *cfg_lds, const uint8_t *ctx_map, const DevAlias *alias, int log_alpha, SimtBits &b, uint32_t *ring, int lane,
+JXL_DEV uint32_t flat_ec_read(const uint32_t *cfg_lds, const uint32_t *cfg_all, const uint8_t *ctx_map, const DevAlias *alias, int log_alpha, SimtBits &b, uint32_t *ring, int lane,
                               uint32_t &state, uint32_t ctx) {
   const uint32_t cluster = ctx_map[ctx];
   const int lb = 12 - log_alpha;
   const uint32_t res = state & 0xfff;
   const uint32_t i = res >> lb, pos = res & ((1u << lb) - 1);
   const DevAlias e = alias[(cluster << log_alpha) + i];
-  const uint32_t cfg = cfg_lds[cluster & 255];
+  const uint32_t cfg = cluster < (uint32_t)kFlatCfgLds ? cfg_lds[cluster] : cfg_all[cluster];
   const bool right = pos >= e.cutoff;
   const uint32_t sym = right ? e.right : i;
   const uint32_t off = right ? (uint32_t)e.off1 + pos : pos;
@@ -158,12 +169,14 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
   const int nslice = 495 * F.num_bctx;
   const uint8_t *ctx_map = B.tables + F.hf_ec[pass].ctx_map_off + (size_t)(done ? 0 : sel) * (size_t)nslice;
   const DevAlias *alias = (const DevAlias *)(B.tables + F.hf_ec[pass].alias_off);
+  const uint32_t *cfg_all = (const uint32_t *)(B.tables + F.hf_ec[pass].cfg_off);
   const int la = F.hf_ec[pass].log_alpha;
   uint32_t state = sbits_read(b, ring, lane, 32);
   const int shift = F.pass_shift[pass];
   const bool accumulate = F.num_passes > 1;
   const int nlf = (F.nb_lf_thr[0] + 1) * (F.nb_lf_thr[1] + 1) * (F.nb_lf_thr[2] + 1), nqf = F.nb_qf_thr + 1;
   const uint8_t *bctx_map = L.bctx_ptr;
+  const int num_bctx = F.num_bctx, frame_xb = F.xb;        // (read through F inside the loop they are re-loaded behind every coefficient store)
   const uint8_t *blkbase = B.pass_nz + (size_t)(done ? 0 : g) * kPassBlkStride;
   uint32_t nblk = done ? 0u : *(const uint32_t *)blkbase;
   const PassBlk *desc = (const PassBlk *)(blkbase + 8);
@@ -234,7 +247,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
             log2c = lcx + lcy; covered = 1 << log2c; size = covered * 64;
             ord = (int)((d.a >> 16) & 15u); qf_idx = (int)((d.a >> 20) & 15u); lfi = (int)(d.a >> 24);
             off = d.off;
-            if (kSparse) { blk_start = ne; blk_cell = cell0 + (size_t)y * (size_t)F.xb + (size_t)x; }
+            if (kSparse) { blk_start = ne; blk_cell = cell0 + (size_t)y * (size_t)frame_xb + (size_t)x; }
             ci = 0;
           }
         }
@@ -251,13 +264,13 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
           idx = idx * nlf + lfi;
           bctx = bctx_map[idx];
           const int nzp = predicted >= 64 ? 64 : predicted;
-          ctx = (uint32_t)((nzp < 8 ? nzp : 4 + nzp / 2) * F.num_bctx + bctx);
+          ctx = (uint32_t)((nzp < 8 ? nzp : 4 + nzp / 2) * num_bctx + bctx);
         }
       }
     }
     if (SIMT_ANY(!done && b.wr - b.rd < 6u)) sbits_topup(b, ring, lane);
     if (!done) {
-      const uint32_t u = flat_ec_read(L.cfg, ctx_map, alias, la, b, ring, lane, state, ctx);
+      const uint32_t u = flat_ec_read(L.cfg, cfg_all, ctx_map, alias, la, b, ring, lane, state, ctx);
       if (run) {
         if (u) {
           const int32_t v = unpack_signed(u) * (1 << shift);
@@ -280,7 +293,7 @@ JXL_DEV uint32_t pass_group_flat(const DevBuffers &B, FlatPassLds &L, int pass, 
         else {
           const uint8_t nzv = (uint8_t)((nz + covered - 1) >> log2c);
           for (int ix = 0; ix < cx; ix++) FLAT_NZ(c, x + ix) = nzv;
-          histo = F.num_bctx * 37 + 458 * bctx;
+          histo = num_bctx * 37 + 458 * bctx;
           order = L.order_ptrs[ord * 3 + c];
           if (!kSparse) blk = B.coef[c] + (size_t)g * 65536 + off;
           prev = nz > size / 16 ? 0 : 1;
