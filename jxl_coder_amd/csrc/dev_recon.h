@@ -110,10 +110,11 @@ JXL_DEV float sp_dequant(const DevFrame &F, uint32_t e, float mul_dm_c, const fl
 // Same values as recon_phaseA (a zero coefficient dequantises to +0 and contributes nothing).  Contains barriers: every work-item calls it.
 template <class Sync>
 JXL_DEV void recon_phaseA_sparse(const DevBuffers &B, const uint8_t *stat, const DevStatic &ST, float *S, int n, int bx, int by,
-                                 int tid, int nthreads, Sync sync, int only_c = -1) {
+                                 int tid, int nthreads, Sync sync, int only_c = -1, int st_known = -1) {
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
-  const int st = B.strategy[o];
+  // st_known: the walkers of one strategy pass it — the strategy map → quant-table index → weight-table offsets are three dependent loads in front of every block otherwise
+  const int st = st_known >= 0 ? st_known : B.strategy[o];
   const int qt = kQuantTableOf[st];
   const uint32_t *ent = B.coef_sp + B.coef_off[o];
   uint32_t cnt = B.coef_cnt[o];
@@ -126,20 +127,37 @@ JXL_DEV void recon_phaseA_sparse(const DevBuffers &B, const uint8_t *stat, const
   const int total = only_c >= 0 ? n : 3 * n;
   for (int k = tid; k < total; k += nthreads) S[k] = 0.0f;
   sync();
+  // The Y entries wait for the X and B ones to be in place (second loop), but their values do not: a work-item's first two Y entries are dequantised in the first
+  // loop, next to the others, and kept in registers — the second loop then has nothing to fetch for them (it used to read every entry and its weight again: two more
+  // dependent round trips per varblock in front of the transform).  Entries beyond a work-item's first two Y ones take the old way.
+  int yk0 = -1, yk1 = -1, ny = 0; float yv0 = 0.0f, yv1 = 0.0f;
   for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)nthreads) {
     const uint32_t e = ent[i];
     const int c = sp_chan(e);
-    if (c == 1 || c > 2 || (only_c >= 0 && c != only_c) || sp_pos(e) >= (uint32_t)n) continue;
+    if (c > 2 || sp_pos(e) >= (uint32_t)n) continue;
+    if (c == 1) {
+      if (ny < 2) { const float v1 = sp_dequant(F, e, mul * F.dm[1], qw[1]); if (ny == 0) { yk0 = (int)sp_pos(e); yv0 = v1; } else { yk1 = (int)sp_pos(e); yv1 = v1; } }
+      ny++;
+      continue;
+    }
+    if (only_c >= 0 && c != only_c) continue;
     S[(only_c >= 0 ? 0 : c * n) + (int)sp_pos(e)] = sp_dequant(F, e, mul * F.dm[c], qw[c]);
   }
   sync();
-  for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)nthreads) {
-    const uint32_t e = ent[i];
-    if (sp_chan(e) != 1 || sp_pos(e) >= (uint32_t)n) continue;
-    const int k = (int)sp_pos(e);
-    const float v1 = sp_dequant(F, e, mul * F.dm[1], qw[1]);
+  const auto put_y = [&](int k, float v1) {
     if (only_c < 0) { S[k] = cfl_add(S[k], kx, v1); S[n + k] = v1; S[2 * n + k] = cfl_add(S[2 * n + k], kb, v1); }
     else S[k] = only_c == 0 ? cfl_add(S[k], kx, v1) : only_c == 1 ? v1 : cfl_add(S[k], kb, v1);
+  };
+  if (yk0 >= 0) put_y(yk0, yv0);
+  if (yk1 >= 0) put_y(yk1, yv1);
+  if (ny > 2) {
+    int seen = 0;
+    for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)nthreads) {
+      const uint32_t e = ent[i];
+      if (sp_chan(e) != 1 || sp_pos(e) >= (uint32_t)n) continue;
+      if (seen++ < 2) continue;                        // placed above
+      put_y((int)sp_pos(e), sp_dequant(F, e, mul * F.dm[1], qw[1]));
+    }
   }
 }
 

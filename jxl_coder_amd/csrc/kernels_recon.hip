@@ -78,7 +78,7 @@ __device__ __forceinline__ void recon_dct32_front(const DevBuffers &B, const uin
   float lf1 = 0.0f;
   if (kSparse) {
     if (llf) lf1 = B.lf_s[li >> 4][o + (size_t)((li >> 2) & 3) * (size_t)F.xb + (size_t)(li & 3)];      // issued before the barriers of the scatter
-    recon_phaseA_sparse(B, stat, ST, S, 1024, bx, by, tid, 256, SyncBlock());
+    recon_phaseA_sparse(B, stat, ST, S, 1024, bx, by, tid, 256, SyncBlock(), -1, kStrategyDct32);
     __syncthreads();                                   // the corner's positions may have received entries: the LLF values below replace them
   } else {
   const int g = (by / 32) * F.xgroups + (bx / 32);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void recon_dct64_mfma(const DevBuffers &B, const uint
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, kh = lane >> 5;
   const int t0 = (wave >> 1) * 32, t1 = (wave & 1) * 32;
   for (int c = 0; c < 3; c++) {
-    if (kSparse) recon_phaseA_sparse(B, stat, ST, S, 4096, bx, by, tid, 256, SyncBlock(), c);
+    if (kSparse) recon_phaseA_sparse(B, stat, ST, S, 4096, bx, by, tid, 256, SyncBlock(), c, kStrategyDct64);
     else recon_phaseA(B, stat, ST, S, 4096, bx, by, tid, 256, c);
     __syncthreads();
     recon_phaseB(B, stat, ST, S, 4096, bx, by, tid, 256, c);
@@ -209,7 +209,7 @@ __device__ __forceinline__ void recon_dct8_block(const DevBuffers &B, const uint
   if (kSparse) {
     float l3[3] = {0.0f, 0.0f, 0.0f};
     if (lane < 3) l3[0] = B.lf_s[lane][o];             // the LLF "corner" of a 1x1 block is the LF sample itself (all scales are 1)
-    recon_phaseA_sparse(B, stat, ST, S, 64, bx, by, lane, 64, SyncBlock());
+    recon_phaseA_sparse(B, stat, ST, S, 64, bx, by, lane, 64, SyncBlock(), -1, 0);
     __syncthreads();
     if (lane < 3) S[lane * 64] = l3[0];
   } else {
@@ -325,7 +325,7 @@ __device__ __forceinline__ void recon_dct_rc_block(const DevBuffers &B, const ui
   constexpr int N = R * C, NJ = N / 64;
   const DevFrame &F = frame_of(B);
   const size_t o = (size_t)by * (size_t)F.xb + (size_t)bx;
-  if (kSparse) recon_phaseA_sparse(B, stat, ST, S, N, bx, by, lane, 64, SyncBlock());
+  if (kSparse) recon_phaseA_sparse(B, stat, ST, S, N, bx, by, lane, 64, SyncBlock(), -1, st);
   else {
   const int qt = kQuantTableOf[st];
   const int g = (by / 32) * F.xgroups + (bx / 32);
