@@ -288,6 +288,27 @@ __global__ void __launch_bounds__(64) k_recon_small_b(const DevBuffers *__restri
     recon_block_body<true, false, kSparse>(B, stat, S, T, cell % xb, by, 0, 256, (int)threadIdx.x, 64, SyncBlock());
   }
 }
+// A walker's position in its size-class list, two entries ahead: the cell of the block after next is requested while this block is worked on, and the strategy byte of the
+// next block (whose cell arrived a block ago) with it — the list entry and the strategy byte used to be two dependent loads in front of every block.
+struct CellWalk {
+  const uint32_t *list; const uint8_t *strategy;
+  uint32_t count, stride, i;
+  int c0, c1, st0;
+  __device__ __forceinline__ CellWalk(const uint32_t *l, const uint8_t *s, uint32_t n, uint32_t first, uint32_t step) : list(l), strategy(s), count(n), stride(step), i(first) {
+    c0 = i < count ? (int)list[i] : -1;
+    c1 = i + stride < count ? (int)list[i + stride] : -1;
+    st0 = c0 >= 0 ? (int)strategy[c0] : -1;
+  }
+  __device__ __forceinline__ bool next(int &cell, int &st) {       // false: the list is done
+    if (c0 < 0) return false;
+    cell = c0; st = st0;
+    i += stride;
+    c0 = c1;
+    c1 = i + stride < count ? (int)list[i + stride] : -1;
+    st0 = c0 >= 0 ? (int)strategy[c0] : -1;
+    return true;
+  }
+};
 // list walkers of the one-wave-per-block families: workgroup `wg` of `nwg` takes every nwg-th entry of the class's size list and
 // reconstructs the blocks of its own strategy.  smem: the workgroup's LDS (k_recon_lists_*: one launch for several families)
 template <bool kSparse>
@@ -306,10 +327,10 @@ __device__ __forceinline__ void recon_dct8_walk(const DevBuffers &B, const uint8
   const uint32_t *list2 = B.big_list[2];
   const uint8_t *strategy = B.strategy;
   const int xb = F.xb, cy0 = F.band_cy0, cy1 = F.band_cy1;
-  for (uint32_t i = wg; i < count; i += nwg) {
-    const int cell = (int)list2[i];
+  CellWalk walk(list2, strategy, count, wg, nwg);
+  for (int cell, st; walk.next(cell, st);) {
     const int by = cell / xb;
-    if (by < cy0 || by >= cy1 || strategy[cell] != 0) continue;
+    if (by < cy0 || by >= cy1 || st != 0) continue;
     __syncthreads();
     recon_dct8_block<kSparse>(B, stat, ST, S, T, cell % xb, by, lane, cx8, cy8);
   }
@@ -410,10 +431,10 @@ __device__ __forceinline__ void recon_dct_rc_walk(const DevBuffers &B, const uin
   const uint32_t *list = B.big_list[LIST];         // (in registers: see recon_dct8_walk)
   const uint8_t *strategy = B.strategy;
   const int xb = F.xb, cy0 = F.band_cy0, cy1 = F.band_cy1;
-  for (uint32_t i = wg; i < count; i += nwg) {
-    const int cell = (int)list[i];
+  CellWalk walk(list, strategy, count, wg, nwg);
+  for (int cell, st; walk.next(cell, st);) {
     const int by = cell / xb;
-    if (by < cy0 || by >= cy1 || strategy[cell] != STRAT) continue;
+    if (by < cy0 || by >= cy1 || st != STRAT) continue;
     __syncthreads();
     recon_dct_rc_block<R, C, kSparse>(B, stat, ST, S, T, ccC, crR, STRAT, cell % xb, by, lane);
   }
@@ -476,10 +497,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) k
   const uint32_t *list0 = B.big_list[0];
   const uint8_t *strategy = B.strategy;
   const int cy0 = F.band_cy0, cy1 = F.band_cy1;
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)list0[i];
+  CellWalk walk(list0, strategy, count, blockIdx.x, gridDim.x);
+  for (int cell, st; walk.next(cell, st);) {
     const int bx = cell % xb, by = cell / xb;
-    if (by < cy0 || by >= cy1 || strategy[cell] != kStrategyDct32) continue;
+    if (by < cy0 || by >= cy1 || st != kStrategyDct32) continue;
     __syncthreads();                                 // the previous block's second pass has finished reading S
     recon_dct32_front<kSparse>(B, stat, ST, L.S, L.LL, bx, by, tid);
     __syncthreads();
@@ -500,10 +521,9 @@ __global__ void __launch_bounds__(256) k_recon_medium_pc_b(const DevBuffers *__r
   const uint32_t *list0 = B.big_list[0];           // (in registers: see recon_dct8_walk)
   const uint8_t *strategy = B.strategy;
   const int cy0 = F.band_cy0, cy1 = F.band_cy1;
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)list0[i];
+  CellWalk walk(list0, strategy, count, blockIdx.x, gridDim.x);
+  for (int cell, st; walk.next(cell, st);) {
     const int bx = cell % xb, by = cell / xb;
-    const int st = strategy[cell];
     if (by < cy0 || by >= cy1 || st == kStrategyDct32 || (skip_rc && (st == 10 || st == 11))) continue;     // k_recon_dct32_b / k_recon_lists_b
     __syncthreads();
     recon_block_body<false, true, kSparse>(B, stat, S, T, bx, by, 257, 1024, tid, 256, SyncBlock());
@@ -523,12 +543,12 @@ __global__ void __launch_bounds__(256) k_recon_large_b(const DevBuffers *__restr
   const uint32_t *list1 = B.big_list[1];           // (in registers: see recon_dct8_walk)
   const uint8_t *strategy = B.strategy;
   const int cy0 = F.band_cy0, cy1 = F.band_cy1;
-  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-    const int cell = (int)list1[i];
+  CellWalk walk(list1, strategy, count, blockIdx.x, gridDim.x);
+  for (int cell, st; walk.next(cell, st);) {
     const int bx = cell % xb, by = cell / xb;
     if (by < cy0 || by >= cy1) continue;
     __syncthreads();
-    if (strategy[cell] == kStrategyDct64) recon_dct64_mfma<kSparse>(B, stat, ST, S, S, bx, by, tid);
+    if (st == kStrategyDct64) recon_dct64_mfma<kSparse>(B, stat, ST, S, S, bx, by, tid);
     else recon_block_body<false, true, kSparse>(B, stat, S, S + 2048, bx, by, 1025, 2048, tid, 256, SyncBlock());
   }
 }
