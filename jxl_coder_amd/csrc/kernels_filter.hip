@@ -95,6 +95,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JXL_FI
 // last bits only.  Frames with three EPF iterations (12-tap first pass) stay on the per-stage kernels.
 __device__ __forceinline__ float dpp_left(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }    // lane - 1: x - 1
 __device__ __forceinline__ float dpp_right(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }   // lane + 1: x + 1
+// epf_inv_sigma (dev_recon.h) for the sweep: the frame's constants in scalar registers and the eight sharpness factors selected, not loaded — the cell's quant-field and
+// sharpness bytes are the only loads (one round trip every eight rows instead of three dependent ones: frame kind, the two bytes, the factor).  Same operations, same order.
+__device__ __forceinline__ float sweep_inv_sigma(const uint8_t *qfm1, const uint8_t *sharp, size_t o, float epf_quant_mul, float quant_scale,
+                                                 float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7) {      // (eight values, not an array: an array argument is promoted to LDS)
+  const int q = qfm1[o], sh = sharp[o];
+  const float sigma_quant = epf_quant_mul / (quant_scale * (float)(q + 1) * -1.1715728752538099024f);
+  float es = e0;
+  es = sh == 1 ? e1 : es; es = sh == 2 ? e2 : es; es = sh == 3 ? e3 : es; es = sh == 4 ? e4 : es; es = sh == 5 ? e5 : es; es = sh == 6 ? e6 : es; es = sh == 7 ? e7 : es;
+  float sigma = sigma_quant * es;
+  if (sigma > -1e-4f) sigma = -1e-4f;
+  return 1.0f / sigma;
+}
 __device__ __forceinline__ bool frame_uses_sweep(const DevFrame &F) { return !F.is_modular && !F.compose && F.epf_iters <= 2; }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
@@ -139,6 +151,11 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
     const float norm = 1.0f / (1.0f + 4 * w1 + 4 * w2);
     gn[c] = sgpr_f(norm); g1[c] = sgpr_f(w1 * norm); g2[c] = sgpr_f(w2 * norm); cs[c] = sgpr_f(F.epf_chscale[c]);      // wave-uniform: scalar registers
   }
+  const float es0 = sgpr_f(F.epf_sharp[0]), es1 = sgpr_f(F.epf_sharp[1]), es2 = sgpr_f(F.epf_sharp[2]), es3 = sgpr_f(F.epf_sharp[3]);
+  const float es4 = sgpr_f(F.epf_sharp[4]), es5 = sgpr_f(F.epf_sharp[5]), es6 = sgpr_f(F.epf_sharp[6]), es7 = sgpr_f(F.epf_sharp[7]);
+  const float eqm = sgpr_f(F.epf_quant_mul), qsc = sgpr_f(F.quant_scale);
+  const uint8_t *cell_qf = B.qfm1 + (ex >> 3), *cell_sharp = B.sharp + (ex >> 3);      // this lane's column of cells
+  const int cells_w = __builtin_amdgcn_readfirstlane(F.xb);
   const float sm1 = 1.65f, sm1b = sgpr_f(sm1 * F.epf_border_sad), sm2 = sgpr_f(1.65f * F.epf_pass2), sm2b = sgpr_f(sm2 * F.epf_border_sad);
   float in[3][3] = {}, G[4][3] = {}, Ev[3] = {}, Eh[3] = {}, E1[3][3] = {};
   float sad_up_e = 0.0f, is1 = 0.0f, is2 = 0.0f;
@@ -196,7 +213,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
       Eh[0] = Eh[1]; Eh[1] = Eh[2]; Eh[2] = ehn;
       // EPF iteration 1 at row e = g - 2: window rows G[0] = e - 1, G[1] = e, G[2] = e + 1
       const int e = t - DG - 2, ey = mirror(e, h);
-      if ((ey >> 3) != cell1) { cell1 = ey >> 3; is1 = epf_inv_sigma(B, F, ex, ey); }
+      if ((ey >> 3) != cell1) { cell1 = ey >> 3; is1 = sweep_inv_sigma(cell_qf, cell_sharp, (size_t)cell1 * (size_t)cells_w, eqm, qsc, es0, es1, es2, es3, es4, es5, es6, es7); }
       const float sad_dn = Ev[0] + Ev[1] + Ev[2] + dpp_left(Ev[1]) + dpp_right(Ev[1]);     // SAD_up(e + 1)
       const float sad_lf = Eh[0] + Eh[1] + Eh[2] + dpp_left(Eh[1]) + dpp_right(Eh[1]);
       const float sad_rt = dpp_right(sad_lf);
@@ -220,7 +237,7 @@ __device__ __forceinline__ void filter_sweep(const DevBuffers &B, const DevFrame
 #pragma unroll
       for (int c = 0; c < 3; c++) { E1[0][c] = E1[1][c]; E1[1][c] = E1[2][c]; E1[2][c] = v[c]; }
       const int f = t - DG - 3, fy = mirror(f, h);
-      if ((fy >> 3) != cell2) { cell2 = fy >> 3; is2 = epf_inv_sigma(B, F, ex, fy); }
+      if ((fy >> 3) != cell2) { cell2 = fy >> 3; is2 = sweep_inv_sigma(cell_qf, cell_sharp, (size_t)cell2 * (size_t)cells_w, eqm, qsc, es0, es1, es2, es3, es4, es5, es6, es7); }
       const bool border = (fy & 7) == 0 || (fy & 7) == 7 || lane_border;
       const float isig = is2 * (border ? sm2b : sm2);
       float tl[3], tr[3];
